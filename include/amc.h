@@ -1,0 +1,179 @@
+/*
+ * amc.h -- C ABI of libamc.so: the MI355X (gfx950) many-chain Metropolis engine.
+ *
+ * This is the drop-in boundary for ONE path of Arianna.jl
+ * (TheDisorderedOrganization/MonteCarlo @ 2025-03-02): the sweep
+ *     make_step!(::Simulation, ::Metropolis)        src/metropolis.jl:302-309
+ *       -> mc_sweep!                                src/metropolis.jl:203-212
+ *         -> mc_step!                               src/metropolis.jl:176-190
+ * over M independent particle_1d chains (example/particle_1d/particle_1d.jl:9-70),
+ * the callback reductions that read its state (callback_energy particle_1d.jl:68-70,
+ * callback_acceptance metropolis.jl:319-321) and the policy-gradient estimator that
+ * sits on it (src/PolicyGuided/estimator.jl:111-134, gradients.jl:93-121).
+ *
+ * The reference is pure Julia and has no FFI of its own; these entry points are
+ * what an `AriannaAlgorithm` subtype (src/algorithms.jl:6-37) binds with `ccall`
+ * -- see INTEGRATION.md for the Julia stub -- and what montecarlo_amd/ (the
+ * Python mirror of that plugin interface) binds with ctypes.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every host buffer for the duration of
+ *    the call; the library owns all device memory.
+ *  - every function returns 0 on success or a negative amc_status; the message
+ *    is available from amc_last_error() (thread-local).  Nothing throws.
+ *  - one handle <-> one device <-> one HIP stream.  Calls on one handle must be
+ *    serialised by the caller.  amc_sweep / amc_init_uniform are asynchronous on
+ *    the handle's stream; every call that returns data to the host synchronises.
+ *  - there is NO CPU fallback: without a usable gfx950 device amc_create fails.
+ */
+#ifndef AMC_H
+#define AMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMC_VERSION_MAJOR 0
+#define AMC_VERSION_MINOR 1
+#define AMC_MAX_MOVES 64        /* K: moves in a pool (Move, metropolis.jl:140-147) */
+#define AMC_MAX_LEARN 8         /* learnable moves per estimator call */
+#define AMC_MAX_QBATCH 256      /* q_batch_size * n_learn must stay < 4096 (12-bit draw id) */
+
+typedef enum amc_status {
+    AMC_OK = 0,
+    AMC_ERR_BAD_ARG = -1,
+    AMC_ERR_HIP = -2,
+    AMC_ERR_OOM = -3,
+    AMC_ERR_NO_DEVICE = -4,
+    AMC_ERR_STATE = -5,
+    AMC_ERR_COMM = -6
+} amc_status;
+
+/* potential(x): free function the driver script defines
+ * (harmonic_oscillator/MC_harmonic_oscillator.jl:4).  A user Julia closure cannot
+ * cross a C ABI, so the engine offers the particle_1d family by id. */
+typedef enum amc_potential {
+    AMC_POTENTIAL_HARMONIC = 0,     /* x*x            (reference) */
+    AMC_POTENTIAL_DOUBLE_WELL = 1   /* (x*x - 1)^2    (BASELINE config 3) */
+} amc_potential;
+
+typedef struct amc_handle amc_handle;
+
+/* Mirrors Metropolis(chains; pool, sweepstep=1, seed=1, ...) metropolis.jl:288-291
+ * plus what the chains/pool objects carry on the Julia side. */
+typedef struct amc_config {
+    uint32_t struct_size;        /* = sizeof(amc_config); ABI guard */
+    int32_t  device;             /* HIP device ordinal */
+    int64_t  n_chains;           /* chains held by THIS handle (local shard) */
+    int64_t  chain_offset;       /* global id of local chain 0; must be even */
+    int64_t  n_chains_global;    /* total chains over all shards (>= offset + n_chains) */
+    int32_t  potential;          /* amc_potential */
+    int32_t  n_moves;            /* K = length(pool) */
+    double   beta;               /* Particle.beta (particle_1d.jl:11), shared by all chains
+                                    unless amc_upload_state passes a per-chain array */
+    const double *sigma;         /* [K] StandardGaussian parameters sigma_k (particle_1d.jl:50) */
+    const double *weight;        /* [K] Move.weight (metropolis.jl:144); must sum to ~1 */
+    uint64_t seed;               /* Metropolis.seed (metropolis.jl:235) -> Philox key */
+    int32_t  sweepstep;          /* Metropolis.sweepstep (metropolis.jl:234), >= 1 */
+    int32_t  per_chain_counters; /* 1: keep Move.accepted_calls/total_calls per chain (needed
+                                    for amc_download_counters; forced on when K > 1).
+                                    0 (K = 1 only): keep only the pool-wide accepted total */
+    void    *stream;             /* optional hipStream_t to run on; NULL -> library-owned */
+} amc_config;
+
+/* Layout of amc_reduce's output (doubles). */
+enum {
+    AMC_RED_SUM_E = 0,       /* sum_c e_c                  -> callback_energy = /M      */
+    AMC_RED_SUM_X = 1,       /* sum_c x_c                                              */
+    AMC_RED_SUM_XX = 2,      /* sum_c x_c^2   (statistic of test/distribution_test.jl:36-37) */
+    AMC_RED_COUNT = 3,       /* local chain count as double                             */
+    AMC_RED_SUM_RATIO0 = 4,  /* + k: sum_c accepted_ck / total_ck -> callback_acceptance = /M */
+    AMC_RED_HEADER = 4
+};
+/* amc_reduce writes AMC_RED_HEADER + K doubles. */
+
+/* amc_pg_estimate writes 5 doubles per learnable move: GradientData for P = 1
+ * (gradients.jl:41-47): j, grad_j, grad_logq_forward, g, n -- SUMS over the local
+ * chains x q_batch samples (the `+` fold of gradients.jl:68-76), n as double. */
+enum { AMC_GD_J = 0, AMC_GD_GRAD_J = 1, AMC_GD_GRAD_LOGQ = 2, AMC_GD_G = 3, AMC_GD_N = 4,
+       AMC_GD_STRIDE = 5 };
+
+const char *amc_last_error(void);
+int  amc_version(void);                          /* major*1000 + minor */
+int  amc_device_count(int *count);
+
+/* Metropolis(chains; ...) constructor, metropolis.jl:240-267 / :288-291.  Asserts
+ * what the reference asserts (weights/parameters well-formed); allocates SoA
+ * state x[M] (+ per-chain counters) in HBM.  State starts at x = 0. */
+int  amc_create(const amc_config *cfg, amc_handle **out);
+int  amc_destroy(amc_handle *h);
+
+/* initialise(): upload chains[c].x (and optionally a per-chain beta array,
+ * Particle.beta).  e is not uploaded: e == potential(x) by construction
+ * (particle_1d.jl:13-15) and is recomputed on device. */
+int  amc_upload_state(amc_handle *h, const double *x, const double *beta_or_null);
+/* Synthetic ensemble: x_c = lo + (hi-lo)*u_c, u from the INIT Philox stream keyed by
+ * the GLOBAL chain id (MC_harmonic_oscillator.jl:13 uses 4rand(rng)-2). */
+int  amc_init_uniform(amc_handle *h, double lo, double hi);
+/* finalise(): chains[c].x / chains[c].e back to the host (either may be NULL). */
+int  amc_download_state(amc_handle *h, double *x, double *e);
+/* pools[c][k].accepted_calls / total_calls, move-major [k*n_chains + c]. */
+int  amc_download_counters(amc_handle *h, int64_t *accepted, int64_t *total);
+/* Pool-wide sums over local chains: accepted[k], total[k] (exact integers). */
+int  amc_counter_totals(amc_handle *h, int64_t *accepted, int64_t *total);
+
+/* n x make_step!(simulation, ::Metropolis) (metropolis.jl:302-309): each is
+ * `sweepstep` mc_step!s per chain.  The n*sweepstep steps run fused in one launch
+ * (state stays in registers); results are identical to n separate calls. */
+int  amc_sweep(amc_handle *h, int64_t n_sweeps);
+/* MH steps done per chain so far (the Philox step index); settable for resume. */
+int  amc_get_step(amc_handle *h, uint64_t *t);
+int  amc_set_step(amc_handle *h, uint64_t t);
+
+/* callback_energy (particle_1d.jl:68-70) / callback_acceptance (metropolis.jl:319-321)
+ * / position moments as LOCAL sums; deterministic two-pass device reduction.
+ * out: AMC_RED_HEADER + K doubles.  Divide by the global chain count after the
+ * cross-shard sum. */
+int  amc_reduce(amc_handle *h, double *out);
+
+/* Move.parameters (shared by all chains, metropolis.jl:252-260): read / replace
+ * sigma_k on the device copy, e.g. after learning_step! (update.jl:50-57). */
+int  amc_set_parameters(amc_handle *h, int k, const double *p, int n);
+int  amc_get_parameters(amc_handle *h, int k, double *p, int n);
+
+/* make_step!(simulation, ::PolicyGradientEstimator) (estimator.jl:111-134) for the
+ * moves learn_ids[0..n_learn) (0-based), q_batch samples per chain per move, in the
+ * reference's order (move-major, then sample).  Like the reference, every sample
+ * leaves x at (x+delta)-delta (gradients.jl:98,103).  out: n_learn*AMC_GD_STRIDE. */
+int  amc_pg_estimate(amc_handle *h, int n_learn, const int *learn_ids, int q_batch,
+                     double *out);
+
+int  amc_sync(amc_handle *h);
+/* hipStream_t the handle launches on (for event timing / graph capture by the host). */
+int  amc_get_stream(amc_handle *h, void **stream);
+/* HIP-event timing on the handle's stream: begin records an event, end records a second
+ * one, waits for it and returns the elapsed device time between the two in ms. */
+int  amc_timing_begin(amc_handle *h);
+int  amc_timing_end(amc_handle *h, double *elapsed_ms);
+
+/* Cross-shard sum over RCCL (xGMI) for hosts without torch.distributed (Julia):
+ * nccl_unique_id is the 128-byte ncclUniqueId made by amc_comm_unique_id on rank 0
+ * and shipped to the other ranks by the caller. */
+int  amc_comm_unique_id(void *id128);
+int  amc_comm_init(amc_handle *h, int rank, int n_ranks, const void *id128);
+int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
+
+/* Parity-test hooks: evaluate arithmetic-spec primitives on the device.
+ * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b.  Host buffers, n entries. */
+int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
+                       double *out, int64_t n);
+/* out4[i] = Philox4x32-10(key = seed, counter of draw (pair[i], t[i], draw, stream)). */
+int  amc_selftest_philox(int device, uint64_t seed, const uint64_t *pair, const uint64_t *t,
+                         uint32_t draw, uint32_t stream, uint32_t *out4, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

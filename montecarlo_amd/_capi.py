@@ -1,0 +1,293 @@
+"""ctypes binding of libamc.so (include/amc.h) -- the only way this package computes.
+
+There is no CPU path: if the shared library is missing, or no gfx950 device is
+usable, construction raises.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C montecarlo_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamc.so")
+
+AMC_MAX_MOVES = 64
+AMC_MAX_LEARN = 8
+AMC_RED_HEADER = 4
+AMC_GD_STRIDE = 5
+
+POTENTIALS = {"harmonic": 0, "double_well": 1}
+
+
+class AmcError(RuntimeError):
+    """Non-zero amc_status from the C ABI (the Julia binding calls error(...) likewise)."""
+
+
+class AmcConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("n_chains", C.c_int64),
+        ("chain_offset", C.c_int64),
+        ("n_chains_global", C.c_int64),
+        ("potential", C.c_int32),
+        ("n_moves", C.c_int32),
+        ("beta", C.c_double),
+        ("sigma", C.POINTER(C.c_double)),
+        ("weight", C.POINTER(C.c_double)),
+        ("seed", C.c_uint64),
+        ("sweepstep", C.c_int32),
+        ("per_chain_counters", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libamc.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmcError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C montecarlo_amd/csrc). "
+            "montecarlo_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    i64p = C.POINTER(C.c_int64)
+    sig = {
+        "amc_last_error": (C.c_char_p, []),
+        "amc_version": (C.c_int, []),
+        "amc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "amc_create": (C.c_int, [C.POINTER(AmcConfig), C.POINTER(H)]),
+        "amc_destroy": (C.c_int, [H]),
+        "amc_upload_state": (C.c_int, [H, dp, dp]),
+        "amc_init_uniform": (C.c_int, [H, C.c_double, C.c_double]),
+        "amc_download_state": (C.c_int, [H, dp, dp]),
+        "amc_download_counters": (C.c_int, [H, i64p, i64p]),
+        "amc_counter_totals": (C.c_int, [H, i64p, i64p]),
+        "amc_sweep": (C.c_int, [H, C.c_int64]),
+        "amc_get_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "amc_set_step": (C.c_int, [H, C.c_uint64]),
+        "amc_reduce": (C.c_int, [H, dp]),
+        "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
+        "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
+        "amc_pg_estimate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amc_sync": (C.c_int, [H]),
+        "amc_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+        "amc_timing_begin": (C.c_int, [H]),
+        "amc_timing_end": (C.c_int, [H, dp]),
+        "amc_comm_unique_id": (C.c_int, [C.c_void_p]),
+        "amc_comm_init": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
+        "amc_allreduce_sum": (C.c_int, [H, dp, C.c_int]),
+        "amc_selftest_math": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, C.c_int64]),
+        "amc_selftest_philox": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                          C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load().amc_last_error()
+        raise AmcError(f"amc error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().amc_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _dptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HipEngine:
+    """One amc_handle: the device-resident shard of the chain ensemble.
+
+    Mirrors what the reference's ``Metropolis`` object owns (pools, seed, rngs,
+    sweepstep: src/metropolis.jl:232-239), SoA on one MI355X.
+    """
+
+    def __init__(self, *, n_chains: int, chain_offset: int = 0, n_chains_global: Optional[int] = None,
+                 potential: str = "harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
+                 weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
+                 per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None):
+        lib = load()
+        if potential not in POTENTIALS:
+            raise AmcError(f"unknown potential {potential!r}; the HIP engine offers {sorted(POTENTIALS)}")
+        self.n_chains = int(n_chains)
+        self.n_moves = len(sigma)
+        self._sigma = (C.c_double * self.n_moves)(*[float(s) for s in sigma])
+        self._weight = (C.c_double * self.n_moves)(*[float(w) for w in weight])
+        cfg = AmcConfig()
+        cfg.struct_size = C.sizeof(AmcConfig)
+        cfg.device = int(device)
+        cfg.n_chains = self.n_chains
+        cfg.chain_offset = int(chain_offset)
+        cfg.n_chains_global = int(n_chains_global if n_chains_global is not None else chain_offset + n_chains)
+        cfg.potential = POTENTIALS[potential]
+        cfg.n_moves = self.n_moves
+        cfg.beta = float(beta)
+        cfg.sigma = self._sigma
+        cfg.weight = self._weight
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.sweepstep = int(sweepstep)
+        cfg.per_chain_counters = 1 if per_chain_counters else 0
+        cfg.stream = stream
+        self._lib = lib
+        self._h = C.c_void_p()
+        _check(lib.amc_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- lifetime --------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.amc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state -----------------------------------------------------------------
+    def upload_state(self, x: np.ndarray, beta: Optional[np.ndarray] = None) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (self.n_chains,):
+            raise AmcError(f"upload_state: x has shape {x.shape}, expected ({self.n_chains},)")
+        if beta is not None:
+            beta = np.ascontiguousarray(beta, dtype=np.float64)
+            if beta.shape != (self.n_chains,):
+                raise AmcError("upload_state: beta must have one entry per chain")
+        _check(self._lib.amc_upload_state(self._h, _dptr(x), _dptr(beta)))
+
+    def init_uniform(self, lo: float, hi: float) -> None:
+        _check(self._lib.amc_init_uniform(self._h, float(lo), float(hi)))
+
+    def download_state(self, want_e: bool = True):
+        x = np.empty(self.n_chains, dtype=np.float64)
+        e = np.empty(self.n_chains, dtype=np.float64) if want_e else None
+        _check(self._lib.amc_download_state(self._h, _dptr(x), _dptr(e)))
+        return x, e
+
+    def download_counters(self):
+        acc = np.empty((self.n_moves, self.n_chains), dtype=np.int64)
+        tot = np.empty((self.n_moves, self.n_chains), dtype=np.int64)
+        p = C.POINTER(C.c_int64)
+        _check(self._lib.amc_download_counters(self._h, acc.ctypes.data_as(p), tot.ctypes.data_as(p)))
+        return acc, tot
+
+    def counter_totals(self):
+        acc = np.zeros(self.n_moves, dtype=np.int64)
+        tot = np.zeros(self.n_moves, dtype=np.int64)
+        p = C.POINTER(C.c_int64)
+        _check(self._lib.amc_counter_totals(self._h, acc.ctypes.data_as(p), tot.ctypes.data_as(p)))
+        return acc, tot
+
+    # -- hot path ----------------------------------------------------------------
+    def sweep(self, n_sweeps: int = 1) -> None:
+        _check(self._lib.amc_sweep(self._h, int(n_sweeps)))
+
+    @property
+    def step(self) -> int:
+        t = C.c_uint64(0)
+        _check(self._lib.amc_get_step(self._h, C.byref(t)))
+        return t.value
+
+    @step.setter
+    def step(self, t: int) -> None:
+        _check(self._lib.amc_set_step(self._h, int(t)))
+
+    def reduce(self) -> np.ndarray:
+        out = np.empty(AMC_RED_HEADER + self.n_moves, dtype=np.float64)
+        _check(self._lib.amc_reduce(self._h, _dptr(out)))
+        return out
+
+    def set_parameters(self, k: int, p: Sequence[float]) -> None:
+        a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+        _check(self._lib.amc_set_parameters(self._h, int(k), _dptr(a), int(a.size)))
+
+    def get_parameters(self, k: int) -> np.ndarray:
+        a = np.empty(1, dtype=np.float64)
+        _check(self._lib.amc_get_parameters(self._h, int(k), _dptr(a), 1))
+        return a
+
+    def pg_estimate(self, learn_ids: Sequence[int], q_batch: int) -> np.ndarray:
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
+        _check(self._lib.amc_pg_estimate(self._h, n, ids, int(q_batch), _dptr(out)))
+        return out
+
+    def sync(self) -> None:
+        _check(self._lib.amc_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(self._lib.amc_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def timing_begin(self) -> None:
+        _check(self._lib.amc_timing_begin(self._h))
+
+    def timing_end(self) -> float:
+        ms = C.c_double(0.0)
+        _check(self._lib.amc_timing_end(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- RCCL through the C ABI (what the Julia binding uses) ----------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load().amc_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, n_ranks: int, unique_id: bytes) -> None:
+        buf = C.create_string_buffer(unique_id, 128)
+        _check(self._lib.amc_comm_init(self._h, int(rank), int(n_ranks), buf))
+
+    def allreduce_sum(self, a: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        _check(self._lib.amc_allreduce_sum(self._h, _dptr(a), int(a.size)))
+        return a
+
+
+def selftest_math(fn: str, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+    """Evaluate one arithmetic-spec primitive on the GPU (parity tests only)."""
+    ids = {"exp": 0, "log": 1, "sinpi": 2, "cospi": 3, "sqrt": 4, "div": 5}
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.empty_like(a)
+    _check(load().amc_selftest_math(int(device), ids[fn], _dptr(a), _dptr(b), _dptr(out), a.size))
+    return out
+
+
+def selftest_philox(seed: int, pair: np.ndarray, t: np.ndarray, draw: int, stream: int,
+                    device: int = 0) -> np.ndarray:
+    """Raw Philox4x32-10 words of draw (pair, t, draw, stream) on the GPU (parity tests only)."""
+    pair = np.ascontiguousarray(pair, dtype=np.uint64)
+    t = np.ascontiguousarray(t, dtype=np.uint64)
+    out = np.empty((pair.size, 4), dtype=np.uint32)
+    u64p = C.POINTER(C.c_uint64)
+    _check(load().amc_selftest_philox(int(device), C.c_uint64(int(seed)), pair.ctypes.data_as(u64p),
+                                      t.ctypes.data_as(u64p), int(draw), int(stream),
+                                      out.ctypes.data_as(C.POINTER(C.c_uint32)), pair.size))
+    return out

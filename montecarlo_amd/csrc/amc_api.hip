@@ -1,0 +1,708 @@
+// amc_api.hip -- C ABI (include/amc.h) over the HIP kernels of amc_kernels.h.
+//
+// Host side of the engine: owns device memory, the stream and the step counter;
+// validates arguments the way the reference's constructors assert them
+// (src/metropolis.jl:248-251, Distributions.Categorical's probability-vector check).
+// No CPU fallback: every entry point either runs on the GPU or returns an error.
+#include "../../include/amc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "amc_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define AMC_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "%s failed: %s",    \
+                        #call, hipGetErrorString(e_));                                             \
+    } while (0)
+
+// Minimal RCCL surface, resolved with dlopen so the library has no link-time RCCL
+// dependency and shares the instance a host process may already have loaded.
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // id passed by pointer (see shim)
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct amc_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t M = 0, M_pad = 0, offset = 0, M_global = 0;
+    int potential = 0, K = 1, sweepstep = 1;
+    bool counters = false;      // per-chain counters kept
+    bool beta_arr = false;
+    double beta = 1.0;
+    uint64_t seed = 0;
+    uint64_t t = 0;             // MH steps done (Philox step index)
+    uint64_t t_counted = 0;     // MH steps counted in acc/tot since creation
+    uint64_t t_est = 0;         // estimator calls done
+    double* d_x = nullptr;
+    double* d_beta = nullptr;
+    uint32_t* d_acc = nullptr;
+    uint32_t* d_tot = nullptr;
+    double* d_ptab = nullptr;
+    unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total
+    double* d_partials = nullptr;
+    double* d_out = nullptr;
+    double* h_out = nullptr;    // pinned
+    int red_blocks = 0;
+    int n_cu = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* comm = nullptr;
+    double* d_comm = nullptr;
+    Rccl rccl;
+};
+
+namespace {
+
+int grid_for(const amc_handle* h, int64_t n_items)
+{
+    // memory-streaming shape: <= 8 blocks of 256 per CU, grid-stride the rest
+    int64_t blocks = (n_items + AMC_BLOCK - 1) / AMC_BLOCK;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int push_params(amc_handle* h, const double* sigma, const double* weight)
+{
+    std::vector<double> tab((size_t)amc::PT_ROWS * AMC_MAX_MOVES, 0.0);
+    AMC_HIP(hipMemcpyAsync(tab.data(), h->d_ptab, tab.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < h->K; ++k) {
+        if (sigma) tab[amc::PT_SIGMA * AMC_MAX_MOVES + k] = sigma[k];
+        if (weight) tab[amc::PT_WEIGHT * AMC_MAX_MOVES + k] = weight[k];
+    }
+    AMC_HIP(hipMemcpyAsync(h->d_ptab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));   // tab is a stack-scoped host buffer
+    hipLaunchKernelGGL(amc::prepare_params_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->K);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+template <int POT>
+int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
+{
+    const bool multi = h->K > 1;
+    if (multi) {
+        if (h->beta_arr)
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    } else if (h->counters) {
+        if (h->beta_arr)
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    } else {
+        if (h->beta_arr)
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    }
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+template <int POT, int NL>
+int launch_pg_nl(amc_handle* h, const amc::PgArgs& a, int grid)
+{
+    if (h->beta_arr)
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    else
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+template <int POT>
+int launch_pg(amc_handle* h, const amc::PgArgs& a, int grid, int nl_cap)
+{
+    switch (nl_cap) {
+    case 1: return launch_pg_nl<POT, 1>(h, a, grid);
+    case 2: return launch_pg_nl<POT, 2>(h, a, grid);
+    case 4: return launch_pg_nl<POT, 4>(h, a, grid);
+    default: return launch_pg_nl<POT, 8>(h, a, grid);
+    }
+}
+
+int nl_capacity(int n_learn) { return n_learn <= 1 ? 1 : n_learn <= 2 ? 2 : n_learn <= 4 ? 4 : 8; }
+
+}  // namespace
+
+extern "C" {
+
+const char* amc_last_error(void) { return g_last_error.c_str(); }
+
+int amc_version(void) { return AMC_VERSION_MAJOR * 1000 + AMC_VERSION_MINOR; }
+
+int amc_device_count(int* count)
+{
+    if (!count) return fail(AMC_ERR_BAD_ARG, "amc_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(AMC_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return AMC_OK;
+}
+
+int amc_create(const amc_config* cfg, amc_handle** out)
+{
+    if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(amc_config))
+        return fail(AMC_ERR_BAD_ARG, "amc_create: struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(amc_config));
+    if (cfg->n_chains < 1) return fail(AMC_ERR_BAD_ARG, "amc_create: n_chains must be >= 1");
+    if (cfg->chain_offset < 0 || (cfg->chain_offset & 1))
+        return fail(AMC_ERR_BAD_ARG, "amc_create: chain_offset must be even and >= 0 (shards split on chain pairs)");
+    if (cfg->n_chains_global < cfg->chain_offset + cfg->n_chains)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: n_chains_global < chain_offset + n_chains");
+    if (cfg->n_moves < 1 || cfg->n_moves > AMC_MAX_MOVES)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: n_moves must be in [1, %d]", AMC_MAX_MOVES);
+    if (cfg->sweepstep < 1) return fail(AMC_ERR_BAD_ARG, "amc_create: sweepstep must be >= 1");
+    if (cfg->potential != AMC_POTENTIAL_HARMONIC && cfg->potential != AMC_POTENTIAL_DOUBLE_WELL)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: unknown potential id %d", cfg->potential);
+    if (!cfg->sigma || !cfg->weight) return fail(AMC_ERR_BAD_ARG, "amc_create: sigma/weight is NULL");
+    double wsum = 0.0;
+    for (int k = 0; k < cfg->n_moves; ++k) {
+        if (!(cfg->sigma[k] > 0.0) || !std::isfinite(cfg->sigma[k]))
+            return fail(AMC_ERR_BAD_ARG, "amc_create: sigma[%d] must be finite and > 0", k);
+        if (!(cfg->weight[k] >= 0.0) || !std::isfinite(cfg->weight[k]))
+            return fail(AMC_ERR_BAD_ARG, "amc_create: weight[%d] must be finite and >= 0", k);
+        wsum += cfg->weight[k];
+    }
+    // Categorical(weights) requires a probability vector (isprobvec: sum ~ 1, rtol sqrt(eps))
+    if (std::fabs(wsum - 1.0) > 1.4901161193847656e-08)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: weights must sum to 1 (got %.17g)", wsum);
+    if (cfg->n_moves > 1 && !cfg->per_chain_counters) {
+        // K > 1 needs per-chain (accepted, total) pairs for callback_acceptance's mean of ratios
+    }
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1)
+        return fail(AMC_ERR_NO_DEVICE, "amc_create: no HIP device (%s); this engine has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+    if (cfg->device < 0 || cfg->device >= n_dev)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: device %d out of range [0, %d)", cfg->device, n_dev);
+    AMC_HIP(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    AMC_HIP(hipGetDeviceProperties(&prop, cfg->device));
+
+    amc_handle* h = new (std::nothrow) amc_handle();
+    if (!h) return fail(AMC_ERR_OOM, "amc_create: host allocation failed");
+    h->device = cfg->device;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->M = cfg->n_chains;
+    h->M_pad = ((cfg->n_chains + 1) & ~(int64_t)1) + 2;   // even + one spare pair: 16-B tail loads stay in bounds
+    h->offset = cfg->chain_offset;
+    h->M_global = cfg->n_chains_global;
+    h->potential = cfg->potential;
+    h->K = cfg->n_moves;
+    h->sweepstep = cfg->sweepstep;
+    h->counters = cfg->per_chain_counters != 0 || cfg->n_moves > 1;
+    h->beta = cfg->beta;
+    h->seed = cfg->seed;
+
+    int rc = AMC_OK;
+    auto bail = [&](int code) { amc_destroy(h); return code; };
+#define AMC_TRY(call)                                                                   \
+    do {                                                                                \
+        hipError_t e2_ = (call);                                                        \
+        if (e2_ != hipSuccess) {                                                        \
+            rc = fail(e2_ == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP,           \
+                      "%s failed: %s", #call, hipGetErrorString(e2_));                  \
+            return bail(rc);                                                            \
+        }                                                                               \
+    } while (0)
+
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+    } else {
+        AMC_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    AMC_TRY(hipMalloc(&h->d_x, (size_t)h->M_pad * sizeof(double)));
+    AMC_TRY(hipMemsetAsync(h->d_x, 0, (size_t)h->M_pad * sizeof(double), h->stream));
+    if (h->counters) {
+        const size_t n = (size_t)h->K * (size_t)h->M_pad;
+        AMC_TRY(hipMalloc(&h->d_acc, n * sizeof(uint32_t)));
+        AMC_TRY(hipMemsetAsync(h->d_acc, 0, n * sizeof(uint32_t), h->stream));
+        if (h->K > 1) {
+            AMC_TRY(hipMalloc(&h->d_tot, n * sizeof(uint32_t)));
+            AMC_TRY(hipMemsetAsync(h->d_tot, 0, n * sizeof(uint32_t), h->stream));
+        }
+    }
+    AMC_TRY(hipMalloc(&h->d_ptab, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double)));
+    AMC_TRY(hipMemsetAsync(h->d_ptab, 0, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double), h->stream));
+    AMC_TRY(hipMalloc(&h->d_totals, 2 * AMC_MAX_MOVES * sizeof(unsigned long long)));
+    AMC_TRY(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
+    h->red_blocks = grid_for(h, h->M);
+    {
+        size_t per_block = (size_t)(4 + AMC_MAX_MOVES);
+        if (per_block < (size_t)AMC_MAX_LEARN * 4) per_block = (size_t)AMC_MAX_LEARN * 4;
+        AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * per_block * sizeof(double)));
+    }
+    AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double)));
+    AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double), 0));
+    AMC_TRY(hipEventCreate(&h->ev0));
+    AMC_TRY(hipEventCreate(&h->ev1));
+#undef AMC_TRY
+    rc = push_params(h, cfg->sigma, cfg->weight);
+    if (rc != AMC_OK) return bail(rc);
+    *out = h;
+    return AMC_OK;
+}
+
+int amc_destroy(amc_handle* h)
+{
+    if (!h) return AMC_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    (void)hipFree(h->d_comm);
+    (void)hipFree(h->d_x);
+    (void)hipFree(h->d_beta);
+    (void)hipFree(h->d_acc);
+    (void)hipFree(h->d_tot);
+    (void)hipFree(h->d_ptab);
+    (void)hipFree(h->d_totals);
+    (void)hipFree(h->d_partials);
+    (void)hipFree(h->d_out);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return AMC_OK;
+}
+
+int amc_upload_state(amc_handle* h, const double* x, const double* beta_or_null)
+{
+    if (!h || !x) return fail(AMC_ERR_BAD_ARG, "amc_upload_state: NULL argument");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipMemcpyAsync(h->d_x, x, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (beta_or_null) {
+        if (!h->d_beta) {
+            AMC_HIP(hipMalloc(&h->d_beta, (size_t)h->M_pad * sizeof(double)));
+            AMC_HIP(hipMemsetAsync(h->d_beta, 0, (size_t)h->M_pad * sizeof(double), h->stream));
+        }
+        AMC_HIP(hipMemcpyAsync(h->d_beta, beta_or_null, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->beta_arr = true;
+    }
+    AMC_HIP(hipStreamSynchronize(h->stream));   // caller's buffers are only valid during the call
+    return AMC_OK;
+}
+
+int amc_init_uniform(amc_handle* h, double lo, double hi)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_init_uniform: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    const int grid = grid_for(h, (h->M + 1) / 2);
+    hipLaunchKernelGGL(amc::init_uniform_kernel, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_x, h->M,
+                       (uint64_t)h->offset >> 1, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), lo, hi);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_download_state(amc_handle* h, double* x, double* e)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_download_state: NULL handle");
+    if (!x && !e) return AMC_OK;
+    AMC_HIP(hipSetDevice(h->device));
+    double* dst = x;
+    std::vector<double> tmp;
+    if (!dst) { tmp.resize((size_t)h->M); dst = tmp.data(); }
+    AMC_HIP(hipMemcpyAsync(dst, h->d_x, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    if (e) {
+        // e == potential(x) exactly (particle_1d.jl:33): the same two IEEE multiplies on the host
+        for (int64_t c = 0; c < h->M; ++c) {
+            const double xc = dst[c];
+            if (h->potential == AMC_POTENTIAL_DOUBLE_WELL) {
+                volatile double q = xc * xc;   // volatile: no host-side fma contraction of x*x - 1
+                const double r = q - 1.0;
+                e[c] = r * r;
+            } else {
+                e[c] = xc * xc;
+            }
+        }
+    }
+    return AMC_OK;
+}
+
+int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_download_counters: NULL handle");
+    if (!h->counters)
+        return fail(AMC_ERR_STATE, "amc_download_counters: handle was created with per_chain_counters = 0");
+    AMC_HIP(hipSetDevice(h->device));
+    std::vector<uint32_t> buf((size_t)h->M);
+    for (int k = 0; k < h->K; ++k) {
+        if (accepted) {
+            AMC_HIP(hipMemcpyAsync(buf.data(), h->d_acc + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, h->stream));
+            AMC_HIP(hipStreamSynchronize(h->stream));
+            for (int64_t c = 0; c < h->M; ++c) accepted[(int64_t)k * h->M + c] = buf[(size_t)c];
+        }
+        if (total) {
+            if (h->K > 1) {
+                AMC_HIP(hipMemcpyAsync(buf.data(), h->d_tot + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, h->stream));
+                AMC_HIP(hipStreamSynchronize(h->stream));
+                for (int64_t c = 0; c < h->M; ++c) total[(int64_t)k * h->M + c] = buf[(size_t)c];
+            } else {
+                for (int64_t c = 0; c < h->M; ++c) total[c] = (int64_t)h->t_counted;
+            }
+        }
+    }
+    return AMC_OK;
+}
+
+int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_counter_totals: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    unsigned long long host[2 * AMC_MAX_MOVES];
+    if (h->K > 1) {
+        AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(amc::counter_totals_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, h->d_acc,
+                           h->d_tot, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
+        AMC_HIP(hipGetLastError());
+    }
+    AMC_HIP(hipMemcpyAsync(host, h->d_totals, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < h->K; ++k) {
+        if (accepted) accepted[k] = (int64_t)host[k];
+        if (total) total[k] = (h->K > 1) ? (int64_t)host[AMC_MAX_MOVES + k] : (int64_t)(h->t_counted * (uint64_t)h->M);
+    }
+    return AMC_OK;
+}
+
+int amc_sweep(amc_handle* h, int64_t n_sweeps)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep: NULL handle");
+    if (n_sweeps < 0) return fail(AMC_ERR_BAD_ARG, "amc_sweep: n_sweeps < 0");
+    if (n_sweeps == 0) return AMC_OK;
+    AMC_HIP(hipSetDevice(h->device));
+    int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
+    const int grid = grid_for(h, (h->M + 1) / 2);
+    while (remaining > 0) {
+        const int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
+        amc::SweepArgs a;
+        a.x = h->d_x;
+        a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
+        a.acc = h->d_acc;
+        a.tot = h->d_tot;
+        a.ptab = h->d_ptab;
+        a.acc_total = h->d_totals;
+        a.n_chains = h->M;
+        a.m_stride = h->M_pad;
+        a.pair0 = (uint64_t)h->offset >> 1;
+        a.t0 = h->t;
+        a.n_steps = chunk;
+        a.n_moves = h->K;
+        a.key0 = (uint32_t)h->seed;
+        a.key1 = (uint32_t)(h->seed >> 32);
+        a.beta = h->beta;
+        const int rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep<amc::POT_DOUBLE_WELL>(h, a, grid)
+                                                                   : launch_sweep<amc::POT_HARMONIC>(h, a, grid);
+        if (rc != AMC_OK) return rc;
+        h->t += (uint64_t)chunk;
+        h->t_counted += (uint64_t)chunk;
+        remaining -= chunk;
+    }
+    return AMC_OK;
+}
+
+int amc_get_step(amc_handle* h, uint64_t* t)
+{
+    if (!h || !t) return fail(AMC_ERR_BAD_ARG, "amc_get_step: NULL argument");
+    *t = h->t;
+    return AMC_OK;
+}
+
+int amc_set_step(amc_handle* h, uint64_t t)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_set_step: NULL handle");
+    if (t >> 48) return fail(AMC_ERR_BAD_ARG, "amc_set_step: step index must fit 48 bits");
+    h->t = t;
+    return AMC_OK;
+}
+
+int amc_reduce(amc_handle* h, double* out)
+{
+    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce: NULL argument");
+    AMC_HIP(hipSetDevice(h->device));
+    const int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
+    const int n_vals = 4 + h->K;
+    if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
+        hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
+                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, h->d_partials);
+    else
+        hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
+                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, h->d_partials);
+    AMC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, h->red_blocks,
+                       n_vals, h->d_out);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)n_vals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    unsigned long long acc_total = 0;
+    if (ratio_mode == 0)
+        AMC_HIP(hipMemcpyAsync(&acc_total, h->d_totals, sizeof(acc_total), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
+    if (ratio_mode == 0) {
+        // K == 1 without per-chain counters: total_calls is the same on every chain, so
+        // sum_c accepted_c/total == (sum_c accepted_c)/total up to rounding
+        out[AMC_RED_SUM_RATIO0] = (double)acc_total / (double)h->t_counted;
+    }
+    return AMC_OK;
+}
+
+int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
+{
+    if (!h || !p) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: NULL argument");
+    if (k < 0 || k >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: move index %d out of range", k);
+    if (n != 1) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: StandardGaussian has exactly 1 parameter (sigma)");
+    if (!(p[0] > 0.0) || !std::isfinite(p[0]))
+        return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: sigma must be finite and > 0 (got %.17g)", p[0]);
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipMemcpyAsync(h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, p, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(amc::prepare_params_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->K);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_get_parameters(amc_handle* h, int k, double* p, int n)
+{
+    if (!h || !p) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: NULL argument");
+    if (k < 0 || k >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: move index %d out of range", k);
+    if (n != 1) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: StandardGaussian has exactly 1 parameter (sigma)");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipMemcpyAsync(p, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, double* out)
+{
+    if (!h || !out || (n_learn > 0 && !learn_ids)) return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: NULL argument");
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN)
+        return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)
+        return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: q_batch must be in [1, %d] and q_batch*n_learn < 4096", AMC_MAX_QBATCH);
+    for (int l = 0; l < n_learn; ++l)
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K)
+            return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: learn_ids[%d] = %d out of range", l, learn_ids[l]);
+    if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
+    AMC_HIP(hipSetDevice(h->device));
+    amc::PgArgs a;
+    a.x = h->d_x;
+    a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
+    a.ptab = h->d_ptab;
+    a.partials = h->d_partials;
+    a.n_chains = h->M;
+    a.pair0 = (uint64_t)h->offset >> 1;
+    a.t_est = h->t_est;
+    a.q_batch = q_batch;
+    a.n_learn = n_learn;
+    for (int l = 0; l < AMC_MAX_LEARN; ++l) a.learn_ids[l] = l < n_learn ? learn_ids[l] : 0;
+    a.key0 = (uint32_t)h->seed;
+    a.key1 = (uint32_t)(h->seed >> 32);
+    a.beta = h->beta;
+    const int nl = nl_capacity(n_learn);
+    int grid = grid_for(h, (h->M + 1) / 2);
+    if (grid > h->red_blocks) grid = h->red_blocks;
+    const int rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, grid, nl)
+                                                               : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
+    if (rc != AMC_OK) return rc;
+    // partials layout [grid][nl][4]: reduce the first n_learn*4 of every nl*4 row
+    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, nl * 4,
+                       h->d_out);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < n_learn; ++l) {
+        for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_out[l * 4 + i];
+        out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
+    }
+    h->t_est += 1;
+    return AMC_OK;
+}
+
+int amc_sync(amc_handle* h)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sync: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+int amc_get_stream(amc_handle* h, void** stream)
+{
+    if (!h || !stream) return fail(AMC_ERR_BAD_ARG, "amc_get_stream: NULL argument");
+    *stream = (void*)h->stream;
+    return AMC_OK;
+}
+
+int amc_timing_begin(amc_handle* h)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_timing_begin: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipEventRecord(h->ev0, h->stream));
+    return AMC_OK;
+}
+
+int amc_timing_end(amc_handle* h, double* elapsed_ms)
+{
+    if (!h || !elapsed_ms) return fail(AMC_ERR_BAD_ARG, "amc_timing_end: NULL argument");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipEventRecord(h->ev1, h->stream));
+    AMC_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    AMC_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *elapsed_ms = (double)ms;
+    return AMC_OK;
+}
+
+// ---- RCCL over xGMI, for hosts that have no torch.distributed (the Julia binding) ----
+static int load_rccl(Rccl& r)
+{
+    if (r.lib) return AMC_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return fail(AMC_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+    r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
+    r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    void* init = dlsym(r.lib, "ncclCommInitRank");
+    r.CommInitRank = (int (*)(void**, int, const void*, int))init;
+    if (!r.GetUniqueId || !r.AllReduce || !r.CommDestroy || !init)
+        return fail(AMC_ERR_COMM, "librccl is missing a required symbol");
+    return AMC_OK;
+}
+
+int amc_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_unique_id: NULL argument");
+    static Rccl r;
+    const int rc = load_rccl(r);
+    if (rc != AMC_OK) return rc;
+    const int e = r.GetUniqueId(id128);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclGetUniqueId failed: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
+    return AMC_OK;
+}
+
+int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
+{
+    if (!h || !id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: NULL argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: bad rank/n_ranks");
+    AMC_HIP(hipSetDevice(h->device));
+    const int rc = load_rccl(h->rccl);
+    if (rc != AMC_OK) return rc;
+    // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId /* 128-byte struct BY VALUE */, int rank)
+    struct Id { char b[128]; } id;
+    std::memcpy(&id, id128, sizeof(id));
+    typedef int (*init_fn)(void**, int, Id, int);
+    const int e = ((init_fn)(void*)h->rccl.CommInitRank)(&h->comm, n_ranks, id, rank);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    AMC_HIP(hipMalloc(&h->d_comm, 256 * sizeof(double)));
+    return AMC_OK;
+}
+
+int amc_allreduce_sum(amc_handle* h, double* buf, int n)
+{
+    if (!h || !buf) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: NULL argument");
+    if (n < 0 || n > 256) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, 256]");
+    if (!h->comm) return AMC_OK;   // single shard: the local sum is the global sum
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipMemcpyAsync(h->d_comm, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    AMC_HIP(hipMemcpyAsync(buf, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+// ---- parity-test hooks ----------------------------------------------------------------
+int amc_selftest_math(int device, int fn, const double* a, const double* b_or_null, double* out, int64_t n)
+{
+    if (!a || !out || n < 0 || fn < 0 || fn > 5 || (fn == 5 && !b_or_null))
+        return fail(AMC_ERR_BAD_ARG, "amc_selftest_math: bad argument");
+    if (n == 0) return AMC_OK;
+    AMC_HIP(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    AMC_HIP(hipMalloc(&da, (size_t)n * sizeof(double)));
+    AMC_HIP(hipMalloc(&db, (size_t)n * sizeof(double)));
+    AMC_HIP(hipMalloc(&dout, (size_t)n * sizeof(double)));
+    AMC_HIP(hipMemcpy(da, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    AMC_HIP(hipMemcpy(db, b_or_null ? b_or_null : a, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(amc::selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, da, db, dout, n);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return AMC_OK;
+}
+
+int amc_selftest_philox(int device, uint64_t seed, const uint64_t* pair, const uint64_t* t, uint32_t draw,
+                        uint32_t stream, uint32_t* out4, int64_t n)
+{
+    if (!pair || !t || !out4 || n < 0) return fail(AMC_ERR_BAD_ARG, "amc_selftest_philox: bad argument");
+    if (n == 0) return AMC_OK;
+    AMC_HIP(hipSetDevice(device));
+    uint64_t *dp = nullptr, *dt = nullptr;
+    uint32_t* dout = nullptr;
+    AMC_HIP(hipMalloc(&dp, (size_t)n * sizeof(uint64_t)));
+    AMC_HIP(hipMalloc(&dt, (size_t)n * sizeof(uint64_t)));
+    AMC_HIP(hipMalloc(&dout, (size_t)n * 4 * sizeof(uint32_t)));
+    AMC_HIP(hipMemcpy(dp, pair, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    AMC_HIP(hipMemcpy(dt, t, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(amc::selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), dp, dt, draw, stream, dout, n);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpy(out4, dout, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(dp); (void)hipFree(dt); (void)hipFree(dout);
+    return AMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,451 @@
+// amc_kernels.h -- HIP kernels of the many-chain Metropolis engine (gfx950 / CDNA4).
+//
+// Data layout in HBM: SoA, one f64 per chain
+//   x[M_pad]                      chain positions (Particle.x); e is NOT stored: it is
+//                                 potential(x) by construction (particle_1d.jl:13-15,33)
+//   beta[M_pad]      (optional)   per-chain Particle.beta
+//   acc[K][M_pad], tot[K][M_pad]  u32 Move.accepted_calls / total_calls (when kept)
+//   ptab[PT_ROWS][AMC_MAX_MOVES]  per-move derived parameters (device-computed)
+// One lane owns TWO adjacent chains (one global "pair"): 16-byte loads/stores, one
+// Box-Muller and one accept-uniform Philox call serve both chains.
+// All kernels are HBM-streaming in shape but f64-VALU-bound in practice; no MFMA.
+#pragma once
+
+#include "amc_math.h"
+
+#define AMC_MAX_MOVES 64
+#define AMC_MAX_LEARN 8
+#define AMC_BLOCK 256
+
+namespace amc {
+
+enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1 };
+
+// Rows of the per-move parameter table.
+enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
+       PT_ROWS = 7 };
+
+// potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
+// double well (x*x-1)^2 is BASELINE config 3's.
+template <int POT>
+__device__ __forceinline__ double potential(double x)
+{
+    if (POT == POT_DOUBLE_WELL) {
+        const double q = x * x - 1.0;
+        return q * q;
+    }
+    return x * x;
+}
+
+// One mc_step! (metropolis.jl:176-190) on the particle_1d model, in the reference's
+// operation order:
+//   sample_action!        particle_1d.jl:56-59   delta = 0 + sigma*z
+//   log_proposal_density  particle_1d.jl:52-54   logq = -(d*d)/(2 s^2) - log(2pi s^2)/2
+//   perform_action!       particle_1d.jl:30-35   e1 = e; x += delta; e2 = potential(x)
+//   delta_log_target      metropolis.jl:74 + particle_1d.jl:20-22   (-e2*b) - (-e1*b)
+//   invert_action!        particle_1d.jl:37-40   logq_b == logq_f bit for bit
+//   alpha = min(1, exp(dlogp + logq_b - logq_f)); accept iff alpha > u  (strict)
+//   reject: perform_action_cached! re-applies the negated action: x = (x+d) + (-d)
+template <int POT>
+__device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double logc,
+                                        double z, double u)
+{
+    const double delta = 0.0 + sigma * z;
+    const double logq = (-(delta * delta)) / den - logc;
+    const double e1 = potential<POT>(x);
+    const double xn = x + delta;
+    const double e2 = potential<POT>(xn);
+    const double dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const double arg = (dlogp + logq) - logq;
+    const double alpha = julia_min(1.0, exp_f64(arg));
+    const bool accept = alpha > u;
+    const double xr = xn + (-delta);
+    x = accept ? xn : xr;
+    return accept;
+}
+
+struct SweepArgs {
+    double* x;
+    const double* beta_arr;       // nullptr unless per-chain beta
+    uint32_t* acc;                // [K][m_stride] or nullptr
+    uint32_t* tot;                // [K][m_stride] or nullptr (K > 1 only)
+    const double* ptab;           // [PT_ROWS][AMC_MAX_MOVES]
+    unsigned long long* acc_total;  // pool-wide accepted count (K == 1)
+    int64_t n_chains;             // local chains
+    int64_t m_stride;             // padded length of per-chain arrays
+    uint64_t pair0;               // global pair id of local pair 0 (= chain_offset / 2)
+    uint64_t t0;                  // step index of the first MH step of this launch
+    int32_t n_steps;              // MH steps fused in this launch
+    int32_t n_moves;
+    uint32_t key0, key1;
+    double beta;
+};
+
+// K1: the sweep.  make_step!(::Metropolis) metropolis.jl:302-309 -> mc_sweep! :203-212.
+// MULTI: K > 1 (categorical move pick, parameter table staged in LDS, per-chain counters)
+// COUNT: keep per-chain accepted counter (K == 1)      BETA: per-chain beta array
+template <int POT, bool MULTI, bool COUNT, bool BETA>
+__global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
+{
+    __shared__ double s_tab[MULTI ? 4 * AMC_MAX_MOVES : 1];
+    const int K = a.n_moves;
+    if (MULTI) {
+        for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {
+            s_tab[0 * AMC_MAX_MOVES + i] = a.ptab[PT_SIGMA * AMC_MAX_MOVES + i];
+            s_tab[1 * AMC_MAX_MOVES + i] = a.ptab[PT_DEN * AMC_MAX_MOVES + i];
+            s_tab[2 * AMC_MAX_MOVES + i] = a.ptab[PT_LOGC * AMC_MAX_MOVES + i];
+            s_tab[3 * AMC_MAX_MOVES + i] = a.ptab[PT_CUM * AMC_MAX_MOVES + i];
+        }
+        __syncthreads();
+    }
+    // K == 1: wave-uniform scalars (s_load)
+    const double sigma1 = a.ptab[PT_SIGMA * AMC_MAX_MOVES];
+    const double den1 = a.ptab[PT_DEN * AMC_MAX_MOVES];
+    const double logc1 = a.ptab[PT_LOGC * AMC_MAX_MOVES];
+
+    const int64_t n_pairs = (a.n_chains + 1) >> 1;
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
+    unsigned long long wave_acc = 0;   // wave-uniform
+
+    // wave-uniform trip count: every lane of a wave runs the same iterations (ballot below)
+    for (int64_t base = first; base < n_pairs; base += stride) {
+        const int64_t p = base + threadIdx.x;
+        const bool v0 = p < n_pairs;
+        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+        const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
+        double2 xv = *reinterpret_cast<const double2*>(a.x + 2 * pc);
+        double b0 = a.beta, b1 = a.beta;
+        if (BETA) {
+            const double2 bv = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pc);
+            b0 = bv.x; b1 = bv.y;
+        }
+        const uint64_t pair = a.pair0 + (uint64_t)pc;
+        uint32_t cnt0 = 0, cnt1 = 0;
+
+        for (int s = 0; s < a.n_steps; ++s) {
+            const uint64_t t = a.t0 + (uint64_t)s;
+            double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
+            int k0 = 0, k1 = 0;
+            if (MULTI) {
+                // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
+                // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
+                const u32x4 pk = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS),
+                                               a.key0, a.key1);
+                const double r0 = uniform32(pk.x), r1 = uniform32(pk.y);
+                for (int i = 0; i < K - 1; ++i) {
+                    const double c = s_tab[3 * AMC_MAX_MOVES + i];
+                    k0 += (c <= r0) ? 1 : 0;
+                    k1 += (c <= r1) ? 1 : 0;
+                }
+                sg0 = s_tab[k0]; dn0 = s_tab[AMC_MAX_MOVES + k0]; lc0 = s_tab[2 * AMC_MAX_MOVES + k0];
+                sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
+            }
+            double z0, z1;
+            box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1),
+                       z0, z1);
+            const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS),
+                                           a.key0, a.key1);
+            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, lc0, z0, uniform53(pu.x, pu.y));
+            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, lc1, z1, uniform53(pu.z, pu.w));
+            if (MULTI) {
+                // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
+                if (v0) {
+                    a.acc[(int64_t)k0 * a.m_stride + 2 * p] += a0 ? 1u : 0u;
+                    a.tot[(int64_t)k0 * a.m_stride + 2 * p] += 1u;
+                }
+                if (v1) {
+                    a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] += a1 ? 1u : 0u;
+                    a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] += 1u;
+                }
+            } else {
+                // wavefront-ballot accept mask -> one scalar popcount per chain slot
+                wave_acc += __popcll(__ballot(a0 && v0)) + __popcll(__ballot(a1 && v1));
+                if (COUNT) { cnt0 += a0 ? 1u : 0u; cnt1 += a1 ? 1u : 0u; }
+            }
+        }
+        if (v1) {
+            *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
+        } else if (v0) {
+            a.x[2 * p] = xv.x;
+        }
+        if (!MULTI && COUNT) {
+            if (v1) {
+                uint2* q = reinterpret_cast<uint2*>(a.acc + 2 * p);
+                uint2 c = *q;
+                c.x += cnt0; c.y += cnt1;
+                *q = c;
+            } else if (v0) {
+                a.acc[2 * p] += cnt0;
+            }
+        }
+    }
+    if (!MULTI) {
+        if ((threadIdx.x & 63) == 0 && wave_acc != 0) atomicAdd(a.acc_total, wave_acc);
+    }
+}
+
+// K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
+__global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int64_t n_chains, uint64_t pair0,
+                                                                  uint32_t key0, uint32_t key1, double lo,
+                                                                  double hi)
+{
+    const int64_t n_pairs = (n_chains + 1) >> 1;
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
+        const u32x4 v = philox4x32_10(draw_counter(pair0 + (uint64_t)p, 0, 0, STREAM_INIT), key0, key1);
+        const double x0 = lo + (hi - lo) * uniform53(v.x, v.y);
+        const double x1 = lo + (hi - lo) * uniform53(v.z, v.w);
+        x[2 * p] = x0;
+        if (2 * p + 1 < n_chains) x[2 * p + 1] = x1;
+    }
+}
+
+// Derived per-move parameters, computed ON DEVICE so the arithmetic is the kernel's.
+// den = 2*(s*s); logc = log(2pi*(s*s))/2 (particle_1d.jl:53); cum = running sum of
+// weights in the order Distributions.jl accumulates them; dden, dlhalf: d/dsigma
+// pieces of gradients.jl:28-33 (see oracle amo_grad_log_proposal_density).
+__global__ void prepare_params_kernel(double* ptab, int n_moves)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double cp = 0.0;
+    for (int k = 0; k < n_moves; ++k) {
+        const double sigma = ptab[PT_SIGMA * AMC_MAX_MOVES + k];
+        const double s2 = sigma * sigma;
+        const double ds2 = sigma + sigma;
+        ptab[PT_DEN * AMC_MAX_MOVES + k] = 2.0 * s2;
+        ptab[PT_DDEN * AMC_MAX_MOVES + k] = 2.0 * ds2;
+        const double av = TWO_PI * s2;
+        ptab[PT_LOGC * AMC_MAX_MOVES + k] = log_f64(av) / 2.0;
+        ptab[PT_DLHALF * AMC_MAX_MOVES + k] = ((TWO_PI * ds2) / av) / 2.0;
+        const double w = ptab[PT_WEIGHT * AMC_MAX_MOVES + k];
+        cp = (k == 0) ? w : cp + w;
+        ptab[PT_CUM * AMC_MAX_MOVES + k] = cp;
+    }
+}
+
+// ---- deterministic block reduction helpers -------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sums NV per-thread values over the block; thread 0 writes them to out[0..NV).
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
+{
+    __shared__ double s_part[NV][AMC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double w = wave_sum(v[i]);
+        if (lane == 0) s_part[i][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = s_part[i][0];
+            for (int w = 1; w < AMC_BLOCK / 64; ++w) t += s_part[i][w];
+            out[i] = t;
+        }
+    }
+    __syncthreads();
+}
+
+// K2a: callback reductions, pass 1.  partials[block][4 + K]:
+//   sum e (callback_energy particle_1d.jl:68-70), sum x, sum x^2 (distribution_test.jl:36-37),
+//   count, and per move sum_c accepted/total (callback_acceptance metropolis.jl:319-321).
+// ratio_mode: 0 = none (K == 1 without per-chain counters; host uses the pool-wide total),
+//             1 = K == 1 with per-chain acc (total = t_steps for every chain), 2 = K > 1.
+template <int POT>
+__global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, const uint32_t* acc,
+                                                            const uint32_t* tot, int64_t n_chains,
+                                                            int64_t m_stride, int n_moves, int ratio_mode,
+                                                            uint64_t t_steps, double* partials)
+{
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+        const double xc = x[c];
+        v[0] += potential<POT>(xc);
+        v[1] += xc;
+        v[2] += xc * xc;
+        v[3] += 1.0;
+    }
+    double* out = partials + (int64_t)blockIdx.x * (4 + n_moves);
+    block_sum_store<4>(v, out);
+    if (ratio_mode != 0) {
+        for (int k = 0; k < n_moves; ++k) {
+            double r[1] = {0.0};
+            for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+                const double a = (double)acc[(int64_t)k * m_stride + c];
+                const double n = (ratio_mode == 2) ? (double)tot[(int64_t)k * m_stride + c] : (double)t_steps;
+                r[0] += a / n;    // Int/Int -> Float64 division; 0/0 = NaN like the reference
+            }
+            block_sum_store<1>(r, out + 4 + k);
+        }
+    } else if (threadIdx.x == 0) {
+        for (int k = 0; k < n_moves; ++k) out[4 + k] = 0.0;
+    }
+}
+
+// K2b: pass 2, one block: fixed-order sum of the per-block partials.
+__global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_blocks, int n_vals,
+                                                                  double* out)
+{
+    for (int q = 0; q < n_vals; ++q) {
+        double v[1] = {0.0};
+        for (int b = threadIdx.x; b < n_blocks; b += AMC_BLOCK) v[0] += partials[(int64_t)b * n_vals + q];
+        block_sum_store<1>(v, out + q);
+    }
+}
+
+// Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].
+__global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_t* acc, const uint32_t* tot,
+                                                                    int64_t n_chains, int64_t m_stride,
+                                                                    int n_moves, unsigned long long* out_acc,
+                                                                    unsigned long long* out_tot)
+{
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int k = 0; k < n_moves; ++k) {
+        unsigned long long sa = 0, st = 0;
+        for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+            sa += acc[(int64_t)k * m_stride + c];
+            if (tot) st += tot[(int64_t)k * m_stride + c];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sa += __shfl_down(sa, off, 64);
+            st += __shfl_down(st, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (sa) atomicAdd(out_acc + k, sa);
+            if (st) atomicAdd(out_tot + k, st);
+        }
+    }
+}
+
+struct PgArgs {
+    double* x;
+    const double* beta_arr;
+    const double* ptab;
+    double* partials;             // [grid][NL][4]
+    int64_t n_chains;
+    uint64_t pair0;
+    uint64_t t_est;               // estimator call index
+    int32_t q_batch;
+    int32_t n_learn;
+    int32_t learn_ids[AMC_MAX_LEARN];
+    uint32_t key0, key1;
+    double beta;
+};
+
+// One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
+// Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
+template <int POT>
+__device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, double den, double logc,
+                                          double dden, double dlhalf, double z, double (&g)[4])
+{
+    const double delta = 0.0 + sigma * z;
+    const double q1 = (-(delta * delta)) / den;
+    const double logq = q1 - logc;
+    const double dlogq = -(q1 / den) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
+    const double e1 = potential<POT>(x);
+    const double xn = x + delta;
+    const double e2 = potential<POT>(xn);
+    const double dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const double r = delta * delta;                        // reward, particle_1d.jl:42-44
+    x = xn + (-delta);
+    const double alpha = julia_min(1.0, exp_f64((dlogp + logq) - logq));
+    const double j = r * alpha;
+    g[0] += j;
+    g[1] += j * dlogq;            // forward and backward gradients are bit-identical here
+    g[2] += dlogq;
+    g[3] += dlogq * dlogq;
+}
+
+// K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
+template <int POT, int NL, bool BETA>
+__global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
+{
+    const int64_t n_pairs = (a.n_chains + 1) >> 1;
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    double g[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[l][i] = 0.0;
+
+    for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
+        const bool v1 = 2 * p + 1 < a.n_chains;
+        double2 xv = *reinterpret_cast<const double2*>(a.x + 2 * p);
+        double b0 = a.beta, b1 = a.beta;
+        if (BETA) {
+            const double2 bv = *reinterpret_cast<const double2*>(a.beta_arr + 2 * p);
+            b0 = bv.x; b1 = bv.y;
+        }
+        const uint64_t pair = a.pair0 + (uint64_t)p;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l < a.n_learn) {
+                const int lid = a.learn_ids[l];
+                const double sigma = a.ptab[PT_SIGMA * AMC_MAX_MOVES + lid];
+                const double den = a.ptab[PT_DEN * AMC_MAX_MOVES + lid];
+                const double logc = a.ptab[PT_LOGC * AMC_MAX_MOVES + lid];
+                const double dden = a.ptab[PT_DDEN * AMC_MAX_MOVES + lid];
+                const double dlhalf = a.ptab[PT_DLHALF * AMC_MAX_MOVES + lid];
+                for (int q = 0; q < a.q_batch; ++q) {
+                    double z0, z1;
+                    box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
+                                                          STREAM_ESTIMATOR),
+                                             a.key0, a.key1),
+                               z0, z1);
+                    pg_sample<POT>(xv.x, b0, sigma, den, logc, dden, dlhalf, z0, g[l]);
+                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, logc, dden, dlhalf, z1, g[l]);
+                }
+            }
+        }
+        if (v1) {
+            *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
+        } else {
+            a.x[2 * p] = xv.x;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (l < a.n_learn) block_sum_store<4>(g[l], a.partials + ((int64_t)blockIdx.x * NL + l) * 4);
+    }
+}
+
+// Parity-test hooks (amc_selftest_*): the arithmetic-spec primitives, one value per thread.
+__global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = a[i];
+    double s, c, r = 0.0;
+    switch (fn) {
+    case 0: r = exp_f64(v); break;
+    case 1: r = log_f64(v); break;
+    case 2: sincospi_f64(v, s, c); r = s; break;
+    case 3: sincospi_f64(v, s, c); r = c; break;
+    case 4: r = __builtin_sqrt(v); break;
+    case 5: r = v / b[i]; break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+__global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,
+                                       uint32_t draw, uint32_t stream, uint32_t* out4, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 v = philox4x32_10(draw_counter(pair[i], t[i], draw, stream), key0, key1);
+    out4[4 * i + 0] = v.x; out4[4 * i + 1] = v.y; out4[4 * i + 2] = v.z; out4[4 * i + 3] = v.w;
+}
+
+}  // namespace amc

@@ -1,0 +1,665 @@
+/*
+ * amc_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See amc_oracle.h for scope, parity status and who may load this.
+ *
+ * Reference-shaped data model on purpose (array of Particle structs, one pool
+ * of Move records per chain, parameters shared by all chains), arithmetic in
+ * the reference's operation order.  Citations are relative to /root/reference.
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off -mfma -fopenmp).
+ * -ffp-contract=off matters: every fused multiply-add below is an explicit
+ * fma() and nothing else may be contracted, or host and device diverge.
+ */
+#include "amc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Third-party piece 1: Philox4x32-10 (Random123; Salmon et al., SC'11).     */
+/* The reference's RNG is Julia stdlib Xoshiro via the R= hook               */
+/* (src/metropolis.jl:245,263); replaced by this counter-based generator,    */
+/* bit-compatible with rocRAND's philox4x32_10 engine                        */
+/* (/opt/rocm/include/rocrand/rocrand_philox4x32_10.h:270-303).              */
+/* ------------------------------------------------------------------------ */
+void amo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        uint64_t m0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)m1;
+        uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)m0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Draw schedule: the 128-bit counter names ONE draw of ONE
+ * chain pair: x = step[31:0]; y = step[47:32] | draw<<16 | stream<<28;
+ * (z,w) = global pair id (= rocRAND "subsequence").  Replaces the per-chain
+ * sequential generators rngs[c] = R(seed + c - 1), metropolis.jl:262-263. */
+void amo_counter(uint64_t pair, uint64_t t, uint32_t draw, uint32_t stream, uint32_t ctr[4])
+{
+    ctr[0] = (uint32_t)t;
+    ctr[1] = ((uint32_t)(t >> 32) & 0xFFFFu) | ((draw & 0xFFFu) << 16) | ((stream & 0xFu) << 28);
+    ctr[2] = (uint32_t)pair;
+    ctr[3] = (uint32_t)(pair >> 32);
+}
+
+static void draw4(const amo_sim *s, uint64_t pair, uint64_t t, uint32_t draw,
+                  uint32_t stream, uint32_t out[4]);
+
+/* rand(rng)::Float64 in [0,1) (metropolis.jl:184): 53 random bits * 2^-53.
+ * Same bit packing as rocRAND's uniform_distribution_double(v1, v2)
+ * (rocrand_uniform.h:102-109) without its +2^-53 shift, so 0 is included and
+ * 1 excluded like Julia's rand(). */
+double amo_uniform53(uint32_t lo, uint32_t hi)
+{
+    uint64_t v = (uint64_t)lo | ((uint64_t)(hi >> 11) << 32);
+    return (double)v * 0x1.0p-53;
+}
+
+/* 32-bit uniform in [0,1) for the categorical move pick. */
+double amo_uniform32(uint32_t v)
+{
+    return (double)v * 0x1.0p-32;
+}
+
+/* ------------------------------------------------------------------------ */
+/* exp / log / sincospi: own implementations so host and device agree bit    */
+/* for bit (libm and the GPU's ocml differ in the last ulp).  Constants from  */
+/* tools/gen_math_constants.py.  Accuracy ~1 ulp; NOT correctly rounded, so   */
+/* vs Julia's exp/log an accept decision can flip with probability ~1e-16.   */
+/* ------------------------------------------------------------------------ */
+static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+double amo_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return INFINITY;       /* documented domain cut (true overflow at 709.78) */
+    if (x < -708.0) return 0.0;           /* flush: no subnormal results */
+    const double LOG2E = 0x1.71547652b82fep+0;
+    const double LN2_HI = 0x1.62e42fee00000p-1;
+    const double LN2_LO = 0x1.a39ef35793c76p-33;
+    const double SHIFT = 0x1.8p52;
+    double t = x * LOG2E + SHIFT;         /* round-to-nearest-even integer in the low bits */
+    double kd = t - SHIFT;
+    int64_t ki = (int64_t)(int32_t)(uint32_t)d2u(t);
+    double r = fma(-kd, LN2_HI, x);
+    r = fma(-kd, LN2_LO, r);
+    double p = 0x1.6124613a86d09p-33;     /* 1/13! */
+    p = fma(p, r, 0x1.1eed8eff8d898p-29);
+    p = fma(p, r, 0x1.ae64567f544e4p-26);
+    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, r, 0x1.71de3a556c734p-19);
+    p = fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma(p, r, 0x1.1111111111111p-7);
+    p = fma(p, r, 0x1.5555555555555p-5);
+    p = fma(p, r, 0x1.5555555555555p-3);
+    p = fma(p, r, 0x1.0000000000000p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return u2d(d2u(p) + ((uint64_t)ki << 52));   /* p * 2^k, p in [0.7,1.42], result normal */
+}
+
+/* log(x): argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), then the
+ * classic s = f/(2+f) series with the 7-term minimax polynomial published in
+ * FreeBSD/fdlibm e_log.c (Lg1..Lg7), always taking its "hfsq" form. */
+double amo_log(double x)
+{
+    if (x != x || x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    const double LN2_HI = 0x1.62e42fee00000p-1;
+    const double LN2_LO = 0x1.a39ef35793c76p-33;
+    int64_t k = 0;
+    uint64_t ux = d2u(x);
+    if (ux < 0x0010000000000000ull) {     /* subnormal: scale by 2^54 */
+        x = x * 0x1.0p54;
+        ux = d2u(x);
+        k = -54;
+    }
+    uint32_t hx = (uint32_t)(ux >> 32);
+    k += (int64_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;     /* 1 if m >= sqrt(2): halve it */
+    k += (int64_t)(i >> 20);
+    uint64_t um = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+    double f = u2d(um) - 1.0;
+    double s = f / (2.0 + f);
+    double dk = (double)k;
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * fma(w, fma(w, 0x1.39a09d078c69fp-3, 0x1.c71c51d8e78afp-3), 0x1.999999997fa04p-2);
+    double t2 = z * fma(w, fma(w, fma(w, 0x1.2f112df3e5244p-3, 0x1.7466496cb03dep-3),
+                                 0x1.2492494229359p-2), 0x1.5555555555593p-1);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    return dk * LN2_HI - ((hfsq - fma(s, hfsq + R, dk * LN2_LO)) - f);
+}
+
+/* sincospi(w) for the Box-Muller angle; any finite |w| < 2^31 is handled. */
+void amo_sincospi(double w, double *sp, double *cp)
+{
+    const double SHIFT = 0x1.8p52;
+    double t = (w + w) + SHIFT;           /* n = rint(2w) */
+    double nd = t - SHIFT;
+    uint32_t n = (uint32_t)d2u(t);
+    double r = w - 0.5 * nd;              /* exact, |r| <= 1/4 */
+    double z = r * r;
+    double ps = -0x1.6fadb9f155744p-16;
+    ps = fma(ps, z, 0x1.e8f434d018d63p-12);
+    ps = fma(ps, z, -0x1.e3074fde8871fp-8);
+    ps = fma(ps, z, 0x1.50783487ee782p-4);
+    ps = fma(ps, z, -0x1.32d2cce62bd86p-1);
+    ps = fma(ps, z, 0x1.466bc6775aae2p+1);
+    ps = fma(ps, z, -0x1.4abbce625be53p+2);
+    double s = fma(r, 0x1.1a62633145c07p-53, (r * z) * ps);
+    s = fma(r, 0x1.921fb54442d18p+1, s);
+    double pc = 0x1.20c62c2f2d7f5p-18;
+    pc = fma(pc, z, -0x1.b6e24f44b128fp-14);
+    pc = fma(pc, z, 0x1.f9d38a3763cc3p-10);
+    pc = fma(pc, z, -0x1.a6d1f2a204a8cp-6);
+    pc = fma(pc, z, 0x1.e1f506891babbp-3);
+    pc = fma(pc, z, -0x1.55d3c7e3cbffap+0);
+    pc = fma(pc, z, 0x1.03c1f081b5ac4p+2);
+    pc = fma(pc, z, -0x1.3bd3cc9be45dep+2);
+    double c = fma(pc, z, 1.0);
+    switch (n & 3u) {
+    case 0: *sp = s;  *cp = c;  break;
+    case 1: *sp = c;  *cp = -s; break;
+    case 2: *sp = -s; *cp = -c; break;
+    default: *sp = -c; *cp = s; break;
+    }
+}
+
+/* Third-party piece 2: randn.  The reference draws rand(rng, Normal(0, sigma))
+ * (particle_1d.jl:57), i.e. Distributions.jl 0.25 `mu + sigma * randn(rng)`.
+ * Julia's ziggurat is replaced by rocRAND's Box-Muller map
+ * box_muller_double(uint4) (rocrand_normal.h:78-98): u in (0,1], w in (0,2],
+ * z = sqrt(-2 log u) * (sinpi w, cospi w).  One call serves a chain PAIR. */
+void amo_box_muller(const uint32_t v[4], double z[2])
+{
+    uint64_t v1 = (uint64_t)v[0] ^ ((uint64_t)v[1] << 21);
+    double u = 0x1.0p-53 + (double)v1 * 0x1.0p-53;
+    uint64_t v2 = (uint64_t)v[2] ^ ((uint64_t)v[3] << 21);
+    double w = 0x1.0p-52 + (double)v2 * 0x1.0p-52;
+    double s = sqrt(-2.0 * amo_log(u));
+    double sn, cs;
+    amo_sincospi(w, &sn, &cs);
+    z[0] = sn * s;
+    z[1] = cs * s;
+}
+
+/* ------------------------------------------------------------------------ */
+/* L0 model: example/particle_1d/particle_1d.jl                              */
+/* ------------------------------------------------------------------------ */
+
+/* potential(x): free function defined by the driver script,
+ * harmonic_oscillator/MC_harmonic_oscillator.jl:4  potential(x) = x^2 (== x*x).
+ * The double well (x^2-1)^2 is BASELINE config 3's, not in the reference. */
+double amo_potential(int pot, double x)
+{
+    if (pot == AMO_POT_DOUBLE_WELL) {
+        double q = x * x - 1.0;
+        return q * q;
+    }
+    return x * x;
+}
+
+/* particle_1d.jl:9-16: mutable struct Particle (x, beta, e), e = potential(x). */
+typedef struct { double x, beta, e; } particle_t;
+
+/* particle_1d.jl:26-28 Displacement(delta) + metropolis.jl:140-147 Move's
+ * per-chain mutable part.  policy/parameters/weight are aliased across chains
+ * (metropolis.jl:252-260) and live once in amo_sim. */
+typedef struct { double delta; int64_t total_calls, accepted_calls; } move_t;
+
+struct amo_sim {
+    int64_t M, offset;
+    int pot, K, sweepstep;
+    double *sigma, *weight;   /* shared parameters / weights, length K */
+    particle_t *chains;       /* Vector{Particle} */
+    move_t *pools;            /* pools[c*K + k] */
+    uint64_t seed;
+    uint64_t t;               /* MH steps done so far per chain */
+    uint64_t t_est;           /* estimator make_step! calls so far */
+};
+
+/* particle_1d.jl:20-22: unnormalised_log_target_density(state) = -state[1]*state[2] */
+static inline double unnormalised_log_target_density(double e, double beta)
+{
+    return (-e) * beta;
+}
+
+/* metropolis.jl:74 (generic fallback): logp(x2) - logp(x1) */
+static inline double delta_log_target_density(double e1, double b1, double e2, double b2)
+{
+    return unnormalised_log_target_density(e2, b2) - unnormalised_log_target_density(e1, b1);
+}
+
+/* particle_1d.jl:52-54:  -(d)^2 / (2s^2) - log(2pi * s^2) / 2   (2pi = 2*Float64(pi)) */
+double amo_log_proposal_density(double delta, double sigma)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double s2 = sigma * sigma;
+    return (-(delta * delta)) / (2.0 * s2) - amo_log(TWO_PI * s2) / 2.0;
+}
+
+/* gradients.jl:28-33 withgrad_log_proposal_density!: d/dsigma of the above.
+ * ForwardDiff 0.10's dual-number rules restated by hand (sigma^2 -> (s2, s+s);
+ * c/Dual -> -(v/den)*dden; log -> da/a).  The reference pins only the VALUE
+ * (-5.0 at delta=0, sigma=0.2, atol 1e-10: test/ad_backends_test.jl:31-32). */
+double amo_grad_log_proposal_density(double delta, double sigma)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double s2 = sigma * sigma, ds2 = sigma + sigma;
+    double den = 2.0 * s2, dden = 2.0 * ds2;
+    double q1 = (-(delta * delta)) / den;
+    double dq1 = -(q1 / den) * dden;
+    double a = TWO_PI * s2, da = TWO_PI * ds2;
+    double dl = da / a;
+    return dq1 - dl / 2.0;
+}
+
+/* particle_1d.jl:30-35 perform_action!: e1 = e; x += delta; e = potential(x). */
+static inline void perform_action(particle_t *p, const move_t *m, int pot, double *e1, double *e2)
+{
+    *e1 = p->e;
+    p->x += m->delta;
+    p->e = amo_potential(pot, p->x);
+    *e2 = p->e;
+}
+
+/* Julia's min(a, b): NaN if either is NaN (C fmin would return the non-NaN). */
+static inline double julia_min(double a, double b)
+{
+    if (a != a) return a;
+    if (b != b) return b;
+    return b < a ? b : a;
+}
+
+/* metropolis.jl:176-190 mc_step!, with sample_action! (particle_1d.jl:56-59)
+ * fed an explicit standard normal z and the accept uniform u. */
+static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
+{
+    m->delta = 0.0 + sigma * z;                                    /* :177 -> particle_1d.jl:57 */
+    double logq_forward = amo_log_proposal_density(m->delta, sigma);   /* :178 */
+    double e1, e2;
+    perform_action(p, m, pot, &e1, &e2);                           /* :179 */
+    double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :180 */
+    m->delta = -m->delta;                                          /* :181 invert_action! */
+    double logq_backward = amo_log_proposal_density(m->delta, sigma);  /* :182 */
+    double alpha = julia_min(1.0, amo_exp(dlogp + logq_backward - logq_forward)); /* :183 */
+    if (alpha > u)                                                 /* :184 */
+        return 1;
+    perform_action(p, m, pot, &e1, &e2);   /* :187 perform_action_cached! -> :90 perform_action! */
+    return 0;
+}
+
+int amo_mc_step_explicit(int pot, double beta, double sigma, double z, double u,
+                         double *x, double *e)
+{
+    particle_t p = { *x, beta, *e };
+    move_t m = { 0.0, 0, 0 };
+    int a = mc_step(&p, &m, sigma, pot, z, u);
+    *x = p.x; *e = p.e;
+    return a;
+}
+
+/* Third-party piece 3: rand(rng, Categorical(weights)) at metropolis.jl:206 is
+ * Distributions.jl 0.25's DiscreteNonParametric sampler: one uniform `draw`,
+ * cp = p[1]; i = 1; while cp <= draw && i < n: cp += p[i += 1].  0-based here. */
+int amo_categorical(const double *weights, int K, double r)
+{
+    double cp = weights[0];
+    int i = 0;
+    while (cp <= r && i < K - 1) {
+        i += 1;
+        cp += weights[i];
+    }
+    return i;
+}
+
+static void draw4(const amo_sim *s, uint64_t pair, uint64_t t, uint32_t draw,
+                  uint32_t stream, uint32_t out[4])
+{
+    uint32_t ctr[4], key[2] = { (uint32_t)s->seed, (uint32_t)(s->seed >> 32) };
+    amo_counter(pair, t, draw, stream, ctr);
+    amo_philox4x32_10(ctr, key, out);
+}
+
+/* metropolis.jl:203-212 mc_sweep! for chain c (global id g), steps [t0, t0+mc_steps). */
+static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
+{
+    uint64_t g = (uint64_t)(s->offset + c);
+    uint64_t pair = g >> 1;
+    int half = (int)(g & 1u);
+    particle_t *p = &s->chains[c];
+    move_t *pool = &s->pools[c * s->K];
+    const double *weights = s->weight;                             /* :204 */
+    for (int i = 0; i < mc_steps; ++i) {                           /* :205 */
+        uint64_t t = t0 + (uint64_t)i;
+        uint32_t v[4];
+        int id = 0;
+        if (s->K > 1) {                                            /* :206 */
+            draw4(s, pair, t, AMO_DRAW_CATEGORICAL, AMO_STREAM_METROPOLIS, v);
+            id = amo_categorical(weights, s->K, amo_uniform32(v[half]));
+        }
+        double zz[2];
+        draw4(s, pair, t, AMO_DRAW_NORMAL, AMO_STREAM_METROPOLIS, v);
+        amo_box_muller(v, zz);
+        draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, v);
+        double u = amo_uniform53(v[2 * half], v[2 * half + 1]);
+        move_t *move = &pool[id];                                  /* :207 */
+        move->accepted_calls += mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
+        move->total_calls += 1;                                    /* :209 */
+    }
+}
+
+amo_sim *amo_create(int64_t n_chains, int64_t chain_offset, int potential, double beta,
+                    int n_moves, const double *sigma, const double *weight,
+                    uint64_t seed, int sweepstep)
+{
+    if (n_chains < 0 || n_moves < 1 || sweepstep < 1) return NULL;
+    amo_sim *s = (amo_sim *)calloc(1, sizeof(*s));
+    s->M = n_chains; s->offset = chain_offset; s->pot = potential; s->K = n_moves;
+    s->sweepstep = sweepstep; s->seed = seed;
+    s->sigma = (double *)malloc(sizeof(double) * (size_t)n_moves);
+    s->weight = (double *)malloc(sizeof(double) * (size_t)n_moves);
+    memcpy(s->sigma, sigma, sizeof(double) * (size_t)n_moves);
+    memcpy(s->weight, weight, sizeof(double) * (size_t)n_moves);
+    s->chains = (particle_t *)calloc((size_t)(n_chains > 0 ? n_chains : 1), sizeof(particle_t));
+    s->pools = (move_t *)calloc((size_t)(n_chains > 0 ? n_chains : 1) * (size_t)n_moves, sizeof(move_t));
+    for (int64_t c = 0; c < n_chains; ++c) {
+        s->chains[c].x = 0.0;
+        s->chains[c].beta = beta;
+        s->chains[c].e = amo_potential(potential, 0.0);
+    }
+    return s;
+}
+
+void amo_destroy(amo_sim *s)
+{
+    if (!s) return;
+    free(s->sigma); free(s->weight); free(s->chains); free(s->pools); free(s);
+}
+
+/* particle_1d.jl:13-15: Particle(x, beta) sets e = potential(x). */
+void amo_set_x(amo_sim *s, const double *x)
+{
+    for (int64_t c = 0; c < s->M; ++c) {
+        s->chains[c].x = x[c];
+        s->chains[c].e = amo_potential(s->pot, x[c]);
+    }
+}
+
+void amo_set_beta(amo_sim *s, const double *beta)
+{
+    for (int64_t c = 0; c < s->M; ++c) s->chains[c].beta = beta[c];
+}
+
+/* MC_harmonic_oscillator.jl:13  chains = [System(4rand(rng) - 2, beta) ...],
+ * generalised to lo + (hi-lo)*u, u from the INIT stream of the chain's pair. */
+void amo_init_uniform(amo_sim *s, double lo, double hi)
+{
+    for (int64_t c = 0; c < s->M; ++c) {
+        uint64_t g = (uint64_t)(s->offset + c);
+        int half = (int)(g & 1u);
+        uint32_t v[4];
+        draw4(s, g >> 1, 0, 0, AMO_STREAM_INIT, v);
+        double u = amo_uniform53(v[2 * half], v[2 * half + 1]);
+        double x = lo + (hi - lo) * u;
+        s->chains[c].x = x;
+        s->chains[c].e = amo_potential(s->pot, x);
+    }
+}
+
+void amo_get_state(const amo_sim *s, double *x, double *e)
+{
+    for (int64_t c = 0; c < s->M; ++c) {
+        if (x) x[c] = s->chains[c].x;
+        if (e) e[c] = s->chains[c].e;
+    }
+}
+
+void amo_get_counters(const amo_sim *s, int64_t *accepted, int64_t *total)
+{
+    for (int k = 0; k < s->K; ++k)
+        for (int64_t c = 0; c < s->M; ++c) {
+            if (accepted) accepted[k * s->M + c] = s->pools[c * s->K + k].accepted_calls;
+            if (total) total[k * s->M + c] = s->pools[c * s->K + k].total_calls;
+        }
+}
+
+void amo_set_sigma(amo_sim *s, int k, double sigma) { s->sigma[k] = sigma; }
+double amo_get_sigma(const amo_sim *s, int k) { return s->sigma[k]; }
+uint64_t amo_get_step(const amo_sim *s) { return s->t; }
+void amo_set_step(amo_sim *s, uint64_t t) { s->t = t; }
+
+int amo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* metropolis.jl:302-309 make_step!(simulation, ::Metropolis): map mc_sweep! over
+ * chains; n_threads = 1 is `collect` (parallel=false), > 1 is tcollect (:265). */
+void amo_make_step(amo_sim *s, int n_threads)
+{
+    uint64_t t0 = s->t;
+    int steps = s->sweepstep;
+    if (n_threads <= 1) {
+        for (int64_t c = 0; c < s->M; ++c) mc_sweep(s, c, t0, steps);
+    } else {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+#endif
+        for (int64_t c = 0; c < s->M; ++c) mc_sweep(s, c, t0, steps);
+    }
+    s->t = t0 + (uint64_t)steps;
+}
+
+void amo_make_steps(amo_sim *s, int64_t n, int n_threads)
+{
+    for (int64_t i = 0; i < n; ++i) amo_make_step(s, n_threads);
+}
+
+/* particle_1d.jl:68-70 callback_energy: mean(system.e for system in chains),
+ * a left-to-right sum divided by M. */
+double amo_callback_energy(const amo_sim *s)
+{
+    double acc = 0.0;
+    for (int64_t c = 0; c < s->M; ++c) acc += s->chains[c].e;
+    return acc / (double)s->M;
+}
+
+/* metropolis.jl:319-321 callback_acceptance: mean over chains of the per-chain
+ * vector [accepted_calls / total_calls for move in pool]; 0/0 -> NaN. */
+void amo_callback_acceptance(const amo_sim *s, double *out)
+{
+    for (int k = 0; k < s->K; ++k) {
+        double acc = 0.0;
+        for (int64_t c = 0; c < s->M; ++c) {
+            const move_t *m = &s->pools[c * s->K + k];
+            acc += (double)m->accepted_calls / (double)m->total_calls;
+        }
+        out[k] = acc / (double)s->M;
+    }
+}
+
+/* Statistic of test/distribution_test.jl:33-37 (mean/std of positions). */
+void amo_moments(const amo_sim *s, double out[2])
+{
+    double sx = 0.0, sxx = 0.0;
+    for (int64_t c = 0; c < s->M; ++c) {
+        double x = s->chains[c].x;
+        sx += x;
+        sxx += x * x;
+    }
+    out[0] = sx; out[1] = sxx;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Policy-guided Monte Carlo: src/PolicyGuided/                              */
+/* ------------------------------------------------------------------------ */
+
+/* gradients.jl:93-109 pgmc_estimate after gradients.jl:117-121
+ * sample_gradient_data, P = 1.  gd = (j, dj, dlogq_forward, g). */
+static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
+{
+    m->delta = 0.0 + sigma * z;                                     /* :119 sample_action! */
+    double logq_f = amo_log_proposal_density(m->delta, sigma);     /* :97 */
+    double dlogq_f = amo_grad_log_proposal_density(m->delta, sigma);
+    double e1, e2;
+    perform_action(p, m, pot, &e1, &e2);                            /* :98 */
+    double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :99 */
+    double r = m->delta * m->delta;                                 /* :100 reward, particle_1d.jl:42-44 */
+    m->delta = -m->delta;                                           /* :101 */
+    double logq_b = amo_log_proposal_density(m->delta, sigma);     /* :102 */
+    double dlogq_b = amo_grad_log_proposal_density(m->delta, sigma);
+    perform_action(p, m, pot, &e1, &e2);                            /* :103 always reverts */
+    double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f)); /* :104 */
+    double j = r * alpha;                                           /* :105 */
+    gd[0] = j;
+    gd[1] = j * (alpha == 1.0 ? dlogq_f : dlogq_b);                 /* :106 */
+    gd[2] = dlogq_f;
+    gd[3] = dlogq_f * dlogq_f;                                      /* :107 */
+}
+
+/* estimator.jl:111-134 make_step!(::PolicyGradientEstimator): for each learnable
+ * move, foldxl(+) of GradientData (gradients.jl:68-76) over chains x q_batch
+ * samples.  The caller owns the running accumulators (:130-131).  Draws come
+ * from the ESTIMATOR stream (the reference replays the sampler's seeds,
+ * estimator.jl:91-92,107 -- a quirk that is deliberately not reproduced). */
+void amo_pg_estimate(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *out)
+{
+    uint64_t t = s->t_est;
+    for (int l = 0; l < n_learn; ++l) {
+        int lid = learn_ids[l];
+        double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+        int64_t n = 0;
+        for (int64_t c = 0; c < s->M; ++c) {
+            uint64_t g = (uint64_t)(s->offset + c);
+            int half = (int)(g & 1u);
+            for (int q = 0; q < q_batch; ++q) {
+                uint32_t v[4];
+                double zz[2], gd[4];
+                draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
+                amo_box_muller(v, zz);
+                pgmc_sample(&s->chains[c], &s->pools[c * s->K + lid], s->sigma[lid], s->pot,
+                            zz[half], gd);
+                for (int i = 0; i < 4; ++i) acc[i] += gd[i];
+                n += 1;
+            }
+        }
+        for (int i = 0; i < 4; ++i) out[l * 5 + i] = acc[i];
+        out[l * 5 + 4] = (double)n;
+    }
+    s->t_est = t + 1;
+}
+
+/* learning.jl:32-34,50-52,77-79,103-105,130-134,160-164 learning_step! for P = 1;
+ * gd is the AVERAGED GradientData (gradients.jl:83-85).  inv(g + eps*I) is a
+ * scalar reciprocal here. */
+double amo_learning_step(int opt, double h0, double h1, double theta, const double gd[4])
+{
+    double j = gd[0], dj = gd[1], dlogq = gd[2], g = gd[3];
+    switch (opt) {
+    case AMO_OPT_VPG:                       /* eta = h0 */
+        return theta + h0 * dj;
+    case AMO_OPT_BLPG:
+        return theta + h0 * (dj - j * dlogq);
+    case AMO_OPT_BLAPG: {                   /* delta = h0, eps = h1 */
+        double eta = sqrt(2.0 * h0 / (dj * dj + h1));
+        return theta + eta * (dj - j * dlogq);
+    }
+    case AMO_OPT_NPG: {                     /* eta = h0, eps = h1 */
+        double Finv = 1.0 / (g + h1 * 1.0);
+        return theta + h0 * Finv * dj;
+    }
+    case AMO_OPT_ANPG: {
+        double Finv = 1.0 / (g + h1 * 1.0);
+        double eta = sqrt(2.0 * h0 / (dj * (Finv * dj)));
+        return theta + eta * Finv * dj;
+    }
+    case AMO_OPT_BLANPG: {
+        double Finv = 1.0 / (g + h1 * 1.0);
+        double bj = dj - j * dlogq;
+        double eta = sqrt(2.0 * h0 / (bj * (Finv * bj)));
+        return theta + eta * Finv * bj;
+    }
+    default:                                /* Static: never in learn_ids, estimator.jl:72 */
+        return theta;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* simulation.jl:95-117 build_schedule (three methods)                       */
+/* ------------------------------------------------------------------------ */
+int64_t amo_build_schedule_linear(int64_t steps, int64_t burn, int64_t dt, int64_t *out, int64_t cap)
+{
+    int64_t n = 0, last = -1;
+    for (int64_t t = burn; t <= steps; t += dt) {          /* collect(burn:dt:steps) */
+        if (n < cap) out[n] = t;
+        n++; last = t;
+    }
+    if (last != steps) {                                   /* ∪ [steps] */
+        if (n < cap) out[n] = steps;
+        n++;
+    }
+    return n;
+}
+
+static int64_t push_unique(int64_t *out, int64_t n, int64_t cap, int64_t v)
+{
+    for (int64_t i = (n > 64 ? n - 64 : 0); i < n && i < cap; ++i)
+        if (out[i] == v) return n;          /* duplicates only ever sit next to each other */
+    if (n < cap) out[n] = v;
+    return n + 1;
+}
+
+int64_t amo_build_schedule_block(int64_t steps, int64_t burn, const int64_t *block, int n_block,
+                                 int64_t *out, int64_t cap)
+{
+    int64_t last = block[n_block - 1];
+    int64_t nblock = (steps - burn) / last;                /* :114 */
+    int64_t n = 0;
+    for (int64_t m = 1; m <= nblock; ++m)                  /* :115 */
+        for (int b = 0; b < n_block; ++b) {
+            int64_t v = block[b] + burn + (m - 1) * last;
+            if (v <= steps) n = push_unique(out, n, cap, v);   /* :116 filter + unique */
+        }
+    n = push_unique(out, n, cap, steps);
+    return n;
+}
+
+int64_t amo_build_schedule_log(int64_t steps, int64_t burn, double base, int64_t *out, int64_t cap)
+{
+    int64_t n = 0;
+    n = push_unique(out, n, cap, burn);                    /* :105 */
+    int nmax = (int)floor(log((double)(steps - burn)) / log(base));
+    for (int k = 0; k <= nmax; ++k) {
+        double p = pow(base, (double)k);
+        if (p != floor(p)) return -1;                      /* Int(base^n) throws InexactError */
+        n = push_unique(out, n, cap, burn + (int64_t)p);
+    }
+    n = push_unique(out, n, cap, steps);
+    return n;
+}

@@ -1,0 +1,108 @@
+/*
+ * amc_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's many-chain Metropolis hot path
+ * (Arianna.jl @ 2025-03-02: src/metropolis.jl, example/particle_1d/particle_1d.jl,
+ * src/PolicyGuided/{gradients,estimator,update,learning}.jl, src/simulation.jl
+ * schedule helpers).  Every function in amc_oracle.c cites the reference
+ * file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (montecarlo_amd/, libamc.so) never does.
+ *
+ * PARITY STATUS: "parity unpinned" at the bit level.  The reference is Julia
+ * (not runnable in this image) and none of its tests pins an RNG bitstream,
+ * a trajectory or an accept count.  The oracle is pinned against everything
+ * the reference's tests DO hold for this path:
+ *   - test/ad_backends_test.jl:27-32  (logq, dlogq/dsigma closed form, 1e-10)
+ *   - test/distribution_test.jl:36-37 (mean, std of sampled x, atol 1e-3)
+ *   - test/pgmc_test.jl:45,50         (<e> = 0.25 +- 0.05, sigma* = 1.2 +- 0.2,
+ *                                      Static optimiser leaves sigma untouched)
+ * and against published known-answer vectors of its third-party pieces
+ * (Random123 Philox4x32-10 KATs; rocRAND's uniform / Box-Muller maps).
+ *
+ * RNG: the reference uses one Xoshiro per chain, seeded seed+c-1
+ * (metropolis.jl:262-263), through its public `R=` plug point.  Julia's
+ * Xoshiro seeding and ziggurat randn cannot be reproduced without Julia, so
+ * oracle and product both use the counter-based draw schedule of DESIGN.md §3
+ * (Philox4x32-10 keyed by seed, counter = (step, draw, stream, chain pair)).
+ */
+#ifndef AMC_ORACLE_H
+#define AMC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { AMO_POT_HARMONIC = 0, AMO_POT_DOUBLE_WELL = 1 };
+enum { AMO_STREAM_INIT = 0, AMO_STREAM_METROPOLIS = 1, AMO_STREAM_ESTIMATOR = 2 };
+enum { AMO_DRAW_NORMAL = 0, AMO_DRAW_ACCEPT = 1, AMO_DRAW_CATEGORICAL = 2 };
+enum {
+    AMO_OPT_STATIC = 0, AMO_OPT_VPG = 1, AMO_OPT_BLPG = 2, AMO_OPT_BLAPG = 3,
+    AMO_OPT_NPG = 4, AMO_OPT_ANPG = 5, AMO_OPT_BLANPG = 6
+};
+
+typedef struct amo_sim amo_sim;
+
+/* ---- arithmetic spec primitives (exported for known-answer tests) ---- */
+void   amo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void   amo_counter(uint64_t pair, uint64_t t, uint32_t draw, uint32_t stream, uint32_t ctr[4]);
+double amo_exp(double x);
+double amo_log(double x);
+void   amo_sincospi(double w, double *s, double *c);
+void   amo_box_muller(const uint32_t v[4], double z[2]);
+double amo_uniform53(uint32_t lo, uint32_t hi);   /* [0,1), 53 bits */
+double amo_uniform32(uint32_t v);                 /* [0,1), 32 bits */
+double amo_potential(int pot, double x);
+double amo_log_proposal_density(double delta, double sigma);
+double amo_grad_log_proposal_density(double delta, double sigma);
+int    amo_categorical(const double *weights, int K, double r);
+/* one mc_step! on a lone particle with explicit draws (z, u): returns 1/0, updates x,e */
+int    amo_mc_step_explicit(int pot, double beta, double sigma, double z, double u,
+                            double *x, double *e);
+
+/* ---- simulation object: Vector{Particle} + per-chain pools + Metropolis ---- */
+amo_sim *amo_create(int64_t n_chains, int64_t chain_offset, int potential, double beta,
+                    int n_moves, const double *sigma, const double *weight,
+                    uint64_t seed, int sweepstep);
+void   amo_destroy(amo_sim *s);
+void   amo_set_x(amo_sim *s, const double *x);            /* Particle(x, beta) ctor */
+void   amo_set_beta(amo_sim *s, const double *beta);      /* per-chain beta */
+void   amo_init_uniform(amo_sim *s, double lo, double hi);
+void   amo_get_state(const amo_sim *s, double *x, double *e);
+void   amo_get_counters(const amo_sim *s, int64_t *accepted, int64_t *total); /* [k*M + c] */
+void   amo_set_sigma(amo_sim *s, int k, double sigma);
+double amo_get_sigma(const amo_sim *s, int k);
+uint64_t amo_get_step(const amo_sim *s);
+void   amo_set_step(amo_sim *s, uint64_t t);
+
+void   amo_make_step(amo_sim *s, int n_threads);          /* make_step!(::Metropolis) */
+void   amo_make_steps(amo_sim *s, int64_t n, int n_threads);
+
+double amo_callback_energy(const amo_sim *s);
+void   amo_callback_acceptance(const amo_sim *s, double *out /* K */);
+void   amo_moments(const amo_sim *s, double out[2]);      /* sum x, sum x^2 */
+
+/* make_step!(::PolicyGradientEstimator): out[n_learn][5] = (j, dj, dlogq_fwd, g, n) */
+void   amo_pg_estimate(amo_sim *s, int n_learn, const int *learn_ids, int q_batch,
+                       double *out);
+/* learning_step! for P = 1: gd = averaged (j, dj, dlogq_fwd, g); returns new parameter */
+double amo_learning_step(int opt, double hyper0, double hyper1, double theta,
+                         const double gd[4]);
+
+/* build_schedule: returns number of entries written (<= cap) */
+int64_t amo_build_schedule_linear(int64_t steps, int64_t burn, int64_t dt,
+                                  int64_t *out, int64_t cap);
+int64_t amo_build_schedule_block(int64_t steps, int64_t burn, const int64_t *block,
+                                 int n_block, int64_t *out, int64_t cap);
+int64_t amo_build_schedule_log(int64_t steps, int64_t burn, double base,
+                               int64_t *out, int64_t cap);
+
+int    amo_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,320 @@
+"""ctypes wrapper of the CPU oracle (oracle/libamc_oracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+``OracleEngine`` exposes the same methods as ``montecarlo_amd._capi.HipEngine`` so the
+host logic (Simulation loop, callbacks, sharding, all-reduce) can be exercised on a
+CPU-only box through the package's ``engine_factory`` test seam.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libamc_oracle.so")
+
+POTENTIALS = {"harmonic": 0, "double_well": 1}
+OPTIMISERS = {"Static": 0, "VPG": 1, "BLPG": 2, "BLAPG": 3, "NPG": 4, "ANPG": 5, "BLANPG": 6}
+STREAM_INIT, STREAM_METROPOLIS, STREAM_ESTIMATOR = 0, 1, 2
+DRAW_NORMAL, DRAW_ACCEPT, DRAW_CATEGORICAL = 0, 1, 2
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src_newer = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
+        for f in ("amc_oracle.c", "amc_oracle.h", "Makefile"))
+    if force or src_newer:
+        subprocess.run(["make", "-C", ORACLE_DIR, "-B"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    u32p = C.POINTER(C.c_uint32)
+    i64p = C.POINTER(C.c_int64)
+    S = C.c_void_p
+    sig = {
+        "amo_philox4x32_10": (None, [u32p, u32p, u32p]),
+        "amo_counter": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]),
+        "amo_exp": (C.c_double, [C.c_double]),
+        "amo_log": (C.c_double, [C.c_double]),
+        "amo_sincospi": (None, [C.c_double, dp, dp]),
+        "amo_box_muller": (None, [u32p, dp]),
+        "amo_uniform53": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "amo_uniform32": (C.c_double, [C.c_uint32]),
+        "amo_potential": (C.c_double, [C.c_int, C.c_double]),
+        "amo_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),
+        "amo_grad_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),
+        "amo_categorical": (C.c_int, [dp, C.c_int, C.c_double]),
+        "amo_mc_step_explicit": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]),
+        "amo_create": (S, [C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, dp, dp, C.c_uint64, C.c_int]),
+        "amo_destroy": (None, [S]),
+        "amo_set_x": (None, [S, dp]),
+        "amo_set_beta": (None, [S, dp]),
+        "amo_init_uniform": (None, [S, C.c_double, C.c_double]),
+        "amo_get_state": (None, [S, dp, dp]),
+        "amo_get_counters": (None, [S, i64p, i64p]),
+        "amo_set_sigma": (None, [S, C.c_int, C.c_double]),
+        "amo_get_sigma": (C.c_double, [S, C.c_int]),
+        "amo_get_step": (C.c_uint64, [S]),
+        "amo_set_step": (None, [S, C.c_uint64]),
+        "amo_make_step": (None, [S, C.c_int]),
+        "amo_make_steps": (None, [S, C.c_int64, C.c_int]),
+        "amo_callback_energy": (C.c_double, [S]),
+        "amo_callback_acceptance": (None, [S, dp]),
+        "amo_moments": (None, [S, dp]),
+        "amo_pg_estimate": (None, [S, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amo_learning_step": (C.c_double, [C.c_int, C.c_double, C.c_double, C.c_double, dp]),
+        "amo_build_schedule_linear": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int64]),
+        "amo_build_schedule_block": (C.c_int64, [C.c_int64, C.c_int64, i64p, C.c_int, i64p, C.c_int64]),
+        "amo_build_schedule_log": (C.c_int64, [C.c_int64, C.c_int64, C.c_double, i64p, C.c_int64]),
+        "amo_max_threads": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---- primitive helpers ---------------------------------------------------------------
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    load().amo_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def counter(pair, t, draw, stream):
+    o = (C.c_uint32 * 4)()
+    load().amo_counter(pair, t, draw, stream, o)
+    return [int(v) for v in o]
+
+
+def draw_words(seed, pair, t, draw, stream):
+    return philox(counter(pair, t, draw, stream), [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+
+
+def sincospi(w):
+    s, c = C.c_double(), C.c_double()
+    load().amo_sincospi(w, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def box_muller(v):
+    a = (C.c_uint32 * 4)(*v)
+    z = (C.c_double * 2)()
+    load().amo_box_muller(a, z)
+    return z[0], z[1]
+
+
+def mc_step_explicit(pot, beta, sigma, z, u, x, e):
+    xx, ee = C.c_double(x), C.c_double(e)
+    a = load().amo_mc_step_explicit(pot, beta, sigma, z, u, C.byref(xx), C.byref(ee))
+    return a, xx.value, ee.value
+
+
+def build_schedule(steps, burn, spec):
+    lib = load()
+    cap = int(steps) + 8
+    out = (C.c_int64 * cap)()
+    if isinstance(spec, float):
+        n = lib.amo_build_schedule_log(steps, burn, spec, out, cap)
+    elif isinstance(spec, (list, tuple)):
+        b = (C.c_int64 * len(spec))(*spec)
+        n = lib.amo_build_schedule_block(steps, burn, b, len(spec), out, cap)
+    else:
+        n = lib.amo_build_schedule_linear(steps, burn, int(spec), out, cap)
+    if n < 0:
+        raise ValueError("InexactError")
+    return [int(out[i]) for i in range(n)]
+
+
+def learning_step(opt: str, h0: float, h1: float, theta: float, gd4) -> float:
+    a = (C.c_double * 4)(*gd4)
+    return load().amo_learning_step(OPTIMISERS[opt], h0, h1, theta, a)
+
+
+class OracleSim:
+    """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
+
+    def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
+                 weight=(1.0,), seed=1, sweepstep=1):
+        self.lib = load()
+        self.M = int(n_chains)
+        self.K = len(sigma)
+        s = (C.c_double * self.K)(*[float(v) for v in sigma])
+        w = (C.c_double * self.K)(*[float(v) for v in weight])
+        self.h = self.lib.amo_create(self.M, int(chain_offset), POTENTIALS[potential], float(beta), self.K, s, w,
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweepstep))
+        if not self.h:
+            raise ValueError("amo_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.amo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.M,)
+        self.lib.amo_set_x(self.h, _dptr(x))
+
+    def set_beta(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == (self.M,)
+        self.lib.amo_set_beta(self.h, _dptr(b))
+
+    def init_uniform(self, lo, hi):
+        self.lib.amo_init_uniform(self.h, float(lo), float(hi))
+
+    def state(self):
+        x = np.empty(self.M)
+        e = np.empty(self.M)
+        self.lib.amo_get_state(self.h, _dptr(x), _dptr(e))
+        return x, e
+
+    def counters(self):
+        acc = np.empty((self.K, self.M), dtype=np.int64)
+        tot = np.empty((self.K, self.M), dtype=np.int64)
+        p = C.POINTER(C.c_int64)
+        self.lib.amo_get_counters(self.h, acc.ctypes.data_as(p), tot.ctypes.data_as(p))
+        return acc, tot
+
+    def make_steps(self, n=1, threads=1):
+        self.lib.amo_make_steps(self.h, int(n), int(threads))
+
+    def energy(self):
+        return self.lib.amo_callback_energy(self.h)
+
+    def acceptance(self):
+        out = np.empty(self.K)
+        self.lib.amo_callback_acceptance(self.h, _dptr(out))
+        return out
+
+    def moments(self):
+        out = np.empty(2)
+        self.lib.amo_moments(self.h, _dptr(out))
+        return out
+
+    def pg_estimate(self, learn_ids, q_batch):
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, 5))
+        self.lib.amo_pg_estimate(self.h, n, ids, int(q_batch), _dptr(out))
+        return out
+
+    def set_sigma(self, k, s):
+        self.lib.amo_set_sigma(self.h, int(k), float(s))
+
+    def get_sigma(self, k):
+        return self.lib.amo_get_sigma(self.h, int(k))
+
+    @property
+    def step(self):
+        return self.lib.amo_get_step(self.h)
+
+    @step.setter
+    def step(self, t):
+        self.lib.amo_set_step(self.h, int(t))
+
+
+class OracleEngine:
+    """Same surface as montecarlo_amd._capi.HipEngine, computed by the CPU oracle.
+
+    A test double for CPU-only runs of the host logic; never shipped, never a fallback."""
+
+    def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
+                 sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
+                 stream=None):
+        self.n_chains = int(n_chains)
+        self.n_moves = len(sigma)
+        self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
+                             weight=weight, seed=seed, sweepstep=sweepstep)
+        self.sim.set_x(np.zeros(self.n_chains))
+        self.threads = 1
+
+    def close(self):
+        self.sim.close()
+
+    def upload_state(self, x, beta=None):
+        self.sim.set_x(x)
+        if beta is not None:
+            self.sim.set_beta(beta)
+
+    def init_uniform(self, lo, hi):
+        self.sim.init_uniform(lo, hi)
+
+    def download_state(self, want_e=True):
+        x, e = self.sim.state()
+        return x, (e if want_e else None)
+
+    def download_counters(self):
+        return self.sim.counters()
+
+    def counter_totals(self):
+        acc, tot = self.sim.counters()
+        return acc.sum(axis=1), tot.sum(axis=1)
+
+    def sweep(self, n_sweeps=1):
+        self.sim.make_steps(n_sweeps, self.threads)
+
+    @property
+    def step(self):
+        return self.sim.step
+
+    @step.setter
+    def step(self, t):
+        self.sim.step = t
+
+    def reduce(self):
+        out = np.empty(4 + self.n_moves)
+        m = self.sim.moments()
+        out[0] = self.sim.energy() * self.n_chains
+        out[1], out[2] = m[0], m[1]
+        out[3] = float(self.n_chains)
+        out[4:] = self.sim.acceptance() * self.n_chains
+        return out
+
+    def set_parameters(self, k, p):
+        self.sim.set_sigma(k, float(np.asarray(p).reshape(-1)[0]))
+
+    def get_parameters(self, k):
+        return np.array([self.sim.get_sigma(k)])
+
+    def pg_estimate(self, learn_ids, q_batch):
+        return self.sim.pg_estimate(learn_ids, q_batch)
+
+    def sync(self):
+        pass
+
+    def timing_begin(self):
+        pass
+
+    def timing_end(self):
+        return 0.0
