@@ -1,0 +1,27 @@
+"""montecarlo_amd: MI355X-native many-chain Metropolis engine behind Arianna.jl's plugin API.
+
+The compute path is libamc.so (hand-written HIP for gfx950, C ABI in include/amc.h).  This
+package is the host-side mirror of the reference's interface for that one path -- Move / pool /
+Simulation / run -- so a user of TheDisorderedOrganization/MonteCarlo's particle_1d examples finds
+the same names.  There is no CPU implementation here: without the built extension and a GPU,
+constructing ``Metropolis`` raises.
+"""
+from ._capi import AmcError, HipEngine, device_count
+from .metropolis import Metropolis, callback_acceptance, callback_energy, callback_moments
+from .policy_guided import (ANPG, BLANPG, BLAPG, BLPG, NPG, VPG, GradientData, PolicyGradientEstimator,
+                            PolicyGradientUpdate, Static, average, initialise_gradient_data, learning_step)
+from .sharding import allreduce_sum, shard_range
+from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
+                         build_schedule, julia_repr, run)
+from .system import Displacement, Move, ParticleChains, StandardGaussian, potential
+
+__all__ = [
+    "AmcError", "HipEngine", "device_count",
+    "Metropolis", "callback_acceptance", "callback_energy", "callback_moments",
+    "ANPG", "BLANPG", "BLAPG", "BLPG", "NPG", "VPG", "Static", "GradientData", "PolicyGradientEstimator",
+    "PolicyGradientUpdate", "average", "initialise_gradient_data", "learning_step",
+    "allreduce_sum", "shard_range",
+    "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
+    "build_schedule", "julia_repr", "run",
+    "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
+]

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int6
 // Derived per-move parameters, computed ON DEVICE so the arithmetic is the kernel's.
 // den = 2*(s*s); logc = log(2pi*(s*s))/2 (particle_1d.jl:53); cum = running sum of
 // weights in the order Distributions.jl accumulates them; dden, dlhalf: d/dsigma
-// pieces of gradients.jl:28-33 (see oracle amo_grad_log_proposal_density).
+// pieces of gradients.jl:28-33 (ForwardDiff's dual rules written out).
 __global__ void prepare_params_kernel(double* ptab, int n_moves)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -1,0 +1,172 @@
+"""``Metropolis``: the HIP-backed algorithm object for the reference's hot path.
+
+Mirror of ``Metropolis`` (src/metropolis.jl:232-291) and its ``make_step!`` (:302-309) behind the
+plugin protocol, plus the two callbacks that read its state (``callback_acceptance`` :319-321,
+``callback_energy`` example/particle_1d/particle_1d.jl:68-70).  All arithmetic runs in
+libamc.so's kernels; this file only owns the shard bookkeeping and the cross-shard sum.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import sharding
+from ._capi import AMC_RED_HEADER, HipEngine
+from .simulation import AriannaAlgorithm, Simulation, _calls, julia_repr
+from .system import Move, ParticleChains
+
+
+class Metropolis(AriannaAlgorithm):
+    """Metropolis(chains; pool, sweepstep=1, seed=1, ...) -- src/metropolis.jl:288-291.
+
+    ``R`` / ``parallel`` are accepted for signature compatibility and ignored: the generator is
+    the counter-based Philox of DESIGN.md §3 and the chains run on the GPU.
+    ``engine_factory`` is a TEST SEAM (default and only shipped engine: ``HipEngine``); tests on
+    CPU-only boxes pass a double built on the oracle to exercise this host logic.
+    """
+
+    fusable = True
+
+    def __init__(self, chains: ParticleChains, pool: Optional[Sequence[Move]] = None, sweepstep: int = 1,
+                 seed: int = 1, R=None, parallel: bool = False, device: Optional[int] = None,
+                 per_chain_counters: bool = True, download_on_finalise: bool = True,
+                 engine_factory: Optional[Callable[..., object]] = None, **extras):
+        if pool is None or len(pool) == 0:
+            raise ValueError("Metropolis: pool is missing")
+        if not all(isinstance(m, Move) for m in pool):
+            raise TypeError("Metropolis: pool must hold Move objects")
+        self.pool = tuple(pool)
+        self.sweepstep = int(sweepstep)
+        self.seed = int(seed)
+        self.parallel = bool(parallel)
+        self.chains = chains
+        self.rank, self.world_size = sharding.world()
+        start, stop = sharding.shard_range(len(chains), self.rank, self.world_size)
+        if stop <= start:
+            raise ValueError(f"rank {self.rank} owns no chains: use at most {(len(chains) + 1) // 2} ranks")
+        self.shard = (start, stop)
+        chains.shard = (start, stop)
+        self.download_on_finalise = download_on_finalise
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        factory = engine_factory or HipEngine
+        self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains),
+                              potential=chains.potential, beta=chains.beta,
+                              sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],
+                              seed=self.seed, sweepstep=self.sweepstep,
+                              per_chain_counters=per_chain_counters or len(self.pool) > 1, device=device)
+        self._epoch = 0          # bumped whenever the device state changes
+        self._red_key = None
+        self._red_val = None
+
+    # ---- plugin protocol ---------------------------------------------------------------
+    def initialise(self, simulation: Simulation) -> None:
+        start, stop = self.shard
+        ch = self.chains
+        beta = None if ch.beta_array is None else ch.beta_array[start:stop]
+        if ch.x is not None:
+            x = ch.x if ch.x.shape[0] == stop - start else ch.x[start:stop]
+            self.engine.upload_state(x, beta)
+        else:
+            lo, hi = ch.init_uniform if ch.init_uniform is not None else (0.0, 0.0)
+            if beta is not None:
+                self.engine.upload_state(np.zeros(stop - start), beta)
+            self.engine.init_uniform(lo, hi)
+        self._epoch += 1
+
+    def make_step(self, simulation: Simulation) -> None:
+        """make_step!(simulation, ::Metropolis), src/metropolis.jl:302-309: one sweep of every chain."""
+        self.engine.sweep(1)
+        self._epoch += 1
+
+    def make_steps(self, simulation: Simulation, n: int) -> None:
+        """n consecutive make_step!s fused in one launch (state stays in registers)."""
+        self.engine.sweep(n)
+        self._epoch += 1
+
+    def finalise(self, simulation: Simulation) -> None:
+        if self.download_on_finalise:
+            x, e = self.engine.download_state(want_e=True)
+            self.chains.x, self.chains.e = x, e        # this rank's shard, like chains[c].x / .e
+        acc, tot = self.engine.counter_totals()
+        tot_all = sharding.allreduce_sum(np.concatenate([acc, tot]).astype(np.float64))
+        K = len(self.pool)
+        for k, move in enumerate(self.pool):
+            move.accepted_calls = int(tot_all[k])
+            move.total_calls = int(tot_all[K + k])
+
+    def sync(self) -> None:
+        self.engine.sync()
+
+    def write_algorithm(self, io, scheduler) -> None:
+        """src/metropolis.jl:346-363."""
+        io.write("\tMetropolis\n")
+        io.write(f"\t\tCalls: {_calls(scheduler)}\n")
+        io.write(f"\t\tMC steps per simulation step: {self.sweepstep}\n")
+        io.write(f"\t\tSeed: {self.seed}\n")
+        io.write(f"\t\tParallel: gfx950 HIP kernels, {self.world_size} shard(s)\n")
+        io.write("\t\tMoves:\n")
+        for k, move in enumerate(self.pool, start=1):
+            io.write(f"\t\t\tMove {k}:\n\t\t\t\tAction: Displacement\n\t\t\t\tPolicy: StandardGaussian\n")
+            io.write(f"\t\t\t\tParameters: {julia_repr(move.parameters)}\n\t\t\t\tWeight: {julia_repr(move.weight)}\n")
+
+    # ---- state the dependants read (pools, parameters) ------------------------------------
+    def set_parameters(self, k: int, parameters) -> None:
+        """Push Move.parameters of move k to the device copy (after learning_step!, update.jl:53)."""
+        p = np.atleast_1d(np.asarray(parameters, dtype=np.float64))
+        self.engine.set_parameters(k, p)
+        if self.pool[k].parameters is not parameters:
+            self.pool[k].parameters[...] = p
+
+    def download_counters(self):
+        """pools[c][k].accepted_calls / total_calls of this rank's shard, shape (K, M_local)."""
+        return self.engine.download_counters()
+
+    # ---- reductions behind the callbacks ---------------------------------------------------
+    def reductions(self) -> dict:
+        """One device reduction + ONE all-reduce per observation point, shared by all callbacks."""
+        key = self._epoch
+        if self._red_key == key and self._red_val is not None:
+            return self._red_val
+        red = sharding.allreduce_sum(self.engine.reduce())
+        n = red[3]
+        val = {
+            "energy": red[0] / n,                      # mean(system.e for system in chains)
+            "mean_x": red[1] / n,
+            "mean_x2": red[2] / n,
+            "n_chains": int(round(n)),
+            "acceptance": red[AMC_RED_HEADER:] / n,    # mean over chains of accepted/total per move
+        }
+        self._red_key, self._red_val = key, val
+        return val
+
+    def invalidate_reductions(self) -> None:
+        """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
+        self._epoch += 1
+
+
+def _find_metropolis(simulation: Simulation):
+    found = [a for a in simulation.algorithms if isinstance(a, Metropolis)]
+    if len(found) != 1:
+        # the reference's generator splat only works with exactly one Metropolis (metropolis.jl:320)
+        raise ValueError(f"callbacks need exactly one Metropolis in the algorithm list, found {len(found)}")
+    return found[0]
+
+
+def callback_energy(simulation: Simulation) -> float:
+    """callback_energy, example/particle_1d/particle_1d.jl:68-70: mean energy over all chains."""
+    return float(_find_metropolis(simulation).reductions()["energy"])
+
+
+def callback_acceptance(simulation: Simulation) -> np.ndarray:
+    """callback_acceptance, src/metropolis.jl:319-321: per move, mean over chains of
+    accepted_calls/total_calls (NaN before the first step, like the reference's 0/0)."""
+    return np.array(_find_metropolis(simulation).reductions()["acceptance"], dtype=np.float64)
+
+
+def callback_moments(simulation: Simulation) -> np.ndarray:
+    """[mean(x), mean(x^2)] over all chains: the statistic test/distribution_test.jl:36-37 checks."""
+    r = _find_metropolis(simulation).reductions()
+    return np.array([r["mean_x"], r["mean_x2"]])

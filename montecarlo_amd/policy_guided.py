@@ -1,0 +1,190 @@
+"""Policy-guided Monte Carlo on the HIP path: src/PolicyGuided/ of the reference.
+
+  GradientData, +, average      gradients.jl:41-85
+  PolicyGradientEstimator       estimator.jl:38-134   (per-sample arithmetic: HIP kernel K3)
+  PolicyGradientUpdate          update.jl:14-57
+  Static VPG BLPG BLAPG NPG ANPG BLANPG + learning_step!   learning.jl:16-164
+The per-chain x per-sample estimate (gradients.jl:93-121) runs on the GPU; the fold over chains
+is the kernel's block reduction + ONE all-reduce; the O(P^2) optimiser algebra stays on the host
+(as in the reference) and the new sigma is pushed to the device copy.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import sharding
+from .metropolis import Metropolis
+from .simulation import AriannaAlgorithm, Simulation, _calls
+
+
+# ---- optimisers, learning.jl ---------------------------------------------------------------
+class PolicyGradient:
+    """abstract type PolicyGradient (learning.jl:9)."""
+
+
+@dataclass(frozen=True)
+class Static(PolicyGradient):
+    pass
+
+
+@dataclass(frozen=True)
+class VPG(PolicyGradient):
+    eta: float
+
+
+@dataclass(frozen=True)
+class BLPG(PolicyGradient):
+    eta: float
+
+
+@dataclass(frozen=True)
+class BLAPG(PolicyGradient):
+    delta: float
+    eps_id: float = 0.0
+
+
+@dataclass(frozen=True)
+class NPG(PolicyGradient):
+    eta: float
+    eps_id: float = 0.0
+
+
+@dataclass(frozen=True)
+class ANPG(PolicyGradient):
+    delta: float
+    eps_id: float = 0.0
+
+
+@dataclass(frozen=True)
+class BLANPG(PolicyGradient):
+    delta: float
+    eps_id: float = 0.0
+
+
+@dataclass
+class GradientData:
+    """gradients.jl:41-47: objective j, its gradient, grad logq of the forward action, metric g, count n."""
+    j: float
+    grad_j: np.ndarray
+    grad_logq_forward: np.ndarray
+    g: np.ndarray
+    n: int
+
+    def __add__(self, o: "GradientData") -> "GradientData":                       # gradients.jl:68-76
+        return GradientData(self.j + o.j, self.grad_j + o.grad_j, self.grad_logq_forward + o.grad_logq_forward,
+                            self.g + o.g, self.n + o.n)
+
+
+def initialise_gradient_data(parameters: np.ndarray) -> GradientData:            # gradients.jl:54-61
+    z = np.zeros_like(np.asarray(parameters, dtype=np.float64))
+    return GradientData(0.0, z.copy(), z.copy(), np.outer(z, z), 0)
+
+
+def average(gd: GradientData) -> GradientData:                                   # gradients.jl:83-85
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return GradientData(gd.j / gd.n if gd.n else float("nan"), gd.grad_j / gd.n, gd.grad_logq_forward / gd.n,
+                            gd.g / gd.n, gd.n)
+
+
+def learning_step(parameters: np.ndarray, gd: GradientData, opt: PolicyGradient) -> None:
+    """learning_step!(parameters, gd, opt): in-place update, one method per optimiser
+    (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164)."""
+    eye = np.eye(parameters.shape[0])
+    if isinstance(opt, VPG):
+        parameters[...] = parameters + opt.eta * gd.grad_j
+    elif isinstance(opt, BLPG):
+        parameters[...] = parameters + opt.eta * (gd.grad_j - gd.j * gd.grad_logq_forward)
+    elif isinstance(opt, BLAPG):
+        eta = np.sqrt(2 * opt.delta / (np.dot(gd.grad_j, gd.grad_j) + opt.eps_id))
+        parameters[...] = parameters + eta * (gd.grad_j - gd.j * gd.grad_logq_forward)
+    elif isinstance(opt, NPG):
+        parameters[...] = parameters + opt.eta * np.linalg.inv(gd.g + opt.eps_id * eye) @ gd.grad_j
+    elif isinstance(opt, ANPG):
+        f_inv = np.linalg.inv(gd.g + opt.eps_id * eye)
+        eta = np.sqrt(2 * opt.delta / (gd.grad_j @ (f_inv @ gd.grad_j)))
+        parameters[...] = parameters + eta * f_inv @ gd.grad_j
+    elif isinstance(opt, BLANPG):
+        f_inv = np.linalg.inv(gd.g + opt.eps_id * eye)
+        bj = gd.grad_j - gd.j * gd.grad_logq_forward
+        eta = np.sqrt(2 * opt.delta / (bj @ (f_inv @ bj)))
+        parameters[...] = parameters + eta * f_inv @ bj
+    elif isinstance(opt, Static):
+        pass
+    else:
+        raise TypeError(f"No learning_step! is defined for {type(opt).__name__}")
+
+
+# ---- estimator.jl ------------------------------------------------------------------------------
+class PolicyGradientEstimator(AriannaAlgorithm):
+    """PolicyGradientEstimator(chains; dependencies=(Metropolis,), optimisers, q_batch_size=1, ...)
+    (estimator.jl:103-109).  ``ad_backend`` is accepted and ignored: d logq / d sigma of the Gaussian
+    policy is evaluated in closed form by the kernel (test/ad_backends_test.jl pins all backends equal)."""
+
+    def __init__(self, chains, dependencies=None, optimisers=None, q_batch_size: int = 1, ad_backend=None,
+                 R=None, parallel: bool = False, **extras):
+        assert dependencies is not None and len(dependencies) == 1                 # :104
+        assert isinstance(dependencies[0], Metropolis)                             # :105
+        self.metropolis: Metropolis = dependencies[0]
+        self.pool = self.metropolis.pool
+        self.seed = self.metropolis.seed
+        self.optimisers = tuple(optimisers)
+        assert len(self.optimisers) == len(self.pool)                              # :70
+        self.learn_ids: List[int] = [k for k, o in enumerate(self.optimisers) if not isinstance(o, Static)]  # :72
+        self.q_batch_size = int(q_batch_size)
+        self.parameters_list = [m.parameters for m in self.pool]
+        self.objectives = np.zeros(len(self.learn_ids))                            # :83
+        self.gradients_data: List[GradientData] = [initialise_gradient_data(self.parameters_list[k])
+                                                   for k in self.learn_ids]        # :84
+        self.parallel = parallel
+
+    def make_step(self, simulation: Simulation) -> None:
+        """estimator.jl:111-134: fold GradientData over chains x q_batch samples per learnable move."""
+        if not self.learn_ids:
+            return
+        local = self.metropolis.engine.pg_estimate(self.learn_ids, self.q_batch_size)
+        self.metropolis.invalidate_reductions()      # every sample leaves x at (x+d)-d (gradients.jl:103)
+        total = sharding.allreduce_sum(local.reshape(-1)).reshape(local.shape)
+        for k in range(len(self.learn_ids)):
+            gd = GradientData(float(total[k, 0]), np.array([total[k, 1]]), np.array([total[k, 2]]),
+                              np.array([[total[k, 3]]]), int(round(total[k, 4])))
+            self.gradients_data[k] = self.gradients_data[k] + gd                   # :130
+            self.objectives[k] = self.gradients_data[k].j / self.gradients_data[k].n   # :131
+
+    def write_algorithm(self, io, scheduler) -> None:                              # :136-147
+        io.write("\tPolicyGradientEstimator\n")
+        io.write(f"\t\tCalls: {_calls(scheduler)}\n")
+        io.write(f"\t\tLearnable moves: {[k + 1 for k in self.learn_ids]}\n")
+        io.write(f"\t\tQ batch size: {self.q_batch_size}\n\t\tAD backend: closed form (HIP kernel)\n")
+        io.write(f"\t\tSeed: {self.seed}\n")
+
+
+# ---- update.jl ------------------------------------------------------------------------------------
+class PolicyGradientUpdate(AriannaAlgorithm):
+    """PolicyGradientUpdate(chains; dependencies=(PolicyGradientEstimator,)) (update.jl:43-48)."""
+
+    def __init__(self, chains, dependencies=None, **extras):
+        assert dependencies is not None and len(dependencies) == 1
+        assert isinstance(dependencies[0], PolicyGradientEstimator)
+        self.estimator: PolicyGradientEstimator = dependencies[0]
+        self.optimisers = self.estimator.optimisers
+        self.learn_ids = self.estimator.learn_ids
+        self.parameters_list = self.estimator.parameters_list
+
+    def make_step(self, simulation: Simulation) -> None:
+        """update.jl:50-57: average -> learning_step! -> reset; then refresh the device copy of sigma."""
+        est = self.estimator
+        for k, lid in enumerate(self.learn_ids):
+            gd = average(est.gradients_data[k])
+            learning_step(self.parameters_list[lid], gd, self.optimisers[lid])
+            est.gradients_data[k] = initialise_gradient_data(self.parameters_list[lid])
+            est.metropolis.set_parameters(lid, self.parameters_list[lid])
+
+    def write_algorithm(self, io, scheduler) -> None:                              # update.jl:59-67
+        io.write("\tPolicyGradientUpdate\n")
+        io.write(f"\t\tCalls: {_calls(scheduler)}\n")
+        io.write(f"\t\tLearnable moves: {[k + 1 for k in self.learn_ids]}\n\t\tOptimisers:\n")
+        for k, opt in enumerate(self.optimisers, start=1):
+            io.write(f"\t\t\tMove {k}: {opt}\n")

@@ -1,0 +1,374 @@
+"""Caller side of the hot path: the algorithm plugin protocol, ``Simulation`` and ``run``.
+
+Python mirror of the reference's driver so the HIP ``Metropolis`` slots in the way an
+``AriannaAlgorithm`` does in Julia:
+  protocol      src/algorithms.jl:6-37   initialise / make_step! / finalise / write_algorithm
+  Simulation    src/simulation.jl:16-88  (NamedTuple list -> instances, dependencies by type)
+  schedules     src/simulation.jl:95-117 build_schedule (three methods)
+  run!          src/simulation.jl:175-204
+  StoreCallbacks src/algorithms.jl:62-109, StoreParameters src/metropolis.jl:380-450,
+  PrintTimeSteps src/algorithms.jl:310-323
+Per-chain text I/O (StoreTrajectories / StoreBackups / StoreLastFrames) is out of scope at
+M = 1e7.  One addition over the reference: ``run(fuse=True)`` looks ahead in
+the schedules and issues one fused launch for every stretch of sweeps no other algorithm
+observes (results identical to stepping one by one).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+import time
+from typing import Any, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import sharding
+
+
+class AriannaAlgorithm:
+    """src/algorithms.jl:6-37: the four generic functions every algorithm implements."""
+
+    def initialise(self, simulation: "Simulation") -> None:
+        return None
+
+    def make_step(self, simulation: "Simulation") -> None:
+        return None
+
+    def finalise(self, simulation: "Simulation") -> None:
+        return None
+
+    def write_algorithm(self, io, scheduler) -> None:
+        io.write(f"\t{type(self).__name__}\n")
+
+
+# ---------------------------------------------------------------------------------------
+# build_schedule, src/simulation.jl:95-117
+# ---------------------------------------------------------------------------------------
+def build_schedule(steps: int, burn: int, spec) -> List[int]:
+    """Three methods, dispatched on the type of ``spec`` like the reference:
+    int dt -> burn:dt:steps U [steps]; float base -> log-spaced; list block -> repeated blocks."""
+    steps, burn = int(steps), int(burn)
+    if isinstance(spec, bool):
+        raise TypeError("build_schedule: spec must be int, float or list")
+    if isinstance(spec, (int, np.integer)):
+        out = list(range(burn, steps + 1, int(spec)))
+        if not out or out[-1] != steps:
+            out.append(steps)
+        return out
+    if isinstance(spec, float):
+        nmax = math.floor(math.log(steps - burn) / math.log(spec))
+        vals = [burn]
+        for n in range(nmax + 1):
+            p = spec ** n
+            if p != math.floor(p):
+                raise ValueError(f"InexactError: Int({p})")   # Int(base^n) throws in the reference
+            vals.append(burn + int(p))
+        vals.append(steps)
+        return _unique(vals)
+    block = [int(b) for b in spec]
+    nblock = (steps - burn) // block[-1]
+    vals: List[int] = []
+    for m in range(1, nblock + 1):
+        vals.extend(b + burn + (m - 1) * block[-1] for b in block)
+    vals.append(steps)
+    return [v for v in _unique(vals) if v <= steps]
+
+
+def _unique(vals: Iterable[int]) -> List[int]:
+    seen, out = set(), []
+    for v in vals:
+        if v not in seen:
+            seen.add(v)
+            out.append(v)
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# Julia-style printing of callback values ("$t $(callback(simulation))", algorithms.jl:99)
+# ---------------------------------------------------------------------------------------
+def julia_repr(v) -> str:
+    """string(v) as Julia prints Float64 / Vector{Float64}: shortest round-trip digits, fixed
+    notation for 1e-4 <= |x| < 1e6, otherwise d.ddde±n; NaN, Inf; vectors as [a, b]."""
+    if isinstance(v, (list, tuple, np.ndarray)):
+        return "[" + ", ".join(julia_repr(x) for x in np.asarray(v).tolist()) + "]"
+    if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
+        return str(int(v))
+    x = float(v)
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    sign = "-" if math.copysign(1.0, x) < 0 else ""
+    if x == 0.0:
+        return sign + "0.0"
+    m, _, e = repr(abs(x)).partition("e")
+    ip, _, fp = m.partition(".")
+    digits = ip + fp
+    point = len(ip) + (int(e) if e else 0)          # value = 0.digits * 10^point
+    stripped = digits.lstrip("0")
+    point -= len(digits) - len(stripped)
+    digits = stripped.rstrip("0") or "0"
+    e10 = point - 1
+    if -5 < e10 < 6:
+        if point <= 0:
+            body = "0." + "0" * (-point) + digits
+        elif point >= len(digits):
+            body = digits + "0" * (point - len(digits)) + ".0"
+        else:
+            body = digits[:point] + "." + digits[point:]
+    else:
+        body = digits[0] + "." + (digits[1:] or "0") + "e" + str(e10)
+    return sign + body
+
+
+# ---------------------------------------------------------------------------------------
+# Simulation, src/simulation.jl:16-88
+# ---------------------------------------------------------------------------------------
+class Simulation:
+    def __init__(self, chains, algorithm_list: Sequence[Dict[str, Any]], steps: int, path: str = "data",
+                 verbose: bool = False):
+        self.chains = chains
+        self.steps = int(steps)
+        self.t = 0
+        self.path = path
+        self.verbose = verbose
+        self.rank, self.world_size = sharding.world()
+        schedulers, algorithms, names = [], [], []
+        for constructor in algorithm_list:
+            constructor = dict(constructor)
+            cls = constructor.pop("algorithm")
+            names.append(cls)
+            scheduler = constructor.pop("scheduler", range(1, self.steps + 1))      # :74
+            dependencies = constructor.pop("dependencies", None)
+            kwargs = dict(constructor)
+            if dependencies is not None:                                             # :77-81
+                parents = [a for a, n in zip(algorithms, names[:-1]) if n in tuple(dependencies)]
+                kwargs["dependencies"] = tuple(parents)
+            kwargs.update(path=path, steps=self.steps, verbose=verbose)              # :82
+            algorithms.append(cls(chains, **kwargs))                                 # :83
+            schedulers.append(scheduler)
+        self.algorithms = tuple(algorithms)
+        self.schedulers = tuple(schedulers)
+        assert len(self.schedulers) == len(self.algorithms)                         # :45
+        for s in self.schedulers:
+            if not isinstance(s, range):
+                assert all(0 <= x <= self.steps for x in s), "scheduler entries must lie in [0, steps]"   # :46
+                assert all(a <= b for a, b in zip(s, s[1:])), "scheduler must be sorted"              # :47
+        # counters = findfirst(x -> x > 0, scheduler)  (:49), 0-based here; None if nothing > 0
+        self.counters: List[Optional[int]] = [next((i for i, x in enumerate(s) if x > 0), None)
+                                              for s in self.schedulers]
+        if self.rank == 0:
+            os.makedirs(path, exist_ok=True)                                         # :50
+
+    # summary.log, src/simulation.jl:124-165 (rank 0 only)
+    def _write_summary(self) -> None:
+        if self.rank != 0:
+            return
+        with open(os.path.join(self.path, "summary.log"), "w") as f:
+            f.write("SIMULATION SUMMARY\n\nSimulation:\n")
+            f.write(f"\tSteps: {self.steps}\n\tNumber of chains: {len(self.chains)}\n")
+            f.write(f"\tNumber of algorithms: {len(self.algorithms)}\n\tVerbose: {str(self.verbose).lower()}\n")
+            f.write(f"\tStarted on {time.strftime('%Y-%m-%dT%H:%M:%S')}\n\nSystem:\n")
+            f.write(f"\tParticle{{Float64}} x {len(self.chains)} ({self.chains.potential}, SoA on MI355X)\n\n")
+            f.write("Algorithms:\n")
+            for alg, sched in zip(self.algorithms, self.schedulers):
+                alg.write_algorithm(f, sched)
+            f.write("\n")
+
+    def _update_summary(self, sim_time: float) -> None:
+        if self.rank != 0:
+            return
+        with open(os.path.join(self.path, "summary.log"), "a") as f:
+            f.write(f"Report:\n\tSimulation time: {sim_time} s\n")
+
+    def _finalise_summary(self) -> None:
+        if self.rank != 0 or not os.path.exists(os.path.join(self.path, "summary.log")):
+            return
+        total = 0
+        for root, _dirs, files in os.walk(self.path):
+            total += sum(os.path.getsize(os.path.join(root, fn)) for fn in files)
+        with open(os.path.join(self.path, "summary.log"), "a") as f:
+            f.write(f"\tSimulation size: {total / 1024 ** 2} MB\n")
+            f.write(f"\tStatus: Completed on {time.strftime('%Y-%m-%dT%H:%M:%S')}\n")
+
+
+def _calls(scheduler) -> int:
+    """write_algorithm's "Calls:" line: length(filter(x -> 0 < x <= scheduler[end], scheduler))."""
+    if len(scheduler) == 0:
+        return 0
+    last = scheduler[-1]
+    return sum(1 for x in scheduler if 0 < x <= last)
+
+
+def _due(simulation: Simulation, k: int) -> Optional[int]:
+    c = simulation.counters[k]
+    s = simulation.schedulers[k]
+    if c is None or c >= len(s):
+        return None          # the reference would index out of bounds here (simulation.jl:186)
+    return s[c]
+
+
+def run(simulation: Simulation, fuse: bool = True) -> None:
+    """run!(simulation), src/simulation.jl:175-204.
+
+    ``fuse``: when the next n time steps schedule nothing but one fusable algorithm (the HIP
+    Metropolis), issue them as ONE launch.  Algorithm order inside a time
+    step and every observable state are the same as without fusion.
+    """
+    sim = simulation
+    try:
+        for alg in sim.algorithms:                                                  # :179-181
+            alg.initialise(sim)
+        sim._write_summary()                                                        # :182
+        t_start = time.perf_counter()
+        t = 1
+        n_alg = len(sim.algorithms)
+        while t <= sim.steps:                                                       # :184
+            sim.t = t
+            advance = 1
+            due = [k for k in range(n_alg) if _due(sim, k) == t]
+            if fuse and len(due) == 1 and getattr(sim.algorithms[due[0]], "fusable", False):
+                k = due[0]
+                others = [d for j in range(n_alg) if j != k for d in [_due(sim, j)] if d is not None]
+                horizon = min(others) if others else sim.steps + 1
+                n = _consecutive(sim.schedulers[k], sim.counters[k], t, min(horizon - 1, sim.steps))
+                if n > 1:
+                    sim.algorithms[k].make_steps(sim, n)
+                    sim.counters[k] += n
+                    advance = n
+                    sim.t = t + n - 1
+                    t += advance
+                    continue
+            for k in due:                                                           # :185-190
+                sim.algorithms[k].make_step(sim)
+                sim.counters[k] += 1
+            t += advance
+        for alg in sim.algorithms:
+            sync = getattr(alg, "sync", None)
+            if sync:
+                sync()
+        sim_time = time.perf_counter() - t_start
+        if sim.verbose and sim.rank == 0:
+            print(f"\nSimulation completed in {sim_time} s")
+        sim._update_summary(sim_time)                                               # :193
+    finally:
+        for alg in sim.algorithms:                                                  # :196-198
+            alg.finalise(sim)
+        sim._finalise_summary()
+
+
+def _consecutive(scheduler, counter: int, t: int, t_last: int) -> int:
+    """How many of t, t+1, ... (<= t_last) are consecutive entries of ``scheduler`` from ``counter``."""
+    if t_last < t:
+        return 0
+    if isinstance(scheduler, range) and scheduler.step == 1:
+        return max(0, min(t_last, scheduler[-1]) - t + 1)
+    n = 0
+    while counter + n < len(scheduler) and scheduler[counter + n] == t + n and t + n <= t_last:
+        n += 1
+    return n
+
+
+# ---------------------------------------------------------------------------------------
+# StoreCallbacks, src/algorithms.jl:62-109
+# ---------------------------------------------------------------------------------------
+class StoreCallbacks(AriannaAlgorithm):
+    def __init__(self, chains, path=None, callbacks=None, store_first: bool = True, store_last: bool = False,
+                 **extras):
+        self.callbacks = tuple(callbacks or ())
+        self.store_first, self.store_last = store_first, store_last
+        self.rank, _ = sharding.world()
+        self.paths = [os.path.join(path, cb.__name__.replace("callback_", "") + ".dat") for cb in self.callbacks]
+        self.files: List[Any] = []
+        self.rows: List[List[tuple]] = [[] for _ in self.callbacks]   # in-memory copy (t, value)
+
+    def initialise(self, simulation: Simulation) -> None:
+        if self.rank == 0:
+            for p in self.paths:
+                os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
+            self.files = [open(p, "w") for p in self.paths]
+        if self.store_first:                                                        # :93
+            self.make_step(simulation)
+
+    def make_step(self, simulation: Simulation) -> None:                            # :97-102
+        for i, cb in enumerate(self.callbacks):
+            value = cb(simulation)          # every rank calls: the callback all-reduces
+            self.rows[i].append((simulation.t, value))
+            if self.rank == 0:
+                self.files[i].write(f"{simulation.t} {julia_repr(value)}\n")
+                self.files[i].flush()
+
+    def finalise(self, simulation: Simulation) -> None:
+        if self.store_last:
+            self.make_step(simulation)
+        for f in self.files:
+            f.close()
+        self.files = []
+
+    def write_algorithm(self, io, scheduler) -> None:
+        io.write("\tStoreCallbacks\n")
+        io.write(f"\t\tCalls: {_calls(scheduler)}\n")
+        io.write(f"\t\tCallbacks: {[cb.__name__ for cb in self.callbacks]}\n")
+        io.write(f"\t\tStore first: {str(self.store_first).lower()}\n\t\tStore last: {str(self.store_last).lower()}\n")
+
+
+# ---------------------------------------------------------------------------------------
+# StoreParameters, src/metropolis.jl:380-450
+# ---------------------------------------------------------------------------------------
+class StoreParameters(AriannaAlgorithm):
+    def __init__(self, chains, dependencies=None, path=None, ids=None, store_first: bool = True,
+                 store_last: bool = False, **extras):
+        assert dependencies is not None and len(dependencies) == 1
+        metropolis = dependencies[0]
+        pool = metropolis.pool
+        self.ids = list(range(len(pool))) if ids is None else list(ids)
+        self.parameters_list = [pool[k].parameters for k in self.ids]
+        self.store_first, self.store_last = store_first, store_last
+        self.rank, _ = sharding.world()
+        self.paths = [os.path.join(path, "parameters", str(k + 1), "parameters.dat") for k in self.ids]  # 1-based dirs
+        self.files: List[Any] = []
+        self.rows: List[List[tuple]] = [[] for _ in self.ids]
+
+    def initialise(self, simulation: Simulation) -> None:
+        if self.rank == 0:
+            for p in self.paths:
+                os.makedirs(os.path.dirname(p), exist_ok=True)
+            self.files = [open(p, "w") for p in self.paths]
+        if self.store_first:
+            self.make_step(simulation)
+
+    def make_step(self, simulation: Simulation) -> None:
+        for i, prm in enumerate(self.parameters_list):
+            self.rows[i].append((simulation.t, prm.copy()))
+            if self.rank == 0:
+                self.files[i].write(f"{simulation.t} {julia_repr(prm)}\n")
+                self.files[i].flush()
+
+    def finalise(self, simulation: Simulation) -> None:
+        if self.store_last:
+            self.make_step(simulation)
+        for f in self.files:
+            f.close()
+        self.files = []
+
+    def write_algorithm(self, io, scheduler) -> None:
+        io.write("\tStoreParameters\n")
+        io.write(f"\t\tCalls: {_calls(scheduler)}\n")
+
+
+class PrintTimeSteps(AriannaAlgorithm):
+    """src/algorithms.jl:310-323: progress bar."""
+
+    def __init__(self, chains, **extras):
+        self.rank, _ = sharding.world()
+
+    def make_step(self, simulation: Simulation) -> None:
+        if self.rank != 0:
+            return
+        t = simulation.t
+        percent = t / simulation.steps
+        filled = int(round(percent * 50))
+        bar = "\033[1;34m" + "■" * filled + "\033[0m" + "□" * (50 - filled)
+        sys.stdout.write(f"\rProgress: [{bar}] {percent * 100:.0f}% t = {t}")
+        sys.stdout.flush()

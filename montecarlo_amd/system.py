@@ -1,0 +1,110 @@
+"""The particle_1d model objects a driver script builds (example/particle_1d/particle_1d.jl).
+
+Host-side descriptions only -- the arithmetic runs in the HIP kernels.  Names follow the
+reference: ``Particle`` (:9-16), ``Displacement`` (:26-28), ``StandardGaussian`` (:48-50),
+``Move`` (src/metropolis.jl:140-162).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+POTENTIALS = ("harmonic", "double_well")
+
+
+def potential(name: str, x):
+    """potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2); double well (x^2-1)^2."""
+    x = np.asarray(x, dtype=np.float64)
+    if name == "harmonic":
+        return x * x
+    if name == "double_well":
+        q = x * x - 1.0
+        return q * q
+    raise ValueError(f"unknown potential {name!r}; the HIP engine offers {POTENTIALS}")
+
+
+class ParticleChains:
+    """``chains::Vector{Particle}`` (particle_1d.jl:9-16) as one SoA ensemble description.
+
+    The reference holds M mutable ``Particle(x, beta, e)`` objects; at M = 1e7 that is an
+    HBM-resident f64 array owned by the engine.  This object names the GLOBAL ensemble:
+    its size, beta (scalar or per chain), potential, and where the initial positions come
+    from -- a host array, or ``uniform(lo, hi)`` drawn on device (the example scripts use
+    ``4rand(rng) - 2``, MC_harmonic_oscillator.jl:13).
+    After ``finalise`` the arrays ``x`` / ``e`` hold this rank's shard again.
+    """
+
+    def __init__(self, n_chains: int, beta, potential: str = "harmonic", x: Optional[np.ndarray] = None,
+                 init_uniform: Optional[tuple] = None):
+        if potential not in POTENTIALS:
+            raise ValueError(f"unknown potential {potential!r}; the HIP engine offers {POTENTIALS}")
+        self.n_chains = int(n_chains)
+        self.potential = potential
+        self.beta_array = None
+        if np.ndim(beta) == 0:
+            self.beta = float(beta)
+        else:
+            self.beta_array = np.ascontiguousarray(beta, dtype=np.float64)
+            assert self.beta_array.shape == (self.n_chains,)
+            self.beta = float(self.beta_array[0])
+        self.x = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        if self.x is not None:
+            assert self.x.shape == (self.n_chains,)
+        self.init_uniform = init_uniform
+        self.e = None
+        self.shard = (0, self.n_chains)
+
+    @classmethod
+    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential: str = "harmonic"):
+        return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)))
+
+    def __len__(self) -> int:
+        return self.n_chains
+
+
+@dataclass
+class Displacement:
+    """Action: shift x by delta (particle_1d.jl:26-28)."""
+    delta: float = 0.0
+
+
+@dataclass(frozen=True)
+class StandardGaussian:
+    """Policy: delta ~ Normal(0, sigma) (particle_1d.jl:48-59)."""
+
+    @staticmethod
+    def setup_parameters() -> Dict[str, float]:
+        return {"sigma": 1.0}
+
+
+@dataclass
+class Move:
+    """Move(action, policy, parameters, weight) (src/metropolis.jl:140-162).
+
+    ``parameters`` is a 1-element float array (ComponentArray(sigma=...) in the reference),
+    shared by every chain (metropolis.jl:252-260).  ``total_calls`` / ``accepted_calls`` are
+    pool-wide sums here; per-chain values come from ``Metropolis.download_counters``.
+    """
+    action: Displacement
+    policy: StandardGaussian
+    parameters: np.ndarray
+    weight: float
+    total_calls: int = 0
+    accepted_calls: int = 0
+
+    def __post_init__(self):
+        p = self.parameters
+        if isinstance(p, dict):
+            p = [p["sigma"]]
+        self.parameters = np.atleast_1d(np.asarray(p, dtype=np.float64)).copy()
+        if self.parameters.shape != (1,):
+            raise ValueError("StandardGaussian has exactly one parameter (sigma)")
+        if not isinstance(self.action, Displacement) or not isinstance(self.policy, StandardGaussian):
+            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian policy only")
+        self.weight = float(self.weight)
+
+    @property
+    def sigma(self) -> float:
+        return float(self.parameters[0])

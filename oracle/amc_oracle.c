@@ -663,3 +663,28 @@ int64_t amo_build_schedule_log(int64_t steps, int64_t burn, double base, int64_t
     n = push_unique(out, n, cap, steps);
     return n;
 }
+
+/* Statistic of test/distribution_test.jl:9-39: run `steps` sweeps, pool the positions of all
+ * chains at every scheduled sample time (burn, burn+dt, ..., StoreTrajectories' rows) and
+ * return n, sum x, sum x^2 of the pooled sample.  Also returns the time average of
+ * callback_energy over the same schedule (pgmc_test.jl:45 style) in out[3]. */
+void amo_run_pooled_moments(amo_sim *s, int64_t steps, int64_t burn, int64_t dt, int n_threads, double out[4])
+{
+    /* chains are independent (metropolis.jl:303-307), so each chain runs all its steps in turn */
+    double n = 0.0, sx = 0.0, sxx = 0.0, se = 0.0;
+    const uint64_t t0 = s->t;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 1 ? n_threads : 1) reduction(+ : n, sx, sxx, se)
+#endif
+    for (int64_t c = 0; c < s->M; ++c) {
+        for (int64_t t = 1; t <= steps; ++t) {
+            mc_sweep(s, c, t0 + (uint64_t)(t - 1) * (uint64_t)s->sweepstep, s->sweepstep);
+            if (t >= burn && (t - burn) % dt == 0) {
+                double x = s->chains[c].x;
+                sx += x; sxx += x * x; n += 1.0; se += s->chains[c].e;
+            }
+        }
+    }
+    s->t = t0 + (uint64_t)steps * (uint64_t)s->sweepstep;
+    out[0] = n; out[1] = sx; out[2] = sxx; out[3] = se / n;
+}

@@ -100,6 +100,10 @@ int64_t amo_build_schedule_block(int64_t steps, int64_t burn, const int64_t *blo
 int64_t amo_build_schedule_log(int64_t steps, int64_t burn, double base,
                                int64_t *out, int64_t cap);
 
+/* pooled-position statistic of test/distribution_test.jl (n, sum x, sum x^2, mean energy) */
+void   amo_run_pooled_moments(amo_sim *s, int64_t steps, int64_t burn, int64_t dt, int n_threads,
+                              double out[4]);
+
 int    amo_max_threads(void);
 
 #ifdef __cplusplus

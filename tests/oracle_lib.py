@@ -81,6 +81,7 @@ def load() -> C.CDLL:
         "amo_build_schedule_linear": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int64]),
         "amo_build_schedule_block": (C.c_int64, [C.c_int64, C.c_int64, i64p, C.c_int, i64p, C.c_int64]),
         "amo_build_schedule_log": (C.c_int64, [C.c_int64, C.c_int64, C.c_double, i64p, C.c_int64]),
+        "amo_run_pooled_moments": (None, [S, C.c_int64, C.c_int64, C.c_int64, C.c_int, dp]),
         "amo_max_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -227,6 +228,11 @@ class OracleSim:
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
         out = np.zeros((n, 5))
         self.lib.amo_pg_estimate(self.h, n, ids, int(q_batch), _dptr(out))
+        return out
+
+    def run_pooled_moments(self, steps, burn, dt, threads=1):
+        out = np.zeros(4)
+        self.lib.amo_run_pooled_moments(self.h, int(steps), int(burn), int(dt), int(threads), _dptr(out))
         return out
 
     def set_sigma(self, k, s):

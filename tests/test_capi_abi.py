@@ -1,0 +1,102 @@
+"""C-ABI checks that need no GPU: libamc.so loads, exports every symbol include/amc.h declares,
+agrees with the Python struct layout, and fails loudly (no CPU fallback) without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "amc.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(amc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(amc):
+    lib = amc.load()
+    names = declared_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"libamc.so does not export {name} declared in include/amc.h"
+
+
+def test_python_binding_covers_the_header(amc):
+    lib = amc.load()
+    for name in declared_functions():
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None or name in ("amc_last_error", "amc_version"), f"{name} has no ctypes signature"
+
+
+def test_struct_layout_matches_c(amc, tmp_path):
+    """sizeof / offsets of amc_config as the C compiler sees them == the ctypes mirror."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "amc.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(amc_config), offsetof(amc_config, n_chains), offsetof(amc_config, beta),"
+                   "offsetof(amc_config, sigma), offsetof(amc_config, seed), offsetof(amc_config, stream));return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    S = amc.AmcConfig
+    assert got == [C.sizeof(S), S.n_chains.offset, S.beta.offset, S.sigma.offset, S.seed.offset, S.stream.offset]
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "plain.c"
+    src.write_text('#include "amc.h"\nint main(void){return AMC_OK;}\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "plain.o")], check=True)
+
+
+def test_version(amc):
+    assert amc.load().amc_version() >= 1
+
+
+def test_argument_validation_needs_no_gpu(amc):
+    """Bad arguments are rejected before any device is touched (reference asserts: metropolis.jl:249-251)."""
+    lib = amc.load()
+    h = C.c_void_p()
+    cfg = amc.AmcConfig()
+    assert lib.amc_create(C.byref(cfg), C.byref(h)) == -1          # struct_size = 0: ABI guard
+    assert b"struct_size" in lib.amc_last_error()
+    sig = (C.c_double * 2)(0.1, 0.2)
+    wgt = (C.c_double * 2)(0.5, 0.6)
+    cfg.struct_size = C.sizeof(amc.AmcConfig)
+    cfg.n_chains, cfg.n_chains_global, cfg.n_moves, cfg.sweepstep = 10, 10, 2, 1
+    cfg.sigma, cfg.weight = sig, wgt
+    assert lib.amc_create(C.byref(cfg), C.byref(h)) == -1 and b"sum to 1" in lib.amc_last_error()
+    wgt[1] = 0.5
+    cfg.chain_offset = 3
+    cfg.n_chains_global = 13
+    assert lib.amc_create(C.byref(cfg), C.byref(h)) == -1 and b"even" in lib.amc_last_error()
+    cfg.chain_offset = 0
+    sig[0] = -1.0
+    assert lib.amc_create(C.byref(cfg), C.byref(h)) == -1 and b"sigma" in lib.amc_last_error()
+    assert lib.amc_sweep(None, 1) == -1 and lib.amc_reduce(None, None) == -1
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_fails_loudly_without_a_gpu(amc):
+    """No silent CPU path: constructing the engine without a device raises with a clear message."""
+    assert amc.device_count() == 0
+    with pytest.raises(amc.AmcError, match="no HIP device"):
+        amc.HipEngine(n_chains=10, sigma=[0.1], weight=[1.0])
+    import montecarlo_amd as ma
+    chains = ma.ParticleChains.uniform(10, 2.0)
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 1.0),)
+    with pytest.raises(ma.AmcError):
+        ma.Metropolis(chains, pool=pool)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under montecarlo_amd/ may mention it."""
+    pkg = os.path.join(ROOT, "montecarlo_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle_lib" not in text and "libamc_oracle" not in text and "amo_" not in text, fn

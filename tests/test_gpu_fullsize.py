@@ -1,0 +1,177 @@
+"""BASELINE.json's full sizes (M = 1e7 chains per GPU) on the HIP path: size-independent properties,
+the reference's statistical known answers tightened by the ensemble size, and the host driver
+(Simulation / run / callbacks) running end to end on the device against the oracle engine."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import montecarlo_amd as ma
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
+M_FULL = 10_000_000
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_config2_harmonic_statistics_at_full_size(gpu):
+    """BASELINE config 2: harmonic, beta = 2, sigma = 0.1, M = 1e7.  The reference's targets
+    (distribution_test.jl:36-37, atol 1e-3) hold with margin at this ensemble size."""
+    e = gpu.HipEngine(n_chains=M_FULL, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=1,
+                      per_chain_counters=False)
+    e.init_uniform(-2, 2)
+    e.sweep(3000)                                   # burn-in, fused
+    acc0, tot0 = e.counter_totals()
+    sx = sxx = se = 0.0
+    n = 20
+    for _ in range(n):
+        e.sweep(100)
+        r = e.reduce()
+        se += r[0] / M_FULL
+        sx += r[1] / M_FULL
+        sxx += r[2] / M_FULL
+    acc1, tot1 = e.counter_totals()
+    mean, var = sx / n, sxx / n - (sx / n) ** 2
+    assert mean == pytest.approx(0.0, abs=5e-4)
+    assert math.sqrt(var) == pytest.approx(0.5, abs=5e-4)
+    assert se / n == pytest.approx(0.25, abs=5e-4)                                     # <e> = 1/(2 beta)
+    rate = (acc1[0] - acc0[0]) / (tot1[0] - tot0[0])
+    assert rate == pytest.approx(KATS["analytic"]["acceptance"]["beta=2.0,sigma=0.1"], abs=3e-4)
+    assert tot1[0] == M_FULL * 5000
+    e.close()
+
+
+def test_config3_double_well_mixed_pool_at_full_size(gpu):
+    """BASELINE config 3: U = (x^2 - 1)^2, beta = 2, two sigmas (0.1, 1.0), weights (0.5, 0.5), M = 1e7.
+    Known answers by quadrature: <U> = 0.272864, <x^2> = 0.852136."""
+    from scipy import integrate
+    z = integrate.quad(lambda x: math.exp(-2 * (x * x - 1) ** 2), -4, 4)[0]
+    mean_u = integrate.quad(lambda x: (x * x - 1) ** 2 * math.exp(-2 * (x * x - 1) ** 2), -4, 4)[0] / z
+    mean_x2 = integrate.quad(lambda x: x * x * math.exp(-2 * (x * x - 1) ** 2), -4, 4)[0] / z
+    k = KATS["analytic"]["double_well_beta2"]
+    assert mean_u == pytest.approx(k["mean_U"], abs=1e-6) and mean_x2 == pytest.approx(k["mean_x2"], abs=1e-6)
+    e = gpu.HipEngine(n_chains=M_FULL, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
+    e.init_uniform(-2, 2)
+    e.sweep(400)
+    r = e.reduce()
+    assert r[0] / M_FULL == pytest.approx(mean_u, abs=1.5e-3)
+    assert r[2] / M_FULL == pytest.approx(mean_x2, abs=1.5e-3)
+    assert r[1] / M_FULL == pytest.approx(0.0, abs=1.5e-3)
+    acc, tot = e.counter_totals()
+    assert tot.sum() == M_FULL * 400 and abs(tot[0] / tot.sum() - 0.5) < 1e-3           # categorical pick is fair
+    ratio = r[4:] / M_FULL
+    assert np.allclose(ratio, acc / tot, atol=2e-3) and ratio[0] > ratio[1]               # small steps accept more
+    e.close()
+
+
+def test_full_size_properties(gpu):
+    """Properties that need no oracle run at 1e7: determinism, fused == stepwise, shard invariance,
+    e == potential(x), counter conservation."""
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=11)
+    a = gpu.HipEngine(n_chains=M_FULL, **kw)
+    b = gpu.HipEngine(n_chains=M_FULL, **kw)
+    a.init_uniform(-2, 2)
+    b.init_uniform(-2, 2)
+    a.sweep(12)
+    for _ in range(12):
+        b.sweep(1)
+    xa, ea = a.download_state()
+    xb, _ = b.download_state()
+    assert np.array_equal(bits(xa), bits(xb))                       # fused == stepwise, run-to-run deterministic
+    assert np.array_equal(ea, xa * xa)
+    acc_a, tot_a = a.download_counters()
+    assert tot_a.min() == tot_a.max() == 12 and acc_a.max() <= 12
+    assert acc_a.sum() == a.counter_totals()[0][0] == b.counter_totals()[0][0]
+    b.close()
+    # two half-size shards reproduce the whole
+    half = M_FULL // 2
+    parts = []
+    for off in (0, half):
+        p = gpu.HipEngine(n_chains=half, chain_offset=off, n_chains_global=M_FULL, **kw)
+        p.init_uniform(-2, 2)
+        p.sweep(12)
+        parts.append(p.download_state()[0])
+        p.close()
+    assert np.array_equal(bits(np.concatenate(parts)), bits(xa))
+    # reductions are deterministic (two-pass, fixed order) and consistent with a host sum
+    r1, r2 = a.reduce(), a.reduce()
+    assert np.array_equal(bits(r1), bits(r2))
+    assert r1[0] == pytest.approx(float(np.sum(ea)), rel=1e-11) and r1[1] == pytest.approx(float(np.sum(xa)), abs=1e-6)
+    assert r1[4] / M_FULL == pytest.approx(acc_a.sum() / (12 * M_FULL), rel=1e-12)
+    a.close()
+
+
+def test_slice_of_full_size_run_matches_oracle(gpu, oracle):
+    """Chains are independent and keyed by global id: an oracle run of a 4096-chain slice taken from the
+    middle of the 1e7 ensemble must equal the same slice of the device run, bit for bit."""
+    kw = dict(potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=123)
+    e = gpu.HipEngine(n_chains=M_FULL, **kw)
+    e.init_uniform(-2, 2)
+    e.sweep(20)
+    x, _ = e.download_state()
+    acc, tot = e.download_counters()
+    for off in (0, 5_000_000, M_FULL - 4096):
+        o = oracle.OracleSim(4096, chain_offset=off, **kw)
+        o.init_uniform(-2, 2)
+        o.make_steps(20, threads=4)
+        assert np.array_equal(bits(x[off:off + 4096]), bits(o.state()[0]))
+        ao, to = o.counters()
+        assert np.array_equal(acc[:, off:off + 4096], ao) and np.array_equal(tot[:, off:off + 4096], to)
+    e.close()
+
+
+# ---- the host driver on the device -------------------------------------------------------------------------------
+def _run_config1(engine_factory, path, steps=3000):
+    chains = ma.ParticleChains.uniform(10, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 1.0),)
+    sampletimes = ma.build_schedule(steps, 1000, [0, 10])
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, parallel=False, engine_factory=engine_factory),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance), scheduler=sampletimes))
+    sim = ma.Simulation(chains, al, steps, path=str(path))
+    ma.run(sim)
+    return sim, pool
+
+
+def test_config1_driver_on_device_matches_oracle_engine(gpu, oracle, tmp_path):
+    """BASELINE config 1 (MC_harmonic_oscillator.jl: M = 10, beta = 2, sigma = 0.1, seed 42) through
+    Simulation / run / StoreCallbacks on the GPU; same rows as the oracle-backed run."""
+    dev, pool_d = _run_config1(None, tmp_path / "hip")
+    ref, pool_r = _run_config1(oracle.OracleEngine, tmp_path / "cpu")
+    assert isinstance(dev.algorithms[0].engine, gpu.HipEngine)
+    assert np.array_equal(bits(dev.chains.x), bits(ref.chains.x)) and np.array_equal(bits(dev.chains.e), bits(ref.chains.e))
+    assert (pool_d[0].accepted_calls, pool_d[0].total_calls) == (pool_r[0].accepted_calls, pool_r[0].total_calls)
+    rows_d, rows_r = dev.algorithms[1].rows, ref.algorithms[1].rows
+    assert [t for t, _ in rows_d[0]] == [t for t, _ in rows_r[0]] and len(rows_d[0]) == 202
+    np.testing.assert_allclose([v for _, v in rows_d[0]], [v for _, v in rows_r[0]], rtol=1e-13)
+    np.testing.assert_allclose(np.array([v for _, v in rows_d[1]]), np.array([v for _, v in rows_r[1]]), rtol=1e-13,
+                               equal_nan=True)
+    assert open(tmp_path / "hip" / "acceptance.dat").readline() == "0 [NaN]\n"
+
+
+def test_config5_pgmc_learns_sigma_on_device(gpu, tmp_path):
+    """BASELINE config 5 at reduced M: PGMC_harmonic_oscillator.jl pool (sigma 0.2 / 0.1, weights 0.6 / 0.4),
+    optimisers (Static, VPG); with 1e5 chains the gradient is ~1e4x less noisy than the example's M = 10,
+    so a larger eta reaches the plateau sigma* ~ 1.2 (pgmc_test.jl:50, atol 0.2) in 400 updates."""
+    M, steps = 100_000, 400
+    chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
+            ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.5))),
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
+               scheduler=ma.build_schedule(steps, 200, 20)))
+    sim = ma.Simulation(chains, al, steps, path=str(tmp_path))
+    ma.run(sim)
+    assert pool[0].sigma == 0.2                                             # Static stays exactly
+    assert pool[1].sigma == pytest.approx(KATS["pgmc"]["sigma_star"], abs=KATS["pgmc"]["sigma_atol"])
+    assert sim.algorithms[0].engine.get_parameters(1)[0] == pool[1].sigma   # device copy follows the host array
+    energies = [v for t, v in sim.algorithms[3].rows[0] if t >= 200]
+    assert np.mean(energies) == pytest.approx(0.25, abs=5e-3)

@@ -1,0 +1,290 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors.  Bit-exact for chain state, energies and accept counts; reductions within a stated
+relative tolerance (summation order differs; the reference itself is order-unstable under foldxt).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RED_RTOL = 1e-10      # device tree-sum vs the oracle's left-to-right sum
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def fh(lst):
+    return np.array([float.fromhex(v) for v in lst])
+
+
+# ---- arithmetic spec primitives on the device -------------------------------------------------------
+def test_device_math_bit_exact(gpu, oracle):
+    lib = oracle.load()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-708, 5, 200000), rng.uniform(-1e-3, 1e-3, 1000),
+                         [0.0, -0.0, 1e-300, -1e-300, -708.0, -708.5, -745.0, 709.0, 709.5, np.inf, -np.inf, np.nan]])
+    assert np.array_equal(bits(gpu.selftest_math("exp", xs)), bits([lib.amo_exp(v) for v in xs]))
+    xs = np.concatenate([rng.uniform(0, 1, 200000), np.exp(rng.uniform(-700, 700, 50000)),
+                         [1.0, 2.0 ** -53, 5e-324, 2.2e-308, 0.0, np.inf, -1.0, np.nan]])
+    assert np.array_equal(bits(gpu.selftest_math("log", xs)), bits([lib.amo_log(v) for v in xs]))
+    ws = np.concatenate([(rng.integers(0, 2 ** 53, 200000) + 1) * 2.0 ** -52, [0.25, 0.5, 1.0, 1.5, 2.0, 2.0 ** -52]])
+    ref = np.array([oracle.sincospi(v) for v in ws])
+    assert np.array_equal(bits(gpu.selftest_math("sinpi", ws)), bits(ref[:, 0]))
+    assert np.array_equal(bits(gpu.selftest_math("cospi", ws)), bits(ref[:, 1]))
+
+
+def test_device_sqrt_and_division_are_ieee(gpu):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.uniform(0, 80, 300000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, np.inf, 4.0]])
+    assert np.array_equal(bits(gpu.selftest_math("sqrt", a)), bits(np.sqrt(a)))
+    num = -rng.uniform(0, 30, 400000) ** 2
+    den = 2 * np.exp(rng.uniform(-6, 3, 400000)) ** 2
+    assert np.array_equal(bits(gpu.selftest_math("div", num, den)), bits(num / den))
+
+
+def test_device_philox_words(gpu, oracle):
+    rng = np.random.default_rng(2)
+    for seed, draw, stream in [(1, 0, 1), (0x123456789ABCDEF, 5, 2), (2 ** 64 - 1, 4095, 0)]:
+        pairs = rng.integers(0, 2 ** 40, 500).astype(np.uint64)
+        ts = rng.integers(0, 2 ** 47, 500).astype(np.uint64)
+        dev = gpu.selftest_philox(seed, pairs, ts, draw, stream)
+        ref = np.array([oracle.draw_words(seed, int(p), int(t), draw, stream) for p, t in zip(pairs, ts)], dtype=np.uint32)
+        assert np.array_equal(dev, ref)
+    kat = json.load(open(os.path.join(GOLDEN, "philox_kats.json")))
+    for d in kat["draw_schedule"]:
+        dev = gpu.selftest_philox(d["seed"], np.array([d["pair"]], dtype=np.uint64), np.array([d["t"]], dtype=np.uint64),
+                                  d["draw"], d["stream"])
+        assert dev[0].tolist() == d["words"]
+
+
+# ---- the sweep: HIP vs oracle ----------------------------------------------------------------------------
+POOLS = {1: ([0.1], [1.0]), 2: ([0.1, 1.0], [0.5, 0.5]), 3: ([0.1, 1.0, 0.3], [0.2, 0.5, 0.3]),
+         7: ([0.2] * 7, [0.4] + [0.1] * 6)}
+
+
+def run_pair(gpu, oracle, M, K, potential, sweeps, sweepstep=1, counters=True, offset=0, fused=False,
+             beta=2.0, beta_arr=None, seed=7, x0=None):
+    sigma, weight = POOLS[K]
+    e = gpu.HipEngine(n_chains=M, chain_offset=offset, n_chains_global=offset + M, potential=potential, beta=beta,
+                      sigma=sigma, weight=weight, seed=seed, sweepstep=sweepstep, per_chain_counters=counters)
+    o = oracle.OracleSim(M, chain_offset=offset, potential=potential, beta=beta, sigma=sigma, weight=weight, seed=seed,
+                         sweepstep=sweepstep)
+    if x0 is None:
+        e.init_uniform(-2, 2)
+        o.init_uniform(-2, 2)
+    else:
+        e.upload_state(x0)
+        o.set_x(x0)
+    if beta_arr is not None:
+        e.upload_state(o.state()[0], beta_arr)
+        o.set_beta(beta_arr)
+    if fused:
+        e.sweep(sweeps)
+    else:
+        for _ in range(sweeps):
+            e.sweep(1)
+    o.make_steps(sweeps)
+    return e, o
+
+
+def assert_same(e, o, counters=True):
+    x, en = e.download_state()
+    xo, eo = o.state()
+    assert np.array_equal(bits(x), bits(xo)), f"x differs on {np.count_nonzero(bits(x) != bits(xo))} chains"
+    assert np.array_equal(bits(en), bits(eo))
+    acc, tot = e.counter_totals()
+    ao, to = o.counters()
+    assert np.array_equal(acc, ao.sum(1)) and np.array_equal(tot, to.sum(1))      # accept counts bit-exact
+    if counters:
+        a2, t2 = e.download_counters()
+        assert np.array_equal(a2, ao) and np.array_equal(t2, to)
+    red = e.reduce()
+    M = x.size
+    assert red[3] == M
+    assert red[0] / M == pytest.approx(o.energy(), rel=RED_RTOL)
+    mom = o.moments()
+    assert red[1] == pytest.approx(mom[0], rel=1e-9, abs=1e-9 * M) and red[2] == pytest.approx(mom[1], rel=RED_RTOL)
+    np.testing.assert_allclose(red[4:] / M, o.acceptance(), rtol=RED_RTOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("M,K,potential,sweeps,sweepstep", [
+    (1, 1, "harmonic", 10, 1),                # a single chain (half-empty pair)
+    (2, 2, "double_well", 10, 1),
+    (10, 1, "harmonic", 200, 1),              # BASELINE config 1 shape
+    (1000, 1, "harmonic", 50, 1),
+    (1001, 1, "harmonic", 20, 3),             # odd M: ragged tail lane
+    (4097, 2, "double_well", 30, 2),          # BASELINE config 3 shape
+    (777, 3, "harmonic", 25, 1),
+    (513, 7, "harmonic", 12, 1),              # pgmc_test.jl pool: 7 moves
+    (65536, 1, "harmonic", 8, 1),
+])
+def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
+    e, o = run_pair(gpu, oracle, M, K, potential, sweeps, sweepstep)
+    assert_same(e, o)
+    e.close()
+
+
+def test_sweep_bit_exact_beyond_one_grid(gpu, oracle):
+    """More pairs than 2048 x 256 threads: the grid-stride path, sweeps x M = 3.6e6 updates."""
+    e, o = run_pair(gpu, oracle, 1_200_001, 1, "harmonic", 3)
+    assert_same(e, o)
+    e.close()
+
+
+def test_pool_wide_counter_mode(gpu, oracle):
+    """per_chain_counters = 0 (the benchmark's 16 B/update mode): x and the accepted total still exact."""
+    e, o = run_pair(gpu, oracle, 5000, 1, "harmonic", 20, counters=False)
+    assert_same(e, o, counters=False)
+    with pytest.raises(gpu.AmcError, match="per_chain_counters"):
+        e.download_counters()
+    e.close()
+
+
+def test_fused_launch_equals_separate_launches(gpu, oracle):
+    e, o = run_pair(gpu, oracle, 3000, 2, "harmonic", 16, sweepstep=2, fused=True)
+    assert_same(e, o)
+    e.close()
+
+
+def test_shard_at_offset_and_shard_invariance_on_one_device(gpu, oracle):
+    e, o = run_pair(gpu, oracle, 3001, 2, "harmonic", 16, offset=123456)
+    assert_same(e, o)
+    e.close()
+    # the same global range as 1 shard and as 3 shards on one device
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=5)
+    whole = gpu.HipEngine(n_chains=1001, **kw)
+    whole.init_uniform(-2, 2)
+    whole.sweep(25)
+    parts = []
+    for start, stop in [(0, 334), (334, 700), (700, 1001)]:
+        p = gpu.HipEngine(n_chains=stop - start, chain_offset=start, n_chains_global=1001, **kw)
+        p.init_uniform(-2, 2)
+        p.sweep(25)
+        parts.append((p.download_state()[0], p.download_counters()[0]))
+        p.close()
+    assert np.array_equal(bits(np.concatenate([p[0] for p in parts])), bits(whole.download_state()[0]))
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), whole.download_counters()[0])
+    whole.close()
+
+
+def test_per_chain_beta(gpu, oracle):
+    b = np.random.default_rng(1).uniform(1.0, 3.0, 2049)
+    e, o = run_pair(gpu, oracle, 2049, 1, "double_well", 16, beta_arr=b)
+    assert_same(e, o)
+    e.close()
+
+
+def test_uploaded_state_and_nonfinite_chains(gpu, oracle):
+    """Edge cases the domain has: chains at +-inf / NaN never accept and stay put (alpha = NaN, Julia min);
+    huge |x| overflows e to inf; -0.0 survives."""
+    x0 = np.random.default_rng(3).uniform(-2, 2, 64)
+    x0[[0, 1, 2, 3, 4, 5]] = [np.inf, -np.inf, np.nan, 1e200, -0.0, 1e-320]
+    e, o = run_pair(gpu, oracle, 64, 1, "harmonic", 20, x0=x0)
+    assert_same(e, o)
+    x, _ = e.download_state()
+    acc, _ = e.download_counters()
+    assert np.isposinf(x[0]) and np.isneginf(x[1]) and np.isnan(x[2]) and np.all(acc[0, :3] == 0)
+    e.close()
+
+
+def test_parameter_update_and_step_counter(gpu, oracle):
+    """amc_set_parameters (learning_step! result) and amc_set_step (resume) keep parity."""
+    e, o = run_pair(gpu, oracle, 999, 2, "harmonic", 5)
+    e.set_parameters(1, [0.37])
+    o.set_sigma(1, 0.37)
+    assert e.get_parameters(1)[0] == 0.37
+    e.sweep(5)
+    o.make_steps(5)
+    assert_same(e, o)
+    assert e.step == 10 == o.step
+    e.step = 1 << 33
+    o.step = 1 << 33
+    e.sweep(3)
+    o.make_steps(3)
+    x, _ = e.download_state()
+    assert np.array_equal(bits(x), bits(o.state()[0]))
+    with pytest.raises(gpu.AmcError):
+        e.set_parameters(0, [-1.0])
+    with pytest.raises(gpu.AmcError):
+        e.set_parameters(5, [0.1])
+    e.close()
+
+
+def test_first_row_acceptance_is_nan(gpu):
+    """callback_acceptance at t = 0 is 0/0 = NaN per move (store_first row, algorithms.jl:93)."""
+    for K, counters in [(1, True), (1, False), (2, True)]:
+        sigma, weight = POOLS[K]
+        e = gpu.HipEngine(n_chains=100, sigma=sigma, weight=weight, per_chain_counters=counters)
+        assert np.all(np.isnan(e.reduce()[4:]))
+        e.close()
+
+
+# ---- golden vectors -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("idx", range(4))
+def test_hip_matches_golden_trajectories(gpu, idx):
+    case = json.load(open(os.path.join(GOLDEN, "oracle_trajectories.json")))["cases"][idx]
+    sp = case["spec"]
+    e = gpu.HipEngine(n_chains=sp["M"], chain_offset=sp["offset"], n_chains_global=sp["offset"] + sp["M"],
+                      potential=sp["potential"], beta=sp["beta"], sigma=sp["sigma"], weight=sp["weight"],
+                      seed=sp["seed"], sweepstep=sp["sweepstep"])
+    e.init_uniform(-2.0, 2.0)
+    done = 0
+    for snap in case["snapshots"]:
+        e.sweep(snap["sweep"] - done)
+        done = snap["sweep"]
+        x, en = e.download_state()
+        assert np.array_equal(bits(x), bits(fh(snap["x"]))) and np.array_equal(bits(en), bits(fh(snap["e"])))
+        acc, tot = e.download_counters()
+        assert acc.tolist() == snap["accepted"] and tot.tolist() == snap["total"]
+        if "energy" in snap:
+            red = e.reduce()
+            assert red[0] / sp["M"] == pytest.approx(float.fromhex(snap["energy"]), rel=1e-14)
+            np.testing.assert_allclose(red[4:] / sp["M"], fh(snap["acceptance"]), rtol=1e-14, equal_nan=True)
+    e.sweep(256 - done)
+    g = e.pg_estimate(list(range(len(sp["sigma"]))), 3)
+    np.testing.assert_allclose(g.ravel(), fh(case["pg_estimate_q3"]), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(bits(e.download_state()[0]), bits(fh(case["x_after_pg"])))
+    e.close()
+
+
+# ---- policy-gradient estimator --------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,learn,q", [(5001, [1, 2], 3), (1000, [0], 1), (64, [0, 1, 2], 10), (2047, [2, 0], 2)])
+def test_pg_estimate_parity(gpu, oracle, M, learn, q):
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1, 0.4], weight=[0.5, 0.25, 0.25], seed=3)
+    e = gpu.HipEngine(n_chains=M, **kw)
+    o = oracle.OracleSim(M, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    e.sweep(5)
+    o.make_steps(5)
+    for _ in range(3):          # the estimator call index advances the Philox counter
+        g, go = e.pg_estimate(learn, q), o.pg_estimate(learn, q)
+        scale = np.abs(go).max(axis=0) + 1.0
+        assert np.all(np.abs(g - go) <= 1e-10 * scale * np.sqrt(M * q))
+        assert np.array_equal(g[:, 4], go[:, 4])
+        assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))   # (x+d)-d drift reproduced exactly
+    e.close()
+
+
+def test_pg_estimate_seven_move_pool(gpu, oracle):
+    """pgmc_test.jl shape: 7 moves, 6 learnable, q_batch_size 10."""
+    sigma, weight = POOLS[7]
+    kw = dict(potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=42)
+    e = gpu.HipEngine(n_chains=10, **kw)
+    o = oracle.OracleSim(10, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    g, go = e.pg_estimate([1, 2, 3, 4, 5, 6], 10), o.pg_estimate([1, 2, 3, 4, 5, 6], 10)
+    np.testing.assert_allclose(g, go, rtol=1e-11, atol=1e-11)
+    assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    with pytest.raises(gpu.AmcError):
+        e.pg_estimate([0, 1, 2, 3, 4, 5, 6, 0, 1], 1)          # > AMC_MAX_LEARN
+    with pytest.raises(gpu.AmcError):
+        e.pg_estimate([9], 1)
+    e.close()

@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's driver (Simulation / run / schedules / callbacks / optimisers),
+exercised on CPU through the engine_factory test seam with the oracle as the engine."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import montecarlo_amd as ma
+from montecarlo_amd import policy_guided as pg
+
+
+def make_sim(oracle, path, M=10, steps=300, burn=50, pool=None, extra=(), fuse_sched=None, seed=42, sweepstep=1):
+    chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+    pool = pool or (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 1.0),)
+    sampletimes = ma.build_schedule(steps, burn, [0, 10])
+    algorithm_list = (
+        dict(algorithm=ma.Metropolis, pool=pool, seed=seed, sweepstep=sweepstep, engine_factory=oracle.OracleEngine),
+        *extra,
+        dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
+             scheduler=fuse_sched or sampletimes),
+    )
+    return ma.Simulation(chains, algorithm_list, steps, path=str(path)), pool
+
+
+def test_build_schedule_matches_the_c_restatement(oracle):
+    for args in [(10 ** 5, 1000, [0, 10]), (1000, 0, [0, 1, 5]), (100, 10, 30), (100, 10, 45), (10 ** 4, 100, 1000),
+                 (1000, 10, 2.0), (10 ** 5, 1000, 10.0), (977, 13, [0, 3, 7])]:
+        assert ma.build_schedule(*args) == oracle.build_schedule(*args), args
+    with pytest.raises(ValueError):
+        ma.build_schedule(1000, 10, 1.5)
+
+
+def test_julia_repr():
+    assert ma.julia_repr(0.25) == "0.25" and ma.julia_repr(1e-5) == "1.0e-5" and ma.julia_repr(1e6) == "1.0e6"
+    assert ma.julia_repr(100000.0) == "100000.0" and ma.julia_repr(float("nan")) == "NaN"
+    assert ma.julia_repr(np.array([0.5, float("nan")])) == "[0.5, NaN]" and ma.julia_repr(-0.0) == "-0.0"
+    assert ma.julia_repr(0.1 + 0.2) == "0.30000000000000004" and ma.julia_repr(1234567.0) == "1.234567e6"
+
+
+def test_config1_plumbing_rows_and_first_row(oracle, tmp_path):
+    """MC_harmonic_oscillator.jl at reduced length: callback files get one row at t = 0 (store_first,
+    acceptance = 0/0 = NaN) plus one per schedule entry; "$t $(value)" format."""
+    sim, pool = make_sim(oracle, tmp_path, steps=2000, burn=100)
+    ma.run(sim)
+    energy = open(tmp_path / "energy.dat").read().splitlines()
+    acc = open(tmp_path / "acceptance.dat").read().splitlines()
+    n_sched = len(ma.build_schedule(2000, 100, [0, 10]))
+    assert len(energy) == len(acc) == n_sched + 1
+    assert acc[0] == "0 [NaN]" and energy[0].startswith("0 ")
+    assert [int(r.split()[0]) for r in energy[1:4]] == [100, 110, 120] and energy[-1].startswith("2000 ")
+    assert pool[0].total_calls == 10 * 2000 and 0 < pool[0].accepted_calls < pool[0].total_calls
+    summary = open(tmp_path / "summary.log").read()
+    assert "Metropolis" in summary and "Calls: 2000" in summary and "Simulation time" in summary
+    assert sim.chains.x.shape == (10,) and np.array_equal(sim.chains.e, sim.chains.x ** 2)
+
+
+def test_fused_run_equals_stepwise_run(oracle, tmp_path):
+    """run(fuse=True) batches sweeps nobody observes; every row and the final state are identical."""
+    rows = []
+    for i, fuse in enumerate((False, True)):
+        sim, _ = make_sim(oracle, tmp_path / str(i), steps=500, burn=40)
+        ma.run(sim, fuse=fuse)
+        rows.append((open(tmp_path / str(i) / "energy.dat").read(), open(tmp_path / str(i) / "acceptance.dat").read(),
+                     sim.chains.x.copy()))
+    assert rows[0][0] == rows[1][0] and rows[0][1] == rows[1][1] and np.array_equal(rows[0][2], rows[1][2])
+
+
+def test_fusion_issues_few_launches(oracle, tmp_path):
+    calls = []
+
+    class Counting(oracle.OracleEngine):
+        def sweep(self, n=1):
+            calls.append(n)
+            super().sweep(n)
+
+    chains = ma.ParticleChains.uniform(4, 2.0)
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 1.0),)
+    al = (dict(algorithm=ma.Metropolis, pool=pool, engine_factory=Counting),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy,), scheduler=[100, 200, 300]))
+    ma.run(ma.Simulation(chains, al, 300, path=str(tmp_path)))
+    assert calls == [99, 1, 99, 1, 99, 1] and sum(calls) == 300
+
+
+def test_sweepstep_is_mc_steps_per_sweep(oracle, tmp_path):
+    """metropolis.jl:205: one make_step! = sweepstep mc_step!s; sweepstep=3 x 100 sweeps == 300 single steps."""
+    a, _ = make_sim(oracle, tmp_path / "a", steps=100, burn=10, sweepstep=3)
+    b, _ = make_sim(oracle, tmp_path / "b", steps=300, burn=10, sweepstep=1)
+    ma.run(a)
+    ma.run(b)
+    assert np.array_equal(a.chains.x, b.chains.x)
+
+
+def test_dependencies_resolved_by_type(oracle, tmp_path):
+    """simulation.jl:77-81: dependencies=(Metropolis,) becomes the previously built instance."""
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
+            ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+    extra = (dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.001))),
+             dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+             dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=[50, 100]))
+    sim, pool = make_sim(oracle, tmp_path, steps=100, burn=10, pool=pool, extra=extra)
+    met, est, upd, prm, _cb = sim.algorithms
+    assert est.metropolis is met and upd.estimator is est and est.learn_ids == [1]
+    assert prm.parameters_list[1] is pool[1].parameters          # shared object, like the aliasing at metropolis.jl:252-260
+    ma.run(sim)
+    assert pool[0].sigma == 0.2                                  # Static never moves (estimator.jl:72)
+    assert pool[1].sigma != 0.1 and met.engine.get_parameters(1)[0] == pool[1].sigma
+    rows = open(tmp_path / "parameters" / "2" / "parameters.dat").read().splitlines()
+    assert [r.split()[0] for r in rows] == ["0", "50", "100"] and rows[0] == "0 [0.1]"
+
+
+def test_callbacks_require_exactly_one_metropolis(oracle, tmp_path):
+    chains = ma.ParticleChains.uniform(4, 2.0)
+    al = (dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy,)),)
+    with pytest.raises(ValueError):
+        ma.run(ma.Simulation(chains, al, 3, path=str(tmp_path)))
+
+
+def test_constructor_errors(oracle):
+    chains = ma.ParticleChains.uniform(4, 2.0)
+    with pytest.raises(ValueError):
+        ma.Metropolis(chains, pool=None, engine_factory=oracle.OracleEngine)
+    with pytest.raises(TypeError):
+        ma.Metropolis(chains, pool=("move",), engine_factory=oracle.OracleEngine)
+    with pytest.raises(ValueError):
+        ma.ParticleChains(4, 2.0, potential="lennard_jones")
+    with pytest.raises(ValueError):
+        ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1, 0.2], 1.0)
+    with pytest.raises(AssertionError):
+        ma.Simulation(chains, (dict(algorithm=ma.StoreCallbacks, callbacks=(), scheduler=[5, 3]),), 10, path="/tmp/x_amc")
+
+
+# ---- optimisers: learning.jl vs the oracle's C restatement (P = 1) ----------------------------------------
+@pytest.mark.parametrize("name,opt,h0,h1", [
+    ("VPG", pg.VPG(1e-3), 1e-3, 0.0), ("BLPG", pg.BLPG(1e-3), 1e-3, 0.0), ("BLAPG", pg.BLAPG(1e-6, 1e-6), 1e-6, 1e-6),
+    ("NPG", pg.NPG(1e-2, 1e-6), 1e-2, 1e-6), ("ANPG", pg.ANPG(1e-6, 1e-6), 1e-6, 1e-6),
+    ("BLANPG", pg.BLANPG(1e-6, 1e-6), 1e-6, 1e-6), ("Static", pg.Static(), 0.0, 0.0)])
+def test_learning_step_matches_oracle(oracle, name, opt, h0, h1):
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        theta = rng.uniform(0.05, 2.0)
+        j, dj, dlq, g = rng.uniform(0, 0.3), rng.normal(0, 0.2), rng.normal(0, 1), rng.uniform(0.1, 30)
+        p = np.array([theta])
+        gd = pg.GradientData(j, np.array([dj]), np.array([dlq]), np.array([[g]]), 1)
+        pg.learning_step(p, gd, opt)
+        want = oracle.learning_step(name, h0, h1, theta, [j, dj, dlq, g])
+        assert p[0] == pytest.approx(want, rel=1e-14, abs=1e-300)
+
+
+def test_gradient_data_algebra():
+    a = pg.GradientData(1.0, np.array([2.0]), np.array([3.0]), np.array([[4.0]]), 2)
+    s = a + a
+    assert (s.j, s.grad_j[0], s.grad_logq_forward[0], s.g[0, 0], s.n) == (2.0, 4.0, 6.0, 8.0, 4)
+    m = pg.average(s)
+    assert (m.j, m.grad_j[0], m.g[0, 0], m.n) == (0.5, 1.0, 2.0, 4)
+    z = pg.initialise_gradient_data(np.array([0.2]))
+    assert z.j == 0.0 and z.n == 0 and z.g.shape == (1, 1)
+
+
+def test_shard_range_even_boundaries_and_cover():
+    for n in (1, 2, 7, 10, 101, 10 ** 7, 8 * 10 ** 7 + 3):
+        for w in (1, 2, 3, 8):
+            if n < 2 * w - 1:
+                continue
+            rs = [ma.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            assert all(a % 2 == 0 for a, _ in rs)
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 3      # one pair of imbalance + the odd tail chain

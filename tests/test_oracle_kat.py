@@ -1,0 +1,265 @@
+"""Pins the CPU oracle: published KATs of its third-party pieces, the reference's closed forms,
+the committed golden vectors, and per-function behaviour of the restated Julia code (CPU only)."""
+import json
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def fh(lst):
+    return np.array([float.fromhex(v) for v in lst])
+
+
+def ulp_err(a, b):
+    return 0.0 if a == b else abs(a - b) / math.ulp(b)
+
+
+# ---- Philox4x32-10 and the draw schedule ------------------------------------------------------
+def test_philox_random123_kat(oracle):
+    for kat in load_json("philox_kats.json")["random123_kat"]:
+        assert oracle.philox(kat["ctr"], kat["key"]) == kat["out"]
+
+
+def test_draw_schedule_golden(oracle):
+    for d in load_json("philox_kats.json")["draw_schedule"]:
+        assert oracle.counter(d["pair"], d["t"], d["draw"], d["stream"]) == d["counter"]
+        w = oracle.draw_words(d["seed"], d["pair"], d["t"], d["draw"], d["stream"])
+        assert w == d["words"]
+        assert list(oracle.box_muller(w)) == list(fh(d["box_muller"]))
+        lib = oracle.load()
+        assert lib.amo_uniform53(w[0], w[1]) == float.fromhex(d["u53"][0])
+        assert lib.amo_uniform53(w[2], w[3]) == float.fromhex(d["u53"][1])
+        assert lib.amo_uniform32(w[0]) == float.fromhex(d["u32"])
+
+
+def test_counter_packing_is_rocrand_layout(oracle):
+    # x = step low word, y = step[47:32] | draw<<16 | stream<<28, (z, w) = pair id (rocRAND "subsequence")
+    c = oracle.counter((7 << 32) | 9, (0xABCD << 32) | 0x12345678, 0xFFF, 0xF)
+    assert c == [0x12345678, 0xABCD | (0xFFF << 16) | (0xF << 28), 9, 7]
+    # distinct draws / streams / steps / pairs never collide
+    seen = set()
+    for pair in (0, 1, 2 ** 32):
+        for t in (0, 1, 2 ** 32, 2 ** 47):
+            for draw in (0, 1, 2, 4095):
+                for stream in (0, 1, 2):
+                    seen.add(tuple(oracle.counter(pair, t, draw, stream)))
+    assert len(seen) == 3 * 4 * 4 * 3
+
+
+def test_uniform_maps(oracle):
+    lib = oracle.load()
+    assert lib.amo_uniform53(0, 0) == 0.0                              # [0, 1): 0 included ...
+    assert lib.amo_uniform53(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -53   # ... 1 excluded (Julia rand())
+    assert lib.amo_uniform53(1, 0) == 2.0 ** -53
+    assert lib.amo_uniform53(0, 1 << 11) == 2.0 ** -21
+    assert lib.amo_uniform53(0, (1 << 11) - 1) == 0.0                  # low 11 bits of the high word unused
+    assert lib.amo_uniform32(0) == 0.0 and lib.amo_uniform32(0xFFFFFFFF) == 1.0 - 2.0 ** -32
+
+
+def test_box_muller_is_rocrand_map(oracle):
+    # rocrand_normal.h:78-98: u = 2^-53 + v1*2^-53, w = 2^-52 + v2*2^-52, z = sqrt(-2 log u)*(sinpi w, cospi w)
+    rnd = random.Random(3)
+    for _ in range(2000):
+        v = [rnd.getrandbits(32) for _ in range(4)]
+        v1 = v[0] ^ (v[1] << 21)
+        v2 = v[2] ^ (v[3] << 21)
+        u = 2.0 ** -53 + v1 * 2.0 ** -53
+        w = 2.0 ** -52 + v2 * 2.0 ** -52
+        s = math.sqrt(-2.0 * math.log(u))
+        z0, z1 = oracle.box_muller(v)
+        r = math.fmod(w, 2.0)
+        assert z0 == pytest.approx(s * math.sin(math.pi * r), rel=1e-13, abs=1e-14)
+        assert z1 == pytest.approx(s * math.cos(math.pi * r), rel=1e-13, abs=1e-14)
+    # u = 1 (v1 = 2^53 - 1) gives exactly zero radius, never NaN / inf
+    assert all(abs(z) == 0.0 for z in oracle.box_muller([0x001FFFFF, 0xFFFFFFFF, 5, 5]))
+    z0, z1 = oracle.box_muller([0, 0, 0, 0])           # u = 2^-53: the largest radius, finite
+    assert math.isfinite(z0) and math.isfinite(z1) and math.hypot(z0, z1) == pytest.approx(math.sqrt(2 * 53 * math.log(2)))
+
+
+def test_normal_moments(oracle):
+    z = np.array([oracle.box_muller(oracle.draw_words(11, p, 3, 0, 1)) for p in range(100000)]).ravel()
+    assert abs(z.mean()) < 4 / math.sqrt(z.size)
+    assert abs(z.var() - 1) < 4 * math.sqrt(2 / z.size)
+    assert abs((z ** 4).mean() - 3) < 0.1
+
+
+# ---- own exp / log / sincospi ------------------------------------------------------------------
+def test_exp_accuracy_and_edges(oracle):
+    lib = oracle.load()
+    rnd = random.Random(1)
+    worst = max(ulp_err(lib.amo_exp(x), math.exp(x)) for x in (rnd.uniform(-708, 700) for _ in range(100000)))
+    assert worst <= 1.0
+    assert lib.amo_exp(0.0) == 1.0 and lib.amo_exp(-0.0) == 1.0
+    assert all(lib.amo_exp(x) >= 1.0 for x in (1e-300, 1e-17, 1e-9, 0.5, 700.0))   # alpha = 1 whenever dlogp >= 0
+    assert all(lib.amo_exp(-x) <= 1.0 for x in (1e-300, 1e-17, 1e-9, 0.5, 700.0))
+    assert lib.amo_exp(-708.5) == 0.0 and lib.amo_exp(-1e308) == 0.0 and lib.amo_exp(-math.inf) == 0.0
+    assert lib.amo_exp(709.5) == math.inf and lib.amo_exp(math.inf) == math.inf
+    assert math.isnan(lib.amo_exp(math.nan))
+    assert lib.amo_exp(-708.0) > 0.0
+
+
+def test_log_accuracy_and_edges(oracle):
+    lib = oracle.load()
+    rnd = random.Random(2)
+    xs = [rnd.random() for _ in range(50000)] + [math.exp(rnd.uniform(-700, 700)) for _ in range(50000)]
+    assert max(ulp_err(lib.amo_log(x), math.log(x)) for x in xs if x > 0) <= 1.0
+    assert lib.amo_log(1.0) == 0.0
+    assert lib.amo_log(0.0) == -math.inf and lib.amo_log(math.inf) == math.inf
+    assert math.isnan(lib.amo_log(-1.0)) and math.isnan(lib.amo_log(math.nan))
+    assert lib.amo_log(5e-324) == pytest.approx(math.log(5e-324), rel=1e-15)
+    assert lib.amo_log(2.0 ** -53) == pytest.approx(-53 * math.log(2), rel=1e-15)
+
+
+def test_sincospi_accuracy_and_quadrants(oracle):
+    rnd = random.Random(4)
+    for _ in range(50000):
+        w = (rnd.getrandbits(53) + 1) * 2.0 ** -52
+        s, c = oracle.sincospi(w)
+        r = math.fmod(w, 2.0)
+        assert abs(s - math.sin(math.pi * r)) < 1e-15 and abs(c - math.cos(math.pi * r)) < 1e-15
+        assert abs(s * s + c * c - 1) < 5e-16
+    assert oracle.sincospi(0.5) == (1.0, -0.0) or oracle.sincospi(0.5)[0] == 1.0
+    assert oracle.sincospi(1.0)[1] == -1.0 and oracle.sincospi(1.5)[0] == -1.0 and oracle.sincospi(2.0)[1] == 1.0
+    assert oracle.sincospi(0.25) == pytest.approx((math.sqrt(0.5), math.sqrt(0.5)), rel=3e-16)
+
+
+# ---- the particle_1d model (example/particle_1d/particle_1d.jl) -------------------------------------
+def test_log_proposal_density_reference_closed_form(oracle):
+    """test/ad_backends_test.jl:19-32: delta = 0, sigma = 0.2 -> logq = 0.6904993792294276, dlogq = -5 (1e-10)."""
+    k = load_json("reference_kats.json")["ad_backends"]
+    lib = oracle.load()
+    assert lib.amo_log_proposal_density(k["delta"], k["sigma"]) == pytest.approx(k["logq"], abs=k["atol"])
+    assert lib.amo_grad_log_proposal_density(k["delta"], k["sigma"]) == pytest.approx(k["grad_sigma"], abs=k["atol"])
+    rnd = random.Random(5)
+    for _ in range(2000):
+        d, s = rnd.gauss(0, 1), math.exp(rnd.uniform(-3, 2))
+        assert lib.amo_log_proposal_density(d, s) == pytest.approx(-d * d / (2 * s * s) - 0.5 * math.log(2 * math.pi * s * s), rel=1e-13, abs=1e-13)
+        assert lib.amo_grad_log_proposal_density(d, s) == pytest.approx(d * d / s ** 3 - 1 / s, rel=1e-12, abs=1e-12)
+        assert lib.amo_log_proposal_density(d, s) == lib.amo_log_proposal_density(-d, s)   # backward == forward, bit for bit
+
+
+def test_potentials(oracle):
+    lib = oracle.load()
+    assert lib.amo_potential(0, 1.5) == 2.25 and lib.amo_potential(1, 1.5) == 1.5625 and lib.amo_potential(1, 1.0) == 0.0
+
+
+def test_categorical_walk(oracle):
+    """Distributions.jl DiscreteNonParametric sampler (metropolis.jl:206): first i with cumsum > draw."""
+    lib = oracle.load()
+    w = np.array([0.4, 0.1, 0.1, 0.4])
+    wp = w.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))
+    cum = [0.4, 0.4 + 0.1, 0.4 + 0.1 + 0.1]
+    for r, want in [(0.0, 0), (0.3999, 0), (0.4, 1), (cum[1], 2), (0.59, 2), (cum[2], 3), (0.9999999, 3)]:
+        assert lib.amo_categorical(wp, 4, r) == want
+    one = np.array([1.0])
+    assert lib.amo_categorical(one.ctypes.data_as(type(wp)), 1, 0.999) == 0
+
+
+def test_mc_step_semantics(oracle):
+    """metropolis.jl:176-190 on explicit draws: strict alpha > u, reject re-applies the negated action."""
+    beta, sigma = 2.0, 0.1
+    # downhill move: alpha == 1 -> accepted for every u in [0, 1)
+    a, x, e = oracle.mc_step_explicit(0, beta, sigma, -1.0, 1.0 - 2.0 ** -53, 1.0, 1.0)
+    assert a == 1 and x == 1.0 + (0.0 + sigma * -1.0) and e == x * x
+    # uphill: alpha = exp(-beta*(e2-e1)) evaluated as in the reference
+    x0 = 1.0
+    d = 0.0 + sigma * 1.0
+    x1 = x0 + d
+    lq = oracle.load().amo_log_proposal_density(d, sigma)
+    alpha = oracle.load().amo_exp(((-(x1 * x1)) * beta - (-(x0 * x0)) * beta + lq) - lq)
+    a, x, e = oracle.mc_step_explicit(0, beta, sigma, 1.0, math.nextafter(alpha, 0.0), x0, x0 * x0)
+    assert a == 1 and x == x1
+    a, x, e = oracle.mc_step_explicit(0, beta, sigma, 1.0, alpha, x0, x0 * x0)       # alpha > u is strict
+    assert a == 0 and x == (x0 + d) + (-d) and e == x * x
+    # the revert is NOT a restore: (x + d) + (-d) can differ from x in the last bit
+    diffs = 0
+    rnd = random.Random(6)
+    for _ in range(2000):
+        xs, z = rnd.uniform(-2, 2), rnd.gauss(0, 1)
+        a, x, e = oracle.mc_step_explicit(0, beta, sigma, z, 1.0 - 2.0 ** -53, xs, xs * xs)
+        if a == 0:
+            dd = 0.0 + sigma * z
+            assert x == (xs + dd) + (-dd)
+            diffs += x != xs
+    assert diffs > 0
+    # NaN / inf states: alpha is NaN (Julia min propagates NaN) -> never accepted
+    for bad in (math.inf, -math.inf, math.nan):
+        a, x, e = oracle.mc_step_explicit(0, beta, sigma, 0.3, 0.0, bad, bad * bad)
+        assert a == 0
+
+
+# ---- golden trajectories (self-generated; pins the oracle against drift) ---------------------------
+@pytest.mark.parametrize("idx", range(4))
+def test_golden_trajectories(oracle, idx):
+    case = load_json("oracle_trajectories.json")["cases"][idx]
+    sp = case["spec"]
+    o = oracle.OracleSim(sp["M"], chain_offset=sp["offset"], potential=sp["potential"], beta=sp["beta"],
+                         sigma=sp["sigma"], weight=sp["weight"], seed=sp["seed"], sweepstep=sp["sweepstep"])
+    o.init_uniform(-2.0, 2.0)
+    done = 0
+    for snap in case["snapshots"]:
+        o.make_steps(snap["sweep"] - done)
+        done = snap["sweep"]
+        x, e = o.state()
+        assert np.array_equal(x, fh(snap["x"])) and np.array_equal(e, fh(snap["e"]))
+        acc, tot = o.counters()
+        assert acc.tolist() == snap["accepted"] and tot.tolist() == snap["total"]
+        if "energy" in snap:
+            assert o.energy() == float.fromhex(snap["energy"])
+            assert np.array_equal(o.acceptance(), fh(snap["acceptance"]), equal_nan=True)
+    o.make_steps(256 - done)
+    g = o.pg_estimate(list(range(len(sp["sigma"]))), 3)
+    assert np.array_equal(g.ravel(), fh(case["pg_estimate_q3"]))
+    assert np.array_equal(o.state()[0], fh(case["x_after_pg"]))
+
+
+def test_threads_do_not_change_results(oracle):
+    """collect vs tcollect (metropolis.jl:265): chains are independent, so the result is identical."""
+    a = oracle.OracleSim(1001, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=9)
+    b = oracle.OracleSim(1001, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=9)
+    a.init_uniform(-2, 2)
+    b.init_uniform(-2, 2)
+    a.make_steps(20, 1)
+    b.make_steps(20, 4)
+    assert np.array_equal(a.state()[0], b.state()[0]) and np.array_equal(a.counters()[0], b.counters()[0])
+
+
+def test_shard_invariance_of_the_oracle(oracle):
+    """RNG keyed by GLOBAL chain id: any even split of the ensemble reproduces the unsplit run."""
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=5)
+    whole = oracle.OracleSim(101, **kw)
+    whole.init_uniform(-2, 2)
+    whole.make_steps(30)
+    xs, accs = [], []
+    for start, stop in [(0, 34), (34, 70), (70, 101)]:
+        part = oracle.OracleSim(stop - start, chain_offset=start, **kw)
+        part.init_uniform(-2, 2)
+        part.make_steps(30)
+        xs.append(part.state()[0])
+        accs.append(part.counters()[0])
+    assert np.array_equal(np.concatenate(xs), whole.state()[0])
+    assert np.array_equal(np.concatenate(accs, axis=1), whole.counters()[0])
+
+
+# ---- build_schedule (src/simulation.jl:95-117) ----------------------------------------------------------
+def test_build_schedule_reference_values(oracle):
+    k = load_json("reference_kats.json")["schedule"]
+    s = oracle.build_schedule(k["steps"], k["burn"], k["block"])
+    assert len(s) == k["n_entries"] and s[0] == k["first"] and s[-1] == k["last"]
+    assert all(b - a == k["stride"] for a, b in zip(s, s[1:]))
+    assert oracle.build_schedule(100, 10, 30) == [10, 40, 70, 100]
+    assert oracle.build_schedule(100, 10, 45) == [10, 55, 100]          # ∪ [steps]
+    assert oracle.build_schedule(10 ** 5, 1000, 10 ** 4) == list(range(1000, 10 ** 5, 10 ** 4)) + [10 ** 5]
+    assert oracle.build_schedule(1000, 10, 2.0) == [10, 11, 12, 14, 18, 26, 42, 74, 138, 266, 522, 1000]
+    with pytest.raises(ValueError):
+        oracle.build_schedule(1000, 10, 1.5)                           # Int(1.5) is an InexactError in Julia

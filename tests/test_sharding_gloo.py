@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: world_size-2 torch.distributed (gloo) runs of the sharded Simulation.
+
+Each rank owns an even-aligned range of GLOBAL chain ids; sweeps need no collective; callbacks and
+the estimator fold are one all-reduce(sum).  Because the Philox counter is keyed by the global chain
+id, every callback row and the learned sigma must equal the single-process run (shard invariance).
+The engine is the oracle double (no GPU here); the sharding / all-reduce code under test is the
+product's (montecarlo_amd/sharding.py, metropolis.py, policy_guided.py).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as dist
+import montecarlo_amd as ma
+import oracle_lib as O
+
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+rank = dist.get_rank() if world > 1 else 0
+out = sys.argv[1]
+M, steps = 37, 60
+chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
+        ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, engine_factory=O.OracleEngine),
+      dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.01)), q_batch_size=2),
+      dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=ma.build_schedule(steps, 10, 2)),
+      dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance, ma.callback_moments),
+           scheduler=ma.build_schedule(steps, 10, 5)))
+sim = ma.Simulation(chains, al, steps, path=os.path.join(out, "data"))
+ma.run(sim)
+cb = sim.algorithms[-1]
+res = dict(rank=rank, shard=list(sim.algorithms[0].shard), x=[v.hex() for v in chains.x],
+           energy=[(t, float(v)) for t, v in cb.rows[0]], acceptance=[(t, [float(a) for a in v]) for t, v in cb.rows[1]],
+           sigma=[float(m.sigma) for m in pool], accepted=[m.accepted_calls for m in pool], total=[m.total_calls for m in pool])
+json.dump(res, open(os.path.join(out, f"rank{{rank}}.json"), "w"))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_world(tmp_path, world):
+    out = tmp_path / f"w{world}"
+    out.mkdir()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    if world == 1:
+        cmd = [sys.executable, str(script), str(out)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [json.load(open(out / f"rank{k}.json")) for k in range(world)]
+
+
+@pytest.mark.slow
+def test_two_ranks_reproduce_one_rank(tmp_path):
+    one = run_world(tmp_path, 1)[0]
+    two = run_world(tmp_path, 2)
+    assert two[0]["shard"] == [0, 20] and two[1]["shard"] == [20, 37]          # even boundary
+    # per-chain states: concatenated shards == the unsharded run, bit for bit
+    assert two[0]["x"] + two[1]["x"] == one["x"]
+    for r in two:
+        # every rank sees the same global callback values
+        assert [t for t, _ in r["energy"]] == [t for t, _ in one["energy"]]
+        np.testing.assert_allclose([v for _, v in r["energy"]], [v for _, v in one["energy"]], rtol=1e-13)
+        np.testing.assert_allclose(np.array([v for _, v in r["acceptance"]]), np.array([v for _, v in one["acceptance"]]),
+                                   rtol=1e-13, equal_nan=True)
+        # sigma stays replicated without a broadcast: same all-reduced GradientData -> same learning_step!
+        np.testing.assert_allclose(r["sigma"], one["sigma"], rtol=1e-12)
+        assert r["sigma"][0] == 0.2 and r["sigma"][1] != 0.1
+        assert r["accepted"] == one["accepted"] and r["total"] == one["total"]
+    assert two[0]["energy"] == two[1]["energy"]
