@@ -48,8 +48,8 @@ def cpu_baseline(budget_s: float = 12.0):
         sim.make_steps(1, threads)                       # warm-up / first touch
         sweeps, t0 = 0, time.perf_counter()
         while True:
-            sim.make_steps(2, threads)
-            sweeps += 2
+            sim.make_steps(16, threads)
+            sweeps += 16
             dt = time.perf_counter() - t0
             if dt >= budget or sweeps >= 4000:
                 break
