@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -74,12 +75,15 @@ struct amc_handle {
     uint32_t* d_acc = nullptr;
     uint32_t* d_tot = nullptr;
     double* d_ptab = nullptr;
-    unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total
+    unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
+    unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
+    int n_slots = 0;
     double* d_partials = nullptr;
     double* d_out = nullptr;
     double* h_out = nullptr;    // pinned
     int red_blocks = 0;
     int n_cu = 256;
+    int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* comm = nullptr;
     double* d_comm = nullptr;
@@ -92,7 +96,7 @@ int grid_for(const amc_handle* h, int64_t n_items)
 {
     // memory-streaming shape: <= 8 blocks of 256 per CU, grid-stride the rest
     int64_t blocks = (n_items + AMC_BLOCK - 1) / AMC_BLOCK;
-    const int64_t cap = (int64_t)h->n_cu * 8;
+    const int64_t cap = (int64_t)h->n_cu * h->blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -158,6 +162,19 @@ int launch_pg(amc_handle* h, const amc::PgArgs& a, int grid, int nl_cap)
     case 4: return launch_pg_nl<POT, 4>(h, a, grid);
     default: return launch_pg_nl<POT, 8>(h, a, grid);
     }
+}
+
+// Pool-wide accepted total (K == 1): sum of the per-block slots the sweep kernel maintains.
+int sum_acc_slots(amc_handle* h, unsigned long long* out)
+{
+    std::vector<unsigned long long> slots((size_t)h->n_slots);
+    AMC_HIP(hipMemcpyAsync(slots.data(), h->d_acc_slots, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long t = 0;
+    for (unsigned long long v : slots) t += v;
+    *out = t;
+    return AMC_OK;
 }
 
 int nl_capacity(int n_learn) { return n_learn <= 1 ? 1 : n_learn <= 2 ? 2 : n_learn <= 4 ? 4 : 8; }
@@ -227,6 +244,10 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     if (!h) return fail(AMC_ERR_OOM, "amc_create: host allocation failed");
     h->device = cfg->device;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* env = std::getenv("AMC_BLOCKS_PER_CU")) {   // tuning knob, 1..64
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 64) h->blocks_per_cu = v;
+    }
     h->M = cfg->n_chains;
     h->M_pad = ((cfg->n_chains + 1) & ~(int64_t)1) + 2;   // even + one spare pair: 16-B tail loads stay in bounds
     h->offset = cfg->chain_offset;
@@ -271,6 +292,9 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     AMC_TRY(hipMemsetAsync(h->d_ptab, 0, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_totals, 2 * AMC_MAX_MOVES * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
+    h->n_slots = h->n_cu * h->blocks_per_cu;
+    AMC_TRY(hipMalloc(&h->d_acc_slots, (size_t)h->n_slots * sizeof(unsigned long long)));
+    AMC_TRY(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
     h->red_blocks = grid_for(h, h->M);
     {
         size_t per_block = (size_t)(4 + AMC_MAX_MOVES);
@@ -301,6 +325,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_tot);
     (void)hipFree(h->d_ptab);
     (void)hipFree(h->d_totals);
+    (void)hipFree(h->d_acc_slots);
     (void)hipFree(h->d_partials);
     (void)hipFree(h->d_out);
     if (h->h_out) (void)hipHostFree(h->h_out);
@@ -406,6 +431,12 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     }
     AMC_HIP(hipMemcpyAsync(host, h->d_totals, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    if (h->K == 1) {
+        unsigned long long acc = 0;
+        const int rc = sum_acc_slots(h, &acc);
+        if (rc != AMC_OK) return rc;
+        host[0] = acc;
+    }
     for (int k = 0; k < h->K; ++k) {
         if (accepted) accepted[k] = (int64_t)host[k];
         if (total) total[k] = (h->K > 1) ? (int64_t)host[AMC_MAX_MOVES + k] : (int64_t)(h->t_counted * (uint64_t)h->M);
@@ -429,7 +460,7 @@ int amc_sweep(amc_handle* h, int64_t n_sweeps)
         a.acc = h->d_acc;
         a.tot = h->d_tot;
         a.ptab = h->d_ptab;
-        a.acc_total = h->d_totals;
+        a.acc_total = h->d_acc_slots;
         a.n_chains = h->M;
         a.m_stride = h->M_pad;
         a.pair0 = (uint64_t)h->offset >> 1;
@@ -482,9 +513,11 @@ int amc_reduce(amc_handle* h, double* out)
     AMC_HIP(hipGetLastError());
     AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)n_vals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     unsigned long long acc_total = 0;
-    if (ratio_mode == 0)
-        AMC_HIP(hipMemcpyAsync(&acc_total, h->d_totals, sizeof(acc_total), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    if (ratio_mode == 0) {
+        const int rc = sum_acc_slots(h, &acc_total);
+        if (rc != AMC_OK) return rc;
+    }
     for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
     if (ratio_mode == 0) {
         // K == 1 without per-chain counters: total_calls is the same on every chain, so

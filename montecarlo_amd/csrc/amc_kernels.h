@@ -108,17 +108,28 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
     unsigned long long wave_acc = 0;   // wave-uniform
 
-    // wave-uniform trip count: every lane of a wave runs the same iterations (ballot below)
+    // wave-uniform trip count: every lane of a wave runs the same iterations (ballot below).
+    // Software prefetch: the 16-B load of the NEXT grid-stride iteration is issued before this
+    // iteration's ~600 VALU instructions, so HBM latency hides behind the wave's own arithmetic.
+    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    if (first < n_pairs) {
+        const int64_t p0 = first + threadIdx.x;
+        const int64_t pc0 = (p0 < n_pairs) ? p0 : 0;
+        x_nxt = *reinterpret_cast<const double2*>(a.x + 2 * pc0);
+        if (BETA) b_nxt = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pc0);
+    }
     for (int64_t base = first; base < n_pairs; base += stride) {
         const int64_t p = base + threadIdx.x;
         const bool v0 = p < n_pairs;
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
         const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
-        double2 xv = *reinterpret_cast<const double2*>(a.x + 2 * pc);
-        double b0 = a.beta, b1 = a.beta;
-        if (BETA) {
-            const double2 bv = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pc);
-            b0 = bv.x; b1 = bv.y;
+        double2 xv = x_nxt;
+        const double b0 = b_nxt.x, b1 = b_nxt.y;
+        if (base + stride < n_pairs) {
+            const int64_t pn = base + stride + threadIdx.x;
+            const int64_t pcn = (pn < n_pairs) ? pn : 0;
+            x_nxt = *reinterpret_cast<const double2*>(a.x + 2 * pcn);
+            if (BETA) b_nxt = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pcn);
         }
         const uint64_t pair = a.pair0 + (uint64_t)pc;
         uint32_t cnt0 = 0, cnt1 = 0;
@@ -181,7 +192,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
     }
     if (!MULTI) {
-        if ((threadIdx.x & 63) == 0 && wave_acc != 0) atomicAdd(a.acc_total, wave_acc);
+        // Pool-wide accepted count: each block owns ONE u64 slot (plain read-modify-write by one
+        // lane, no atomics: thousands of same-address atomics at kernel end serialise at ~13 ns
+        // each).  The host sums the slots when a total is asked for.
+        __shared__ unsigned long long s_acc[AMC_BLOCK / 64];
+        if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = wave_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc[w];
+            if (t != 0) a.acc_total[blockIdx.x] += t;
+        }
     }
 }
 

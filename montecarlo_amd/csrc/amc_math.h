@@ -30,9 +30,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
         const uint64_t m0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t m1 = (uint64_t)0xCD9E8D57u * c.z;
         u32x4 n;
-        n.x = (uint32_t)(m1 >> 32) ^ c.y ^ k0;
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(m1 >> 32), c.y, k0, 0x96);   // a ^ b ^ c in one VALU op
         n.y = (uint32_t)m1;
-        n.z = (uint32_t)(m0 >> 32) ^ c.w ^ k1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(m0 >> 32), c.w, k1, 0x96);
         n.w = (uint32_t)m0;
         c = n;
         k0 += 0x9E3779B9u;
