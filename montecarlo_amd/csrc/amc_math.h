@@ -62,7 +62,8 @@ __device__ __forceinline__ double uniform53(uint32_t lo, uint32_t hi)
 
 __device__ __forceinline__ double uniform32(uint32_t v) { return (double)v * 0x1.0p-32; }
 
-__device__ __forceinline__ double exp_f64(double x)
+// exp(x) for x in [-708, 709] WITHOUT the range / NaN guards (callers mask those cases).
+__device__ __forceinline__ double exp_core_f64(double x)
 {
     const double LOG2E = 0x1.71547652b82fep+0;
     const double LN2_HI = 0x1.62e42fee00000p-1;
@@ -87,11 +88,46 @@ __device__ __forceinline__ double exp_f64(double x)
     p = __builtin_fma(p, r, 0x1.0000000000000p-1);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    double y = __longlong_as_double(__double_as_longlong(p) + (long long)((uint64_t)ki << 52));
+    return __longlong_as_double(__double_as_longlong(p) + (long long)((uint64_t)ki << 52));
+}
+
+// Full-domain exp of the arithmetic spec: 0 below -708 (no subnormals), +inf above 709, NaN -> NaN.
+__device__ __forceinline__ double exp_f64(double x)
+{
+    double y = exp_core_f64(x);
     y = (x < -708.0) ? 0.0 : y;
     y = (x > 709.0) ? __builtin_huge_val() : y;
     y = (x != x) ? x : y;
     return y;
+}
+
+// log(x) for POSITIVE NORMAL FINITE x (the Box-Muller radius argument, u in [2^-53, 1]): the spec's
+// log without its subnormal pre-scaling and without the 0 / inf / negative / NaN guards.
+__device__ __forceinline__ double log_pos_normal_f64(double x)
+{
+    const double LN2_HI = 0x1.62e42fee00000p-1;
+    const double LN2_LO = 0x1.a39ef35793c76p-33;
+    const uint64_t ux = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(ux >> 32);
+    int32_t k = (int32_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    k += (int32_t)(i >> 20);
+    const uint64_t um = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+    const double f = __longlong_as_double((long long)um) - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 0x1.39a09d078c69fp-3, 0x1.c71c51d8e78afp-3),
+                                        0x1.999999997fa04p-2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 0x1.2f112df3e5244p-3,
+                                                                         0x1.7466496cb03dep-3),
+                                                         0x1.2492494229359p-2),
+                                        0x1.5555555555593p-1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * LN2_HI - ((hfsq - __builtin_fma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
 __device__ __forceinline__ double log_f64(double x)
@@ -161,9 +197,11 @@ __device__ __forceinline__ void sincospi_f64(double w, double& sp, double& cp)
     const bool swap = (n & 1u) != 0u;
     const double a = swap ? c : s;      // |sin| carrier
     const double b = swap ? s : c;      // |cos| carrier
-    // n&3: 0 (s, c); 1 (c, -s); 2 (-s, -c); 3 (-c, s)
-    sp = (n & 2u) ? -a : a;
-    cp = (((n + 1u) & 2u) != 0u) ? -b : b;
+    // n&3: 0 (s, c); 1 (c, -s); 2 (-s, -c); 3 (-c, s): negation = flipping the sign bit
+    const uint64_t sa = (uint64_t)(n & 2u) << 62;
+    const uint64_t sb = (uint64_t)((n + 1u) & 2u) << 62;
+    sp = __longlong_as_double((long long)((uint64_t)__double_as_longlong(a) ^ sa));
+    cp = __longlong_as_double((long long)((uint64_t)__double_as_longlong(b) ^ sb));
 }
 
 // rocRAND box_muller_double(uint4) map (rocrand_normal.h:78-98) on own log/sincospi:
@@ -174,7 +212,7 @@ __device__ __forceinline__ void box_muller(u32x4 v, double& z0, double& z1)
     const double u = 0x1.0p-53 + (double)v1 * 0x1.0p-53;
     const uint64_t v2 = (uint64_t)v.z ^ ((uint64_t)v.w << 21);
     const double w = 0x1.0p-52 + (double)v2 * 0x1.0p-52;
-    const double s = __builtin_sqrt(-2.0 * log_f64(u));
+    const double s = __builtin_sqrt(-2.0 * log_pos_normal_f64(u));   // u in [2^-53, 1]: positive normal
     double sn, cs;
     sincospi_f64(w, sn, cs);
     z0 = sn * s;
