@@ -73,7 +73,8 @@ typedef struct amc_config {
     int32_t  n_moves;            /* K = length(pool) */
     double   beta;               /* Particle.beta (particle_1d.jl:11), shared by all chains
                                     unless amc_upload_state passes a per-chain array */
-    const double *sigma;         /* [K] StandardGaussian parameters sigma_k (particle_1d.jl:50) */
+    const double *sigma;         /* [K] StandardGaussian parameters sigma_k (particle_1d.jl:50),
+                                    each in [1e-100, 1e100] */
     const double *weight;        /* [K] Move.weight (metropolis.jl:144); must sum to ~1 */
     uint64_t seed;               /* Metropolis.seed (metropolis.jl:235) -> Philox key */
     int32_t  sweepstep;          /* Metropolis.sweepstep (metropolis.jl:234), >= 1 */
@@ -166,7 +167,8 @@ int  amc_comm_init(amc_handle *h, int rank, int n_ranks, const void *id128);
 int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
 
 /* Parity-test hooks: evaluate arithmetic-spec primitives on the device.
- * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b.  Host buffers, n entries. */
+ * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b (IEEE), 6 a/b by the kernel's
+ * reciprocal-correction sequence (must equal 5 bit for bit).  Host buffers, n entries. */
 int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
                        double *out, int64_t n);
 /* out4[i] = Philox4x32-10(key = seed, counter of draw (pair[i], t[i], draw, stream)). */

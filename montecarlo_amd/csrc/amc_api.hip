@@ -216,8 +216,8 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     if (!cfg->sigma || !cfg->weight) return fail(AMC_ERR_BAD_ARG, "amc_create: sigma/weight is NULL");
     double wsum = 0.0;
     for (int k = 0; k < cfg->n_moves; ++k) {
-        if (!(cfg->sigma[k] > 0.0) || !std::isfinite(cfg->sigma[k]))
-            return fail(AMC_ERR_BAD_ARG, "amc_create: sigma[%d] must be finite and > 0", k);
+        if (!(cfg->sigma[k] >= 1e-100) || !(cfg->sigma[k] <= 1e100))
+            return fail(AMC_ERR_BAD_ARG, "amc_create: sigma[%d] must lie in [1e-100, 1e100]", k);
         if (!(cfg->weight[k] >= 0.0) || !std::isfinite(cfg->weight[k]))
             return fail(AMC_ERR_BAD_ARG, "amc_create: weight[%d] must be finite and >= 0", k);
         wsum += cfg->weight[k];
@@ -532,8 +532,8 @@ int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
     if (!h || !p) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: NULL argument");
     if (k < 0 || k >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: move index %d out of range", k);
     if (n != 1) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: StandardGaussian has exactly 1 parameter (sigma)");
-    if (!(p[0] > 0.0) || !std::isfinite(p[0]))
-        return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: sigma must be finite and > 0 (got %.17g)", p[0]);
+    if (!(p[0] >= 1e-100) || !(p[0] <= 1e100))
+        return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: sigma must lie in [1e-100, 1e100] (got %.17g)", p[0]);
     AMC_HIP(hipSetDevice(h->device));
     AMC_HIP(hipMemcpyAsync(h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, p, sizeof(double), hipMemcpyHostToDevice, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
@@ -700,7 +700,7 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
 // ---- parity-test hooks ----------------------------------------------------------------
 int amc_selftest_math(int device, int fn, const double* a, const double* b_or_null, double* out, int64_t n)
 {
-    if (!a || !out || n < 0 || fn < 0 || fn > 5 || (fn == 5 && !b_or_null))
+    if (!a || !out || n < 0 || fn < 0 || fn > 6 || (fn >= 5 && !b_or_null))
         return fail(AMC_ERR_BAD_ARG, "amc_selftest_math: bad argument");
     if (n == 0) return AMC_OK;
     AMC_HIP(hipSetDevice(device));

@@ -23,7 +23,24 @@ enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1 };
 
 // Rows of the per-move parameter table.
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
-       PT_ROWS = 7 };
+       PT_RDEN = 7, PT_ROWS = 8 };
+
+// a / b, correctly rounded, for a divisor b whose reciprocal y = RN(1/b) is precomputed
+// (b = 2 sigma^2 is one value per move).  Two Markstein corrections: q1 is a faithful rounding of
+// a/b (|q0 - a/b| < 1.5 ulp, so q0 + r0*y is within 2^-52 relative of a/b before its one rounding),
+// and Markstein's theorem (Muller et al., Handbook of FP Arithmetic, 2nd ed., Thm 4.10: q faithful,
+// |y - 1/b| < 2^-53 |1/b|, r = a - bq exact  =>  RN(q + r y) = RN(a/b)) makes q2 the IEEE quotient.
+// Needs a, b, 1/b normal or a == 0: guaranteed by the 1e-100 <= sigma <= 1e100 check in the C ABI.
+// (a == -0.0 returns +0.0; both consumers subtract a non-zero constant next, so it never shows.)
+// 5 f64 ops instead of v_div_scale x2 + v_rcp_f64 + 7 fma + v_div_fmas + v_div_fixup.
+__device__ __forceinline__ double div_by_const(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-q0, b, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-q1, b, a);
+    return __builtin_fma(r1, y, q1);
+}
 
 // potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
 // double well (x*x-1)^2 is BASELINE config 3's.
@@ -47,11 +64,11 @@ __device__ __forceinline__ double potential(double x)
 //   alpha = min(1, exp(dlogp + logq_b - logq_f)); accept iff alpha > u  (strict)
 //   reject: perform_action_cached! re-applies the negated action: x = (x+d) + (-d)
 template <int POT>
-__device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double logc,
-                                        double z, double u)
+__device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double rden,
+                                        double logc, double z, double u)
 {
     const double delta = 0.0 + sigma * z;
-    const double logq = (-(delta * delta)) / den - logc;
+    const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den, bit for bit
     const double e1 = potential<POT>(x);
     const double xn = x + delta;
     const double e2 = potential<POT>(xn);
@@ -92,7 +109,7 @@ struct SweepArgs {
 template <int POT, bool MULTI, bool COUNT, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
-    __shared__ double s_tab[MULTI ? 4 * AMC_MAX_MOVES : 1];
+    __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     const int K = a.n_moves;
     if (MULTI) {
         for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {
@@ -100,6 +117,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             s_tab[1 * AMC_MAX_MOVES + i] = a.ptab[PT_DEN * AMC_MAX_MOVES + i];
             s_tab[2 * AMC_MAX_MOVES + i] = a.ptab[PT_LOGC * AMC_MAX_MOVES + i];
             s_tab[3 * AMC_MAX_MOVES + i] = a.ptab[PT_CUM * AMC_MAX_MOVES + i];
+            s_tab[4 * AMC_MAX_MOVES + i] = a.ptab[PT_RDEN * AMC_MAX_MOVES + i];
         }
         __syncthreads();
     }
@@ -107,6 +125,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const double sigma1 = a.ptab[PT_SIGMA * AMC_MAX_MOVES];
     const double den1 = a.ptab[PT_DEN * AMC_MAX_MOVES];
     const double logc1 = a.ptab[PT_LOGC * AMC_MAX_MOVES];
+    const double rden1 = a.ptab[PT_RDEN * AMC_MAX_MOVES];
 
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
@@ -142,6 +161,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         for (int s = 0; s < a.n_steps; ++s) {
             const uint64_t t = a.t0 + (uint64_t)s;
             double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
+            double rd0 = rden1, rd1 = rden1;
             int k0 = 0, k1 = 0;
             if (MULTI) {
                 // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
@@ -156,14 +176,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 }
                 sg0 = s_tab[k0]; dn0 = s_tab[AMC_MAX_MOVES + k0]; lc0 = s_tab[2 * AMC_MAX_MOVES + k0];
                 sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
+                rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
             }
             double z0, z1;
             box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1),
                        z0, z1);
             const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS),
                                            a.key0, a.key1);
-            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, lc0, z0, uniform53(pu.x, pu.y));
-            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, lc1, z1, uniform53(pu.z, pu.w));
+            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform53(pu.x, pu.y));
+            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform53(pu.z, pu.w));
             if (MULTI) {
                 // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
                 if (v0) {
@@ -241,6 +262,7 @@ __global__ void prepare_params_kernel(double* ptab, int n_moves)
         const double s2 = sigma * sigma;
         const double ds2 = sigma + sigma;
         ptab[PT_DEN * AMC_MAX_MOVES + k] = 2.0 * s2;
+        ptab[PT_RDEN * AMC_MAX_MOVES + k] = 1.0 / (2.0 * s2);        // RN(1/den) for div_by_const
         ptab[PT_DDEN * AMC_MAX_MOVES + k] = 2.0 * ds2;
         const double av = TWO_PI * s2;
         ptab[PT_LOGC * AMC_MAX_MOVES + k] = log_f64(av) / 2.0;
@@ -372,13 +394,13 @@ struct PgArgs {
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
 template <int POT>
-__device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, double den, double logc,
-                                          double dden, double dlhalf, double z, double (&g)[4])
+__device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, double den, double rden,
+                                          double logc, double dden, double dlhalf, double z, double (&g)[4])
 {
     const double delta = 0.0 + sigma * z;
-    const double q1 = (-(delta * delta)) / den;
+    const double q1 = div_by_const(-(delta * delta), den, rden);
     const double logq = q1 - logc;
-    const double dlogq = -(q1 / den) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
+    const double dlogq = -div_by_const(q1, den, rden) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
     const double e1 = potential<POT>(x);
     const double xn = x + delta;
     const double e2 = potential<POT>(xn);
@@ -420,6 +442,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
                 const int lid = a.learn_ids[l];
                 const double sigma = a.ptab[PT_SIGMA * AMC_MAX_MOVES + lid];
                 const double den = a.ptab[PT_DEN * AMC_MAX_MOVES + lid];
+                const double rden = a.ptab[PT_RDEN * AMC_MAX_MOVES + lid];
                 const double logc = a.ptab[PT_LOGC * AMC_MAX_MOVES + lid];
                 const double dden = a.ptab[PT_DDEN * AMC_MAX_MOVES + lid];
                 const double dlhalf = a.ptab[PT_DLHALF * AMC_MAX_MOVES + lid];
@@ -429,8 +452,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1);
-                    pg_sample<POT>(xv.x, b0, sigma, den, logc, dden, dlhalf, z0, g[l]);
-                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, logc, dden, dlhalf, z1, g[l]);
+                    pg_sample<POT>(xv.x, b0, sigma, den, rden, logc, dden, dlhalf, z0, g[l]);
+                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, rden, logc, dden, dlhalf, z1, g[l]);
                 }
             }
         }
@@ -460,6 +483,7 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
     case 3: sincospi_f64(v, s, c); r = c; break;
     case 4: r = __builtin_sqrt(v); break;
     case 5: r = v / b[i]; break;
+    case 6: r = div_by_const(v, b[i], 1.0 / b[i]); break;
     default: break;
     }
     out[i] = r;

@@ -48,6 +48,31 @@ def test_device_sqrt_and_division_are_ieee(gpu):
     assert np.array_equal(bits(gpu.selftest_math("div", num, den)), bits(num / den))
 
 
+def test_reciprocal_correction_division_is_ieee(gpu):
+    """The sweep kernel divides by den = 2 sigma^2 with a precomputed reciprocal and two Markstein
+    corrections (amc_kernels.h div_by_const); it must equal the IEEE quotient for every input."""
+    rng = np.random.default_rng(4)
+    n = 2_000_000
+    sig = np.exp(rng.uniform(np.log(1e-100), np.log(1e100), n))
+    den = 2.0 * (sig * sig)
+    z = np.concatenate([rng.normal(0, 1, n - 6), [0.0, -0.0, 7e-16, 8.6, 1.0, 1e-8]])
+    num = -((0.0 + sig * z) ** 2)
+    got, want = gpu.selftest_math("div_by_const", num, den), num / den
+    nz = num != 0
+    assert np.array_equal(bits(got[nz]), bits(want[nz]))
+    assert np.all(got[~nz] == 0.0)       # a = -0.0 yields +0.0: logq = q - logc is the same either way
+    # adversarial divisors: all-ones / sparse significands, powers of two, and numerators next to them
+    m = (np.uint64(0x3FF0000000000000) | rng.integers(0, 2 ** 52, n, dtype=np.uint64)).view(np.float64)
+    den = np.concatenate([np.nextafter(2.0, 0) * np.ones(n // 4), np.nextafter(1.0, 2) * np.ones(n // 4),
+                          m[: n // 4], 2.0 ** rng.integers(-300, 300, n // 4)])
+    num = -m * np.exp(rng.uniform(-60, 5, n))
+    assert np.array_equal(bits(gpu.selftest_math("div_by_const", num, den)), bits(num / den))
+    q = -m[: n // 2]                       # numerators of the form RN(q*b) and their neighbours: near-exact quotients
+    b = m[n // 2:]
+    for a in (q * b, np.nextafter(q * b, 0), np.nextafter(q * b, -np.inf)):
+        assert np.array_equal(bits(gpu.selftest_math("div_by_const", a, b)), bits(a / b))
+
+
 def test_device_philox_words(gpu, oracle):
     rng = np.random.default_rng(2)
     for seed, draw, stream in [(1, 0, 1), (0x123456789ABCDEF, 5, 2), (2 ** 64 - 1, 4095, 0)]:
