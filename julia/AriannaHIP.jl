@@ -1,0 +1,173 @@
+# AriannaHIP.jl -- the reference-side binding of libamc.so (include/amc.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S ENVIRONMENT: the build image and the GPU box have no Julia.
+# This is the stub a maintainer of TheDisorderedOrganization/MonteCarlo (Arianna.jl) would add; it
+# is written against the reference's own interfaces:
+#   AriannaAlgorithm protocol            src/algorithms.jl:6-37
+#   Metropolis(chains; pool, ...)        src/metropolis.jl:288-291
+#   callback_acceptance                  src/metropolis.jl:319-321
+#   callback_energy                      example/particle_1d/particle_1d.jl:68-70
+#   PolicyGradientEstimator / Update     src/PolicyGuided/estimator.jl:103-134, update.jl:43-57
+# Every ccall below names the C entry point and its argument types exactly as include/amc.h
+# declares them.
+module AriannaHIP
+
+using Arianna
+using Arianna.PolicyGuided
+import Arianna: initialise, make_step!, finalise, write_algorithm
+
+const libamc = get(ENV, "LIBAMC", "libamc.so")
+
+# struct amc_config (include/amc.h) -- field order and types are the ABI
+struct AmcConfig
+    struct_size::UInt32
+    device::Int32
+    n_chains::Int64
+    chain_offset::Int64
+    n_chains_global::Int64
+    potential::Int32
+    n_moves::Int32
+    beta::Float64
+    sigma::Ptr{Float64}
+    weight::Ptr{Float64}
+    seed::UInt64
+    sweepstep::Int32
+    per_chain_counters::Int32
+    stream::Ptr{Cvoid}
+end
+
+const POTENTIAL_HARMONIC = Int32(0)
+const POTENTIAL_DOUBLE_WELL = Int32(1)
+
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:amc_last_error, libamc), Cstring, ()))
+    error("libamc: $msg (status $rc)")      # the reference's convention: error("No ... is defined"), metropolis.jl:26
+end
+
+"""
+    HIPMetropolis(chains; pool, sweepstep=1, seed=1, device=0, potential=:harmonic, ...)
+
+Drop-in for `Metropolis` (src/metropolis.jl:232-291) on one MI355X.  `chains` is the usual
+`Vector{Particle}`; the pool must hold `Displacement` moves with a `StandardGaussian` policy.
+"""
+mutable struct HIPMetropolis{P} <: Arianna.AriannaAlgorithm
+    handle::Ptr{Cvoid}
+    pools::Vector{P}        # kept so dependants (StoreParameters, estimator) find `.pools`, `.seed`
+    sweepstep::Int
+    seed::Int
+    n_chains::Int
+    K::Int
+end
+
+function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic,
+                       chain_offset=0, n_chains_global=length(chains), per_chain_counters=true, extras...)
+    pools = [deepcopy(pool) for _ in chains]                       # metropolis.jl:289
+    sigma = Float64[move.parameters.σ for move in pool]
+    weight = Float64[move.weight for move in pool]
+    # same checks as metropolis.jl:249-251 (identical parameters/weights across chains hold by construction)
+    handle = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve sigma weight begin
+        cfg = AmcConfig(UInt32(sizeof(AmcConfig)), Int32(device), length(chains), chain_offset, n_chains_global,
+                        potential === :double_well ? POTENTIAL_DOUBLE_WELL : POTENTIAL_HARMONIC,
+                        Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
+                        Int32(sweepstep), Int32(per_chain_counters), C_NULL)
+        check(ccall((:amc_create, libamc), Cint, (Ref{AmcConfig}, Ref{Ptr{Cvoid}}), cfg, handle))
+    end
+    alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), length(pool))
+    finalizer(a -> ccall((:amc_destroy, libamc), Cint, (Ptr{Cvoid},), a.handle), alg)
+    return alg
+end
+
+# initialise: upload chains[c].x (and per-chain beta)                         src/algorithms.jl:13
+function initialise(alg::HIPMetropolis, simulation::Simulation)
+    x = Float64[s.x for s in simulation.chains]
+    β = Float64[s.β for s in simulation.chains]
+    βptr = all(==(β[1]), β) ? Ptr{Float64}(C_NULL) : pointer(β)
+    GC.@preserve x β check(ccall((:amc_upload_state, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+                                 alg.handle, x, βptr))
+    return nothing
+end
+
+# make_step!: one sweep of every chain                                        src/metropolis.jl:302-309
+function make_step!(::Simulation, alg::HIPMetropolis)
+    check(ccall((:amc_sweep, libamc), Cint, (Ptr{Cvoid}, Int64), alg.handle, 1))
+    return nothing
+end
+
+# finalise: chains[c].x / .e and pools[c][k] counters back into the reference's objects
+function finalise(alg::HIPMetropolis, simulation::Simulation)
+    M, K = alg.n_chains, alg.K
+    x = Vector{Float64}(undef, M); e = Vector{Float64}(undef, M)
+    check(ccall((:amc_download_state, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), alg.handle, x, e))
+    acc = Matrix{Int64}(undef, M, K); tot = Matrix{Int64}(undef, M, K)       # move-major == column-major (M, K)
+    check(ccall((:amc_download_counters, libamc), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), alg.handle, acc, tot))
+    for c in 1:M
+        simulation.chains[c].x = x[c]; simulation.chains[c].e = e[c]
+        for k in 1:K
+            alg.pools[c][k].accepted_calls = acc[c, k]; alg.pools[c][k].total_calls = tot[c, k]
+        end
+    end
+    return nothing
+end
+
+function write_algorithm(io, alg::HIPMetropolis, scheduler)
+    println(io, "\tHIPMetropolis (libamc, gfx950)")
+    println(io, "\t\tCalls: $(length(filter(x -> 0 < x ≤ scheduler[end], scheduler)))")
+    println(io, "\t\tMC steps per simulation step: $(alg.sweepstep)")
+    println(io, "\t\tSeed: $(alg.seed)")
+end
+
+hip_algorithm(simulation) = only(filter(a -> isa(a, HIPMetropolis), simulation.algorithms))
+
+# out = [Σe, Σx, Σx², count, Σ_c acc_ck/tot_ck ...]   (AMC_RED_* in amc.h)
+function reduce(alg::HIPMetropolis)
+    out = Vector{Float64}(undef, 4 + alg.K)
+    check(ccall((:amc_reduce, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), alg.handle, out))
+    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.handle, out, length(out)))
+    return out
+end
+
+# callbacks with the reference's names/values                                 particle_1d.jl:68-70, metropolis.jl:319-321
+callback_energy(simulation) = (r = reduce(hip_algorithm(simulation)); r[1] / r[4])
+callback_acceptance(simulation) = (r = reduce(hip_algorithm(simulation)); r[5:end] ./ r[4])
+
+"""
+    HIPPolicyGradientEstimator(chains; dependencies=(HIPMetropolis,), optimisers, q_batch_size=1)
+
+Mirror of PolicyGradientEstimator (estimator.jl:103-134): the per-sample arithmetic of
+gradients.jl:93-121 runs in the kernel, the `+` fold is its reduction (+ all-reduce across shards).
+`gradients_data`, `objectives`, `learn_ids`, `parameters_list` keep the reference's meaning, so the stock
+`PolicyGradientUpdate`'s `learning_step!` (learning.jl) can be reused; after it, push sigma with
+`set_parameters!`.
+"""
+mutable struct HIPPolicyGradientEstimator{O,VG} <: Arianna.AriannaAlgorithm
+    metropolis::HIPMetropolis
+    optimisers::O
+    learn_ids::Vector{Int}
+    q_batch_size::Int
+    gradients_data::VG
+    objectives::Vector{Float64}
+end
+
+function make_step!(::Simulation, alg::HIPPolicyGradientEstimator)
+    n = length(alg.learn_ids)
+    ids = Cint[k - 1 for k in alg.learn_ids]                                  # C side is 0-based
+    out = Matrix{Float64}(undef, 5, n)                                        # (j, ∇j, ∇logq, g, n) per move
+    check(ccall((:amc_pg_estimate, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Ptr{Float64}),
+                alg.metropolis.handle, n, ids, alg.q_batch_size, out))
+    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.metropolis.handle, out, length(out)))
+    for k in 1:n
+        gd = PolicyGuided.GradientData(out[1, k], [out[2, k]], [out[3, k]], fill(out[4, k], 1, 1), Int(out[5, k]))
+        alg.gradients_data[k] = alg.gradients_data[k] + gd                    # estimator.jl:130
+        alg.objectives[k] = alg.gradients_data[k].j / alg.gradients_data[k].n # estimator.jl:131
+    end
+    return nothing
+end
+
+function set_parameters!(alg::HIPMetropolis, k::Int, parameters)
+    p = Float64[parameters.σ]
+    check(ccall((:amc_set_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), alg.handle, k - 1, p, 1))
+end
+
+end # module
