@@ -138,6 +138,11 @@ int  amc_set_step(amc_handle *h, uint64_t t);
  * out: AMC_RED_HEADER + K doubles.  Divide by the global chain count after the
  * cross-shard sum. */
 int  amc_reduce(amc_handle *h, double *out);
+/* The same reduction split in two so the host need not drain the stream: _begin enqueues the kernels
+ * and the device->host copy and returns; _end waits for THAT copy only (sweeps queued after _begin keep
+ * running) and returns the values as of _begin.  One reduction may be in flight per handle. */
+int  amc_reduce_begin(amc_handle *h);
+int  amc_reduce_end(amc_handle *h, double *out);
 
 /* Move.parameters (shared by all chains, metropolis.jl:252-260): read / replace
  * sigma_k on the device copy, e.g. after learning_step! (update.jl:50-57). */

@@ -79,6 +79,8 @@ def load() -> C.CDLL:
         "amc_get_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "amc_set_step": (C.c_int, [H, C.c_uint64]),
         "amc_reduce": (C.c_int, [H, dp]),
+        "amc_reduce_begin": (C.c_int, [H]),
+        "amc_reduce_end": (C.c_int, [H, dp]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_pg_estimate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
@@ -217,6 +219,15 @@ class HipEngine:
     def reduce(self) -> np.ndarray:
         out = np.empty(AMC_RED_HEADER + self.n_moves, dtype=np.float64)
         _check(self._lib.amc_reduce(self._h, _dptr(out)))
+        return out
+
+    def reduce_begin(self) -> None:
+        """Enqueue the reduction; sweeps queued afterwards keep running while the host does other work."""
+        _check(self._lib.amc_reduce_begin(self._h))
+
+    def reduce_end(self) -> np.ndarray:
+        out = np.empty(AMC_RED_HEADER + self.n_moves, dtype=np.float64)
+        _check(self._lib.amc_reduce_end(self._h, _dptr(out)))
         return out
 
     def set_parameters(self, k: int, p: Sequence[float]) -> None:

@@ -84,7 +84,9 @@ struct amc_handle {
     int red_blocks = 0;
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
+    bool red_pending = false;
+    uint64_t red_t_counted = 0;
     void* comm = nullptr;
     double* d_comm = nullptr;
     Rccl rccl;
@@ -305,6 +307,7 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double), 0));
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
+    AMC_TRY(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
@@ -331,6 +334,7 @@ int amc_destroy(amc_handle* h)
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_red) (void)hipEventDestroy(h->ev_red);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return AMC_OK;
@@ -495,9 +499,10 @@ int amc_set_step(amc_handle* h, uint64_t t)
     return AMC_OK;
 }
 
-int amc_reduce(amc_handle* h, double* out)
+int amc_reduce_begin(amc_handle* h)
 {
-    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce: NULL argument");
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_reduce_begin: NULL handle");
+    if (h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
     AMC_HIP(hipSetDevice(h->device));
     const int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
     const int n_vals = 4 + h->K;
@@ -508,23 +513,39 @@ int amc_reduce(amc_handle* h, double* out)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, h->d_partials);
     AMC_HIP(hipGetLastError());
+    // pass 2 also folds the per-block accepted slots (K == 1) into one exact integer-valued double
     hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, h->red_blocks,
-                       n_vals, h->d_out);
+                       n_vals, h->d_out, h->d_acc_slots, h->n_slots);
     AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)n_vals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    unsigned long long acc_total = 0;
-    AMC_HIP(hipStreamSynchronize(h->stream));
-    if (ratio_mode == 0) {
-        const int rc = sum_acc_slots(h, &acc_total);
-        if (rc != AMC_OK) return rc;
-    }
+    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)(n_vals + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
+    h->red_pending = true;
+    h->red_t_counted = h->t_counted;
+    return AMC_OK;
+}
+
+int amc_reduce_end(amc_handle* h, double* out)
+{
+    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce_end: NULL argument");
+    if (!h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_end: no reduction in flight (call amc_reduce_begin)");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipEventSynchronize(h->ev_red));     // waits for the reduction only, not for work queued after it
+    h->red_pending = false;
+    const int n_vals = 4 + h->K;
     for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
-    if (ratio_mode == 0) {
+    if (h->K == 1 && !h->counters) {
         // K == 1 without per-chain counters: total_calls is the same on every chain, so
-        // sum_c accepted_c/total == (sum_c accepted_c)/total up to rounding (DESIGN.md §5)
-        out[AMC_RED_SUM_RATIO0] = (double)acc_total / (double)h->t_counted;
+        // sum_c accepted_c/total == (sum_c accepted_c)/total up to rounding (DESIGN.md section 4)
+        out[AMC_RED_SUM_RATIO0] = h->h_out[n_vals] / (double)h->red_t_counted;
     }
     return AMC_OK;
+}
+
+int amc_reduce(amc_handle* h, double* out)
+{
+    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce: NULL argument");
+    const int rc = amc_reduce_begin(h);
+    return rc != AMC_OK ? rc : amc_reduce_end(h, out);
 }
 
 int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
@@ -587,7 +608,7 @@ int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batc
     if (rc != AMC_OK) return rc;
     // partials layout [grid][nl][4]: reduce the first n_learn*4 of every nl*4 row
     hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, nl * 4,
-                       h->d_out);
+                       h->d_out, (const unsigned long long*)nullptr, 0);
     AMC_HIP(hipGetLastError());
     AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));

@@ -341,14 +341,29 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
     }
 }
 
-// K2b: pass 2, one block: fixed-order sum of the per-block partials.
+// K2b: pass 2, one block: fixed-order sum of the per-block partials; out[n_vals] receives the sum
+// of the per-block accepted slots (exact: integers below 2^53) when slots != nullptr.
 __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_blocks, int n_vals,
-                                                                  double* out)
+                                                                  double* out, const unsigned long long* slots,
+                                                                  int n_slots)
 {
     for (int q = 0; q < n_vals; ++q) {
         double v[1] = {0.0};
         for (int b = threadIdx.x; b < n_blocks; b += AMC_BLOCK) v[0] += partials[(int64_t)b * n_vals + q];
         block_sum_store<1>(v, out + q);
+    }
+    if (slots) {
+        __shared__ unsigned long long s_u[AMC_BLOCK / 64];
+        unsigned long long t = 0;
+        for (int b = threadIdx.x; b < n_slots; b += AMC_BLOCK) t += slots[b];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((threadIdx.x & 63) == 0) s_u[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long a = 0;
+            for (int w = 0; w < AMC_BLOCK / 64; ++w) a += s_u[w];
+            out[n_vals] = (double)a;
+        }
     }
 }
 

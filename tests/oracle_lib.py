@@ -307,6 +307,13 @@ class OracleEngine:
         out[4:] = self.sim.acceptance() * self.n_chains
         return out
 
+    def reduce_begin(self):
+        self._pending = self.reduce()
+
+    def reduce_end(self):
+        out, self._pending = self._pending, None
+        return out
+
     def set_parameters(self, k, p):
         self.sim.set_sigma(k, float(np.asarray(p).reshape(-1)[0]))
 
