@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs merged into gpurun_out/ into the committed summaries under profiles/.
+
+  profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of `bench.py`
+  profiles/<tag>_pmc_summary.json    per-launch averages of the PMC passes for the sweep kernel
+  profiles/pmc_traffic.json          HBM bytes per sweep launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+                                     read by bench.py for roofline.traffic
+"""
+import csv, glob, json, os, shutil, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "profiles"); os.makedirs(out, exist_ok=True)
+g = os.path.join(ROOT, "gpurun_out")
+for f in glob.glob(os.path.join(g, "prof", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
+    print(open(f).read()[:900])
+summary = collections.OrderedDict()
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for f in glob.glob(os.path.join(g, d, "*", "*counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "sweep_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = (r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"])
+        for k, v in agg.items():
+            summary[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+        if agg:
+            summary["_kernel"] = dict(zip(("name", "grid", "workgroup", "vgpr", "sgpr", "lds"), meta))
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    fetch_kb, write_kb = summary["FETCH_SIZE"]["mean_per_launch"], summary["WRITE_SIZE"]["mean_per_launch"]
+    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
+    summary["_traffic"] = {"fetch_bytes_corrected_x2": 2 * fetch_kb * 1024, "write_bytes": write_kb * 1024,
+                           "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 16 * 10_000_000,
+                           "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled"}
+    json.dump({"sweep_kernel_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_summary.json"},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
