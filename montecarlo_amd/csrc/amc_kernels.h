@@ -65,7 +65,7 @@ __device__ __forceinline__ double potential(double x)
 //   reject: perform_action_cached! re-applies the negated action: x = (x+d) + (-d)
 template <int POT>
 __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double rden,
-                                        double logc, double z, double u)
+                                        double logc, double z, double u, const double* T)
 {
     const double delta = 0.0 + sigma * z;
     const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den, bit for bit
@@ -80,7 +80,7 @@ __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, do
     //   arg < -708 or NaN  -> alpha == 0 or NaN (Julia's min keeps NaN) : reject
     // identical decisions to the full-domain form, ~15 fewer VALU instructions per chain.
     // (bitwise | and & on purpose: no short-circuit branches, both chains' exp stay interleaved)
-    const bool accept = (arg >= 0.0) | ((arg >= -708.0) & (exp_core_f64(arg) > u));
+    const bool accept = (arg >= 0.0) | ((arg >= -708.0) & (exp_core_f64(arg, T) > u));
     const double xr = xn + (-delta);
     x = accept ? xn : xr;
     return accept;
@@ -110,6 +110,8 @@ template <int POT, bool MULTI, bool COUNT, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
+    __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 6.4 KB
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     const int K = a.n_moves;
     if (MULTI) {
         for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {
@@ -180,11 +182,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             }
             double z0, z1;
             box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1),
-                       z0, z1);
+                       z0, z1, s_math);
             const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS),
                                            a.key0, a.key1);
-            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform53(pu.x, pu.y));
-            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform53(pu.z, pu.w));
+            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math);
+            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math);
             if (MULTI) {
                 // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
                 if (v0) {
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int6
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
         const u32x4 v = philox4x32_10(draw_counter(pair0 + (uint64_t)p, 0, 0, STREAM_INIT), key0, key1);
-        const double x0 = lo + (hi - lo) * uniform53(v.x, v.y);
-        const double x1 = lo + (hi - lo) * uniform53(v.z, v.w);
+        const double x0 = lo + (hi - lo) * uniform_co(v.x, v.y);
+        const double x1 = lo + (hi - lo) * uniform_co(v.z, v.w);
         x[2 * p] = x0;
         if (2 * p + 1 < n_chains) x[2 * p + 1] = x1;
     }
@@ -410,7 +412,8 @@ struct PgArgs {
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
 template <int POT>
 __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, double den, double rden,
-                                          double logc, double dden, double dlhalf, double z, double (&g)[4])
+                                          double logc, double dden, double dlhalf, double z, double (&g)[4],
+                                          const double* T)
 {
     const double delta = 0.0 + sigma * z;
     const double q1 = div_by_const(-(delta * delta), den, rden);
@@ -422,7 +425,7 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     const double dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = delta * delta;                        // reward, particle_1d.jl:42-44
     x = xn + (-delta);
-    const double alpha = julia_min(1.0, exp_f64((dlogp + logq) - logq));
+    const double alpha = julia_min(1.0, exp_f64((dlogp + logq) - logq, T));
     const double j = r * alpha;
     g[0] += j;
     g[1] += j * dlogq;            // forward and backward gradients are bit-identical here
@@ -434,6 +437,8 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
 template <int POT, int NL, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
 {
+    __shared__ double s_math[TAB_DOUBLES];
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     double g[NL][4];
@@ -466,9 +471,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
-                               z0, z1);
-                    pg_sample<POT>(xv.x, b0, sigma, den, rden, logc, dden, dlhalf, z0, g[l]);
-                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, rden, logc, dden, dlhalf, z1, g[l]);
+                               z0, z1, s_math);
+                    pg_sample<POT>(xv.x, b0, sigma, den, rden, logc, dden, dlhalf, z0, g[l], s_math);
+                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, rden, logc, dden, dlhalf, z1, g[l], s_math);
                 }
             }
         }
@@ -487,18 +492,21 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
 // Parity-test hooks (amc_selftest_*): the arithmetic-spec primitives, one value per thread.
 __global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
 {
+    __shared__ double s_math[TAB_DOUBLES];
+    stage_math_tables(s_math, threadIdx.x, blockDim.x);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double v = a[i];
     double s, c, r = 0.0;
     switch (fn) {
-    case 0: r = exp_f64(v); break;
+    case 0: r = exp_f64(v, s_math); break;
     case 1: r = log_f64(v); break;
-    case 2: sincospi_f64(v, s, c); r = s; break;
-    case 3: sincospi_f64(v, s, c); r = c; break;
+    case 2: sincospi_f64(v, s, c, s_math); r = s; break;
+    case 3: sincospi_f64(v, s, c, s_math); r = c; break;
     case 4: r = __builtin_sqrt(v); break;
     case 5: r = v / b[i]; break;
     case 6: r = div_by_const(v, b[i], 1.0 / b[i]); break;
+    case 7: r = logbm_f64(v, s_math); break;
     default: break;
     }
     out[i] = r;

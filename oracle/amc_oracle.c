@@ -11,6 +11,7 @@
  * fma() and nothing else may be contracted, or host and device diverge.
  */
 #include "amc_oracle.h"
+#include "amc_tables.inc"
 
 #include <math.h>
 #include <stdlib.h>
@@ -26,6 +27,9 @@
 /* bit-compatible with rocRAND's philox4x32_10 engine                        */
 /* (/opt/rocm/include/rocrand/rocrand_philox4x32_10.h:270-303).              */
 /* ------------------------------------------------------------------------ */
+static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
 void amo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
@@ -59,14 +63,28 @@ void amo_counter(uint64_t pair, uint64_t t, uint32_t draw, uint32_t stream, uint
 static void draw4(const amo_sim *s, uint64_t pair, uint64_t t, uint32_t draw,
                   uint32_t stream, uint32_t out[4]);
 
-/* rand(rng)::Float64 in [0,1) (metropolis.jl:184): 53 random bits * 2^-53.
- * Same bit packing as rocRAND's uniform_distribution_double(v1, v2)
- * (rocrand_uniform.h:102-109) without its +2^-53 shift, so 0 is included and
- * 1 excluded like Julia's rand(). */
-double amo_uniform53(uint32_t lo, uint32_t hi)
+/* rand(rng)::Float64 in [0,1) (metropolis.jl:184).  Julia's own construction (Random stdlib,
+ * rand(r, CloseOpen12()) - 1): 52 random bits become the significand of a double in [1,2), then
+ * subtract 1.  The 64-bit word is (hi:lo), its top 52 bits are used. */
+static inline double bits_to_12(uint32_t lo, uint32_t hi, uint64_t expo)
 {
-    uint64_t v = (uint64_t)lo | ((uint64_t)(hi >> 11) << 32);
-    return (double)v * 0x1.0p-53;
+    uint64_t m = (((uint64_t)hi << 32) | lo) >> 12;
+    return u2d(expo | m);
+}
+
+double amo_uniform_co(uint32_t lo, uint32_t hi)      /* [0,1): d - 1, d in [1,2) */
+{
+    return bits_to_12(lo, hi, 0x3ff0000000000000ull) - 1.0;
+}
+
+double amo_uniform_oc(uint32_t lo, uint32_t hi)      /* (0,1]: 2 - d (Box-Muller radius argument) */
+{
+    return 2.0 - bits_to_12(lo, hi, 0x3ff0000000000000ull);
+}
+
+double amo_angle_oc2(uint32_t lo, uint32_t hi)       /* (0,2]: 4 - d', d' in [2,4) (Box-Muller angle / pi) */
+{
+    return 4.0 - bits_to_12(lo, hi, 0x4000000000000000ull);
 }
 
 /* 32-bit uniform in [0,1) for the categorical move pick. */
@@ -81,38 +99,33 @@ double amo_uniform32(uint32_t v)
 /* tools/gen_math_constants.py.  Accuracy ~1 ulp; NOT correctly rounded, so   */
 /* vs Julia's exp/log an accept decision can flip with probability ~1e-16.   */
 /* ------------------------------------------------------------------------ */
-static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
-static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
 double amo_exp(double x)
 {
+    /* exp(x) = 2^m * 2^(j/32) * e^r, k = 32 m + j = rint(x * 32/ln2), |r| <= ln2/64: table of 32
+     * correctly rounded 2^(j/32) and a degree-6 Taylor polynomial (error < 4e-18). */
     if (x != x) return x;
     if (x > 709.0) return INFINITY;       /* documented domain cut (true overflow at 709.78) */
     if (x < -708.0) return 0.0;           /* flush: no subnormal results */
-    const double LOG2E = 0x1.71547652b82fep+0;
-    const double LN2_HI = 0x1.62e42fee00000p-1;
-    const double LN2_LO = 0x1.a39ef35793c76p-33;
+    const double INV_L = 0x1.71547652b82fep+5;      /* 32/ln2 */
+    const double L_HI = 0x1.62e42fee00000p-6;       /* ln2/32 split hi/lo */
+    const double L_LO = 0x1.a39ef35793c76p-38;
     const double SHIFT = 0x1.8p52;
-    double t = x * LOG2E + SHIFT;         /* round-to-nearest-even integer in the low bits */
+    double t = fma(x, INV_L, SHIFT);      /* round-to-nearest-even integer in the low bits */
     double kd = t - SHIFT;
-    int64_t ki = (int64_t)(int32_t)(uint32_t)d2u(t);
-    double r = fma(-kd, LN2_HI, x);
-    r = fma(-kd, LN2_LO, r);
-    double p = 0x1.6124613a86d09p-33;     /* 1/13! */
-    p = fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = fma(p, r, 0x1.ae64567f544e4p-26);
-    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = fma(p, r, 0x1.71de3a556c734p-19);
-    p = fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = fma(p, r, 0x1.6c16c16c16c17p-10);
+    int32_t ki = (int32_t)(uint32_t)d2u(t);
+    double r = fma(-kd, L_HI, x);
+    r = fma(-kd, L_LO, r);
+    double p = 0x1.6c16c16c16c17p-10;     /* 1/720 */
     p = fma(p, r, 0x1.1111111111111p-7);
     p = fma(p, r, 0x1.5555555555555p-5);
     p = fma(p, r, 0x1.5555555555555p-3);
     p = fma(p, r, 0x1.0000000000000p-1);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return u2d(d2u(p) + ((uint64_t)ki << 52));   /* p * 2^k, p in [0.7,1.42], result normal */
+    double y = AMC_TAB_EXP2[ki & 31] * p;
+    int64_t m = (int64_t)(ki >> 5);       /* arithmetic shift: floor(k / 32) */
+    return u2d(d2u(y) + ((uint64_t)m << 52));   /* y * 2^m, y in [0.98, 2.02), result normal */
 }
 
 /* log(x): argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), then the
@@ -151,53 +164,72 @@ double amo_log(double x)
     return dk * LN2_HI - ((hfsq - fma(s, hfsq + R, dk * LN2_LO)) - f);
 }
 
-/* sincospi(w) for the Box-Muller angle; any finite |w| < 2^31 is handled. */
+/* log(u) for the Box-Muller radius, u positive normal (here u in [2^-52, 1]): division-free.
+ * u = 2^k * m with m centred into [sqrt(2)/2, sqrt(2)) as in amo_log; table index = (low exponent
+ * bit : top 7 significand bits) of m; r = m/c - 1 by one fma with INVC = RN(1/c), then
+ * log m = LOGC + log1p(r), log1p by its degree-7 Taylor polynomial (|r| < 2^-7: error < 2e-18).
+ * The two intervals touching 1 use c = 1, so log(1) = 0 exactly and -2 log u is never negative. */
+double amo_logbm(double u)
+{
+    const double LN2_HI = 0x1.62e42fee00000p-1;
+    const double LN2_LO = 0x1.a39ef35793c76p-33;
+    uint64_t ux = d2u(u);
+    uint32_t hx = (uint32_t)(ux >> 32);
+    int32_t k = (int32_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;       /* 1 if m >= sqrt(2): halve it */
+    k += (int32_t)(i >> 20);
+    hx |= i ^ 0x3ff00000u;                          /* exponent field 0x3ff (m >= 1) or 0x3fe (m < 1) */
+    double m = u2d(((uint64_t)hx << 32) | (ux & 0xffffffffull));
+    uint32_t idx = (hx >> 13) & 0xffu;
+    double r = fma(m, AMC_TAB_LOG_INVC[idx], -1.0);
+    double p = 0x1.2492492492492p-3;                /* 1/7 */
+    p = fma(p, r, -0x1.5555555555555p-3);           /* -1/6 */
+    p = fma(p, r, 0x1.999999999999ap-3);            /*  1/5 */
+    p = fma(p, r, -0x1.0000000000000p-2);           /* -1/4 */
+    p = fma(p, r, 0x1.5555555555555p-2);            /*  1/3 */
+    p = fma(p, r, -0x1.0000000000000p-1);           /* -1/2 */
+    p = fma(p, r, 1.0);
+    double dk = (double)k;
+    double hi = fma(dk, LN2_HI, AMC_TAB_LOG_LOGC[idx]);
+    return fma(p, r, fma(dk, LN2_LO, hi));
+}
+
+/* sincospi(w) for the Box-Muller angle, |w| < 2^24: n = rint(64 w), r = w - n/64 (exact, |r| <= 1/128),
+ * sin(pi r), cos(pi r) by short Taylor polynomials, rotated by the table angle pi*(n mod 128)/64. */
 void amo_sincospi(double w, double *sp, double *cp)
 {
     const double SHIFT = 0x1.8p52;
-    double t = (w + w) + SHIFT;           /* n = rint(2w) */
+    double t = fma(w, 64.0, SHIFT);
     double nd = t - SHIFT;
-    uint32_t n = (uint32_t)d2u(t);
-    double r = w - 0.5 * nd;              /* exact, |r| <= 1/4 */
+    uint32_t j = (uint32_t)d2u(t) & 127u;
+    double r = fma(nd, -0x1.0p-6, w);
     double z = r * r;
-    double ps = -0x1.6fadb9f155744p-16;
-    ps = fma(ps, z, 0x1.e8f434d018d63p-12);
-    ps = fma(ps, z, -0x1.e3074fde8871fp-8);
-    ps = fma(ps, z, 0x1.50783487ee782p-4);
-    ps = fma(ps, z, -0x1.32d2cce62bd86p-1);
-    ps = fma(ps, z, 0x1.466bc6775aae2p+1);
-    ps = fma(ps, z, -0x1.4abbce625be53p+2);
-    double s = fma(r, 0x1.1a62633145c07p-53, (r * z) * ps);
-    s = fma(r, 0x1.921fb54442d18p+1, s);
-    double pc = 0x1.20c62c2f2d7f5p-18;
-    pc = fma(pc, z, -0x1.b6e24f44b128fp-14);
-    pc = fma(pc, z, 0x1.f9d38a3763cc3p-10);
-    pc = fma(pc, z, -0x1.a6d1f2a204a8cp-6);
-    pc = fma(pc, z, 0x1.e1f506891babbp-3);
-    pc = fma(pc, z, -0x1.55d3c7e3cbffap+0);
-    pc = fma(pc, z, 0x1.03c1f081b5ac4p+2);
-    pc = fma(pc, z, -0x1.3bd3cc9be45dep+2);
-    double c = fma(pc, z, 1.0);
-    switch (n & 3u) {
-    case 0: *sp = s;  *cp = c;  break;
-    case 1: *sp = c;  *cp = -s; break;
-    case 2: *sp = -s; *cp = -c; break;
-    default: *sp = -c; *cp = s; break;
-    }
+    double ps = -0x1.32d2cce62bd86p-1;              /* -pi^7/7! */
+    ps = fma(ps, z, 0x1.466bc6775aae2p+1);          /*  pi^5/5! */
+    ps = fma(ps, z, -0x1.4abbce625be53p+2);         /* -pi^3/3! */
+    ps = fma(ps, z, 0x1.921fb54442d18p+1);          /*  pi      */
+    double sr = ps * r;
+    double pc = -0x1.55d3c7e3cbffap+0;              /* -pi^6/6! */
+    pc = fma(pc, z, 0x1.03c1f081b5ac4p+2);          /*  pi^4/4! */
+    pc = fma(pc, z, -0x1.3bd3cc9be45dep+2);         /* -pi^2/2! */
+    double cr = fma(pc, z, 1.0);
+    double S = AMC_TAB_SINPI[j], C = AMC_TAB_COSPI[j];
+    *sp = fma(S, cr, C * sr);
+    *cp = fma(C, cr, -(S * sr));
 }
 
 /* Third-party piece 2: randn.  The reference draws rand(rng, Normal(0, sigma))
  * (particle_1d.jl:57), i.e. Distributions.jl 0.25 `mu + sigma * randn(rng)`.
- * Julia's ziggurat is replaced by rocRAND's Box-Muller map
- * box_muller_double(uint4) (rocrand_normal.h:78-98): u in (0,1], w in (0,2],
- * z = sqrt(-2 log u) * (sinpi w, cospi w).  One call serves a chain PAIR. */
+ * Julia's ziggurat is replaced by a Box-Muller pair in the shape of rocRAND's
+ * box_muller_double(uint4) (rocrand_normal.h:78-98): u in (0,1] from words (x,y), w in (0,2]
+ * from (z,w), z = sqrt(-2 log u) * (sinpi w, cospi w), with 52-bit uniforms and the table-driven
+ * log / sincospi above.  One call serves a chain PAIR. */
 void amo_box_muller(const uint32_t v[4], double z[2])
 {
-    uint64_t v1 = (uint64_t)v[0] ^ ((uint64_t)v[1] << 21);
-    double u = 0x1.0p-53 + (double)v1 * 0x1.0p-53;
-    uint64_t v2 = (uint64_t)v[2] ^ ((uint64_t)v[3] << 21);
-    double w = 0x1.0p-52 + (double)v2 * 0x1.0p-52;
-    double s = sqrt(-2.0 * amo_log(u));
+    double u = amo_uniform_oc(v[0], v[1]);          /* (0,1] */
+    double w = amo_angle_oc2(v[2], v[3]);           /* (0,2] */
+    double s = sqrt(-2.0 * amo_logbm(u));
     double sn, cs;
     amo_sincospi(w, &sn, &cs);
     z[0] = sn * s;
@@ -363,7 +395,7 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         draw4(s, pair, t, AMO_DRAW_NORMAL, AMO_STREAM_METROPOLIS, v);
         amo_box_muller(v, zz);
         draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, v);
-        double u = amo_uniform53(v[2 * half], v[2 * half + 1]);
+        double u = amo_uniform_co(v[2 * half], v[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
         move->accepted_calls += mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
         move->total_calls += 1;                                    /* :209 */
@@ -421,7 +453,7 @@ void amo_init_uniform(amo_sim *s, double lo, double hi)
         int half = (int)(g & 1u);
         uint32_t v[4];
         draw4(s, g >> 1, 0, 0, AMO_STREAM_INIT, v);
-        double u = amo_uniform53(v[2 * half], v[2 * half + 1]);
+        double u = amo_uniform_co(v[2 * half], v[2 * half + 1]);
         double x = lo + (hi - lo) * u;
         s->chains[c].x = x;
         s->chains[c].e = amo_potential(s->pot, x);

@@ -53,7 +53,10 @@ double amo_exp(double x);
 double amo_log(double x);
 void   amo_sincospi(double w, double *s, double *c);
 void   amo_box_muller(const uint32_t v[4], double z[2]);
-double amo_uniform53(uint32_t lo, uint32_t hi);   /* [0,1), 53 bits */
+double amo_logbm(double u);                         /* table-driven log for the Box-Muller radius */
+double amo_uniform_co(uint32_t lo, uint32_t hi);    /* [0,1), 52 bits: Julia's rand(Float64) construction */
+double amo_uniform_oc(uint32_t lo, uint32_t hi);    /* (0,1] */
+double amo_angle_oc2(uint32_t lo, uint32_t hi);     /* (0,2] */
 double amo_uniform32(uint32_t v);                 /* [0,1), 32 bits */
 double amo_potential(int pot, double x);
 double amo_log_proposal_density(double delta, double sigma);

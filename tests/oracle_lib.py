@@ -29,7 +29,7 @@ _lib = None
 def build(force: bool = False) -> str:
     src_newer = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-        for f in ("amc_oracle.c", "amc_oracle.h", "Makefile"))
+        for f in ("amc_oracle.c", "amc_oracle.h", "amc_tables.inc", "Makefile"))
     if force or src_newer:
         subprocess.run(["make", "-C", ORACLE_DIR, "-B"], check=True, capture_output=True)
     return LIB_PATH
@@ -53,7 +53,10 @@ def load() -> C.CDLL:
         "amo_log": (C.c_double, [C.c_double]),
         "amo_sincospi": (None, [C.c_double, dp, dp]),
         "amo_box_muller": (None, [u32p, dp]),
-        "amo_uniform53": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "amo_logbm": (C.c_double, [C.c_double]),
+        "amo_uniform_co": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "amo_uniform_oc": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "amo_angle_oc2": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_uniform32": (C.c_double, [C.c_uint32]),
         "amo_potential": (C.c_double, [C.c_int, C.c_double]),
         "amo_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),

@@ -33,7 +33,10 @@ def test_device_math_bit_exact(gpu, oracle):
     xs = np.concatenate([rng.uniform(0, 1, 200000), np.exp(rng.uniform(-700, 700, 50000)),
                          [1.0, 2.0 ** -53, 5e-324, 2.2e-308, 0.0, np.inf, -1.0, np.nan]])
     assert np.array_equal(bits(gpu.selftest_math("log", xs)), bits([lib.amo_log(v) for v in xs]))
-    ws = np.concatenate([(rng.integers(0, 2 ** 53, 200000) + 1) * 2.0 ** -52, [0.25, 0.5, 1.0, 1.5, 2.0, 2.0 ** -52]])
+    us = np.concatenate([1.0 - rng.integers(0, 2 ** 52, 200000) * 2.0 ** -52, 1.0 - rng.uniform(0, 0.02, 50000),
+                         np.exp(rng.uniform(-36, 0, 50000)), [1.0, 1.0 - 2.0 ** -52, 2.0 ** -52, 0.5, 0.7071067811865476]])
+    assert np.array_equal(bits(gpu.selftest_math("logbm", us)), bits([lib.amo_logbm(v) for v in us]))
+    ws = np.concatenate([2.0 - rng.integers(0, 2 ** 52, 200000) * 2.0 ** -51, [0.25, 0.5, 1.0, 1.5, 2.0, 2.0 ** -51]])
     ref = np.array([oracle.sincospi(v) for v in ws])
     assert np.array_equal(bits(gpu.selftest_math("sinpi", ws)), bits(ref[:, 0]))
     assert np.array_equal(bits(gpu.selftest_math("cospi", ws)), bits(ref[:, 1]))

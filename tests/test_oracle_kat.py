@@ -37,8 +37,8 @@ def test_draw_schedule_golden(oracle):
         assert w == d["words"]
         assert list(oracle.box_muller(w)) == list(fh(d["box_muller"]))
         lib = oracle.load()
-        assert lib.amo_uniform53(w[0], w[1]) == float.fromhex(d["u53"][0])
-        assert lib.amo_uniform53(w[2], w[3]) == float.fromhex(d["u53"][1])
+        assert lib.amo_uniform_co(w[0], w[1]) == float.fromhex(d["u_co"][0])
+        assert lib.amo_uniform_co(w[2], w[3]) == float.fromhex(d["u_co"][1])
         assert lib.amo_uniform32(w[0]) == float.fromhex(d["u32"])
 
 
@@ -57,33 +57,41 @@ def test_counter_packing_is_rocrand_layout(oracle):
 
 
 def test_uniform_maps(oracle):
+    """52 random bits -> significand of a double in [1,2) (or [2,4)), Julia's rand(Float64) construction."""
     lib = oracle.load()
-    assert lib.amo_uniform53(0, 0) == 0.0                              # [0, 1): 0 included ...
-    assert lib.amo_uniform53(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -53   # ... 1 excluded (Julia rand())
-    assert lib.amo_uniform53(1, 0) == 2.0 ** -53
-    assert lib.amo_uniform53(0, 1 << 11) == 2.0 ** -21
-    assert lib.amo_uniform53(0, (1 << 11) - 1) == 0.0                  # low 11 bits of the high word unused
+    assert lib.amo_uniform_co(0, 0) == 0.0                                   # [0, 1): 0 included ...
+    assert lib.amo_uniform_co(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -52    # ... 1 excluded (Julia rand())
+    assert lib.amo_uniform_co(0, 1 << 31) == 0.5 and lib.amo_uniform_co(1 << 12, 0) == 2.0 ** -52
+    assert lib.amo_uniform_co((1 << 12) - 1, 0) == 0.0                       # low 12 bits of the low word unused
+    assert lib.amo_uniform_oc(0, 0) == 1.0 and lib.amo_uniform_oc(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -52   # (0, 1]
+    assert lib.amo_angle_oc2(0, 0) == 2.0 and lib.amo_angle_oc2(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -51     # (0, 2]
     assert lib.amo_uniform32(0) == 0.0 and lib.amo_uniform32(0xFFFFFFFF) == 1.0 - 2.0 ** -32
-
-
-def test_box_muller_is_rocrand_map(oracle):
-    # rocrand_normal.h:78-98: u = 2^-53 + v1*2^-53, w = 2^-52 + v2*2^-52, z = sqrt(-2 log u)*(sinpi w, cospi w)
-    rnd = random.Random(3)
+    rnd = random.Random(7)
     for _ in range(2000):
+        lo, hi = rnd.getrandbits(32), rnd.getrandbits(32)
+        m = ((hi << 32) | lo) >> 12
+        assert lib.amo_uniform_co(lo, hi) == m * 2.0 ** -52
+        assert lib.amo_uniform_oc(lo, hi) == 1.0 - m * 2.0 ** -52
+        assert lib.amo_angle_oc2(lo, hi) == 2.0 - m * 2.0 ** -51
+
+
+def test_box_muller_map(oracle):
+    """Shape of rocRAND's box_muller_double(uint4) (rocrand_normal.h:78-98): words (x,y) -> u in (0,1],
+    (z,w) -> angle in (0,2], z = sqrt(-2 log u) * (sinpi, cospi); checked against libm."""
+    lib = oracle.load()
+    rnd = random.Random(3)
+    for _ in range(3000):
         v = [rnd.getrandbits(32) for _ in range(4)]
-        v1 = v[0] ^ (v[1] << 21)
-        v2 = v[2] ^ (v[3] << 21)
-        u = 2.0 ** -53 + v1 * 2.0 ** -53
-        w = 2.0 ** -52 + v2 * 2.0 ** -52
+        u = lib.amo_uniform_oc(v[0], v[1])
+        w = lib.amo_angle_oc2(v[2], v[3])
         s = math.sqrt(-2.0 * math.log(u))
         z0, z1 = oracle.box_muller(v)
         r = math.fmod(w, 2.0)
-        assert z0 == pytest.approx(s * math.sin(math.pi * r), rel=1e-13, abs=1e-14)
-        assert z1 == pytest.approx(s * math.cos(math.pi * r), rel=1e-13, abs=1e-14)
-    # u = 1 (v1 = 2^53 - 1) gives exactly zero radius, never NaN / inf
-    assert all(abs(z) == 0.0 for z in oracle.box_muller([0x001FFFFF, 0xFFFFFFFF, 5, 5]))
-    z0, z1 = oracle.box_muller([0, 0, 0, 0])           # u = 2^-53: the largest radius, finite
-    assert math.isfinite(z0) and math.isfinite(z1) and math.hypot(z0, z1) == pytest.approx(math.sqrt(2 * 53 * math.log(2)))
+        assert z0 == pytest.approx(s * math.sin(math.pi * r), rel=1e-13, abs=2e-15)
+        assert z1 == pytest.approx(s * math.cos(math.pi * r), rel=1e-13, abs=2e-15)
+    assert oracle.box_muller([0, 0, 5, 5]) == (0.0, 0.0)               # u = 1: zero radius exactly, never NaN
+    z0, z1 = oracle.box_muller([0xFFFFFFFF, 0xFFFFFFFF, 0, 0])         # u = 2^-52: largest radius, angle 2 pi
+    assert math.isfinite(z0) and math.isfinite(z1) and math.hypot(z0, z1) == pytest.approx(math.sqrt(2 * 52 * math.log(2)))
 
 
 def test_normal_moments(oracle):
@@ -98,7 +106,10 @@ def test_exp_accuracy_and_edges(oracle):
     lib = oracle.load()
     rnd = random.Random(1)
     worst = max(ulp_err(lib.amo_exp(x), math.exp(x)) for x in (rnd.uniform(-708, 700) for _ in range(100000)))
-    assert worst <= 1.0
+    assert worst <= 2.0
+    for _ in range(100000):                      # the accept shortcut relies on these two inequalities
+        x = rnd.uniform(0, 3)
+        assert lib.amo_exp(x) >= 1.0 and lib.amo_exp(-x) <= 1.0
     assert lib.amo_exp(0.0) == 1.0 and lib.amo_exp(-0.0) == 1.0
     assert all(lib.amo_exp(x) >= 1.0 for x in (1e-300, 1e-17, 1e-9, 0.5, 700.0))   # alpha = 1 whenever dlogp >= 0
     assert all(lib.amo_exp(-x) <= 1.0 for x in (1e-300, 1e-17, 1e-9, 0.5, 700.0))
@@ -120,16 +131,29 @@ def test_log_accuracy_and_edges(oracle):
     assert lib.amo_log(2.0 ** -53) == pytest.approx(-53 * math.log(2), rel=1e-15)
 
 
+def test_logbm_accuracy_sign_and_exact_zero(oracle):
+    """Table-driven Box-Muller log: <= 1 ulp, log(1) == 0 exactly, never positive on (0, 1]."""
+    lib = oracle.load()
+    rnd = random.Random(8)
+    us = [lib.amo_uniform_oc(rnd.getrandbits(32), rnd.getrandbits(32)) for _ in range(100000)]
+    us += [1.0 - rnd.random() * 0.02 for _ in range(50000)] + [math.exp(rnd.uniform(-36, 0)) for _ in range(50000)]
+    us += [1.0, 1.0 - 2.0 ** -52, 1.0 - 2.0 ** -53 * 2, 2.0 ** -52, 0.5, 0.7071067811865476, 0.7071067811865475]
+    for u in us:
+        got = lib.amo_logbm(u)
+        assert got <= 0.0 and ulp_err(got, math.log(u)) <= 1.0, u
+    assert lib.amo_logbm(1.0) == 0.0
+
+
 def test_sincospi_accuracy_and_quadrants(oracle):
     rnd = random.Random(4)
     for _ in range(50000):
-        w = (rnd.getrandbits(53) + 1) * 2.0 ** -52
+        w = oracle.load().amo_angle_oc2(rnd.getrandbits(32), rnd.getrandbits(32))
         s, c = oracle.sincospi(w)
         r = math.fmod(w, 2.0)
         assert abs(s - math.sin(math.pi * r)) < 1e-15 and abs(c - math.cos(math.pi * r)) < 1e-15
         assert abs(s * s + c * c - 1) < 5e-16
-    assert oracle.sincospi(0.5) == (1.0, -0.0) or oracle.sincospi(0.5)[0] == 1.0
-    assert oracle.sincospi(1.0)[1] == -1.0 and oracle.sincospi(1.5)[0] == -1.0 and oracle.sincospi(2.0)[1] == 1.0
+    assert oracle.sincospi(0.5) == (1.0, 0.0) and oracle.sincospi(1.0) == (0.0, -1.0)
+    assert oracle.sincospi(1.5) == (-1.0, 0.0) and oracle.sincospi(2.0) == (0.0, 1.0)
     assert oracle.sincospi(0.25) == pytest.approx((math.sqrt(0.5), math.sqrt(0.5)), rel=3e-16)
 
 
