@@ -86,6 +86,18 @@ __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, do
     return accept;
 }
 
+// 16-byte store of a chain pair with the sc1 (write-through) policy: the line does not stay dirty
+// in the XCD's L2, so the kernel boundary does not pay for writing back up to 32 MB of dirty lines
+// (MI355X_MICROARCH.md, store flavours / "boundary" row: + B / 6 TB/s for B dirty bytes).
+__device__ __forceinline__ void store_pair_writethrough(double* p, double2 v)
+{
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    d2_t t;
+    t.x = v.x;
+    t.y = v.y;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+}
+
 struct SweepArgs {
     double* x;
     const double* beta_arr;       // nullptr unless per-chain beta
@@ -111,7 +123,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 6.4 KB
-    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     const int K = a.n_moves;
     if (MULTI) {
         for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {
@@ -135,27 +146,40 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     unsigned long long wave_acc = 0;   // wave-uniform
 
     // wave-uniform trip count: every lane of a wave runs the same iterations (ballot below).
-    // Software prefetch: the 16-B load of the NEXT grid-stride iteration is issued before this
-    // iteration's ~600 VALU instructions, so HBM latency hides behind the wave's own arithmetic.
-    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    // Software prefetch, two grid-stride iterations deep: the 16-B loads of iterations i+1 and i+2
+    // are in flight while iteration i's ~280 VALU instructions run, so HBM latency (also under a
+    // saturated memory system) hides behind the wave's own arithmetic.  The first two loads are
+    // issued BEFORE the math tables are staged into LDS, so that staging overlaps their latency.
+    auto load_x = [&](int64_t b) -> double2 {
+        const int64_t q = b + threadIdx.x;
+        return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
+    };
+    auto load_b = [&](int64_t b) -> double2 {
+        const int64_t q = b + threadIdx.x;
+        return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
+    };
+    double2 x_n1 = {0.0, 0.0}, x_n2 = {0.0, 0.0}, b_n1 = {a.beta, a.beta}, b_n2 = {a.beta, a.beta};
     if (first < n_pairs) {
-        const int64_t p0 = first + threadIdx.x;
-        const int64_t pc0 = (p0 < n_pairs) ? p0 : 0;
-        x_nxt = *reinterpret_cast<const double2*>(a.x + 2 * pc0);
-        if (BETA) b_nxt = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pc0);
+        x_n1 = load_x(first);
+        if (BETA) b_n1 = load_b(first);
     }
+    if (first + stride < n_pairs) {
+        x_n2 = load_x(first + stride);
+        if (BETA) b_n2 = load_b(first + stride);
+    }
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     for (int64_t base = first; base < n_pairs; base += stride) {
         const int64_t p = base + threadIdx.x;
         const bool v0 = p < n_pairs;
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
         const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
-        double2 xv = x_nxt;
-        const double b0 = b_nxt.x, b1 = b_nxt.y;
-        if (base + stride < n_pairs) {
-            const int64_t pn = base + stride + threadIdx.x;
-            const int64_t pcn = (pn < n_pairs) ? pn : 0;
-            x_nxt = *reinterpret_cast<const double2*>(a.x + 2 * pcn);
-            if (BETA) b_nxt = *reinterpret_cast<const double2*>(a.beta_arr + 2 * pcn);
+        double2 xv = x_n1;
+        const double b0 = b_n1.x, b1 = b_n1.y;
+        x_n1 = x_n2;
+        b_n1 = b_n2;
+        if (base + 2 * stride < n_pairs) {
+            x_n2 = load_x(base + 2 * stride);
+            if (BETA) b_n2 = load_b(base + 2 * stride);
         }
         const uint64_t pair = a.pair0 + (uint64_t)pc;
         uint32_t cnt0 = 0, cnt1 = 0;
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             }
         }
         if (v1) {
-            *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
+            store_pair_writethrough(a.x + 2 * p, xv);
         } else if (v0) {
             a.x[2 * p] = xv.x;
         }
