@@ -125,6 +125,22 @@ int  amc_download_counters(amc_handle *h, int64_t *accepted, int64_t *total);
 /* Pool-wide sums over local chains: accepted[k], total[k] (exact integers). */
 int  amc_counter_totals(amc_handle *h, int64_t *accepted, int64_t *total);
 
+/* Resume: restore pools[c][k].accepted_calls / total_calls ([k*n_chains + c], total may be NULL for
+ * K = 1) on a handle with per-chain counters; or, for a K = 1 handle without them, the pool-wide
+ * accepted total and the number of counted steps.  Together with amc_upload_state, amc_set_step,
+ * amc_set_estimator_step and amc_set_parameters this restores a run exactly (the reference's
+ * StoreBackups, src/algorithms.jl:264-303, is write-only and saves neither RNG state nor counters). */
+int  amc_upload_counters(amc_handle *h, const int64_t *accepted, const int64_t *total);
+int  amc_set_counter_totals(amc_handle *h, const int64_t *accepted, uint64_t steps_counted);
+
+/* Device-side stand-ins for the per-chain text trajectories (StoreTrajectories, src/algorithms.jl:154-210;
+ * the pooled positions are what test/distribution_test.jl:33-37 and the density plot consume):
+ * histogram over n_bins half-open bins of [lo, hi), bin = floor((x - lo) * (n_bins / (hi - lo)));
+ * counts has n_bins + 3 entries: bins, then x < lo, x >= hi, NaN.  Local shard only (sum across shards). */
+int  amc_histogram(amc_handle *h, double lo, double hi, int n_bins, uint64_t *counts);
+/* x[first + i*stride], i < count: a strided binary snapshot of this shard. */
+int  amc_download_strided(amc_handle *h, int64_t first, int64_t stride, int64_t count, double *x);
+
 /* n x make_step!(simulation, ::Metropolis) (metropolis.jl:302-309): each is
  * `sweepstep` mc_step!s per chain.  The n*sweepstep steps run fused in one launch
  * (state stays in registers); results are identical to n separate calls. */
@@ -132,6 +148,9 @@ int  amc_sweep(amc_handle *h, int64_t n_sweeps);
 /* MH steps done per chain so far (the Philox step index); settable for resume. */
 int  amc_get_step(amc_handle *h, uint64_t *t);
 int  amc_set_step(amc_handle *h, uint64_t t);
+/* estimator make_step! calls done so far (the estimator stream's step index). */
+int  amc_get_estimator_step(amc_handle *h, uint64_t *t);
+int  amc_set_estimator_step(amc_handle *h, uint64_t t);
 
 /* callback_energy (particle_1d.jl:68-70) / callback_acceptance (metropolis.jl:319-321)
  * / position moments as LOCAL sums; deterministic two-pass device reduction.

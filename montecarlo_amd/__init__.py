@@ -13,6 +13,7 @@ from .policy_guided import (ANPG, BLANPG, BLAPG, BLPG, NPG, VPG, GradientData, P
 from .sharding import allreduce_sum, shard_range
 from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
                          build_schedule, julia_repr, run)
+from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
 from .system import Displacement, Move, ParticleChains, StandardGaussian, potential
 
 __all__ = [
@@ -23,5 +24,6 @@ __all__ = [
     "allreduce_sum", "shard_range",
     "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
     "build_schedule", "julia_repr", "run",
+    "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
     "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
 ]

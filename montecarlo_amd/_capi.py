@@ -75,6 +75,12 @@ def load() -> C.CDLL:
         "amc_download_state": (C.c_int, [H, dp, dp]),
         "amc_download_counters": (C.c_int, [H, i64p, i64p]),
         "amc_counter_totals": (C.c_int, [H, i64p, i64p]),
+        "amc_upload_counters": (C.c_int, [H, i64p, i64p]),
+        "amc_set_counter_totals": (C.c_int, [H, i64p, C.c_uint64]),
+        "amc_histogram": (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_uint64)]),
+        "amc_download_strided": (C.c_int, [H, C.c_int64, C.c_int64, C.c_int64, dp]),
+        "amc_get_estimator_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "amc_set_estimator_step": (C.c_int, [H, C.c_uint64]),
         "amc_sweep": (C.c_int, [H, C.c_int64]),
         "amc_get_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "amc_set_step": (C.c_int, [H, C.c_uint64]),
@@ -201,6 +207,37 @@ class HipEngine:
         p = C.POINTER(C.c_int64)
         _check(self._lib.amc_counter_totals(self._h, acc.ctypes.data_as(p), tot.ctypes.data_as(p)))
         return acc, tot
+
+    def upload_counters(self, accepted: np.ndarray, total: Optional[np.ndarray] = None) -> None:
+        p = C.POINTER(C.c_int64)
+        a = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n_moves, self.n_chains)
+        t = None if total is None else np.ascontiguousarray(total, dtype=np.int64).reshape(self.n_moves, self.n_chains)
+        _check(self._lib.amc_upload_counters(self._h, a.ctypes.data_as(p), None if t is None else t.ctypes.data_as(p)))
+
+    def set_counter_totals(self, accepted: int, steps_counted: int) -> None:
+        a = np.array([int(accepted)], dtype=np.int64)
+        _check(self._lib.amc_set_counter_totals(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), int(steps_counted)))
+
+    def histogram(self, lo: float, hi: float, n_bins: int) -> np.ndarray:
+        """counts[n_bins + 3]: the bins of [lo, hi), then below lo, at/above hi, NaN (this shard only)."""
+        out = np.zeros(int(n_bins) + 3, dtype=np.uint64)
+        _check(self._lib.amc_histogram(self._h, float(lo), float(hi), int(n_bins), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def download_strided(self, first: int, stride: int, count: int) -> np.ndarray:
+        out = np.empty(int(count), dtype=np.float64)
+        _check(self._lib.amc_download_strided(self._h, int(first), int(stride), int(count), _dptr(out)))
+        return out
+
+    @property
+    def estimator_step(self) -> int:
+        t = C.c_uint64(0)
+        _check(self._lib.amc_get_estimator_step(self._h, C.byref(t)))
+        return t.value
+
+    @estimator_step.setter
+    def estimator_step(self, t: int) -> None:
+        _check(self._lib.amc_set_estimator_step(self._h, int(t)))
 
     # -- hot path ----------------------------------------------------------------
     def sweep(self, n_sweeps: int = 1) -> None:

@@ -484,6 +484,116 @@ int amc_sweep(amc_handle* h, int64_t n_sweeps)
     return AMC_OK;
 }
 
+int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* total)
+{
+    if (!h || !accepted) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: NULL argument");
+    if (!h->counters)
+        return fail(AMC_ERR_STATE, "amc_upload_counters: handle was created with per_chain_counters = 0 "
+                                   "(use amc_set_counter_totals)");
+    if (h->K > 1 && !total) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: total is required when K > 1");
+    AMC_HIP(hipSetDevice(h->device));
+    std::vector<uint32_t> buf((size_t)h->M);
+    unsigned long long acc_sum = 0;
+    for (int k = 0; k < h->K; ++k) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int64_t* src = pass == 0 ? accepted : total;
+            uint32_t* dst = pass == 0 ? h->d_acc : h->d_tot;
+            if (!src || !dst) continue;
+            for (int64_t c = 0; c < h->M; ++c) {
+                const int64_t v = src[(int64_t)k * h->M + c];
+                if (v < 0 || v > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
+                buf[(size_t)c] = (uint32_t)v;
+                if (pass == 0) acc_sum += (unsigned long long)v;
+            }
+            AMC_HIP(hipMemcpyAsync(dst + (size_t)k * h->M_pad, buf.data(), (size_t)h->M * sizeof(uint32_t),
+                                   hipMemcpyHostToDevice, h->stream));
+            AMC_HIP(hipStreamSynchronize(h->stream));
+        }
+    }
+    if (h->K == 1) {
+        // total_calls is the same on every chain for K = 1: it IS the number of counted steps
+        if (total) {
+            for (int64_t c = 1; c < h->M; ++c)
+                if (total[c] != total[0]) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: K = 1 totals must be uniform");
+            h->t_counted = (uint64_t)total[0];
+        }
+        AMC_HIP(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
+        AMC_HIP(hipMemcpyAsync(h->d_acc_slots, &acc_sum, sizeof(acc_sum), hipMemcpyHostToDevice, h->stream));
+        AMC_HIP(hipStreamSynchronize(h->stream));
+    }
+    return AMC_OK;
+}
+
+int amc_set_counter_totals(amc_handle* h, const int64_t* accepted, uint64_t steps_counted)
+{
+    if (!h || !accepted) return fail(AMC_ERR_BAD_ARG, "amc_set_counter_totals: NULL argument");
+    if (h->K != 1 || h->counters)
+        return fail(AMC_ERR_STATE, "amc_set_counter_totals: only for K = 1 handles without per-chain counters");
+    if (accepted[0] < 0) return fail(AMC_ERR_BAD_ARG, "amc_set_counter_totals: negative count");
+    AMC_HIP(hipSetDevice(h->device));
+    const unsigned long long acc = (unsigned long long)accepted[0];
+    AMC_HIP(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
+    AMC_HIP(hipMemcpyAsync(h->d_acc_slots, &acc, sizeof(acc), hipMemcpyHostToDevice, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    h->t_counted = steps_counted;
+    return AMC_OK;
+}
+
+int amc_histogram(amc_handle* h, double lo, double hi, int n_bins, uint64_t* counts)
+{
+    if (!h || !counts) return fail(AMC_ERR_BAD_ARG, "amc_histogram: NULL argument");
+    if (n_bins < 1 || n_bins > 8192 || !(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi))
+        return fail(AMC_ERR_BAD_ARG, "amc_histogram: need 1 <= n_bins <= 8192 and finite lo < hi");
+    AMC_HIP(hipSetDevice(h->device));
+    unsigned long long* d_counts = nullptr;
+    const size_t bytes = (size_t)(n_bins + 3) * sizeof(unsigned long long);
+    AMC_HIP(hipMalloc(&d_counts, bytes));
+    AMC_HIP(hipMemsetAsync(d_counts, 0, bytes, h->stream));
+    const double inv_w = (double)n_bins / (hi - lo);
+    hipLaunchKernelGGL(amc::histogram_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), (size_t)(n_bins + 3) * sizeof(unsigned int),
+                       h->stream, h->d_x, h->M, lo, hi, inv_w, n_bins, d_counts);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) return fail(AMC_ERR_HIP, "amc_histogram: %s", hipGetErrorString(e));
+    return AMC_OK;
+}
+
+int amc_download_strided(amc_handle* h, int64_t first, int64_t stride, int64_t count, double* x)
+{
+    if (!h || !x) return fail(AMC_ERR_BAD_ARG, "amc_download_strided: NULL argument");
+    if (first < 0 || stride < 1 || count < 0 || (count > 0 && first + (count - 1) * stride >= h->M))
+        return fail(AMC_ERR_BAD_ARG, "amc_download_strided: range [first + i*stride] leaves the local shard");
+    if (count == 0) return AMC_OK;
+    AMC_HIP(hipSetDevice(h->device));
+    double* d_out = nullptr;
+    AMC_HIP(hipMalloc(&d_out, (size_t)count * sizeof(double)));
+    hipLaunchKernelGGL(amc::gather_strided_kernel, dim3(grid_for(h, count)), dim3(AMC_BLOCK), 0, h->stream, h->d_x, first,
+                       stride, count, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(x, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(AMC_ERR_HIP, "amc_download_strided: %s", hipGetErrorString(e));
+    return AMC_OK;
+}
+
+int amc_get_estimator_step(amc_handle* h, uint64_t* t)
+{
+    if (!h || !t) return fail(AMC_ERR_BAD_ARG, "amc_get_estimator_step: NULL argument");
+    *t = h->t_est;
+    return AMC_OK;
+}
+
+int amc_set_estimator_step(amc_handle* h, uint64_t t)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_set_estimator_step: NULL handle");
+    if (t >> 48) return fail(AMC_ERR_BAD_ARG, "amc_set_estimator_step: call index must fit 48 bits");
+    h->t_est = t;
+    return AMC_OK;
+}
+
 int amc_get_step(amc_handle* h, uint64_t* t)
 {
     if (!h || !t) return fail(AMC_ERR_BAD_ARG, "amc_get_step: NULL argument");

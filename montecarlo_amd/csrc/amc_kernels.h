@@ -513,6 +513,42 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
     }
 }
 
+// Device-side replacement for the per-chain text trajectories (StoreTrajectories, src/algorithms.jl:154-210):
+// histogram of the chain positions over half-open bins [lo + i w, lo + (i+1) w), i < n_bins, with
+// bin = floor((x - lo) * inv_w) in this exact f64 form; counts[n_bins..n_bins+2] = below lo, >= hi, NaN.
+// Per-block LDS histogram (u32 LDS atomics), flushed with one u64 global atomic per non-empty bin.
+__global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, int64_t n_chains, double lo, double hi,
+                                                               double inv_w, int n_bins, unsigned long long* counts)
+{
+    extern __shared__ unsigned int s_hist[];
+    for (int i = threadIdx.x; i < n_bins + 3; i += AMC_BLOCK) s_hist[i] = 0u;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+        const double v = x[c];
+        int b;
+        if (v != v) b = n_bins + 2;
+        else if (v < lo) b = n_bins;
+        else if (v >= hi) b = n_bins + 1;
+        else {
+            b = (int)((v - lo) * inv_w);
+            b = b < n_bins ? b : n_bins - 1;       // (hi - ulp - lo) * inv_w can round up to n_bins
+        }
+        atomicAdd(&s_hist[b], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bins + 3; i += AMC_BLOCK)
+        if (s_hist[i]) atomicAdd(&counts[i], (unsigned long long)s_hist[i]);
+}
+
+// Strided snapshot: out[i] = x[first + i*stride] (binary stand-in for a subset of trajectory files).
+__global__ __launch_bounds__(AMC_BLOCK) void gather_strided_kernel(const double* x, int64_t first, int64_t stride,
+                                                                    int64_t count, double* out)
+{
+    const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < count; i += gs) out[i] = x[first + i * stride];
+}
+
 // Parity-test hooks (amc_selftest_*): the arithmetic-spec primitives, one value per thread.
 __global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
 {

@@ -63,6 +63,9 @@ class Metropolis(AriannaAlgorithm):
 
     # ---- plugin protocol ---------------------------------------------------------------
     def initialise(self, simulation: Simulation) -> None:
+        if getattr(self, "restored", False):        # storage.restore() already put the state on the device
+            self._epoch += 1
+            return
         start, stop = self.shard
         ch = self.chains
         beta = None if ch.beta_array is None else ch.beta_array[start:stop]

@@ -733,3 +733,16 @@ void amo_run_pooled_moments(amo_sim *s, int64_t steps, int64_t burn, int64_t dt,
     s->t = t0 + (uint64_t)steps * (uint64_t)s->sweepstep;
     out[0] = n; out[1] = sx; out[2] = sxx; out[3] = se / n;
 }
+
+/* Resume helpers (the reference's StoreBackups is write-only: src/algorithms.jl:264-303). */
+void amo_set_counters(amo_sim *s, const int64_t *accepted, const int64_t *total)
+{
+    for (int k = 0; k < s->K; ++k)
+        for (int64_t c = 0; c < s->M; ++c) {
+            s->pools[c * s->K + k].accepted_calls = accepted[k * s->M + c];
+            s->pools[c * s->K + k].total_calls = total[k * s->M + c];
+        }
+}
+
+uint64_t amo_get_estimator_step(const amo_sim *s) { return s->t_est; }
+void amo_set_estimator_step(amo_sim *s, uint64_t t) { s->t_est = t; }

@@ -107,6 +107,10 @@ int64_t amo_build_schedule_log(int64_t steps, int64_t burn, double base,
 void   amo_run_pooled_moments(amo_sim *s, int64_t steps, int64_t burn, int64_t dt, int n_threads,
                               double out[4]);
 
+void   amo_set_counters(amo_sim *s, const int64_t *accepted, const int64_t *total);
+uint64_t amo_get_estimator_step(const amo_sim *s);
+void   amo_set_estimator_step(amo_sim *s, uint64_t t);
+
 int    amo_max_threads(void);
 
 #ifdef __cplusplus

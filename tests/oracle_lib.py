@@ -85,6 +85,9 @@ def load() -> C.CDLL:
         "amo_build_schedule_block": (C.c_int64, [C.c_int64, C.c_int64, i64p, C.c_int, i64p, C.c_int64]),
         "amo_build_schedule_log": (C.c_int64, [C.c_int64, C.c_int64, C.c_double, i64p, C.c_int64]),
         "amo_run_pooled_moments": (None, [S, C.c_int64, C.c_int64, C.c_int64, C.c_int, dp]),
+        "amo_set_counters": (None, [S, i64p, i64p]),
+        "amo_get_estimator_step": (C.c_uint64, [S]),
+        "amo_set_estimator_step": (None, [S, C.c_uint64]),
         "amo_max_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -309,6 +312,36 @@ class OracleEngine:
         out[3] = float(self.n_chains)
         out[4:] = self.sim.acceptance() * self.n_chains
         return out
+
+    def upload_counters(self, accepted, total=None):
+        a = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n_moves, self.n_chains)
+        t = a * 0 + self.sim.step if total is None else np.ascontiguousarray(total, dtype=np.int64).reshape(a.shape)
+        p = C.POINTER(C.c_int64)
+        self.sim.lib.amo_set_counters(self.sim.h, a.ctypes.data_as(p), t.ctypes.data_as(p))
+
+    def histogram(self, lo, hi, n_bins):
+        x, _ = self.sim.state()
+        out = np.zeros(n_bins + 3, dtype=np.uint64)
+        inv_w = n_bins / (hi - lo)
+        nan = np.isnan(x)
+        below, above = (x < lo) & ~nan, (x >= hi) & ~nan
+        inside = ~(nan | below | above)
+        b = np.minimum(((x[inside] - lo) * inv_w).astype(np.int64), n_bins - 1)
+        out[:n_bins] = np.bincount(b, minlength=n_bins).astype(np.uint64)
+        out[n_bins], out[n_bins + 1], out[n_bins + 2] = below.sum(), above.sum(), nan.sum()
+        return out
+
+    def download_strided(self, first, stride, count):
+        x, _ = self.sim.state()
+        return x[first:first + count * stride:stride][:count].copy()
+
+    @property
+    def estimator_step(self):
+        return self.sim.lib.amo_get_estimator_step(self.sim.h)
+
+    @estimator_step.setter
+    def estimator_step(self, t):
+        self.sim.lib.amo_set_estimator_step(self.sim.h, int(t))
 
     def reduce_begin(self):
         self._pending = self.reduce()

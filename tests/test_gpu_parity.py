@@ -317,3 +317,66 @@ def test_pg_estimate_seven_move_pool(gpu, oracle):
     with pytest.raises(gpu.AmcError):
         e.pg_estimate([9], 1)
     e.close()
+
+
+# ---- histogram / strided snapshot / exact resume (device-side stand-ins for the per-chain text I/O) ----------------
+def test_histogram_and_strided_snapshot(gpu):
+    M = 100_003
+    e = gpu.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=21)
+    e.init_uniform(-2, 2)
+    e.sweep(30)
+    x, _ = e.download_state()
+    for lo, hi, nb in [(-2.0, 2.0, 200), (-0.5, 1.25, 7), (-3.0, 3.0, 8192)]:
+        got = e.histogram(lo, hi, nb)
+        inv_w = nb / (hi - lo)
+        inside = (x >= lo) & (x < hi)
+        want = np.bincount(np.minimum(((x[inside] - lo) * inv_w).astype(np.int64), nb - 1), minlength=nb)
+        assert np.array_equal(got[:nb], want.astype(np.uint64))
+        assert (got[nb], got[nb + 1], got[nb + 2]) == ((x < lo).sum(), (x >= hi).sum(), 0) and got.sum() == M
+    xn = x.copy()
+    xn[[5, 77]] = np.nan
+    xn[9] = np.inf
+    e.upload_state(xn)
+    got = e.histogram(-2.0, 2.0, 10)
+    assert got[12] == 2 and got[11] >= 1 and got.sum() == M            # NaN bucket, +inf counted as >= hi
+    e.upload_state(x)
+    for first, stride, count in [(0, 1, 10), (3, 1000, 100), (M - 1, 1, 1), (1, 2, M // 2)]:
+        assert np.array_equal(bits(e.download_strided(first, stride, count)), bits(x[first:first + count * stride:stride][:count]))
+    with pytest.raises(gpu.AmcError):
+        e.download_strided(0, 1000, 200)                                 # leaves the shard
+    with pytest.raises(gpu.AmcError):
+        e.histogram(1.0, 1.0, 10)
+    e.close()
+
+
+@pytest.mark.parametrize("K,counters", [(1, True), (1, False), (2, True)])
+def test_exact_resume(gpu, K, counters):
+    """x + counters + sigma + (seed, step) restore a run bit for bit: the generator is counter-based."""
+    sigma, weight = POOLS[K]
+    kw = dict(n_chains=5001, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=77, per_chain_counters=counters)
+    a = gpu.HipEngine(**kw)
+    a.init_uniform(-2, 2)
+    a.sweep(40)
+    a.pg_estimate([0], 2)
+    a.set_parameters(0, [0.17])
+    x, _ = a.download_state()
+    acc_t, tot_t = a.counter_totals()
+    b = gpu.HipEngine(**kw)
+    b.upload_state(x)
+    b.set_parameters(0, [0.17])
+    b.step, b.estimator_step = a.step, a.estimator_step
+    if counters or K > 1:
+        acc, tot = a.download_counters()
+        b.upload_counters(acc, tot)
+    else:
+        b.set_counter_totals(int(acc_t[0]), int(tot_t[0]) // 5001)
+    for eng in (a, b):
+        eng.sweep(25)
+        eng.pg_estimate([0], 2)
+    assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
+    assert all(np.array_equal(u, v) for u, v in zip(a.counter_totals(), b.counter_totals()))
+    np.testing.assert_array_equal(a.reduce(), b.reduce())
+    if counters or K > 1:
+        assert all(np.array_equal(u, v) for u, v in zip(a.download_counters(), b.download_counters()))
+    a.close()
+    b.close()

@@ -168,3 +168,45 @@ def test_shard_range_even_boundaries_and_cover():
             assert all(a % 2 == 0 for a, _ in rs)
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 3      # one pair of imbalance + the odd tail chain
+
+
+# ---- device-side stand-ins for the per-chain text I/O (storage.py) ---------------------------------------------
+def test_histogram_snapshots_and_exact_resume(oracle, tmp_path):
+    pool = lambda: (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
+                    ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+    def build(path, steps, p):
+        chains = ma.ParticleChains.uniform(300, 2.0)
+        al = (dict(algorithm=ma.Metropolis, pool=p, seed=11, engine_factory=oracle.OracleEngine),
+              dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.05))),
+              dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+              dict(algorithm=ma.StoreHistogram, dependencies=(ma.Metropolis,), lo=-1.5, hi=1.5, bins=30, scheduler=list(range(10, steps + 1, 10))),
+              dict(algorithm=ma.StoreSnapshots, dependencies=(ma.Metropolis,), stride=64, scheduler=list(range(20, steps + 1, 20))))
+        return ma.Simulation(chains, al, steps, path=str(path))
+    # one run of 120 steps ...
+    p_full = pool()
+    full = build(tmp_path / "full", 120, p_full)
+    ma.run(full)
+    hist = full.algorithms[3]
+    assert int(hist.global_counts.sum()) == 300 * 12 and int(hist.global_counts[30 + 2]) == 0
+    rows = open(tmp_path / "full" / "histogram.dat").read().splitlines()
+    assert len(rows) == 31 and rows[0].startswith("# samples 3600")
+    snaps = np.load(tmp_path / "full" / "snapshots_rank0.npy")
+    ids = np.load(tmp_path / "full" / "snapshots_rank0_chain_ids.npy")
+    assert snaps.shape == (7, 1 + 5) and list(snaps[:, 0]) == [0, 20, 40, 60, 80, 100, 120] and list(ids) == [0, 64, 128, 192, 256]
+    assert np.array_equal(snaps[-1, 1:], full.chains.x[ids])
+    # ... equals 50 steps + checkpoint + restore into a fresh object + 70 steps, bit for bit
+    p_a = pool()
+    a = build(tmp_path / "a", 50, p_a)
+    ma.run(a)
+    ma.checkpoint(a.algorithms[0], str(tmp_path / "ckpt"), estimator=a.algorithms[1])
+    p_b = pool()
+    b = build(tmp_path / "b", 70, p_b)
+    ma.restore(b.algorithms[0], str(tmp_path / "ckpt"), estimator=b.algorithms[1])
+    ma.run(b)
+    assert np.array_equal(b.chains.x, full.chains.x)
+    assert [m.sigma for m in p_b] == [m.sigma for m in p_full] and p_b[1].sigma != 0.1
+    assert [(m.accepted_calls, m.total_calls) for m in p_b] == [(m.accepted_calls, m.total_calls) for m in p_full]
+    with pytest.raises(ValueError):
+        other = build(tmp_path / "c", 10, pool())
+        other.algorithms[0].seed = 12
+        ma.restore(other.algorithms[0], str(tmp_path / "ckpt"))
