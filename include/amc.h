@@ -175,6 +175,24 @@ int  amc_get_parameters(amc_handle *h, int k, double *p, int n);
 int  amc_pg_estimate(amc_handle *h, int n_learn, const int *learn_ids, int q_batch,
                      double *out);
 
+/* Device-resident variant of the estimator/update pair (no host round trip per step):
+ *   amc_pg_accumulate  = make_step!(::PolicyGradientEstimator): the same kernel as amc_pg_estimate, then
+ *                        (if amc_comm_init was called) ONE in-place RCCL all-reduce of 4*n_learn doubles on
+ *                        the engine's stream, then gradients_data[k] += gd on the device (estimator.jl:130).
+ *   amc_pg_update      = make_step!(::PolicyGradientUpdate) (update.jl:50-57): average, learning_step! for
+ *                        P = 1 with optimiser ids below and their two hyper-parameters (eta or delta, eps_id),
+ *                        reset, refresh the device copy of sigma and its derived table.  Asynchronous.
+ *   amc_pg_get_accumulated  reads the running sums (j, grad_j, grad_logq, g, n) per move (synchronises);
+ *                        returns AMC_ERR_STATE if some step produced a sigma outside [1e-100, 1e100]. */
+typedef enum amc_optimiser {      /* src/PolicyGuided/learning.jl:16-164 */
+    AMC_OPT_STATIC = 0, AMC_OPT_VPG = 1, AMC_OPT_BLPG = 2, AMC_OPT_BLAPG = 3,
+    AMC_OPT_NPG = 4, AMC_OPT_ANPG = 5, AMC_OPT_BLANPG = 6
+} amc_optimiser;
+int  amc_pg_accumulate(amc_handle *h, int n_learn, const int *learn_ids, int q_batch);
+int  amc_pg_update(amc_handle *h, int n_learn, const int *learn_ids, const int *optimiser,
+                   const double *hyper0, const double *hyper1);
+int  amc_pg_get_accumulated(amc_handle *h, int n_learn, const int *learn_ids, double *out);
+
 int  amc_sync(amc_handle *h);
 /* hipStream_t the handle launches on (for event timing / graph capture by the host). */
 int  amc_get_stream(amc_handle *h, void **stream);

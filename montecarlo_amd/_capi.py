@@ -90,6 +90,9 @@ def load() -> C.CDLL:
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_pg_estimate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amc_pg_accumulate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int]),
+        "amc_pg_update": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]),
+        "amc_pg_get_accumulated": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), dp]),
         "amc_sync": (C.c_int, [H]),
         "amc_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
         "amc_timing_begin": (C.c_int, [H]),
@@ -281,6 +284,29 @@ class HipEngine:
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
         out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
         _check(self._lib.amc_pg_estimate(self._h, n, ids, int(q_batch), _dptr(out)))
+        return out
+
+    def pg_accumulate(self, learn_ids: Sequence[int], q_batch: int) -> None:
+        """Estimator step kept on the device: gradients_data[k] += gd (asynchronous)."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        _check(self._lib.amc_pg_accumulate(self._h, n, ids, int(q_batch)))
+
+    def pg_update(self, learn_ids: Sequence[int], kinds: Sequence[int], hyper0: Sequence[float],
+                  hyper1: Sequence[float]) -> None:
+        """average -> learning_step! -> reset on the device; sigma and its table are refreshed in place."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        kd = (C.c_int * max(n, 1))(*[int(k) for k in kinds])
+        h0 = (C.c_double * max(n, 1))(*[float(v) for v in hyper0])
+        h1 = (C.c_double * max(n, 1))(*[float(v) for v in hyper1])
+        _check(self._lib.amc_pg_update(self._h, n, ids, kd, h0, h1))
+
+    def pg_get_accumulated(self, learn_ids: Sequence[int]) -> np.ndarray:
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
+        _check(self._lib.amc_pg_get_accumulated(self._h, n, ids, _dptr(out)))
         return out
 
     def sync(self) -> None:

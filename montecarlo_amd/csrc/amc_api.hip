@@ -89,6 +89,8 @@ struct amc_handle {
     uint64_t red_t_counted = 0;
     void* comm = nullptr;
     double* d_comm = nullptr;
+    double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
+    int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     Rccl rccl;
 };
 
@@ -305,6 +307,10 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     }
     AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double)));
     AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double), 0));
+    AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * 5 * sizeof(double)));
+    AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
+    AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
+    AMC_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream));
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
     AMC_TRY(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
@@ -322,6 +328,8 @@ int amc_destroy(amc_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     (void)hipFree(h->d_comm);
+    (void)hipFree(h->d_gd_acc);
+    (void)hipFree(h->d_status);
     (void)hipFree(h->d_x);
     (void)hipFree(h->d_beta);
     (void)hipFree(h->d_acc);
@@ -684,16 +692,18 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
     return AMC_OK;
 }
 
-int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, double* out)
+// Validates, launches K3 over this shard and leaves sum_{chains x q} (j, grad j, grad logq, g) per learnable
+// move in h->d_out[l*4 + i] (device, on the stream).  Shared by the host- and device-resident estimator paths.
+static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out)
 {
-    if (!h || !out || (n_learn > 0 && !learn_ids)) return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: NULL argument");
-    if (n_learn < 0 || n_learn > AMC_MAX_LEARN)
-        return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
     if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)
-        return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: q_batch must be in [1, %d] and q_batch*n_learn < 4096", AMC_MAX_QBATCH);
+        return fail(AMC_ERR_BAD_ARG, "%s: q_batch must be in [1, %d] and q_batch*n_learn < 4096", who, AMC_MAX_QBATCH);
     for (int l = 0; l < n_learn; ++l)
         if (learn_ids[l] < 0 || learn_ids[l] >= h->K)
-            return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: learn_ids[%d] = %d out of range", l, learn_ids[l]);
+            return fail(AMC_ERR_BAD_ARG, "%s: learn_ids[%d] = %d out of range", who, l, learn_ids[l]);
+    *nl_out = 0;
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;
@@ -720,13 +730,90 @@ int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batc
     hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, nl * 4,
                        h->d_out, (const unsigned long long*)nullptr, 0);
     AMC_HIP(hipGetLastError());
+    h->t_est += 1;
+    *nl_out = nl;
+    return AMC_OK;
+}
+
+int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, double* out)
+{
+    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: NULL argument");
+    int nl = 0;
+    const int rc = pg_launch(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &nl);
+    if (rc != AMC_OK || n_learn == 0) return rc;
     AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
     for (int l = 0; l < n_learn; ++l) {
         for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_out[l * 4 + i];
         out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
     }
-    h->t_est += 1;
+    return AMC_OK;
+}
+
+static amc::PgIds make_ids(int n_learn, const int* learn_ids)
+{
+    amc::PgIds ids;
+    for (int l = 0; l < AMC_MAX_LEARN; ++l) ids.v[l] = l < n_learn ? learn_ids[l] : 0;
+    return ids;
+}
+
+int amc_pg_accumulate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: NULL handle");
+    int nl = 0;
+    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl);
+    if (rc != AMC_OK || n_learn == 0) return rc;
+    double n_samples = (double)h->M * (double)q_batch;
+    if (h->comm) {          // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
+        const int e = h->rccl.AllReduce(h->d_out, h->d_out, (size_t)nl * 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+        if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+        n_samples = (double)h->M_global * (double)q_batch;
+    }
+    hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
+                       n_samples, h->d_gd_acc);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_pg_update(amc_handle* h, int n_learn, const int* learn_ids, const int* optimiser, const double* hyper0,
+                  const double* hyper1)
+{
+    if (!h || (n_learn > 0 && (!learn_ids || !optimiser || !hyper0 || !hyper1)))
+        return fail(AMC_ERR_BAD_ARG, "amc_pg_update: NULL argument");
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_update: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (n_learn == 0) return AMC_OK;
+    amc::PgOpts opt;
+    for (int l = 0; l < AMC_MAX_LEARN; ++l) {
+        opt.kind[l] = 0; opt.h0[l] = 0.0; opt.h1[l] = 0.0;
+    }
+    for (int l = 0; l < n_learn; ++l) {
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_update: learn_ids[%d] out of range", l);
+        if (optimiser[l] < AMC_OPT_STATIC || optimiser[l] > AMC_OPT_BLANPG)
+            return fail(AMC_ERR_BAD_ARG, "amc_pg_update: No learning_step! is defined for optimiser id %d", optimiser[l]);
+        opt.kind[l] = optimiser[l]; opt.h0[l] = hyper0[l]; opt.h1[l] = hyper1[l];
+    }
+    AMC_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
+                       make_ids(n_learn, learn_ids), opt, h->K, h->d_status);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_pg_get_accumulated(amc_handle* h, int n_learn, const int* learn_ids, double* out)
+{
+    if (!h || !out || (n_learn > 0 && !learn_ids)) return fail(AMC_ERR_BAD_ARG, "amc_pg_get_accumulated: NULL argument");
+    AMC_HIP(hipSetDevice(h->device));
+    std::vector<double> acc((size_t)AMC_MAX_MOVES * 5);
+    int status = 0;
+    AMC_HIP(hipMemcpyAsync(acc.data(), h->d_gd_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipMemcpyAsync(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < n_learn; ++l) {
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_get_accumulated: learn_ids[%d] out of range", l);
+        for (int i = 0; i < 5; ++i) out[l * AMC_GD_STRIDE + i] = acc[(size_t)learn_ids[l] * 5 + i];
+    }
+    if (status != 0)
+        return fail(AMC_ERR_STATE, "a learning step produced a sigma outside [1e-100, 1e100] (or NaN) and was not applied");
     return AMC_OK;
 }
 

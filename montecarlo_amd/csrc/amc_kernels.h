@@ -278,9 +278,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int6
 // den = 2*(s*s); logc = log(2pi*(s*s))/2 (particle_1d.jl:53); cum = running sum of
 // weights in the order Distributions.jl accumulates them; dden, dlhalf: d/dsigma
 // pieces of gradients.jl:28-33 (ForwardDiff's dual rules written out).
-__global__ void prepare_params_kernel(double* ptab, int n_moves)
+__device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double TWO_PI = 0x1.921fb54442d18p+2;
     double cp = 0.0;
     for (int k = 0; k < n_moves; ++k) {
@@ -297,6 +296,78 @@ __global__ void prepare_params_kernel(double* ptab, int n_moves)
         cp = (k == 0) ? w : cp + w;
         ptab[PT_CUM * AMC_MAX_MOVES + k] = cp;
     }
+}
+
+__global__ void prepare_params_kernel(double* ptab, int n_moves)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    prepare_params(ptab, n_moves);
+}
+
+// ---- device-resident policy-gradient bookkeeping (src/PolicyGuided/estimator.jl:130-131, update.jl:50-57) ----
+struct PgIds { int32_t v[AMC_MAX_LEARN]; };
+struct PgOpts { int32_t kind[AMC_MAX_LEARN]; double h0[AMC_MAX_LEARN]; double h1[AMC_MAX_LEARN]; };
+enum { OPT_STATIC = 0, OPT_VPG = 1, OPT_BLPG = 2, OPT_BLAPG = 3, OPT_NPG = 4, OPT_ANPG = 5, OPT_BLANPG = 6 };
+
+// gradients_data[k] = gradients_data[k] + gd (estimator.jl:130): red[l*4 + i] holds the (all-reduced) sums of
+// (j, grad j, grad logq, g) over chains x q_batch samples of learnable move l; acc is [AMC_MAX_MOVES][5].
+__global__ void pg_accumulate_kernel(const double* red, int n_learn, PgIds ids, double n_samples, double* acc)
+{
+    const int l = threadIdx.x;
+    if (l >= n_learn) return;
+    double* a = acc + ids.v[l] * 5;
+    for (int i = 0; i < 4; ++i) a[i] += red[l * 4 + i];
+    a[4] += n_samples;
+}
+
+// make_step!(::PolicyGradientUpdate) (update.jl:50-57) for P = 1: average (gradients.jl:83-85), learning_step!
+// (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164; inv(g + eps I) is a scalar reciprocal), reset
+// the accumulators, refresh the derived parameter table.  A step that leaves sigma outside [1e-100, 1e100]
+// (or NaN) is not applied; status[0] is set instead.
+__global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int l = 0; l < n_learn; ++l) {
+        const int k = ids.v[l];
+        double* a = acc + k * 5;
+        const double n = a[4];
+        const double j = a[0] / n, dj = a[1] / n, dlogq = a[2] / n, g = a[3] / n;
+        const double theta = ptab[PT_SIGMA * AMC_MAX_MOVES + k];
+        const double h0 = opt.h0[l], h1 = opt.h1[l];
+        double next = theta;
+        switch (opt.kind[l]) {
+        case OPT_VPG: next = theta + h0 * dj; break;
+        case OPT_BLPG: next = theta + h0 * (dj - j * dlogq); break;
+        case OPT_BLAPG: {
+            const double eta = __builtin_sqrt(2.0 * h0 / (dj * dj + h1));
+            next = theta + eta * (dj - j * dlogq);
+            break;
+        }
+        case OPT_NPG: {
+            const double finv = 1.0 / (g + h1 * 1.0);
+            next = theta + h0 * finv * dj;
+            break;
+        }
+        case OPT_ANPG: {
+            const double finv = 1.0 / (g + h1 * 1.0);
+            const double eta = __builtin_sqrt(2.0 * h0 / (dj * (finv * dj)));
+            next = theta + eta * finv * dj;
+            break;
+        }
+        case OPT_BLANPG: {
+            const double finv = 1.0 / (g + h1 * 1.0);
+            const double bj = dj - j * dlogq;
+            const double eta = __builtin_sqrt(2.0 * h0 / (bj * (finv * bj)));
+            next = theta + eta * finv * bj;
+            break;
+        }
+        default: break;
+        }
+        if (next >= 1e-100 && next <= 1e100) ptab[PT_SIGMA * AMC_MAX_MOVES + k] = next;
+        else status[0] = 1;
+        for (int i = 0; i < 5; ++i) a[i] = 0.0;
+    }
+    prepare_params(ptab, n_moves);
 }
 
 // ---- deterministic block reduction helpers -------------------------------------

@@ -90,6 +90,8 @@ class Metropolis(AriannaAlgorithm):
         self._epoch += 1
 
     def finalise(self, simulation: Simulation) -> None:
+        if getattr(self, "device_params_dirty", False):
+            self.pull_parameters()
         if self.download_on_finalise:
             x, e = self.engine.download_state(want_e=True)
             self.chains.x, self.chains.e = x, e        # this rank's shard, like chains[c].x / .e
@@ -122,6 +124,12 @@ class Metropolis(AriannaAlgorithm):
         self.engine.set_parameters(k, p)
         if self.pool[k].parameters is not parameters:
             self.pool[k].parameters[...] = p
+
+    def pull_parameters(self) -> None:
+        """Refresh the host copies of Move.parameters from the device (after device-resident learning steps)."""
+        for k, move in enumerate(self.pool):
+            move.parameters[...] = self.engine.get_parameters(k)
+        self.device_params_dirty = False
 
     def download_counters(self):
         """pools[c][k].accepted_calls / total_calls of this rank's shard, shape (K, M_local)."""

@@ -78,6 +78,25 @@ class GradientData:
                             self.g + o.g, self.n + o.n)
 
 
+def optimiser_code(opt: PolicyGradient):
+    """(amc_optimiser id, hyper0, hyper1) of an optimiser object, for the device-resident update."""
+    if isinstance(opt, Static):
+        return 0, 0.0, 0.0
+    if isinstance(opt, VPG):
+        return 1, opt.eta, 0.0
+    if isinstance(opt, BLPG):
+        return 2, opt.eta, 0.0
+    if isinstance(opt, BLAPG):
+        return 3, opt.delta, opt.eps_id
+    if isinstance(opt, NPG):
+        return 4, opt.eta, opt.eps_id
+    if isinstance(opt, ANPG):
+        return 5, opt.delta, opt.eps_id
+    if isinstance(opt, BLANPG):
+        return 6, opt.delta, opt.eps_id
+    raise TypeError(f"No learning_step! is defined for {type(opt).__name__}")
+
+
 def initialise_gradient_data(parameters: np.ndarray) -> GradientData:            # gradients.jl:54-61
     z = np.zeros_like(np.asarray(parameters, dtype=np.float64))
     return GradientData(0.0, z.copy(), z.copy(), np.outer(z, z), 0)
@@ -124,7 +143,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
     policy is evaluated in closed form by the kernel (test/ad_backends_test.jl pins all backends equal)."""
 
     def __init__(self, chains, dependencies=None, optimisers=None, q_batch_size: int = 1, ad_backend=None,
-                 R=None, parallel: bool = False, **extras):
+                 R=None, parallel: bool = False, device_resident: Optional[bool] = None, **extras):
         assert dependencies is not None and len(dependencies) == 1                 # :104
         assert isinstance(dependencies[0], Metropolis)                             # :105
         self.metropolis: Metropolis = dependencies[0]
@@ -139,10 +158,30 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         self.gradients_data: List[GradientData] = [initialise_gradient_data(self.parameters_list[k])
                                                    for k in self.learn_ids]        # :84
         self.parallel = parallel
+        # device_resident: keep gradients_data and the learning step on the GPU (amc_pg_accumulate / amc_pg_update):
+        # no host round trip per step.  Default: on when this process holds the whole ensemble (the cross-process
+        # sum below goes through torch.distributed on the host); the values are identical either way.
+        eng = self.metropolis.engine
+        if device_resident is None:
+            device_resident = self.metropolis.world_size == 1 and hasattr(eng, "pg_accumulate")
+        self.device_resident = bool(device_resident)
+
+    def refresh(self) -> None:
+        """Device-resident mode: pull the running gradients_data / objectives to the host (synchronises)."""
+        if self.device_resident and self.learn_ids:
+            acc = self.metropolis.engine.pg_get_accumulated(self.learn_ids)
+            for k in range(len(self.learn_ids)):
+                self.gradients_data[k] = GradientData(float(acc[k, 0]), np.array([acc[k, 1]]), np.array([acc[k, 2]]),
+                                                      np.array([[acc[k, 3]]]), int(round(acc[k, 4])))
+                self.objectives[k] = acc[k, 0] / acc[k, 4] if acc[k, 4] else 0.0
 
     def make_step(self, simulation: Simulation) -> None:
         """estimator.jl:111-134: fold GradientData over chains x q_batch samples per learnable move."""
         if not self.learn_ids:
+            return
+        if self.device_resident:
+            self.metropolis.engine.pg_accumulate(self.learn_ids, self.q_batch_size)
+            self.metropolis.invalidate_reductions()
             return
         local = self.metropolis.engine.pg_estimate(self.learn_ids, self.q_batch_size)
         self.metropolis.invalidate_reductions()      # every sample leaves x at (x+d)-d (gradients.jl:103)
@@ -176,6 +215,12 @@ class PolicyGradientUpdate(AriannaAlgorithm):
     def make_step(self, simulation: Simulation) -> None:
         """update.jl:50-57: average -> learning_step! -> reset; then refresh the device copy of sigma."""
         est = self.estimator
+        if est.device_resident:
+            codes = [optimiser_code(self.optimisers[lid]) for lid in self.learn_ids]
+            est.metropolis.engine.pg_update(self.learn_ids, [c[0] for c in codes], [c[1] for c in codes],
+                                            [c[2] for c in codes])
+            est.metropolis.device_params_dirty = True      # host copies of Move.parameters are refreshed lazily
+            return
         for k, lid in enumerate(self.learn_ids):
             gd = average(est.gradients_data[k])
             learning_step(self.parameters_list[lid], gd, self.optimisers[lid])

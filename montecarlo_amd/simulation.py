@@ -322,6 +322,7 @@ class StoreParameters(AriannaAlgorithm):
         assert dependencies is not None and len(dependencies) == 1
         metropolis = dependencies[0]
         pool = metropolis.pool
+        self.metropolis = metropolis
         self.ids = list(range(len(pool))) if ids is None else list(ids)
         self.parameters_list = [pool[k].parameters for k in self.ids]
         self.store_first, self.store_last = store_first, store_last
@@ -339,6 +340,8 @@ class StoreParameters(AriannaAlgorithm):
             self.make_step(simulation)
 
     def make_step(self, simulation: Simulation) -> None:
+        if getattr(self.metropolis, "device_params_dirty", False):
+            self.metropolis.pull_parameters()       # sigma was updated by a device-resident learning step
         for i, prm in enumerate(self.parameters_list):
             self.rows[i].append((simulation.t, prm.copy()))
             if self.rank == 0:

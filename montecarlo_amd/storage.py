@@ -104,6 +104,10 @@ class StoreSnapshots(AriannaAlgorithm):
 def checkpoint(metropolis: Metropolis, path: str, estimator=None) -> str:
     """Write this rank's shard so that `restore` continues the run bit for bit."""
     eng = metropolis.engine
+    if getattr(metropolis, "device_params_dirty", False):
+        metropolis.pull_parameters()
+    if estimator is not None:
+        estimator.refresh()
     x, _ = eng.download_state(want_e=False)
     start, stop = metropolis.shard
     acc_tot, tot_tot = eng.counter_totals()

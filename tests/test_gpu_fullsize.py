@@ -175,3 +175,43 @@ def test_config5_pgmc_learns_sigma_on_device(gpu, tmp_path):
     assert sim.algorithms[0].engine.get_parameters(1)[0] == pool[1].sigma   # device copy follows the host array
     energies = [v for t, v in sim.algorithms[3].rows[0] if t >= 200]
     assert np.mean(energies) == pytest.approx(0.25, abs=5e-3)
+
+
+def _run_pgmc(device_resident, path, optimisers, weights, M=20_000, steps=60, q=3, engine_factory=None):
+    chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+    pool = tuple(ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, w) for w in weights)
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, engine_factory=engine_factory),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=optimisers, q_batch_size=q,
+               device_resident=device_resident),
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=ma.build_schedule(steps, 10, 2)),
+          dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=ma.build_schedule(steps, 10, 10)))
+    sim = ma.Simulation(chains, al, steps, path=str(path))
+    ma.run(sim)
+    return sim, pool
+
+
+def test_device_resident_learning_matches_host_path_and_oracle(gpu, oracle, tmp_path):
+    """amc_pg_accumulate / amc_pg_update (gradients_data and learning_step! kept on the GPU) against the host
+    path (amc_pg_estimate + numpy learning_step!) and against the oracle-backed run, all 7 optimisers."""
+    weights = KATS["pgmc"]["weights"]
+    optimisers = (ma.Static(), ma.VPG(0.05), ma.BLPG(0.05), ma.BLAPG(1e-4, 1e-6), ma.NPG(1e-2, 1e-6), ma.ANPG(1e-4, 1e-6),
+                  ma.BLANPG(1e-4, 1e-6))
+    dev, pool_d = _run_pgmc(True, tmp_path / "dev", optimisers, weights)
+    host, pool_h = _run_pgmc(False, tmp_path / "host", optimisers, weights)
+    ref, pool_r = _run_pgmc(False, tmp_path / "ref", optimisers, weights, engine_factory=oracle.OracleEngine)
+    assert dev.algorithms[1].device_resident and not host.algorithms[1].device_resident
+    sd, sh, sr = ([m.sigma for m in p] for p in (pool_d, pool_h, pool_r))
+    assert sd[0] == sh[0] == sr[0] == 0.2 and all(s != 0.2 for s in sd[1:])
+    np.testing.assert_allclose(sd, sh, rtol=1e-12)
+    np.testing.assert_allclose(sh, sr, rtol=1e-9)          # device tree sums vs the oracle's sequential fold
+    np.testing.assert_allclose(dev.chains.x, host.chains.x, rtol=0, atol=1e-9)
+    rows_d = open(tmp_path / "dev" / "parameters" / "2" / "parameters.dat").read().splitlines()
+    rows_h = open(tmp_path / "host" / "parameters" / "2" / "parameters.dat").read().splitlines()
+    assert [r.split()[0] for r in rows_d] == [r.split()[0] for r in rows_h] == ["0", "10", "20", "30", "40", "50", "60"]
+    eng = dev.algorithms[0].engine
+    assert np.all(eng.pg_get_accumulated([1, 2, 3, 4, 5, 6])[:, 4] == 0)        # reset after the last update
+    with pytest.raises(gpu.AmcError, match="sigma outside"):
+        eng.pg_accumulate([1], 1)
+        eng.pg_update([1], [1], [-1e6], [0.0])                                   # VPG with a huge negative eta
+        eng.pg_get_accumulated([1])
+    assert eng.get_parameters(1)[0] == pool_d[1].sigma                           # the bad step was not applied
