@@ -115,6 +115,56 @@ struct SweepArgs {
     double beta;
 };
 
+// `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
+template <int POT, bool MULTI, bool COUNT>
+__device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, double b0, double b1, uint64_t pair,
+                                           int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
+                                           double sigma1, double den1, double rden1, double logc1,
+                                           unsigned long long& wave_acc, uint32_t& cnt0, uint32_t& cnt1)
+{
+    const int K = a.n_moves;
+    for (int s = 0; s < a.n_steps; ++s) {
+        const uint64_t t = a.t0 + (uint64_t)s;
+        double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
+        double rd0 = rden1, rd1 = rden1;
+        int k0 = 0, k1 = 0;
+        if (MULTI) {
+            // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
+            // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
+            const u32x4 pk = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS), a.key0, a.key1);
+            const double r0 = uniform32(pk.x), r1 = uniform32(pk.y);
+            for (int i = 0; i < K - 1; ++i) {
+                const double c = s_tab[3 * AMC_MAX_MOVES + i];
+                k0 += (c <= r0) ? 1 : 0;
+                k1 += (c <= r1) ? 1 : 0;
+            }
+            sg0 = s_tab[k0]; dn0 = s_tab[AMC_MAX_MOVES + k0]; lc0 = s_tab[2 * AMC_MAX_MOVES + k0];
+            sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
+            rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
+        }
+        double z0, z1;
+        box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1), z0, z1, s_math);
+        const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
+        const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math);
+        const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math);
+        if (MULTI) {
+            // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
+            if (v0) {
+                a.acc[(int64_t)k0 * a.m_stride + 2 * p] += a0 ? 1u : 0u;
+                a.tot[(int64_t)k0 * a.m_stride + 2 * p] += 1u;
+            }
+            if (v1) {
+                a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] += a1 ? 1u : 0u;
+                a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] += 1u;
+            }
+        } else {
+            // wavefront-ballot accept mask -> one scalar popcount per chain slot
+            wave_acc += __popcll(__ballot(a0 && v0)) + __popcll(__ballot(a1 && v1));
+            if (COUNT) { cnt0 += a0 ? 1u : 0u; cnt1 += a1 ? 1u : 0u; }
+        }
+    }
+}
+
 // K1: the sweep.  make_step!(::Metropolis) metropolis.jl:302-309 -> mc_sweep! :203-212.
 // MULTI: K > 1 (categorical move pick, parameter table staged in LDS, per-chain counters)
 // COUNT: keep per-chain accepted counter (K == 1)      BETA: per-chain beta array
@@ -144,102 +194,96 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
     unsigned long long wave_acc = 0;   // wave-uniform
+    uint32_t cnt0 = 0, cnt1 = 0;
 
-    // wave-uniform trip count: every lane of a wave runs the same iterations (ballot below).
-    // Software prefetch, two grid-stride iterations deep: the 16-B loads of iterations i+1 and i+2
-    // are in flight while iteration i's ~280 VALU instructions run, so HBM latency (also under a
-    // saturated memory system) hides behind the wave's own arithmetic.  The first two loads are
-    // issued BEFORE the math tables are staged into LDS, so that staging overlaps their latency.
-    auto load_x = [&](int64_t b) -> double2 {
-        const int64_t q = b + threadIdx.x;
-        return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
-    };
-    auto load_b = [&](int64_t b) -> double2 {
-        const int64_t q = b + threadIdx.x;
-        return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
-    };
-    double2 x_n1 = {0.0, 0.0}, x_n2 = {0.0, 0.0}, b_n1 = {a.beta, a.beta}, b_n2 = {a.beta, a.beta};
-    if (first < n_pairs) {
-        x_n1 = load_x(first);
-        if (BETA) b_n1 = load_b(first);
-    }
-    if (first + stride < n_pairs) {
-        x_n2 = load_x(first + stride);
-        if (BETA) b_n2 = load_b(first + stride);
-    }
-    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
-    for (int64_t base = first; base < n_pairs; base += stride) {
-        const int64_t p = base + threadIdx.x;
-        const bool v0 = p < n_pairs;
-        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-        const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
-        double2 xv = x_n1;
-        const double b0 = b_n1.x, b1 = b_n1.y;
-        x_n1 = x_n2;
-        b_n1 = b_n2;
-        if (base + 2 * stride < n_pairs) {
-            x_n2 = load_x(base + 2 * stride);
-            if (BETA) b_n2 = load_b(base + 2 * stride);
+    if (!MULTI && !COUNT) {
+        // ---- streamed form.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` at the top of a loop that carries a
+        // prefetched load across its back edge while stores are pending: vmcnt counts loads and stores together
+        // and the two kinds complete out of order with respect to each other, so no counted wait can name one
+        // load ("mixed pending events" in LLVM's SIInsertWaitcnts).  A store issued at the END of an iteration
+        // is therefore waited for immediately, at full write-through latency.  The schedule below issues BOTH
+        // memory operations at the START of an iteration -- the prefetch of iteration i+1 and the store of
+        // iteration i-1's result (kept one iteration in registers) -- so the vmcnt(0) at the top of the next
+        // iteration finds them a whole iteration (~2 us of other waves' arithmetic) old and does not stall.
+        auto load_x = [&](int64_t b) -> double2 {
+            const int64_t q = b + threadIdx.x;
+            return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
+        };
+        auto load_b = [&](int64_t b) -> double2 {
+            const int64_t q = b + threadIdx.x;
+            return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
+        };
+        double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+        if (first < n_pairs) {
+            x_nxt = load_x(first);
+            if (BETA) b_nxt = load_b(first);
         }
-        const uint64_t pair = a.pair0 + (uint64_t)pc;
-        uint32_t cnt0 = 0, cnt1 = 0;
-
-        for (int s = 0; s < a.n_steps; ++s) {
-            const uint64_t t = a.t0 + (uint64_t)s;
-            double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
-            double rd0 = rden1, rd1 = rden1;
-            int k0 = 0, k1 = 0;
-            if (MULTI) {
-                // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
-                // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
-                const u32x4 pk = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS),
-                                               a.key0, a.key1);
-                const double r0 = uniform32(pk.x), r1 = uniform32(pk.y);
-                for (int i = 0; i < K - 1; ++i) {
-                    const double c = s_tab[3 * AMC_MAX_MOVES + i];
-                    k0 += (c <= r0) ? 1 : 0;
-                    k1 += (c <= r1) ? 1 : 0;
-                }
-                sg0 = s_tab[k0]; dn0 = s_tab[AMC_MAX_MOVES + k0]; lc0 = s_tab[2 * AMC_MAX_MOVES + k0];
-                sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
-                rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
+        stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load
+        double2 x_done = {0.0, 0.0};
+        int64_t p_done = -1;
+        for (int64_t base = first; base < n_pairs; base += stride) {
+            const int64_t p = base + threadIdx.x;
+            const bool v0 = p < n_pairs;
+            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+            const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
+            double2 xv = x_nxt;
+            const double b0 = b_nxt.x, b1 = b_nxt.y;
+            if (base + stride < n_pairs) {
+                x_nxt = load_x(base + stride);
+                if (BETA) b_nxt = load_b(base + stride);
             }
-            double z0, z1;
-            box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1),
-                       z0, z1, s_math);
-            const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS),
-                                           a.key0, a.key1);
-            const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math);
-            const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math);
-            if (MULTI) {
-                // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
-                if (v0) {
-                    a.acc[(int64_t)k0 * a.m_stride + 2 * p] += a0 ? 1u : 0u;
-                    a.tot[(int64_t)k0 * a.m_stride + 2 * p] += 1u;
-                }
-                if (v1) {
-                    a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] += a1 ? 1u : 0u;
-                    a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] += 1u;
-                }
-            } else {
-                // wavefront-ballot accept mask -> one scalar popcount per chain slot
-                wave_acc += __popcll(__ballot(a0 && v0)) + __popcll(__ballot(a1 && v1));
-                if (COUNT) { cnt0 += a0 ? 1u : 0u; cnt1 += a1 ? 1u : 0u; }
+            // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
+            if (p_done >= 0) store_pair_writethrough(a.x + 2 * p_done, x_done);
+            pair_steps<POT, false, false>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
+                                          rden1, logc1, wave_acc, cnt0, cnt1);
+            x_done = xv;
+            p_done = v0 ? p : -1;
+        }
+        if (p_done >= 0) store_pair_writethrough(a.x + 2 * p_done, x_done);
+    } else {
+        // ---- general form (per-chain counters and/or K > 1): compiler-managed memory operations
+        auto load_x = [&](int64_t b) -> double2 {
+            const int64_t q = b + threadIdx.x;
+            return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
+        };
+        auto load_b = [&](int64_t b) -> double2 {
+            const int64_t q = b + threadIdx.x;
+            return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
+        };
+        double2 x_n1 = {0.0, 0.0}, b_n1 = {a.beta, a.beta};
+        if (first < n_pairs) {
+            x_n1 = load_x(first);
+            if (BETA) b_n1 = load_b(first);
+        }
+        stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
+        for (int64_t base = first; base < n_pairs; base += stride) {
+            const int64_t p = base + threadIdx.x;
+            const bool v0 = p < n_pairs;
+            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+            const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
+            double2 xv = x_n1;
+            const double b0 = b_n1.x, b1 = b_n1.y;
+            if (base + stride < n_pairs) {   // software prefetch of the next grid-stride iteration
+                x_n1 = load_x(base + stride);
+                if (BETA) b_n1 = load_b(base + stride);
             }
-        }
-        if (v1) {
-            store_pair_writethrough(a.x + 2 * p, xv);
-        } else if (v0) {
-            a.x[2 * p] = xv.x;
-        }
-        if (!MULTI && COUNT) {
+            cnt0 = cnt1 = 0;
+            pair_steps<POT, MULTI, COUNT>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
+                                          rden1, logc1, wave_acc, cnt0, cnt1);
             if (v1) {
-                uint2* q = reinterpret_cast<uint2*>(a.acc + 2 * p);
-                uint2 c = *q;
-                c.x += cnt0; c.y += cnt1;
-                *q = c;
+                *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
             } else if (v0) {
-                a.acc[2 * p] += cnt0;
+                a.x[2 * p] = xv.x;
+            }
+            if (!MULTI && COUNT) {
+                if (v1) {
+                    uint2* q = reinterpret_cast<uint2*>(a.acc + 2 * p);
+                    uint2 c = *q;
+                    c.x += cnt0; c.y += cnt1;
+                    *q = c;
+                } else if (v0) {
+                    a.acc[2 * p] += cnt0;
+                }
             }
         }
     }
