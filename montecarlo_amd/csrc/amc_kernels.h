@@ -142,6 +142,13 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
             sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
             rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
         }
+        // K > 1: the selected moves' counters are fetched NOW, right after the pick, so their latency hides
+        // behind the Box-Muller / exp arithmetic below (loaded at the point of use they were waited for at once).
+        uint32_t ca0 = 0, ct0 = 0, ca1 = 0, ct1 = 0;
+        if (MULTI) {
+            if (v0) { ca0 = a.acc[(int64_t)k0 * a.m_stride + 2 * p]; ct0 = a.tot[(int64_t)k0 * a.m_stride + 2 * p]; }
+            if (v1) { ca1 = a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1]; ct1 = a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1]; }
+        }
         double z0, z1;
         box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1), z0, z1, s_math);
         const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
@@ -150,12 +157,12 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         if (MULTI) {
             // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
             if (v0) {
-                a.acc[(int64_t)k0 * a.m_stride + 2 * p] += a0 ? 1u : 0u;
-                a.tot[(int64_t)k0 * a.m_stride + 2 * p] += 1u;
+                a.acc[(int64_t)k0 * a.m_stride + 2 * p] = ca0 + (a0 ? 1u : 0u);
+                a.tot[(int64_t)k0 * a.m_stride + 2 * p] = ct0 + 1u;
             }
             if (v1) {
-                a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] += a1 ? 1u : 0u;
-                a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] += 1u;
+                a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] = ca1 + (a1 ? 1u : 0u);
+                a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] = ct1 + 1u;
             }
         } else {
             // wavefront-ballot accept mask -> one scalar popcount per chain slot
@@ -256,6 +263,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (BETA) b_n1 = load_b(first);
         }
         stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
+        // same schedule as the streamed form: prefetch, this iteration's per-chain counters and the PREVIOUS
+        // iteration's stores are all issued at the start of the iteration
+        double2 x_done = {0.0, 0.0};
+        uint2 c_done = {0u, 0u};
+        int64_t p_done = -1;
+        bool pair_done = false;
         for (int64_t base = first; base < n_pairs; base += stride) {
             const int64_t p = base + threadIdx.x;
             const bool v0 = p < n_pairs;
@@ -267,23 +280,36 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 x_n1 = load_x(base + stride);
                 if (BETA) b_n1 = load_b(base + stride);
             }
+            uint2 cv = {0u, 0u};
+            if (!MULTI && COUNT) {
+                if (v1) cv = *reinterpret_cast<const uint2*>(a.acc + 2 * p);
+                else if (v0) cv.x = a.acc[2 * p];
+            }
+            if (p_done >= 0) {               // results of the previous iteration
+                if (pair_done) {
+                    *reinterpret_cast<double2*>(a.x + 2 * p_done) = x_done;
+                    if (!MULTI && COUNT) *reinterpret_cast<uint2*>(a.acc + 2 * p_done) = c_done;
+                } else {
+                    a.x[2 * p_done] = x_done.x;
+                    if (!MULTI && COUNT) a.acc[2 * p_done] = c_done.x;
+                }
+            }
             cnt0 = cnt1 = 0;
             pair_steps<POT, MULTI, COUNT>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
                                           rden1, logc1, wave_acc, cnt0, cnt1);
-            if (v1) {
-                *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
-            } else if (v0) {
-                a.x[2 * p] = xv.x;
-            }
-            if (!MULTI && COUNT) {
-                if (v1) {
-                    uint2* q = reinterpret_cast<uint2*>(a.acc + 2 * p);
-                    uint2 c = *q;
-                    c.x += cnt0; c.y += cnt1;
-                    *q = c;
-                } else if (v0) {
-                    a.acc[2 * p] += cnt0;
-                }
+            x_done = xv;
+            c_done.x = cv.x + cnt0;
+            c_done.y = cv.y + cnt1;
+            p_done = v0 ? p : -1;
+            pair_done = v1;
+        }
+        if (p_done >= 0) {
+            if (pair_done) {
+                *reinterpret_cast<double2*>(a.x + 2 * p_done) = x_done;
+                if (!MULTI && COUNT) *reinterpret_cast<uint2*>(a.acc + 2 * p_done) = c_done;
+            } else {
+                a.x[2 * p_done] = x_done.x;
+                if (!MULTI && COUNT) a.acc[2 * p_done] = c_done.x;
             }
         }
     }
