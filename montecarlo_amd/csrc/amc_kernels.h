@@ -179,7 +179,7 @@ template <int POT, bool MULTI, bool COUNT, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
-    __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 6.4 KB
+    __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
     const int K = a.n_moves;
     if (MULTI) {
         for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {

@@ -181,7 +181,7 @@ double amo_logbm(double u)
     k += (int32_t)(i >> 20);
     hx |= i ^ 0x3ff00000u;                          /* exponent field 0x3ff (m >= 1) or 0x3fe (m < 1) */
     double m = u2d(((uint64_t)hx << 32) | (ux & 0xffffffffull));
-    uint32_t idx = (hx >> 13) & 0xffu;
+    uint32_t idx = ((hx >> 13) & 0xffu) - AMC_TAB_LOG_IDX_MIN;    /* only 53..181 occur */
     double r = fma(m, AMC_TAB_LOG_INVC[idx], -1.0);
     double p = 0x1.2492492492492p-3;                /* 1/7 */
     p = fma(p, r, -0x1.5555555555555p-3);           /* -1/6 */
