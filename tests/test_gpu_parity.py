@@ -380,3 +380,26 @@ def test_exact_resume(gpu, K, counters):
         assert all(np.array_equal(u, v) for u, v in zip(a.download_counters(), b.download_counters()))
     a.close()
     b.close()
+
+
+def test_rccl_through_the_c_abi_single_rank(gpu, oracle):
+    """amc_comm_unique_id / amc_comm_init / amc_allreduce_sum (RCCL via dlopen, what the Julia binding uses) and
+    the in-place all-reduce inside amc_pg_accumulate, on a 1-rank communicator: values must be unchanged."""
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=3)
+    e = gpu.HipEngine(n_chains=20001, **kw)
+    o = oracle.OracleSim(20001, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    e.sweep(3)
+    o.make_steps(3)
+    uid = gpu.HipEngine.comm_unique_id()
+    assert len(uid) == 128
+    e.comm_init(0, 1, uid)
+    a = np.array([1.5, -2.0, 3.25, 1e300])
+    assert np.array_equal(e.allreduce_sum(a), a)
+    e.pg_accumulate([1], 2)
+    acc = e.pg_get_accumulated([1])
+    want = o.pg_estimate([1], 2)
+    np.testing.assert_allclose(acc, want, rtol=1e-10)
+    assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    e.close()
