@@ -18,6 +18,13 @@ import numpy as np
 
 def world() -> Tuple[int, int]:
     """(rank, world_size) of the default process group, (0, 1) when not initialised."""
+    # A process group can only exist if the caller has imported torch already; never import it from here:
+    # torch bundles its own HIP runtime, and loading it AFTER libamc.so has bound the system one puts two
+    # HIP runtimes in the process (the C-ABI RCCL path then fails).  Multi-GPU scripts import torch and call
+    # init_process_group before building the Simulation, so torch is always first in that case.
+    import sys
+    if "torch" not in sys.modules:
+        return 0, 1
     try:
         import torch.distributed as dist
     except Exception:
