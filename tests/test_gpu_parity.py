@@ -403,3 +403,55 @@ def test_rccl_through_the_c_abi_single_rank(gpu, oracle):
     np.testing.assert_allclose(acc, want, rtol=1e-10)
     assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
     e.close()
+
+
+def test_extreme_ids_seeds_and_step_indices(gpu, oracle):
+    """64-bit seeds, chain offsets beyond 2^32 pairs and step indices beyond 2^32 all reach the Philox counter
+    unchanged (DESIGN.md section 3.1 packing)."""
+    sigma, weight = POOLS[2]
+    for seed, offset, step in [(2 ** 64 - 1, 2 ** 34, 2 ** 32 - 3), (0x0123456789ABCDEF, 2 ** 40 + 2, 2 ** 47 - 100)]:
+        kw = dict(potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=seed)
+        e = gpu.HipEngine(n_chains=3001, chain_offset=offset, n_chains_global=offset + 3001, **kw)
+        o = oracle.OracleSim(3001, chain_offset=offset, **kw)
+        e.init_uniform(-2, 2)
+        o.init_uniform(-2, 2)
+        e.step = step
+        o.step = step
+        e.sweep(7)                       # crosses 2^32 in the first case
+        o.make_steps(7)
+        assert_same(e, o)
+        e.close()
+    e = gpu.HipEngine(n_chains=10, sigma=[0.1], weight=[1.0])
+    with pytest.raises(gpu.AmcError):
+        e.step = 2 ** 48                 # 48-bit step index
+    e.close()
+
+
+def test_largest_pool_and_long_sweepstep(gpu, oracle):
+    """AMC_MAX_MOVES = 64 moves with unequal weights; sweepstep = 50 fused steps per make_step!."""
+    K = 64
+    w = np.arange(1, K + 1, dtype=np.float64)
+    w /= w.sum()
+    sig = list(np.linspace(0.05, 1.5, K))
+    kw = dict(potential="double_well", beta=1.5, sigma=sig, weight=list(w), seed=99, sweepstep=50)
+    e = gpu.HipEngine(n_chains=2049, **kw)
+    o = oracle.OracleSim(2049, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    e.sweep(4)
+    o.make_steps(4, 4)
+    assert_same(e, o)
+    assert e.step == 200
+    with pytest.raises(gpu.AmcError):
+        gpu.HipEngine(n_chains=10, sigma=[0.1] * 65, weight=[1 / 65] * 65)
+    e.close()
+
+
+def test_per_chain_beta_with_mixed_pool_and_estimator(gpu, oracle):
+    b = np.random.default_rng(5).uniform(0.5, 4.0, 4097)
+    e, o = run_pair(gpu, oracle, 4097, 3, "harmonic", 12, beta_arr=b)
+    assert_same(e, o)
+    g, go = e.pg_estimate([0, 2], 2), o.pg_estimate([0, 2], 2)
+    np.testing.assert_allclose(g, go, rtol=1e-10, atol=1e-9)
+    assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    e.close()
