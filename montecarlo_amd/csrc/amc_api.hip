@@ -253,7 +253,7 @@ int amc_create(const amc_config* cfg, amc_handle** out)
         if (v >= 1 && v <= 64) h->blocks_per_cu = v;
     }
     h->M = cfg->n_chains;
-    h->M_pad = ((cfg->n_chains + 1) & ~(int64_t)1) + 2;   // even + one spare pair: 16-B tail loads stay in bounds
+    h->M_pad = ((cfg->n_chains + 1) & ~(int64_t)1) + AMC_PAD_DOUBLES;   // even + padding: unclamped 16-B tail loads stay in bounds
     h->offset = cfg->chain_offset;
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;

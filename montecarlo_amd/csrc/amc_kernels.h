@@ -16,6 +16,8 @@
 #define AMC_MAX_MOVES 64
 #define AMC_MAX_LEARN 8
 #define AMC_BLOCK 256
+#define AMC_PAD_DOUBLES 520      // readable padding behind every per-chain array: a ragged last block-iteration
+                                 // may load up to 255 pairs past the end without a clamp
 
 namespace amc {
 
@@ -95,7 +97,10 @@ __device__ __forceinline__ void store_pair_writethrough(double* p, double2 v)
     d2_t t;
     t.x = v.x;
     t.y = v.y;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
+    // trailing s_nop 1: a VMEM store of more than 8 bytes reads its data VGPRs over the next cycles, and a
+    // VALU write to them needs 2 wait states on gfx940+/gfx950 (LLVM inserts them for its own stores, never
+    // around inline asm) -- without it lanes 12..15 of each row stored a later value of the registers.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
 }
 
 struct SweepArgs {
@@ -212,14 +217,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         // memory operations at the START of an iteration -- the prefetch of iteration i+1 and the store of
         // iteration i-1's result (kept one iteration in registers) -- so the vmcnt(0) at the top of the next
         // iteration finds them a whole iteration (~2 us of other waves' arithmetic) old and does not stall.
-        auto load_x = [&](int64_t b) -> double2 {
-            const int64_t q = b + threadIdx.x;
-            return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
-        };
-        auto load_b = [&](int64_t b) -> double2 {
-            const int64_t q = b + threadIdx.x;
-            return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
-        };
+        // An iteration that has a successor covers 256 in-range pairs on every lane (stride >= 256), so the
+        // loop body runs without per-lane predicates; only the LAST iteration of a block can be ragged and is
+        // peeled.  Loads need no clamp either: the arrays carry AMC_PAD_DOUBLES of readable padding.
+        auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
+        auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
         double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
         if (first < n_pairs) {
             x_nxt = load_x(first);
@@ -227,26 +229,31 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
         stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load
         double2 x_done = {0.0, 0.0};
-        int64_t p_done = -1;
-        for (int64_t base = first; base < n_pairs; base += stride) {
+        int64_t base_done = -1;                                  // block-uniform
+        int64_t base = first;
+        for (; base + stride < n_pairs; base += stride) {        // full iterations
+            const int64_t p = base + threadIdx.x;
+            double2 xv = x_nxt;
+            const double b0 = b_nxt.x, b1 = b_nxt.y;
+            x_nxt = load_x(base + stride);
+            if (BETA) b_nxt = load_b(base + stride);
+            if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            pair_steps<POT, false, false>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math, sigma1, den1,
+                                          rden1, logc1, wave_acc, cnt0, cnt1);
+            x_done = xv;
+            base_done = base;
+        }
+        if (base < n_pairs) {                                    // last, possibly ragged, iteration
             const int64_t p = base + threadIdx.x;
             const bool v0 = p < n_pairs;
             const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-            const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
             double2 xv = x_nxt;
-            const double b0 = b_nxt.x, b1 = b_nxt.y;
-            if (base + stride < n_pairs) {
-                x_nxt = load_x(base + stride);
-                if (BETA) b_nxt = load_b(base + stride);
-            }
+            if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            pair_steps<POT, false, false>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1, s_tab, s_math,
+                                          sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1);
             // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
-            if (p_done >= 0) store_pair_writethrough(a.x + 2 * p_done, x_done);
-            pair_steps<POT, false, false>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
-                                          rden1, logc1, wave_acc, cnt0, cnt1);
-            x_done = xv;
-            p_done = v0 ? p : -1;
+            if (v0) store_pair_writethrough(a.x + 2 * p, xv);
         }
-        if (p_done >= 0) store_pair_writethrough(a.x + 2 * p_done, x_done);
     } else {
         // ---- general form (per-chain counters and/or K > 1): compiler-managed memory operations
         auto load_x = [&](int64_t b) -> double2 {

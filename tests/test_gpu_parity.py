@@ -166,6 +166,22 @@ def test_sweep_bit_exact_beyond_one_grid(gpu, oracle):
     e.close()
 
 
+@pytest.mark.parametrize("counters", [False, True])
+def test_sweep_bit_exact_three_grid_stride_iterations(gpu, oracle, counters):
+    """3e6 chains = 1.5e6 pairs = three grid-stride iterations per thread (full, full, ragged): exercises the
+    prefetch / delayed-store schedule of both sweep forms, two sweeps so stored values are re-read."""
+    e = gpu.HipEngine(n_chains=3_000_001, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=7,
+                      per_chain_counters=counters)
+    o = oracle.OracleSim(3_000_001, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=7)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    e.sweep(1)
+    e.sweep(1)
+    o.make_steps(2, oracle.load().amo_max_threads())
+    assert_same(e, o, counters=counters)
+    e.close()
+
+
 def test_pool_wide_counter_mode(gpu, oracle):
     """per_chain_counters = 0 (the benchmark's 16 B/update mode): x and the accepted total still exact."""
     e, o = run_pair(gpu, oracle, 5000, 1, "harmonic", 20, counters=False)
