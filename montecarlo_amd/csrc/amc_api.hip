@@ -122,28 +122,34 @@ int push_params(amc_handle* h, const double* sigma, const double* weight)
     return AMC_OK;
 }
 
-template <int POT>
-int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
+template <int POT, bool SINGLE>
+int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     const bool multi = h->K > 1;
     if (multi) {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     } else if (h->counters) {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     } else {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     }
     AMC_HIP(hipGetLastError());
     return AMC_OK;
+}
+
+template <int POT>
+int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
+{
+    return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
 }
 
 template <int POT, int NL>

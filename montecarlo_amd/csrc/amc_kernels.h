@@ -121,14 +121,15 @@ struct SweepArgs {
 };
 
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
-template <int POT, bool MULTI, bool COUNT>
+template <int POT, bool MULTI, bool COUNT, bool SINGLE>
 __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, double b0, double b1, uint64_t pair,
                                            int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
                                            double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& cnt0, uint32_t& cnt1)
 {
     const int K = a.n_moves;
-    for (int s = 0; s < a.n_steps; ++s) {
+    const int n_steps = SINGLE ? 1 : a.n_steps;      // SINGLE: the sweepstep = 1 launch, straight-line code
+    for (int s = 0; s < n_steps; ++s) {
         const uint64_t t = a.t0 + (uint64_t)s;
         double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
         double rd0 = rden1, rd1 = rden1;
@@ -180,7 +181,8 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
 // K1: the sweep.  make_step!(::Metropolis) metropolis.jl:302-309 -> mc_sweep! :203-212.
 // MULTI: K > 1 (categorical move pick, parameter table staged in LDS, per-chain counters)
 // COUNT: keep per-chain accepted counter (K == 1)      BETA: per-chain beta array
-template <int POT, bool MULTI, bool COUNT, bool BETA>
+// SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
+template <int POT, bool MULTI, bool COUNT, bool BETA, bool SINGLE>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             x_nxt = load_x(base + stride);
             if (BETA) b_nxt = load_b(base + stride);
             if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            pair_steps<POT, false, false>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math, sigma1, den1,
+            pair_steps<POT, false, false, SINGLE>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math, sigma1, den1,
                                           rden1, logc1, wave_acc, cnt0, cnt1);
             x_done = xv;
             base_done = base;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             const bool v1 = v0 && (2 * p + 1 < a.n_chains);
             double2 xv = x_nxt;
             if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            pair_steps<POT, false, false>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1, s_tab, s_math,
+            pair_steps<POT, false, false, SINGLE>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1, s_tab, s_math,
                                           sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1);
             // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
             if (v0) store_pair_writethrough(a.x + 2 * p, xv);
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 }
             }
             cnt0 = cnt1 = 0;
-            pair_steps<POT, MULTI, COUNT>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
+            pair_steps<POT, MULTI, COUNT, SINGLE>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
                                           rden1, logc1, wave_acc, cnt0, cnt1);
             x_done = xv;
             c_done.x = cv.x + cnt0;
@@ -321,16 +323,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
     }
     if (!MULTI) {
-        // Pool-wide accepted count: each block owns ONE u64 slot (plain read-modify-write by one
-        // lane, no atomics: thousands of same-address atomics at kernel end serialise at ~13 ns
-        // each).  The host sums the slots when a total is asked for.
+        // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
+        // address at kernel end serialise at ~13 ns each; one address per block does not contend).
+        // The final reduce pass sums the slots when a total is asked for.
         __shared__ unsigned long long s_acc[AMC_BLOCK / 64];
         if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = wave_acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long t = 0;
             for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc[w];
-            if (t != 0) a.acc_total[blockIdx.x] += t;
+            // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
+            if (t != 0) __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
