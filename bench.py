@@ -128,11 +128,12 @@ def main():
         return None
 
     def step(i):
-        eng.sweep(1)
         if cb_every and (i + 1) % cb_every == 0:
             finish_callback()
-            eng.reduce_begin()
+            eng.sweep_reduce_begin(1)        # the sweep whose state the callbacks observe: sums formed in-kernel
             pending[0] = True
+        else:
+            eng.sweep(1)
 
     def barrier():
         eng.sync()

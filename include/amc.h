@@ -161,6 +161,9 @@ int  amc_reduce(amc_handle *h, double *out);
  * and the device->host copy and returns; _end waits for THAT copy only (sweeps queued after _begin keep
  * running) and returns the values as of _begin.  One reduction may be in flight per handle. */
 int  amc_reduce_begin(amc_handle *h);
+/* n make_step!s followed by amc_reduce_begin of the resulting state; for K = 1 handles without per-chain
+ * counters the sums are formed inside the last sweep launch (no second pass over the chains). */
+int  amc_sweep_reduce_begin(amc_handle *h, int64_t n_sweeps);
 int  amc_reduce_end(amc_handle *h, double *out);
 
 /* Move.parameters (shared by all chains, metropolis.jl:252-260): read / replace

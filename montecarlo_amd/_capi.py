@@ -86,6 +86,7 @@ def load() -> C.CDLL:
         "amc_set_step": (C.c_int, [H, C.c_uint64]),
         "amc_reduce": (C.c_int, [H, dp]),
         "amc_reduce_begin": (C.c_int, [H]),
+        "amc_sweep_reduce_begin": (C.c_int, [H, C.c_int64]),
         "amc_reduce_end": (C.c_int, [H, dp]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
@@ -264,6 +265,10 @@ class HipEngine:
     def reduce_begin(self) -> None:
         """Enqueue the reduction; sweeps queued afterwards keep running while the host does other work."""
         _check(self._lib.amc_reduce_begin(self._h))
+
+    def sweep_reduce_begin(self, n_sweeps: int = 1) -> None:
+        """n sweeps, then the callback reduction of the resulting state (fused into the last launch when possible)."""
+        _check(self._lib.amc_sweep_reduce_begin(self._h, int(n_sweeps)))
 
     def reduce_end(self) -> np.ndarray:
         out = np.empty(AMC_RED_HEADER + self.n_moves, dtype=np.float64)

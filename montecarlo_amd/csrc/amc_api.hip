@@ -147,6 +147,24 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 }
 
 template <int POT>
+int launch_sweep_reduce(amc_handle* h, const amc::SweepArgs& a, int grid)
+{
+    if (a.n_steps == 1) {
+        if (h->beta_arr)
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    } else {
+        if (h->beta_arr)
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+    }
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+template <int POT>
 int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
@@ -462,14 +480,14 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     return AMC_OK;
 }
 
-int amc_sweep(amc_handle* h, int64_t n_sweeps)
+// n_sweeps x sweepstep MH steps in launches of at most 2^20 steps; when fuse_reduce is set (streamed form
+// only) the LAST launch also leaves the callback partial sums of the final state in d_partials[grid][5].
+static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* grid_out)
 {
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep: NULL handle");
-    if (n_sweeps < 0) return fail(AMC_ERR_BAD_ARG, "amc_sweep: n_sweeps < 0");
-    if (n_sweeps == 0) return AMC_OK;
     AMC_HIP(hipSetDevice(h->device));
     int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
     const int grid = grid_for(h, (h->M + 1) / 2);
+    if (grid_out) *grid_out = grid;
     while (remaining > 0) {
         const int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
         amc::SweepArgs a;
@@ -488,14 +506,29 @@ int amc_sweep(amc_handle* h, int64_t n_sweeps)
         a.key0 = (uint32_t)h->seed;
         a.key1 = (uint32_t)(h->seed >> 32);
         a.beta = h->beta;
-        const int rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep<amc::POT_DOUBLE_WELL>(h, a, grid)
-                                                                   : launch_sweep<amc::POT_HARMONIC>(h, a, grid);
+        a.red_partials = h->d_partials;
+        const bool last = remaining == chunk;
+        int rc;
+        if (fuse_reduce && last)
+            rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep_reduce<amc::POT_DOUBLE_WELL>(h, a, grid)
+                                                             : launch_sweep_reduce<amc::POT_HARMONIC>(h, a, grid);
+        else
+            rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep<amc::POT_DOUBLE_WELL>(h, a, grid)
+                                                             : launch_sweep<amc::POT_HARMONIC>(h, a, grid);
         if (rc != AMC_OK) return rc;
         h->t += (uint64_t)chunk;
         h->t_counted += (uint64_t)chunk;
         remaining -= chunk;
     }
     return AMC_OK;
+}
+
+int amc_sweep(amc_handle* h, int64_t n_sweeps)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep: NULL handle");
+    if (n_sweeps < 0) return fail(AMC_ERR_BAD_ARG, "amc_sweep: n_sweeps < 0");
+    if (n_sweeps == 0) return AMC_OK;
+    return sweep_impl(h, n_sweeps, false, nullptr);
 }
 
 int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* total)
@@ -640,6 +673,29 @@ int amc_reduce_begin(amc_handle* h)
     // pass 2 also folds the per-block accepted slots (K == 1) into one exact integer-valued double
     hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, h->red_blocks,
                        n_vals, h->d_out, h->d_acc_slots, h->n_slots);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)(n_vals + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
+    h->red_pending = true;
+    h->red_t_counted = h->t_counted;
+    return AMC_OK;
+}
+
+int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
+    if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
+    if (h->red_pending) return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
+    if (h->K > 1 || h->counters) {          // no fused form: sweep, then the ordinary two-pass reduction
+        const int rc = sweep_impl(h, n_sweeps, false, nullptr);
+        return rc != AMC_OK ? rc : amc_reduce_begin(h);
+    }
+    int grid = 0;
+    const int rc = sweep_impl(h, n_sweeps, true, &grid);
+    if (rc != AMC_OK) return rc;
+    const int n_vals = 4 + h->K;            // = 5: the partials rows the fused kernel wrote
+    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, n_vals,
+                       h->d_out, h->d_acc_slots, h->n_slots);
     AMC_HIP(hipGetLastError());
     AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)(n_vals + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipEventRecord(h->ev_red, h->stream));

@@ -103,6 +103,37 @@ __device__ __forceinline__ void store_pair_writethrough(double* p, double2 v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
 }
 
+// ---- deterministic block reduction helpers -------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sums NV per-thread values over the block; thread 0 writes them to out[0..NV).
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
+{
+    __shared__ double s_part[NV][AMC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double w = wave_sum(v[i]);
+        if (lane == 0) s_part[i][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = s_part[i][0];
+            for (int w = 1; w < AMC_BLOCK / 64; ++w) t += s_part[i][w];
+            out[i] = t;
+        }
+    }
+    __syncthreads();
+}
+
 struct SweepArgs {
     double* x;
     const double* beta_arr;       // nullptr unless per-chain beta
@@ -118,6 +149,7 @@ struct SweepArgs {
     int32_t n_moves;
     uint32_t key0, key1;
     double beta;
+    double* red_partials;         // REDUCE launches: [grid][5] block partials of (sum e, sum x, sum x^2, count, 0)
 };
 
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
@@ -182,9 +214,13 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
 // MULTI: K > 1 (categorical move pick, parameter table staged in LDS, per-chain counters)
 // COUNT: keep per-chain accepted counter (K == 1)      BETA: per-chain beta array
 // SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
-template <int POT, bool MULTI, bool COUNT, bool BETA, bool SINGLE>
+// REDUCE (streamed form only): also leave the callback sums of the state AFTER the sweep in red_partials, so a
+//         sweep that is followed by callback_energy / callback_acceptance needs no second pass over x
+template <int POT, bool MULTI, bool COUNT, bool BETA, bool SINGLE, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
+    static_assert(!REDUCE || (!MULTI && !COUNT), "fused reduction exists for the streamed form only");
+    double red[4] = {0.0, 0.0, 0.0, 0.0};
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
     const int K = a.n_moves;
@@ -242,6 +278,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
             pair_steps<POT, false, false, SINGLE>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math, sigma1, den1,
                                           rden1, logc1, wave_acc, cnt0, cnt1);
+            if (REDUCE) {
+                red[0] += potential<POT>(xv.x) + potential<POT>(xv.y);
+                red[1] += xv.x + xv.y;
+                red[2] += xv.x * xv.x + xv.y * xv.y;
+                red[3] += 2.0;
+            }
             x_done = xv;
             base_done = base;
         }
@@ -255,6 +297,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                                           sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1);
             // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
             if (v0) store_pair_writethrough(a.x + 2 * p, xv);
+            if (REDUCE) {
+                if (v0) { red[0] += potential<POT>(xv.x); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
+                if (v1) { red[0] += potential<POT>(xv.y); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
+            }
+        }
+        if (REDUCE) {
+            double* out = a.red_partials + (int64_t)blockIdx.x * 5;
+            block_sum_store<4>(red, out);
+            if (threadIdx.x == 0) out[4] = 0.0;      // ratio column: the host divides the pool-wide slot total
         }
     } else {
         // ---- general form (per-chain counters and/or K > 1): compiler-managed memory operations
@@ -448,37 +499,6 @@ __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds i
         for (int i = 0; i < 5; ++i) a[i] = 0.0;
     }
     prepare_params(ptab, n_moves);
-}
-
-// ---- deterministic block reduction helpers -------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Sums NV per-thread values over the block; thread 0 writes them to out[0..NV).
-template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
-{
-    __shared__ double s_part[NV][AMC_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double w = wave_sum(v[i]);
-        if (lane == 0) s_part[i][wave] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double t = s_part[i][0];
-            for (int w = 1; w < AMC_BLOCK / 64; ++w) t += s_part[i][w];
-            out[i] = t;
-        }
-    }
-    __syncthreads();
 }
 
 // K2a: callback reductions, pass 1.  partials[block][4 + K]:

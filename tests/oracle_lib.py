@@ -346,6 +346,10 @@ class OracleEngine:
     def reduce_begin(self):
         self._pending = self.reduce()
 
+    def sweep_reduce_begin(self, n_sweeps=1):
+        self.sweep(n_sweeps)
+        self._pending = self.reduce()
+
     def reduce_end(self):
         out, self._pending = self._pending, None
         return out

@@ -471,3 +471,34 @@ def test_per_chain_beta_with_mixed_pool_and_estimator(gpu, oracle):
     np.testing.assert_allclose(g, go, rtol=1e-10, atol=1e-9)
     assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
     e.close()
+
+
+@pytest.mark.parametrize("M,n,counters,K", [(1_000_003, 1, False, 1), (1_000_003, 3, False, 1), (5001, 1, True, 1), (5001, 2, True, 2)])
+def test_fused_sweep_and_callback_reduction(gpu, oracle, M, n, counters, K):
+    """amc_sweep_reduce_begin: the callback sums of the state AFTER the sweep, formed inside the sweep launch
+    (K = 1 pool-wide-counter mode) or by the ordinary two-pass reduction behind it (other modes)."""
+    sigma, weight = POOLS[K]
+    kw = dict(potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=13)
+    e = gpu.HipEngine(n_chains=M, per_chain_counters=counters, **kw)
+    o = oracle.OracleSim(M, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    e.sweep(2)
+    o.make_steps(2, 4)
+    e.sweep_reduce_begin(n)
+    e.sweep(1)                                  # work queued behind the reduction must not disturb it
+    red = e.reduce_end()
+    o.make_steps(n, 4)
+    assert red[3] == M
+    np.testing.assert_allclose(red[0] / M, o.energy(), rtol=RED_RTOL)
+    mom = o.moments()
+    np.testing.assert_allclose(red[1], mom[0], rtol=1e-9, atol=1e-9 * M)
+    np.testing.assert_allclose(red[2], mom[1], rtol=RED_RTOL)
+    np.testing.assert_allclose(red[4:] / M, o.acceptance(), rtol=RED_RTOL, equal_nan=True)
+    o.make_steps(1, 4)
+    assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    with pytest.raises(gpu.AmcError):
+        e.sweep_reduce_begin(1)
+        e.sweep_reduce_begin(1)                 # only one reduction in flight
+    e.reduce_end()
+    e.close()
