@@ -79,13 +79,27 @@ class Metropolis(AriannaAlgorithm):
             self.engine.init_uniform(lo, hi)
         self._epoch += 1
 
-    def make_step(self, simulation: Simulation) -> None:
-        """make_step!(simulation, ::Metropolis), src/metropolis.jl:302-309: one sweep of every chain."""
-        self.engine.sweep(1)
+    def make_step(self, simulation: Simulation, with_reductions: bool = False) -> None:
+        """make_step!(simulation, ::Metropolis), src/metropolis.jl:302-309: one sweep of every chain.
+
+        ``with_reductions``: a callback observes the state right after this sweep (run() looks ahead in the
+        schedule), so the sums are formed inside the sweep launch instead of by a second pass over the chains."""
+        self._drop_pending_reduction()
+        if with_reductions and hasattr(self.engine, "sweep_reduce_begin"):
+            self.engine.sweep_reduce_begin(1)
+            self._pending_red_epoch = self._epoch + 1
+        else:
+            self.engine.sweep(1)
         self._epoch += 1
+
+    def _drop_pending_reduction(self) -> None:
+        if getattr(self, "_pending_red_epoch", None) is not None:
+            self.engine.reduce_end()            # nobody asked for it: discard
+            self._pending_red_epoch = None
 
     def make_steps(self, simulation: Simulation, n: int) -> None:
         """n consecutive make_step!s fused in one launch (state stays in registers)."""
+        self._drop_pending_reduction()
         self.engine.sweep(n)
         self._epoch += 1
 
@@ -141,7 +155,13 @@ class Metropolis(AriannaAlgorithm):
         key = self._epoch
         if self._red_key == key and self._red_val is not None:
             return self._red_val
-        red = sharding.allreduce_sum(self.engine.reduce())
+        if getattr(self, "_pending_red_epoch", None) == self._epoch:
+            local = self.engine.reduce_end()    # formed inside the sweep launch (make_step(with_reductions=True))
+            self._pending_red_epoch = None
+        else:
+            self._drop_pending_reduction()
+            local = self.engine.reduce()
+        red = sharding.allreduce_sum(local)
         n = red[3]
         val = {
             "energy": red[0] / n,                      # mean(system.e for system in chains)

@@ -142,6 +142,8 @@ class PolicyGradientEstimator(AriannaAlgorithm):
     (estimator.jl:103-109).  ``ad_backend`` is accepted and ignored: d logq / d sigma of the Gaussian
     policy is evaluated in closed form by the kernel (test/ad_backends_test.jl pins all backends equal)."""
 
+    mutates_chains = True       # every sample leaves x at (x + delta) - delta (gradients.jl:98,103)
+
     def __init__(self, chains, dependencies=None, optimisers=None, q_batch_size: int = 1, ad_backend=None,
                  R=None, parallel: bool = False, device_resident: Optional[bool] = None, **extras):
         assert dependencies is not None and len(dependencies) == 1                 # :104

@@ -240,8 +240,12 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
                     sim.t = t + n - 1
                     t += advance
                     continue
-            for k in due:                                                           # :185-190
-                sim.algorithms[k].make_step(sim)
+            for i, k in enumerate(due):                                             # :185-190
+                alg = sim.algorithms[k]
+                if getattr(alg, "fusable", False) and _observed_next(sim, due[i + 1:]):
+                    alg.make_step(sim, with_reductions=True)    # callbacks follow at this t: sums formed in-kernel
+                else:
+                    alg.make_step(sim)
                 sim.counters[k] += 1
             t += advance
         for alg in sim.algorithms:
@@ -256,6 +260,18 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
         for alg in sim.algorithms:                                                  # :196-198
             alg.finalise(sim)
         sim._finalise_summary()
+
+
+def _observed_next(simulation: Simulation, later: Sequence[int]) -> bool:
+    """True if, among the algorithms still due at this time step, one that reads the reductions comes before
+    any that moves the chains (the estimator perturbs x: src/PolicyGuided/gradients.jl:98,103)."""
+    for k in later:
+        alg = simulation.algorithms[k]
+        if getattr(alg, "mutates_chains", False):
+            return False
+        if getattr(alg, "wants_reductions", False):
+            return True
+    return False
 
 
 def _consecutive(scheduler, counter: int, t: int, t_last: int) -> int:
@@ -274,6 +290,8 @@ def _consecutive(scheduler, counter: int, t: int, t_last: int) -> int:
 # StoreCallbacks, src/algorithms.jl:62-109
 # ---------------------------------------------------------------------------------------
 class StoreCallbacks(AriannaAlgorithm):
+    wants_reductions = True
+
     def __init__(self, chains, path=None, callbacks=None, store_first: bool = True, store_last: bool = False,
                  **extras):
         self.callbacks = tuple(callbacks or ())

@@ -28,6 +28,8 @@ class StoreHistogram(AriannaAlgorithm):
     of all chain positions at every scheduled time; `finalise` all-reduces it and rank 0 writes
     `histogram.dat` (bin_lo bin_hi count) plus the pooled mean / std estimated from the bin-free moments."""
 
+    wants_reductions = True
+
     def __init__(self, chains, dependencies=None, path=None, lo: float = -2.0, hi: float = 2.0, bins: int = 200,
                  **extras):
         assert dependencies is not None and len(dependencies) == 1 and isinstance(dependencies[0], Metropolis)
