@@ -213,7 +213,8 @@ int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
 
 /* Parity-test hooks: evaluate arithmetic-spec primitives on the device.
  * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b (IEEE), 6 a/b by the kernel's
- * reciprocal-correction sequence (must equal 5 bit for bit), 7 the Box-Muller log.  Host buffers. */
+ * reciprocal-correction sequence (must equal 5 bit for bit), 7 the Box-Muller log, 8 the Box-Muller
+ * radius sqrt (must equal 4 bit for bit on {0} U [2^-52, 80]).  Host buffers. */
 int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
                        double *out, int64_t n);
 /* out4[i] = Philox4x32-10(key = seed, counter of draw (pair[i], t[i], draw, stream)). */

@@ -266,6 +266,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (BETA) b_nxt = load_b(first);
         }
         stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load
+        // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
+        // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
+        // the prefetch issued a few dozen instructions earlier instead of leaving it a whole iteration.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), other counters untouched
         double2 x_done = {0.0, 0.0};
         int64_t base_done = -1;                                  // block-uniform
         int64_t base = first;
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (BETA) b_n1 = load_b(first);
         }
         stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once, see above
         // same schedule as the streamed form: prefetch, this iteration's per-chain counters and the PREVIOUS
         // iteration's stores are all issued at the start of the iteration
         double2 x_done = {0.0, 0.0};
@@ -738,6 +743,7 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
     case 5: r = v / b[i]; break;
     case 6: r = div_by_const(v, b[i], 1.0 / b[i]); break;
     case 7: r = logbm_f64(v, s_math); break;
+    case 8: r = sqrt_radius_f64(v); break;
     default: break;
     }
     out[i] = r;

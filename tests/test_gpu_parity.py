@@ -46,6 +46,12 @@ def test_device_sqrt_and_division_are_ieee(gpu):
     rng = np.random.default_rng(1)
     a = np.concatenate([rng.uniform(0, 80, 300000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, np.inf, 4.0]])
     assert np.array_equal(bits(gpu.selftest_math("sqrt", a)), bits(np.sqrt(a)))
+    # the Box-Muller radius takes sqrt(-2 log u), u in (0,1] on the 2^-52 grid, by the kernel's own unscaled
+    # sequence (amc_math.h sqrt_radius_f64): every value class that can occur, incl. exact 0 (u = 1)
+    r = np.concatenate([rng.uniform(0, 80, 2_000_000), np.exp(rng.uniform(np.log(2.0 ** -53), np.log(80), 1_000_000)),
+                        -2.0 * np.log(1.0 - rng.integers(0, 2 ** 52, 1_000_000) * 2.0 ** -52),
+                        [0.0, 2.0 ** -52, 2.0 ** -51, 72.0873, 1.0, 4.0, np.nextafter(4.0, 0), np.nextafter(4.0, 5)]])
+    assert np.array_equal(bits(gpu.selftest_math("sqrt_radius", r)), bits(np.sqrt(r)))
     num = -rng.uniform(0, 30, 400000) ** 2
     den = 2 * np.exp(rng.uniform(-6, 3, 400000)) ** 2
     assert np.array_equal(bits(gpu.selftest_math("div", num, den)), bits(num / den))

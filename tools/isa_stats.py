@@ -3,7 +3,7 @@
 import re, collections, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args=[a for a in sys.argv[1:] if not a.startswith('-')]
-name = args[0] if args else '_ZN3amc12sweep_kernelILi0ELb0ELb0ELb0ELb1EEEvNS_9SweepArgsE'
+name = args[0] if args else '_ZN3amc12sweep_kernelILi0ELb0ELb0ELb0ELb1ELb0EEEvNS_9SweepArgsE'
 subprocess.run(['/opt/rocm/bin/hipcc','-O3','-std=c++17','--offload-arch=gfx950','-ffp-contract=off','-fno-fast-math','-S','--cuda-device-only',
                 os.path.join(ROOT,'montecarlo_amd/csrc/amc_api.hip'),'-o','/tmp/amc.s'],check=True,stderr=subprocess.DEVNULL)
 s=open('/tmp/amc.s').read()
