@@ -67,7 +67,8 @@ __device__ __forceinline__ double potential(double x)
 //   reject: perform_action_cached! re-applies the negated action: x = (x+d) + (-d)
 template <int POT>
 __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double rden,
-                                        double logc, double z, double u, const double* T)
+                                        double logc, double z, double u, const double* T,
+                                        unsigned long long& wave_mask)
 {
     const double delta = 0.0 + sigma * z;
     const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den, bit for bit
@@ -82,7 +83,12 @@ __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, do
     //   arg < -708 or NaN  -> alpha == 0 or NaN (Julia's min keeps NaN) : reject
     // identical decisions to the full-domain form, ~15 fewer VALU instructions per chain.
     // (bitwise | and & on purpose: no short-circuit branches, both chains' exp stay interleaved)
-    const bool accept = (arg >= 0.0) | ((arg >= -708.0) & (exp_core_f64(arg, T) > u));
+    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
+    const bool accept = c_pos | (c_rng & c_exp);
+    // the wavefront's accept mask, formed from the three compare masks on the scalar unit (a ballot of `accept`
+    // itself goes through a 0/1 VGPR and a second compare)
+    wave_mask = __builtin_amdgcn_ballot_w64(c_pos) |
+                (__builtin_amdgcn_ballot_w64(c_rng) & __builtin_amdgcn_ballot_w64(c_exp));
     const double xr = xn + (-delta);
     x = accept ? xn : xr;
     return accept;
@@ -152,13 +158,30 @@ struct SweepArgs {
     double* red_partials;         // REDUCE launches: [grid][5] block partials of (sum e, sum x, sum x^2, count, 0)
 };
 
+// The two Philox results of one MH step of a pair (normal draw, accept draw): pure functions of
+// (seed, pair, step), so they can be formed before the pair's state has arrived from memory.
+struct StepDraws {
+    u32x4 normal, accept;
+};
+
+__device__ __forceinline__ StepDraws step_draws(const SweepArgs& a, uint64_t pair, uint64_t t)
+{
+    StepDraws d;
+    d.normal = philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1);
+    d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
+    return d;
+}
+
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
-template <int POT, bool MULTI, bool COUNT, bool SINGLE>
+// PRE: the draws of the (single) step were formed ahead by the caller and come in `pre`.
+template <int POT, bool MULTI, bool COUNT, bool SINGLE, bool PRE = false>
 __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, double b0, double b1, uint64_t pair,
                                            int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
                                            double sigma1, double den1, double rden1, double logc1,
-                                           unsigned long long& wave_acc, uint32_t& cnt0, uint32_t& cnt1)
+                                           unsigned long long& wave_acc, uint32_t& cnt0, uint32_t& cnt1,
+                                           const StepDraws* pre = nullptr)
 {
+    static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
     const int K = a.n_moves;
     const int n_steps = SINGLE ? 1 : a.n_steps;      // SINGLE: the sweepstep = 1 launch, straight-line code
     for (int s = 0; s < n_steps; ++s) {
@@ -188,10 +211,12 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
             if (v1) { ca1 = a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1]; ct1 = a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1]; }
         }
         double z0, z1;
-        box_muller(philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1), z0, z1, s_math);
-        const u32x4 pu = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
-        const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math);
-        const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math);
+        const StepDraws dr = PRE ? *pre : step_draws(a, pair, t);
+        box_muller(dr.normal, z0, z1, s_math);
+        const u32x4 pu = dr.accept;
+        unsigned long long m0, m1;
+        const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math, m0);
+        const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math, m1);
         if (MULTI) {
             // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
             if (v0) {
@@ -204,7 +229,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
             }
         } else {
             // wavefront-ballot accept mask -> one scalar popcount per chain slot
-            wave_acc += __popcll(__ballot(a0 && v0)) + __popcll(__ballot(a1 && v1));
+            wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
             if (COUNT) { cnt0 += a0 ? 1u : 0u; cnt1 += a1 ? 1u : 0u; }
         }
     }
@@ -265,6 +290,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             x_nxt = load_x(first);
             if (BETA) b_nxt = load_b(first);
         }
+        // SINGLE: the Philox draws of an iteration are formed one iteration ahead -- those of the first iteration
+        // right here, while the first load and the table loads are in flight (the arithmetic of ~80 VALU
+        // instructions per wave would otherwise start only after both have landed).
+        constexpr bool AHEAD = SINGLE;
+        StepDraws dr_nxt = {};
+        if (AHEAD && first < n_pairs) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
         stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load
         // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
         // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
@@ -280,8 +311,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             x_nxt = load_x(base + stride);
             if (BETA) b_nxt = load_b(base + stride);
             if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            pair_steps<POT, false, false, SINGLE>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math, sigma1, den1,
-                                          rden1, logc1, wave_acc, cnt0, cnt1);
+            const StepDraws dr = dr_nxt;
+            pair_steps<POT, false, false, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math,
+                                                          sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1, &dr);
+            // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
+            if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
             if (REDUCE) {
                 red[0] += potential<POT>(xv.x) + potential<POT>(xv.y);
                 red[1] += xv.x + xv.y;
@@ -297,8 +331,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             const bool v1 = v0 && (2 * p + 1 < a.n_chains);
             double2 xv = x_nxt;
             if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            pair_steps<POT, false, false, SINGLE>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1, s_tab, s_math,
-                                          sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1);
+            pair_steps<POT, false, false, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
+                                                          s_tab, s_math, sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1,
+                                                          &dr_nxt);
             // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
             if (v0) store_pair_writethrough(a.x + 2 * p, xv);
             if (REDUCE) {
