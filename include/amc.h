@@ -153,7 +153,8 @@ int  amc_get_estimator_step(amc_handle *h, uint64_t *t);
 int  amc_set_estimator_step(amc_handle *h, uint64_t t);
 
 /* callback_energy (particle_1d.jl:68-70) / callback_acceptance (metropolis.jl:319-321)
- * / position moments as LOCAL sums; deterministic two-pass device reduction.
+ * / position moments as LOCAL sums; deterministic (fixed summation order for a given grid): per-block
+ * partial sums on the device, column sums by the host (K <= 4) or by two further device passes.
  * out: AMC_RED_HEADER + K doubles.  Divide by the global chain count after the
  * cross-shard sum. */
 int  amc_reduce(amc_handle *h, double *out);

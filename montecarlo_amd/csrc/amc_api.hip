@@ -57,6 +57,8 @@ struct Rccl {
 
 }  // namespace
 
+static const int RED_HOST_STRIDE = 8;   // doubles per row of the host-summed partials (one 64-byte write)
+
 struct amc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -79,6 +81,10 @@ struct amc_handle {
     unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
     int n_slots = 0;
     double* d_partials = nullptr;
+    double* d_partials2 = nullptr;   // [32][n_vals + 1]: first level of the final reduce
+    double* h_partials = nullptr;    // pinned [n_slots][RED_HOST_STRIDE]: block partials the HOST sums (4 + K <= 8)
+    int red_rows = 0;                // rows of the reduction in flight
+    bool red_host = false;           // ... and whether they sit in h_partials
     double* d_out = nullptr;
     double* h_out = nullptr;    // pinned
     int red_blocks = 0;
@@ -329,8 +335,10 @@ int amc_create(const amc_config* cfg, amc_handle** out)
         if (per_block < (size_t)AMC_MAX_LEARN * 4) per_block = (size_t)AMC_MAX_LEARN * 4;
         AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * per_block * sizeof(double)));
     }
-    AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double)));
-    AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4) * sizeof(double), 0));
+    AMC_TRY(hipHostMalloc((void**)&h->h_partials, (size_t)h->n_cu * h->blocks_per_cu * RED_HOST_STRIDE * sizeof(double), 0));
+    AMC_TRY(hipMalloc(&h->d_partials2, (size_t)32 * (4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
+    AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
+    AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double), 0));
     AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * 5 * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
@@ -362,6 +370,8 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_totals);
     (void)hipFree(h->d_acc_slots);
     (void)hipFree(h->d_partials);
+    (void)hipFree(h->d_partials2);
+    if (h->h_partials) (void)hipHostFree(h->h_partials);
     (void)hipFree(h->d_out);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -481,7 +491,7 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
 }
 
 // n_sweeps x sweepstep MH steps in launches of at most 2^20 steps; when fuse_reduce is set (streamed form
-// only) the LAST launch also leaves the callback partial sums of the final state in d_partials[grid][5].
+// only) the LAST launch also leaves the callback partial sums of the final state in h_partials[grid][8].
 static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* grid_out)
 {
     AMC_HIP(hipSetDevice(h->device));
@@ -506,7 +516,8 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
         a.key0 = (uint32_t)h->seed;
         a.key1 = (uint32_t)(h->seed >> 32);
         a.beta = h->beta;
-        a.red_partials = h->d_partials;
+        a.red_partials = h->h_partials;
+        a.red_stride = RED_HOST_STRIDE;
         const bool last = remaining == chunk;
         int rc;
         if (fuse_reduce && last)
@@ -656,6 +667,30 @@ int amc_set_step(amc_handle* h, uint64_t t)
     return AMC_OK;
 }
 
+// Final passes of a reduction over d_partials[n_rows][n_vals] (+ the accepted slots): n_vals + 1 doubles to `out`
+// (device or pinned host memory).  Two levels above FINAL_SPLIT_ROWS rows, see reduce_final_kernel.
+static const int FINAL_BLOCKS = 32, FINAL_SPLIT_ROWS = 256;
+static int launch_final_reduce(amc_handle* h, int n_rows, int n_vals, double* out, const unsigned long long* slots,
+                               int n_slots)
+{
+    if (n_rows <= FINAL_SPLIT_ROWS) {
+        hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, n_rows, n_vals,
+                           out, slots, n_slots, n_rows, n_slots);
+        AMC_HIP(hipGetLastError());
+        return AMC_OK;
+    }
+    const int rpb = (n_rows + FINAL_BLOCKS - 1) / FINAL_BLOCKS, spb = (n_slots + FINAL_BLOCKS - 1) / FINAL_BLOCKS;
+    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(FINAL_BLOCKS), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, n_rows,
+                       n_vals, h->d_partials2, slots, n_slots, rpb, spb);
+    AMC_HIP(hipGetLastError());
+    // second level: the 32 rows of n_vals + 1 columns; its own slot column (index n_vals + 1) is written as 0 and
+    // lies past what any caller reads
+    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials2, FINAL_BLOCKS,
+                       n_vals + 1, out, (const unsigned long long*)nullptr, 0, FINAL_BLOCKS, 0);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
 int amc_reduce_begin(amc_handle* h)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_reduce_begin: NULL handle");
@@ -663,20 +698,31 @@ int amc_reduce_begin(amc_handle* h)
     AMC_HIP(hipSetDevice(h->device));
     const int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
     const int n_vals = 4 + h->K;
+    // Few columns (K <= 4): the blocks store their partial rows straight into pinned, device-mapped host memory
+    // and the HOST forms the column sums in amc_reduce_end -- no final-pass launches (~5 us each even when empty)
+    // and no D2H copy in stream order (which would hold the next sweep back for a copy-engine round trip).
+    const bool host = n_vals <= RED_HOST_STRIDE;
+    double* rows = host ? h->h_partials : h->d_partials;
+    const int stride = host ? RED_HOST_STRIDE : n_vals;
+    const unsigned long long* slots = (host && ratio_mode == 0) ? h->d_acc_slots : nullptr;
     if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
-                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, h->d_partials);
+                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
+                           h->n_slots);
     else
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
-                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, h->d_partials);
+                           h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
+                           h->n_slots);
     AMC_HIP(hipGetLastError());
-    // pass 2 also folds the per-block accepted slots (K == 1) into one exact integer-valued double
-    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, h->red_blocks,
-                       n_vals, h->d_out, h->d_acc_slots, h->n_slots);
-    AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)(n_vals + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!host) {
+        // many columns: device final passes, result (n_vals + 1 doubles) stored into the pinned result buffer
+        const int rc = launch_final_reduce(h, h->red_blocks, n_vals, h->h_out, h->d_acc_slots, h->n_slots);
+        if (rc != AMC_OK) return rc;
+    }
     AMC_HIP(hipEventRecord(h->ev_red, h->stream));
     h->red_pending = true;
+    h->red_host = host;
+    h->red_rows = h->red_blocks;
     h->red_t_counted = h->t_counted;
     return AMC_OK;
 }
@@ -686,20 +732,17 @@ int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
     if (h->red_pending) return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
-    if (h->K > 1 || h->counters) {          // no fused form: sweep, then the ordinary two-pass reduction
+    if (h->K > 1 || h->counters) {          // no fused form: sweep, then the ordinary reduction pass
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
     int grid = 0;
-    const int rc = sweep_impl(h, n_sweeps, true, &grid);
+    const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote h_partials[grid][8]
     if (rc != AMC_OK) return rc;
-    const int n_vals = 4 + h->K;            // = 5: the partials rows the fused kernel wrote
-    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, n_vals,
-                       h->d_out, h->d_acc_slots, h->n_slots);
-    AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)(n_vals + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipEventRecord(h->ev_red, h->stream));
     h->red_pending = true;
+    h->red_host = true;
+    h->red_rows = grid;
     h->red_t_counted = h->t_counted;
     return AMC_OK;
 }
@@ -712,11 +755,24 @@ int amc_reduce_end(amc_handle* h, double* out)
     AMC_HIP(hipEventSynchronize(h->ev_red));     // waits for the reduction only, not for work queued after it
     h->red_pending = false;
     const int n_vals = 4 + h->K;
-    for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
+    double slot_total;
+    if (h->red_host) {
+        // fixed order: rows 0, 1, 2, ... per column (a function of the grid only)
+        double acc[RED_HOST_STRIDE] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < h->red_rows; ++r) {
+            const double* row = h->h_partials + (size_t)r * RED_HOST_STRIDE;
+            for (int i = 0; i < n_vals; ++i) acc[i] += row[i];
+        }
+        for (int i = 0; i < n_vals; ++i) out[i] = acc[i];
+        slot_total = acc[4];                     // K == 1, pool-wide counter: exact (integers below 2^53)
+    } else {
+        for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
+        slot_total = h->h_out[n_vals];
+    }
     if (h->K == 1 && !h->counters) {
         // K == 1 without per-chain counters: total_calls is the same on every chain, so
         // sum_c accepted_c/total == (sum_c accepted_c)/total up to rounding
-        out[AMC_RED_SUM_RATIO0] = h->h_out[n_vals] / (double)h->red_t_counted;
+        out[AMC_RED_SUM_RATIO0] = slot_total / (double)h->red_t_counted;
     }
     return AMC_OK;
 }
@@ -789,9 +845,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
                                                                : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
     if (rc != AMC_OK) return rc;
     // partials layout [grid][nl][4]: reduce the first n_learn*4 of every nl*4 row
-    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, grid, nl * 4,
-                       h->d_out, (const unsigned long long*)nullptr, 0);
-    AMC_HIP(hipGetLastError());
+    { const int rc2 = launch_final_reduce(h, grid, nl * 4, h->d_out, nullptr, 0); if (rc2 != AMC_OK) return rc2; }
     h->t_est += 1;
     *nl_out = nl;
     return AMC_OK;

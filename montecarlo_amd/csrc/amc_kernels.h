@@ -155,7 +155,9 @@ struct SweepArgs {
     int32_t n_moves;
     uint32_t key0, key1;
     double beta;
-    double* red_partials;         // REDUCE launches: [grid][5] block partials of (sum e, sum x, sum x^2, count, 0)
+    double* red_partials;         // REDUCE launches: [grid][red_stride] block partials of (sum e, sum x, sum x^2, count,
+                                  // this block's pool-wide accepted slot after the launch), pinned host memory
+    int32_t red_stride;
 };
 
 // The two Philox results of one MH step of a pair (normal draw, accept draw): pure functions of
@@ -341,11 +343,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 if (v1) { red[0] += potential<POT>(xv.y); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
             }
         }
-        if (REDUCE) {
-            double* out = a.red_partials + (int64_t)blockIdx.x * 5;
-            block_sum_store<4>(red, out);
-            if (threadIdx.x == 0) out[4] = 0.0;      // ratio column: the host divides the pool-wide slot total
-        }
+        if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
     } else {
         // ---- general form (per-chain counters and/or K > 1): compiler-managed memory operations
         auto load_x = [&](int64_t b) -> double2 {
@@ -423,8 +421,16 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         if (threadIdx.x == 0) {
             unsigned long long t = 0;
             for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc[w];
-            // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
-            if (t != 0) __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (REDUCE) {
+                // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
+                // value after this launch (exact in a double below 2^53); the rows are summed by the host
+                const unsigned long long now =
+                    __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
+                a.red_partials[(int64_t)blockIdx.x * a.red_stride + 4] = (double)now;
+            } else if (t != 0) {
+                // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
+                __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -546,11 +552,14 @@ __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds i
 //   count, and per move sum_c accepted/total (callback_acceptance metropolis.jl:319-321).
 // ratio_mode: 0 = none (K == 1 without per-chain counters; host uses the pool-wide total),
 //             1 = K == 1 with per-chain acc (total = t_steps for every chain), 2 = K > 1.
+// Rows are p_stride doubles apart (device buffer, or pinned host memory when the host forms the column sums).
+// slots != nullptr (ratio_mode 0): column 4 of row b = sum of the accepted slots b, b + grid, ... (exact).
 template <int POT>
 __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, const uint32_t* acc,
                                                             const uint32_t* tot, int64_t n_chains,
                                                             int64_t m_stride, int n_moves, int ratio_mode,
-                                                            uint64_t t_steps, double* partials)
+                                                            uint64_t t_steps, double* partials, int p_stride,
+                                                            const unsigned long long* slots, int n_slots)
 {
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
         v[2] += xc * xc;
         v[3] += 1.0;
     }
-    double* out = partials + (int64_t)blockIdx.x * (4 + n_moves);
+    double* out = partials + (int64_t)blockIdx.x * p_stride;
     block_sum_store<4>(v, out);
     if (ratio_mode != 0) {
         for (int k = 0; k < n_moves; ++k) {
@@ -575,32 +584,72 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
         }
     } else if (threadIdx.x == 0) {
         for (int k = 0; k < n_moves; ++k) out[4 + k] = 0.0;
+        if (slots) {
+            unsigned long long a = 0;
+            for (int s = blockIdx.x; s < n_slots; s += gridDim.x) a += slots[s];
+            out[4] = (double)a;
+        }
     }
 }
 
-// K2b: pass 2, one block: fixed-order sum of the per-block partials; out[n_vals] receives the sum
-// of the per-block accepted slots (exact: integers below 2^53) when slots != nullptr.
-__global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_blocks, int n_vals,
+// K2b: final passes of a reduction: fixed-order column sums of the per-block partials [n_rows][n_vals].
+// Block g sums rows [g*rows_per_block, (g+1)*rows_per_block) and writes row g of `out` ([gridDim][n_vals + 1]);
+// column n_vals receives the sum of block g's slice of the per-block accepted slots (exact: integers below 2^53;
+// 0 when slots == nullptr).  Launched twice when there are many rows -- 32 blocks, then one block over their 32
+// rows with the slot column as an ordinary column -- because one CU alone streams 2048 rows from far memory in
+// ~10 us; once (gridDim = 1) otherwise.  Either way the order of additions depends on the row count only.
+__global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_rows, int n_vals,
                                                                   double* out, const unsigned long long* slots,
-                                                                  int n_slots)
+                                                                  int n_slots, int rows_per_block, int slots_per_block)
 {
-    for (int q = 0; q < n_vals; ++q) {
-        double v[1] = {0.0};
-        for (int b = threadIdx.x; b < n_blocks; b += AMC_BLOCK) v[0] += partials[(int64_t)b * n_vals + q];
-        block_sum_store<1>(v, out + q);
-    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int n_blocks = (n_rows - r0 < rows_per_block) ? ((n_rows - r0 > 0) ? n_rows - r0 : 0) : rows_per_block;
+    partials += (int64_t)r0 * n_vals;
+    out += (int64_t)blockIdx.x * (n_vals + 1);
+    // All loads of a chunk of <= 8 columns (and of the slots) are issued before the first sum is formed.  Per
+    // column: thread t adds rows t, t+256, ... in turn, then the wave shuffle tree, then waves 0..3.
+    unsigned long long t = 0;
     if (slots) {
-        __shared__ unsigned long long s_u[AMC_BLOCK / 64];
-        unsigned long long t = 0;
-        for (int b = threadIdx.x; b < n_slots; b += AMC_BLOCK) t += slots[b];
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-        if ((threadIdx.x & 63) == 0) s_u[threadIdx.x >> 6] = t;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long a = 0;
-            for (int w = 0; w < AMC_BLOCK / 64; ++w) a += s_u[w];
-            out[n_vals] = (double)a;
+        const int s0 = blockIdx.x * slots_per_block;
+        const int s1 = (s0 + slots_per_block < n_slots) ? s0 + slots_per_block : n_slots;
+        for (int b = s0 + threadIdx.x; b < s1; b += AMC_BLOCK) t += slots[b];
+    }
+    for (int q0 = 0; q0 < n_vals; q0 += 8) {
+        const int nq = (n_vals - q0 < 8) ? n_vals - q0 : 8;
+        double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 4 * AMC_BLOCK) {
+            // four rows per trip; every load is unconditional (index clamped, value masked) so that all 32 are in
+            // flight together
+            double w[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = b0 + j * AMC_BLOCK;
+                const bool row_ok = b < n_blocks;
+                const double* row = partials + (int64_t)(row_ok ? b : 0) * n_vals + q0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double x = row[(i < nq) ? i : 0];
+                    w[j][i] = (row_ok && i < nq) ? x : 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += w[j][i];
         }
+        double r[8];
+        block_sum_store<8>(v, r);          // thread 0 holds the sums in r
+        if (threadIdx.x == 0)
+            for (int i = 0; i < nq; ++i) out[q0 + i] = r[i];
+    }
+    __shared__ unsigned long long s_u[AMC_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) s_u[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        for (int w = 0; w < AMC_BLOCK / 64; ++w) a += s_u[w];
+        out[n_vals] = (double)a;
     }
 }
 
