@@ -165,6 +165,14 @@ def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
     e.close()
 
 
+def test_wide_reduction_rows_use_device_final_passes(gpu, oracle):
+    """K = 7 gives 11 columns per partial row (> 8: the host-summed 64-byte rows do not apply) and 200 001 chains
+    give 782 rows (> 256): the two-level device final pass of amc_reduce."""
+    e, o = run_pair(gpu, oracle, 200_001, 7, "double_well", 4)
+    assert_same(e, o)
+    e.close()
+
+
 def test_sweep_bit_exact_beyond_one_grid(gpu, oracle):
     """More pairs than 2048 x 256 threads: the grid-stride path, sweeps x M = 3.6e6 updates."""
     e, o = run_pair(gpu, oracle, 1_200_001, 1, "harmonic", 3)
