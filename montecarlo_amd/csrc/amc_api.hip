@@ -76,6 +76,9 @@ struct amc_handle {
     double* d_beta = nullptr;
     uint32_t* d_acc = nullptr;
     uint32_t* d_tot = nullptr;
+    uint8_t* d_log = nullptr;   // [log_depth][M_pad] step log: (move << 1) | accepted per chain and MH step
+    int log_depth = 32;         // rows of the step log (env AMC_LOG_DEPTH, 1..256)
+    int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
     double* d_ptab = nullptr;
     unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
     unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
@@ -132,7 +135,7 @@ template <int POT, bool SINGLE>
 int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     const bool multi = h->K > 1;
-    if (multi) {
+    if (multi) {          // K > 1 always keeps per-chain counters (callback_acceptance is a mean of per-chain ratios)
         if (h->beta_arr)
             hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
@@ -149,6 +152,28 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
             hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     }
     AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+// Adds the pending rows of the step log into the per-chain counters (on the stream).  Everything that reads or
+// replaces d_acc / d_tot calls this first.
+int fold_log(amc_handle* h)
+{
+    if (!h->d_log || h->log_fill == 0) return AMC_OK;
+    const int grid = grid_for(h, (h->M + 3) / 4);
+#define AMC_FOLD(KS)                                                                                                  \
+    hipLaunchKernelGGL(amc::fold_log_kernel<KS>, dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, h->d_log, \
+                       h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K)
+    switch (h->K) {
+    case 1: AMC_FOLD(1); break;
+    case 2: AMC_FOLD(2); break;
+    case 3: AMC_FOLD(3); break;
+    case 4: AMC_FOLD(4); break;
+    default: AMC_FOLD(0); break;
+    }
+#undef AMC_FOLD
+    AMC_HIP(hipGetLastError());
+    h->log_fill = 0;
     return AMC_OK;
 }
 
@@ -283,7 +308,7 @@ int amc_create(const amc_config* cfg, amc_handle** out)
         if (v >= 1 && v <= 64) h->blocks_per_cu = v;
     }
     h->M = cfg->n_chains;
-    h->M_pad = ((cfg->n_chains + 1) & ~(int64_t)1) + AMC_PAD_DOUBLES;   // even + padding: unclamped 16-B tail loads stay in bounds
+    h->M_pad = ((cfg->n_chains + 3) & ~(int64_t)3) + AMC_PAD_DOUBLES;   // multiple of 4 + padding: unclamped 16-B tail loads stay in bounds
     h->offset = cfg->chain_offset;
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;
@@ -321,6 +346,12 @@ int amc_create(const amc_config* cfg, amc_handle** out)
             AMC_TRY(hipMalloc(&h->d_tot, n * sizeof(uint32_t)));
             AMC_TRY(hipMemsetAsync(h->d_tot, 0, n * sizeof(uint32_t), h->stream));
         }
+        if (const char* env = std::getenv("AMC_LOG_DEPTH")) {     // tuning knob, 1..256
+            const int v = std::atoi(env);
+            if (v >= 1 && v <= 256) h->log_depth = v;
+        }
+        AMC_TRY(hipMalloc(&h->d_log, (size_t)h->log_depth * (size_t)h->M_pad));
+        AMC_TRY(hipMemsetAsync(h->d_log, 0, (size_t)h->log_depth * (size_t)h->M_pad, h->stream));
     }
     AMC_TRY(hipMalloc(&h->d_ptab, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_ptab, 0, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double), h->stream));
@@ -366,6 +397,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_beta);
     (void)hipFree(h->d_acc);
     (void)hipFree(h->d_tot);
+    (void)hipFree(h->d_log);
     (void)hipFree(h->d_ptab);
     (void)hipFree(h->d_totals);
     (void)hipFree(h->d_acc_slots);
@@ -442,6 +474,7 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
     if (!h->counters)
         return fail(AMC_ERR_STATE, "amc_download_counters: handle was created with per_chain_counters = 0");
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     std::vector<uint32_t> buf((size_t)h->M);
     for (int k = 0; k < h->K; ++k) {
         if (accepted) {
@@ -469,6 +502,7 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_counter_totals: NULL handle");
     AMC_HIP(hipSetDevice(h->device));
     unsigned long long host[2 * AMC_MAX_MOVES];
+    { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     if (h->K > 1) {
         AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
         hipLaunchKernelGGL(amc::counter_totals_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, h->d_acc,
@@ -499,12 +533,19 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
     const int grid = grid_for(h, (h->M + 1) / 2);
     if (grid_out) *grid_out = grid;
     while (remaining > 0) {
-        const int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
+        int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
+        if (h->d_log) {      // per-chain counters: one log row per MH step; a full log is folded before it is reused
+            if (h->log_fill == h->log_depth) {
+                const int rc = fold_log(h);
+                if (rc != AMC_OK) return rc;
+            }
+            if (chunk > h->log_depth - h->log_fill) chunk = h->log_depth - h->log_fill;
+        }
         amc::SweepArgs a;
         a.x = h->d_x;
         a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
-        a.acc = h->d_acc;
-        a.tot = h->d_tot;
+        a.log = h->d_log;
+        a.log_pos = h->log_fill;
         a.ptab = h->d_ptab;
         a.acc_total = h->d_acc_slots;
         a.n_chains = h->M;
@@ -529,6 +570,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
         if (rc != AMC_OK) return rc;
         h->t += (uint64_t)chunk;
         h->t_counted += (uint64_t)chunk;
+        if (h->d_log) h->log_fill += chunk;
         remaining -= chunk;
     }
     return AMC_OK;
@@ -550,6 +592,7 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
                                    "(use amc_set_counter_totals)");
     if (h->K > 1 && !total) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: total is required when K > 1");
     AMC_HIP(hipSetDevice(h->device));
+    h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
     std::vector<uint32_t> buf((size_t)h->M);
     unsigned long long acc_sum = 0;
     for (int k = 0; k < h->K; ++k) {
@@ -698,6 +741,7 @@ int amc_reduce_begin(amc_handle* h)
     AMC_HIP(hipSetDevice(h->device));
     const int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
     const int n_vals = 4 + h->K;
+    if (ratio_mode != 0) { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     // Few columns (K <= 4): the blocks store their partial rows straight into pinned, device-mapped host memory
     // and the HOST forms the column sums in amc_reduce_end -- no final-pass launches (~5 us each even when empty)
     // and no D2H copy in stream order (which would hold the next sweep back for a copy-engine round trip).

@@ -143,8 +143,7 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
 struct SweepArgs {
     double* x;
     const double* beta_arr;       // nullptr unless per-chain beta
-    uint32_t* acc;                // [K][m_stride] or nullptr
-    uint32_t* tot;                // [K][m_stride] or nullptr (K > 1 only)
+    uint8_t* log;                 // [log_depth][m_stride] per-chain step log (LOG launches), else nullptr
     const double* ptab;           // [PT_ROWS][AMC_MAX_MOVES]
     unsigned long long* acc_total;  // pool-wide accepted count (K == 1)
     int64_t n_chains;             // local chains
@@ -158,29 +157,45 @@ struct SweepArgs {
     double* red_partials;         // REDUCE launches: [grid][red_stride] block partials of (sum e, sum x, sum x^2, count,
                                   // this block's pool-wide accepted slot after the launch), pinned host memory
     int32_t red_stride;
+    int32_t log_pos;              // row of the step log the first step of this launch writes
 };
 
-// The two Philox results of one MH step of a pair (normal draw, accept draw): pure functions of
-// (seed, pair, step), so they can be formed before the pair's state has arrived from memory.
+// The Philox results of one MH step of a pair (normal draw, accept draw, and for K > 1 the move pick): pure
+// functions of (seed, pair, step), so they can be formed before the pair's state has arrived from memory.
 struct StepDraws {
-    u32x4 normal, accept;
+    u32x4 normal, accept, pick;
 };
 
+template <bool MULTI>
 __device__ __forceinline__ StepDraws step_draws(const SweepArgs& a, uint64_t pair, uint64_t t)
 {
     StepDraws d;
     d.normal = philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1);
     d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
+    if (MULTI) d.pick = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS), a.key0, a.key1);
+    else d.pick = u32x4{0u, 0u, 0u, 0u};
     return d;
+}
+
+// Per-chain Move.accepted_calls / total_calls (metropolis.jl:208-209) are not read-modify-written by the sweep:
+// every MH step appends ONE byte per chain, (move index << 1) | accepted, to a step log (2 bytes per lane, 128
+// contiguous bytes per wave), and fold_log_kernel adds a batch of log rows into the u32 counters when somebody
+// asks for them or the log is full.  The counters themselves cost 16 K bytes of HBM traffic per chain and pass
+// (every line of every move's array is touched); the log costs 1.
+__device__ __forceinline__ void store_log_pair(const SweepArgs& a, int row, int64_t p, uint32_t word)
+{
+    *reinterpret_cast<uint16_t*>(a.log + (int64_t)row * a.m_stride + 2 * p) = (uint16_t)word;
 }
 
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
 // PRE: the draws of the (single) step were formed ahead by the caller and come in `pre`.
-template <int POT, bool MULTI, bool COUNT, bool SINGLE, bool PRE = false>
+// LOG: the step-log word of the pair; SINGLE launches hand it back in `log_word` (the caller stores it together
+// with x), multi-step launches store one word per step right away.
+template <int POT, bool MULTI, bool LOG, bool SINGLE, bool PRE = false>
 __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, double b0, double b1, uint64_t pair,
                                            int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
                                            double sigma1, double den1, double rden1, double logc1,
-                                           unsigned long long& wave_acc, uint32_t& cnt0, uint32_t& cnt1,
+                                           unsigned long long& wave_acc, uint32_t& log_word,
                                            const StepDraws* pre = nullptr)
 {
     static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
@@ -188,14 +203,14 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
     const int n_steps = SINGLE ? 1 : a.n_steps;      // SINGLE: the sweepstep = 1 launch, straight-line code
     for (int s = 0; s < n_steps; ++s) {
         const uint64_t t = a.t0 + (uint64_t)s;
+        const StepDraws dr = PRE ? *pre : step_draws<MULTI>(a, pair, t);
         double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
         double rd0 = rden1, rd1 = rden1;
         int k0 = 0, k1 = 0;
         if (MULTI) {
             // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
             // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
-            const u32x4 pk = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS), a.key0, a.key1);
-            const double r0 = uniform32(pk.x), r1 = uniform32(pk.y);
+            const double r0 = uniform32(dr.pick.x), r1 = uniform32(dr.pick.y);
             for (int i = 0; i < K - 1; ++i) {
                 const double c = s_tab[3 * AMC_MAX_MOVES + i];
                 k0 += (c <= r0) ? 1 : 0;
@@ -205,48 +220,34 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
             sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
             rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
         }
-        // K > 1: the selected moves' counters are fetched NOW, right after the pick, so their latency hides
-        // behind the Box-Muller / exp arithmetic below (loaded at the point of use they were waited for at once).
-        uint32_t ca0 = 0, ct0 = 0, ca1 = 0, ct1 = 0;
-        if (MULTI) {
-            if (v0) { ca0 = a.acc[(int64_t)k0 * a.m_stride + 2 * p]; ct0 = a.tot[(int64_t)k0 * a.m_stride + 2 * p]; }
-            if (v1) { ca1 = a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1]; ct1 = a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1]; }
-        }
         double z0, z1;
-        const StepDraws dr = PRE ? *pre : step_draws(a, pair, t);
         box_muller(dr.normal, z0, z1, s_math);
         const u32x4 pu = dr.accept;
         unsigned long long m0, m1;
         const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math, m0);
         const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math, m1);
-        if (MULTI) {
-            // Move.accepted_calls += ...; Move.total_calls += 1  (metropolis.jl:208-209)
-            if (v0) {
-                a.acc[(int64_t)k0 * a.m_stride + 2 * p] = ca0 + (a0 ? 1u : 0u);
-                a.tot[(int64_t)k0 * a.m_stride + 2 * p] = ct0 + 1u;
-            }
-            if (v1) {
-                a.acc[(int64_t)k1 * a.m_stride + 2 * p + 1] = ca1 + (a1 ? 1u : 0u);
-                a.tot[(int64_t)k1 * a.m_stride + 2 * p + 1] = ct1 + 1u;
-            }
-        } else {
-            // wavefront-ballot accept mask -> one scalar popcount per chain slot
-            wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
-            if (COUNT) { cnt0 += a0 ? 1u : 0u; cnt1 += a1 ? 1u : 0u; }
+        // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
+        if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
+        if (LOG) {
+            // Move.accepted_calls += accepted; Move.total_calls += 1 (metropolis.jl:208-209), deferred: see above
+            log_word = ((uint32_t)k0 << 1 | (a0 ? 1u : 0u)) | (((uint32_t)k1 << 1 | (a1 ? 1u : 0u)) << 8);
+            if (!SINGLE && v0) store_log_pair(a, a.log_pos + s, p, log_word);
         }
     }
 }
 
 // K1: the sweep.  make_step!(::Metropolis) metropolis.jl:302-309 -> mc_sweep! :203-212.
-// MULTI: K > 1 (categorical move pick, parameter table staged in LDS, per-chain counters)
-// COUNT: keep per-chain accepted counter (K == 1)      BETA: per-chain beta array
+// MULTI: K > 1 (categorical move pick, parameter table staged in LDS)
+// LOG: per-chain counters are kept (always when K > 1): one step-log byte per chain and MH step
+// BETA: per-chain beta array
 // SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
-// REDUCE (streamed form only): also leave the callback sums of the state AFTER the sweep in red_partials, so a
-//         sweep that is followed by callback_energy / callback_acceptance needs no second pass over x
-template <int POT, bool MULTI, bool COUNT, bool BETA, bool SINGLE, bool REDUCE = false>
+// REDUCE (K == 1, pool-wide counter only): also leave the callback sums of the state AFTER the sweep in
+//         red_partials, so a sweep that is followed by callback_energy / callback_acceptance needs no second pass
+template <int POT, bool MULTI, bool LOG, bool BETA, bool SINGLE, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
-    static_assert(!REDUCE || (!MULTI && !COUNT), "fused reduction exists for the streamed form only");
+    static_assert(!REDUCE || (!MULTI && !LOG), "the fused reduction has no per-chain acceptance ratios");
+    static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             s_tab[3 * AMC_MAX_MOVES + i] = a.ptab[PT_CUM * AMC_MAX_MOVES + i];
             s_tab[4 * AMC_MAX_MOVES + i] = a.ptab[PT_RDEN * AMC_MAX_MOVES + i];
         }
-        __syncthreads();
+        // visible to the block after the barrier that ends stage_math_tables below
     }
     // K == 1: wave-uniform scalars (s_load)
     const double sigma1 = a.ptab[PT_SIGMA * AMC_MAX_MOVES];
@@ -271,150 +272,92 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
     unsigned long long wave_acc = 0;   // wave-uniform
-    uint32_t cnt0 = 0, cnt1 = 0;
 
-    if (!MULTI && !COUNT) {
-        // ---- streamed form.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` at the top of a loop that carries a
-        // prefetched load across its back edge while stores are pending: vmcnt counts loads and stores together
-        // and the two kinds complete out of order with respect to each other, so no counted wait can name one
-        // load ("mixed pending events" in LLVM's SIInsertWaitcnts).  A store issued at the END of an iteration
-        // is therefore waited for immediately, at full write-through latency.  The schedule below issues BOTH
-        // memory operations at the START of an iteration -- the prefetch of iteration i+1 and the store of
-        // iteration i-1's result (kept one iteration in registers) -- so the vmcnt(0) at the top of the next
-        // iteration finds them a whole iteration (~2 us of other waves' arithmetic) old and does not stall.
-        // An iteration that has a successor covers 256 in-range pairs on every lane (stride >= 256), so the
-        // loop body runs without per-lane predicates; only the LAST iteration of a block can be ragged and is
-        // peeled.  Loads need no clamp either: the arrays carry AMC_PAD_DOUBLES of readable padding.
-        auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
-        auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
-        double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
-        if (first < n_pairs) {
-            x_nxt = load_x(first);
-            if (BETA) b_nxt = load_b(first);
+    // Memory schedule.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` at the top of a loop that carries a
+    // prefetched load across its back edge while stores are pending: vmcnt counts loads and stores together
+    // and the two kinds complete out of order with respect to each other, so no counted wait can name one
+    // load ("mixed pending events" in LLVM's SIInsertWaitcnts).  A store issued at the END of an iteration
+    // is therefore waited for immediately, at full write-through latency.  The schedule below issues ALL
+    // memory operations at the START of an iteration -- the prefetch of iteration i+1 and the stores of
+    // iteration i-1's results (x and the step-log word, kept one iteration in registers) -- so the vmcnt(0) at
+    // the end of the iteration finds them a whole iteration (~2 us of other waves' arithmetic) old.
+    // An iteration that has a successor covers 256 in-range pairs on every lane (stride >= 256), so the
+    // loop body runs without per-lane predicates; only the LAST iteration of a block can be ragged and is
+    // peeled.  Loads need no clamp either: the arrays carry AMC_PAD_DOUBLES of readable padding.
+    auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
+    auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
+    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    if (first < n_pairs) {
+        x_nxt = load_x(first);
+        if (BETA) b_nxt = load_b(first);
+    }
+    // SINGLE: the Philox draws of an iteration are formed one iteration ahead -- those of the first iteration
+    // right here, while the first load and the table loads are in flight (the arithmetic of ~80 VALU
+    // instructions per wave would otherwise start only after both have landed).
+    constexpr bool AHEAD = SINGLE;
+    StepDraws dr_nxt = {};
+    if (AHEAD && first < n_pairs) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load; ends in a barrier
+    // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
+    // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
+    // the prefetch issued a few dozen instructions earlier instead of leaving it a whole iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), other counters untouched
+    double2 x_done = {0.0, 0.0};
+    uint32_t lw_done = 0;
+    int64_t base_done = -1;                                  // block-uniform
+    int64_t base = first;
+    for (; base + stride < n_pairs; base += stride) {        // full iterations
+        const int64_t p = base + threadIdx.x;
+        double2 xv = x_nxt;
+        const double b0 = b_nxt.x, b1 = b_nxt.y;
+        x_nxt = load_x(base + stride);
+        if (BETA) b_nxt = load_b(base + stride);
+        if (base_done >= 0) {
+            store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
-        // SINGLE: the Philox draws of an iteration are formed one iteration ahead -- those of the first iteration
-        // right here, while the first load and the table loads are in flight (the arithmetic of ~80 VALU
-        // instructions per wave would otherwise start only after both have landed).
-        constexpr bool AHEAD = SINGLE;
-        StepDraws dr_nxt = {};
-        if (AHEAD && first < n_pairs) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
-        stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load
-        // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
-        // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
-        // the prefetch issued a few dozen instructions earlier instead of leaving it a whole iteration.
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), other counters untouched
-        double2 x_done = {0.0, 0.0};
-        int64_t base_done = -1;                                  // block-uniform
-        int64_t base = first;
-        for (; base + stride < n_pairs; base += stride) {        // full iterations
-            const int64_t p = base + threadIdx.x;
-            double2 xv = x_nxt;
-            const double b0 = b_nxt.x, b1 = b_nxt.y;
-            x_nxt = load_x(base + stride);
-            if (BETA) b_nxt = load_b(base + stride);
-            if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            const StepDraws dr = dr_nxt;
-            pair_steps<POT, false, false, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math,
-                                                          sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1, &dr);
-            // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
-            if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
-            if (REDUCE) {
-                red[0] += potential<POT>(xv.x) + potential<POT>(xv.y);
-                red[1] += xv.x + xv.y;
-                red[2] += xv.x * xv.x + xv.y * xv.y;
-                red[3] += 2.0;
-            }
-            x_done = xv;
-            base_done = base;
+        const StepDraws dr = dr_nxt;
+        uint32_t lw = 0;
+        pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math,
+                                                   sigma1, den1, rden1, logc1, wave_acc, lw, &dr);
+        // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
+        if (AHEAD) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(p + stride), a.t0);
+        if (REDUCE) {
+            red[0] += potential<POT>(xv.x) + potential<POT>(xv.y);
+            red[1] += xv.x + xv.y;
+            red[2] += xv.x * xv.x + xv.y * xv.y;
+            red[3] += 2.0;
         }
-        if (base < n_pairs) {                                    // last, possibly ragged, iteration
-            const int64_t p = base + threadIdx.x;
-            const bool v0 = p < n_pairs;
-            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-            double2 xv = x_nxt;
-            if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
-            pair_steps<POT, false, false, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
-                                                          s_tab, s_math, sigma1, den1, rden1, logc1, wave_acc, cnt0, cnt1,
-                                                          &dr_nxt);
-            // a lone last chain (odd n_chains) writes its whole pair: the odd slot is padding
-            if (v0) store_pair_writethrough(a.x + 2 * p, xv);
-            if (REDUCE) {
-                if (v0) { red[0] += potential<POT>(xv.x); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
-                if (v1) { red[0] += potential<POT>(xv.y); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
-            }
+        x_done = xv;
+        lw_done = lw;
+        base_done = base;
+    }
+    if (base < n_pairs) {                                    // last, possibly ragged, iteration
+        const int64_t p = base + threadIdx.x;
+        const bool v0 = p < n_pairs;
+        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+        double2 xv = x_nxt;
+        if (base_done >= 0) {
+            store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
-        if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
-    } else {
-        // ---- general form (per-chain counters and/or K > 1): compiler-managed memory operations
-        auto load_x = [&](int64_t b) -> double2 {
-            const int64_t q = b + threadIdx.x;
-            return *reinterpret_cast<const double2*>(a.x + 2 * ((q < n_pairs) ? q : 0));
-        };
-        auto load_b = [&](int64_t b) -> double2 {
-            const int64_t q = b + threadIdx.x;
-            return *reinterpret_cast<const double2*>(a.beta_arr + 2 * ((q < n_pairs) ? q : 0));
-        };
-        double2 x_n1 = {0.0, 0.0}, b_n1 = {a.beta, a.beta};
-        if (first < n_pairs) {
-            x_n1 = load_x(first);
-            if (BETA) b_n1 = load_b(first);
+        uint32_t lw = 0;
+        pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
+                                                   s_tab, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt);
+        // a lone last chain (odd n_chains) writes its whole pair (x and log): the odd slot is padding
+        if (v0) {
+            store_pair_writethrough(a.x + 2 * p, xv);
+            if (LOG && SINGLE) store_log_pair(a, a.log_pos, p, lw);
         }
-        stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once, see above
-        // same schedule as the streamed form: prefetch, this iteration's per-chain counters and the PREVIOUS
-        // iteration's stores are all issued at the start of the iteration
-        double2 x_done = {0.0, 0.0};
-        uint2 c_done = {0u, 0u};
-        int64_t p_done = -1;
-        bool pair_done = false;
-        for (int64_t base = first; base < n_pairs; base += stride) {
-            const int64_t p = base + threadIdx.x;
-            const bool v0 = p < n_pairs;
-            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-            const int64_t pc = v0 ? p : 0;   // clamp: out-of-range lanes recompute pair 0, never store
-            double2 xv = x_n1;
-            const double b0 = b_n1.x, b1 = b_n1.y;
-            if (base + stride < n_pairs) {   // software prefetch of the next grid-stride iteration
-                x_n1 = load_x(base + stride);
-                if (BETA) b_n1 = load_b(base + stride);
-            }
-            uint2 cv = {0u, 0u};
-            if (!MULTI && COUNT) {
-                if (v1) cv = *reinterpret_cast<const uint2*>(a.acc + 2 * p);
-                else if (v0) cv.x = a.acc[2 * p];
-            }
-            if (p_done >= 0) {               // results of the previous iteration
-                if (pair_done) {
-                    *reinterpret_cast<double2*>(a.x + 2 * p_done) = x_done;
-                    if (!MULTI && COUNT) *reinterpret_cast<uint2*>(a.acc + 2 * p_done) = c_done;
-                } else {
-                    a.x[2 * p_done] = x_done.x;
-                    if (!MULTI && COUNT) a.acc[2 * p_done] = c_done.x;
-                }
-            }
-            cnt0 = cnt1 = 0;
-            pair_steps<POT, MULTI, COUNT, SINGLE>(a, xv, b0, b1, a.pair0 + (uint64_t)pc, p, v0, v1, s_tab, s_math, sigma1, den1,
-                                          rden1, logc1, wave_acc, cnt0, cnt1);
-            x_done = xv;
-            c_done.x = cv.x + cnt0;
-            c_done.y = cv.y + cnt1;
-            p_done = v0 ? p : -1;
-            pair_done = v1;
-        }
-        if (p_done >= 0) {
-            if (pair_done) {
-                *reinterpret_cast<double2*>(a.x + 2 * p_done) = x_done;
-                if (!MULTI && COUNT) *reinterpret_cast<uint2*>(a.acc + 2 * p_done) = c_done;
-            } else {
-                a.x[2 * p_done] = x_done.x;
-                if (!MULTI && COUNT) a.acc[2 * p_done] = c_done.x;
-            }
+        if (REDUCE) {
+            if (v0) { red[0] += potential<POT>(xv.x); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
+            if (v1) { red[0] += potential<POT>(xv.y); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
         }
     }
+    if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
     if (!MULTI) {
         // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
         // address at kernel end serialise at ~13 ns each; one address per block does not contend).
-        // The final reduce pass sums the slots when a total is asked for.
         __shared__ unsigned long long s_acc[AMC_BLOCK / 64];
         if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = wave_acc;
         __syncthreads();
@@ -430,6 +373,65 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             } else if (t != 0) {
                 // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
                 __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// Adds `n_rows` rows of the step log into the per-chain u32 counters acc[K][m_stride] / tot[K][m_stride]
+// (tot == nullptr when K == 1: total_calls is the step count).  KS > 0: K == KS <= 4, four chains per thread with
+// the deltas in registers (u32 log loads, 16-byte counter accesses); KS == 0: any K, one chain per thread, one
+// read-modify-write per logged step.  Entries of the padding behind n_chains are never interpreted as moves.
+template <int KS>
+__global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, uint32_t* acc,
+                                                              uint32_t* tot, int64_t n_chains, int64_t m_stride,
+                                                              int n_moves)
+{
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    if (KS > 0) {
+        const int64_t n_quads = (n_chains + 3) >> 2;          // m_stride is a multiple of 4 with >= 4 of padding
+        for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
+            uint32_t da[KS > 0 ? KS : 1][4], dt[KS > 0 ? KS : 1][4];
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) da[k][j] = dt[k][j] = 0u;
+            for (int r = 0; r < n_rows; ++r) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(log + (int64_t)r * m_stride + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t b = (w >> (8 * j)) & 0xFFu;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        const uint32_t hit = ((b >> 1) == (uint32_t)k) ? 1u : 0u;
+                        dt[k][j] += hit;
+                        da[k][j] += hit & b;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                uint4* pa = reinterpret_cast<uint4*>(acc + (int64_t)k * m_stride + 4 * q);
+                uint4 va = *pa;
+                va.x += da[k][0]; va.y += da[k][1]; va.z += da[k][2]; va.w += da[k][3];
+                *pa = va;
+                if (tot) {
+                    uint4* pt = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + 4 * q);
+                    uint4 vt = *pt;
+                    vt.x += dt[k][0]; vt.y += dt[k][1]; vt.z += dt[k][2]; vt.w += dt[k][3];
+                    *pt = vt;
+                }
+            }
+        }
+    } else {
+        for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+            for (int r = 0; r < n_rows; ++r) {
+                const uint32_t b = log[(int64_t)r * m_stride + c];
+                const uint32_t k = b >> 1;
+                if (k < (uint32_t)n_moves) {
+                    acc[(int64_t)k * m_stride + c] += b & 1u;
+                    if (tot) tot[(int64_t)k * m_stride + c] += 1u;
+                }
             }
         }
     }
