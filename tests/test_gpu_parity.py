@@ -165,6 +165,20 @@ def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
     e.close()
 
 
+@pytest.mark.parametrize("depth", [1, 3, 256])
+@pytest.mark.parametrize("K,fused", [(1, False), (2, False), (2, True), (7, True)])
+def test_step_log_depths(gpu, oracle, monkeypatch, depth, K, fused):
+    """Per-chain counters go through the step log (one byte per chain and MH step) and are folded into acc/tot on
+    demand or when the log is full: every depth, single-step and multi-step launches, register and generic fold."""
+    monkeypatch.setenv("AMC_LOG_DEPTH", str(depth))
+    e, o = run_pair(gpu, oracle, 1001, K, "double_well", 11, sweepstep=2, fused=fused)
+    assert_same(e, o)
+    e.sweep(5)                    # counters were folded by the download above; the log starts over
+    o.make_steps(5)
+    assert_same(e, o)
+    e.close()
+
+
 def test_wide_reduction_rows_use_device_final_passes(gpu, oracle):
     """K = 7 gives 11 columns per partial row (> 8: the host-summed 64-byte rows do not apply) and 200 001 chains
     give 782 rows (> 256): the two-level device final pass of amc_reduce."""
