@@ -724,7 +724,6 @@ template <int POT, int NL, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
 {
     __shared__ double s_math[TAB_DOUBLES];
-    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     double g[NL][4];
@@ -733,15 +732,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[l][i] = 0.0;
 
-    for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
-        const bool v1 = 2 * p + 1 < a.n_chains;
-        double2 xv = *reinterpret_cast<const double2*>(a.x + 2 * p);
-        double b0 = a.beta, b1 = a.beta;
-        if (BETA) {
-            const double2 bv = *reinterpret_cast<const double2*>(a.beta_arr + 2 * p);
-            b0 = bv.x; b1 = bv.y;
-        }
-        const uint64_t pair = a.pair0 + (uint64_t)p;
+    // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
+    // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
+    // padded), the ragged last iteration peeled.
+    auto samples = [&](double2& xv, double b0, double b1, uint64_t pair, bool v1) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (l < a.n_learn) {
@@ -763,10 +757,39 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
                 }
             }
         }
-        if (v1) {
-            *reinterpret_cast<double2*>(a.x + 2 * p) = xv;
-        } else {
-            a.x[2 * p] = xv.x;
+    };
+    auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
+    auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
+    const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
+    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    if (first < n_pairs) {
+        x_nxt = load_x(first);
+        if (BETA) b_nxt = load_b(first);
+    }
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
+    double2 x_done = {0.0, 0.0};
+    int64_t base_done = -1;
+    int64_t base = first;
+    for (; base + stride < n_pairs; base += stride) {        // full iterations
+        double2 xv = x_nxt;
+        const double b0 = b_nxt.x, b1 = b_nxt.y;
+        x_nxt = load_x(base + stride);
+        if (BETA) b_nxt = load_b(base + stride);
+        if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true);
+        x_done = xv;
+        base_done = base;
+    }
+    if (base < n_pairs) {                                    // last, possibly ragged, iteration
+        const int64_t p = base + threadIdx.x;
+        const bool v0 = p < n_pairs;
+        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+        double2 xv = x_nxt;
+        if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        if (v0) {
+            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, v1);
+            store_pair_writethrough(a.x + 2 * p, xv);        // a lone last chain writes its whole pair: padding
         }
     }
 #pragma unroll
