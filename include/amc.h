@@ -56,7 +56,8 @@ typedef enum amc_status {
  * cross a C ABI, so the engine offers the particle_1d family by id. */
 typedef enum amc_potential {
     AMC_POTENTIAL_HARMONIC = 0,     /* x*x            (reference) */
-    AMC_POTENTIAL_DOUBLE_WELL = 1   /* (x*x - 1)^2    (BASELINE config 3) */
+    AMC_POTENTIAL_DOUBLE_WELL = 1,  /* (x*x - 1)^2    (BASELINE config 3) */
+    AMC_POTENTIAL_CUSTOM = 2        /* a C expression in x, compiled for gfx950 at run time: amc_create_custom */
 } amc_potential;
 
 typedef struct amc_handle amc_handle;
@@ -110,6 +111,19 @@ int  amc_device_count(int *count);
  * state x[M] (+ per-chain counters) in HBM.  State starts at x = 0. */
 int  amc_create(const amc_config *cfg, amc_handle **out);
 int  amc_destroy(amc_handle *h);
+
+/* The reference lets the driver script define `potential(x)` freely (a global Julia function,
+ * harmonic_oscillator/MC_harmonic_oscillator.jl:4; docs/src/man/system.md).  amc_create_custom is that hook on
+ * the GPU path: cfg->potential = AMC_POTENTIAL_CUSTOM and potential_expr is the body as ONE C expression in the
+ * double `x`, e.g. "x*x*x*x - 2.0*x*x + 0.25*x".  The sweep / reduction / estimator kernels are instantiated for
+ * it with hiprtc on first use (about 1 s per kernel form, cached per process).  Vocabulary with bit-reproducible
+ * results on any IEEE-754 host: + - * / (never contracted into fma), sqrt, fabs, fma, and the engine's own
+ * amc_exp / amc_log.  Other device math functions (exp, sin, pow ...) compile too but
+ * are only accurate to the device library's ulps.  Allowed characters: printable ASCII except # \ ; { } " ' ` $ @.
+ * A malformed expression fails here with the compiler's first diagnostics in amc_last_error(). */
+int  amc_create_custom(const amc_config *cfg, const char *potential_expr, amc_handle **out);
+/* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
+int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);
 
 /* initialise(): upload chains[c].x (and optionally a per-chain beta array,
  * Particle.beta).  e is not uploaded: e == potential(x) by construction

@@ -14,7 +14,7 @@ from .sharding import allreduce_sum, shard_range
 from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
                          build_schedule, julia_repr, run)
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
-from .system import Displacement, Move, ParticleChains, StandardGaussian, potential
+from .system import CustomPotential, Displacement, Move, ParticleChains, StandardGaussian, potential
 
 __all__ = [
     "AmcError", "HipEngine", "device_count",
@@ -25,5 +25,5 @@ __all__ = [
     "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
-    "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
+    "CustomPotential", "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
 ]

@@ -21,6 +21,7 @@ AMC_RED_HEADER = 4
 AMC_GD_STRIDE = 5
 
 POTENTIALS = {"harmonic": 0, "double_well": 1}
+AMC_POTENTIAL_CUSTOM = 2
 
 
 class AmcError(RuntimeError):
@@ -69,6 +70,8 @@ def load() -> C.CDLL:
         "amc_version": (C.c_int, []),
         "amc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "amc_create": (C.c_int, [C.POINTER(AmcConfig), C.POINTER(H)]),
+        "amc_create_custom": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.POINTER(H)]),
+        "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
         "amc_init_uniform": (C.c_int, [H, C.c_double, C.c_double]),
@@ -125,6 +128,14 @@ def device_count() -> int:
     return n.value if rc == 0 else 0
 
 
+def potential_check(expr: str) -> str:
+    """Compile-only check of a custom potential expression (no GPU needed); returns the compiler log, raises
+    AmcError with the first diagnostics when the expression does not compile."""
+    buf = C.create_string_buffer(8192)
+    _check(load().amc_potential_check(str(expr).encode(), buf, len(buf)))
+    return buf.value.decode(errors="replace")
+
+
 def _dptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -137,12 +148,14 @@ class HipEngine:
     """
 
     def __init__(self, *, n_chains: int, chain_offset: int = 0, n_chains_global: Optional[int] = None,
-                 potential: str = "harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
+                 potential="harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None):
         lib = load()
-        if potential not in POTENTIALS:
-            raise AmcError(f"unknown potential {potential!r}; the HIP engine offers {sorted(POTENTIALS)}")
+        expr = getattr(potential, "expr", None)        # system.CustomPotential: a C expression in x
+        if expr is None and potential not in POTENTIALS:
+            raise AmcError(f"unknown potential {potential!r}; the HIP engine offers {sorted(POTENTIALS)} "
+                           "and CustomPotential(expr)")
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
         self._sigma = (C.c_double * self.n_moves)(*[float(s) for s in sigma])
@@ -153,7 +166,7 @@ class HipEngine:
         cfg.n_chains = self.n_chains
         cfg.chain_offset = int(chain_offset)
         cfg.n_chains_global = int(n_chains_global if n_chains_global is not None else chain_offset + n_chains)
-        cfg.potential = POTENTIALS[potential]
+        cfg.potential = AMC_POTENTIAL_CUSTOM if expr is not None else POTENTIALS[potential]
         cfg.n_moves = self.n_moves
         cfg.beta = float(beta)
         cfg.sigma = self._sigma
@@ -164,7 +177,10 @@ class HipEngine:
         cfg.stream = stream
         self._lib = lib
         self._h = C.c_void_p()
-        _check(lib.amc_create(C.byref(cfg), C.byref(self._h)))
+        if expr is not None:
+            _check(lib.amc_create_custom(C.byref(cfg), str(expr).encode(), C.byref(self._h)))
+        else:
+            _check(lib.amc_create(C.byref(cfg), C.byref(self._h)))
 
     # -- lifetime --------------------------------------------------------------
     def close(self) -> None:

@@ -15,11 +15,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "amc_kernels.h"
+#include "amc_rtc_sources.gen.h"   // the three kernel headers as string literals (Makefile), for hiprtc
 
 namespace {
 
@@ -101,6 +104,9 @@ struct amc_handle {
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     Rccl rccl;
+    std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x)
+    std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
+    std::vector<hipModule_t> rtc_mods;
 };
 
 namespace {
@@ -238,6 +244,165 @@ int sum_acc_slots(amc_handle* h, unsigned long long* out)
 
 int nl_capacity(int n_learn) { return n_learn <= 1 ? 1 : n_learn <= 2 ? 2 : n_learn <= 4 ? 4 : 8; }
 
+// ---- kernels compiled at run time for a user-defined potential (AMC_POTENTIAL_CUSTOM) ---------------------------
+// `potential` is a free function of the driver script in the reference (MC_harmonic_oscillator.jl:4); here it is a
+// C expression in `x`, and the templates of amc_kernels.h are instantiated for it by hiprtc (resolved with dlopen,
+// like RCCL: no link-time dependency).  One hiprtc program per kernel instantiation, compiled on first use
+// (~1 s each) and cached per process by (expression, instantiation); modules are loaded per handle (= per device).
+struct Hiprtc {
+    void* lib = nullptr;
+    int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*AddNameExpression)(void*, const char*) = nullptr;
+    int (*CompileProgram)(void*, int, const char**) = nullptr;
+    int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+    int (*GetProgramLog)(void*, char*) = nullptr;
+    int (*GetCodeSize)(void*, size_t*) = nullptr;
+    int (*GetCode)(void*, char*) = nullptr;
+    int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
+    int (*DestroyProgram)(void**) = nullptr;
+};
+
+std::mutex g_rtc_mu;
+Hiprtc g_hiprtc;
+struct RtcCode { std::vector<char> code; std::string lowered; };
+std::map<std::string, RtcCode> g_rtc_code;        // key: expression '\n' instantiation
+
+int load_hiprtc(Hiprtc& r)
+{
+    if (r.lib) return AMC_OK;
+    const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return fail(AMC_ERR_HIP, "custom potential: cannot dlopen libhiprtc: %s", dlerror());
+#define AMC_RTC_SYM(field, name)                                                        \
+    r.field = (decltype(r.field))dlsym(r.lib, name);                                    \
+    if (!r.field) { r.lib = nullptr; return fail(AMC_ERR_HIP, "libhiprtc is missing %s", name); }
+    AMC_RTC_SYM(CreateProgram, "hiprtcCreateProgram");
+    AMC_RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
+    AMC_RTC_SYM(CompileProgram, "hiprtcCompileProgram");
+    AMC_RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+    AMC_RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
+    AMC_RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
+    AMC_RTC_SYM(GetCode, "hiprtcGetCode");
+    AMC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
+    AMC_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+#undef AMC_RTC_SYM
+    return AMC_OK;
+}
+
+// The expression becomes the body of a function-like macro: keep it to one line of ordinary expression text.
+int validate_potential_expr(const char* expr)
+{
+    if (!expr) return fail(AMC_ERR_BAD_ARG, "custom potential: expression is NULL");
+    const size_t n = std::strlen(expr);
+    if (n == 0 || n > 4000) return fail(AMC_ERR_BAD_ARG, "custom potential: expression must have 1..4000 characters");
+    bool has_x = false;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)expr[i];
+        if (c < 0x20 || c > 0x7e || c == '#' || c == '\\' || c == ';' || c == '{' || c == '}' || c == '"' || c == '\'' ||
+            c == '`' || c == '$' || c == '@')
+            return fail(AMC_ERR_BAD_ARG, "custom potential: character 0x%02x at offset %zu is not allowed in the expression", c, i);
+        const bool ident_before = i > 0 && (std::isalnum((unsigned char)expr[i - 1]) || expr[i - 1] == '_');
+        const bool ident_after = i + 1 < n && (std::isalnum((unsigned char)expr[i + 1]) || expr[i + 1] == '_');
+        if (c == 'x' && !ident_before && !ident_after) has_x = true;
+    }
+    if (!has_x) return fail(AMC_ERR_BAD_ARG, "custom potential: the expression does not mention x");
+    return AMC_OK;
+}
+
+// Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
+// Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
+int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode** out, std::string* log_out)
+{
+    std::lock_guard<std::mutex> lock(g_rtc_mu);
+    const std::string key = expr + "\n" + inst;
+    auto it = g_rtc_code.find(key);
+    if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
+    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
+    const std::string src = "#define AMC_USER_POTENTIAL(x) (" + expr + ")\n#include \"amc_kernels.h\"\n";
+    const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES};
+    const char* names[] = {"amc_kernels.h", "amc_math.h", "amc_tables.h"};
+    void* prog = nullptr;
+    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", 3, headers, names);
+    if (e != 0) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", e);
+    e = g_hiprtc.AddNameExpression(prog, inst.c_str());
+    if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
+    // the flags of the offline build (Makefile): only the explicit fma()s may fuse
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    e = g_hiprtc.CompileProgram(prog, 5, opts);
+    std::string log;
+    size_t ls = 0;
+    if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+        log.resize(ls);
+        g_hiprtc.GetProgramLog(prog, &log[0]);
+    }
+    if (log_out) *log_out = log;
+    if (e != 0) {
+        g_hiprtc.DestroyProgram(&prog);
+        // the first diagnostic is what the user needs; keep the message bounded
+        return fail(AMC_ERR_BAD_ARG, "custom potential does not compile: %.400s", log.empty() ? "(no log)" : log.c_str());
+    }
+    RtcCode rc;
+    size_t cs = 0;
+    const char* lowered = nullptr;
+    if (g_hiprtc.GetCodeSize(prog, &cs) != 0 || cs == 0 || g_hiprtc.GetLoweredName(prog, inst.c_str(), &lowered) != 0 || !lowered) {
+        g_hiprtc.DestroyProgram(&prog);
+        return fail(AMC_ERR_HIP, "hiprtc produced no code for %s", inst.c_str());
+    }
+    rc.code.resize(cs);
+    g_hiprtc.GetCode(prog, rc.code.data());
+    rc.lowered = lowered;
+    g_hiprtc.DestroyProgram(&prog);
+    *out = &g_rtc_code.emplace(key, std::move(rc)).first->second;
+    return AMC_OK;
+}
+
+// The function of instantiation `inst` for this handle's expression, loaded on this handle's device.
+int rtc_function(amc_handle* h, const std::string& inst, hipFunction_t* fn)
+{
+    auto it = h->rtc_fn.find(inst);
+    if (it != h->rtc_fn.end()) { *fn = it->second; return AMC_OK; }
+    const RtcCode* code = nullptr;
+    { const int rc = rtc_compile(h->pot_expr, inst, &code, nullptr); if (rc != AMC_OK) return rc; }
+    hipModule_t mod = nullptr;
+    AMC_HIP(hipModuleLoadData(&mod, code->code.data()));
+    h->rtc_mods.push_back(mod);
+    hipFunction_t f = nullptr;
+    AMC_HIP(hipModuleGetFunction(&f, mod, code->lowered.c_str()));
+    h->rtc_fn[inst] = f;
+    *fn = f;
+    return AMC_OK;
+}
+
+int rtc_launch(amc_handle* h, const std::string& inst, int grid, void** params)
+{
+    hipFunction_t fn = nullptr;
+    { const int rc = rtc_function(h, inst, &fn); if (rc != AMC_OK) return rc; }
+    AMC_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, AMC_BLOCK, 1, 1, 0, h->stream, params, nullptr));
+    return AMC_OK;
+}
+
+const char* tf(bool b) { return b ? "true" : "false"; }
+
+// sweep_kernel<POT_CUSTOM, MULTI, LOG, BETA, SINGLE, REDUCE> with the flags launch_sweep_s / launch_sweep_reduce pick
+int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
+{
+    const bool multi = h->K > 1, log = multi || h->counters;
+    const std::string inst = std::string("amc::sweep_kernel<2,") + tf(multi) + "," + tf(log) + "," + tf(h->beta_arr) + "," +
+                             tf(a.n_steps == 1) + "," + tf(reduce) + ">";
+    void* params[] = {&a};
+    return rtc_launch(h, inst, grid, params);
+}
+
+int launch_pg_custom(amc_handle* h, amc::PgArgs& a, int grid, int nl_cap)
+{
+    const std::string inst = "amc::pg_estimate_kernel<2," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + ">";
+    void* params[] = {&a};
+    return rtc_launch(h, inst, grid, params);
+}
+
 }  // namespace
 
 extern "C" {
@@ -256,7 +421,7 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-int amc_create(const amc_config* cfg, amc_handle** out)
+static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out)
 {
     if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
     *out = nullptr;
@@ -270,8 +435,16 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     if (cfg->n_moves < 1 || cfg->n_moves > AMC_MAX_MOVES)
         return fail(AMC_ERR_BAD_ARG, "amc_create: n_moves must be in [1, %d]", AMC_MAX_MOVES);
     if (cfg->sweepstep < 1) return fail(AMC_ERR_BAD_ARG, "amc_create: sweepstep must be >= 1");
-    if (cfg->potential != AMC_POTENTIAL_HARMONIC && cfg->potential != AMC_POTENTIAL_DOUBLE_WELL)
+    if (cfg->potential == AMC_POTENTIAL_CUSTOM) {
+        if (!potential_expr)
+            return fail(AMC_ERR_BAD_ARG, "amc_create: AMC_POTENTIAL_CUSTOM needs its expression: use amc_create_custom");
+        const int rc_expr = validate_potential_expr(potential_expr);
+        if (rc_expr != AMC_OK) return rc_expr;
+    } else if (potential_expr) {
+        return fail(AMC_ERR_BAD_ARG, "amc_create_custom: cfg->potential must be AMC_POTENTIAL_CUSTOM");
+    } else if (cfg->potential != AMC_POTENTIAL_HARMONIC && cfg->potential != AMC_POTENTIAL_DOUBLE_WELL) {
         return fail(AMC_ERR_BAD_ARG, "amc_create: unknown potential id %d", cfg->potential);
+    }
     if (!cfg->sigma || !cfg->weight) return fail(AMC_ERR_BAD_ARG, "amc_create: sigma/weight is NULL");
     double wsum = 0.0;
     for (int k = 0; k < cfg->n_moves; ++k) {
@@ -312,6 +485,7 @@ int amc_create(const amc_config* cfg, amc_handle** out)
     h->offset = cfg->chain_offset;
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;
+    if (potential_expr) h->pot_expr = potential_expr;
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
     h->counters = cfg->per_chain_counters != 0 || cfg->n_moves > 1;
@@ -380,8 +554,36 @@ int amc_create(const amc_config* cfg, amc_handle** out)
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
+    if (h->potential == AMC_POTENTIAL_CUSTOM) {
+        // compile the smallest kernel now so that a malformed expression fails HERE, with the compiler's message
+        hipFunction_t fn = nullptr;
+        rc = rtc_function(h, "amc::energy_kernel<2>", &fn);
+        if (rc != AMC_OK) return bail(rc);
+    }
     *out = h;
     return AMC_OK;
+}
+
+int amc_create(const amc_config* cfg, amc_handle** out) { return create_impl(cfg, nullptr, out); }
+
+int amc_create_custom(const amc_config* cfg, const char* potential_expr, amc_handle** out)
+{
+    if (!potential_expr) return fail(AMC_ERR_BAD_ARG, "amc_create_custom: potential_expr is NULL");
+    return create_impl(cfg, potential_expr, out);
+}
+
+int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
+{
+    if (log && log_capacity > 0) log[0] = 0;
+    { const int rc = validate_potential_expr(potential_expr); if (rc != AMC_OK) return rc; }
+    const RtcCode* code = nullptr;
+    std::string text;
+    const int rc = rtc_compile(potential_expr, "amc::energy_kernel<2>", &code, &text);
+    if (log && log_capacity > 0) {
+        std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
+        log[log_capacity - 1] = 0;
+    }
+    return rc;
 }
 
 int amc_destroy(amc_handle* h)
@@ -390,6 +592,7 @@ int amc_destroy(amc_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    for (hipModule_t m : h->rtc_mods) (void)hipModuleUnload(m);
     (void)hipFree(h->d_comm);
     (void)hipFree(h->d_gd_acc);
     (void)hipFree(h->d_status);
@@ -452,6 +655,22 @@ int amc_download_state(amc_handle* h, double* x, double* e)
     if (!dst) { tmp.resize((size_t)h->M); dst = tmp.data(); }
     AMC_HIP(hipMemcpyAsync(dst, h->d_x, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    if (e && h->potential == AMC_POTENTIAL_CUSTOM) {
+        // the host cannot evaluate the user's expression: e = potential(x) by the run-time compiled kernel
+        double* d_e = nullptr;
+        AMC_HIP(hipMalloc(&d_e, (size_t)h->M * sizeof(double)));
+        const double* d_x = h->d_x;
+        int64_t m = h->M;
+        void* params[] = {&d_x, &m, &d_e};
+        int rc = rtc_launch(h, "amc::energy_kernel<2>", h->red_blocks, params);
+        hipError_t he = hipSuccess;
+        if (rc == AMC_OK) he = hipMemcpyAsync(e, d_e, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (rc == AMC_OK && he == hipSuccess) he = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_e);
+        if (rc != AMC_OK) return rc;
+        if (he != hipSuccess) return fail(AMC_ERR_HIP, "amc_download_state: %s", hipGetErrorString(he));
+        return AMC_OK;
+    }
     if (e) {
         // e == potential(x) exactly (particle_1d.jl:33): the same two IEEE multiplies on the host
         for (int64_t c = 0; c < h->M; ++c) {
@@ -561,7 +780,9 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
         a.red_stride = RED_HOST_STRIDE;
         const bool last = remaining == chunk;
         int rc;
-        if (fuse_reduce && last)
+        if (h->potential == AMC_POTENTIAL_CUSTOM)
+            rc = launch_sweep_custom(h, a, grid, fuse_reduce && last);
+        else if (fuse_reduce && last)
             rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep_reduce<amc::POT_DOUBLE_WELL>(h, a, grid)
                                                              : launch_sweep_reduce<amc::POT_HARMONIC>(h, a, grid);
         else
@@ -749,7 +970,16 @@ int amc_reduce_begin(amc_handle* h)
     double* rows = host ? h->h_partials : h->d_partials;
     const int stride = host ? RED_HOST_STRIDE : n_vals;
     const unsigned long long* slots = (host && ratio_mode == 0) ? h->d_acc_slots : nullptr;
-    if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
+    if (h->potential == AMC_POTENTIAL_CUSTOM) {
+        const double* d_x = h->d_x;
+        const uint32_t *d_acc = h->d_acc, *d_tot = h->d_tot;
+        int64_t m = h->M, m_pad = h->M_pad;
+        int k = h->K, mode = ratio_mode, st = stride, n_slots = h->n_slots;
+        uint64_t t_counted = h->t_counted;
+        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots};
+        const int rc = rtc_launch(h, "amc::reduce_kernel<2>", h->red_blocks, params);
+        if (rc != AMC_OK) return rc;
+    } else if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
                            h->n_slots);
@@ -885,8 +1115,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     const int nl = nl_capacity(n_learn);
     int grid = grid_for(h, (h->M + 1) / 2);
     if (grid > h->red_blocks) grid = h->red_blocks;
-    const int rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, grid, nl)
-                                                               : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
+    const int rc = (h->potential == AMC_POTENTIAL_CUSTOM)        ? launch_pg_custom(h, a, grid, nl)
+                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, grid, nl)
+                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
     if (rc != AMC_OK) return rc;
     // partials layout [grid][nl][4]: reduce the first n_learn*4 of every nl*4 row
     { const int rc2 = launch_final_reduce(h, grid, nl * 4, h->d_out, nullptr, 0); if (rc2 != AMC_OK) return rc2; }

@@ -21,7 +21,7 @@
 
 namespace amc {
 
-enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1 };
+enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1, POT_CUSTOM = 2 };
 
 // Rows of the per-move parameter table.
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
@@ -44,11 +44,30 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
     return __builtin_fma(r1, y, q1);
 }
 
-// potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
-// double well (x*x-1)^2 is BASELINE config 3's.
-template <int POT>
-__device__ __forceinline__ double potential(double x)
+// POT_CUSTOM: `potential` is a free function the driver SCRIPT defines in the reference
+// (harmonic_oscillator/MC_harmonic_oscillator.jl:4; docs/src/man/system.md).  A Julia closure cannot cross the
+// C ABI, so amc_create_custom takes the body as a C expression in `x` and the kernels of this header are
+// compiled for it at run time (hiprtc, amc_api.hip: the translation unit defines AMC_USER_POTENTIAL before
+// including this file).  The expression sees IEEE + - * / (no contraction: -ffp-contract=off), sqrt, fabs, fma,
+// and the arithmetic spec's own amc_exp / amc_log (bit-reproducible on any IEEE host).
+#ifndef AMC_USER_POTENTIAL
+#define AMC_USER_POTENTIAL(x) (x)        // offline build: POT_CUSTOM kernels are never instantiated
+#endif
+__device__ __forceinline__ double user_potential(double x, const double* amc_tables_)
 {
+#define amc_exp(v) (::amc::exp_f64((v), amc_tables_))
+#define amc_log(v) (::amc::log_f64((v)))
+    return AMC_USER_POTENTIAL(x);
+#undef amc_exp
+#undef amc_log
+}
+
+// potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
+// double well (x*x-1)^2 is BASELINE config 3's.  T: the block's LDS copy of the math tables (custom only).
+template <int POT>
+__device__ __forceinline__ double potential(double x, const double* T)
+{
+    if (POT == POT_CUSTOM) return user_potential(x, T);
     if (POT == POT_DOUBLE_WELL) {
         const double q = x * x - 1.0;
         return q * q;
@@ -72,9 +91,9 @@ __device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, do
 {
     const double delta = 0.0 + sigma * z;
     const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den, bit for bit
-    const double e1 = potential<POT>(x);
+    const double e1 = potential<POT>(x, T);
     const double xn = x + delta;
-    const double e2 = potential<POT>(xn);
+    const double e2 = potential<POT>(xn, T);
     const double dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double arg = (dlogp + logq) - logq;
     // alpha = min(1, exp(arg)); accept iff alpha > u, with u in [0, 1).  Decided without forming alpha:
@@ -323,7 +342,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(p + stride), a.t0);
         if (REDUCE) {
-            red[0] += potential<POT>(xv.x) + potential<POT>(xv.y);
+            red[0] += potential<POT>(xv.x, s_math) + potential<POT>(xv.y, s_math);
             red[1] += xv.x + xv.y;
             red[2] += xv.x * xv.x + xv.y * xv.y;
             red[3] += 2.0;
@@ -350,8 +369,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, p, lw);
         }
         if (REDUCE) {
-            if (v0) { red[0] += potential<POT>(xv.x); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
-            if (v1) { red[0] += potential<POT>(xv.y); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
+            if (v0) { red[0] += potential<POT>(xv.x, s_math); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
+            if (v1) { red[0] += potential<POT>(xv.y, s_math); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
         }
     }
     if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
@@ -564,10 +583,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
                                                             const unsigned long long* slots, int n_slots)
 {
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    __shared__ double s_math[POT == POT_CUSTOM ? TAB_DOUBLES : 1];      // a custom potential may call amc_exp
+    if (POT == POT_CUSTOM) stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
         const double xc = x[c];
-        v[0] += potential<POT>(xc);
+        v[0] += potential<POT>(xc, s_math);
         v[1] += xc;
         v[2] += xc * xc;
         v[3] += 1.0;
@@ -705,9 +726,9 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     const double q1 = div_by_const(-(delta * delta), den, rden);
     const double logq = q1 - logc;
     const double dlogq = -div_by_const(q1, den, rden) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
-    const double e1 = potential<POT>(x);
+    const double e1 = potential<POT>(x, T);
     const double xn = x + delta;
-    const double e2 = potential<POT>(xn);
+    const double e2 = potential<POT>(xn, T);
     const double dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = delta * delta;                        // reward, particle_1d.jl:42-44
     x = xn + (-delta);
@@ -824,6 +845,18 @@ __global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, i
     __syncthreads();
     for (int i = threadIdx.x; i < n_bins + 3; i += AMC_BLOCK)
         if (s_hist[i]) atomicAdd(&counts[i], (unsigned long long)s_hist[i]);
+}
+
+// e[c] = potential(x[c]) (Particle.e, particle_1d.jl:13-15,33) for amc_download_state when the host cannot
+// evaluate the potential itself (POT_CUSTOM).
+template <int POT>
+__global__ __launch_bounds__(AMC_BLOCK) void energy_kernel(const double* x, int64_t n_chains, double* e)
+{
+    __shared__ double s_math[TAB_DOUBLES];
+    stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride)
+        e[c] = potential<POT>(x[c], s_math);
 }
 
 // Strided snapshot: out[i] = x[first + i*stride] (binary stand-in for a subset of trajectory files).

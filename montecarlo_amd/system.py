@@ -14,8 +14,26 @@ import numpy as np
 POTENTIALS = ("harmonic", "double_well")
 
 
-def potential(name: str, x):
+@dataclass(frozen=True)
+class CustomPotential:
+    """A user-defined ``potential(x)`` for the GPU path.
+
+    In the reference the driver script defines ``potential`` as a free Julia function
+    (harmonic_oscillator/MC_harmonic_oscillator.jl:4); a closure cannot cross the C ABI, so the body is
+    given as ONE C expression in ``x`` (e.g. ``"x*x*x*x - 2.0*x*x + 0.25*x"``) and the HIP kernels are
+    compiled for it at run time (``amc_create_custom``, include/amc.h).  ``+ - * /``, ``sqrt``, ``fabs``,
+    ``fma``, ``amc_exp``, ``amc_log`` give results that are bit-reproducible on an IEEE host.
+    """
+    expr: str
+
+    def __str__(self) -> str:
+        return f"custom: {self.expr}"
+
+
+def potential(name, x):
     """potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2); double well (x^2-1)^2."""
+    if isinstance(name, CustomPotential):
+        raise ValueError("a CustomPotential is evaluated by the device kernels only (download_state returns e)")
     x = np.asarray(x, dtype=np.float64)
     if name == "harmonic":
         return x * x
@@ -36,10 +54,10 @@ class ParticleChains:
     After ``finalise`` the arrays ``x`` / ``e`` hold this rank's shard again.
     """
 
-    def __init__(self, n_chains: int, beta, potential: str = "harmonic", x: Optional[np.ndarray] = None,
+    def __init__(self, n_chains: int, beta, potential="harmonic", x: Optional[np.ndarray] = None,
                  init_uniform: Optional[tuple] = None):
-        if potential not in POTENTIALS:
-            raise ValueError(f"unknown potential {potential!r}; the HIP engine offers {POTENTIALS}")
+        if not isinstance(potential, CustomPotential) and potential not in POTENTIALS:
+            raise ValueError(f"unknown potential {potential!r}; the HIP engine offers {POTENTIALS} and CustomPotential(expr)")
         self.n_chains = int(n_chains)
         self.potential = potential
         self.beta_array = None
@@ -57,7 +75,7 @@ class ParticleChains:
         self.shard = (0, self.n_chains)
 
     @classmethod
-    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential: str = "harmonic"):
+    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential="harmonic"):
         return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)))
 
     def __len__(self) -> int:

@@ -243,8 +243,13 @@ void amo_box_muller(const uint32_t v[4], double z[2])
 /* potential(x): free function defined by the driver script,
  * harmonic_oscillator/MC_harmonic_oscillator.jl:4  potential(x) = x^2 (== x*x).
  * The double well (x^2-1)^2 is BASELINE config 3's, not in the reference. */
+static double (*g_custom_potential)(double) = 0;
+
+void amo_set_custom_potential(double (*fn)(double)) { g_custom_potential = fn; }
+
 double amo_potential(int pot, double x)
 {
+    if (pot == AMO_POT_CUSTOM) return g_custom_potential ? g_custom_potential(x) : (0.0 / 0.0);
     if (pot == AMO_POT_DOUBLE_WELL) {
         double q = x * x - 1.0;
         return q * q;

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-enum { AMO_POT_HARMONIC = 0, AMO_POT_DOUBLE_WELL = 1 };
+enum { AMO_POT_HARMONIC = 0, AMO_POT_DOUBLE_WELL = 1, AMO_POT_CUSTOM = 2 };
 enum { AMO_STREAM_INIT = 0, AMO_STREAM_METROPOLIS = 1, AMO_STREAM_ESTIMATOR = 2 };
 enum { AMO_DRAW_NORMAL = 0, AMO_DRAW_ACCEPT = 1, AMO_DRAW_CATEGORICAL = 2 };
 enum {
@@ -59,6 +59,10 @@ double amo_uniform_oc(uint32_t lo, uint32_t hi);    /* (0,1] */
 double amo_angle_oc2(uint32_t lo, uint32_t hi);     /* (0,2] */
 double amo_uniform32(uint32_t v);                 /* [0,1), 32 bits */
 double amo_potential(int pot, double x);
+/* AMO_POT_CUSTOM: `potential` is a free GLOBAL function of the driver script in the reference
+ * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,
+ * compiled by gcc (-ffp-contract=off), here.  Process-global, like the reference's. */
+void   amo_set_custom_potential(double (*fn)(double));
 double amo_log_proposal_density(double delta, double sigma);
 double amo_grad_log_proposal_density(double delta, double sigma);
 int    amo_categorical(const double *weights, int K, double r);

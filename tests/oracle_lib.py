@@ -19,6 +19,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libamc_oracle.so")
 
 POTENTIALS = {"harmonic": 0, "double_well": 1}
+POT_CUSTOM = 2
 OPTIMISERS = {"Static": 0, "VPG": 1, "BLPG": 2, "BLAPG": 3, "NPG": 4, "ANPG": 5, "BLANPG": 6}
 STREAM_INIT, STREAM_METROPOLIS, STREAM_ESTIMATOR = 0, 1, 2
 DRAW_NORMAL, DRAW_ACCEPT, DRAW_CATEGORICAL = 0, 1, 2
@@ -49,6 +50,7 @@ def load() -> C.CDLL:
     sig = {
         "amo_philox4x32_10": (None, [u32p, u32p, u32p]),
         "amo_counter": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]),
+        "amo_set_custom_potential": (None, [C.c_void_p]),
         "amo_exp": (C.c_double, [C.c_double]),
         "amo_log": (C.c_double, [C.c_double]),
         "amo_sincospi": (None, [C.c_double, dp, dp]),
@@ -161,6 +163,39 @@ def learning_step(opt: str, h0: float, h1: float, theta: float, gd4) -> float:
     return load().amo_learning_step(OPTIMISERS[opt], h0, h1, theta, a)
 
 
+_custom_libs = {}
+
+
+def install_custom_potential(expr: str) -> None:
+    """gcc-compile `double f(double x) { return <expr>; }` with the oracle's flags (no contraction) and make it the
+    oracle's global `potential` -- the CPU twin of amc_create_custom's hiprtc build.  amc_exp / amc_log resolve to
+    the oracle's own amo_exp / amo_log."""
+    import hashlib
+    import tempfile
+    lib = load()
+    key = hashlib.sha1(expr.encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_pot_")
+        src, so = os.path.join(d, "pot.c"), os.path.join(d, f"pot_{key}.so")
+        with open(src, "w") as f:
+            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
+                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+                    f"double amo_user_potential(double x) {{ return ({expr}); }}\n")
+        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    fn = C.cast(_custom_libs[key].amo_user_potential, C.c_void_p)
+    lib.amo_set_custom_potential(fn)
+
+
+def _potential_id(potential) -> int:
+    expr = getattr(potential, "expr", None)
+    if expr is not None:
+        install_custom_potential(expr)
+        return POT_CUSTOM
+    return POTENTIALS[potential]
+
+
 class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
@@ -171,7 +206,7 @@ class OracleSim:
         self.K = len(sigma)
         s = (C.c_double * self.K)(*[float(v) for v in sigma])
         w = (C.c_double * self.K)(*[float(v) for v in weight])
-        self.h = self.lib.amo_create(self.M, int(chain_offset), POTENTIALS[potential], float(beta), self.K, s, w,
+        self.h = self.lib.amo_create(self.M, int(chain_offset), _potential_id(potential), float(beta), self.K, s, w,
                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweepstep))
         if not self.h:
             raise ValueError("amo_create failed")
