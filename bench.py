@@ -93,6 +93,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: RCCL / the HIP runtime may print banners to fd 1 (e.g. RCCL's version block at
+    # communicator creation), so fd 1 is pointed at stderr for the whole run and the line goes to a private copy.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,7 +211,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

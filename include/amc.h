@@ -210,6 +210,13 @@ int  amc_pg_accumulate(amc_handle *h, int n_learn, const int *learn_ids, int q_b
 int  amc_pg_update(amc_handle *h, int n_learn, const int *learn_ids, const int *optimiser,
                    const double *hyper0, const double *hyper1);
 int  amc_pg_get_accumulated(amc_handle *h, int n_learn, const int *learn_ids, double *out);
+/* n_steps x [ make_step!(::Metropolis); make_step!(::PolicyGradientEstimator); make_step!(::PolicyGradientUpdate)
+ * if do_update ] -- the three algorithms run! calls back to back at one time step (src/simulation.jl:185-190,
+ * PGMC_harmonic_oscillator.jl:24-33) -- enqueued by ONE host call: amc_sweep(h, 1), amc_pg_accumulate, amc_pg_update
+ * in that order per step, results identical to the separate calls.  For hosts whose per-call cost (Julia ccall,
+ * ctypes) would otherwise exceed the ~0.1 ms of device work per step. */
+int  amc_pgmc_steps(amc_handle *h, int64_t n_steps, int n_learn, const int *learn_ids, int q_batch,
+                    int do_update, const int *optimiser, const double *hyper0, const double *hyper1);
 
 int  amc_sync(amc_handle *h);
 /* hipStream_t the handle launches on (for event timing / graph capture by the host). */

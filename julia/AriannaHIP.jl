@@ -38,6 +38,7 @@ end
 
 const POTENTIAL_HARMONIC = Int32(0)
 const POTENTIAL_DOUBLE_WELL = Int32(1)
+const POTENTIAL_CUSTOM = Int32(2)          # potential given as a C expression in x (amc_create_custom)
 
 function check(rc::Cint)
     rc == 0 && return nothing
@@ -46,7 +47,7 @@ function check(rc::Cint)
 end
 
 """
-    HIPMetropolis(chains; pool, sweepstep=1, seed=1, device=0, potential=:harmonic, ...)
+    HIPMetropolis(chains; pool, sweepstep=1, seed=1, device=0, potential=:harmonic | :double_well | "C expression in x", ...)
 
 Drop-in for `Metropolis` (src/metropolis.jl:232-291) on one MI355X.  `chains` is the usual
 `Vector{Particle}`; the pool must hold `Displacement` moves with a `StandardGaussian` policy.
@@ -68,11 +69,19 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
     # same checks as metropolis.jl:249-251 (identical parameters/weights across chains hold by construction)
     handle = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve sigma weight begin
+        pot_id = potential isa AbstractString ? POTENTIAL_CUSTOM :
+                 potential === :double_well ? POTENTIAL_DOUBLE_WELL : POTENTIAL_HARMONIC
         cfg = AmcConfig(UInt32(sizeof(AmcConfig)), Int32(device), length(chains), chain_offset, n_chains_global,
-                        potential === :double_well ? POTENTIAL_DOUBLE_WELL : POTENTIAL_HARMONIC,
+                        pot_id,
                         Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL)
-        check(ccall((:amc_create, libamc), Cint, (Ref{AmcConfig}, Ref{Ptr{Cvoid}}), cfg, handle))
+        if potential isa AbstractString
+            # the script's `potential(x) = ...` (MC_harmonic_oscillator.jl:4) restated as a C expression in x
+            check(ccall((:amc_create_custom, libamc), Cint, (Ref{AmcConfig}, Cstring, Ref{Ptr{Cvoid}}),
+                        cfg, potential, handle))
+        else
+            check(ccall((:amc_create, libamc), Cint, (Ref{AmcConfig}, Ref{Ptr{Cvoid}}), cfg, handle))
+        end
     end
     alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), length(pool))
     finalizer(a -> ccall((:amc_destroy, libamc), Cint, (Ptr{Cvoid},), a.handle), alg)

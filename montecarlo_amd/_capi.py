@@ -97,6 +97,8 @@ def load() -> C.CDLL:
         "amc_pg_accumulate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int]),
         "amc_pg_update": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]),
         "amc_pg_get_accumulated": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), dp]),
+        "amc_pgmc_steps": (C.c_int, [H, C.c_int64, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int),
+                                     dp, dp]),
         "amc_sync": (C.c_int, [H]),
         "amc_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
         "amc_timing_begin": (C.c_int, [H]),
@@ -322,6 +324,17 @@ class HipEngine:
         h0 = (C.c_double * max(n, 1))(*[float(v) for v in hyper0])
         h1 = (C.c_double * max(n, 1))(*[float(v) for v in hyper1])
         _check(self._lib.amc_pg_update(self._h, n, ids, kd, h0, h1))
+
+    def pgmc_steps(self, n_steps: int, learn_ids: Sequence[int], q_batch: int, kinds: Optional[Sequence[int]] = None,
+                   hyper0: Sequence[float] = (), hyper1: Sequence[float] = ()) -> None:
+        """n x [sweep(1); pg_accumulate; pg_update if kinds is given] enqueued by one call (asynchronous)."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        do_update = kinds is not None
+        kd = (C.c_int * max(n, 1))(*[int(k) for k in (kinds or [0] * n)])
+        h0 = (C.c_double * max(n, 1))(*[float(v) for v in (hyper0 if do_update else [0.0] * n)])
+        h1 = (C.c_double * max(n, 1))(*[float(v) for v in (hyper1 if do_update else [0.0] * n)])
+        _check(self._lib.amc_pgmc_steps(self._h, int(n_steps), n, ids, int(q_batch), 1 if do_update else 0, kd, h0, h1))
 
     def pg_get_accumulated(self, learn_ids: Sequence[int]) -> np.ndarray:
         n = len(learn_ids)

@@ -103,6 +103,8 @@ struct amc_handle {
     double* d_comm = nullptr;
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
+    uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
+    double* d_pg_groups = nullptr;      // [groups][AMC_MAX_LEARN * 4]
     Rccl rccl;
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x)
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
@@ -548,6 +550,12 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
     AMC_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream));
+    {
+        const size_t groups = (size_t)(h->n_slots + amc::PG_GROUP - 1) / amc::PG_GROUP + 1;
+        AMC_TRY(hipMalloc(&h->d_pg_tickets, (groups + 1) * sizeof(uint32_t)));
+        AMC_TRY(hipMemsetAsync(h->d_pg_tickets, 0, (groups + 1) * sizeof(uint32_t), h->stream));
+        AMC_TRY(hipMalloc(&h->d_pg_groups, groups * AMC_MAX_LEARN * 4 * sizeof(double)));
+    }
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
     AMC_TRY(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
@@ -596,6 +604,8 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_comm);
     (void)hipFree(h->d_gd_acc);
     (void)hipFree(h->d_status);
+    (void)hipFree(h->d_pg_tickets);
+    (void)hipFree(h->d_pg_groups);
     (void)hipFree(h->d_x);
     (void)hipFree(h->d_beta);
     (void)hipFree(h->d_acc);
@@ -1086,7 +1096,9 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 
 // Validates, launches K3 over this shard and leaves sum_{chains x q} (j, grad j, grad logq, g) per learnable
 // move in h->d_out[l*4 + i] (device, on the stream).  Shared by the host- and device-resident estimator paths.
-static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out)
+// tail: 1 = sums only, 2 = + gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
+static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
+                     int tail = 1, const amc::PgOpts* opt = nullptr)
 {
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
@@ -1112,6 +1124,17 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.key0 = (uint32_t)h->seed;
     a.key1 = (uint32_t)(h->seed >> 32);
     a.beta = h->beta;
+    a.tail_mode = tail;
+    a.n_moves = h->K;
+    a.tickets = h->d_pg_tickets;
+    a.group_sums = h->d_pg_groups;
+    a.out = h->d_out;
+    a.gd_acc = h->d_gd_acc;
+    a.ptab_rw = h->d_ptab;
+    a.status = h->d_status;
+    a.n_samples = (double)h->M * (double)q_batch;
+    if (opt) a.opt = *opt;
+    else for (int l = 0; l < AMC_MAX_LEARN; ++l) { a.opt.kind[l] = 0; a.opt.h0[l] = 0.0; a.opt.h1[l] = 0.0; }
     const int nl = nl_capacity(n_learn);
     int grid = grid_for(h, (h->M + 1) / 2);
     if (grid > h->red_blocks) grid = h->red_blocks;
@@ -1119,8 +1142,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
                    : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, grid, nl)
                                                                  : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
     if (rc != AMC_OK) return rc;
-    // partials layout [grid][nl][4]: reduce the first n_learn*4 of every nl*4 row
-    { const int rc2 = launch_final_reduce(h, grid, nl * 4, h->d_out, nullptr, 0); if (rc2 != AMC_OK) return rc2; }
+    // the launch itself left sum_{blocks} partials[grid][nl][4] in d_out[nl*4] (in-kernel final reduction)
     h->t_est += 1;
     *nl_out = nl;
     return AMC_OK;
@@ -1148,21 +1170,50 @@ static amc::PgIds make_ids(int n_learn, const int* learn_ids)
     return ids;
 }
 
-int amc_pg_accumulate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch)
+// make_step!(::PolicyGradientEstimator) on the device, optionally followed by make_step!(::PolicyGradientUpdate)
+// (opt != nullptr).  Single shard: ONE launch (the estimator kernel's last block folds, accumulates and, if asked,
+// takes the learning step).  Shards connected by amc_comm_init: estimator launch, in-place all-reduce, then the
+// small accumulate (and update) kernels.
+static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, const amc::PgOpts* opt)
 {
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: NULL handle");
     int nl = 0;
-    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl);
+    const int tail = h->comm ? 1 : (opt ? 3 : 2);
+    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt);
     if (rc != AMC_OK || n_learn == 0) return rc;
-    double n_samples = (double)h->M * (double)q_batch;
-    if (h->comm) {          // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
-        const int e = h->rccl.AllReduce(h->d_out, h->d_out, (size_t)nl * 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
-        if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-        n_samples = (double)h->M_global * (double)q_batch;
-    }
+    if (!h->comm) return AMC_OK;
+    // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
+    const int e = h->rccl.AllReduce(h->d_out, h->d_out, (size_t)nl * 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    const double n_samples = (double)h->M_global * (double)q_batch;
     hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
                        n_samples, h->d_gd_acc);
     AMC_HIP(hipGetLastError());
+    if (opt) {
+        hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
+                           make_ids(n_learn, learn_ids), *opt, h->K, h->d_status);
+        AMC_HIP(hipGetLastError());
+    }
+    return AMC_OK;
+}
+
+int amc_pg_accumulate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: NULL handle");
+    return pg_accumulate_impl(h, n_learn, learn_ids, q_batch, nullptr);
+}
+
+static int make_opts(amc_handle* h, int n_learn, const int* learn_ids, const int* optimiser, const double* hyper0,
+                     const double* hyper1, amc::PgOpts* opt)
+{
+    for (int l = 0; l < AMC_MAX_LEARN; ++l) {
+        opt->kind[l] = 0; opt->h0[l] = 0.0; opt->h1[l] = 0.0;
+    }
+    for (int l = 0; l < n_learn; ++l) {
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_update: learn_ids[%d] out of range", l);
+        if (optimiser[l] < AMC_OPT_STATIC || optimiser[l] > AMC_OPT_BLANPG)
+            return fail(AMC_ERR_BAD_ARG, "amc_pg_update: No learning_step! is defined for optimiser id %d", optimiser[l]);
+        opt->kind[l] = optimiser[l]; opt->h0[l] = hyper0[l]; opt->h1[l] = hyper1[l];
+    }
     return AMC_OK;
 }
 
@@ -1174,19 +1225,34 @@ int amc_pg_update(amc_handle* h, int n_learn, const int* learn_ids, const int* o
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_update: n_learn must be in [0, %d]", AMC_MAX_LEARN);
     if (n_learn == 0) return AMC_OK;
     amc::PgOpts opt;
-    for (int l = 0; l < AMC_MAX_LEARN; ++l) {
-        opt.kind[l] = 0; opt.h0[l] = 0.0; opt.h1[l] = 0.0;
-    }
-    for (int l = 0; l < n_learn; ++l) {
-        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_update: learn_ids[%d] out of range", l);
-        if (optimiser[l] < AMC_OPT_STATIC || optimiser[l] > AMC_OPT_BLANPG)
-            return fail(AMC_ERR_BAD_ARG, "amc_pg_update: No learning_step! is defined for optimiser id %d", optimiser[l]);
-        opt.kind[l] = optimiser[l]; opt.h0[l] = hyper0[l]; opt.h1[l] = hyper1[l];
-    }
+    { const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt); if (rc != AMC_OK) return rc; }
     AMC_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
                        make_ids(n_learn, learn_ids), opt, h->K, h->d_status);
     AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_pgmc_steps(amc_handle* h, int64_t n_steps, int n_learn, const int* learn_ids, int q_batch, int do_update,
+                   const int* optimiser, const double* hyper0, const double* hyper1)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: NULL handle");
+    if (n_steps < 0) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: n_steps < 0");
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (n_learn > 0 && (!learn_ids || (do_update && (!optimiser || !hyper0 || !hyper1))))
+        return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: NULL argument");
+    amc::PgOpts opt;
+    if (do_update && n_learn > 0) {
+        const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt);
+        if (rc != AMC_OK) return rc;
+    }
+    // the three make_step!s of one time step (src/simulation.jl:185-190), n_steps times, from one host call: two
+    // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
+    for (int64_t i = 0; i < n_steps; ++i) {
+        int rc = sweep_impl(h, 1, false, nullptr);
+        if (rc == AMC_OK) rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr);
+        if (rc != AMC_OK) return rc;
+    }
     return AMC_OK;
 }
 

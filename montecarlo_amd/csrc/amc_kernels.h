@@ -509,24 +509,29 @@ enum { OPT_STATIC = 0, OPT_VPG = 1, OPT_BLPG = 2, OPT_BLAPG = 3, OPT_NPG = 4, OP
 
 // gradients_data[k] = gradients_data[k] + gd (estimator.jl:130): red[l*4 + i] holds the (all-reduced) sums of
 // (j, grad j, grad logq, g) over chains x q_batch samples of learnable move l; acc is [AMC_MAX_MOVES][5].
+__device__ __forceinline__ void pg_accumulate_one(const double* red, int l, int lid, double n_samples, double* acc)
+{
+    double* a = acc + lid * 5;
+    for (int i = 0; i < 4; ++i) a[i] += red[l * 4 + i];
+    a[4] += n_samples;
+}
+
 __global__ void pg_accumulate_kernel(const double* red, int n_learn, PgIds ids, double n_samples, double* acc)
 {
     const int l = threadIdx.x;
     if (l >= n_learn) return;
-    double* a = acc + ids.v[l] * 5;
-    for (int i = 0; i < 4; ++i) a[i] += red[l * 4 + i];
-    a[4] += n_samples;
+    pg_accumulate_one(red, l, ids.v[l], n_samples, acc);
 }
 
 // make_step!(::PolicyGradientUpdate) (update.jl:50-57) for P = 1: average (gradients.jl:83-85), learning_step!
 // (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164; inv(g + eps I) is a scalar reciprocal), reset
 // the accumulators, refresh the derived parameter table.  A step that leaves sigma outside [1e-100, 1e100]
 // (or NaN) is not applied; status[0] is set instead.
-__global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
+__device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_learn, const int32_t* ids,
+                                              const PgOpts& opt, int n_moves, int* status)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int l = 0; l < n_learn; ++l) {
-        const int k = ids.v[l];
+        const int k = ids[l];
         double* a = acc + k * 5;
         const double n = a[4];
         const double j = a[0] / n, dj = a[1] / n, dlogq = a[2] / n, g = a[3] / n;
@@ -566,6 +571,12 @@ __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds i
         for (int i = 0; i < 5; ++i) a[i] = 0.0;
     }
     prepare_params(ptab, n_moves);
+}
+
+__global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
 }
 
 // K2a: callback reductions, pass 1.  partials[block][4 + K]:
@@ -713,7 +724,21 @@ struct PgArgs {
     int32_t learn_ids[AMC_MAX_LEARN];
     uint32_t key0, key1;
     double beta;
+    // Tail of the launch (no further launches for the fold's bookkeeping; each tiny launch costs ~5 us plus a ~6 us
+    // dependent-launch gap on this part).  tail_mode 0: block partials only; 1: + their fixed-order sum in `out`
+    // [NL*4]; 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
+    int32_t tail_mode;
+    int32_t n_moves;
+    uint32_t* tickets;            // [1 + n_groups], zero between launches
+    double* group_sums;           // [n_groups][NL*4]
+    double* out;
+    double* gd_acc;               // [AMC_MAX_MOVES][5]
+    double* ptab_rw;              // == ptab (written by the update)
+    int* status;
+    double n_samples;
+    PgOpts opt;
 };
+enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kernel final reduction
 
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
@@ -740,11 +765,32 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     g[3] += dlogq * dlogq;
 }
 
+// Column sums, in row order, of rows[n_rows][NV] that OTHER blocks wrote (agent-scope loads, one per thread and
+// trip so that they are all in flight together), staged through `scratch` (capacity cap_rows rows).  Called by the
+// whole block; the sums are valid in threads < NV.
+template <int NV>
+__device__ __forceinline__ double ordered_column_sum(const double* rows, int n_rows, double* scratch, int cap_rows)
+{
+    double t = 0.0;
+    for (int base = 0; base < n_rows; base += cap_rows) {
+        const int nr = (n_rows - base < cap_rows) ? n_rows - base : cap_rows;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * NV; i += AMC_BLOCK)
+            scratch[i] = __hip_atomic_load(rows + (int64_t)base * NV + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x < NV)
+            for (int r = 0; r < nr; ++r) t += scratch[r * NV + threadIdx.x];
+    }
+    return t;
+}
+
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
 template <int POT, int NL, bool BETA>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
 {
-    __shared__ double s_math[TAB_DOUBLES];
+    // the math tables; after the sampling loop the same LDS stages the rows of the in-kernel final reduction
+    constexpr int SCRATCH = (PG_GROUP * NL * 4 > TAB_DOUBLES) ? PG_GROUP * NL * 4 : TAB_DOUBLES;
+    __shared__ double s_math[SCRATCH];
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     double g[NL][4];
@@ -813,9 +859,69 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
             store_pair_writethrough(a.x + 2 * p, xv);        // a lone last chain writes its whole pair: padding
         }
     }
+    // Block partial sums -> row blockIdx.x of partials[grid][NL][4].  All cross-block traffic of the tail below goes
+    // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
+    // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /
+    // invalidate per block, which cost ~70 us per launch over 2048 blocks when it was tried.
+    constexpr int NV = NL * 4;
+    double* row = a.partials + (int64_t)blockIdx.x * NV;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        if (l < a.n_learn) block_sum_store<4>(g[l], a.partials + ((int64_t)blockIdx.x * NL + l) * 4);
+        double r[4] = {0.0, 0.0, 0.0, 0.0};
+        if (l < a.n_learn) block_sum_store<4>(g[l], r);              // thread 0 holds the sums
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(row + l * 4 + i, r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.tail_mode == 0) return;
+
+    // In-kernel final reduction, two levels of "the last one to arrive sums": the last block of each group of
+    // PG_GROUP consecutive blocks adds the group's rows in row order, the last group to finish adds the group sums in
+    // group order -- the ORDER of additions depends on the grid only, not on which block happens to be last.
+    // Ordering: thread 0 wrote the row, waits for those stores (vmcnt(0)) and only then takes its ticket; the block
+    // that draws the last ticket reads the rows after the ticket's return value has arrived.
+    __shared__ int s_role;
+    __shared__ double s_tot[NV];
+    const int grp = blockIdx.x / PG_GROUP;
+    const int n_groups = (gridDim.x + PG_GROUP - 1) / PG_GROUP;
+    const int r0 = grp * PG_GROUP;
+    const int n_rows = ((int)gridDim.x - r0 < PG_GROUP) ? (int)gridDim.x - r0 : PG_GROUP;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = __hip_atomic_fetch_add(a.tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_role = (prev == (uint32_t)n_rows - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_role != 1) return;
+    constexpr int CAP_ROWS = SCRATCH / NV;             // >= PG_GROUP
+    {
+        const double t = ordered_column_sum<NV>(a.partials + (int64_t)r0 * NV, n_rows, s_math, CAP_ROWS);
+        if (threadIdx.x < NV) {
+            __hip_atomic_store(a.group_sums + grp * NV + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();                                   // NV <= 32: the stores above all belong to wave 0, now complete
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const uint32_t prev = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_role = (prev == (uint32_t)n_groups - 1u) ? 2 : 0;
+    }
+    __syncthreads();
+    if (s_role != 2) return;
+    {
+        const double t = ordered_column_sum<NV>(a.group_sums, n_groups, s_math, CAP_ROWS);
+        if (threadIdx.x < NV) {
+            a.out[threadIdx.x] = t;
+            s_tot[threadIdx.x] = t;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.tail_mode >= 2) {
+            for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, a.learn_ids[l], a.n_samples, a.gd_acc);
+            if (a.tail_mode >= 3) pg_update_all(a.ptab_rw, a.gd_acc, a.n_learn, a.learn_ids, a.opt, a.n_moves, a.status);
+        }
     }
 }
 

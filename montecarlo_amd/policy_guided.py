@@ -143,6 +143,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
     policy is evaluated in closed form by the kernel (test/ad_backends_test.jl pins all backends equal)."""
 
     mutates_chains = True       # every sample leaves x at (x + delta) - delta (gradients.jl:98,103)
+    pgmc_role = "estimator"     # run() may issue [Metropolis, this, PolicyGradientUpdate] as one engine call
 
     def __init__(self, chains, dependencies=None, optimisers=None, q_batch_size: int = 1, ad_backend=None,
                  R=None, parallel: bool = False, device_resident: Optional[bool] = None, **extras):
@@ -194,6 +195,25 @@ class PolicyGradientEstimator(AriannaAlgorithm):
             self.gradients_data[k] = self.gradients_data[k] + gd                   # :130
             self.objectives[k] = self.gradients_data[k].j / self.gradients_data[k].n   # :131
 
+    def make_steps_grouped(self, simulation: Simulation, n: int, update: Optional["PolicyGradientUpdate"]) -> bool:
+        """n time steps that schedule exactly [Metropolis, this estimator(, update)] (PGMC_harmonic_oscillator.jl:24-33
+        has them every t) as ONE engine call: same launches in the same order, without ~6 host calls per step.
+        False when this configuration cannot be grouped (the caller then steps the algorithms one by one)."""
+        eng = self.metropolis.engine
+        if not (self.device_resident and self.learn_ids and hasattr(eng, "pgmc_steps")):
+            return False
+        self.metropolis._drop_pending_reduction()
+        if update is not None:
+            codes = [optimiser_code(self.optimisers[lid]) for lid in self.learn_ids]
+            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, [c[0] for c in codes], [c[1] for c in codes],
+                           [c[2] for c in codes])
+            self.metropolis.device_params_dirty = True
+        else:
+            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size)
+        self.metropolis._epoch += 1
+        self.metropolis.invalidate_reductions()
+        return True
+
     def write_algorithm(self, io, scheduler) -> None:                              # :136-147
         io.write("\tPolicyGradientEstimator\n")
         io.write(f"\t\tCalls: {_calls(scheduler)}\n")
@@ -205,6 +225,8 @@ class PolicyGradientEstimator(AriannaAlgorithm):
 # ---- update.jl ------------------------------------------------------------------------------------
 class PolicyGradientUpdate(AriannaAlgorithm):
     """PolicyGradientUpdate(chains; dependencies=(PolicyGradientEstimator,)) (update.jl:43-48)."""
+
+    pgmc_role = "update"
 
     def __init__(self, chains, dependencies=None, **extras):
         assert dependencies is not None and len(dependencies) == 1

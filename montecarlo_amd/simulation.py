@@ -240,6 +240,14 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
                     sim.t = t + n - 1
                     t += advance
                     continue
+            if fuse and len(due) in (2, 3):
+                n = _pgmc_group(sim, due, t)
+                if n:
+                    for k in due:
+                        sim.counters[k] += n
+                    sim.t = t + n - 1
+                    t += n
+                    continue
             for i, k in enumerate(due):                                             # :185-190
                 alg = sim.algorithms[k]
                 if getattr(alg, "fusable", False) and _observed_next(sim, due[i + 1:]):
@@ -260,6 +268,30 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
         for alg in sim.algorithms:                                                  # :196-198
             alg.finalise(sim)
         sim._finalise_summary()
+
+
+def _pgmc_group(simulation: Simulation, due: Sequence[int], t: int) -> int:
+    """If the algorithms due at ``t`` are exactly [fusable Metropolis, its device-resident estimator(, that
+    estimator's update)] in this order, issue the next n time steps with the same pattern (and nothing else due) as
+    ONE engine call and return n; 0 when the pattern does not apply."""
+    sim = simulation
+    algs = [sim.algorithms[k] for k in due]
+    if not getattr(algs[0], "fusable", False) or getattr(algs[1], "pgmc_role", None) != "estimator":
+        return 0
+    est = algs[1]
+    if getattr(est, "metropolis", None) is not algs[0]:
+        return 0
+    upd = None
+    if len(due) == 3:
+        upd = algs[2]
+        if getattr(upd, "pgmc_role", None) != "update" or getattr(upd, "estimator", None) is not est:
+            return 0
+    others = [d for j in range(len(sim.algorithms)) if j not in due for d in [_due(sim, j)] if d is not None]
+    t_last = min((min(others) - 1) if others else sim.steps, sim.steps)
+    n = min(_consecutive(sim.schedulers[k], sim.counters[k], t, t_last) for k in due)
+    if n < 1 or not hasattr(est, "make_steps_grouped"):
+        return 0
+    return n if est.make_steps_grouped(sim, n, upd) else 0
 
 
 def _observed_next(simulation: Simulation, later: Sequence[int]) -> bool:

@@ -398,6 +398,36 @@ class OracleEngine:
     def pg_estimate(self, learn_ids, q_batch):
         return self.sim.pg_estimate(learn_ids, q_batch)
 
+    # device-resident estimator / update of the HIP engine (amc_pg_accumulate / amc_pg_update / amc_pgmc_steps),
+    # restated on the host: running sums per move, learning step by the oracle's amo_learning_step
+    def pg_accumulate(self, learn_ids, q_batch):
+        gd = self.sim.pg_estimate(learn_ids, q_batch)
+        acc = self.__dict__.setdefault("_gd_acc", {})
+        for row, k in zip(gd, learn_ids):
+            acc[k] = acc.get(k, np.zeros(5)) + row
+        self.pgmc_calls = getattr(self, "pgmc_calls", 0)
+
+    def pg_update(self, learn_ids, kinds, hyper0, hyper1):
+        acc = self.__dict__.setdefault("_gd_acc", {})
+        names = {v: k for k, v in OPTIMISERS.items()}
+        for k, kind, h0, h1 in zip(learn_ids, kinds, hyper0, hyper1):
+            a = acc.get(k, np.zeros(5))
+            gd4 = [a[i] / a[4] for i in range(4)]
+            self.sim.set_sigma(k, learning_step(names[int(kind)], float(h0), float(h1), self.sim.get_sigma(k), gd4))
+            acc[k] = np.zeros(5)
+
+    def pg_get_accumulated(self, learn_ids):
+        acc = self.__dict__.setdefault("_gd_acc", {})
+        return np.array([acc.get(k, np.zeros(5)) for k in learn_ids]).reshape(len(learn_ids), 5)
+
+    def pgmc_steps(self, n_steps, learn_ids, q_batch, kinds=None, hyper0=(), hyper1=()):
+        self.pgmc_calls = getattr(self, "pgmc_calls", 0) + 1
+        for _ in range(int(n_steps)):
+            self.sweep(1)
+            self.pg_accumulate(learn_ids, q_batch)
+            if kinds is not None:
+                self.pg_update(learn_ids, kinds, hyper0, hyper1)
+
     def sync(self):
         pass
 

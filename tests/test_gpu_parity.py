@@ -530,3 +530,33 @@ def test_fused_sweep_and_callback_reduction(gpu, oracle, M, n, counters, K):
         e.sweep_reduce_begin(1)                 # only one reduction in flight
     e.reduce_end()
     e.close()
+
+
+@pytest.mark.parametrize("do_update", [False, True])
+def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update):
+    """amc_pgmc_steps(n) == n x [amc_sweep(1); amc_pg_accumulate; amc_pg_update]: same launches in the same order
+    (src/simulation.jl:185-190 runs the three algorithms back to back at every t), bit for bit."""
+    kw = dict(n_chains=40001, potential="harmonic", beta=2.0, sigma=[0.2, 0.1, 0.3], weight=[0.5, 0.25, 0.25], seed=19)
+    ids, kinds, h0, h1 = [1, 2], [1, 4], [0.5, 0.01], [0.0, 1e-6]            # VPG(0.5), NPG(0.01, 1e-6)
+    a, b = gpu.HipEngine(**kw), gpu.HipEngine(**kw)
+    for e in (a, b):
+        e.init_uniform(-2, 2)
+        e.sweep(2)
+    n = 37                                                                   # crosses a step-log fold
+    a.pgmc_steps(n, ids, 2, kinds if do_update else None, h0, h1)
+    for _ in range(n):
+        b.sweep(1)
+        b.pg_accumulate(ids, 2)
+        if do_update:
+            b.pg_update(ids, kinds, h0, h1)
+    assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
+    assert np.array_equal(bits(a.pg_get_accumulated(ids)), bits(b.pg_get_accumulated(ids)))
+    for k in range(3):
+        assert a.get_parameters(k)[0] == b.get_parameters(k)[0]
+    if do_update:
+        assert a.get_parameters(1)[0] != 0.1 and a.get_parameters(0)[0] == 0.2
+    acc_a, tot_a = a.download_counters()
+    acc_b, tot_b = b.download_counters()
+    assert np.array_equal(acc_a, acc_b) and np.array_equal(tot_a, tot_b)
+    assert a.step == b.step == 2 + n and a.estimator_step == b.estimator_step == n
+    a.close(); b.close()

@@ -210,3 +210,51 @@ def test_histogram_snapshots_and_exact_resume(oracle, tmp_path):
         other = build(tmp_path / "c", 10, pool())
         other.algorithms[0].seed = 12
         ma.restore(other.algorithms[0], str(tmp_path / "ckpt"))
+
+
+def _pgmc_sim(oracle, path, steps, update_sched=None, factory=None):
+    chains = ma.ParticleChains.uniform(12, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
+            ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+    upd = dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,))
+    if update_sched is not None:
+        upd["scheduler"] = update_sched
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=5, engine_factory=factory or oracle.OracleEngine),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.01)),
+               q_batch_size=2),
+          upd,
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
+               scheduler=ma.build_schedule(steps, 20, 25)))
+    return ma.Simulation(chains, al, steps, path=str(path)), pool
+
+
+@pytest.mark.parametrize("update_sched", [None, "every2"])
+def test_grouped_pgmc_steps_equal_stepwise(oracle, tmp_path, update_sched):
+    """run(fuse=True) issues [Metropolis, estimator, update] time steps as one engine call per run of such steps
+    (PGMC_harmonic_oscillator.jl:24-33 schedules all three every t); rows, state and sigma are those of fuse=False."""
+    steps = 120
+    sched = None if update_sched is None else ma.build_schedule(steps, 10, 2)       # pgmc_test.jl:38: update every 2
+    out = []
+    for i, fuse in enumerate((False, True)):
+        sim, pool = _pgmc_sim(oracle, tmp_path / str(i), steps, sched)
+        ma.run(sim, fuse=fuse)
+        out.append((open(tmp_path / str(i) / "energy.dat").read(), open(tmp_path / str(i) / "acceptance.dat").read(),
+                    sim.chains.x.copy(), pool[1].sigma, getattr(sim.algorithms[0].engine, "pgmc_calls", 0)))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+    assert out[0][3] != 0.1                          # the learnable sigma moved
+    assert out[0][4] == 0 and out[1][4] > 0          # only the fused run used the grouped call
+
+
+def test_grouped_pgmc_issues_few_engine_calls(oracle, tmp_path):
+    calls = []
+
+    class Counting(oracle.OracleEngine):
+        def pgmc_steps(self, n, *a, **k):
+            calls.append(n)
+            super().pgmc_steps(n, *a, **k)
+
+    sim, _ = _pgmc_sim(oracle, tmp_path, 100, factory=Counting)
+    ma.run(sim)
+    # callbacks at 20, 45, 70, 95, 100 cut the run into groups that end right before an observed step
+    assert sum(calls) == 100 - 5 and max(calls) == 24 and len(calls) <= 6

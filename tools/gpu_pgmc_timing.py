@@ -10,7 +10,7 @@ M = int(os.environ.get("M", 10_000_000)); steps = int(os.environ.get("STEPS", 30
 chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
 pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
         ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
-al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
+al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, download_on_finalise=False),   # time the step loop, not a 160 MB download
       dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.5)), q_batch_size=1),
       dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
       dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance), scheduler=ma.build_schedule(steps, 100, 10)))
