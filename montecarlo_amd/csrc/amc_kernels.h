@@ -179,10 +179,11 @@ struct SweepArgs {
     int32_t log_pos;              // row of the step log the first step of this launch writes
 };
 
-// The Philox results of one MH step of a pair (normal draw, accept draw, and for K > 1 the move pick): pure
-// functions of (seed, pair, step), so they can be formed before the pair's state has arrived from memory.
+// The Philox results of one MH step of a pair (normal draw, accept draw; for K > 1 the move pick takes the bits
+// the 52-bit maps leave unused in both): pure functions of (seed, pair, step), so they can be formed before the
+// pair's state has arrived from memory.
 struct StepDraws {
-    u32x4 normal, accept, pick;
+    u32x4 normal, accept;
 };
 
 template <bool MULTI>
@@ -191,8 +192,6 @@ __device__ __forceinline__ StepDraws step_draws(const SweepArgs& a, uint64_t pai
     StepDraws d;
     d.normal = philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1);
     d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
-    if (MULTI) d.pick = philox4x32_10(draw_counter(pair, t, DRAW_CATEGORICAL, STREAM_METROPOLIS), a.key0, a.key1);
-    else d.pick = u32x4{0u, 0u, 0u, 0u};
     return d;
 }
 
@@ -229,7 +228,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         if (MULTI) {
             // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
             // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
-            const double r0 = uniform32(dr.pick.x), r1 = uniform32(dr.pick.y);
+            const double r0 = uniform_pick(dr.normal.x, dr.accept.x), r1 = uniform_pick(dr.normal.z, dr.accept.z);
             for (int i = 0; i < K - 1; ++i) {
                 const double c = s_tab[3 * AMC_MAX_MOVES + i];
                 k0 += (c <= r0) ? 1 : 0;

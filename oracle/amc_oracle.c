@@ -87,10 +87,12 @@ double amo_angle_oc2(uint32_t lo, uint32_t hi)       /* (0,2]: 4 - d', d' in [2,
     return 4.0 - bits_to_12(lo, hi, 0x4000000000000000ull);
 }
 
-/* 32-bit uniform in [0,1) for the categorical move pick. */
-double amo_uniform32(uint32_t v)
+/* 24-bit uniform in [0,1) for the categorical move pick (metropolis.jl:206), from bits the 52-bit maps above
+ * leave unused: the low 12 bits of the chain's low word of the step's NORMAL draw (high half) and of its ACCEPT
+ * draw (low half).  No third Philox call per step (arithmetic spec v3). */
+double amo_uniform_pick(uint32_t normal_lo, uint32_t accept_lo)
 {
-    return (double)v * 0x1.0p-32;
+    return (double)(((normal_lo & 0xFFFu) << 12) | (accept_lo & 0xFFFu)) * 0x1.0p-24;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -390,17 +392,17 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
     const double *weights = s->weight;                             /* :204 */
     for (int i = 0; i < mc_steps; ++i) {                           /* :205 */
         uint64_t t = t0 + (uint64_t)i;
-        uint32_t v[4];
+        uint32_t v[4], va[4];
         int id = 0;
-        if (s->K > 1) {                                            /* :206 */
-            draw4(s, pair, t, AMO_DRAW_CATEGORICAL, AMO_STREAM_METROPOLIS, v);
-            id = amo_categorical(weights, s->K, amo_uniform32(v[half]));
-        }
-        double zz[2];
+        /* the step's two Philox draws are pure functions of (seed, pair, t): formed first, consumed in the
+         * reference's order -- categorical pick (:206), proposal normal, accept uniform */
         draw4(s, pair, t, AMO_DRAW_NORMAL, AMO_STREAM_METROPOLIS, v);
+        draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, va);
+        if (s->K > 1)                                              /* :206 */
+            id = amo_categorical(weights, s->K, amo_uniform_pick(v[2 * half], va[2 * half]));
+        double zz[2];
         amo_box_muller(v, zz);
-        draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, v);
-        double u = amo_uniform_co(v[2 * half], v[2 * half + 1]);
+        double u = amo_uniform_co(va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
         move->accepted_calls += mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
         move->total_calls += 1;                                    /* :209 */

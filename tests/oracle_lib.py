@@ -22,7 +22,7 @@ POTENTIALS = {"harmonic": 0, "double_well": 1}
 POT_CUSTOM = 2
 OPTIMISERS = {"Static": 0, "VPG": 1, "BLPG": 2, "BLAPG": 3, "NPG": 4, "ANPG": 5, "BLANPG": 6}
 STREAM_INIT, STREAM_METROPOLIS, STREAM_ESTIMATOR = 0, 1, 2
-DRAW_NORMAL, DRAW_ACCEPT, DRAW_CATEGORICAL = 0, 1, 2
+DRAW_NORMAL, DRAW_ACCEPT = 0, 1
 
 _lib = None
 
@@ -59,7 +59,7 @@ def load() -> C.CDLL:
         "amo_uniform_co": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_uniform_oc": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_angle_oc2": (C.c_double, [C.c_uint32, C.c_uint32]),
-        "amo_uniform32": (C.c_double, [C.c_uint32]),
+        "amo_uniform_pick": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_potential": (C.c_double, [C.c_int, C.c_double]),
         "amo_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),
         "amo_grad_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),

@@ -39,7 +39,7 @@ def test_draw_schedule_golden(oracle):
         lib = oracle.load()
         assert lib.amo_uniform_co(w[0], w[1]) == float.fromhex(d["u_co"][0])
         assert lib.amo_uniform_co(w[2], w[3]) == float.fromhex(d["u_co"][1])
-        assert lib.amo_uniform32(w[0]) == float.fromhex(d["u32"])
+        assert lib.amo_uniform_pick(w[0], w[2]) == float.fromhex(d["pick"])
 
 
 def test_counter_packing_is_rocrand_layout(oracle):
@@ -65,7 +65,10 @@ def test_uniform_maps(oracle):
     assert lib.amo_uniform_co((1 << 12) - 1, 0) == 0.0                       # low 12 bits of the low word unused
     assert lib.amo_uniform_oc(0, 0) == 1.0 and lib.amo_uniform_oc(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -52   # (0, 1]
     assert lib.amo_angle_oc2(0, 0) == 2.0 and lib.amo_angle_oc2(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -51     # (0, 2]
-    assert lib.amo_uniform32(0) == 0.0 and lib.amo_uniform32(0xFFFFFFFF) == 1.0 - 2.0 ** -32
+    # categorical pick: 12 spare bits of the normal draw's low word (high half), 12 of the accept draw's (low half)
+    assert lib.amo_uniform_pick(0, 0) == 0.0 and lib.amo_uniform_pick(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -24
+    assert lib.amo_uniform_pick(0xFFFFF000, 0xFFFFF000) == 0.0              # only bits the 52-bit maps do not use
+    assert lib.amo_uniform_pick(0x800, 0) == 0.5 and lib.amo_uniform_pick(0, 1) == 2.0 ** -24
     rnd = random.Random(7)
     for _ in range(2000):
         lo, hi = rnd.getrandbits(32), rnd.getrandbits(32)

@@ -34,8 +34,9 @@ M, steps = 37, 60
 chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
 pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
         ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+learn = ma.VPG(0.01) if os.environ.get("AMC_TEST_LEARN", "1") == "1" else ma.Static()
 al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, engine_factory=O.OracleEngine),
-      dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.01)), q_batch_size=2),
+      dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), learn), q_batch_size=2),
       dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=ma.build_schedule(steps, 10, 2)),
       dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance, ma.callback_moments),
            scheduler=ma.build_schedule(steps, 10, 5)))
@@ -57,12 +58,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(tmp_path, world):
-    out = tmp_path / f"w{world}"
+def run_world(tmp_path, world, learn=True):
+    out = tmp_path / f"w{world}{'L' if learn else 'S'}"
     out.mkdir()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", AMC_TEST_LEARN="1" if learn else "0")
     if world == 1:
         cmd = [sys.executable, str(script), str(out)]
     else:
@@ -78,8 +79,10 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     one = run_world(tmp_path, 1)[0]
     two = run_world(tmp_path, 2)
     assert two[0]["shard"] == [0, 20] and two[1]["shard"] == [20, 37]          # even boundary
-    # per-chain states: concatenated shards == the unsharded run, bit for bit
-    assert two[0]["x"] + two[1]["x"] == one["x"]
+    # per-chain states: sigma is learned from sums whose rounding depends on how the chains are split (the
+    # reference's own foldxt is order-unstable), so positions agree to rounding here; see the bit-exact test below
+    fx = lambda lst: np.array([float.fromhex(v) for v in lst])
+    np.testing.assert_allclose(fx(two[0]["x"] + two[1]["x"]), fx(one["x"]), rtol=1e-10, atol=1e-13)
     for r in two:
         # every rank sees the same global callback values
         assert [t for t, _ in r["energy"]] == [t for t, _ in one["energy"]]
@@ -91,3 +94,14 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
         assert r["sigma"][0] == 0.2 and r["sigma"][1] != 0.1
         assert r["accepted"] == one["accepted"] and r["total"] == one["total"]
     assert two[0]["energy"] == two[1]["energy"]
+
+
+@pytest.mark.slow
+def test_two_ranks_bit_exact_without_learning(tmp_path):
+    """With every optimiser Static nothing the chains see depends on a cross-shard sum: the concatenated shards equal
+    the unsharded run bit for bit (Philox keyed by the GLOBAL chain id)."""
+    one = run_world(tmp_path, 1, learn=False)[0]
+    two = run_world(tmp_path, 2, learn=False)
+    assert two[0]["x"] + two[1]["x"] == one["x"]
+    for r in two:
+        assert r["sigma"] == [0.2, 0.1] and r["accepted"] == one["accepted"] and r["total"] == one["total"]
