@@ -756,7 +756,14 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     const double dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = delta * delta;                        // reward, particle_1d.jl:42-44
     x = xn + (-delta);
-    const double alpha = julia_min(1.0, exp_f64((dlogp + logq) - logq, T));
+    // alpha = min(1, exp(arg)) with Julia's NaN-propagating min, without the generic guards: exp(arg >= 0) >= 1 and
+    // exp(arg <= 0) <= 1 hold exactly for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);
+    // arg < -708 -> 0;  NaN -> NaN.  Bit-identical to julia_min(1.0, exp_f64(arg)), 9 instead of 18 select/compare ops.
+    const double arg = (dlogp + logq) - logq;
+    double ex = exp_core_f64(arg, T);
+    asm volatile("" : "+v"(ex));          // keep the exp unconditional: no divergent branch around it
+    double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
+    alpha = (arg >= 0.0) ? 1.0 : alpha;
     const double j = r * alpha;
     g[0] += j;
     g[1] += j * dlogq;            // forward and backward gradients are bit-identical here
