@@ -253,3 +253,41 @@ def test_custom_potential_compile_error_reaches_the_caller(gpu):
     with pytest.raises(gpu.AmcError) as ei:
         gpu.HipEngine(n_chains=64, potential=CustomPotential("x * (2.0 +"), sigma=[0.1], weight=[1.0])
     assert "does not compile" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_custom_potential_at_full_size_statistics_and_speed(gpu):
+    """M = 1e7 chains in a tilted quartic well given as an expression: <U>, <x>, <x^2> against quadrature, and the
+    run-time compiled sweep is as fast as the offline kernels (potential(x) is the only code that differs)."""
+    import math
+    from scipy import integrate
+    M, beta = 10_000_000, 2.0
+    U = lambda x: x ** 4 - 2.0 * x * x + 0.25 * x
+    z = integrate.quad(lambda x: math.exp(-beta * U(x)), -4, 4)[0]
+    mean = lambda f: integrate.quad(lambda x: f(x) * math.exp(-beta * U(x)), -4, 4)[0] / z
+    e = gpu.HipEngine(n_chains=M, potential=CustomPotential(TILTED), beta=beta, sigma=[0.15, 1.2], weight=[0.5, 0.5], seed=4)
+    e.init_uniform(-2, 2)
+    e.sweep(600)
+    r = e.reduce()
+    assert r[0] / M == pytest.approx(mean(U), abs=2e-3)
+    assert r[1] / M == pytest.approx(mean(lambda x: x), abs=3e-3)
+    assert r[2] / M == pytest.approx(mean(lambda x: x * x), abs=3e-3)
+    e.close()
+
+    def us_per_sweep(pot):
+        eng = gpu.HipEngine(n_chains=M, potential=pot, beta=beta, sigma=[0.1], weight=[1.0], seed=1, per_chain_counters=False)
+        eng.init_uniform(-2, 2)
+        for _ in range(300):
+            eng.sweep(1)
+        eng.sync()
+        best = 1e9
+        for _ in range(3):
+            eng.timing_begin()
+            for _ in range(300):
+                eng.sweep(1)
+            best = min(best, eng.timing_end() / 300 * 1e3)
+        eng.close()
+        return best
+    t_builtin, t_custom = us_per_sweep("harmonic"), us_per_sweep(CustomPotential("x*x"))
+    print(f"sweep us: offline harmonic {t_builtin:.1f}, hiprtc x*x {t_custom:.1f}")
+    assert t_custom < 1.10 * t_builtin
