@@ -120,7 +120,9 @@ int  amc_destroy(amc_handle *h);
  * results on any IEEE-754 host: + - * / (never contracted into fma), sqrt, fabs, fma, and the engine's own
  * amc_exp / amc_log.  Other device math functions (exp, sin, pow ...) compile too but
  * are only accurate to the device library's ulps.  Allowed characters: printable ASCII except # \ ; { } " ' ` $ @.
- * A malformed expression fails here with the compiler's first diagnostics in amc_last_error(). */
+ * A malformed expression fails here with the compiler's first diagnostics in amc_last_error().
+ * Environment: AMC_RTC_CACHE_DIR=<dir> keeps the compiled code objects on disk (one file per expression and kernel
+ * form, keyed by a hash that includes the kernel sources), so later processes skip the compile. */
 int  amc_create_custom(const amc_config *cfg, const char *potential_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
 int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);

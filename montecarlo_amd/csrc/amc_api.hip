@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -314,6 +315,60 @@ int validate_potential_expr(const char* expr)
     return AMC_OK;
 }
 
+// Optional on-disk cache of compiled code objects (AMC_RTC_CACHE_DIR; unset = in-process cache only): one file per
+// (expression, instantiation, kernel sources), named by a 64-bit FNV-1a hash of all three, holding the lowered name
+// and the code object.  A corrupt or truncated file is ignored and recompiled.
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string rtc_cache_path(const std::string& expr, const std::string& inst)
+{
+    const char* dir = std::getenv("AMC_RTC_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    uint64_t h = fnv1a(expr);
+    h = fnv1a(inst, h ^ 0x9E3779B97F4A7C15ull);
+    h = fnv1a(AMC_RTC_SRC_KERNELS, h);
+    h = fnv1a(AMC_RTC_SRC_MATH, h);
+    h = fnv1a(AMC_RTC_SRC_TABLES, h);
+    char name[64];
+    std::snprintf(name, sizeof(name), "/amc_rtc_%016llx.bin", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+
+bool rtc_cache_load(const std::string& path, RtcCode* out)
+{
+    if (path.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t hdr[3] = {0, 0, 0};                       // magic, name length, code length
+    bool ok = std::fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == 0x31435452434d41ull && hdr[1] > 0 && hdr[1] < 4096 &&
+              hdr[2] > 0 && hdr[2] < (1ull << 30);
+    if (ok) {
+        out->lowered.resize((size_t)hdr[1]);
+        out->code.resize((size_t)hdr[2]);
+        ok = std::fread(&out->lowered[0], 1, (size_t)hdr[1], f) == hdr[1] &&
+             std::fread(out->code.data(), 1, (size_t)hdr[2], f) == hdr[2] && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+void rtc_cache_store(const std::string& path, const RtcCode& rc)
+{
+    if (path.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;                                    // an unwritable cache directory is not an error
+    const uint64_t hdr[3] = {0x31435452434d41ull, rc.lowered.size(), rc.code.size()};
+    const bool ok = std::fwrite(hdr, sizeof(hdr), 1, f) == 1 && std::fwrite(rc.lowered.data(), 1, rc.lowered.size(), f) == rc.lowered.size() &&
+                    std::fwrite(rc.code.data(), 1, rc.code.size(), f) == rc.code.size();
+    std::fclose(f);
+    if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());   // atomic publish
+}
+
 // Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
 // Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
 int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode** out, std::string* log_out)
@@ -322,6 +377,15 @@ int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode*
     const std::string key = expr + "\n" + inst;
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
+    const std::string cache_file = rtc_cache_path(expr, inst);
+    {
+        RtcCode cached;
+        if (rtc_cache_load(cache_file, &cached)) {
+            if (log_out) log_out->clear();
+            *out = &g_rtc_code.emplace(key, std::move(cached)).first->second;
+            return AMC_OK;
+        }
+    }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     const std::string src = "#define AMC_USER_POTENTIAL(x) (" + expr + ")\n#include \"amc_kernels.h\"\n";
     const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES};
@@ -357,6 +421,7 @@ int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode*
     g_hiprtc.GetCode(prog, rc.code.data());
     rc.lowered = lowered;
     g_hiprtc.DestroyProgram(&prog);
+    rtc_cache_store(cache_file, rc);
     *out = &g_rtc_code.emplace(key, std::move(rc)).first->second;
     return AMC_OK;
 }

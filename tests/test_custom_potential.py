@@ -291,3 +291,26 @@ def test_custom_potential_at_full_size_statistics_and_speed(gpu):
     t_builtin, t_custom = us_per_sweep("harmonic"), us_per_sweep(CustomPotential("x*x"))
     print(f"sweep us: offline harmonic {t_builtin:.1f}, hiprtc x*x {t_custom:.1f}")
     assert t_custom < 1.10 * t_builtin
+
+
+def test_disk_cache_of_compiled_potentials(amc, tmp_path, monkeypatch):
+    """AMC_RTC_CACHE_DIR: a second PROCESS finds the code object on disk instead of compiling (needs no GPU)."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from montecarlo_amd import _capi as A\n"
+            "t = time.perf_counter(); A.potential_check('x*x*x + 0.125*x - 3.0'); print(time.perf_counter() - t)\n" % root)
+    env = dict(os.environ, AMC_RTC_CACHE_DIR=str(tmp_path))
+    times = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        times.append(float(r.stdout.strip().splitlines()[-1]))
+    files = [f for f in os.listdir(tmp_path) if f.startswith("amc_rtc_") and f.endswith(".bin")]
+    assert len(files) == 1 and os.path.getsize(tmp_path / files[0]) > 10_000
+    assert times[1] < 0.5 * times[0]                     # a file read instead of a compile
+    # a damaged entry is recompiled, not trusted
+    with open(tmp_path / files[0], "r+b") as f:
+        f.truncate(100)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and os.path.getsize(tmp_path / files[0]) > 10_000
