@@ -179,4 +179,57 @@ function set_parameters!(alg::HIPMetropolis, k::Int, parameters)
     check(ccall((:amc_set_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), alg.handle, k - 1, p, 1))
 end
 
+# kw-constructor in the shape Simulation builds algorithms with (src/simulation.jl:76-83; estimator.jl:103-109):
+# `dependencies=(HIPMetropolis,)` arrives as the previously built instance.
+function HIPPolicyGradientEstimator(chains; dependencies=missing, optimisers=missing, q_batch_size=1, extras...)
+    @assert length(dependencies) == 1
+    @assert isa(dependencies[1], HIPMetropolis)
+    metropolis = dependencies[1]
+    @assert length(optimisers) == metropolis.K                                   # estimator.jl:70
+    learn_ids = [k for k in eachindex(optimisers) if !isa(optimisers[k], PolicyGuided.Static)]   # :72
+    parameters_list = [move.parameters for move in metropolis.pools[1]]
+    gradients_data = map(k -> PolicyGuided.initialise_gradient_data(parameters_list[k]), learn_ids)   # :84
+    return HIPPolicyGradientEstimator(metropolis, optimisers, learn_ids, q_batch_size, gradients_data,
+                                      zeros(Float64, length(learn_ids)))
+end
+
+"""
+    HIPPolicyGradientUpdate(chains; dependencies=(HIPPolicyGradientEstimator,))
+
+Mirror of PolicyGradientUpdate (update.jl:43-57): `average` -> the STOCK `learning_step!` (learning.jl:32-164) on the
+shared `parameters` arrays -> reset, then the new sigma is pushed to the device copy (`amc_set_parameters`).
+"""
+struct HIPPolicyGradientUpdate{E} <: Arianna.AriannaAlgorithm
+    estimator::E
+end
+
+function HIPPolicyGradientUpdate(chains; dependencies=missing, extras...)
+    @assert length(dependencies) == 1
+    @assert isa(dependencies[1], HIPPolicyGradientEstimator)
+    return HIPPolicyGradientUpdate(dependencies[1])
+end
+
+function make_step!(::Simulation, alg::HIPPolicyGradientUpdate)
+    est = alg.estimator
+    parameters_list = [move.parameters for move in est.metropolis.pools[1]]     # aliased across chains, metropolis.jl:252-260
+    for (k, lid) in enumerate(est.learn_ids)
+        gd = PolicyGuided.average(est.gradients_data[k])                         # update.jl:52
+        PolicyGuided.learning_step!(parameters_list[lid], gd, est.optimisers[lid])   # :53
+        est.gradients_data[k] = PolicyGuided.initialise_gradient_data(parameters_list[lid])   # :54
+        set_parameters!(est.metropolis, lid, parameters_list[lid])
+    end
+    return nothing
+end
+
+# Device-resident alternative for long PGMC runs: n x [sweep; estimator; update] from ONE ccall (amc_pgmc_steps):
+# gradients_data and the learning step stay on the GPU.  optimiser ids / hyper-parameters as in amc.h (amc_optimiser).
+function pgmc_steps!(metropolis::HIPMetropolis, n::Integer, learn_ids::Vector{Int}, q_batch::Integer,
+                     optimiser::Vector{Cint}, hyper0::Vector{Float64}, hyper1::Vector{Float64})
+    ids = Cint[k - 1 for k in learn_ids]
+    check(ccall((:amc_pgmc_steps, libamc), Cint,
+                (Ptr{Cvoid}, Int64, Cint, Ptr{Cint}, Cint, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
+                metropolis.handle, n, length(ids), ids, q_batch, 1, optimiser, hyper0, hyper1))
+    return nothing
+end
+
 end # module
