@@ -62,6 +62,7 @@ struct Rccl {
 }  // namespace
 
 static const int RED_HOST_STRIDE = 8;   // doubles per row of the host-summed partials (one 64-byte write)
+static const int RATIO_STRIDE = 4;      // doubles per row of the fold's acceptance-ratio partials (K <= 4)
 
 struct amc_handle {
     int device = 0;
@@ -92,6 +93,8 @@ struct amc_handle {
     double* h_partials = nullptr;    // pinned [n_slots][RED_HOST_STRIDE]: block partials the HOST sums (4 + K <= 8)
     int red_rows = 0;                // rows of the reduction in flight
     bool red_host = false;           // ... and whether they sit in h_partials
+    double* h_ratio = nullptr;       // pinned [n_slots][RATIO_STRIDE]: acceptance-ratio partials of a fold (K <= 4)
+    int red_ratio_rows = 0;          // rows of h_ratio that belong to the reduction in flight (0: none)
     double* d_out = nullptr;
     double* h_out = nullptr;    // pinned
     int red_blocks = 0;
@@ -166,19 +169,32 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 
 // Adds the pending rows of the step log into the per-chain counters (on the stream).  Everything that reads or
 // replaces d_acc / d_tot calls this first.
-int fold_log(amc_handle* h)
+// with_ratio (K <= 4): the launch also leaves callback_acceptance's per-move sums as block partials in h_ratio
+// (rows = its grid; *ratio_rows receives the count) and runs even when no log row is pending.
+int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
 {
-    if (!h->d_log || h->log_fill == 0) return AMC_OK;
+    if (!h->d_log || (h->log_fill == 0 && !with_ratio)) return AMC_OK;
     const int grid = grid_for(h, (h->M + 3) / 4);
-#define AMC_FOLD(KS)                                                                                                  \
-    hipLaunchKernelGGL(amc::fold_log_kernel<KS>, dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, h->d_log, \
-                       h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K)
-    switch (h->K) {
-    case 1: AMC_FOLD(1); break;
-    case 2: AMC_FOLD(2); break;
-    case 3: AMC_FOLD(3); break;
-    case 4: AMC_FOLD(4); break;
-    default: AMC_FOLD(0); break;
+#define AMC_FOLD(KS, RATIO)                                                                                           \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+    if (with_ratio) {
+        switch (h->K) {
+        case 1: AMC_FOLD(1, true); break;
+        case 2: AMC_FOLD(2, true); break;
+        case 3: AMC_FOLD(3, true); break;
+        case 4: AMC_FOLD(4, true); break;
+        default: return fail(AMC_ERR_STATE, "fold_log: ratio sums ride on the K <= 4 fold only");
+        }
+        if (ratio_rows) *ratio_rows = grid;
+    } else {
+        switch (h->K) {
+        case 1: AMC_FOLD(1, false); break;
+        case 2: AMC_FOLD(2, false); break;
+        case 3: AMC_FOLD(3, false); break;
+        case 4: AMC_FOLD(4, false); break;
+        default: AMC_FOLD(0, false); break;
+        }
     }
 #undef AMC_FOLD
     AMC_HIP(hipGetLastError());
@@ -186,22 +202,30 @@ int fold_log(amc_handle* h)
     return AMC_OK;
 }
 
-template <int POT>
-int launch_sweep_reduce(amc_handle* h, const amc::SweepArgs& a, int grid)
+template <int POT, bool MULTI, bool LOG>
+int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     if (a.n_steps == 1) {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     } else {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     }
     AMC_HIP(hipGetLastError());
     return AMC_OK;
+}
+
+template <int POT>
+int launch_sweep_reduce(amc_handle* h, const amc::SweepArgs& a, int grid)
+{
+    if (h->K > 1) return launch_sweep_reduce_ml<POT, true, true>(h, a, grid);
+    if (h->counters) return launch_sweep_reduce_ml<POT, false, true>(h, a, grid);
+    return launch_sweep_reduce_ml<POT, false, false>(h, a, grid);
 }
 
 template <int POT>
@@ -608,6 +632,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * per_block * sizeof(double)));
     }
     AMC_TRY(hipHostMalloc((void**)&h->h_partials, (size_t)h->n_cu * h->blocks_per_cu * RED_HOST_STRIDE * sizeof(double), 0));
+    AMC_TRY(hipHostMalloc((void**)&h->h_ratio, (size_t)h->n_cu * h->blocks_per_cu * RATIO_STRIDE * sizeof(double), 0));
     AMC_TRY(hipMalloc(&h->d_partials2, (size_t)32 * (4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
     AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
     AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double), 0));
@@ -682,6 +707,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_partials);
     (void)hipFree(h->d_partials2);
     if (h->h_partials) (void)hipHostFree(h->h_partials);
+    if (h->h_ratio) (void)hipHostFree(h->h_ratio);
     (void)hipFree(h->d_out);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1035,16 +1061,26 @@ int amc_reduce_begin(amc_handle* h)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_reduce_begin: NULL handle");
     if (h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
     AMC_HIP(hipSetDevice(h->device));
-    const int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
+    int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
     const int n_vals = 4 + h->K;
-    if (ratio_mode != 0) { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
+    h->red_ratio_rows = 0;
+    if (ratio_mode != 0 && h->K <= 4) {
+        // per-chain counters, few moves: the fold of the step log forms the acceptance-ratio sums while the counters
+        // are in its registers (rows in h_ratio); the pass below then reads x only
+        const int rc = fold_log(h, true, &h->red_ratio_rows);
+        if (rc != AMC_OK) return rc;
+        ratio_mode = 0;
+    } else if (ratio_mode != 0) {
+        const int rc = fold_log(h);
+        if (rc != AMC_OK) return rc;
+    }
     // Few columns (K <= 4): the blocks store their partial rows straight into pinned, device-mapped host memory
     // and the HOST forms the column sums in amc_reduce_end -- no final-pass launches (~5 us each even when empty)
     // and no D2H copy in stream order (which would hold the next sweep back for a copy-engine round trip).
     const bool host = n_vals <= RED_HOST_STRIDE;
     double* rows = host ? h->h_partials : h->d_partials;
     const int stride = host ? RED_HOST_STRIDE : n_vals;
-    const unsigned long long* slots = (host && ratio_mode == 0) ? h->d_acc_slots : nullptr;
+    const unsigned long long* slots = (host && ratio_mode == 0 && h->red_ratio_rows == 0) ? h->d_acc_slots : nullptr;
     if (h->potential == AMC_POTENTIAL_CUSTOM) {
         const double* d_x = h->d_x;
         const uint32_t *d_acc = h->d_acc, *d_tot = h->d_tot;
@@ -1081,13 +1117,20 @@ int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
     if (h->red_pending) return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
-    if (h->K > 1 || h->counters) {          // no fused form: sweep, then the ordinary reduction pass
+    if (h->K > 4) {                         // wide rows: sweep, then the ordinary reduction passes
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
     int grid = 0;
-    const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote h_partials[grid][8]
+    const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote the sums over x to h_partials[grid][8]
     if (rc != AMC_OK) return rc;
+    h->red_ratio_rows = 0;
+    if (h->counters) {
+        // per-chain counters: the fold of the step log (pending rows incl. this sweep's) forms the ratio sums -- no
+        // pass re-reads x or the counters
+        const int rc2 = fold_log(h, true, &h->red_ratio_rows);
+        if (rc2 != AMC_OK) return rc2;
+    }
     AMC_HIP(hipEventRecord(h->ev_red, h->stream));
     h->red_pending = true;
     h->red_host = true;
@@ -1108,9 +1151,14 @@ int amc_reduce_end(amc_handle* h, double* out)
     if (h->red_host) {
         // fixed order: rows 0, 1, 2, ... per column (a function of the grid only)
         double acc[RED_HOST_STRIDE] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const int n_cols = h->red_ratio_rows > 0 ? 4 : n_vals;       // columns 4.. come from the fold's rows
         for (int r = 0; r < h->red_rows; ++r) {
             const double* row = h->h_partials + (size_t)r * RED_HOST_STRIDE;
-            for (int i = 0; i < n_vals; ++i) acc[i] += row[i];
+            for (int i = 0; i < n_cols; ++i) acc[i] += row[i];
+        }
+        for (int r = 0; r < h->red_ratio_rows; ++r) {
+            const double* row = h->h_ratio + (size_t)r * RATIO_STRIDE;
+            for (int k = 0; k < h->K; ++k) acc[4 + k] += row[k];
         }
         for (int i = 0; i < n_vals; ++i) out[i] = acc[i];
         slot_total = acc[4];                     // K == 1, pool-wide counter: exact (integers below 2^53)

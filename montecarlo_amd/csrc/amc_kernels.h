@@ -259,12 +259,14 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
 // LOG: per-chain counters are kept (always when K > 1): one step-log byte per chain and MH step
 // BETA: per-chain beta array
 // SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
-// REDUCE (K == 1, pool-wide counter only): also leave the callback sums of the state AFTER the sweep in
-//         red_partials, so a sweep that is followed by callback_energy / callback_acceptance needs no second pass
+// REDUCE: also leave the callback sums of the state AFTER the sweep in red_partials (sum e, sum x, sum x^2, count;
+//         and, pool-wide counter only, the accepted total), so a sweep that is followed by callback_energy /
+//         callback_acceptance needs no second pass over x
 template <int POT, bool MULTI, bool LOG, bool BETA, bool SINGLE, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
-    static_assert(!REDUCE || (!MULTI && !LOG), "the fused reduction has no per-chain acceptance ratios");
+    // REDUCE with LOG (per-chain counters): rows carry the sums over x only; the acceptance ratios of the same
+    // callback come from the fold of the step log that follows (fold_log_kernel<KS, true>)
     static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         if (threadIdx.x == 0) {
             unsigned long long t = 0;
             for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc[w];
-            if (REDUCE) {
+            if (REDUCE && !LOG) {
                 // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
                 // value after this launch (exact in a double below 2^53); the rows are summed by the host
                 const unsigned long long now =
@@ -400,13 +402,22 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 // (tot == nullptr when K == 1: total_calls is the step count).  KS > 0: K == KS <= 4, four chains per thread with
 // the deltas in registers (u32 log loads, 16-byte counter accesses); KS == 0: any K, one chain per thread, one
 // read-modify-write per logged step.  Entries of the padding behind n_chains are never interpreted as moves.
-template <int KS>
+// RATIO (KS > 0): the counters are in registers right after the update, so the launch also forms
+// callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
+// 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
+// total_ck is t_counted on every chain when K == 1 (tot == nullptr).
+template <int KS, bool RATIO = false>
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, uint32_t* acc,
                                                               uint32_t* tot, int64_t n_chains, int64_t m_stride,
-                                                              int n_moves)
+                                                              int n_moves, uint64_t t_counted, double* ratio_partials,
+                                                              int rp_stride)
 {
+    static_assert(!RATIO || KS > 0, "ratio sums ride on the register-resident fold");
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     if (KS > 0) {
+        double ratio[KS > 0 ? KS : 1];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) ratio[k] = 0.0;
         const int64_t n_quads = (n_chains + 3) >> 2;          // m_stride is a multiple of 4 with >= 4 of padding
         for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
             uint32_t da[KS > 0 ? KS : 1][4], dt[KS > 0 ? KS : 1][4];
@@ -433,14 +444,23 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                 uint4 va = *pa;
                 va.x += da[k][0]; va.y += da[k][1]; va.z += da[k][2]; va.w += da[k][3];
                 *pa = va;
+                uint4 vt = {0u, 0u, 0u, 0u};
                 if (tot) {
                     uint4* pt = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + 4 * q);
-                    uint4 vt = *pt;
+                    vt = *pt;
                     vt.x += dt[k][0]; vt.y += dt[k][1]; vt.z += dt[k][2]; vt.w += dt[k][3];
                     *pt = vt;
                 }
+                if (RATIO) {
+                    const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j < n_chains)             // the padding behind the last chain has no ratio
+                            ratio[k] += (double)a4[j] / (tot ? (double)t4[j] : (double)t_counted);
+                }
             }
         }
+        if (RATIO) block_sum_store<(KS > 0 ? KS : 1)>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
     } else {
         for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
             for (int r = 0; r < n_rows; ++r) {
