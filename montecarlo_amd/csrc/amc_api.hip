@@ -234,25 +234,29 @@ int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
     return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
 }
 
-template <int POT, int NL>
-int launch_pg_nl(amc_handle* h, const amc::PgArgs& a, int grid)
+template <int POT, int NL, int SWEEP>
+int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid)
 {
     if (h->beta_arr)
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     else
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false, SWEEP>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     AMC_HIP(hipGetLastError());
     return AMC_OK;
 }
 
+// sweep: 0 = estimator only; 1 / 2 = preceded by one make_step!(::Metropolis) in the same launch (K == 1 / K > 1;
+// offered for up to 2 learnable moves, see pg_fusable)
 template <int POT>
-int launch_pg(amc_handle* h, const amc::PgArgs& a, int grid, int nl_cap)
+int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep)
 {
+    if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1>(h, a, sw, grid);
+    if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2>(h, a, sw, grid);
     switch (nl_cap) {
-    case 1: return launch_pg_nl<POT, 1>(h, a, grid);
-    case 2: return launch_pg_nl<POT, 2>(h, a, grid);
-    case 4: return launch_pg_nl<POT, 4>(h, a, grid);
-    default: return launch_pg_nl<POT, 8>(h, a, grid);
+    case 1: return launch_pg_nls<POT, 1, 0>(h, a, sw, grid);
+    case 2: return launch_pg_nls<POT, 2, 0>(h, a, sw, grid);
+    case 4: return launch_pg_nls<POT, 4, 0>(h, a, sw, grid);
+    default: return launch_pg_nls<POT, 8, 0>(h, a, sw, grid);
     }
 }
 
@@ -487,10 +491,11 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
     return rtc_launch(h, inst, grid, params);
 }
 
-int launch_pg_custom(amc_handle* h, amc::PgArgs& a, int grid, int nl_cap)
+int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep)
 {
-    const std::string inst = "amc::pg_estimate_kernel<2," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + ">";
-    void* params[] = {&a};
+    const std::string inst = "amc::pg_estimate_kernel<2," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
+                             std::to_string(sweep) + ">";
+    void* params[] = {&a, &sw};
     return rtc_launch(h, inst, grid, params);
 }
 
@@ -844,6 +849,29 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     return AMC_OK;
 }
 
+static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
+{
+    amc::SweepArgs a;
+    a.x = h->d_x;
+    a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
+    a.log = h->d_log;
+    a.log_pos = h->log_fill;
+    a.ptab = h->d_ptab;
+    a.acc_total = h->d_acc_slots;
+    a.n_chains = h->M;
+    a.m_stride = h->M_pad;
+    a.pair0 = (uint64_t)h->offset >> 1;
+    a.t0 = h->t;
+    a.n_steps = n_steps;
+    a.n_moves = h->K;
+    a.key0 = (uint32_t)h->seed;
+    a.key1 = (uint32_t)(h->seed >> 32);
+    a.beta = h->beta;
+    a.red_partials = h->h_partials;
+    a.red_stride = RED_HOST_STRIDE;
+    return a;
+}
+
 // n_sweeps x sweepstep MH steps in launches of at most 2^20 steps; when fuse_reduce is set (streamed form
 // only) the LAST launch also leaves the callback partial sums of the final state in h_partials[grid][8].
 static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* grid_out)
@@ -861,24 +889,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
             }
             if (chunk > h->log_depth - h->log_fill) chunk = h->log_depth - h->log_fill;
         }
-        amc::SweepArgs a;
-        a.x = h->d_x;
-        a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
-        a.log = h->d_log;
-        a.log_pos = h->log_fill;
-        a.ptab = h->d_ptab;
-        a.acc_total = h->d_acc_slots;
-        a.n_chains = h->M;
-        a.m_stride = h->M_pad;
-        a.pair0 = (uint64_t)h->offset >> 1;
-        a.t0 = h->t;
-        a.n_steps = chunk;
-        a.n_moves = h->K;
-        a.key0 = (uint32_t)h->seed;
-        a.key1 = (uint32_t)(h->seed >> 32);
-        a.beta = h->beta;
-        a.red_partials = h->h_partials;
-        a.red_stride = RED_HOST_STRIDE;
+        amc::SweepArgs a = make_sweep_args(h, chunk);
         const bool last = remaining == chunk;
         int rc;
         if (h->potential == AMC_POTENTIAL_CUSTOM)
@@ -1210,8 +1221,9 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 // Validates, launches K3 over this shard and leaves sum_{chains x q} (j, grad j, grad logq, g) per learnable
 // move in h->d_out[l*4 + i] (device, on the stream).  Shared by the host- and device-resident estimator paths.
 // tail: 1 = sums only, 2 = + gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
+// with_sweep: the launch first does one make_step!(::Metropolis) (caller checked pg_fusable).
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
-                     int tail = 1, const amc::PgOpts* opt = nullptr)
+                     int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false)
 {
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
@@ -1251,10 +1263,21 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     const int nl = nl_capacity(n_learn);
     int grid = grid_for(h, (h->M + 1) / 2);
     if (grid > h->red_blocks) grid = h->red_blocks;
-    const int rc = (h->potential == AMC_POTENTIAL_CUSTOM)        ? launch_pg_custom(h, a, grid, nl)
-                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, grid, nl)
-                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, grid, nl);
+    int sweep = 0;
+    if (with_sweep) {
+        if (h->log_fill == h->log_depth) { const int rcf = fold_log(h); if (rcf != AMC_OK) return rcf; }
+        sweep = h->K > 1 ? 2 : 1;
+    }
+    amc::SweepArgs sw = make_sweep_args(h, 1);
+    const int rc = (h->potential == AMC_POTENTIAL_CUSTOM)        ? launch_pg_custom(h, a, sw, grid, nl, sweep)
+                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep)
+                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep);
     if (rc != AMC_OK) return rc;
+    if (with_sweep) {
+        h->t += 1;
+        h->t_counted += 1;
+        h->log_fill += 1;
+    }
     // the launch itself left sum_{blocks} partials[grid][nl][4] in d_out[nl*4] (in-kernel final reduction)
     h->t_est += 1;
     *nl_out = nl;
@@ -1287,11 +1310,12 @@ static amc::PgIds make_ids(int n_learn, const int* learn_ids)
 // (opt != nullptr).  Single shard: ONE launch (the estimator kernel's last block folds, accumulates and, if asked,
 // takes the learning step).  Shards connected by amc_comm_init: estimator launch, in-place all-reduce, then the
 // small accumulate (and update) kernels.
-static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, const amc::PgOpts* opt)
+static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, const amc::PgOpts* opt,
+                              bool with_sweep = false)
 {
     int nl = 0;
     const int tail = h->comm ? 1 : (opt ? 3 : 2);
-    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt);
+    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep);
     if (rc != AMC_OK || n_learn == 0) return rc;
     if (!h->comm) return AMC_OK;
     // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
@@ -1361,9 +1385,14 @@ int amc_pgmc_steps(amc_handle* h, int64_t n_steps, int n_learn, const int* learn
     }
     // the three make_step!s of one time step (src/simulation.jl:185-190), n_steps times, from one host call: two
     // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
+    // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, per-chain counters
+    // (step log), at most two learnable moves (the kernel forms offered with a leading sweep)
+    const bool fused = h->sweepstep == 1 && h->d_log != nullptr && n_learn >= 1 && n_learn <= 2 &&
+                       std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     for (int64_t i = 0; i < n_steps; ++i) {
-        int rc = sweep_impl(h, 1, false, nullptr);
-        if (rc == AMC_OK) rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr);
+        int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);
+        if (rc == AMC_OK)
+            rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr, fused);
         if (rc != AMC_OK) return rc;
     }
     return AMC_OK;

@@ -398,6 +398,20 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     }
 }
 
+// The same pool-wide bookkeeping for kernels that run an MH step without being the sweep kernel (K == 1 only).
+__device__ __forceinline__ void add_block_accepts(unsigned long long* acc_total, unsigned long long wave_acc)
+{
+    __shared__ unsigned long long s_acc2[AMC_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) s_acc2[threadIdx.x >> 6] = wave_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc2[w];
+        if (t != 0) __hip_atomic_fetch_add(acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
 // Adds `n_rows` rows of the step log into the per-chain u32 counters acc[K][m_stride] / tot[K][m_stride]
 // (tot == nullptr when K == 1: total_calls is the step count).  KS > 0: K == KS <= 4, four chains per thread with
 // the deltas in registers (u32 log loads, 16-byte counter accesses); KS == 0: any K, one chain per thread, one
@@ -811,12 +825,38 @@ __device__ __forceinline__ double ordered_column_sum(const double* rows, int n_r
 }
 
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
-template <int POT, int NL, bool BETA>
-__global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
+// SWEEP != 0: the launch first performs ONE make_step!(::Metropolis) of sweepstep = 1 on the pair it has just loaded
+// (1: K == 1, 2: K > 1; per-chain counters through the step log in both) -- run! calls the two algorithms back to
+// back at the same t (src/simulation.jl:185-190), and x then makes one HBM round trip for both instead of two.
+// Per chain the operations and their order are those of the two separate launches.
+template <int POT, int NL, bool BETA, int SWEEP = 0>
+__global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     // the math tables; after the sampling loop the same LDS stages the rows of the in-kernel final reduction
     constexpr int SCRATCH = (PG_GROUP * NL * 4 > TAB_DOUBLES) ? PG_GROUP * NL * 4 : TAB_DOUBLES;
     __shared__ double s_math[SCRATCH];
+    __shared__ double s_tab[SWEEP == 2 ? 5 * AMC_MAX_MOVES : 1];
+    if (SWEEP == 2) {
+        for (int i = threadIdx.x; i < sw.n_moves; i += AMC_BLOCK) {
+            s_tab[0 * AMC_MAX_MOVES + i] = sw.ptab[PT_SIGMA * AMC_MAX_MOVES + i];
+            s_tab[1 * AMC_MAX_MOVES + i] = sw.ptab[PT_DEN * AMC_MAX_MOVES + i];
+            s_tab[2 * AMC_MAX_MOVES + i] = sw.ptab[PT_LOGC * AMC_MAX_MOVES + i];
+            s_tab[3 * AMC_MAX_MOVES + i] = sw.ptab[PT_CUM * AMC_MAX_MOVES + i];
+            s_tab[4 * AMC_MAX_MOVES + i] = sw.ptab[PT_RDEN * AMC_MAX_MOVES + i];
+        }
+    }
+    const double sw_sigma1 = SWEEP ? sw.ptab[PT_SIGMA * AMC_MAX_MOVES] : 0.0;
+    const double sw_den1 = SWEEP ? sw.ptab[PT_DEN * AMC_MAX_MOVES] : 0.0;
+    const double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
+    const double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
+    unsigned long long wave_acc = 0;
+    // one mc_step! of the pair (mc_sweep! with mc_steps = 1), its step-log byte pair stored right away
+    auto mh = [&](double2& xv, double b0, double b1, uint64_t pair, int64_t p, bool v0, bool v1) {
+        uint32_t lw = 0;
+        pair_steps<POT, SWEEP == 2, true, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_math, sw_sigma1, sw_den1,
+                                                sw_rden1, sw_logc1, wave_acc, lw);
+        if (v0) store_log_pair(sw, sw.log_pos, p, lw);
+    };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     double g[NL][4];
@@ -870,6 +910,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
         x_nxt = load_x(base + stride);
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
         samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true);
         x_done = xv;
         base_done = base;
@@ -880,11 +921,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a)
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
         double2 xv = x_nxt;
         if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
         if (v0) {
             samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, v1);
             store_pair_writethrough(a.x + 2 * p, xv);        // a lone last chain writes its whole pair: padding
         }
     }
+    if (SWEEP == 1) add_block_accepts(sw.acc_total, wave_acc);   // K == 1: the pool-wide accepted total (counter_totals)
     // Block partial sums -> row blockIdx.x of partials[grid][NL][4].  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
     // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /

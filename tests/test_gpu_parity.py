@@ -533,14 +533,37 @@ def test_fused_sweep_and_callback_reduction(gpu, oracle, M, n, counters, K):
 
 
 @pytest.mark.parametrize("do_update", [False, True])
-def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update):
-    """amc_pgmc_steps(n) == n x [amc_sweep(1); amc_pg_accumulate; amc_pg_update]: same launches in the same order
-    (src/simulation.jl:185-190 runs the three algorithms back to back at every t), bit for bit."""
-    kw = dict(n_chains=40001, potential="harmonic", beta=2.0, sigma=[0.2, 0.1, 0.3], weight=[0.5, 0.25, 0.25], seed=19)
+@pytest.mark.parametrize("case", ["k3", "k1", "k2_beta", "k5_wide", "custom"])
+def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update, case):
+    """amc_pgmc_steps(n) == n x [amc_sweep(1); amc_pg_accumulate; amc_pg_update] bit for bit
+    (src/simulation.jl:185-190 runs the three algorithms back to back at every t).  With per-chain counters and at most
+    two learnable moves the sweep rides in the estimator launch (one HBM round trip of x per time step): K = 1 and
+    K > 1 forms, per-chain beta, a run-time compiled potential; "k5_wide" (three learnable moves) takes two launches."""
+    from montecarlo_amd import CustomPotential
+    M = 40001
+    kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1, 0.3], weight=[0.5, 0.25, 0.25], seed=19)
     ids, kinds, h0, h1 = [1, 2], [1, 4], [0.5, 0.01], [0.0, 1e-6]            # VPG(0.5), NPG(0.01, 1e-6)
+    beta = None
+    if case == "k1":
+        kw.update(sigma=[0.15], weight=[1.0])
+        ids, kinds, h0, h1 = [0], [2], [0.3], [0.0]                          # BLPG(0.3)
+    elif case == "k2_beta":
+        kw.update(sigma=[0.2, 0.4], weight=[0.5, 0.5], potential="double_well")
+        ids, kinds, h0, h1 = [1], [1], [0.2], [0.0]
+        beta = np.random.default_rng(5).uniform(0.5, 3.0, M)
+    elif case == "k5_wide":
+        kw.update(sigma=[0.2, 0.1, 0.3, 0.25, 0.5], weight=[0.2] * 5)
+        ids, kinds, h0, h1 = [0, 2, 4], [1, 1, 6], [0.1, 0.1, 1e-6], [0.0, 0.0, 1e-6]
+    elif case == "custom":
+        kw.update(potential=CustomPotential("x*x*x*x - 2.0*x*x + 0.25*x"), sigma=[0.3, 0.6], weight=[0.5, 0.5])
+        ids, kinds, h0, h1 = [0, 1], [1, 1], [0.05, 0.05], [0.0, 0.0]
     a, b = gpu.HipEngine(**kw), gpu.HipEngine(**kw)
+    x0 = np.random.default_rng(6).uniform(-2, 2, M)
     for e in (a, b):
-        e.init_uniform(-2, 2)
+        if beta is not None:
+            e.upload_state(x0, beta)
+        else:
+            e.init_uniform(-2, 2)
         e.sweep(2)
     n = 37                                                                   # crosses a step-log fold
     a.pgmc_steps(n, ids, 2, kinds if do_update else None, h0, h1)
@@ -551,12 +574,14 @@ def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update):
             b.pg_update(ids, kinds, h0, h1)
     assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
     assert np.array_equal(bits(a.pg_get_accumulated(ids)), bits(b.pg_get_accumulated(ids)))
-    for k in range(3):
+    for k in range(len(kw["sigma"])):
         assert a.get_parameters(k)[0] == b.get_parameters(k)[0]
     if do_update:
-        assert a.get_parameters(1)[0] != 0.1 and a.get_parameters(0)[0] == 0.2
+        assert a.get_parameters(ids[0])[0] != kw["sigma"][ids[0]]
     acc_a, tot_a = a.download_counters()
     acc_b, tot_b = b.download_counters()
     assert np.array_equal(acc_a, acc_b) and np.array_equal(tot_a, tot_b)
+    assert np.array_equal(a.counter_totals()[0], b.counter_totals()[0])
     assert a.step == b.step == 2 + n and a.estimator_step == b.estimator_step == n
+    np.testing.assert_allclose(a.reduce(), b.reduce(), rtol=1e-13, equal_nan=True)
     a.close(); b.close()
