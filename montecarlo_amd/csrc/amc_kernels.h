@@ -829,6 +829,8 @@ __device__ __forceinline__ double ordered_column_sum(const double* rows, int n_r
 // (1: K == 1, 2: K > 1; per-chain counters through the step log in both) -- run! calls the two algorithms back to
 // back at the same t (src/simulation.jl:185-190), and x then makes one HBM round trip for both instead of two.
 // Per chain the operations and their order are those of the two separate launches.
+// (96-104 VGPRs: 4-5 waves per SIMD.  Capping the registers for 6-8 waves spills and is slower: 104 -> 111 / 155 /
+// 194 us per config-5 step, measured.)
 template <int POT, int NL, bool BETA, int SWEEP = 0>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {

@@ -4,7 +4,7 @@ with the chains left on the device.  Run under rocprofv3 --kernel-trace --stats 
 committed as profiles/<round>_config{3,5}_kernel_stats.csv."""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.environ.get("AMC_PKG_ROOT", ROOT))      # A/B: a variant copy of the package (tools/gpu_ab.py snapshot)
 import montecarlo_amd as ma
 
 M = int(os.environ.get("M", 10_000_000)); steps = int(os.environ.get("STEPS", 1000))
