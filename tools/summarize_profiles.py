@@ -11,12 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = os.path.join(ROOT, "profiles"); os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
-for f in glob.glob(os.path.join(g, "prof", "*", "*_kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the latest run's."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(os.path.join(g, "prof", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
     print(open(f).read()[:900])
 summary = collections.OrderedDict()
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in glob.glob(os.path.join(g, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(g, d, "*", "*counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "sweep_kernel" in r["Kernel_Name"]:
