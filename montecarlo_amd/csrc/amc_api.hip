@@ -577,7 +577,9 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         if (v >= 1 && v <= 64) h->blocks_per_cu = v;
     }
     h->M = cfg->n_chains;
-    h->M_pad = ((cfg->n_chains + 3) & ~(int64_t)3) + AMC_PAD_DOUBLES;   // multiple of 4 + padding: unclamped 16-B tail loads stay in bounds
+    // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
+    // (M_pad is a multiple of 256): a wave's 128-byte step-log store then covers exactly one aligned line
+    h->M_pad = ((cfg->n_chains + AMC_PAD_DOUBLES + 255) / 256) * 256;
     h->offset = cfg->chain_offset;
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;
