@@ -1,0 +1,37 @@
+"""The two driver scripts of the reference's harmonic-oscillator example, on this engine (examples/*.py), run end to
+end on the device at reduced length and checked against the reference's own known answers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def test_mc_harmonic_oscillator_example(gpu, tmp_path, capsys):
+    import mc_harmonic_oscillator as ex
+    sim = ex.main(["--chains", "20000", "--steps", "3000", "--path", str(tmp_path / "mc")])
+    out = capsys.readouterr().out
+    assert "mean(energies), std(energies)" in out
+    hist = sim.algorithms[2]
+    assert hist.mean == pytest.approx(0.0, abs=3e-3) and hist.std == pytest.approx(0.5, abs=3e-3)   # distribution_test.jl:36-37
+    rows = np.loadtxt(tmp_path / "mc" / "energy.dat", usecols=(0, 1))
+    assert rows[0, 0] == 0 and rows[-1, 0] == 3000
+    assert rows[rows[:, 0] >= 300, 1].mean() == pytest.approx(0.25, abs=3e-3)
+    acc = open(tmp_path / "mc" / "acceptance.dat").read().splitlines()
+    assert acc[0] == "0 [NaN]" and float(acc[-1].split("[")[1].strip("]")) == pytest.approx(0.93655, abs=2e-3)
+    assert os.path.exists(tmp_path / "mc" / "summary.log") and os.path.exists(tmp_path / "mc" / "histogram.dat")
+
+
+def test_pgmc_harmonic_oscillator_example(gpu, tmp_path, capsys):
+    import pgmc_harmonic_oscillator as ex
+    sim = ex.main(["--chains", "50000", "--steps", "1500", "--eta", "0.4", "--path", str(tmp_path / "pgmc")])
+    out = capsys.readouterr().out
+    assert "learned sigma" in out
+    pool = sim.algorithms[0].pool
+    assert pool[0].sigma == 0.2 and pool[1].sigma == pytest.approx(1.2, abs=0.2)          # pgmc_test.jl:45,50
+    rows = open(tmp_path / "pgmc" / "parameters" / "2" / "parameters.dat").read().splitlines()
+    assert rows[0] == "0 [0.1]" and rows[-1].startswith("1500 [")
