@@ -63,8 +63,12 @@ def cpu_baseline(budget_s: float = 12.0):
                 break
     except OSError:
         pass
+    import shutil
+    julia = shutil.which("julia")        # the reference itself can only be timed where Julia exists
     return {
         "value": out["all"][0], "unit": "chain-updates/s", "cores": cores, "kind": "port",
+        "reference_runtime": f"julia at {julia} (reference not timed: no package depot offline)" if julia else
+                             "julia not found on this host: the reference (pure Julia) cannot be timed here",
         "sample": f"oracle/amc_oracle.c (C restatement of mc_sweep!, OpenMP over chains), M=1e6 chains x "
                   f"{out['all'][1]} sweeps in {out['all'][2]:.1f} s on {cores} threads; same workload otherwise",
         "single_thread_value": out["single"][0], "cpu_model": cpu_model,

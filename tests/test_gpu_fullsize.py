@@ -215,3 +215,13 @@ def test_device_resident_learning_matches_host_path_and_oracle(gpu, oracle, tmp_
         eng.pg_update([1], [1], [-1e6], [0.0])                                   # VPG with a huge negative eta
         eng.pg_get_accumulated([1])
     assert eng.get_parameters(1)[0] == pool_d[1].sigma                           # the bad step was not applied
+
+
+def test_pgmc_example_learning_curve_on_device(gpu):
+    """The reference's published PGMC learning curve (learning.png of PGMC_harmonic_oscillator.jl):
+    VPG eta = 1e-3 takes sigma_2 from 0.1 to ~0.33 at t = 1e3.  Same configuration on the device with 2e5 chains (the
+    gradient noise of the M = 10 example averaged out): the curve's value at t = 1e3 and its monotone rise."""
+    from test_oracle_reference_tests import _pgmc_example_sigma_at
+    s = _pgmc_example_sigma_at(None, 200_000, 42, [250, 500, 1000])
+    assert s[0] < s[1] < s[2]
+    assert s[2] == pytest.approx(0.33, abs=0.03)

@@ -91,3 +91,30 @@ def test_pgmc_objective_peaks_near_sigma_star(oracle):
     assert vals[1.2][0] == pytest.approx(0.18597, abs=3e-3)
     assert vals[0.6][0] < vals[1.2][0] > vals[2.0][0]
     assert vals[0.6][1] > 0 > vals[2.0][1]                      # gradient points towards sigma*
+
+
+def _pgmc_example_sigma_at(engine_factory, M, seed, times):
+    """example/particle_1d/harmonic_oscillator/PGMC_harmonic_oscillator.jl:9-35: pool sigma = (0.2, 0.1), weights
+    (0.6, 0.4), optimisers (Static, VPG(0.001)), estimator and update every step; returns sigma_2 at `times`."""
+    chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
+            ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=seed, engine_factory=engine_factory),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.001))),
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+          dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=list(times)))
+    with tempfile.TemporaryDirectory() as path:
+        ma.run(ma.Simulation(chains, al, times[-1], path=path))
+        rows = open(os.path.join(path, "parameters", "2", "parameters.dat")).read().splitlines()
+    assert pool[0].sigma == 0.2
+    return [float(r.split("[")[1].strip("]")) for r in rows][1:]
+
+
+def test_pgmc_example_learning_curve(oracle):
+    """The reference publishes the learning curve of its PGMC example as a figure
+    (example/particle_1d/harmonic_oscillator/learning.png, script PGMC_harmonic_oscillator.jl:45-51): with VPG
+    eta = 1e-3, M = 10, sigma_2 has grown from 0.1 to ~0.33 at t = 1e3.  Eight seeds of the same
+    configuration on the oracle."""
+    s1000 = [_pgmc_example_sigma_at(oracle.OracleEngine, 10, seed, [1000])[0] for seed in range(40, 48)]
+    assert np.mean(s1000) == pytest.approx(0.33, abs=0.03)
+    assert all(abs(s - 0.33) < 0.08 for s in s1000)
