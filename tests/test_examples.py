@@ -16,6 +16,9 @@ def test_mc_harmonic_oscillator_example(gpu, tmp_path, capsys):
     sim = ex.main(["--chains", "20000", "--steps", "3000", "--path", str(tmp_path / "mc")])
     out = capsys.readouterr().out
     assert "mean(energies), std(energies)" in out
+    # the reference's density.png overlay (MC_harmonic_oscillator.jl:40-51) as a number: sampled vs sqrt(beta/pi) exp(-beta x^2)
+    dev = float([ln for ln in out.splitlines() if ln.startswith("max |sampled density")][0].rsplit("=", 1)[1])
+    assert dev < 0.02
     hist = sim.algorithms[2]
     assert hist.mean == pytest.approx(0.0, abs=3e-3) and hist.std == pytest.approx(0.5, abs=3e-3)   # distribution_test.jl:36-37
     rows = np.loadtxt(tmp_path / "mc" / "energy.dat", usecols=(0, 1))
