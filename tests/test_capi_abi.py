@@ -100,3 +100,28 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle_lib" not in text and "libamc_oracle" not in text and "amo_" not in text, fn
+
+
+@pytest.mark.gpu
+def test_plain_c_client_links_and_runs(tmp_path):
+    """tests/aux/c_usage.c: a C99 program linked against libamc.so only (the boundary a Julia ccall / cgo / JNI binding
+    sees), built-in and run-time compiled potentials, checked against quadrature."""
+    import math
+    from scipy import integrate
+    lib_dir = os.path.join(ROOT, "montecarlo_amd")
+    exe = tmp_path / "c_usage"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "aux", "c_usage.c"), "-o", str(exe), os.path.join(lib_dir, "libamc.so"),
+                    "-lm", f"-Wl,-rpath,{lib_dir}"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    dw = dict(zip(lines[0].split()[1::2], map(float, lines[0].split()[2::2])))
+    assert dw["mean_U"] == pytest.approx(0.272864, abs=5e-3) and dw["mean_x2"] == pytest.approx(0.852136, abs=8e-3)
+    assert dw["acc0"] > dw["acc1"] > 0.2
+    U = lambda x: 0.5 * x * x + 0.25 * x ** 4
+    z = integrate.quad(lambda x: math.exp(-2 * U(x)), -5, 5)[0]
+    mean_u = integrate.quad(lambda x: U(x) * math.exp(-2 * U(x)), -5, 5)[0] / z
+    cu = dict(zip(lines[1].split()[1::2], map(float, lines[1].split()[2::2])))
+    assert cu["mean_U"] == pytest.approx(mean_u, abs=5e-3) and cu["mean_x"] == pytest.approx(0.0, abs=8e-3)
+    assert "n_moves must be in" in lines[2]
