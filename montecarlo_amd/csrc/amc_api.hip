@@ -110,6 +110,7 @@ struct amc_handle {
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
     double* d_pg_groups = nullptr;      // [groups][AMC_MAX_LEARN * 4]
     Rccl rccl;
+    bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x)
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
     std::vector<hipModule_t> rtc_mods;
@@ -576,6 +577,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         const int v = std::atoi(env);
         if (v >= 1 && v <= 64) h->blocks_per_cu = v;
     }
+    if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
     h->M = cfg->n_chains;
     // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
     // (M_pad is a multiple of 256): a wave's 128-byte step-log store then covers exactly one aligned line
@@ -871,6 +873,7 @@ static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
     a.beta = h->beta;
     a.red_partials = h->h_partials;
     a.red_stride = RED_HOST_STRIDE;
+    a.exact_accept = h->exact_accept ? 1 : 0;
     return a;
 }
 

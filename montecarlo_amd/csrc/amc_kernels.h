@@ -15,9 +15,11 @@
 
 #define AMC_MAX_MOVES 64
 #define AMC_MAX_LEARN 8
+#ifndef AMC_BLOCK
 #define AMC_BLOCK 256
-#define AMC_PAD_DOUBLES 520      // readable padding behind every per-chain array: a ragged last block-iteration
-                                 // may load up to 255 pairs past the end without a clamp
+#endif
+#define AMC_PAD_DOUBLES (2 * AMC_BLOCK + 8)   // readable padding behind every per-chain array: a ragged last
+                                 // block-iteration may load up to AMC_BLOCK - 1 pairs past the end without a clamp
 
 namespace amc {
 
@@ -84,33 +86,89 @@ __device__ __forceinline__ double potential(double x, const double* T)
 //   invert_action!        particle_1d.jl:37-40   logq_b == logq_f bit for bit
 //   alpha = min(1, exp(dlogp + logq_b - logq_f)); accept iff alpha > u  (strict)
 //   reject: perform_action_cached! re-applies the negated action: x = (x+d) + (-d)
+// split in three: the part every chain needs in f64 (propose), the exact accept decision in the reference's
+// arithmetic (accept_exact), and a floating-point FILTER that settles the decision from a float estimate whenever the
+// estimate's rigorous error interval does not contain u (accept_filter) -- the same idea as the filtered exact
+// predicates of computational geometry.  logq, arg and exp(arg) feed nothing but that one comparison.
+struct Proposal {
+    double delta, xn, dlogp;
+};
+
 template <int POT>
-__device__ __forceinline__ bool mh_step(double& x, double beta, double sigma, double den, double rden,
-                                        double logc, double z, double u, const double* T,
-                                        unsigned long long& wave_mask)
+__device__ __forceinline__ Proposal propose(double x, double beta, double sigma, double z, const double* T)
 {
-    const double delta = 0.0 + sigma * z;
-    const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den, bit for bit
+    Proposal p;
+    p.delta = 0.0 + sigma * z;
     const double e1 = potential<POT>(x, T);
-    const double xn = x + delta;
-    const double e2 = potential<POT>(xn, T);
-    const double dlogp = ((-e2) * beta) - ((-e1) * beta);
+    p.xn = x + p.delta;
+    const double e2 = potential<POT>(p.xn, T);
+    p.dlogp = ((-e2) * beta) - ((-e1) * beta);
+    return p;
+}
+
+// The reference-ordered decision.  alpha = min(1, exp(arg)); accept iff alpha > u, with u in [0, 1).  Decided
+// without forming alpha:
+//   arg >= 0           -> exp(arg) >= 1 -> alpha == 1 > u           : accept
+//   -708 <= arg < 0    -> alpha == exp(arg) (<= 1)                  : accept iff exp(arg) > u
+//   arg < -708 or NaN  -> alpha == 0 or NaN (Julia's min keeps NaN) : reject
+// (bitwise | and & on purpose: no short-circuit branches)
+__device__ __forceinline__ bool accept_exact(double delta, double dlogp, double den, double rden, double logc, double u,
+                                             const double* T)
+{
+    const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den - logc, bit for bit
     const double arg = (dlogp + logq) - logq;
-    // alpha = min(1, exp(arg)); accept iff alpha > u, with u in [0, 1).  Decided without forming alpha:
-    //   arg >= 0           -> exp(arg) >= 1 -> alpha == 1 > u           : accept
-    //   -708 <= arg < 0    -> alpha == exp(arg) (<= 1)                  : accept iff exp(arg) > u
-    //   arg < -708 or NaN  -> alpha == 0 or NaN (Julia's min keeps NaN) : reject
-    // identical decisions to the full-domain form, ~15 fewer VALU instructions per chain.
-    // (bitwise | and & on purpose: no short-circuit branches, both chains' exp stay interleaved)
     const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
-    const bool accept = c_pos | (c_rng & c_exp);
-    // the wavefront's accept mask, formed from the three compare masks on the scalar unit (a ballot of `accept`
-    // itself goes through a 0/1 VGPR and a second compare)
-    wave_mask = __builtin_amdgcn_ballot_w64(c_pos) |
-                (__builtin_amdgcn_ballot_w64(c_rng) & __builtin_amdgcn_ballot_w64(c_exp));
-    const double xr = xn + (-delta);
-    x = accept ? xn : xr;
-    return accept;
+    return c_pos | (c_rng & c_exp);
+}
+
+// Filter.  Inputs: dlogp (exact, f64) and the HIGH word of the chain's accept draw (u = top 52 bits of (hi:lo), so
+// k 2^-24 <= u < (k+1) 2^-24 with k = hi >> 8, both ends exact floats).  Error budget of the estimate
+// ex = v_exp_f32(log2e * float(dlogp)) against the spec's exp(arg), for -17 <= dlogp < 1e-12 (relative):
+//   arg vs dlogp      arg = fl(fl(dlogp + logq) - logq), |arg - dlogp| <= 2^-53 (2|dlogp| + |logq|) with
+//                     |logq| <= z^2/2 (1 + 2^-50) + |log(2 pi s^2)/2| <= 37 + 231 (|z| <= 8.5, 1e-100 <= s <= 1e100)
+//                                                                                                       < 4e-14
+//   float(dlogp)      2^-24 * 17                                                                          1.1e-6
+//   * log2e (float)   constant 1.3e-8 rel + product rounding 6e-8, times |y| <= 24.6, times ln 2          1.3e-6
+//   v_exp_f32         1 ulp by the ISA; amc_selftest_accept_filter measures it exhaustively               < 5e-7
+//   spec exp vs exp   2 ulp f64                                                                            4e-16
+//   * (1 -+ eps)      one float rounding                                                                    6e-8
+// total < 3.1e-6; eps = 2^-16 = 1.5e-5 leaves a factor 5.  Outside the range: dlogp > 1e-12 -> arg > 0 -> accept;
+// dlogp < -17 -> the clamped estimate is an upper bound only.  NaN compares false everywhere -> undecided.
+// Undecided with probability ~3e-5 per chain-step; then the whole wave takes accept_exact.
+#define AMC_FILTER_EPS 0x1.0p-16f
+__device__ __forceinline__ void accept_filter(double dlogp, uint32_t u_hi, bool& acc, bool& rej)
+{
+    const float t = (float)dlogp;
+    const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
+    const float kf = (float)(u_hi >> 8);                                   // exact: k < 2^24
+    const float lo = ex * ((1.0f - AMC_FILTER_EPS) * 0x1.0p+24f);          // lower bound of exp(arg) 2^24 (t >= -17)
+    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * 0x1.0p+24f);          // upper bound of exp(arg) 2^24
+    acc = (dlogp > 1e-12) | ((t >= -17.0f) & (lo > kf + 1.0f));            // exp(arg) > (k+1) 2^-24 > u, or arg > 0
+    rej = (dlogp < -1e-12) & (hi < kf);                                    // arg < 0 and exp(arg) < k 2^-24 <= u
+}
+
+// One mc_step! of both chains of a pair.  force_exact (wave-uniform; tests) sends every wave through accept_exact.
+template <int POT>
+__device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, double sg0, double sg1, double dn0, double dn1,
+                                        double rd0, double rd1, double lc0, double lc1, double z0, double z1, u32x4 pu,
+                                        const double* T, bool force_exact, bool& a0, bool& a1,
+                                        unsigned long long& m0, unsigned long long& m1)
+{
+    const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
+    bool r0, r1;
+    accept_filter(p0.dlogp, pu.y, a0, r0);              // even chain: u from words (x, y), odd: (z, w)
+    accept_filter(p1.dlogp, pu.w, a1, r1);
+    const bool undecided = !(a0 | r0) | !(a1 | r1);
+    if (force_exact || __builtin_amdgcn_ballot_w64(undecided) != 0ull) {
+        // the reference-ordered arithmetic decides (it agrees with the filter wherever the filter decided)
+        a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_co(pu.x, pu.y), T);
+        a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_co(pu.z, pu.w), T);
+    }
+    m0 = __builtin_amdgcn_ballot_w64(a0);
+    m1 = __builtin_amdgcn_ballot_w64(a1);
+    const double xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
+    xv.x = a0 ? p0.xn : xr0;
+    xv.y = a1 ? p1.xn : xr1;
 }
 
 // 16-byte store of a chain pair with the sc1 (write-through) policy: the line does not stay dirty
@@ -177,6 +235,7 @@ struct SweepArgs {
                                   // this block's pool-wide accepted slot after the launch), pinned host memory
     int32_t red_stride;
     int32_t log_pos;              // row of the step log the first step of this launch writes
+    int32_t exact_accept;         // != 0: skip the accept filter, every decision by accept_exact (tests; AMC_EXACT_ACCEPT)
 };
 
 // The Philox results of one MH step of a pair (normal draw, accept draw; for K > 1 the move pick takes the bits
@@ -242,8 +301,8 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         box_muller(dr.normal, z0, z1, s_math);
         const u32x4 pu = dr.accept;
         unsigned long long m0, m1;
-        const bool a0 = mh_step<POT>(xv.x, b0, sg0, dn0, rd0, lc0, z0, uniform_co(pu.x, pu.y), s_math, m0);
-        const bool a1 = mh_step<POT>(xv.y, b1, sg1, dn1, rd1, lc1, z1, uniform_co(pu.z, pu.w), s_math, m1);
+        bool a0, a1;
+        mh_pair<POT>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, pu, s_math, a.exact_accept != 0, a0, a1, m0, m1);
         // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
         if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
         if (LOG) {
