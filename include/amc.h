@@ -241,6 +241,10 @@ int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
  * radius sqrt (must equal 4 bit for bit on {0} U [2^-52, 80]).  Host buffers. */
 int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
                        double *out, int64_t n);
+/* The sweep kernel settles most accept decisions from a float estimate of exp(dlogp) whose error interval is rigorous
+ * (DESIGN.md section 3.6); this hook walks EVERY float t in [t_to, t_from] (t_to <= t_from <= 0) on the device and
+ * returns the largest relative deviation of that estimate from the arithmetic spec's f64 exp(t). */
+int  amc_selftest_accept_filter(int device, float t_from, float t_to, double *max_rel_err);
 /* out4[i] = Philox4x32-10(key = seed, counter of draw (pair[i], t[i], draw, stream)). */
 int  amc_selftest_philox(int device, uint64_t seed, const uint64_t *pair, const uint64_t *t,
                          uint32_t draw, uint32_t stream, uint32_t *out4, int64_t n);

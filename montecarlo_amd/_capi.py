@@ -107,6 +107,7 @@ def load() -> C.CDLL:
         "amc_comm_init": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "amc_allreduce_sum": (C.c_int, [H, dp, C.c_int]),
         "amc_selftest_math": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, C.c_int64]),
+        "amc_selftest_accept_filter": (C.c_int, [C.c_int, C.c_float, C.c_float, dp]),
         "amc_selftest_philox": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]),
     }
@@ -387,6 +388,14 @@ def selftest_math(fn: str, a: np.ndarray, b: Optional[np.ndarray] = None, device
     out = np.empty_like(a)
     _check(load().amc_selftest_math(int(device), ids[fn], _dptr(a), _dptr(b), _dptr(out), a.size))
     return out
+
+
+def selftest_accept_filter(t_from: float, t_to: float, device: int = 0) -> float:
+    """Largest relative deviation of the accept filter's float estimate from the spec's f64 exp over EVERY float in
+    [t_to, t_from] (t_to <= t_from <= 0), measured on the GPU (parity tests only)."""
+    out = C.c_double(0.0)
+    _check(load().amc_selftest_accept_filter(int(device), C.c_float(t_from), C.c_float(t_to), C.byref(out)))
+    return out.value
 
 
 def selftest_philox(seed: int, pair: np.ndarray, t: np.ndarray, draw: int, stream: int,

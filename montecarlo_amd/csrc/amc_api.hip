@@ -1539,6 +1539,29 @@ int amc_selftest_math(int device, int fn, const double* a, const double* b_or_nu
     return AMC_OK;
 }
 
+int amc_selftest_accept_filter(int device, float t_from, float t_to, double* max_rel_err)
+{
+    if (!max_rel_err || !(t_from <= 0.0f) || !(t_to <= t_from) || !(t_to >= -1e30f))
+        return fail(AMC_ERR_BAD_ARG, "amc_selftest_accept_filter: need 0 >= t_from >= t_to (negative floats, from the one nearer zero)");
+    AMC_HIP(hipSetDevice(device));
+    // negative floats order like their bit patterns: -0.0 = 0x80000000 < ... ; walk from t_from down to t_to
+    uint32_t b0, b1;
+    float f0 = t_from == 0.0f ? -0.0f : t_from;
+    std::memcpy(&b0, &f0, 4);
+    std::memcpy(&b1, &t_to, 4);
+    const uint64_t count = (uint64_t)b1 - (uint64_t)b0 + 1;
+    unsigned long long* d_max = nullptr;
+    AMC_HIP(hipMalloc(&d_max, sizeof(unsigned long long)));
+    AMC_HIP(hipMemset(d_max, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(amc::selftest_filter_kernel, dim3(4096), dim3(256), 0, 0, b0, count, d_max);
+    AMC_HIP(hipGetLastError());
+    unsigned long long bits = 0;
+    AMC_HIP(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
+    (void)hipFree(d_max);
+    std::memcpy(max_rel_err, &bits, sizeof(double));
+    return AMC_OK;
+}
+
 int amc_selftest_philox(int device, uint64_t seed, const uint64_t* pair, const uint64_t* t, uint32_t draw,
                         uint32_t stream, uint32_t* out4, int64_t n)
 {

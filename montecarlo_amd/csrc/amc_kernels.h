@@ -1127,6 +1127,29 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
     out[i] = r;
 }
 
+// Exhaustive check of the accept filter's float estimate (accept_filter): for EVERY float t with bit pattern in
+// [bits_lo, bits_hi] the relative deviation of v_exp_f32(max(t, -17) * log2e) from the spec's f64 exp(t); the maximum
+// over the range lands in out_max_bits (bits of a non-negative double compare like integers).
+__global__ __launch_bounds__(256) void selftest_filter_kernel(uint32_t bits_lo, uint64_t count, unsigned long long* out_max_bits)
+{
+    __shared__ double s_math[TAB_DOUBLES];
+    stage_math_tables(s_math, threadIdx.x, 256);
+    double worst = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const float t = __uint_as_float(bits_lo + (uint32_t)i);
+        const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
+        const double ref = exp_f64((double)__builtin_fmaxf(t, -17.0f), s_math);
+        const double rel = __builtin_fabs((double)ex - ref) / ref;
+        worst = (rel > worst) ? rel : worst;                  // NaN never enters (ref is finite and positive here)
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(worst, off, 64);
+        worst = (o > worst) ? o : worst;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max_bits, (unsigned long long)__double_as_longlong(worst));
+}
+
 __global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,
                                        uint32_t draw, uint32_t stream, uint32_t* out4, int64_t n)
 {

@@ -585,3 +585,54 @@ def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update, case):
     assert a.step == b.step == 2 + n and a.estimator_step == b.estimator_step == n
     np.testing.assert_allclose(a.reduce(), b.reduce(), rtol=1e-13, equal_nan=True)
     a.close(); b.close()
+
+
+# ---- the accept filter (amc_kernels.h accept_filter / mh_pair) --------------------------------
+def test_accept_filter_estimate_stays_inside_its_error_budget(gpu):
+    """EVERY float in [-17, 0] (1.1e9 values): the float estimate v_exp_f32(t * log2e) deviates from the spec's f64
+    exp(t) by less than the 1.9e-6 the error budget grants the float product and the hardware exponential together
+    (eps = 2^-16 = 1.5e-5 is the interval the kernel actually uses)."""
+    worst = gpu.selftest_accept_filter(0.0, -17.0)
+    assert 0.0 < worst < 1.9e-6, worst
+    assert gpu.selftest_accept_filter(0.0, -1e-3) < 2e-7            # near 0 the estimate is a float rounding of ~1
+    assert gpu.selftest_accept_filter(-17.0, -1e30) < 1.9e-6         # below -17 the argument is clamped
+
+
+@pytest.mark.parametrize("K,potential,counters", [(1, "harmonic", False), (2, "double_well", True)])
+def test_filtered_and_exact_accept_decisions_agree_on_millions_of_steps(gpu, monkeypatch, K, potential, counters):
+    """The same run with the filter (default) and with every decision taken by the reference-ordered arithmetic
+    (AMC_EXACT_ACCEPT=1): states and accept counts bit for bit.  3e6 chains x 24 steps = 7e7 decisions, ~2000 of which
+    fall inside the filter's error interval and take the exact path in the filtered run as well."""
+    sigma, weight = POOLS[K]
+    kw = dict(n_chains=3_000_001, potential=potential, beta=2.0, sigma=sigma, weight=weight, seed=123, per_chain_counters=counters)
+    runs = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("AMC_EXACT_ACCEPT", exact)
+        e = gpu.HipEngine(**kw)
+        e.init_uniform(-2, 2)
+        for _ in range(4):
+            e.sweep(1)
+        e.sweep(20)
+        runs.append((e.download_state()[0], e.counter_totals()[0]))
+        e.close()
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    assert np.array_equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize("sigma", [1e-100, 1e-9, 3e-4, 25.0, 1e6, 1e100])
+def test_accept_filter_at_extreme_step_sizes(gpu, oracle, sigma):
+    """dlogp ~ 0 (tiny steps: every decision is inside the |dlogp| <= 1e-12 band or next to it), dlogp << -17 and
+    overflowing potentials (huge steps): filter and oracle must still agree bit for bit."""
+    M = 50001
+    kw = dict(potential="double_well", beta=2.0, sigma=[sigma], weight=[1.0], seed=31)
+    e = gpu.HipEngine(n_chains=M, **kw)
+    o = oracle.OracleSim(M, **kw)
+    x0 = np.random.default_rng(9).uniform(-2, 2, M)
+    x0[:7] = [0.0, -0.0, 1.0, -1.0, 1e-200, 1e150, -1e155]        # flat spots of the well, underflow / overflow of x^2
+    e.upload_state(x0); o.set_x(x0)
+    for _ in range(3):
+        e.sweep(1)
+    e.sweep(9)
+    o.make_steps(12, 8)
+    assert_same(e, o)
+    e.close()
