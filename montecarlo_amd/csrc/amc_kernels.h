@@ -136,39 +136,65 @@ __device__ __forceinline__ bool accept_exact(double delta, double dlogp, double 
 // dlogp < -17 -> the clamped estimate is an upper bound only.  NaN compares false everywhere -> undecided.
 // Undecided with probability ~3e-5 per chain-step; then the whole wave takes accept_exact.
 #define AMC_FILTER_EPS 0x1.0p-16f
-__device__ __forceinline__ void accept_filter(double dlogp, uint32_t u_hi, bool& acc, bool& rej)
+// The five primitive comparisons of one chain; the decision masks are formed from their ballots on the scalar unit
+// (a ballot of a COMPOUND bool goes through a 0/1 VGPR and a second compare).  The sign tests use the float t:
+// |t| > 2e-12 implies |dlogp| > 1e-12 with room to spare (t = RN(dlogp), relative 6e-8); a dlogp that underflows to
+// t = 0 simply is not settled by its sign.
+struct FilterCmp {
+    bool pos, neg, rng, lo, hi;
+};
+
+__device__ __forceinline__ FilterCmp accept_filter(double dlogp, uint32_t u_hi)
 {
     const float t = (float)dlogp;
     const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
     const float kf = (float)(u_hi >> 8);                                   // exact: k < 2^24
-    const float lo = ex * ((1.0f - AMC_FILTER_EPS) * 0x1.0p+24f);          // lower bound of exp(arg) 2^24 (t >= -17)
-    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * 0x1.0p+24f);          // upper bound of exp(arg) 2^24
-    acc = (dlogp > 1e-12) | ((t >= -17.0f) & (lo > kf + 1.0f));            // exp(arg) > (k+1) 2^-24 > u, or arg > 0
-    rej = (dlogp < -1e-12) & (hi < kf);                                    // arg < 0 and exp(arg) < k 2^-24 <= u
+    // lower / upper bound of exp(arg) 2^24, the lower one already minus 1: one rounding each (in the budget)
+    const float lo1 = __builtin_fmaf(ex, (1.0f - AMC_FILTER_EPS) * 0x1.0p+24f, -1.0f);
+    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * 0x1.0p+24f);
+    FilterCmp c;
+    c.pos = t > 2e-12f;                 // arg > 0: accept whatever u is
+    c.neg = t < -2e-12f;                // arg < 0
+    c.rng = t >= -17.0f;                // the estimate is two-sided
+    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-24 > u
+    c.hi = hi < kf;                     // exp(arg) < k 2^-24 <= u
+    return c;
 }
 
-// One mc_step! of both chains of a pair.  force_exact (wave-uniform; tests) sends every wave through accept_exact.
+// One mc_step! of both chains of a pair.  force_mask (wave-uniform, all ones or zero; tests) sends every wave through
+// accept_exact.  acc_bits: bit 0 = even chain accepted, bit 8 = odd chain accepted (the step-log word's accept bits).
 template <int POT>
 __device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, double sg0, double sg1, double dn0, double dn1,
                                         double rd0, double rd1, double lc0, double lc1, double z0, double z1, u32x4 pu,
-                                        const double* T, bool force_exact, bool& a0, bool& a1,
+                                        const double* T, unsigned long long force_mask, uint32_t& acc_bits,
                                         unsigned long long& m0, unsigned long long& m1)
 {
     const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
-    bool r0, r1;
-    accept_filter(p0.dlogp, pu.y, a0, r0);              // even chain: u from words (x, y), odd: (z, w)
-    accept_filter(p1.dlogp, pu.w, a1, r1);
-    const bool undecided = !(a0 | r0) | !(a1 | r1);
-    if (force_exact || __builtin_amdgcn_ballot_w64(undecided) != 0ull) {
-        // the reference-ordered arithmetic decides (it agrees with the filter wherever the filter decided)
-        a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_co(pu.x, pu.y), T);
-        a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_co(pu.z, pu.w), T);
-    }
-    m0 = __builtin_amdgcn_ballot_w64(a0);
-    m1 = __builtin_amdgcn_ballot_w64(a1);
     const double xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
-    xv.x = a0 ? p0.xn : xr0;
-    xv.y = a1 ? p1.xn : xr1;
+    const FilterCmp c0 = accept_filter(p0.dlogp, pu.y);           // even chain: u from words (x, y), odd: (z, w)
+    const FilterCmp c1 = accept_filter(p1.dlogp, pu.w);
+#define AMC_B(c) __builtin_amdgcn_ballot_w64(c)
+    const unsigned long long acc0 = AMC_B(c0.pos) | (AMC_B(c0.rng) & AMC_B(c0.lo)), rej0 = AMC_B(c0.neg) & AMC_B(c0.hi);
+    const unsigned long long acc1 = AMC_B(c1.pos) | (AMC_B(c1.rng) & AMC_B(c1.lo)), rej1 = AMC_B(c1.neg) & AMC_B(c1.hi);
+    const unsigned long long undecided = AMC_B(true) & ~((acc0 | rej0) & (acc1 | rej1));
+#undef AMC_B
+    if ((undecided | force_mask) != 0ull) {
+        // the reference-ordered arithmetic decides (it agrees with the filter wherever the filter decided)
+        const bool a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_co(pu.x, pu.y), T);
+        const bool a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_co(pu.z, pu.w), T);
+        m0 = __builtin_amdgcn_ballot_w64(a0);
+        m1 = __builtin_amdgcn_ballot_w64(a1);
+        xv.x = a0 ? p0.xn : xr0;
+        xv.y = a1 ? p1.xn : xr1;
+        acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
+    } else {
+        const bool a0 = c0.pos | (c0.rng & c0.lo), a1 = c1.pos | (c1.rng & c1.lo);
+        m0 = acc0;
+        m1 = acc1;
+        xv.x = a0 ? p0.xn : xr0;
+        xv.y = a1 ? p1.xn : xr1;
+        acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
+    }
 }
 
 // 16-byte store of a chain pair with the sc1 (write-through) policy: the line does not stay dirty
@@ -301,13 +327,14 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         box_muller(dr.normal, z0, z1, s_math);
         const u32x4 pu = dr.accept;
         unsigned long long m0, m1;
-        bool a0, a1;
-        mh_pair<POT>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, pu, s_math, a.exact_accept != 0, a0, a1, m0, m1);
+        uint32_t acc_bits;
+        mh_pair<POT>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, pu, s_math,
+                     a.exact_accept ? ~0ull : 0ull, acc_bits, m0, m1);
         // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
         if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
         if (LOG) {
             // Move.accepted_calls += accepted; Move.total_calls += 1 (metropolis.jl:208-209), deferred: see above
-            log_word = ((uint32_t)k0 << 1 | (a0 ? 1u : 0u)) | (((uint32_t)k1 << 1 | (a1 ? 1u : 0u)) << 8);
+            log_word = acc_bits | ((uint32_t)k0 << 1) | ((uint32_t)k1 << 9);
             if (!SINGLE && v0) store_log_pair(a, a.log_pos + s, p, log_word);
         }
     }
