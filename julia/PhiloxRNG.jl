@@ -9,9 +9,10 @@
 # The reference builds `rngs[c] = R(seed + c - 1)` (metropolis.jl:262-263): the constructor argument minus the
 # seed (a type parameter here, because `R` must be a DataType) is the zero-based GLOBAL chain id.
 # Per mc_step! the reference draws, in this order (metropolis.jl:206, particle_1d.jl:57, metropolis.jl:184):
-#   rand(rng, Categorical(w)) -> one Float64 uniform      = 24 spare bits of draws 0 and 1 of the step (uniform_pick)
+#   rand(rng, Categorical(w)) -> one Float64 uniform      = low 24 bits of the chain's word of draw 1 (uniform_pick)
 #   rand(rng, Normal(0, s))   -> one randn(rng, Float64)  = the chain's half of draw 0 (Box-Muller pair)
-#   rand(rng)                 -> one Float64 uniform      = draw 1 of the step (52-bit map)
+#   rand(rng)                 -> one Float64 uniform      = 12 spare bits of draw 0 + top 40 bits of the chain's word
+#                                                           of draw 1 (uniform_accept, spec v4)
 # so the n-th call of a chain's generator is (step, kind) = divrem(n, 3).  The estimator stream (STREAM = 2)
 # draws one randn per sample: call n is draw n of estimator step `est_step` (set it before each make_step!).
 module PhiloxRNGs
@@ -51,8 +52,13 @@ bits12(lo::UInt32, hi::UInt32, expo::UInt64) = reinterpret(Float64, expo | (((UI
 uniform_co(lo, hi) = bits12(lo, hi, 0x3ff0000000000000) - 1.0      # [0,1): Julia's own rand(Float64) construction
 uniform_oc(lo, hi) = 2.0 - bits12(lo, hi, 0x3ff0000000000000)      # (0,1]
 angle_oc2(lo, hi) = 4.0 - bits12(lo, hi, 0x4000000000000000)       # (0,2]
-# categorical move pick: low 12 bits (unused by the 52-bit maps) of the chain's low word of the normal and accept draws
-uniform_pick(normal_lo::UInt32, accept_lo::UInt32) = Float64(((normal_lo & 0x00000fff) << 12) | (accept_lo & 0x00000fff)) * 2.0^-24
+# spec v4: move pick = low 24 bits of the chain's accept-draw word; accept uniform = 52-bit significand with the 12
+# spare bits of the normal draw's low word on top and the top 40 bits of the accept-draw word below
+uniform_pick(lo::UInt32) = Float64(lo & 0x00ffffff) * 2.0^-24
+function uniform_accept(normal_lo::UInt32, lo::UInt32, hi::UInt32)
+    m = (UInt64(normal_lo & 0x00000fff) << 40) | (((UInt64(hi) << 32) | lo) >> 24)
+    return reinterpret(Float64, 0x3ff0000000000000 | m) - 1.0
+end
 
 # table-driven log for the Box-Muller radius (DESIGN.md §3.4); fma() must be a true fused multiply-add
 function logbm(u::Float64)
@@ -108,12 +114,12 @@ function Random.rand(rng::PhiloxRNG{SEED,1}, ::Random.SamplerTrivial{Random.Clos
     t, kind = divrem(next_call!(rng), UInt64(3))
     pair, odd = rng.chain >> 1, rng.chain & 1
     if kind == 0
+        va = draw_words(UInt64(SEED), pair, t, 1, 1)
+        return odd == 0 ? uniform_pick(va[1]) : uniform_pick(va[3])
+    elseif kind == 2
         vn = draw_words(UInt64(SEED), pair, t, 0, 1)
         va = draw_words(UInt64(SEED), pair, t, 1, 1)
-        return odd == 0 ? uniform_pick(vn[1], va[1]) : uniform_pick(vn[3], va[3])
-    elseif kind == 2
-        v = draw_words(UInt64(SEED), pair, t, 1, 1)
-        return odd == 0 ? uniform_co(v[1], v[2]) : uniform_co(v[3], v[4])
+        return odd == 0 ? uniform_accept(vn[1], va[1], va[2]) : uniform_accept(vn[3], va[3], va[4])
     end
     error("PhiloxRNG: rand() called where the draw schedule expects randn() (call $(rng.calls - 1))")
 end

@@ -144,35 +144,45 @@ struct FilterCmp {
     bool pos, neg, rng, lo, hi;
 };
 
-__device__ __forceinline__ FilterCmp accept_filter(double dlogp, uint32_t u_hi)
+// k: the top BITS bits of u's significand (u in [k, k+1) 2^-BITS; 12 when only the normal draw is at hand, 24 with
+// the accept draw as well).
+template <int BITS>
+__device__ __forceinline__ FilterCmp accept_filter(double dlogp, uint32_t k)
 {
     const float t = (float)dlogp;
     const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
-    const float kf = (float)(u_hi >> 8);                                   // exact: k < 2^24
-    // lower / upper bound of exp(arg) 2^24, the lower one already minus 1: one rounding each (in the budget)
-    const float lo1 = __builtin_fmaf(ex, (1.0f - AMC_FILTER_EPS) * 0x1.0p+24f, -1.0f);
-    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * 0x1.0p+24f);
+    const float kf = (float)k;                                             // exact: k < 2^24
+    constexpr float SCALE = (float)(1u << BITS);
+    // lower / upper bound of exp(arg) 2^BITS, the lower one already minus 1: one rounding each (in the budget)
+    const float lo1 = __builtin_fmaf(ex, (1.0f - AMC_FILTER_EPS) * SCALE, -1.0f);
+    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * SCALE);
     FilterCmp c;
     c.pos = t > 2e-12f;                 // arg > 0: accept whatever u is
     c.neg = t < -2e-12f;                // arg < 0
     c.rng = t >= -17.0f;                // the estimate is two-sided
-    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-24 > u
-    c.hi = hi < kf;                     // exp(arg) < k 2^-24 <= u
+    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-BITS > u
+    c.hi = hi < kf;                     // exp(arg) < k 2^-BITS <= u
     return c;
 }
 
 // One mc_step! of both chains of a pair.  force_mask (wave-uniform, all ones or zero; tests) sends every wave through
 // accept_exact.  acc_bits: bit 0 = even chain accepted, bit 8 = odd chain accepted (the step-log word's accept bits).
-template <int POT>
+// LAZY (K == 1): the accept draw is not formed up front.  The top 12 bits of u come from the normal draw (spec v4),
+// which brackets u to 2^-12: the decision is settled without the second Philox call unless exp(arg) falls into u's
+// cell (~1.2e-4 per chain-step, ~1.5 % of wave-steps); `pu` is then formed here.  !LAZY (K > 1: the move pick needs
+// the accept draw anyway): 24-bit bracket.
+template <int POT, bool LAZY>
 __device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, double sg0, double sg1, double dn0, double dn1,
-                                        double rd0, double rd1, double lc0, double lc1, double z0, double z1, u32x4 pu,
+                                        double rd0, double rd1, double lc0, double lc1, double z0, double z1,
+                                        u32x4 pn, u32x4 pu, u32x4 accept_ctr, uint32_t key0, uint32_t key1,
                                         const double* T, unsigned long long force_mask, uint32_t& acc_bits,
                                         unsigned long long& m0, unsigned long long& m1)
 {
     const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
     const double xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
-    const FilterCmp c0 = accept_filter(p0.dlogp, pu.y);           // even chain: u from words (x, y), odd: (z, w)
-    const FilterCmp c1 = accept_filter(p1.dlogp, pu.w);
+    const uint32_t a0_12 = pn.x & 0xFFFu, a1_12 = pn.z & 0xFFFu;      // even chain: words (x, y), odd: (z, w)
+    const FilterCmp c0 = LAZY ? accept_filter<12>(p0.dlogp, a0_12) : accept_filter<24>(p0.dlogp, (a0_12 << 12) | (pu.y >> 20));
+    const FilterCmp c1 = LAZY ? accept_filter<12>(p1.dlogp, a1_12) : accept_filter<24>(p1.dlogp, (a1_12 << 12) | (pu.w >> 20));
 #define AMC_B(c) __builtin_amdgcn_ballot_w64(c)
     const unsigned long long acc0 = AMC_B(c0.pos) | (AMC_B(c0.rng) & AMC_B(c0.lo)), rej0 = AMC_B(c0.neg) & AMC_B(c0.hi);
     const unsigned long long acc1 = AMC_B(c1.pos) | (AMC_B(c1.rng) & AMC_B(c1.lo)), rej1 = AMC_B(c1.neg) & AMC_B(c1.hi);
@@ -180,8 +190,12 @@ __device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, doubl
 #undef AMC_B
     if ((undecided | force_mask) != 0ull) {
         // the reference-ordered arithmetic decides (it agrees with the filter wherever the filter decided)
-        const bool a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_co(pu.x, pu.y), T);
-        const bool a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_co(pu.z, pu.w), T);
+        if (LAZY) {
+            asm volatile("" : "+v"(accept_ctr.z));       // pins the second Philox call inside this arm (no speculation)
+            pu = philox4x32_10(accept_ctr, key0, key1);
+        }
+        const bool a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_accept(pn.x, pu.x, pu.y), T);
+        const bool a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_accept(pn.z, pu.z, pu.w), T);
         m0 = __builtin_amdgcn_ballot_w64(a0);
         m1 = __builtin_amdgcn_ballot_w64(a1);
         xv.x = a0 ? p0.xn : xr0;
@@ -264,9 +278,9 @@ struct SweepArgs {
     int32_t exact_accept;         // != 0: skip the accept filter, every decision by accept_exact (tests; AMC_EXACT_ACCEPT)
 };
 
-// The Philox results of one MH step of a pair (normal draw, accept draw; for K > 1 the move pick takes the bits
-// the 52-bit maps leave unused in both): pure functions of (seed, pair, step), so they can be formed before the
-// pair's state has arrived from memory.
+// The Philox results of one MH step of a pair (normal draw; for K > 1 also the accept draw, whose low bits are the
+// move pick): pure functions of (seed, pair, step), so they can be formed before the pair's state has arrived from
+// memory.
 struct StepDraws {
     u32x4 normal, accept;
 };
@@ -276,7 +290,9 @@ __device__ __forceinline__ StepDraws step_draws(const SweepArgs& a, uint64_t pai
 {
     StepDraws d;
     d.normal = philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1);
-    d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
+    // K == 1: the accept draw is formed only for the waves whose decision the normal draw's 12 bits do not settle
+    if (MULTI) d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
+    else d.accept = u32x4{0u, 0u, 0u, 0u};
     return d;
 }
 
@@ -313,7 +329,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         if (MULTI) {
             // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
             // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
-            const double r0 = uniform_pick(dr.normal.x, dr.accept.x), r1 = uniform_pick(dr.normal.z, dr.accept.z);
+            const double r0 = uniform_pick(dr.accept.x), r1 = uniform_pick(dr.accept.z);
             for (int i = 0; i < K - 1; ++i) {
                 const double c = s_tab[3 * AMC_MAX_MOVES + i];
                 k0 += (c <= r0) ? 1 : 0;
@@ -328,8 +344,9 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, doub
         const u32x4 pu = dr.accept;
         unsigned long long m0, m1;
         uint32_t acc_bits;
-        mh_pair<POT>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, pu, s_math,
-                     a.exact_accept ? ~0ull : 0ull, acc_bits, m0, m1);
+        mh_pair<POT, !MULTI>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, dr.normal, pu,
+                             draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1, s_math,
+                             a.exact_accept ? ~0ull : 0ull, acc_bits, m0, m1);
         // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
         if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
         if (LOG) {

@@ -87,12 +87,27 @@ double amo_angle_oc2(uint32_t lo, uint32_t hi)       /* (0,2]: 4 - d', d' in [2,
     return 4.0 - bits_to_12(lo, hi, 0x4000000000000000ull);
 }
 
-/* 24-bit uniform in [0,1) for the categorical move pick (metropolis.jl:206), from bits the 52-bit maps above
- * leave unused: the low 12 bits of the chain's low word of the step's NORMAL draw (high half) and of its ACCEPT
- * draw (low half).  No third Philox call per step (arithmetic spec v3). */
-double amo_uniform_pick(uint32_t normal_lo, uint32_t accept_lo)
+/* Arithmetic spec v4: the accept uniform of rand(rng) in metropolis.jl:184 and the uniform
+ * of rand(rng, Categorical(weights)) in :206, for one chain of a pair.
+ *   normal_lo : the chain's LOW word of the step's NORMAL draw (even chain: x, odd: z); its low 12 bits are not
+ *               used by the 52-bit Box-Muller maps
+ *   (hi:lo)   : the chain's 64-bit word W of the step's ACCEPT draw (even: (y:x), odd: (w:z))
+ * accept uniform: 52 bits, the TOP 12 from normal_lo, the other 40 the top 40 bits of W -- Julia's
+ *               rand(Float64) construction (d in [1,2) minus 1) on that significand.  The kernels can bracket u from
+ *               the normal draw alone and need the accept draw only when the bracket does not settle the decision.
+ * move pick   : the low 24 bits of W. */
+double amo_uniform_accept(uint32_t normal_lo, uint32_t lo, uint32_t hi)
 {
-    return (double)(((normal_lo & 0xFFFu) << 12) | (accept_lo & 0xFFFu)) * 0x1.0p-24;
+    uint64_t m = ((uint64_t)(normal_lo & 0xFFFu) << 40) | ((((uint64_t)hi << 32) | lo) >> 24);
+    uint64_t b = 0x3ff0000000000000ull | m;
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d - 1.0;
+}
+
+double amo_uniform_pick(uint32_t lo)
+{
+    return (double)(lo & 0xFFFFFFu) * 0x1.0p-24;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -399,10 +414,10 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         draw4(s, pair, t, AMO_DRAW_NORMAL, AMO_STREAM_METROPOLIS, v);
         draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, va);
         if (s->K > 1)                                              /* :206 */
-            id = amo_categorical(weights, s->K, amo_uniform_pick(v[2 * half], va[2 * half]));
+            id = amo_categorical(weights, s->K, amo_uniform_pick(va[2 * half]));
         double zz[2];
         amo_box_muller(v, zz);
-        double u = amo_uniform_co(va[2 * half], va[2 * half + 1]);
+        double u = amo_uniform_accept(v[2 * half], va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
         move->accepted_calls += mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
         move->total_calls += 1;                                    /* :209 */

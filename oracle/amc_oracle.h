@@ -38,7 +38,7 @@ extern "C" {
 
 enum { AMO_POT_HARMONIC = 0, AMO_POT_DOUBLE_WELL = 1, AMO_POT_CUSTOM = 2 };
 enum { AMO_STREAM_INIT = 0, AMO_STREAM_METROPOLIS = 1, AMO_STREAM_ESTIMATOR = 2 };
-enum { AMO_DRAW_NORMAL = 0, AMO_DRAW_ACCEPT = 1 };   /* the move pick takes spare bits of both (amo_uniform_pick) */
+enum { AMO_DRAW_NORMAL = 0, AMO_DRAW_ACCEPT = 1 };
 enum {
     AMO_OPT_STATIC = 0, AMO_OPT_VPG = 1, AMO_OPT_BLPG = 2, AMO_OPT_BLAPG = 3,
     AMO_OPT_NPG = 4, AMO_OPT_ANPG = 5, AMO_OPT_BLANPG = 6
@@ -57,7 +57,8 @@ double amo_logbm(double u);                         /* table-driven log for the 
 double amo_uniform_co(uint32_t lo, uint32_t hi);    /* [0,1), 52 bits: Julia's rand(Float64) construction */
 double amo_uniform_oc(uint32_t lo, uint32_t hi);    /* (0,1] */
 double amo_angle_oc2(uint32_t lo, uint32_t hi);     /* (0,2] */
-double amo_uniform_pick(uint32_t normal_lo, uint32_t accept_lo);   /* [0,1), 24 bits: categorical move pick */
+double amo_uniform_accept(uint32_t normal_lo, uint32_t lo, uint32_t hi);   /* [0,1), 52 bits: top 12 from the normal draw */
+double amo_uniform_pick(uint32_t lo);                /* [0,1), 24 bits: categorical move pick */
 double amo_potential(int pot, double x);
 /* AMO_POT_CUSTOM: `potential` is a free GLOBAL function of the driver script in the reference
  * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,

@@ -59,7 +59,8 @@ def load() -> C.CDLL:
         "amo_uniform_co": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_uniform_oc": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_angle_oc2": (C.c_double, [C.c_uint32, C.c_uint32]),
-        "amo_uniform_pick": (C.c_double, [C.c_uint32, C.c_uint32]),
+        "amo_uniform_pick": (C.c_double, [C.c_uint32]),
+        "amo_uniform_accept": (C.c_double, [C.c_uint32, C.c_uint32, C.c_uint32]),
         "amo_potential": (C.c_double, [C.c_int, C.c_double]),
         "amo_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),
         "amo_grad_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),

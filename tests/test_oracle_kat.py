@@ -39,7 +39,8 @@ def test_draw_schedule_golden(oracle):
         lib = oracle.load()
         assert lib.amo_uniform_co(w[0], w[1]) == float.fromhex(d["u_co"][0])
         assert lib.amo_uniform_co(w[2], w[3]) == float.fromhex(d["u_co"][1])
-        assert lib.amo_uniform_pick(w[0], w[2]) == float.fromhex(d["pick"])
+        assert lib.amo_uniform_pick(w[0]) == float.fromhex(d["pick"])
+        assert lib.amo_uniform_accept(w[3], w[0], w[1]) == float.fromhex(d["u_accept"])
 
 
 def test_counter_packing_is_rocrand_layout(oracle):
@@ -65,15 +66,21 @@ def test_uniform_maps(oracle):
     assert lib.amo_uniform_co((1 << 12) - 1, 0) == 0.0                       # low 12 bits of the low word unused
     assert lib.amo_uniform_oc(0, 0) == 1.0 and lib.amo_uniform_oc(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -52   # (0, 1]
     assert lib.amo_angle_oc2(0, 0) == 2.0 and lib.amo_angle_oc2(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -51     # (0, 2]
-    # categorical pick: 12 spare bits of the normal draw's low word (high half), 12 of the accept draw's (low half)
-    assert lib.amo_uniform_pick(0, 0) == 0.0 and lib.amo_uniform_pick(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -24
-    assert lib.amo_uniform_pick(0xFFFFF000, 0xFFFFF000) == 0.0              # only bits the 52-bit maps do not use
-    assert lib.amo_uniform_pick(0x800, 0) == 0.5 and lib.amo_uniform_pick(0, 1) == 2.0 ** -24
+    # spec v4.  Move pick: the low 24 bits of the chain's accept-draw word.  Accept uniform: 52-bit significand whose
+    # top 12 bits are the normal draw's spare bits and whose other 40 are the top 40 bits of the accept-draw word.
+    assert lib.amo_uniform_pick(0) == 0.0 and lib.amo_uniform_pick(0xFFFFFFFF) == 1.0 - 2.0 ** -24
+    assert lib.amo_uniform_pick(0xFF000000) == 0.0 and lib.amo_uniform_pick(0x800000) == 0.5 and lib.amo_uniform_pick(1) == 2.0 ** -24
+    assert lib.amo_uniform_accept(0, 0, 0) == 0.0 and lib.amo_uniform_accept(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -52
+    assert lib.amo_uniform_accept(0x800, 0, 0) == 0.5 and lib.amo_uniform_accept(0xFFFFF001, 0, 0) == 2.0 ** -12
+    assert lib.amo_uniform_accept(0, 1 << 24, 0) == 2.0 ** -52 and lib.amo_uniform_accept(0, (1 << 24) - 1, 0) == 0.0   # W's low 24 bits: the pick's
+    assert lib.amo_uniform_accept(0, 0, 1 << 31) == 2.0 ** -13
     rnd = random.Random(7)
     for _ in range(2000):
         lo, hi = rnd.getrandbits(32), rnd.getrandbits(32)
         m = ((hi << 32) | lo) >> 12
         assert lib.amo_uniform_co(lo, hi) == m * 2.0 ** -52
+        a = rnd.getrandbits(32)
+        assert lib.amo_uniform_accept(a, lo, hi) == (((a & 0xFFF) << 40) | (((hi << 32) | lo) >> 24)) * 2.0 ** -52
         assert lib.amo_uniform_oc(lo, hi) == 1.0 - m * 2.0 ** -52
         assert lib.amo_angle_oc2(lo, hi) == 2.0 - m * 2.0 ** -51
 
