@@ -11,7 +11,7 @@ M = int(os.environ.get("M", 10_000_000))
 K = int(os.environ.get("K", 1))
 sigma = [0.1, 1.0][:K]; weight = [[1.0], [0.5, 0.5]][K - 1]
 e = A.HipEngine(n_chains=M, potential="harmonic" if K == 1 else "double_well", beta=2.0, sigma=sigma, weight=weight,
-                seed=1, per_chain_counters=(K > 1))
+                seed=1, per_chain_counters=(K > 1) or os.environ.get('COUNTERS') == '1')
 e.init_uniform(-2, 2)
 t0 = time.time()
 while time.time() - t0 < 0.6:
