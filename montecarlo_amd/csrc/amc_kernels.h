@@ -223,7 +223,10 @@ __device__ __forceinline__ void store_pair_writethrough(double* p, double2 v)
     // trailing s_nop 1: a VMEM store of more than 8 bytes reads its data VGPRs over the next cycles, and a
     // VALU write to them needs 2 wait states on gfx940+/gfx950 (LLVM inserts them for its own stores, never
     // around inline asm) -- without it lanes 12..15 of each row stored a later value of the registers.
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
+#ifndef AMC_STORE_FLAVOR
+#define AMC_STORE_FLAVOR "sc1"
+#endif
+    asm volatile("global_store_dwordx4 %0, %1, off " AMC_STORE_FLAVOR "\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
 }
 
 // ---- deterministic block reduction helpers -------------------------------------
