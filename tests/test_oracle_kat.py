@@ -297,3 +297,64 @@ def test_build_schedule_reference_values(oracle):
     assert oracle.build_schedule(1000, 10, 2.0) == [10, 11, 12, 14, 18, 26, 42, 74, 138, 266, 522, 1000]
     with pytest.raises(ValueError):
         oracle.build_schedule(1000, 10, 1.5)                           # Int(1.5) is an InexactError in Julia
+
+
+# ---- the reference's call order on the engine's draw schedule (what julia/PhiloxRNG.jl implements) -----------------
+class _PhiloxCalls:
+    """The per-chain generator of julia/PhiloxRNG.jl restated in Python: the reference's mc_sweep! makes three calls
+    per mc_step! -- rand(rng, Categorical(w)), randn via Normal(0, sigma), rand(rng) (metropolis.jl:206,
+    particle_1d.jl:57, metropolis.jl:184) -- and the n-th call of chain c maps to (step, kind) = divmod(n, 3):
+      kind 0  move pick      low 24 bits of the chain's word of draw 1
+      kind 1  normal         the chain's half of the Box-Muller pair of draw 0
+      kind 2  accept uniform 12 spare bits of draw 0 on top of the top 40 bits of the chain's word of draw 1"""
+
+    def __init__(self, oracle, seed, chain):
+        self.o, self.lib, self.seed, self.chain, self.calls = oracle, oracle.load(), seed, chain, 0
+
+    def _next(self, want):
+        t, kind = divmod(self.calls, 3)
+        assert kind in want
+        self.calls += 1
+        return t, kind
+
+    def rand(self):
+        t, kind = self._next((0, 2))
+        pair, odd = self.chain >> 1, self.chain & 1
+        va = self.o.draw_words(self.seed, pair, t, 1, 1)
+        if kind == 0:
+            return self.lib.amo_uniform_pick(va[2 * odd])
+        vn = self.o.draw_words(self.seed, pair, t, 0, 1)
+        return self.lib.amo_uniform_accept(vn[2 * odd], va[2 * odd], va[2 * odd + 1])
+
+    def randn(self):
+        t, _ = self._next((1,))
+        return self.o.box_muller(self.o.draw_words(self.seed, self.chain >> 1, t, 0, 1))[self.chain & 1]
+
+
+def test_reference_call_order_on_the_draw_schedule_reproduces_the_oracle(oracle):
+    """mc_sweep! (metropolis.jl:203-212) written against an RNG OBJECT, like the reference, with the generator above:
+    positions, energies and per-move counters equal the oracle's counter-indexed sweep bit for bit.  This is the
+    mapping the reference's `R=` hook would consume through julia/PhiloxRNG.jl."""
+    M, steps, seed, offset = 9, 40, 2 ** 40 + 17, 6
+    sigma, weight, beta = [0.3, 1.1, 0.05], [0.5, 0.2, 0.3], 2.0
+    o = oracle.OracleSim(M, chain_offset=offset, potential="double_well", beta=beta, sigma=sigma, weight=weight, seed=seed)
+    o.init_uniform(-2, 2)
+    x0, e0 = o.state()
+    o.make_steps(steps)
+    xo, eo = o.state()
+    acc_o, tot_o = o.counters()
+    lib = oracle.load()
+    w = (__import__("ctypes").c_double * 3)(*weight)
+    for c in range(M):
+        rng = _PhiloxCalls(oracle, seed, offset + c)
+        x, e = float(x0[c]), float(e0[c])
+        acc, tot = [0, 0, 0], [0, 0, 0]
+        for _ in range(steps):
+            k = lib.amo_categorical(w, 3, rng.rand())                          # :206
+            z = rng.randn()                                                    # sample_action!
+            u = rng.rand()                                                     # :184 (drawn after the proposal)
+            a, x, e = oracle.mc_step_explicit(1, beta, sigma[k], z, u, x, e)   # :176-190
+            acc[k] += a
+            tot[k] += 1
+        assert x == xo[c] and e == eo[c]
+        assert acc == acc_o[:, c].tolist() and tot == tot_o[:, c].tolist()
