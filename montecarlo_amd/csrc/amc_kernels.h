@@ -898,7 +898,7 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     x = xn + (-delta);
     // alpha = min(1, exp(arg)) with Julia's NaN-propagating min, without the generic guards: exp(arg >= 0) >= 1 and
     // exp(arg <= 0) <= 1 hold exactly for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);
-    // arg < -708 -> 0;  NaN -> NaN.  Bit-identical to julia_min(1.0, exp_f64(arg)), 9 instead of 18 select/compare ops.
+    // arg < -708 -> 0;  NaN -> NaN.  Bit-identical to Julia's NaN-propagating min(1.0, exp(arg)) on the full-domain exp, 9 instead of 18 select/compare ops.
     const double arg = (dlogp + logq) - logq;
     double ex = exp_core_f64(arg, T);
     asm volatile("" : "+v"(ex));          // keep the exp unconditional: no divergent branch around it
