@@ -837,7 +837,7 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     if (h->K > 1) {
         AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(amc::counter_totals_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, h->d_acc,
+        hipLaunchKernelGGL(amc::counter_totals_kernel, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream, h->d_acc,
                            h->d_tot, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
         AMC_HIP(hipGetLastError());
     }

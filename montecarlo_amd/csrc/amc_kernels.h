@@ -736,12 +736,19 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
     __shared__ double s_math[POT == POT_CUSTOM ? TAB_DOUBLES : 1];      // a custom potential may call amc_exp
     if (POT == POT_CUSTOM) stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
-        const double xc = x[c];
-        v[0] += potential<POT>(xc, s_math);
-        v[1] += xc;
-        v[2] += xc * xc;
+    const int64_t n_pairs = (n_chains + 1) >> 1;              // 16-byte loads; x is padded, the odd slot of a lone last chain is masked
+    for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
+        const double2 xp = *reinterpret_cast<const double2*>(x + 2 * p);
+        v[0] += potential<POT>(xp.x, s_math);
+        v[1] += xp.x;
+        v[2] += xp.x * xp.x;
         v[3] += 1.0;
+        if (2 * p + 1 < n_chains) {
+            v[0] += potential<POT>(xp.y, s_math);
+            v[1] += xp.y;
+            v[2] += xp.y * xp.y;
+            v[3] += 1.0;
+        }
     }
     double* out = partials + (int64_t)blockIdx.x * p_stride;
     block_sum_store<4>(v, out);
@@ -826,27 +833,45 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* p
     }
 }
 
-// Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].
+// Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].  16-byte loads, one atomic per
+// block and value (same-address atomics serialise at ~13 ns each: per-wave atomics from a full grid cost 0.2 ms here).
 __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_t* acc, const uint32_t* tot,
                                                                     int64_t n_chains, int64_t m_stride,
                                                                     int n_moves, unsigned long long* out_acc,
                                                                     unsigned long long* out_tot)
 {
+    __shared__ unsigned long long s_a[AMC_BLOCK / 64], s_t[AMC_BLOCK / 64];
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    const int64_t n_quads = (n_chains + 3) >> 2;              // rows are padded: the last quad is readable
     for (int k = 0; k < n_moves; ++k) {
         unsigned long long sa = 0, st = 0;
-        for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
-            sa += acc[(int64_t)k * m_stride + c];
-            if (tot) st += tot[(int64_t)k * m_stride + c];
+        for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
+            const uint4 va = *reinterpret_cast<const uint4*>(acc + (int64_t)k * m_stride + 4 * q);
+            const uint4 vt = tot ? *reinterpret_cast<const uint4*>(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
+            const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < n_chains) {                   // the padding behind the last chain holds no counts
+                    sa += a4[j];
+                    st += t4[j];
+                }
         }
         for (int off = 32; off > 0; off >>= 1) {
             sa += __shfl_down(sa, off, 64);
             st += __shfl_down(st, off, 64);
         }
         if ((threadIdx.x & 63) == 0) {
-            if (sa) atomicAdd(out_acc + k, sa);
-            if (st) atomicAdd(out_tot + k, st);
+            s_a[threadIdx.x >> 6] = sa;
+            s_t[threadIdx.x >> 6] = st;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long ta = 0, tt = 0;
+            for (int w = 0; w < AMC_BLOCK / 64; ++w) { ta += s_a[w]; tt += s_t[w]; }
+            if (ta) atomicAdd(out_acc + k, ta);
+            if (tt) atomicAdd(out_tot + k, tt);
+        }
+        __syncthreads();
     }
 }
 
