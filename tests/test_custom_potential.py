@@ -314,3 +314,29 @@ def test_disk_cache_of_compiled_potentials(amc, tmp_path, monkeypatch):
         f.truncate(100)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and os.path.getsize(tmp_path / files[0]) > 10_000
+
+
+@pytest.mark.gpu
+def test_custom_potential_with_nan_region(gpu, oracle):
+    """U(x) = x - log(x): NaN for x < 0 (the spec's log returns NaN there), +inf at 0.  A proposal into the forbidden
+    region has a NaN energy, Julia's min keeps the NaN and `alpha > u` is false: rejected.  The accept filter must
+    leave such decisions to the reference-ordered arithmetic; chains started at x < 0 carry NaN energies throughout."""
+    M = 20011
+    eng, ref = _pair(gpu, oracle, M, "x - amc_log(x)", beta=1.0, sigma=[0.8], weight=[1.0], seed=2, per_chain_counters=True)
+    x0 = np.random.default_rng(1).uniform(-0.5, 3.0, M)
+    x0[:3] = [0.0, -0.0, 1e-300]
+    eng.upload_state(x0); ref.set_x(x0)
+    for _ in range(3):
+        eng.sweep(1)
+    eng.sweep(17)
+    ref.make_steps(20, 8)
+    x, e = eng.download_state()
+    xo, eo = ref.state()
+    assert np.array_equal(bits(x), bits(xo))
+    nan = np.isnan(eo)                                  # NaN payloads are not part of the spec: compare as NaN
+    assert np.array_equal(np.isnan(e), nan) and np.array_equal(bits(e[~nan]), bits(eo[~nan]))
+    acc, tot = eng.download_counters()
+    ao, to = ref.counters()
+    assert np.array_equal(acc, ao) and np.array_equal(tot, to)
+    assert np.isnan(e[x0 < 0]).all() and np.isfinite(e[(x0 > 0.5)]).all()
+    eng.close(); ref.close()
