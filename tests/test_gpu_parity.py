@@ -601,8 +601,8 @@ def test_accept_filter_estimate_stays_inside_its_error_budget(gpu):
 @pytest.mark.parametrize("K,potential,counters", [(1, "harmonic", False), (2, "double_well", True)])
 def test_filtered_and_exact_accept_decisions_agree_on_millions_of_steps(gpu, monkeypatch, K, potential, counters):
     """The same run with the filter (default) and with every decision taken by the reference-ordered arithmetic
-    (AMC_EXACT_ACCEPT=1): states and accept counts bit for bit.  3e6 chains x 24 steps = 7e7 decisions, ~2000 of which
-    fall inside the filter's error interval and take the exact path in the filtered run as well."""
+    (AMC_EXACT_ACCEPT=1): states and accept counts bit for bit.  3e6 chains x 804 steps = 2.4e9 decisions; ~1e5 of them
+    (K = 1: 12-bit bracket of u) fall inside the filter's interval and take the exact path in the filtered run as well."""
     sigma, weight = POOLS[K]
     kw = dict(n_chains=3_000_001, potential=potential, beta=2.0, sigma=sigma, weight=weight, seed=123, per_chain_counters=counters)
     runs = []
@@ -612,7 +612,7 @@ def test_filtered_and_exact_accept_decisions_agree_on_millions_of_steps(gpu, mon
         e.init_uniform(-2, 2)
         for _ in range(4):
             e.sweep(1)
-        e.sweep(20)
+        e.sweep(800)
         runs.append((e.download_state()[0], e.counter_totals()[0]))
         e.close()
     assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
