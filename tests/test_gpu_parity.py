@@ -636,3 +636,43 @@ def test_accept_filter_at_extreme_step_sizes(gpu, oracle, sigma):
     o.make_steps(12, 8)
     assert_same(e, o)
     e.close()
+
+
+def test_randomised_configurations_against_the_oracle(gpu, oracle):
+    """Forty seeded random configurations -- pool size, step sizes over 12 decades, weights, beta (scalar or per chain,
+    over 6 decades), potential, chain count and offset, sweepstep, launch pattern -- each bit for bit against the
+    oracle: states, energies, per-chain counters, reductions."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        K = int(rng.choice([1, 1, 2, 3, 5]))
+        sigma = list(np.exp(rng.uniform(np.log(1e-6), np.log(1e6), K)))
+        w = rng.uniform(0.05, 1.0, K)
+        weight = list(w / w.sum())
+        weight[-1] = 1.0 - sum(weight[:-1])
+        M = int(rng.integers(1, 6000))
+        offset = 2 * int(rng.integers(0, 2 ** 33))
+        beta = float(np.exp(rng.uniform(np.log(1e-3), np.log(1e3))))
+        potential = str(rng.choice(["harmonic", "double_well"]))
+        sweepstep = int(rng.choice([1, 1, 2, 5]))
+        counters = bool(rng.integers(0, 2)) or K > 1
+        kw = dict(potential=potential, beta=beta, sigma=sigma, weight=weight, seed=int(rng.integers(0, 2 ** 63)), sweepstep=sweepstep)
+        e = gpu.HipEngine(n_chains=M, chain_offset=offset, n_chains_global=offset + M, per_chain_counters=counters, **kw)
+        o = oracle.OracleSim(M, chain_offset=offset, **kw)
+        x0 = rng.normal(0, 1.5, M) * float(np.exp(rng.uniform(-3, 3)))
+        if rng.random() < 0.4:
+            b = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), M))
+            e.upload_state(x0, b); o.set_x(x0); o.set_beta(b)
+        else:
+            e.upload_state(x0); o.set_x(x0)
+        n1, n2 = int(rng.integers(0, 4)), int(rng.integers(1, 40))
+        for _ in range(n1):
+            e.sweep(1)
+        e.sweep(n2)
+        o.make_steps(n1 + n2, 4)
+        try:
+            assert_same(e, o, counters=counters)
+        except AssertionError as err:
+            raise AssertionError(f"case {case}: K={K} sigma={sigma} beta={beta} {potential} M={M} sweepstep={sweepstep} "
+                                 f"counters={counters} launches={n1}+{n2}: {err}") from None
+        finally:
+            e.close()
