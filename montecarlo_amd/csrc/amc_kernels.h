@@ -211,22 +211,30 @@ __device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, doubl
     }
 }
 
-// 16-byte store of a chain pair with the sc1 (write-through) policy: the line does not stay dirty
-// in the XCD's L2, so the kernel boundary does not pay for writing back up to 32 MB of dirty lines
-// (MI355X_MICROARCH.md, store flavours / "boundary" row: + B / 6 TB/s for B dirty bytes).
-__device__ __forceinline__ void store_pair_writethrough(double* p, double2 v)
+// 16-byte loads / stores of a chain pair.  Stores use the sc1 (write-through) policy: the line does not stay dirty in
+// the XCD's L2, so the kernel boundary does not pay for writing back up to 32 MB of dirty lines
+// (MI355X_MICROARCH.md, store flavours / "boundary" row: + B / 6 TB/s for B dirty bytes; plain, nt and sc0 sc1 stores
+// were re-measured: sc1 is the fastest).  The address lives on the SCALAR unit: a buffer resource at the block's (uniform)
+// base plus the lane's constant byte offset threadIdx.x * 16 -- no per-lane 64-bit address arithmetic in the loop
+// (4 VALU instructions per load/store pair otherwise).  aux 16 = sc1.
+typedef uint32_t u32v4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 load_pair_block(const double* block_base)
 {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    d2_t t;
-    t.x = v.x;
-    t.y = v.y;
-    // trailing s_nop 1: a VMEM store of more than 8 bytes reads its data VGPRs over the next cycles, and a
-    // VALU write to them needs 2 wait states on gfx940+/gfx950 (LLVM inserts them for its own stores, never
-    // around inline asm) -- without it lanes 12..15 of each row stored a later value of the registers.
-#ifndef AMC_STORE_FLAVOR
-#define AMC_STORE_FLAVOR "sc1"
-#endif
-    asm volatile("global_store_dwordx4 %0, %1, off " AMC_STORE_FLAVOR "\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)block_base, 0, 0x7fffffff, 0x00020000);
+    const u32v4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, threadIdx.x * 16, 0, 0);
+    double2 d;
+    d.x = __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x));
+    d.y = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+    return d;
+}
+
+__device__ __forceinline__ void store_pair_block_writethrough(double* block_base, double2 d)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)block_base, 0, 0x7fffffff, 0x00020000);
+    const uint64_t a = (uint64_t)__double_as_longlong(d.x), b = (uint64_t)__double_as_longlong(d.y);
+    const u32v4_t v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, threadIdx.x * 16, 0, 16);
 }
 
 // ---- deterministic block reduction helpers -------------------------------------
@@ -410,8 +418,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // An iteration that has a successor covers 256 in-range pairs on every lane (stride >= 256), so the
     // loop body runs without per-lane predicates; only the LAST iteration of a block can be ragged and is
     // peeled.  Loads need no clamp either: the arrays carry AMC_PAD_DOUBLES of readable padding.
-    auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
-    auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
+    auto load_x = [&](int64_t b) -> double2 { return load_pair_block(a.x + 2 * b); };
+    auto load_b = [&](int64_t b) -> double2 { return load_pair_block(a.beta_arr + 2 * b); };
     double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
     if (first < n_pairs) {
         x_nxt = load_x(first);
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         x_nxt = load_x(base + stride);
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) {
-            store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            store_pair_block_writethrough(a.x + 2 * base_done, x_done);
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
         const StepDraws dr = dr_nxt;
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
         double2 xv = x_nxt;
         if (base_done >= 0) {
-            store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+            store_pair_block_writethrough(a.x + 2 * base_done, x_done);
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
         uint32_t lw = 0;
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                                                    s_tab, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt);
         // a lone last chain (odd n_chains) writes its whole pair (x and log): the odd slot is padding
         if (v0) {
-            store_pair_writethrough(a.x + 2 * p, xv);
+            store_pair_block_writethrough(a.x + 2 * base, xv);
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, p, lw);
         }
         if (REDUCE) {
@@ -1024,8 +1032,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             }
         }
     };
-    auto load_x = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.x + 2 * (b + threadIdx.x)); };
-    auto load_b = [&](int64_t b) -> double2 { return *reinterpret_cast<const double2*>(a.beta_arr + 2 * (b + threadIdx.x)); };
+    auto load_x = [&](int64_t b) -> double2 { return load_pair_block(a.x + 2 * b); };
+    auto load_b = [&](int64_t b) -> double2 { return load_pair_block(a.beta_arr + 2 * b); };
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
     double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
     if (first < n_pairs) {
@@ -1042,7 +1050,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         const double b0 = b_nxt.x, b1 = b_nxt.y;
         x_nxt = load_x(base + stride);
         if (BETA) b_nxt = load_b(base + stride);
-        if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
         samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true);
         x_done = xv;
@@ -1053,11 +1061,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         const bool v0 = p < n_pairs;
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
         double2 xv = x_nxt;
-        if (base_done >= 0) store_pair_writethrough(a.x + 2 * (base_done + threadIdx.x), x_done);
+        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
         if (v0) {
             samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, v1);
-            store_pair_writethrough(a.x + 2 * p, xv);        // a lone last chain writes its whole pair: padding
+            store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
         }
     }
     if (SWEEP == 1) add_block_accepts(sw.acc_total, wave_acc);   // K == 1: the pool-wide accepted total (counter_totals)
