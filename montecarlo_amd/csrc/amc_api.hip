@@ -100,6 +100,7 @@ struct amc_handle {
     int red_blocks = 0;
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
+    int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
     bool red_pending = false;
     uint64_t red_t_counted = 0;
@@ -118,11 +119,11 @@ struct amc_handle {
 
 namespace {
 
-int grid_for(const amc_handle* h, int64_t n_items)
+int grid_for(const amc_handle* h, int64_t n_items, int blocks_per_cu = 0)
 {
     // memory-streaming shape: <= 8 blocks of 256 per CU, grid-stride the rest
     int64_t blocks = (n_items + AMC_BLOCK - 1) / AMC_BLOCK;
-    const int64_t cap = (int64_t)h->n_cu * h->blocks_per_cu;
+    const int64_t cap = (int64_t)h->n_cu * (blocks_per_cu > 0 ? blocks_per_cu : h->blocks_per_cu);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -573,12 +574,13 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (!h) return fail(AMC_ERR_OOM, "amc_create: host allocation failed");
     h->device = cfg->device;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // 8 resident blocks per CU; the K = 1 pool-wide-counter sweep (56 VGPRs, no step log) measures 5 % faster with 6
-    // (29.4 vs 31.2 us at 1e7 chains; the other forms are fastest at 8)
-    h->blocks_per_cu = (cfg->n_moves == 1 && !cfg->per_chain_counters) ? 6 : 8;
+    // 8 resident blocks per CU; the single-step launch of the K = 1 pool-wide-counter sweep (no step log) measures 5 %
+    // faster with 6 (29.4 vs 31.2 us at 1e7 chains; its fused launches and all other forms are fastest at 8)
+    h->blocks_per_cu = 8;
+    h->blocks_per_cu_single = (cfg->n_moves == 1 && !cfg->per_chain_counters) ? 6 : 8;
     if (const char* env = std::getenv("AMC_BLOCKS_PER_CU")) {   // tuning knob, 1..64
         const int v = std::atoi(env);
-        if (v >= 1 && v <= 64) h->blocks_per_cu = v;
+        if (v >= 1 && v <= 64) h->blocks_per_cu = h->blocks_per_cu_single = v;
     }
     if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
     h->M = cfg->n_chains;
@@ -877,6 +879,7 @@ static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
     a.red_partials = h->h_partials;
     a.red_stride = RED_HOST_STRIDE;
     a.exact_accept = h->exact_accept ? 1 : 0;
+    a.n_slots = h->n_slots;
     return a;
 }
 
@@ -886,7 +889,8 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
 {
     AMC_HIP(hipSetDevice(h->device));
     int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
-    const int grid = grid_for(h, (h->M + 1) / 2);
+    // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
+    const int grid = grid_for(h, (h->M + 1) / 2, remaining == 1 ? h->blocks_per_cu_single : 0);
     if (grid_out) *grid_out = grid;
     while (remaining > 0) {
         int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;

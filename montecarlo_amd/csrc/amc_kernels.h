@@ -287,6 +287,7 @@ struct SweepArgs {
     int32_t red_stride;
     int32_t log_pos;              // row of the step log the first step of this launch writes
     int32_t exact_accept;         // != 0: skip the accept filter, every decision by accept_exact (tests; AMC_EXACT_ACCEPT)
+    int32_t n_slots;              // length of acc_total (launches of different grids share it)
 };
 
 // The Philox results of one MH step of a pair (normal draw; for K > 1 also the accept draw, whose low bits are the
@@ -501,8 +502,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (REDUCE && !LOG) {
                 // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
                 // value after this launch (exact in a double below 2^53); the rows are summed by the host
-                const unsigned long long now =
+                unsigned long long now =
                     __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
+                // slots beyond this launch's grid were filled by launches with a larger one (nobody writes them now)
+                for (int sl = (int)blockIdx.x + (int)gridDim.x; sl < a.n_slots; sl += (int)gridDim.x) now += a.acc_total[sl];
                 a.red_partials[(int64_t)blockIdx.x * a.red_stride + 4] = (double)now;
             } else if (t != 0) {
                 // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
