@@ -225,3 +225,25 @@ def test_pgmc_example_learning_curve_on_device(gpu):
     s = _pgmc_example_sigma_at(None, 200_000, 42, [250, 500, 1000])
     assert s[0] < s[1] < s[2]
     assert s[2] == pytest.approx(0.33, abs=0.03)
+
+
+def test_accept_filter_soak_at_full_size(gpu, monkeypatch):
+    """1e7 chains x 2000 steps = 2e10 accept decisions, once through the filter and once through the reference-ordered
+    arithmetic alone (AMC_EXACT_ACCEPT=1): every position and the accepted total must be identical.  About 2.4e6 of the
+    filtered run's decisions fall into the filter's interval and are settled by the exact arithmetic there too."""
+    kw = dict(n_chains=M_FULL, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=5, per_chain_counters=False)
+    runs = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("AMC_EXACT_ACCEPT", exact)
+        e = gpu.HipEngine(**kw)
+        e.init_uniform(-2, 2)
+        e.sweep(1)
+        e.sweep(999)
+        mid = int(e.counter_totals()[0][0])
+        e.sweep(1000)
+        runs.append((e.download_state(want_e=False)[0], int(e.counter_totals()[0][0]), mid))
+        e.close()
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    rate = (runs[0][1] - runs[0][2]) / (1000 * M_FULL)              # the second thousand steps: equilibrated
+    assert rate == pytest.approx(KATS["analytic"]["acceptance"]["beta=2.0,sigma=0.1"], abs=1e-4)
