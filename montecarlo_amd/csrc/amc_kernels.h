@@ -121,8 +121,9 @@ __device__ __forceinline__ bool accept_exact(double delta, double dlogp, double 
     return c_pos | (c_rng & c_exp);
 }
 
-// Filter.  Inputs: dlogp (exact, f64) and the HIGH word of the chain's accept draw (u = top 52 bits of (hi:lo), so
-// k 2^-24 <= u < (k+1) 2^-24 with k = hi >> 8, both ends exact floats).  Error budget of the estimate
+// Filter.  Inputs: dlogp (exact, f64) and k = the top B bits of u's 52-bit significand, so k 2^-B <= u < (k+1) 2^-B with
+// both ends exact floats (B = 12: the bits the normal draw supplies, spec v4; B = 24 once the accept draw is at hand).
+// Error budget of the estimate
 // ex = v_exp_f32(log2e * float(dlogp)) against the spec's exp(arg), for -17 <= dlogp < 1e-12 (relative):
 //   arg vs dlogp      arg = fl(fl(dlogp + logq) - logq), |arg - dlogp| <= 2^-53 (2|dlogp| + |logq|) with
 //                     |logq| <= z^2/2 (1 + 2^-50) + |log(2 pi s^2)/2| <= 37 + 231 (|z| <= 8.5, 1e-100 <= s <= 1e100)
@@ -134,7 +135,8 @@ __device__ __forceinline__ bool accept_exact(double delta, double dlogp, double 
 //   * (1 -+ eps)      one float rounding                                                                    6e-8
 // total < 3.1e-6; eps = 2^-16 = 1.5e-5 leaves a factor 5.  Outside the range: dlogp > 1e-12 -> arg > 0 -> accept;
 // dlogp < -17 -> the clamped estimate is an upper bound only.  NaN compares false everywhere -> undecided.
-// Undecided with probability ~3e-5 per chain-step; then the whole wave takes accept_exact.
+// Undecided when u's cell touches the interval (B = 12: ~1.2e-4 per chain-step, B = 24: ~3e-5); then the whole wave
+// takes accept_exact.
 #define AMC_FILTER_EPS 0x1.0p-16f
 // The five primitive comparisons of one chain; the decision masks are formed from their ballots on the scalar unit
 // (a ballot of a COMPOUND bool goes through a 0/1 VGPR and a second compare).  The sign tests use the float t:
