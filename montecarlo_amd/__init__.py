@@ -6,7 +6,7 @@ Simulation / run -- so a user of TheDisorderedOrganization/MonteCarlo's particle
 the same names.  There is no CPU implementation here: without the built extension and a GPU,
 constructing ``Metropolis`` raises.
 """
-from ._capi import AmcError, HipEngine, device_count
+from ._capi import AmcError, HipEngine, SplitEngine, device_count
 from .metropolis import Metropolis, callback_acceptance, callback_energy, callback_moments
 from .policy_guided import (ANPG, BLANPG, BLAPG, BLPG, NPG, VPG, GradientData, PolicyGradientEstimator,
                             PolicyGradientUpdate, Static, average, initialise_gradient_data, learning_step)
@@ -17,7 +17,7 @@ from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
 from .system import CustomPotential, Displacement, Move, ParticleChains, StandardGaussian, potential
 
 __all__ = [
-    "AmcError", "HipEngine", "device_count",
+    "AmcError", "HipEngine", "SplitEngine", "device_count",
     "Metropolis", "callback_acceptance", "callback_energy", "callback_moments",
     "ANPG", "BLANPG", "BLAPG", "BLPG", "NPG", "VPG", "Static", "GradientData", "PolicyGradientEstimator",
     "PolicyGradientUpdate", "average", "initialise_gradient_data", "learning_step",

@@ -676,3 +676,59 @@ def test_randomised_configurations_against_the_oracle(gpu, oracle):
                                  f"counters={counters} launches={n1}+{n2}: {err}") from None
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("K,counters", [(1, False), (2, True)])
+def test_split_engine_equals_single_engine(gpu, K, counters):
+    """SplitEngine: the shard as sub-shards on separate streams (their launches overlap).  Per-chain results are those
+    of one engine bit for bit (global chain ids); reductions and gradient sums agree to rounding."""
+    sigma, weight = POOLS[K]
+    kw = dict(n_chains=100_003, potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=8, per_chain_counters=counters)
+    one = gpu.HipEngine(**kw)
+    parts = gpu.SplitEngine(n_parts=3, **kw)
+    assert [p.n_chains for p in parts.parts] == [33334, 33334, 33335] and sum(p.n_chains for p in parts.parts) == 100_003
+    for e in (one, parts):
+        e.init_uniform(-2, 2)
+        for _ in range(3):
+            e.sweep(1)
+        e.sweep(7)
+    assert np.array_equal(bits(one.download_state()[0]), bits(parts.download_state()[0]))
+    assert np.array_equal(one.counter_totals()[0], parts.counter_totals()[0])
+    if counters:
+        assert np.array_equal(one.download_counters()[0], parts.download_counters()[0])
+    np.testing.assert_allclose(one.reduce(), parts.reduce(), rtol=1e-12)
+    for e in (one, parts):
+        e.sweep_reduce_begin(1)
+    np.testing.assert_allclose(one.reduce_end(), parts.reduce_end(), rtol=1e-12)
+    np.testing.assert_allclose(one.pg_estimate([0], 2), parts.pg_estimate([0], 2), rtol=1e-11)
+    assert np.array_equal(bits(one.download_state()[0]), bits(parts.download_state()[0]))
+    one.close(); parts.close()
+
+
+def test_metropolis_streams_option(gpu, tmp_path):
+    """Metropolis(streams=2) through the host mirror: same callback rows and final state as streams=1."""
+    import montecarlo_amd as ma
+    out = []
+    for streams in (1, 2):
+        chains = ma.ParticleChains.uniform(50_001, 2.0, -2.0, 2.0)
+        pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 1.0),)
+        al = (dict(algorithm=ma.Metropolis, pool=pool, seed=3, streams=streams),
+              dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance), scheduler=ma.build_schedule(60, 10, 10)))
+        sim = ma.Simulation(chains, al, 60, path=str(tmp_path / str(streams)))
+        ma.run(sim)
+        out.append((chains.x.copy(), [v for _, v in sim.algorithms[1].rows[0]], pool[0].accepted_calls))
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and out[0][2] == out[1][2]
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12)
+
+
+def test_split_engine_snapshots_and_pool_totals(gpu):
+    kw = dict(n_chains=10_001, potential="harmonic", beta=2.0, sigma=[0.2], weight=[1.0], seed=4, per_chain_counters=False)
+    one, parts = gpu.HipEngine(**kw), gpu.SplitEngine(n_parts=2, **kw)
+    for e in (one, parts):
+        e.init_uniform(-2, 2)
+        e.sweep(5)
+    assert np.array_equal(bits(one.download_strided(3, 7, 1400)), bits(parts.download_strided(3, 7, 1400)))
+    assert np.array_equal(one.histogram(-2, 2, 50), parts.histogram(-2, 2, 50))
+    parts.set_counter_totals(1234, 5)
+    assert parts.counter_totals()[0][0] == 1234 and parts.counter_totals()[1][0] == 5 * 10_001
+    one.close(); parts.close()
