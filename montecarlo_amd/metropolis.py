@@ -190,10 +190,14 @@ class Metropolis(AriannaAlgorithm):
 
 
 def _find_metropolis(simulation: Simulation):
+    cached = simulation.__dict__.get("_the_metropolis")
+    if cached is not None:
+        return cached
     found = [a for a in simulation.algorithms if isinstance(a, Metropolis)]
     if len(found) != 1:
         # the reference's generator splat only works with exactly one Metropolis (metropolis.jl:320)
         raise ValueError(f"callbacks need exactly one Metropolis in the algorithm list, found {len(found)}")
+    simulation.__dict__["_the_metropolis"] = found[0]
     return found[0]
 
 

@@ -95,6 +95,8 @@ def julia_repr(v) -> str:
     if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
         return str(int(v))
     x = float(v)
+    if 1e-4 <= abs(x) < 1e6:
+        return repr(x)              # same shortest round-trip digits, same fixed notation (the common case, fast)
     if math.isnan(x):
         return "NaN"
     if math.isinf(x):
