@@ -166,8 +166,37 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         # sum below goes through torch.distributed on the host); the values are identical either way.
         eng = self.metropolis.engine
         if device_resident is None:
-            device_resident = self.metropolis.world_size == 1 and hasattr(eng, "pg_accumulate")
+            if self.metropolis.world_size == 1:
+                device_resident = hasattr(eng, "pg_accumulate")
+            else:
+                device_resident = hasattr(eng, "pg_accumulate") and self.connect_shards()
         self.device_resident = bool(device_resident)
+
+    def connect_shards(self) -> bool:
+        """Sharded runs: give the engines an RCCL communicator of their own (amc_comm_init), so that the estimator's
+        fold is ONE in-place all-reduce of 4 n_learn doubles on each engine's stream and gradients_data / the learning
+        step stay on the devices -- no host round trip per step.  The 128-byte ncclUniqueId travels over the process
+        group the script already has.  libamc.so resolves RCCL with dlopen by soname, i.e. it shares the instance
+        torch.distributed has loaded.  False (host path via pg_estimate + torch all-reduce) when there is no NCCL
+        process group or the engine cannot do it."""
+        met = self.metropolis
+        if getattr(met, "_comm_connected", False):
+            return True
+        eng = met.engine
+        if not (hasattr(eng, "comm_init") and hasattr(eng, "comm_unique_id")):
+            return False
+        import sys
+        if "torch" not in sys.modules:
+            return False
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return False
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(rank, world, box[0])
+        met._comm_connected = True
+        return True
 
     def refresh(self) -> None:
         """Device-resident mode: pull the running gradients_data / objectives to the host (synchronises)."""

@@ -1,0 +1,38 @@
+"""Worker of tests/test_gpu_fullsize.py::test_sharded_pgmc_device_resident_over_rccl: a PGMC run inside a torch.distributed
+(NCCL = RCCL) process group, with the estimator's fold all-reduced on the device through the communicator
+PolicyGradientEstimator.connect_shards() sets up, against the same run on the host path."""
+import json
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch                      # first: libamc.so then shares torch's HIP runtime and RCCL (same sonames)
+import torch.distributed as dist
+import montecarlo_amd as ma
+
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+out = {}
+for mode in ("comm", "host"):
+    chains = ma.ParticleChains.uniform(60_000, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
+            ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.3)),
+               q_batch_size=2, device_resident=(None if mode == "comm" else False)),
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)))
+    with tempfile.TemporaryDirectory() as d:
+        sim = ma.Simulation(chains, al, 120, path=d, verbose=False)
+        est = sim.algorithms[1]
+        if mode == "comm" and dist.get_world_size() == 1:
+            # one rank: the automatic choice is the plain device-resident path; take the communicator route explicitly
+            assert est.connect_shards()
+            est.device_resident = True
+        ma.run(sim)
+    out[mode] = dict(sigma=[m.sigma for m in pool], device_resident=est.device_resident,
+                     connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]))
+if dist.get_rank() == 0:
+    print(json.dumps(out))
+dist.destroy_process_group()

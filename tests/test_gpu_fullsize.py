@@ -247,3 +247,21 @@ def test_accept_filter_soak_at_full_size(gpu, monkeypatch):
     assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
     rate = (runs[0][1] - runs[0][2]) / (1000 * M_FULL)              # the second thousand steps: equilibrated
     assert rate == pytest.approx(KATS["analytic"]["acceptance"]["beta=2.0,sigma=0.1"], abs=1e-4)
+
+
+def test_sharded_pgmc_device_resident_over_rccl():
+    """PGMC inside a torch.distributed NCCL (= RCCL) process group: PolicyGradientEstimator.connect_shards() hands the
+    engines a communicator of their own, the fold is all-reduced in place on the device and the learning step stays
+    there; the learned sigma equals the host path's (pg_estimate + torch all-reduce).  One rank here (the GPU box has
+    one GPU); the code path is the N-rank one."""
+    import json, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "pgmc_comm_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["comm"]["connected"] and out["comm"]["device_resident"] and not out["host"]["device_resident"]
+    assert out["comm"]["sigma"][0] == out["host"]["sigma"][0] == 0.2
+    assert out["comm"]["sigma"][1] == pytest.approx(out["host"]["sigma"][1], rel=1e-12) and out["comm"]["sigma"][1] > 0.5
+    assert out["comm"]["x0"] == pytest.approx(out["host"]["x0"], abs=1e-9)
