@@ -124,6 +124,11 @@ int  amc_destroy(amc_handle *h);
  * Environment: AMC_RTC_CACHE_DIR=<dir> keeps the compiled code objects on disk (one file per expression and kernel
  * form, keyed by a hash that includes the kernel sources), so later processes skip the compile. */
 int  amc_create_custom(const amc_config *cfg, const char *potential_expr, amc_handle **out);
+/* The same with the model's `reward(action, system)` (src/PolicyGuided/gradients.jl:20, evaluated at :100 right after
+ * perform_action!; particle_1d.jl:42-44 defines delta^2) as a second expression, in `delta` and the NEW position `x`
+ * -- what the policy-gradient estimator maximises (E[reward * alpha]).  potential_expr NULL: the built-in potential named
+ * by cfg->potential (its own expression, compiled at run time); reward_expr NULL: delta^2. */
+int  amc_create_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
 int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);
 

@@ -71,6 +71,7 @@ def load() -> C.CDLL:
         "amc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "amc_create": (C.c_int, [C.POINTER(AmcConfig), C.POINTER(H)]),
         "amc_create_custom": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.POINTER(H)]),
+        "amc_create_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -153,7 +154,8 @@ class HipEngine:
     def __init__(self, *, n_chains: int, chain_offset: int = 0, n_chains_global: Optional[int] = None,
                  potential="harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
-                 per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None):
+                 per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
+                 reward_expr: Optional[str] = None):
         lib = load()
         expr = getattr(potential, "expr", None)        # system.CustomPotential: a C expression in x
         if expr is None and potential not in POTENTIALS:
@@ -180,7 +182,13 @@ class HipEngine:
         cfg.stream = stream
         self._lib = lib
         self._h = C.c_void_p()
-        if expr is not None:
+        if reward_expr is not None:
+            # script-defined reward(action, system) (gradients.jl:20): an expression in delta and the new position x
+            if expr is None:
+                cfg.potential = POTENTIALS[potential]
+            _check(lib.amc_create_model(C.byref(cfg), None if expr is None else str(expr).encode(),
+                                        str(reward_expr).encode(), C.byref(self._h)))
+        elif expr is not None:
             _check(lib.amc_create_custom(C.byref(cfg), str(expr).encode(), C.byref(self._h)))
         else:
             _check(lib.amc_create(C.byref(cfg), C.byref(self._h)))

@@ -326,22 +326,24 @@ int load_hiprtc(Hiprtc& r)
 }
 
 // The expression becomes the body of a function-like macro: keep it to one line of ordinary expression text.
-int validate_potential_expr(const char* expr)
+int validate_potential_expr(const char* expr, const char* what = "custom potential", const char* var = "x")
 {
-    if (!expr) return fail(AMC_ERR_BAD_ARG, "custom potential: expression is NULL");
+    if (!expr) return fail(AMC_ERR_BAD_ARG, "%s: expression is NULL", what);
     const size_t n = std::strlen(expr);
-    if (n == 0 || n > 4000) return fail(AMC_ERR_BAD_ARG, "custom potential: expression must have 1..4000 characters");
+    if (n == 0 || n > 4000) return fail(AMC_ERR_BAD_ARG, "%s: expression must have 1..4000 characters", what);
     bool has_x = false;
     for (size_t i = 0; i < n; ++i) {
         const unsigned char c = (unsigned char)expr[i];
         if (c < 0x20 || c > 0x7e || c == '#' || c == '\\' || c == ';' || c == '{' || c == '}' || c == '"' || c == '\'' ||
             c == '`' || c == '$' || c == '@')
-            return fail(AMC_ERR_BAD_ARG, "custom potential: character 0x%02x at offset %zu is not allowed in the expression", c, i);
+            return fail(AMC_ERR_BAD_ARG, "%s: character 0x%02x at offset %zu is not allowed in the expression", what, c, i);
         const bool ident_before = i > 0 && (std::isalnum((unsigned char)expr[i - 1]) || expr[i - 1] == '_');
-        const bool ident_after = i + 1 < n && (std::isalnum((unsigned char)expr[i + 1]) || expr[i + 1] == '_');
-        if (c == 'x' && !ident_before && !ident_after) has_x = true;
+        const size_t vl = std::strlen(var);
+        if (!ident_before && std::strncmp(expr + i, var, vl) == 0 &&
+            !(i + vl < n && (std::isalnum((unsigned char)expr[i + vl]) || expr[i + vl] == '_')))
+            has_x = true;
     }
-    if (!has_x) return fail(AMC_ERR_BAD_ARG, "custom potential: the expression does not mention x");
+    if (!has_x) return fail(AMC_ERR_BAD_ARG, "%s: the expression does not mention %s", what, var);
     return AMC_OK;
 }
 
@@ -417,7 +419,11 @@ int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode*
         }
     }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
-    const std::string src = "#define AMC_USER_POTENTIAL(x) (" + expr + ")\n#include \"amc_kernels.h\"\n";
+    // expr = potential [ '\x01' reward ]
+    const size_t cut = expr.find('\x01');
+    std::string src = "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
+    if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
+    src += "#include \"amc_kernels.h\"\n";
     const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES};
     const char* names[] = {"amc_kernels.h", "amc_math.h", "amc_tables.h"};
     void* prog = nullptr;
@@ -519,7 +525,7 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out)
+static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr)
 {
     if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
     *out = nullptr;
@@ -538,6 +544,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
             return fail(AMC_ERR_BAD_ARG, "amc_create: AMC_POTENTIAL_CUSTOM needs its expression: use amc_create_custom");
         const int rc_expr = validate_potential_expr(potential_expr);
         if (rc_expr != AMC_OK) return rc_expr;
+        if (reward_expr) {
+            const int rc_rew = validate_potential_expr(reward_expr, "custom reward", "delta");
+            if (rc_rew != AMC_OK) return rc_rew;
+        }
     } else if (potential_expr) {
         return fail(AMC_ERR_BAD_ARG, "amc_create_custom: cfg->potential must be AMC_POTENTIAL_CUSTOM");
     } else if (cfg->potential != AMC_POTENTIAL_HARMONIC && cfg->potential != AMC_POTENTIAL_DOUBLE_WELL) {
@@ -591,6 +601,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;
     if (potential_expr) h->pot_expr = potential_expr;
+    if (potential_expr && reward_expr) h->pot_expr += std::string("\x01") + reward_expr;
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
     h->counters = cfg->per_chain_counters != 0 || cfg->n_moves > 1;
@@ -682,6 +693,21 @@ int amc_create_custom(const amc_config* cfg, const char* potential_expr, amc_han
 {
     if (!potential_expr) return fail(AMC_ERR_BAD_ARG, "amc_create_custom: potential_expr is NULL");
     return create_impl(cfg, potential_expr, out);
+}
+
+int amc_create_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, amc_handle** out)
+{
+    if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_model: NULL argument");
+    // a built-in potential with a custom reward: the built-in's own expression, compiled at run time (bit-identical)
+    const char* pot = potential_expr;
+    if (!pot) {
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "amc_create_model: potential_expr is NULL and cfg->potential names no built-in");
+    }
+    amc_config c2 = *cfg;
+    c2.potential = AMC_POTENTIAL_CUSTOM;
+    return create_impl(&c2, pot, out, reward_expr);
 }
 
 int amc_potential_check(const char* potential_expr, char* log, int log_capacity)

@@ -55,14 +55,25 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
 #ifndef AMC_USER_POTENTIAL
 #define AMC_USER_POTENTIAL(x) (x)        // offline build: POT_CUSTOM kernels are never instantiated
 #endif
-__device__ __forceinline__ double user_potential(double x, const double* amc_tables_)
-{
+// reward(action, system) (gradients.jl:20; the model's is particle_1d.jl:42-44, delta^2): likewise script-defined in the
+// reference, evaluated right after perform_action! (gradients.jl:100) -- an expression in `delta` and the NEW position
+// `x`, same vocabulary as the potential.
+#ifndef AMC_USER_REWARD
+#define AMC_USER_REWARD(delta, x) ((delta) * (delta))
+#endif
 #define amc_exp(v) (::amc::exp_f64((v), amc_tables_))
 #define amc_log(v) (::amc::log_f64((v)))
+__device__ __forceinline__ double user_potential(double x, const double* amc_tables_)
+{
     return AMC_USER_POTENTIAL(x);
+}
+
+__device__ __forceinline__ double user_reward(double delta, double x, const double* amc_tables_)
+{
+    return AMC_USER_REWARD(delta, x);
+}
 #undef amc_exp
 #undef amc_log
-}
 
 // potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
 // double well (x*x-1)^2 is BASELINE config 3's.  T: the block's LDS copy of the math tables (custom only).
@@ -932,7 +943,7 @@ __device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, 
     const double xn = x + delta;
     const double e2 = potential<POT>(xn, T);
     const double dlogp = ((-e2) * beta) - ((-e1) * beta);
-    const double r = delta * delta;                        // reward, particle_1d.jl:42-44
+    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : delta * delta;   // reward, particle_1d.jl:42-44
     x = xn + (-delta);
     // alpha = min(1, exp(arg)) with Julia's NaN-propagating min, without the generic guards: exp(arg >= 0) >= 1 and
     // exp(arg <= 0) <= 1 hold exactly for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);

@@ -63,7 +63,8 @@ class Metropolis(AriannaAlgorithm):
         if engine_factory is None and int(streams) > 1:
             # sub-shards of this rank's shard on separate streams (SplitEngine): their launches overlap
             factory = lambda **kw: SplitEngine(n_parts=int(streams), **kw)
-        self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains),
+        extra = {} if getattr(chains, "reward", None) is None else {"reward_expr": chains.reward}
+        self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains), **extra,
                               potential=chains.potential, beta=chains.beta,
                               sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],
                               seed=self.seed, sweepstep=self.sweepstep,

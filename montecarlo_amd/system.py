@@ -55,11 +55,15 @@ class ParticleChains:
     """
 
     def __init__(self, n_chains: int, beta, potential="harmonic", x: Optional[np.ndarray] = None,
-                 init_uniform: Optional[tuple] = None):
+                 init_uniform: Optional[tuple] = None, reward: Optional[str] = None):
         if not isinstance(potential, CustomPotential) and potential not in POTENTIALS:
             raise ValueError(f"unknown potential {potential!r}; the HIP engine offers {POTENTIALS} and CustomPotential(expr)")
         self.n_chains = int(n_chains)
         self.potential = potential
+        # reward(action, system) of the policy-guided estimator (src/PolicyGuided/gradients.jl:20; particle_1d.jl:42-44
+        # defines delta^2): None = delta^2, or a C expression in `delta` and the new position `x`, compiled like a
+        # CustomPotential (amc_create_model)
+        self.reward = reward
         self.beta_array = None
         if np.ndim(beta) == 0:
             self.beta = float(beta)
@@ -75,8 +79,8 @@ class ParticleChains:
         self.shard = (0, self.n_chains)
 
     @classmethod
-    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential="harmonic"):
-        return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)))
+    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential="harmonic", reward: Optional[str] = None):
+        return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)), reward=reward)
 
     def __len__(self) -> int:
         return self.n_chains

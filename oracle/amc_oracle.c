@@ -261,6 +261,9 @@ void amo_box_muller(const uint32_t v[4], double z[2])
  * harmonic_oscillator/MC_harmonic_oscillator.jl:4  potential(x) = x^2 (== x*x).
  * The double well (x^2-1)^2 is BASELINE config 3's, not in the reference. */
 static double (*g_custom_potential)(double) = 0;
+static double (*g_custom_reward)(double, double) = 0;      /* reward(action, system) as f(delta, x_new); 0: delta^2 */
+
+void amo_set_custom_reward(double (*fn)(double, double)) { g_custom_reward = fn; }
 
 void amo_set_custom_potential(double (*fn)(double)) { g_custom_potential = fn; }
 
@@ -597,7 +600,8 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
     double e1, e2;
     perform_action(p, m, pot, &e1, &e2);                            /* :98 */
     double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :99 */
-    double r = m->delta * m->delta;                                 /* :100 reward, particle_1d.jl:42-44 */
+    double r = g_custom_reward ? g_custom_reward(m->delta, p->x)    /* :100 reward(action, system): script-defined */
+                               : m->delta * m->delta;               /*      particle_1d.jl:42-44 */
     m->delta = -m->delta;                                           /* :101 */
     double logq_b = amo_log_proposal_density(m->delta, sigma);     /* :102 */
     double dlogq_b = amo_grad_log_proposal_density(m->delta, sigma);

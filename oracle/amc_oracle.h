@@ -64,6 +64,7 @@ double amo_potential(int pot, double x);
  * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,
  * compiled by gcc (-ffp-contract=off), here.  Process-global, like the reference's. */
 void   amo_set_custom_potential(double (*fn)(double));
+void   amo_set_custom_reward(double (*fn)(double delta, double x_new));   /* NULL: delta^2 (particle_1d.jl:42-44) */
 double amo_log_proposal_density(double delta, double sigma);
 double amo_grad_log_proposal_density(double delta, double sigma);
 int    amo_categorical(const double *weights, int K, double r);

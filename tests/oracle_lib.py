@@ -51,6 +51,7 @@ def load() -> C.CDLL:
         "amo_philox4x32_10": (None, [u32p, u32p, u32p]),
         "amo_counter": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]),
         "amo_set_custom_potential": (None, [C.c_void_p]),
+        "amo_set_custom_reward": (None, [C.c_void_p]),
         "amo_exp": (C.c_double, [C.c_double]),
         "amo_log": (C.c_double, [C.c_double]),
         "amo_sincospi": (None, [C.c_double, dp, dp]),
@@ -189,6 +190,29 @@ def install_custom_potential(expr: str) -> None:
     lib.amo_set_custom_potential(fn)
 
 
+def install_custom_reward(expr: Optional[str]) -> None:
+    """The oracle's global reward(action, system): None restores delta^2; else `double f(double delta, double x)`
+    compiled by gcc like install_custom_potential."""
+    import hashlib
+    import tempfile
+    lib = load()
+    if expr is None:
+        lib.amo_set_custom_reward(None)
+        return
+    key = "r" + hashlib.sha1(expr.encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_rew_")
+        src, so = os.path.join(d, "rew.c"), os.path.join(d, f"rew_{key}.so")
+        with open(src, "w") as f:
+            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
+                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+                    f"double amo_user_reward(double delta, double x) {{ return ({expr}); }}\n")
+        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    lib.amo_set_custom_reward(C.cast(_custom_libs[key].amo_user_reward, C.c_void_p))
+
+
 def _potential_id(potential) -> int:
     expr = getattr(potential, "expr", None)
     if expr is not None:
@@ -201,8 +225,9 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None):
         self.lib = load()
+        install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
         s = (C.c_double * self.K)(*[float(v) for v in sigma])
@@ -299,11 +324,11 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None):
+                 stream=None, reward_expr=None):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
-                             weight=weight, seed=seed, sweepstep=sweepstep)
+                             weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 
