@@ -61,7 +61,7 @@ mutable struct HIPMetropolis{P} <: Arianna.AriannaAlgorithm
     K::Int
 end
 
-function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic,
+function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing,
                        chain_offset=0, n_chains_global=length(chains), per_chain_counters=true, extras...)
     pools = [deepcopy(pool) for _ in chains]                       # metropolis.jl:289
     sigma = Float64[move.parameters.σ for move in pool]
@@ -75,7 +75,12 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
                         pot_id,
                         Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL)
-        if potential isa AbstractString
+        if reward isa AbstractString
+            # script-defined reward(action, system) (particle_1d.jl:42-44) as an expression in delta and the new x
+            pot = potential isa AbstractString ? potential : C_NULL
+            check(ccall((:amc_create_model, libamc), Cint, (Ref{AmcConfig}, Cstring, Cstring, Ref{Ptr{Cvoid}}),
+                        cfg, pot, reward, handle))
+        elseif potential isa AbstractString
             # the script's `potential(x) = ...` (MC_harmonic_oscillator.jl:4) restated as a C expression in x
             check(ccall((:amc_create_custom, libamc), Cint, (Ref{AmcConfig}, Cstring, Ref{Ptr{Cvoid}}),
                         cfg, potential, handle))
