@@ -34,15 +34,40 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 CALLBACK_EVERY_MULTI = 10        # configs[3]: callbacks all-reduced every 10 sweeps when N > 1
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """Oracle (checker) timed on the host: all cores (tcollect analogue) + one thread (parallel=false)."""
+def cpu_allotment():
+    """CPUs this process may really use: affinity mask, cut by a cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                   # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
+def cpu_baseline(budget_s: float = 10.0):
+    """Oracle (checker) timed on the host: one thread (parallel=false) and OpenMP over chains (tcollect analogue) at the
+    thread count that is fastest on this host -- a GPU box may show 256 logical CPUs and grant a fraction of them, so a
+    short ladder of thread counts is timed first and the bounded sample then runs at the best one."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     O.build()
-    cores = O.load().amo_max_threads()
+    visible, quota = cpu_allotment()
+    visible = min(visible, O.load().amo_max_threads())
     m = 1_000_000
-    out = {}
-    for label, threads, budget in (("single", 1, 3.0), ("all", cores, budget_s)):
+
+    def timed(threads, budget, cap=4000):
         sim = O.OracleSim(m, potential="harmonic", beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED)
         sim.init_uniform(-2.0, 2.0)
         sim.make_steps(1, threads)                       # warm-up / first touch
@@ -51,10 +76,17 @@ def cpu_baseline(budget_s: float = 12.0):
             sim.make_steps(16, threads)
             sweeps += 16
             dt = time.perf_counter() - t0
-            if dt >= budget or sweeps >= 4000:
+            if dt >= budget or sweeps >= cap:
                 break
-        out[label] = (m * sweeps / dt, sweeps, dt)
         sim.close()
+        return (m * sweeps / dt, sweeps, dt)
+
+    out = {"single": timed(1, 3.0)}
+    ladder = sorted({t for t in (8, 16, 32, 64, 128, visible, int(quota) if quota else visible) if 1 < t <= visible}
+                    or {visible})
+    probes = {t: timed(t, 1.5)[0] for t in ladder}
+    cores = max(probes, key=probes.get)
+    out["all"] = timed(cores, budget_s)
     cpu_model = "?"
     try:
         for line in open("/proc/cpuinfo"):
@@ -72,6 +104,8 @@ def cpu_baseline(budget_s: float = 12.0):
         "sample": f"oracle/amc_oracle.c (C restatement of mc_sweep!, OpenMP over chains), M=1e6 chains x "
                   f"{out['all'][1]} sweeps in {out['all'][2]:.1f} s on {cores} threads; same workload otherwise",
         "single_thread_value": out["single"][0], "cpu_model": cpu_model,
+        "cpus_visible": visible, "cpu_quota": quota,
+        "thread_ladder": {str(t): round(v) for t, v in probes.items()},
         "note": "SoA-free C port without the reference's per-sweep allocations: a stronger baseline than Julia",
     }
 

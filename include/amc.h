@@ -60,6 +60,18 @@ typedef enum amc_potential {
     AMC_POTENTIAL_CUSTOM = 2        /* a C expression in x, compiled for gfx950 at run time: amc_create_custom */
 } amc_potential;
 
+/* Particle{T} / Displacement{T} are generic in T <: AbstractFloat (particle_1d.jl:9,26).  Float64 is what the reference's
+ * scripts use and the type every parity figure is quoted on.  AMC_DTYPE_F32 keeps x, beta, e, delta and the log-target
+ * difference in Float32 exactly where Julia's promotion rules would: the policy parameters, the
+ * normal variate, log_proposal_density, the acceptance probability and the uniforms stay Float64.  The state then crosses
+ * HBM as 4 + 4 bytes per update; the kernels are the same sources, compiled at run time (hiprtc) on first use.  Host
+ * buffers of this ABI stay `double` whatever the state type: uploads are rounded to Float32 (round to nearest even),
+ * downloads are exact. */
+typedef enum amc_state_dtype {
+    AMC_DTYPE_F64 = 0,
+    AMC_DTYPE_F32 = 1
+} amc_state_dtype;
+
 typedef struct amc_handle amc_handle;
 
 /* Mirrors Metropolis(chains; pool, sweepstep=1, seed=1, ...) metropolis.jl:288-291
@@ -83,7 +95,11 @@ typedef struct amc_config {
                                     for amc_download_counters; forced on when K > 1).
                                     0 (K = 1 only): keep only the pool-wide accepted total */
     void    *stream;             /* optional hipStream_t to run on; NULL -> library-owned */
+    int32_t  state_dtype;        /* amc_state_dtype.  Callers built against the 0.1 layout (struct_size 88, without
+                                    this field) get AMC_DTYPE_F64 */
+    int32_t  reserved;           /* must be 0 */
 } amc_config;
+#define AMC_CONFIG_SIZE_V0_1 88u
 
 /* Layout of amc_reduce's output (doubles). */
 enum {

@@ -44,7 +44,13 @@ class AmcConfig(C.Structure):
         ("sweepstep", C.c_int32),
         ("per_chain_counters", C.c_int32),
         ("stream", C.c_void_p),
+        ("state_dtype", C.c_int32),
+        ("reserved", C.c_int32),
     ]
+
+
+# amc_state_dtype: Particle{T} (particle_1d.jl:9).  "f64" is the parity type; "f32" keeps x, beta, e, delta in Float32.
+STATE_DTYPES = {"f64": 0, "f32": 1, "float64": 0, "float32": 1}
 
 
 _lib = None
@@ -155,8 +161,11 @@ class HipEngine:
                  potential="harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
-                 reward_expr: Optional[str] = None):
+                 reward_expr: Optional[str] = None, dtype: str = "f64"):
         lib = load()
+        if str(dtype) not in STATE_DTYPES:
+            raise AmcError(f"unknown state dtype {dtype!r}; one of {sorted(STATE_DTYPES)}")
+        self.dtype = "f32" if STATE_DTYPES[str(dtype)] else "f64"
         expr = getattr(potential, "expr", None)        # system.CustomPotential: a C expression in x
         if expr is None and potential not in POTENTIALS:
             raise AmcError(f"unknown potential {potential!r}; the HIP engine offers {sorted(POTENTIALS)} "
@@ -180,6 +189,7 @@ class HipEngine:
         cfg.sweepstep = int(sweepstep)
         cfg.per_chain_counters = 1 if per_chain_counters else 0
         cfg.stream = stream
+        cfg.state_dtype = STATE_DTYPES[self.dtype]
         self._lib = lib
         self._h = C.c_void_p()
         if reward_expr is not None:

@@ -112,7 +112,10 @@ struct amc_handle {
     double* d_pg_groups = nullptr;      // [groups][AMC_MAX_LEARN * 4]
     Rccl rccl;
     bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
-    std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x)
+    std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
+    bool f32 = false;             // state_dtype == AMC_DTYPE_F32: d_x / d_beta hold floats
+    bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
+    double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
     std::vector<hipModule_t> rtc_mods;
 };
@@ -403,13 +406,13 @@ void rtc_cache_store(const std::string& path, const RtcCode& rc)
 
 // Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
 // Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
-int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode** out, std::string* log_out)
+int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCode** out, std::string* log_out)
 {
     std::lock_guard<std::mutex> lock(g_rtc_mu);
-    const std::string key = expr + "\n" + inst;
+    const std::string key = expr_in + "\n" + inst;
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
-    const std::string cache_file = rtc_cache_path(expr, inst);
+    const std::string cache_file = rtc_cache_path(expr_in, inst);
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -419,9 +422,13 @@ int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode*
         }
     }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
-    // expr = potential [ '\x01' reward ]
+    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] ]
+    const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
+    const std::string expr = expr_in.substr(f32 ? 1 : 0);
     const size_t cut = expr.find('\x01');
-    std::string src = "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
+    std::string src;
+    if (f32) src += "#define AMC_STATE_F32 1\n";
+    if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
     src += "#include \"amc_kernels.h\"\n";
     const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES};
@@ -444,7 +451,8 @@ int rtc_compile(const std::string& expr, const std::string& inst, const RtcCode*
     if (e != 0) {
         g_hiprtc.DestroyProgram(&prog);
         // the first diagnostic is what the user needs; keep the message bounded
-        return fail(AMC_ERR_BAD_ARG, "custom potential does not compile: %.400s", log.empty() ? "(no log)" : log.c_str());
+        return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr.empty() ? "run-time kernel build failed" : "custom potential does not compile",
+                    log.empty() ? "(no log)" : log.c_str());
     }
     RtcCode rc;
     size_t cs = 0;
@@ -493,7 +501,7 @@ const char* tf(bool b) { return b ? "true" : "false"; }
 int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
 {
     const bool multi = h->K > 1, log = multi || h->counters;
-    const std::string inst = std::string("amc::sweep_kernel<2,") + tf(multi) + "," + tf(log) + "," + tf(h->beta_arr) + "," +
+    const std::string inst = "amc::sweep_kernel<" + std::to_string(h->potential) + "," + tf(multi) + "," + tf(log) + "," + tf(h->beta_arr) + "," +
                              tf(a.n_steps == 1) + "," + tf(reduce) + ">";
     void* params[] = {&a};
     return rtc_launch(h, inst, grid, params);
@@ -501,7 +509,7 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
 
 int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep)
 {
-    const std::string inst = "amc::pg_estimate_kernel<2," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
+    const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
                              std::to_string(sweep) + ">";
     void* params[] = {&a, &sw};
     return rtc_launch(h, inst, grid, params);
@@ -529,8 +537,13 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
 {
     if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
     *out = nullptr;
-    if (cfg->struct_size != sizeof(amc_config))
+    if (cfg->struct_size != sizeof(amc_config) && cfg->struct_size != AMC_CONFIG_SIZE_V0_1)
         return fail(AMC_ERR_BAD_ARG, "amc_create: struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(amc_config));
+    const int state_dtype = cfg->struct_size == sizeof(amc_config) ? cfg->state_dtype : (int)AMC_DTYPE_F64;
+    if (state_dtype != AMC_DTYPE_F64 && state_dtype != AMC_DTYPE_F32)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: unknown state_dtype %d", state_dtype);
+    if (cfg->struct_size == sizeof(amc_config) && cfg->reserved != 0)
+        return fail(AMC_ERR_BAD_ARG, "amc_create: reserved must be 0");
     if (cfg->n_chains < 1) return fail(AMC_ERR_BAD_ARG, "amc_create: n_chains must be >= 1");
     if (cfg->chain_offset < 0 || (cfg->chain_offset & 1))
         return fail(AMC_ERR_BAD_ARG, "amc_create: chain_offset must be even and >= 0 (shards split on chain pairs)");
@@ -600,7 +613,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     h->offset = cfg->chain_offset;
     h->M_global = cfg->n_chains_global;
     h->potential = cfg->potential;
-    if (potential_expr) h->pot_expr = potential_expr;
+    h->f32 = state_dtype == AMC_DTYPE_F32;
+    h->use_rtc = h->f32 || cfg->potential == AMC_POTENTIAL_CUSTOM;
+    if (h->f32) h->pot_expr = "\x02";
+    if (potential_expr) h->pot_expr += potential_expr;
     if (potential_expr && reward_expr) h->pot_expr += std::string("\x01") + reward_expr;
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
@@ -677,11 +693,15 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
-    if (h->potential == AMC_POTENTIAL_CUSTOM) {
+    if (h->use_rtc) {
         // compile the smallest kernel now so that a malformed expression fails HERE, with the compiler's message
         hipFunction_t fn = nullptr;
-        rc = rtc_function(h, "amc::energy_kernel<2>", &fn);
+        rc = rtc_function(h, "amc::energy_kernel<" + std::to_string(h->potential) + ">", &fn);
         if (rc != AMC_OK) return bail(rc);
+    }
+    if (h->f32) {
+        hipError_t e64 = hipMalloc(&h->d_x64, (size_t)h->M_pad * sizeof(double));
+        if (e64 != hipSuccess) return bail(fail(AMC_ERR_OOM, "amc_create: %s", hipGetErrorString(e64)));
     }
     *out = h;
     return AMC_OK;
@@ -702,10 +722,14 @@ int amc_create_model(const amc_config* cfg, const char* potential_expr, const ch
     const char* pot = potential_expr;
     if (!pot) {
         if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
+            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
+                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
         else return fail(AMC_ERR_BAD_ARG, "amc_create_model: potential_expr is NULL and cfg->potential names no built-in");
     }
-    amc_config c2 = *cfg;
+    amc_config c2;
+    std::memset(&c2, 0, sizeof(c2));
+    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));   // a 0.1 caller's struct is shorter
     c2.potential = AMC_POTENTIAL_CUSTOM;
     return create_impl(&c2, pot, out, reward_expr);
 }
@@ -737,6 +761,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_pg_tickets);
     (void)hipFree(h->d_pg_groups);
     (void)hipFree(h->d_x);
+    (void)hipFree(h->d_x64);
     (void)hipFree(h->d_beta);
     (void)hipFree(h->d_acc);
     (void)hipFree(h->d_tot);
@@ -758,17 +783,56 @@ int amc_destroy(amc_handle* h)
     return AMC_OK;
 }
 
+// Float32 state: d_x64 (doubles) -> dst (floats, rounded to nearest) and back, on the stream.
+static int narrow_from_x64(amc_handle* h, double* dst_as_float)
+{
+    const double* in = h->d_x64;
+    int64_t n = h->M;
+    void* params[] = {&in, &n, &dst_as_float};
+    return rtc_launch(h, "amc::narrow_state_kernel", grid_for(h, h->M), params);
+}
+
+static int widen_to_x64(amc_handle* h)
+{
+    const double* in = h->d_x;
+    int64_t n = h->M;
+    double* out = h->d_x64;
+    void* params[] = {&in, &n, &out};
+    return rtc_launch(h, "amc::widen_state_kernel", grid_for(h, h->M), params);
+}
+
+// The positions as doubles on the device: d_x itself, or (Float32 state) the widened copy.
+static int positions_f64(amc_handle* h, const double** out)
+{
+    *out = h->d_x;
+    if (!h->f32) return AMC_OK;
+    *out = h->d_x64;
+    return widen_to_x64(h);
+}
+
 int amc_upload_state(amc_handle* h, const double* x, const double* beta_or_null)
 {
     if (!h || !x) return fail(AMC_ERR_BAD_ARG, "amc_upload_state: NULL argument");
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipMemcpyAsync(h->d_x, x, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->f32) {
+        AMC_HIP(hipMemcpyAsync(h->d_x64, x, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const int rc = narrow_from_x64(h, h->d_x);
+        if (rc != AMC_OK) return rc;
+    } else {
+        AMC_HIP(hipMemcpyAsync(h->d_x, x, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     if (beta_or_null) {
         if (!h->d_beta) {
             AMC_HIP(hipMalloc(&h->d_beta, (size_t)h->M_pad * sizeof(double)));
             AMC_HIP(hipMemsetAsync(h->d_beta, 0, (size_t)h->M_pad * sizeof(double), h->stream));
         }
-        AMC_HIP(hipMemcpyAsync(h->d_beta, beta_or_null, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (h->f32) {
+            AMC_HIP(hipMemcpyAsync(h->d_x64, beta_or_null, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            const int rc = narrow_from_x64(h, h->d_beta);
+            if (rc != AMC_OK) return rc;
+        } else {
+            AMC_HIP(hipMemcpyAsync(h->d_beta, beta_or_null, (size_t)h->M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
         h->beta_arr = true;
     }
     AMC_HIP(hipStreamSynchronize(h->stream));   // caller's buffers are only valid during the call
@@ -780,9 +844,11 @@ int amc_init_uniform(amc_handle* h, double lo, double hi)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_init_uniform: NULL handle");
     AMC_HIP(hipSetDevice(h->device));
     const int grid = grid_for(h, (h->M + 1) / 2);
-    hipLaunchKernelGGL(amc::init_uniform_kernel, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_x, h->M,
+    // Float32 state: System(Float32(lo + (hi - lo) u), beta) -- the Float64 ensemble, rounded
+    hipLaunchKernelGGL(amc::init_uniform_kernel, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->f32 ? h->d_x64 : h->d_x, h->M,
                        (uint64_t)h->offset >> 1, (uint32_t)h->seed, (uint32_t)(h->seed >> 32), lo, hi);
     AMC_HIP(hipGetLastError());
+    if (h->f32) return narrow_from_x64(h, h->d_x);
     return AMC_OK;
 }
 
@@ -794,16 +860,19 @@ int amc_download_state(amc_handle* h, double* x, double* e)
     double* dst = x;
     std::vector<double> tmp;
     if (!dst) { tmp.resize((size_t)h->M); dst = tmp.data(); }
-    AMC_HIP(hipMemcpyAsync(dst, h->d_x, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const double* d_pos = nullptr;
+    { const int rc = positions_f64(h, &d_pos); if (rc != AMC_OK) return rc; }
+    AMC_HIP(hipMemcpyAsync(dst, d_pos, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
-    if (e && h->potential == AMC_POTENTIAL_CUSTOM) {
-        // the host cannot evaluate the user's expression: e = potential(x) by the run-time compiled kernel
+    if (e && h->use_rtc) {
+        // the host cannot evaluate the user's expression (or must not: Float32 arithmetic): e = potential(x) by the
+        // run-time compiled kernel
         double* d_e = nullptr;
         AMC_HIP(hipMalloc(&d_e, (size_t)h->M * sizeof(double)));
         const double* d_x = h->d_x;
         int64_t m = h->M;
         void* params[] = {&d_x, &m, &d_e};
-        int rc = rtc_launch(h, "amc::energy_kernel<2>", h->red_blocks, params);
+        int rc = rtc_launch(h, "amc::energy_kernel<" + std::to_string(h->potential) + ">", h->red_blocks, params);
         hipError_t he = hipSuccess;
         if (rc == AMC_OK) he = hipMemcpyAsync(e, d_e, (size_t)h->M * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (rc == AMC_OK && he == hipSuccess) he = hipStreamSynchronize(h->stream);
@@ -930,7 +999,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
         amc::SweepArgs a = make_sweep_args(h, chunk);
         const bool last = remaining == chunk;
         int rc;
-        if (h->potential == AMC_POTENTIAL_CUSTOM)
+        if (h->use_rtc)
             rc = launch_sweep_custom(h, a, grid, fuse_reduce && last);
         else if (fuse_reduce && last)
             rc = (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_sweep_reduce<amc::POT_DOUBLE_WELL>(h, a, grid)
@@ -1022,8 +1091,10 @@ int amc_histogram(amc_handle* h, double lo, double hi, int n_bins, uint64_t* cou
     AMC_HIP(hipMalloc(&d_counts, bytes));
     AMC_HIP(hipMemsetAsync(d_counts, 0, bytes, h->stream));
     const double inv_w = (double)n_bins / (hi - lo);
+    const double* d_pos = nullptr;
+    { const int rc = positions_f64(h, &d_pos); if (rc != AMC_OK) { (void)hipFree(d_counts); return rc; } }
     hipLaunchKernelGGL(amc::histogram_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), (size_t)(n_bins + 3) * sizeof(unsigned int),
-                       h->stream, h->d_x, h->M, lo, hi, inv_w, n_bins, d_counts);
+                       h->stream, d_pos, h->M, lo, hi, inv_w, n_bins, d_counts);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1041,7 +1112,9 @@ int amc_download_strided(amc_handle* h, int64_t first, int64_t stride, int64_t c
     AMC_HIP(hipSetDevice(h->device));
     double* d_out = nullptr;
     AMC_HIP(hipMalloc(&d_out, (size_t)count * sizeof(double)));
-    hipLaunchKernelGGL(amc::gather_strided_kernel, dim3(grid_for(h, count)), dim3(AMC_BLOCK), 0, h->stream, h->d_x, first,
+    const double* d_pos = nullptr;
+    { const int rc = positions_f64(h, &d_pos); if (rc != AMC_OK) { (void)hipFree(d_out); return rc; } }
+    hipLaunchKernelGGL(amc::gather_strided_kernel, dim3(grid_for(h, count)), dim3(AMC_BLOCK), 0, h->stream, d_pos, first,
                        stride, count, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(x, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1130,14 +1203,14 @@ int amc_reduce_begin(amc_handle* h)
     double* rows = host ? h->h_partials : h->d_partials;
     const int stride = host ? RED_HOST_STRIDE : n_vals;
     const unsigned long long* slots = (host && ratio_mode == 0 && h->red_ratio_rows == 0) ? h->d_acc_slots : nullptr;
-    if (h->potential == AMC_POTENTIAL_CUSTOM) {
+    if (h->use_rtc) {
         const double* d_x = h->d_x;
         const uint32_t *d_acc = h->d_acc, *d_tot = h->d_tot;
         int64_t m = h->M, m_pad = h->M_pad;
         int k = h->K, mode = ratio_mode, st = stride, n_slots = h->n_slots;
         uint64_t t_counted = h->t_counted;
         void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots};
-        const int rc = rtc_launch(h, "amc::reduce_kernel<2>", h->red_blocks, params);
+        const int rc = rtc_launch(h, "amc::reduce_kernel<" + std::to_string(h->potential) + ">", h->red_blocks, params);
         if (rc != AMC_OK) return rc;
     } else if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
@@ -1307,7 +1380,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         sweep = h->K > 1 ? 2 : 1;
     }
     amc::SweepArgs sw = make_sweep_args(h, 1);
-    const int rc = (h->potential == AMC_POTENTIAL_CUSTOM)        ? launch_pg_custom(h, a, sw, grid, nl, sweep)
+    const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep)
                    : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep)
                                                                  : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep);
     if (rc != AMC_OK) return rc;

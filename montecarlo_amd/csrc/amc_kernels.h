@@ -25,6 +25,20 @@ namespace amc {
 
 enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1, POT_CUSTOM = 2 };
 
+// State type.  The reference's Particle{T} / Displacement{T} are generic in T <: AbstractFloat (particle_1d.jl:9,26);
+// Float64 is what its scripts use and what the offline build of this header compiles.  A handle created with
+// state_dtype = AMC_DTYPE_F32 gets the SAME kernel sources compiled at run time with AMC_STATE_F32 defined: x, beta, e,
+// delta and dlogp are then Float32 exactly where Julia's promotion rules keep them Float32 -- the policy parameters,
+// the normal variate, log_proposal_density, the acceptance probability and the uniforms stay Float64
+// (ComponentArray(sigma = 0.1) is Float64; Normal(0f0, sigma) promotes; rand(rng) is Float64).  DESIGN.md section 3.7.
+#ifdef AMC_STATE_F32
+typedef float real_t;
+typedef float2 real2;
+#else
+typedef double real_t;
+typedef double2 real2;
+#endif
+
 // Rows of the per-move parameter table.
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
        PT_RDEN = 7, PT_ROWS = 8 };
@@ -63,14 +77,14 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
 #endif
 #define amc_exp(v) (::amc::exp_f64((v), amc_tables_))
 #define amc_log(v) (::amc::log_f64((v)))
-__device__ __forceinline__ double user_potential(double x, const double* amc_tables_)
+__device__ __forceinline__ real_t user_potential(real_t x, const double* amc_tables_)
 {
-    return AMC_USER_POTENTIAL(x);
+    return (real_t)(AMC_USER_POTENTIAL(x));       // Particle.e is a field of type T: the value is converted on assignment
 }
 
-__device__ __forceinline__ double user_reward(double delta, double x, const double* amc_tables_)
+__device__ __forceinline__ double user_reward(real_t delta, real_t x, const double* amc_tables_)
 {
-    return AMC_USER_REWARD(delta, x);
+    return (double)(AMC_USER_REWARD(delta, x));
 }
 #undef amc_exp
 #undef amc_log
@@ -78,11 +92,11 @@ __device__ __forceinline__ double user_reward(double delta, double x, const doub
 // potential(x): harmonic_oscillator/MC_harmonic_oscillator.jl:4 (x^2 == x*x);
 // double well (x*x-1)^2 is BASELINE config 3's.  T: the block's LDS copy of the math tables (custom only).
 template <int POT>
-__device__ __forceinline__ double potential(double x, const double* T)
+__device__ __forceinline__ real_t potential(real_t x, const double* T)
 {
     if (POT == POT_CUSTOM) return user_potential(x, T);
     if (POT == POT_DOUBLE_WELL) {
-        const double q = x * x - 1.0;
+        const real_t q = x * x - (real_t)1.0;
         return q * q;
     }
     return x * x;
@@ -102,17 +116,17 @@ __device__ __forceinline__ double potential(double x, const double* T)
 // estimate's rigorous error interval does not contain u (accept_filter) -- the same idea as the filtered exact
 // predicates of computational geometry.  logq, arg and exp(arg) feed nothing but that one comparison.
 struct Proposal {
-    double delta, xn, dlogp;
+    real_t delta, xn, dlogp;
 };
 
 template <int POT>
-__device__ __forceinline__ Proposal propose(double x, double beta, double sigma, double z, const double* T)
+__device__ __forceinline__ Proposal propose(real_t x, real_t beta, double sigma, double z, const double* T)
 {
     Proposal p;
-    p.delta = 0.0 + sigma * z;
-    const double e1 = potential<POT>(x, T);
+    p.delta = (real_t)(0.0 + sigma * z);        // Displacement.delta::T = rand(rng, Normal(zero(T), sigma::Float64))
+    const real_t e1 = potential<POT>(x, T);
     p.xn = x + p.delta;
-    const double e2 = potential<POT>(p.xn, T);
+    const real_t e2 = potential<POT>(p.xn, T);
     p.dlogp = ((-e2) * beta) - ((-e1) * beta);
     return p;
 }
@@ -123,11 +137,12 @@ __device__ __forceinline__ Proposal propose(double x, double beta, double sigma,
 //   -708 <= arg < 0    -> alpha == exp(arg) (<= 1)                  : accept iff exp(arg) > u
 //   arg < -708 or NaN  -> alpha == 0 or NaN (Julia's min keeps NaN) : reject
 // (bitwise | and & on purpose: no short-circuit branches)
-__device__ __forceinline__ bool accept_exact(double delta, double dlogp, double den, double rden, double logc, double u,
+__device__ __forceinline__ bool accept_exact(real_t delta, real_t dlogp, double den, double rden, double logc, double u,
                                              const double* T)
 {
-    const double logq = div_by_const(-(delta * delta), den, rden) - logc;   // == (-(d*d)) / den - logc, bit for bit
-    const double arg = (dlogp + logq) - logq;
+    // (delta)^2 and its negation are formed in T, the division by the Float64 2 sigma^2 promotes
+    const double logq = div_by_const((double)(-(delta * delta)), den, rden) - logc;   // == (-(d*d)) / den - logc, bit for bit
+    const double arg = ((double)dlogp + logq) - logq;
     const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
     return c_pos | (c_rng & c_exp);
 }
@@ -160,7 +175,7 @@ struct FilterCmp {
 // k: the top BITS bits of u's significand (u in [k, k+1) 2^-BITS; 12 when only the normal draw is at hand, 24 with
 // the accept draw as well).
 template <int BITS>
-__device__ __forceinline__ FilterCmp accept_filter(double dlogp, uint32_t k)
+__device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
 {
     const float t = (float)dlogp;
     const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
@@ -185,14 +200,14 @@ __device__ __forceinline__ FilterCmp accept_filter(double dlogp, uint32_t k)
 // cell (~1.2e-4 per chain-step, ~1.5 % of wave-steps); `pu` is then formed here.  !LAZY (K > 1: the move pick needs
 // the accept draw anyway): 24-bit bracket.
 template <int POT, bool LAZY>
-__device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, double sg0, double sg1, double dn0, double dn1,
+__device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double sg0, double sg1, double dn0, double dn1,
                                         double rd0, double rd1, double lc0, double lc1, double z0, double z1,
                                         u32x4 pn, u32x4 pu, u32x4 accept_ctr, uint32_t key0, uint32_t key1,
                                         const double* T, unsigned long long force_mask, uint32_t& acc_bits,
                                         unsigned long long& m0, unsigned long long& m1)
 {
     const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
-    const double xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
+    const real_t xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
     const uint32_t a0_12 = pn.x & 0xFFFu, a1_12 = pn.z & 0xFFFu;      // even chain: words (x, y), odd: (z, w)
     const FilterCmp c0 = LAZY ? accept_filter<12>(p0.dlogp, a0_12) : accept_filter<24>(p0.dlogp, (a0_12 << 12) | (pu.y >> 20));
     const FilterCmp c1 = LAZY ? accept_filter<12>(p1.dlogp, a1_12) : accept_filter<24>(p1.dlogp, (a1_12 << 12) | (pu.w >> 20));
@@ -232,22 +247,35 @@ __device__ __forceinline__ void mh_pair(double2& xv, double b0, double b1, doubl
 // (4 VALU instructions per load/store pair otherwise).  aux 16 = sc1.
 typedef uint32_t u32v4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double2 load_pair_block(const double* block_base)
+typedef uint32_t u32v2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ real2 load_pair_block(const real_t* block_base)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)block_base, 0, 0x7fffffff, 0x00020000);
+    real2 d;
+#ifdef AMC_STATE_F32
+    const u32v2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, threadIdx.x * 8, 0, 0);     // a Float32 pair: 8 bytes per lane
+    d.x = __uint_as_float(v.x);
+    d.y = __uint_as_float(v.y);
+#else
     const u32v4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, threadIdx.x * 16, 0, 0);
-    double2 d;
     d.x = __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x));
     d.y = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+#endif
     return d;
 }
 
-__device__ __forceinline__ void store_pair_block_writethrough(double* block_base, double2 d)
+__device__ __forceinline__ void store_pair_block_writethrough(real_t* block_base, real2 d)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)block_base, 0, 0x7fffffff, 0x00020000);
+#ifdef AMC_STATE_F32
+    const u32v2_t v = {__float_as_uint(d.x), __float_as_uint(d.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, threadIdx.x * 8, 0, 16);
+#else
     const uint64_t a = (uint64_t)__double_as_longlong(d.x), b = (uint64_t)__double_as_longlong(d.y);
     const u32v4_t v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
     __builtin_amdgcn_raw_buffer_store_b128(v, r, threadIdx.x * 16, 0, 16);
+#endif
 }
 
 // ---- deterministic block reduction helpers -------------------------------------
@@ -282,8 +310,8 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
 }
 
 struct SweepArgs {
-    double* x;
-    const double* beta_arr;       // nullptr unless per-chain beta
+    real_t* x;
+    const real_t* beta_arr;       // nullptr unless per-chain beta
     uint8_t* log;                 // [log_depth][m_stride] per-chain step log (LOG launches), else nullptr
     const double* ptab;           // [PT_ROWS][AMC_MAX_MOVES]
     unsigned long long* acc_total;  // pool-wide accepted count (K == 1)
@@ -336,7 +364,7 @@ __device__ __forceinline__ void store_log_pair(const SweepArgs& a, int row, int6
 // LOG: the step-log word of the pair; SINGLE launches hand it back in `log_word` (the caller stores it together
 // with x), multi-step launches store one word per step right away.
 template <int POT, bool MULTI, bool LOG, bool SINGLE, bool PRE = false>
-__device__ __forceinline__ void pair_steps(const SweepArgs& a, double2& xv, double b0, double b1, uint64_t pair,
+__device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t b0, real_t b1, uint64_t pair,
                                            int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
                                            double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& log_word,
@@ -432,9 +460,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // An iteration that has a successor covers 256 in-range pairs on every lane (stride >= 256), so the
     // loop body runs without per-lane predicates; only the LAST iteration of a block can be ragged and is
     // peeled.  Loads need no clamp either: the arrays carry AMC_PAD_DOUBLES of readable padding.
-    auto load_x = [&](int64_t b) -> double2 { return load_pair_block(a.x + 2 * b); };
-    auto load_b = [&](int64_t b) -> double2 { return load_pair_block(a.beta_arr + 2 * b); };
-    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    auto load_x = [&](int64_t b) -> real2 { return load_pair_block(a.x + 2 * b); };
+    auto load_b = [&](int64_t b) -> real2 { return load_pair_block(a.beta_arr + 2 * b); };
+    real2 x_nxt = {(real_t)0.0, (real_t)0.0}, b_nxt = {(real_t)a.beta, (real_t)a.beta};
     if (first < n_pairs) {
         x_nxt = load_x(first);
         if (BETA) b_nxt = load_b(first);
@@ -450,14 +478,14 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
     // the prefetch issued a few dozen instructions earlier instead of leaving it a whole iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), other counters untouched
-    double2 x_done = {0.0, 0.0};
+    real2 x_done = {(real_t)0.0, (real_t)0.0};
     uint32_t lw_done = 0;
     int64_t base_done = -1;                                  // block-uniform
     int64_t base = first;
     for (; base + stride < n_pairs; base += stride) {        // full iterations
         const int64_t p = base + threadIdx.x;
-        double2 xv = x_nxt;
-        const double b0 = b_nxt.x, b1 = b_nxt.y;
+        real2 xv = x_nxt;
+        const real_t b0 = b_nxt.x, b1 = b_nxt.y;
         x_nxt = load_x(base + stride);
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) {
@@ -470,10 +498,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                                                    sigma1, den1, rden1, logc1, wave_acc, lw, &dr);
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(p + stride), a.t0);
-        if (REDUCE) {
-            red[0] += potential<POT>(xv.x, s_math) + potential<POT>(xv.y, s_math);
-            red[1] += xv.x + xv.y;
-            red[2] += xv.x * xv.x + xv.y * xv.y;
+        if (REDUCE) {      // the sums are Float64 whatever the state type (a Float32 sum over 1e7 chains keeps no digits)
+            const double x0 = xv.x, x1 = xv.y;
+            red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
+            red[1] += x0 + x1;
+            red[2] += x0 * x0 + x1 * x1;
             red[3] += 2.0;
         }
         x_done = xv;
@@ -484,7 +513,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         const int64_t p = base + threadIdx.x;
         const bool v0 = p < n_pairs;
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-        double2 xv = x_nxt;
+        real2 xv = x_nxt;
         if (base_done >= 0) {
             store_pair_block_writethrough(a.x + 2 * base_done, x_done);
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
@@ -498,8 +527,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (LOG && SINGLE) store_log_pair(a, a.log_pos, p, lw);
         }
         if (REDUCE) {
-            if (v0) { red[0] += potential<POT>(xv.x, s_math); red[1] += xv.x; red[2] += xv.x * xv.x; red[3] += 1.0; }
-            if (v1) { red[0] += potential<POT>(xv.y, s_math); red[1] += xv.y; red[2] += xv.y * xv.y; red[3] += 1.0; }
+            const double x0 = xv.x, x1 = xv.y;
+            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; red[2] += x0 * x0; red[3] += 1.0; }
+            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; red[2] += x1 * x1; red[3] += 1.0; }
         }
     }
     if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
@@ -750,7 +780,7 @@ __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds i
 // Rows are p_stride doubles apart (device buffer, or pinned host memory when the host forms the column sums).
 // slots != nullptr (ratio_mode 0): column 4 of row b = sum of the accepted slots b, b + grid, ... (exact).
 template <int POT>
-__global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, const uint32_t* acc,
+__global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, const uint32_t* acc,
                                                             const uint32_t* tot, int64_t n_chains,
                                                             int64_t m_stride, int n_moves, int ratio_mode,
                                                             uint64_t t_steps, double* partials, int p_stride,
@@ -762,15 +792,16 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const double* x, cons
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t n_pairs = (n_chains + 1) >> 1;              // 16-byte loads; x is padded, the odd slot of a lone last chain is masked
     for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
-        const double2 xp = *reinterpret_cast<const double2*>(x + 2 * p);
-        v[0] += potential<POT>(xp.x, s_math);
-        v[1] += xp.x;
-        v[2] += xp.x * xp.x;
+        const real2 xp = *reinterpret_cast<const real2*>(x + 2 * p);
+        const double x0 = xp.x, x1 = xp.y;
+        v[0] += (double)potential<POT>(xp.x, s_math);
+        v[1] += x0;
+        v[2] += x0 * x0;
         v[3] += 1.0;
         if (2 * p + 1 < n_chains) {
-            v[0] += potential<POT>(xp.y, s_math);
-            v[1] += xp.y;
-            v[2] += xp.y * xp.y;
+            v[0] += (double)potential<POT>(xp.y, s_math);
+            v[1] += x1;
+            v[2] += x1 * x1;
             v[3] += 1.0;
         }
     }
@@ -900,8 +931,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_
 }
 
 struct PgArgs {
-    double* x;
-    const double* beta_arr;
+    real_t* x;
+    const real_t* beta_arr;
     const double* ptab;
     double* partials;             // [grid][NL][4]
     int64_t n_chains;
@@ -931,24 +962,24 @@ enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kern
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
 template <int POT>
-__device__ __forceinline__ void pg_sample(double& x, double beta, double sigma, double den, double rden,
+__device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double den, double rden,
                                           double logc, double dden, double dlhalf, double z, double (&g)[4],
                                           const double* T)
 {
-    const double delta = 0.0 + sigma * z;
-    const double q1 = div_by_const(-(delta * delta), den, rden);
+    const real_t delta = (real_t)(0.0 + sigma * z);
+    const double q1 = div_by_const((double)(-(delta * delta)), den, rden);
     const double logq = q1 - logc;
     const double dlogq = -div_by_const(q1, den, rden) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
-    const double e1 = potential<POT>(x, T);
-    const double xn = x + delta;
-    const double e2 = potential<POT>(xn, T);
-    const double dlogp = ((-e2) * beta) - ((-e1) * beta);
-    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : delta * delta;   // reward, particle_1d.jl:42-44
+    const real_t e1 = potential<POT>(x, T);
+    const real_t xn = x + delta;
+    const real_t e2 = potential<POT>(xn, T);
+    const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);   // reward, particle_1d.jl:42-44 (in T)
     x = xn + (-delta);
     // alpha = min(1, exp(arg)) with Julia's NaN-propagating min, without the generic guards: exp(arg >= 0) >= 1 and
     // exp(arg <= 0) <= 1 hold exactly for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);
     // arg < -708 -> 0;  NaN -> NaN.  Bit-identical to Julia's NaN-propagating min(1.0, exp(arg)) on the full-domain exp, 9 instead of 18 select/compare ops.
-    const double arg = (dlogp + logq) - logq;
+    const double arg = ((double)dlogp + logq) - logq;
     double ex = exp_core_f64(arg, T);
     asm volatile("" : "+v"(ex));          // keep the exp unconditional: no divergent branch around it
     double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
@@ -1008,7 +1039,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
     unsigned long long wave_acc = 0;
     // one mc_step! of the pair (mc_sweep! with mc_steps = 1), its step-log byte pair stored right away
-    auto mh = [&](double2& xv, double b0, double b1, uint64_t pair, int64_t p, bool v0, bool v1) {
+    auto mh = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, int64_t p, bool v0, bool v1) {
         uint32_t lw = 0;
         pair_steps<POT, SWEEP == 2, true, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_math, sw_sigma1, sw_den1,
                                                 sw_rden1, sw_logc1, wave_acc, lw);
@@ -1025,7 +1056,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
     // padded), the ragged last iteration peeled.
-    auto samples = [&](double2& xv, double b0, double b1, uint64_t pair, bool v1) {
+    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v1) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (l < a.n_learn) {
@@ -1048,22 +1079,22 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             }
         }
     };
-    auto load_x = [&](int64_t b) -> double2 { return load_pair_block(a.x + 2 * b); };
-    auto load_b = [&](int64_t b) -> double2 { return load_pair_block(a.beta_arr + 2 * b); };
+    auto load_x = [&](int64_t b) -> real2 { return load_pair_block(a.x + 2 * b); };
+    auto load_b = [&](int64_t b) -> real2 { return load_pair_block(a.beta_arr + 2 * b); };
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
-    double2 x_nxt = {0.0, 0.0}, b_nxt = {a.beta, a.beta};
+    real2 x_nxt = {(real_t)0.0, (real_t)0.0}, b_nxt = {(real_t)a.beta, (real_t)a.beta};
     if (first < n_pairs) {
         x_nxt = load_x(first);
         if (BETA) b_nxt = load_b(first);
     }
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
-    double2 x_done = {0.0, 0.0};
+    real2 x_done = {(real_t)0.0, (real_t)0.0};
     int64_t base_done = -1;
     int64_t base = first;
     for (; base + stride < n_pairs; base += stride) {        // full iterations
-        double2 xv = x_nxt;
-        const double b0 = b_nxt.x, b1 = b_nxt.y;
+        real2 xv = x_nxt;
+        const real_t b0 = b_nxt.x, b1 = b_nxt.y;
         x_nxt = load_x(base + stride);
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
@@ -1076,7 +1107,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         const int64_t p = base + threadIdx.x;
         const bool v0 = p < n_pairs;
         const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-        double2 xv = x_nxt;
+        real2 xv = x_nxt;
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
         if (v0) {
@@ -1182,13 +1213,28 @@ __global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, i
 // e[c] = potential(x[c]) (Particle.e, particle_1d.jl:13-15,33) for amc_download_state when the host cannot
 // evaluate the potential itself (POT_CUSTOM).
 template <int POT>
-__global__ __launch_bounds__(AMC_BLOCK) void energy_kernel(const double* x, int64_t n_chains, double* e)
+__global__ __launch_bounds__(AMC_BLOCK) void energy_kernel(const real_t* x, int64_t n_chains, double* e)
 {
     __shared__ double s_math[TAB_DOUBLES];
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride)
-        e[c] = potential<POT>(x[c], s_math);
+        e[c] = (double)potential<POT>(x[c], s_math);
+}
+
+// Float32 state (AMC_STATE_F32 builds only): the C ABI moves positions as doubles whatever the state type, so uploads
+// are narrowed (T(x), round to nearest even -- what Particle(Float32(x), ...) does) and downloads widened (exact).
+// The kernels that only READ positions for host-side consumers (histogram, strided snapshots) run on the widened copy.
+__global__ __launch_bounds__(AMC_BLOCK) void narrow_state_kernel(const double* in, int64_t n, real_t* out)
+{
+    const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (real_t)in[i];
+}
+
+__global__ __launch_bounds__(AMC_BLOCK) void widen_state_kernel(const real_t* in, int64_t n, double* out)
+{
+    const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (double)in[i];
 }
 
 // Strided snapshot: out[i] = x[first + i*stride] (binary stand-in for a subset of trajectory files).

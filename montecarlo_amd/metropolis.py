@@ -64,6 +64,8 @@ class Metropolis(AriannaAlgorithm):
             # sub-shards of this rank's shard on separate streams (SplitEngine): their launches overlap
             factory = lambda **kw: SplitEngine(n_parts=int(streams), **kw)
         extra = {} if getattr(chains, "reward", None) is None else {"reward_expr": chains.reward}
+        if getattr(chains, "dtype", "f64") != "f64":
+            extra["dtype"] = chains.dtype
         self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains), **extra,
                               potential=chains.potential, beta=chains.beta,
                               sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],

@@ -55,7 +55,13 @@ class ParticleChains:
     """
 
     def __init__(self, n_chains: int, beta, potential="harmonic", x: Optional[np.ndarray] = None,
-                 init_uniform: Optional[tuple] = None, reward: Optional[str] = None):
+                 init_uniform: Optional[tuple] = None, reward: Optional[str] = None, dtype: str = "f64"):
+        if dtype not in ("f64", "f32"):
+            raise ValueError(f"dtype must be 'f64' or 'f32', not {dtype!r}")
+        # Particle{T} (particle_1d.jl:9): "f32" keeps x, beta, e and the displacement in Float32 where Julia's promotion
+        # rules would (policy parameters, proposal density, acceptance stay Float64); host arrays stay float64 and hold
+        # Float32 values
+        self.dtype = dtype
         if not isinstance(potential, CustomPotential) and potential not in POTENTIALS:
             raise ValueError(f"unknown potential {potential!r}; the HIP engine offers {POTENTIALS} and CustomPotential(expr)")
         self.n_chains = int(n_chains)
@@ -79,8 +85,9 @@ class ParticleChains:
         self.shard = (0, self.n_chains)
 
     @classmethod
-    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential="harmonic", reward: Optional[str] = None):
-        return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)), reward=reward)
+    def uniform(cls, n_chains: int, beta, lo: float = -2.0, hi: float = 2.0, potential="harmonic", reward: Optional[str] = None,
+                dtype: str = "f64"):
+        return cls(n_chains, beta, potential, init_uniform=(float(lo), float(hi)), reward=reward, dtype=dtype)
 
     def __len__(self) -> int:
         return self.n_chains

@@ -288,6 +288,7 @@ typedef struct { double delta; int64_t total_calls, accepted_calls; } move_t;
 struct amo_sim {
     int64_t M, offset;
     int pot, K, sweepstep;
+    int f32;                  /* Particle{Float32} / Displacement{Float32}: see the Float32 section below */
     double *sigma, *weight;   /* shared parameters / weights, length K */
     particle_t *chains;       /* Vector{Particle} */
     move_t *pools;            /* pools[c*K + k] */
@@ -367,6 +368,108 @@ static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, doubl
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Float32 state.  Particle{T} and Displacement{T} are generic in T <: AbstractFloat
+ * (particle_1d.jl:9,26); with T = Float32 Julia's promotion rules give:
+ *   x, beta, e, delta              Float32 (struct fields of type T; assignments convert)
+ *   sample_action!  :56-59         rand(rng, Normal(zero(T), sigma::Float64)) is Float64 -> delta = Float32(.)
+ *   log_proposal_density :52-54    (delta)^2 and its negation in Float32, then / (2 sigma^2) promotes: Float64
+ *   perform_action! :30-35         x += delta, e = potential(x) in Float32
+ *   delta_log_target_density       (-e2*beta) - (-e1*beta) in Float32
+ *   alpha, rand(rng), reward*alpha Float64 (Float32 + Float64 promotes)
+ * The policy parameters stay Float64 (setup_parameters :50, ComponentArray(sigma = ...)).  The chain fields below
+ * keep doubles that always hold Float32 values; every Float32 operation is written with C floats. */
+static float (*g_custom_potential_f32)(float) = 0;
+static double (*g_custom_reward_f32)(float, float) = 0;
+
+void amo_set_custom_potential_f32(float (*fn)(float)) { g_custom_potential_f32 = fn; }
+void amo_set_custom_reward_f32(double (*fn)(float, float)) { g_custom_reward_f32 = fn; }
+
+float amo_potential_f32(int pot, float x)
+{
+    if (pot == AMO_POT_CUSTOM) return g_custom_potential_f32 ? g_custom_potential_f32(x) : (0.0f / 0.0f);
+    if (pot == AMO_POT_DOUBLE_WELL) {
+        float q = x * x - 1.0f;
+        return q * q;
+    }
+    return x * x;
+}
+
+static double log_proposal_density_f32(float delta, double sigma)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double s2 = sigma * sigma;
+    float d2 = -(delta * delta);                                   /* Float32 */
+    return (double)d2 / (2.0 * s2) - amo_log(TWO_PI * s2) / 2.0;
+}
+
+static double grad_log_proposal_density_f32(float delta, double sigma)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double s2 = sigma * sigma, ds2 = sigma + sigma;
+    double den = 2.0 * s2, dden = 2.0 * ds2;
+    float d2 = -(delta * delta);
+    double q1 = (double)d2 / den;
+    double dq1 = -(q1 / den) * dden;
+    double a = TWO_PI * s2, da = TWO_PI * ds2;
+    double dl = da / a;
+    return dq1 - dl / 2.0;
+}
+
+static inline void perform_action_f32(particle_t *p, float delta, int pot, float *e1, float *e2)
+{
+    *e1 = (float)p->e;
+    float x = (float)p->x + delta;
+    float e = amo_potential_f32(pot, x);
+    p->x = (double)x;
+    p->e = (double)e;
+    *e2 = e;
+}
+
+static inline float delta_log_target_density_f32(float e1, float e2, float beta)
+{
+    return ((-e2) * beta) - ((-e1) * beta);
+}
+
+static inline int mc_step_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
+{
+    float delta = (float)(0.0 + sigma * z);                        /* :177; the field converts */
+    double logq_forward = log_proposal_density_f32(delta, sigma);  /* :178 */
+    float e1, e2, beta = (float)p->beta;
+    perform_action_f32(p, delta, pot, &e1, &e2);                   /* :179 */
+    float dlogp = delta_log_target_density_f32(e1, e2, beta);      /* :180 */
+    delta = -delta;                                                /* :181 */
+    double logq_backward = log_proposal_density_f32(delta, sigma); /* :182 */
+    double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_backward - logq_forward)); /* :183 */
+    m->delta = (double)delta;
+    if (alpha > u)                                                 /* :184 */
+        return 1;
+    perform_action_f32(p, delta, pot, &e1, &e2);                   /* :187 */
+    return 0;
+}
+
+int amo_mc_step_explicit_f32(int pot, float beta, double sigma, double z, double u, float *x, float *e)
+{
+    particle_t p = { (double)*x, (double)beta, (double)*e };
+    move_t m = { 0.0, 0, 0 };
+    int a = mc_step_f32(&p, &m, sigma, pot, z, u);
+    *x = (float)p.x; *e = (float)p.e;
+    return a;
+}
+
+/* Switches a simulation to Float32 state: x, beta and e are rounded to Float32 now (Particle(Float32(x), Float32(beta)))
+ * and stay Float32 values from here on. */
+void amo_set_state_f32(amo_sim *s, int on)
+{
+    s->f32 = on ? 1 : 0;
+    if (!s->f32) return;
+    for (int64_t c = 0; c < s->M; ++c) {
+        s->chains[c].x = (double)(float)s->chains[c].x;
+        s->chains[c].beta = (double)(float)s->chains[c].beta;
+        s->chains[c].e = (double)amo_potential_f32(s->pot, (float)s->chains[c].x);
+    }
+}
+
 int amo_mc_step_explicit(int pot, double beta, double sigma, double z, double u,
                          double *x, double *e)
 {
@@ -422,7 +525,8 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         amo_box_muller(v, zz);
         double u = amo_uniform_accept(v[2 * half], va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
-        move->accepted_calls += mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
+        move->accepted_calls += s->f32 ? mc_step_f32(p, move, s->sigma[id], s->pot, zz[half], u)
+                                       : mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
         move->total_calls += 1;                                    /* :209 */
     }
 }
@@ -459,6 +563,11 @@ void amo_destroy(amo_sim *s)
 void amo_set_x(amo_sim *s, const double *x)
 {
     for (int64_t c = 0; c < s->M; ++c) {
+        if (s->f32) {
+            s->chains[c].x = (double)(float)x[c];
+            s->chains[c].e = (double)amo_potential_f32(s->pot, (float)x[c]);
+            continue;
+        }
         s->chains[c].x = x[c];
         s->chains[c].e = amo_potential(s->pot, x[c]);
     }
@@ -466,7 +575,7 @@ void amo_set_x(amo_sim *s, const double *x)
 
 void amo_set_beta(amo_sim *s, const double *beta)
 {
-    for (int64_t c = 0; c < s->M; ++c) s->chains[c].beta = beta[c];
+    for (int64_t c = 0; c < s->M; ++c) s->chains[c].beta = s->f32 ? (double)(float)beta[c] : beta[c];
 }
 
 /* MC_harmonic_oscillator.jl:13  chains = [System(4rand(rng) - 2, beta) ...],
@@ -480,6 +589,11 @@ void amo_init_uniform(amo_sim *s, double lo, double hi)
         draw4(s, g >> 1, 0, 0, AMO_STREAM_INIT, v);
         double u = amo_uniform_co(v[2 * half], v[2 * half + 1]);
         double x = lo + (hi - lo) * u;
+        if (s->f32) {                      /* System(Float32(4rand(rng) - 2), beta) */
+            s->chains[c].x = (double)(float)x;
+            s->chains[c].e = (double)amo_potential_f32(s->pot, (float)x);
+            continue;
+        }
         s->chains[c].x = x;
         s->chains[c].e = amo_potential(s->pot, x);
     }
@@ -614,6 +728,30 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
     gd[3] = dlogq_f * dlogq_f;                                      /* :107 */
 }
 
+/* The same sample with Float32 state (promotion rules in the Float32 section above): reward (delta)^2 in Float32,
+ * j = r * alpha in Float64. */
+static void pgmc_sample_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
+{
+    float delta = (float)(0.0 + sigma * z);
+    double logq_f = log_proposal_density_f32(delta, sigma);
+    double dlogq_f = grad_log_proposal_density_f32(delta, sigma);
+    float e1, e2, beta = (float)p->beta;
+    perform_action_f32(p, delta, pot, &e1, &e2);
+    float dlogp = delta_log_target_density_f32(e1, e2, beta);
+    double r = g_custom_reward_f32 ? g_custom_reward_f32(delta, (float)p->x) : (double)(delta * delta);
+    delta = -delta;
+    double logq_b = log_proposal_density_f32(delta, sigma);
+    double dlogq_b = grad_log_proposal_density_f32(delta, sigma);
+    perform_action_f32(p, delta, pot, &e1, &e2);
+    m->delta = (double)delta;
+    double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_b - logq_f));
+    double j = r * alpha;
+    gd[0] = j;
+    gd[1] = j * (alpha == 1.0 ? dlogq_f : dlogq_b);
+    gd[2] = dlogq_f;
+    gd[3] = dlogq_f * dlogq_f;
+}
+
 /* estimator.jl:111-134 make_step!(::PolicyGradientEstimator): for each learnable
  * move, foldxl(+) of GradientData (gradients.jl:68-76) over chains x q_batch
  * samples.  The caller owns the running accumulators (:130-131).  Draws come
@@ -634,8 +772,10 @@ void amo_pg_estimate(amo_sim *s, int n_learn, const int *learn_ids, int q_batch,
                 double zz[2], gd[4];
                 draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
                 amo_box_muller(v, zz);
-                pgmc_sample(&s->chains[c], &s->pools[c * s->K + lid], s->sigma[lid], s->pot,
-                            zz[half], gd);
+                if (s->f32)
+                    pgmc_sample_f32(&s->chains[c], &s->pools[c * s->K + lid], s->sigma[lid], s->pot, zz[half], gd);
+                else
+                    pgmc_sample(&s->chains[c], &s->pools[c * s->K + lid], s->sigma[lid], s->pot, zz[half], gd);
                 for (int i = 0; i < 4; ++i) acc[i] += gd[i];
                 n += 1;
             }

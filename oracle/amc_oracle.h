@@ -65,6 +65,13 @@ double amo_potential(int pot, double x);
  * compiled by gcc (-ffp-contract=off), here.  Process-global, like the reference's. */
 void   amo_set_custom_potential(double (*fn)(double));
 void   amo_set_custom_reward(double (*fn)(double delta, double x_new));   /* NULL: delta^2 (particle_1d.jl:42-44) */
+/* Float32 state (Particle{Float32}, particle_1d.jl:9; promotion rules in amc_oracle.c): switch a simulation over
+ * (rounds x, beta to Float32), the single-step form, and the script-defined functions in their Float32 form. */
+void   amo_set_state_f32(amo_sim *s, int on);
+int    amo_mc_step_explicit_f32(int pot, float beta, double sigma, double z, double u, float *x, float *e);
+float  amo_potential_f32(int pot, float x);
+void   amo_set_custom_potential_f32(float (*fn)(float));
+void   amo_set_custom_reward_f32(double (*fn)(float delta, float x_new));
 double amo_log_proposal_density(double delta, double sigma);
 double amo_grad_log_proposal_density(double delta, double sigma);
 int    amo_categorical(const double *weights, int K, double r);

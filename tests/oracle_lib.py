@@ -52,6 +52,12 @@ def load() -> C.CDLL:
         "amo_counter": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]),
         "amo_set_custom_potential": (None, [C.c_void_p]),
         "amo_set_custom_reward": (None, [C.c_void_p]),
+        "amo_set_custom_potential_f32": (None, [C.c_void_p]),
+        "amo_set_custom_reward_f32": (None, [C.c_void_p]),
+        "amo_set_state_f32": (None, [C.c_void_p, C.c_int]),
+        "amo_potential_f32": (C.c_float, [C.c_int, C.c_float]),
+        "amo_mc_step_explicit_f32": (C.c_int, [C.c_int, C.c_float, C.c_double, C.c_double, C.c_double,
+                                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "amo_exp": (C.c_double, [C.c_double]),
         "amo_log": (C.c_double, [C.c_double]),
         "amo_sincospi": (None, [C.c_double, dp, dp]),
@@ -182,12 +188,16 @@ def install_custom_potential(expr: str) -> None:
         with open(src, "w") as f:
             f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
                     "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
-                    f"double amo_user_potential(double x) {{ return ({expr}); }}\n")
+                    f"double amo_user_potential(double x) {{ return ({expr}); }}\n"
+                    # Float32 state: the same text with x::Float32 (C's usual arithmetic conversions promote against
+                    # double literals like Julia's do); the value is converted to Float32 on return (Particle.e::T)
+                    f"float amo_user_potential_f32(float x) {{ return (float)({expr}); }}\n")
         subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     fn = C.cast(_custom_libs[key].amo_user_potential, C.c_void_p)
     lib.amo_set_custom_potential(fn)
+    lib.amo_set_custom_potential_f32(C.cast(_custom_libs[key].amo_user_potential_f32, C.c_void_p))
 
 
 def install_custom_reward(expr: Optional[str]) -> None:
@@ -198,6 +208,7 @@ def install_custom_reward(expr: Optional[str]) -> None:
     lib = load()
     if expr is None:
         lib.amo_set_custom_reward(None)
+        lib.amo_set_custom_reward_f32(None)
         return
     key = "r" + hashlib.sha1(expr.encode()).hexdigest()[:16]
     if key not in _custom_libs:
@@ -206,11 +217,13 @@ def install_custom_reward(expr: Optional[str]) -> None:
         with open(src, "w") as f:
             f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
                     "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
-                    f"double amo_user_reward(double delta, double x) {{ return ({expr}); }}\n")
+                    f"double amo_user_reward(double delta, double x) {{ return ({expr}); }}\n"
+                    f"double amo_user_reward_f32(float delta, float x) {{ return (double)({expr}); }}\n")
         subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     lib.amo_set_custom_reward(C.cast(_custom_libs[key].amo_user_reward, C.c_void_p))
+    lib.amo_set_custom_reward_f32(C.cast(_custom_libs[key].amo_user_reward_f32, C.c_void_p))
 
 
 def _potential_id(potential) -> int:
@@ -225,8 +238,9 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64"):
         self.lib = load()
+        self.dtype = dtype
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
@@ -236,6 +250,10 @@ class OracleSim:
                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(sweepstep))
         if not self.h:
             raise ValueError("amo_create failed")
+        if dtype == "f32":
+            self.lib.amo_set_state_f32(self.h, 1)
+        elif dtype != "f64":
+            raise ValueError(f"dtype {dtype!r}")
 
     def close(self):
         if self.h:
@@ -324,11 +342,12 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None, reward_expr=None):
+                 stream=None, reward_expr=None, dtype="f64"):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
+        self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
-                             weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr)
+                             weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 

@@ -358,3 +358,72 @@ def test_reference_call_order_on_the_draw_schedule_reproduces_the_oracle(oracle)
             tot[k] += 1
         assert x == xo[c] and e == eo[c]
         assert acc == acc_o[:, c].tolist() and tot == tot_o[:, c].tolist()
+
+
+# ---- Float32 state: the oracle's C-float restatement against an independent numpy.float32 one ---------------------
+def _np_f32_step(lib, pot, beta, sigma, z, u, x):
+    """mc_step! for Particle{Float32} written with numpy.float32 scalars, following Julia's promotion rules:
+    delta = Float32(sigma*z); (delta)^2 in Float32, / (2 sigma^2) in Float64; x, e, dlogp in Float32; alpha in Float64."""
+    f32 = np.float32
+
+    def potf(v):
+        if pot == 1:
+            q = f32(f32(v * v) - f32(1))
+            return f32(q * q)
+        return f32(v * v)
+
+    def logq(d):
+        d2 = f32(-f32(d * d))
+        return float(d2) / (2.0 * (sigma * sigma)) - lib.amo_log(float.fromhex("0x1.921fb54442d18p+2") * (sigma * sigma)) / 2.0
+
+    delta = f32(0.0 + sigma * z)
+    lf = logq(delta)
+    e1 = potf(x)
+    xn = f32(x + delta)
+    e2 = potf(xn)
+    dlogp = f32(f32(f32(-e2) * beta) - f32(f32(-e1) * beta))
+    nd = f32(-delta)
+    lb = logq(nd)
+    alpha = min(1.0, lib.amo_exp(float(dlogp) + lb - lf))
+    if alpha > u:
+        return 1, xn, e2
+    xr = f32(xn + nd)
+    return 0, xr, potf(xr)
+
+
+def test_float32_step_follows_julias_promotion_rules(oracle):
+    import ctypes as C
+    lib = oracle.load()
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    n_acc = 0
+    for _ in range(20000):
+        pot = int(rng.integers(0, 2))
+        beta = f32(rng.uniform(0.5, 3))
+        sigma = float(rng.uniform(0.05, 1.5))
+        z, u = float(rng.normal()), float(rng.uniform())
+        x = f32(rng.uniform(-2, 2))
+        xx, ee = C.c_float(x), C.c_float(lib.amo_potential_f32(pot, C.c_float(x)))
+        a = lib.amo_mc_step_explicit_f32(pot, beta, sigma, z, u, C.byref(xx), C.byref(ee))
+        a2, x2, e2 = _np_f32_step(lib, pot, beta, sigma, z, u, x)
+        assert a == a2 and f32(xx.value) == x2 and f32(ee.value) == e2
+        n_acc += a
+    assert 5000 < n_acc < 19000          # both branches exercised
+
+
+def test_float32_simulation_keeps_float32_values_and_the_right_distribution(oracle):
+    s = oracle.OracleSim(4000, potential="harmonic", beta=2.0, sigma=[0.8], weight=[1.0], seed=3, dtype="f32")
+    s.init_uniform(-2, 2)
+    s.make_steps(300, 8)
+    x, e = s.state()
+    assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    assert np.array_equal(e, (x.astype(np.float32) ** 2).astype(np.float64))
+    assert abs(s.energy() - 0.25) < 0.02             # <x^2> = 1/(2 beta)
+    # the Float64 run from the same seeds differs only at Float32 rounding level early on
+    d = oracle.OracleSim(4000, potential="harmonic", beta=2.0, sigma=[0.8], weight=[1.0], seed=3)
+    d.init_uniform(-2, 2)
+    f = oracle.OracleSim(4000, potential="harmonic", beta=2.0, sigma=[0.8], weight=[1.0], seed=3, dtype="f32")
+    f.init_uniform(-2, 2)
+    d.make_steps(3)
+    f.make_steps(3)
+    assert np.max(np.abs(d.state()[0] - f.state()[0])) < 1e-5
