@@ -27,11 +27,12 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--beta", type=float, default=2.0)
     ap.add_argument("--path", default=None)
+    ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="Particle{T}: Float64 (reference scripts) or Float32")
     args = ap.parse_args(argv)
 
     seed, beta, M, steps = args.seed, args.beta, args.chains, args.steps
     burn = min(1000, steps // 10)
-    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0)                    # x0 = 4 rand() - 2; potential(x) = x^2
+    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0, dtype=args.dtype)                    # x0 = 4 rand() - 2; potential(x) = x^2
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 1.0),)
     sampletimes = ma.build_schedule(steps, burn, [0, 10])
     path = args.path or f"data/MC/particle_1d/Harmonic/beta{beta}/M{M}/seed{seed}"

@@ -27,12 +27,13 @@ def main(argv=None):
     ap.add_argument("--beta", type=float, default=2.0)
     ap.add_argument("--eta", type=float, default=None)
     ap.add_argument("--path", default=None)
+    ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="Particle{T}: Float64 (reference scripts) or Float32")
     args = ap.parse_args(argv)
 
     seed, beta, M, steps = args.seed, args.beta, args.chains, args.steps
     eta = args.eta if args.eta is not None else min(0.5, 0.001 * M / 10)
     burn = min(1000, steps // 10)
-    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0)
+    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0, dtype=args.dtype)
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
             ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
     optimisers = (ma.Static(), ma.VPG(eta))

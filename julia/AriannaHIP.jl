@@ -34,11 +34,16 @@ struct AmcConfig
     sweepstep::Int32
     per_chain_counters::Int32
     stream::Ptr{Cvoid}
+    state_dtype::Int32            # 0: Float64, 1: Float32 (Particle{Float32}); host buffers stay Float64 either way
+    reserved::Int32
 end
 
 const POTENTIAL_HARMONIC = Int32(0)
 const POTENTIAL_DOUBLE_WELL = Int32(1)
 const POTENTIAL_CUSTOM = Int32(2)          # potential given as a C expression in x (amc_create_custom)
+
+# Particle{T}: the state type the engine keeps on the device (DESIGN.md section 3.7)
+eltype_of_state(chains) = typeof(chains[1].x)
 
 function check(rc::Cint)
     rc == 0 && return nothing
@@ -74,7 +79,8 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
         cfg = AmcConfig(UInt32(sizeof(AmcConfig)), Int32(device), length(chains), chain_offset, n_chains_global,
                         pot_id,
                         Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
-                        Int32(sweepstep), Int32(per_chain_counters), C_NULL)
+                        Int32(sweepstep), Int32(per_chain_counters), C_NULL,
+                        Int32(eltype_of_state(chains) === Float32 ? 1 : 0), Int32(0))
         if reward isa AbstractString
             # script-defined reward(action, system) (particle_1d.jl:42-44) as an expression in delta and the new x
             pot = potential isa AbstractString ? potential : C_NULL

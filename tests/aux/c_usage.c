@@ -32,6 +32,19 @@ int main(void)
     printf("custom mean_U %.6f mean_x %.6f\n", red[AMC_RED_SUM_E] / red[AMC_RED_COUNT], red[AMC_RED_SUM_X] / red[AMC_RED_COUNT]);
     amc_destroy(h);
 
+    /* Particle{Float32}: the same calls, Float32 state on the device, double host buffers */
+    cfg.potential = AMC_POTENTIAL_HARMONIC;
+    cfg.state_dtype = AMC_DTYPE_F32;
+    sigma[0] = 0.1;
+    if (amc_create(&cfg, &h)) { fprintf(stderr, "f32: %s\n", amc_last_error()); return 1; }
+    if (amc_init_uniform(h, -2.0, 2.0) || amc_sweep(h, 2000) || amc_reduce(h, red)) {
+        fprintf(stderr, "%s\n", amc_last_error());
+        return 1;
+    }
+    printf("f32 harmonic mean_U %.6f acc %.5f\n", red[AMC_RED_SUM_E] / red[AMC_RED_COUNT], red[4] / red[AMC_RED_COUNT]);
+    amc_destroy(h);
+    cfg.state_dtype = AMC_DTYPE_F64;
+
     /* errors come back as codes + message, never as exceptions */
     cfg.n_moves = 0;
     if (amc_create(&cfg, &h) != AMC_ERR_BAD_ARG) return 2;

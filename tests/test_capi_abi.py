@@ -124,4 +124,6 @@ def test_plain_c_client_links_and_runs(tmp_path):
     mean_u = integrate.quad(lambda x: U(x) * math.exp(-2 * U(x)), -5, 5)[0] / z
     cu = dict(zip(lines[1].split()[1::2], map(float, lines[1].split()[2::2])))
     assert cu["mean_U"] == pytest.approx(mean_u, abs=5e-3) and cu["mean_x"] == pytest.approx(0.0, abs=8e-3)
-    assert "n_moves must be in" in lines[2]
+    f32 = dict(zip(lines[2].split()[2::2], map(float, lines[2].split()[3::2])))     # "f32 harmonic mean_U .. acc .."
+    assert f32["mean_U"] == pytest.approx(0.25, abs=5e-3) and f32["acc"] == pytest.approx(0.9365, abs=5e-3)
+    assert "n_moves must be in" in lines[3]
