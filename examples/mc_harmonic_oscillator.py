@@ -45,6 +45,15 @@ def main(argv=None):
              scheduler=ma.build_schedule(steps, burn, max(1, steps // 10))),
         dict(algorithm=ma.PrintTimeSteps, scheduler=ma.build_schedule(steps, burn, max(1, steps // 10))),
     )
+    # the reference script's per-chain text files (trajectories/<c>/trajectory.dat, restart_t<t>.dat, lastframe.dat), for
+    # the first chains of the ensemble: all of them at the script's own M = 10
+    few = dict(select=(0, 1, min(M, 16)))
+    algorithm_list += (
+        dict(algorithm=ma.StoreTrajectories, scheduler=sampletimes, **few),
+        dict(algorithm=ma.StoreBackups, scheduler=ma.build_schedule(steps, burn, max(1, steps // 10)), store_first=True,
+             store_last=True, **few),
+        dict(algorithm=ma.StoreLastFrames, scheduler=[steps], **few),
+    )
     simulation = ma.Simulation(chains, algorithm_list, steps, path=path, verbose=True)
     ma.run(simulation)
 

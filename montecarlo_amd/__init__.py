@@ -14,6 +14,7 @@ from .sharding import allreduce_sum, shard_range
 from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
                          build_schedule, julia_repr, run)
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
+from .trajectories import DAT, TXT, StoreBackups, StoreLastFrames, StoreTrajectories
 from .system import CustomPotential, Displacement, Move, ParticleChains, StandardGaussian, potential
 
 __all__ = [
@@ -25,5 +26,6 @@ __all__ = [
     "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
+    "DAT", "TXT", "StoreBackups", "StoreLastFrames", "StoreTrajectories",
     "CustomPotential", "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
 ]

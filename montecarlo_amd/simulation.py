@@ -8,8 +8,9 @@ Python mirror of the reference's driver so the HIP ``Metropolis`` slots in the w
   run!          src/simulation.jl:175-204
   StoreCallbacks src/algorithms.jl:62-109, StoreParameters src/metropolis.jl:380-450,
   PrintTimeSteps src/algorithms.jl:310-323
-Per-chain text I/O (StoreTrajectories / StoreBackups / StoreLastFrames) is out of scope at
-M = 1e7.  One addition over the reference: ``run(fuse=True)`` looks ahead in
+Per-chain text I/O (StoreTrajectories / StoreBackups / StoreLastFrames, src/algorithms.jl:154-303) lives in
+trajectories.py (the reference's file layout, for ensembles small enough to have one file per chain); storage.py holds
+what replaces it at M = 1e7.  One addition over the reference: ``run(fuse=True)`` looks ahead in
 the schedules and issues one fused launch for every stretch of sweeps no other algorithm
 observes (results identical to stepping one by one).
 """
@@ -172,7 +173,8 @@ class Simulation:
             f.write(f"\tSteps: {self.steps}\n\tNumber of chains: {len(self.chains)}\n")
             f.write(f"\tNumber of algorithms: {len(self.algorithms)}\n\tVerbose: {str(self.verbose).lower()}\n")
             f.write(f"\tStarted on {time.strftime('%Y-%m-%dT%H:%M:%S')}\n\nSystem:\n")
-            f.write(f"\tParticle{{Float64}} x {len(self.chains)} ({self.chains.potential}, SoA on MI355X)\n\n")
+            tname = "Float32" if getattr(self.chains, "dtype", "f64") == "f32" else "Float64"
+            f.write(f"\tParticle{{{tname}}} x {len(self.chains)} ({self.chains.potential}, SoA on MI355X)\n\n")
             f.write("Algorithms:\n")
             for alg, sched in zip(self.algorithms, self.schedulers):
                 alg.write_algorithm(f, sched)

@@ -27,6 +27,13 @@ def test_mc_harmonic_oscillator_example(gpu, tmp_path, capsys):
     acc = open(tmp_path / "mc" / "acceptance.dat").read().splitlines()
     assert acc[0] == "0 [NaN]" and float(acc[-1].split("[")[1].strip("]")) == pytest.approx(0.93655, abs=2e-3)
     assert os.path.exists(tmp_path / "mc" / "summary.log") and os.path.exists(tmp_path / "mc" / "histogram.dat")
+    # the reference script's per-chain files for the first 16 chains (MC_harmonic_oscillator.jl:24-26)
+    d = tmp_path / "mc" / "trajectories" / "16"
+    traj = np.loadtxt(d / "trajectory.dat")
+    assert traj[0, 0] == 0 and traj[1, 0] == 300 and traj[-1, 0] == 3000 and len(traj) == len(rows)   # store_first row + schedule
+    assert sorted(os.listdir(d)) == sorted(["trajectory.dat", "lastframe.dat"] + [f"restart_t{t}.dat" for t in
+                                                                                 [0] + list(range(300, 3001, 300))])
+    assert float(open(d / "lastframe.dat").read().split()[1]) == traj[-1, 1] == sim.chains.x[15]
 
 
 def test_pgmc_harmonic_oscillator_example(gpu, tmp_path, capsys):
