@@ -259,7 +259,9 @@ int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
 /* Parity-test hooks: evaluate arithmetic-spec primitives on the device.
  * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b (IEEE), 6 a/b by the kernel's
  * reciprocal-correction sequence (must equal 5 bit for bit), 7 the Box-Muller log, 8 the Box-Muller
- * radius sqrt (must equal 4 bit for bit on {0} U [2^-52, 80]).  Host buffers. */
+ * radius sqrt (must equal 4 bit for bit on {0} U [2^-52, 80]); 9 log_proposal_density(delta = a, sigma = b)
+ * (particle_1d.jl:52-54) and 10 its derivative with respect to sigma (withgrad_log_proposal_density!, gradients.jl:28-33)
+ * through the estimator's own code -- the values test/ad_backends_test.jl:31-32 pins.  Host buffers. */
 int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
                        double *out, int64_t n);
 /* The sweep kernel settles most accept decisions from a float estimate of exp(dlogp) whose error interval is rigorous

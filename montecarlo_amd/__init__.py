@@ -15,6 +15,7 @@ from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCall
                          build_schedule, julia_repr, run)
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
 from .trajectories import DAT, TXT, StoreBackups, StoreLastFrames, StoreTrajectories
+from .system import Action, AriannaSystem, Policy
 from .system import CustomPotential, Displacement, Move, ParticleChains, StandardGaussian, potential
 
 __all__ = [
@@ -27,5 +28,5 @@ __all__ = [
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
     "DAT", "TXT", "StoreBackups", "StoreLastFrames", "StoreTrajectories",
-    "CustomPotential", "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
+    "Action", "AriannaSystem", "Policy", "CustomPotential", "Displacement", "Move", "ParticleChains", "StandardGaussian", "potential",
 ]

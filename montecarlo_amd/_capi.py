@@ -538,7 +538,7 @@ class SplitEngine:
 def selftest_math(fn: str, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
     """Evaluate one arithmetic-spec primitive on the GPU (parity tests only)."""
     ids = {"exp": 0, "log": 1, "sinpi": 2, "cospi": 3, "sqrt": 4, "div": 5, "div_by_const": 6, "logbm": 7,
-           "sqrt_radius": 8}
+           "sqrt_radius": 8, "log_proposal_density": 9, "grad_log_proposal_density": 10}
     a = np.ascontiguousarray(a, dtype=np.float64)
     if b is not None:
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -1628,7 +1628,7 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
 // ---- parity-test hooks ----------------------------------------------------------------
 int amc_selftest_math(int device, int fn, const double* a, const double* b_or_null, double* out, int64_t n)
 {
-    if (!a || !out || n < 0 || fn < 0 || fn > 8 || ((fn == 5 || fn == 6) && !b_or_null))
+    if (!a || !out || n < 0 || fn < 0 || fn > 10 || ((fn == 5 || fn == 6 || fn == 9 || fn == 10) && !b_or_null))
         return fail(AMC_ERR_BAD_ARG, "amc_selftest_math: bad argument");
     if (n == 0) return AMC_OK;
     AMC_HIP(hipSetDevice(device));

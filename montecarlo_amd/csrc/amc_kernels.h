@@ -961,15 +961,27 @@ enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kern
 
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
+// log_proposal_density (particle_1d.jl:52-54) and its derivative with respect to sigma as ForwardDiff forms it
+// (withgrad_log_proposal_density!, gradients.jl:28-33), from the per-move table entries of prepare_params.
+struct LogQ { double logq, dlogq; };
+__device__ __forceinline__ LogQ log_proposal_density_withgrad(real_t delta, double den, double rden, double logc,
+                                                              double dden, double dlhalf)
+{
+    const double q1 = div_by_const((double)(-(delta * delta)), den, rden);
+    LogQ r;
+    r.logq = q1 - logc;
+    r.dlogq = -div_by_const(q1, den, rden) * dden - dlhalf;
+    return r;
+}
+
 template <int POT>
 __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double den, double rden,
                                           double logc, double dden, double dlhalf, double z, double (&g)[4],
                                           const double* T)
 {
     const real_t delta = (real_t)(0.0 + sigma * z);
-    const double q1 = div_by_const((double)(-(delta * delta)), den, rden);
-    const double logq = q1 - logc;
-    const double dlogq = -div_by_const(q1, den, rden) * dden - dlhalf;      // ForwardDiff value, gradients.jl:28-33
+    const LogQ lq = log_proposal_density_withgrad(delta, den, rden, logc, dden, dlhalf);
+    const double logq = lq.logq, dlogq = lq.dlogq;
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = x + delta;
     const real_t e2 = potential<POT>(xn, T);
@@ -1264,6 +1276,20 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
     case 6: r = div_by_const(v, b[i], 1.0 / b[i]); break;
     case 7: r = logbm_f64(v, s_math); break;
     case 8: r = sqrt_radius_f64(v); break;
+    case 9:
+    case 10: {
+        // log_proposal_density(delta = a, sigma = b) / its sigma-derivative, through the code the estimator runs:
+        // prepare_params for a one-move pool, then log_proposal_density_withgrad
+        double tab[PT_ROWS * AMC_MAX_MOVES];
+        tab[PT_SIGMA * AMC_MAX_MOVES] = b[i];
+        tab[PT_WEIGHT * AMC_MAX_MOVES] = 1.0;
+        prepare_params(tab, 1);
+        const LogQ lq = log_proposal_density_withgrad((real_t)v, tab[PT_DEN * AMC_MAX_MOVES], tab[PT_RDEN * AMC_MAX_MOVES],
+                                                      tab[PT_LOGC * AMC_MAX_MOVES], tab[PT_DDEN * AMC_MAX_MOVES],
+                                                      tab[PT_DLHALF * AMC_MAX_MOVES]);
+        r = fn == 9 ? lq.logq : lq.dlogq;
+        break;
+    }
     default: break;
     }
     out[i] = r;

@@ -43,7 +43,19 @@ def potential(name, x):
     raise ValueError(f"unknown potential {name!r}; the HIP engine offers {POTENTIALS}")
 
 
-class ParticleChains:
+class AriannaSystem:
+    """abstract type AriannaSystem (src/Arianna.jl:22-23): what a chain is an instance of."""
+
+
+class Action:
+    """abstract type Action (src/metropolis.jl:7)."""
+
+
+class Policy:
+    """abstract type Policy (src/metropolis.jl:14)."""
+
+
+class ParticleChains(AriannaSystem):
     """``chains::Vector{Particle}`` (particle_1d.jl:9-16) as one SoA ensemble description.
 
     The reference holds M mutable ``Particle(x, beta, e)`` objects; at M = 1e7 that is an
@@ -94,13 +106,13 @@ class ParticleChains:
 
 
 @dataclass
-class Displacement:
+class Displacement(Action):
     """Action: shift x by delta (particle_1d.jl:26-28)."""
     delta: float = 0.0
 
 
 @dataclass(frozen=True)
-class StandardGaussian:
+class StandardGaussian(Policy):
     """Policy: delta ~ Normal(0, sigma) (particle_1d.jl:48-59)."""
 
     @staticmethod

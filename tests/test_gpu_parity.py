@@ -57,6 +57,28 @@ def test_device_sqrt_and_division_are_ieee(gpu):
     assert np.array_equal(bits(gpu.selftest_math("div", num, den)), bits(num / den))
 
 
+def test_log_proposal_density_and_gradient_known_answers(gpu, oracle):
+    """test/ad_backends_test.jl:19-32 on the device: delta = 0, sigma = 0.2 -> logq = 0.6904993792294276, d logq / d sigma
+    = -5.0 (atol 1e-10, the reference's own tolerance), through the estimator's code path (prepare_params +
+    log_proposal_density_withgrad); and bit for bit against the oracle on random arguments."""
+    logq = gpu.selftest_math("log_proposal_density", [0.0], [0.2])[0]
+    dlogq = gpu.selftest_math("grad_log_proposal_density", [0.0], [0.2])[0]
+    assert abs(logq - 0.6904993792294276) < 1e-10 and abs(dlogq - (-5.0)) < 1e-10
+    rng = np.random.default_rng(8)
+    n = 200000
+    sig = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n))
+    delta = sig * rng.normal(0, 1, n)
+    lib = oracle.load()
+    want = np.array([lib.amo_log_proposal_density(d, s) for d, s in zip(delta[:20000], sig[:20000])])
+    wantg = np.array([lib.amo_grad_log_proposal_density(d, s) for d, s in zip(delta[:20000], sig[:20000])])
+    got = gpu.selftest_math("log_proposal_density", delta, sig)
+    gotg = gpu.selftest_math("grad_log_proposal_density", delta, sig)
+    assert np.array_equal(bits(got[:20000]), bits(want)) and np.array_equal(bits(gotg[:20000]), bits(wantg))
+    # closed forms (particle_1d.jl:53 and its sigma-derivative delta^2/sigma^3 - 1/sigma)
+    assert np.allclose(got, -delta ** 2 / (2 * sig ** 2) - np.log(2 * np.pi * sig ** 2) / 2, rtol=1e-12, atol=1e-12)
+    assert np.allclose(gotg, delta ** 2 / sig ** 3 - 1 / sig, rtol=1e-10, atol=1e-12)
+
+
 def test_reciprocal_correction_division_is_ieee(gpu):
     """The sweep kernel divides by den = 2 sigma^2 with a precomputed reciprocal and two Markstein
     corrections (amc_kernels.h div_by_const); it must equal the IEEE quotient for every input."""
