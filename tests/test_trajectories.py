@@ -99,3 +99,35 @@ def test_reference_layout_and_rows_on_gpu(gpu, oracle, tmp_path, dtype):
     sim, _ = build(None, M, steps, tmp_path, algorithms(steps), seed=7, dtype=dtype)
     ma.run(sim)
     check_layout(oracle, str(tmp_path), M, steps, 7, dtype=dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [2.0, 3.0])
+def test_harmonic_oscillator_distribution_from_trajectory_files(gpu, tmp_path, beta):
+    """test/distribution_test.jl with its own algorithm list and its own data source -- the per-chain trajectory files,
+    read back like `readdlm(file)[:, 2]` -- at a fifth of its length (2e5 steps; tolerance scaled from its 1e-3 to the
+    ~1.3e-3 standard error of 2e6 correlated samples: 6e-3)."""
+    seed, M, steps, burn = 42, 100, 2 * 10 ** 5, 1000
+    sampletimes = ma.build_schedule(steps, burn, [0, 10])
+    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 1.0),)
+    path = str(tmp_path)
+    algorithm_list = (
+        dict(algorithm=ma.Metropolis, pool=pool, seed=seed, parallel=False),
+        dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance), scheduler=sampletimes),
+        dict(algorithm=ma.StoreTrajectories, scheduler=sampletimes),
+        dict(algorithm=ma.StoreBackups, scheduler=ma.build_schedule(steps, burn, steps // 10), store_first=True, store_last=True),
+        dict(algorithm=ma.StoreLastFrames, scheduler=[steps]),
+        dict(algorithm=ma.PrintTimeSteps, scheduler=ma.build_schedule(steps, burn, steps // 10)),
+    )
+    simulation = ma.Simulation(chains, algorithm_list, steps, path=path, verbose=False)
+    ma.run(simulation)
+    dirs = sorted(os.listdir(os.path.join(path, "trajectories")), key=int)
+    assert dirs == [str(c) for c in range(1, M + 1)]
+    trajectories = [np.loadtxt(os.path.join(path, "trajectories", d, "trajectory.dat"))[1:, 1] for d in dirs]   # drop the t = 0 row
+    positions = np.concatenate(trajectories)
+    assert positions.size == M * len(sampletimes)
+    assert positions.mean() == pytest.approx(0.0, abs=6e-3)
+    assert positions.std() == pytest.approx(1 / np.sqrt(2 * beta), abs=6e-3)
+    assert sorted(f for f in os.listdir(os.path.join(path, "trajectories", "1")) if f.startswith("restart")) == \
+        sorted(f"restart_t{t}.dat" for t in [0] + list(ma.build_schedule(steps, burn, steps // 10)))
