@@ -145,6 +145,17 @@ int  amc_create_custom(const amc_config *cfg, const char *potential_expr, amc_ha
  * -- what the policy-gradient estimator maximises (E[reward * alpha]).  potential_expr NULL: the built-in potential named
  * by cfg->potential (its own expression, compiled at run time); reward_expr NULL: delta^2. */
 int  amc_create_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr, amc_handle **out);
+/* The same with a script-defined POLICY of the Gaussian-displacement family.  The reference hands `system` to
+ * sample_action! and log_proposal_density (src/metropolis.jl:177-182; particle_1d.jl:52-59), so a policy's width may depend
+ * on the state: scale_expr is ONE C expression in the CURRENT position `x`, and the proposal is
+ *     delta = rand(rng, Normal(0, sigma_k * scale(x)))
+ *     log_proposal_density = -(delta)^2 / (2 (sigma_k scale(x))^2) - log(2 pi (sigma_k scale(x))^2) / 2
+ * with the forward density evaluated at the old state and the backward density at the new one, as mc_step! does
+ * (metropolis.jl:178,182): the proposal ratio no longer cancels and enters the acceptance.  scale_expr NULL: scale = 1,
+ * the reference's StandardGaussian (amc_create_model).  The policy-gradient estimator entries refuse such a handle
+ * (AMC_ERR_STATE): their closed-form gradient is the StandardGaussian's. */
+int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
+                             const char *scale_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
 int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);
 

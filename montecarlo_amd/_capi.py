@@ -78,6 +78,7 @@ def load() -> C.CDLL:
         "amc_create": (C.c_int, [C.POINTER(AmcConfig), C.POINTER(H)]),
         "amc_create_custom": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.POINTER(H)]),
         "amc_create_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.POINTER(H)]),
+        "amc_create_policy_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -161,7 +162,7 @@ class HipEngine:
                  potential="harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
-                 reward_expr: Optional[str] = None, dtype: str = "f64"):
+                 reward_expr: Optional[str] = None, dtype: str = "f64", scale_expr: Optional[str] = None):
         lib = load()
         if str(dtype) not in STATE_DTYPES:
             raise AmcError(f"unknown state dtype {dtype!r}; one of {sorted(STATE_DTYPES)}")
@@ -192,7 +193,14 @@ class HipEngine:
         cfg.state_dtype = STATE_DTYPES[self.dtype]
         self._lib = lib
         self._h = C.c_void_p()
-        if reward_expr is not None:
+        if scale_expr is not None:
+            # script-defined policy of the Gaussian-displacement family: proposal width sigma * scale(x)
+            if expr is None:
+                cfg.potential = POTENTIALS[potential]
+            _check(lib.amc_create_policy_model(C.byref(cfg), None if expr is None else str(expr).encode(),
+                                               None if reward_expr is None else str(reward_expr).encode(),
+                                               str(scale_expr).encode(), C.byref(self._h)))
+        elif reward_expr is not None:
             # script-defined reward(action, system) (gradients.jl:20): an expression in delta and the new position x
             if expr is None:
                 cfg.potential = POTENTIALS[potential]

@@ -114,6 +114,7 @@ struct amc_handle {
     bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
     bool f32 = false;             // state_dtype == AMC_DTYPE_F32: d_x / d_beta hold floats
+    bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model): no estimator kernels
     bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
     double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
@@ -424,10 +425,16 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCo
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] ]
     const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
-    const std::string expr = expr_in.substr(f32 ? 1 : 0);
-    const size_t cut = expr.find('\x01');
+    const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
+    std::string expr = expr_full;
     std::string src;
     if (f32) src += "#define AMC_STATE_F32 1\n";
+    const size_t cut_scale = expr.find('\x03');          // ... [ '\x03' proposal-width scale ]
+    if (cut_scale != std::string::npos) {
+        src += "#define AMC_USER_SCALE(x) (" + expr.substr(cut_scale + 1) + ")\n";
+        expr.erase(cut_scale);
+    }
+    const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
     src += "#include \"amc_kernels.h\"\n";
@@ -451,7 +458,7 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCo
     if (e != 0) {
         g_hiprtc.DestroyProgram(&prog);
         // the first diagnostic is what the user needs; keep the message bounded
-        return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr.empty() ? "run-time kernel build failed" : "custom potential does not compile",
+        return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr_full.empty() ? "run-time kernel build failed" : "custom potential does not compile",
                     log.empty() ? "(no log)" : log.c_str());
     }
     RtcCode rc;
@@ -533,7 +540,8 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr)
+static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
+                       const char* scale_expr = nullptr)
 {
     if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
     *out = nullptr;
@@ -560,6 +568,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         if (reward_expr) {
             const int rc_rew = validate_potential_expr(reward_expr, "custom reward", "delta");
             if (rc_rew != AMC_OK) return rc_rew;
+        }
+        if (scale_expr) {
+            const int rc_sc = validate_potential_expr(scale_expr, "proposal-width scale", "x");
+            if (rc_sc != AMC_OK) return rc_sc;
         }
     } else if (potential_expr) {
         return fail(AMC_ERR_BAD_ARG, "amc_create_custom: cfg->potential must be AMC_POTENTIAL_CUSTOM");
@@ -618,6 +630,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (h->f32) h->pot_expr = "\x02";
     if (potential_expr) h->pot_expr += potential_expr;
     if (potential_expr && reward_expr) h->pot_expr += std::string("\x01") + reward_expr;
+    if (potential_expr && scale_expr) { h->pot_expr += std::string("\x03") + scale_expr; h->scaled_policy = true; }
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
     h->counters = cfg->per_chain_counters != 0 || cfg->n_moves > 1;
@@ -732,6 +745,26 @@ int amc_create_model(const amc_config* cfg, const char* potential_expr, const ch
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));   // a 0.1 caller's struct is shorter
     c2.potential = AMC_POTENTIAL_CUSTOM;
     return create_impl(&c2, pot, out, reward_expr);
+}
+
+int amc_create_policy_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* scale_expr,
+                            amc_handle** out)
+{
+    if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_policy_model: NULL argument");
+    if (!scale_expr) return amc_create_model(cfg, potential_expr, reward_expr, out);
+    const char* pot = potential_expr;
+    if (!pot) {
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)
+            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
+                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "amc_create_policy_model: potential_expr is NULL and cfg->potential names no built-in");
+    }
+    amc_config c2;
+    std::memset(&c2, 0, sizeof(c2));
+    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
+    c2.potential = AMC_POTENTIAL_CUSTOM;
+    return create_impl(&c2, pot, out, reward_expr, scale_expr);
 }
 
 int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
@@ -1336,6 +1369,9 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false)
 {
+    if (h->scaled_policy)
+        return fail(AMC_ERR_STATE, "%s: the policy-gradient estimator is written for the StandardGaussian policy; this handle "
+                                   "was created with a state-dependent proposal width (amc_create_policy_model)", who);
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
     if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)

@@ -75,6 +75,14 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
 #ifndef AMC_USER_REWARD
 #define AMC_USER_REWARD(delta, x) ((delta) * (delta))
 #endif
+// A script-defined POLICY of the Gaussian-displacement family (sample_action! / log_proposal_density are the model's,
+// particle_1d.jl:48-59; the reference hands them `system`, so the width may depend on the state): the proposal width is
+// sigma * scale(x) with AMC_USER_SCALE an expression in the CURRENT position x,
+//   sample_action!        delta = rand(rng, Normal(0, sigma*scale(x)))            = 0 + (sigma*scale(x)) * z
+//   log_proposal_density  -(delta)^2 / (2 (sigma*scale(x))^2) - log(2pi (sigma*scale(x))^2) / 2
+// The forward density is evaluated at the old state, the backward one at the new state (mc_step! metropolis.jl:178,182
+// call it before and after perform_action!), so logq_b != logq_f and the proposal ratio is real.  Undefined (offline
+// build, every handle without a scale expression): scale == 1, the StandardGaussian policy of the reference.
 #define amc_exp(v) (::amc::exp_f64((v), amc_tables_))
 #define amc_log(v) (::amc::log_f64((v)))
 __device__ __forceinline__ real_t user_potential(real_t x, const double* amc_tables_)
@@ -86,6 +94,12 @@ __device__ __forceinline__ double user_reward(real_t delta, real_t x, const doub
 {
     return (double)(AMC_USER_REWARD(delta, x));
 }
+#ifdef AMC_USER_SCALE
+__device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_)
+{
+    return (double)(real_t)(AMC_USER_SCALE(x));      // a function of the system returns T; sigma * scale promotes
+}
+#endif
 #undef amc_exp
 #undef amc_log
 
@@ -193,6 +207,33 @@ __device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
     return c;
 }
 
+#ifdef AMC_USER_SCALE
+// One mc_step! with the state-dependent proposal width above, in the reference's operation order.  No filter: the
+// proposal ratio does not cancel, so arg has no cheap estimate; every decision takes the exact arithmetic.
+template <int POT>
+__device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, double z, double u, const double* T)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    const double sc = sigma * user_scale(x, T);
+    const double sc2 = sc * sc;
+    const real_t delta = (real_t)(0.0 + sc * z);
+    const double logq_f = ((double)(-(delta * delta))) / (2.0 * sc2) - log_f64(TWO_PI * sc2) / 2.0;
+    const real_t e1 = potential<POT>(x, T);
+    const real_t xn = x + delta;
+    const real_t e2 = potential<POT>(xn, T);
+    const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const real_t nd = -delta;
+    const double scn = sigma * user_scale(xn, T);
+    const double scn2 = scn * scn;
+    const double logq_b = ((double)(-(nd * nd))) / (2.0 * scn2) - log_f64(TWO_PI * scn2) / 2.0;
+    const double arg = ((double)dlogp + logq_b) - logq_f;
+    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
+    const bool acc = c_pos | (c_rng & c_exp);
+    x = acc ? xn : (real_t)(xn + nd);
+    return acc;
+}
+#endif
+
 // One mc_step! of both chains of a pair.  force_mask (wave-uniform, all ones or zero; tests) sends every wave through
 // accept_exact.  acc_bits: bit 0 = even chain accepted, bit 8 = odd chain accepted (the step-log word's accept bits).
 // LAZY (K == 1): the accept draw is not formed up front.  The top 12 bits of u come from the normal draw (spec v4),
@@ -206,6 +247,17 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
                                         const double* T, unsigned long long force_mask, uint32_t& acc_bits,
                                         unsigned long long& m0, unsigned long long& m1)
 {
+#ifdef AMC_USER_SCALE
+    {
+        if (LAZY) pu = philox4x32_10(accept_ctr, key0, key1);
+        const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(pn.x, pu.x, pu.y), T);
+        const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(pn.z, pu.z, pu.w), T);
+        m0 = __builtin_amdgcn_ballot_w64(a0);
+        m1 = __builtin_amdgcn_ballot_w64(a1);
+        acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
+        return;
+    }
+#endif
     const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
     const real_t xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
     const uint32_t a0_12 = pn.x & 0xFFFu, a1_12 = pn.z & 0xFFFu;      // even chain: words (x, y), odd: (z, w)

@@ -66,6 +66,12 @@ class Metropolis(AriannaAlgorithm):
         extra = {} if getattr(chains, "reward", None) is None else {"reward_expr": chains.reward}
         if getattr(chains, "dtype", "f64") != "f64":
             extra["dtype"] = chains.dtype
+        scales = {getattr(m.policy, "scale", None) for m in self.pool}
+        if scales != {None}:
+            # one policy expression per handle: the kernels are compiled for it
+            if len(scales) != 1:
+                raise ValueError("all moves of a pool must share one policy: either StandardGaussian or one ScaledGaussian(scale)")
+            extra["scale_expr"] = scales.pop()
         self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains), **extra,
                               potential=chains.potential, beta=chains.beta,
                               sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],

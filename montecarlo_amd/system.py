@@ -120,6 +120,20 @@ class StandardGaussian(Policy):
         return {"sigma": 1.0}
 
 
+@dataclass(frozen=True)
+class ScaledGaussian(Policy):
+    """Policy: delta ~ Normal(0, sigma * scale(x)) -- a script-defined policy of the Gaussian-displacement family whose
+    width depends on the state (the reference passes `system` to sample_action! / log_proposal_density,
+    src/metropolis.jl:177-182).  ``scale`` is one C expression in the current position ``x`` (CustomPotential's
+    vocabulary), compiled for the GPU at run time; the forward density is taken at the old state, the backward one at
+    the new state, so the proposal ratio enters the acceptance.  All moves of a pool share the scale expression."""
+    scale: str = "1.0"
+
+    @staticmethod
+    def setup_parameters() -> Dict[str, float]:
+        return {"sigma": 1.0}
+
+
 @dataclass
 class Move:
     """Move(action, policy, parameters, weight) (src/metropolis.jl:140-162).
@@ -129,7 +143,7 @@ class Move:
     pool-wide sums here; per-chain values come from ``Metropolis.download_counters``.
     """
     action: Displacement
-    policy: StandardGaussian
+    policy: Policy
     parameters: np.ndarray
     weight: float
     total_calls: int = 0
@@ -142,8 +156,8 @@ class Move:
         self.parameters = np.atleast_1d(np.asarray(p, dtype=np.float64)).copy()
         if self.parameters.shape != (1,):
             raise ValueError("StandardGaussian has exactly one parameter (sigma)")
-        if not isinstance(self.action, Displacement) or not isinstance(self.policy, StandardGaussian):
-            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian policy only")
+        if not isinstance(self.action, Displacement) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian)):
+            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian or ScaledGaussian policy only")
         self.weight = float(self.weight)
 
     @property

@@ -267,6 +267,14 @@ void amo_set_custom_reward(double (*fn)(double, double)) { g_custom_reward = fn;
 
 void amo_set_custom_potential(double (*fn)(double)) { g_custom_potential = fn; }
 
+/* A script-defined policy of the Gaussian-displacement family: sample_action! / log_proposal_density receive `system`
+ * (particle_1d.jl:52-59), so the proposal width may depend on the state: sigma * scale(x).  0: scale == 1, the
+ * reference's StandardGaussian. */
+static double (*g_custom_scale)(double) = 0;
+static float (*g_custom_scale_f32)(float) = 0;
+void amo_set_custom_scale(double (*fn)(double)) { g_custom_scale = fn; }
+void amo_set_custom_scale_f32(float (*fn)(float)) { g_custom_scale_f32 = fn; }
+
 double amo_potential(int pot, double x)
 {
     if (pot == AMO_POT_CUSTOM) return g_custom_potential ? g_custom_potential(x) : (0.0 / 0.0);
@@ -354,13 +362,17 @@ static inline double julia_min(double a, double b)
  * fed an explicit standard normal z and the accept uniform u. */
 static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
 {
-    m->delta = 0.0 + sigma * z;                                    /* :177 -> particle_1d.jl:57 */
-    double logq_forward = amo_log_proposal_density(m->delta, sigma);   /* :178 */
+    /* the policy's width at the state it is asked about: the old one for sample_action! and the forward density, the
+     * new one for the backward density (system has moved by then) */
+    double s_f = g_custom_scale ? sigma * g_custom_scale(p->x) : sigma;
+    m->delta = 0.0 + s_f * z;                                      /* :177 -> particle_1d.jl:57 */
+    double logq_forward = amo_log_proposal_density(m->delta, s_f); /* :178 */
     double e1, e2;
     perform_action(p, m, pot, &e1, &e2);                           /* :179 */
     double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :180 */
     m->delta = -m->delta;                                          /* :181 invert_action! */
-    double logq_backward = amo_log_proposal_density(m->delta, sigma);  /* :182 */
+    double s_b = g_custom_scale ? sigma * g_custom_scale(p->x) : sigma;
+    double logq_backward = amo_log_proposal_density(m->delta, s_b);    /* :182 */
     double alpha = julia_min(1.0, amo_exp(dlogp + logq_backward - logq_forward)); /* :183 */
     if (alpha > u)                                                 /* :184 */
         return 1;
@@ -433,13 +445,15 @@ static inline float delta_log_target_density_f32(float e1, float e2, float beta)
 
 static inline int mc_step_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
 {
-    float delta = (float)(0.0 + sigma * z);                        /* :177; the field converts */
-    double logq_forward = log_proposal_density_f32(delta, sigma);  /* :178 */
+    double s_f = g_custom_scale_f32 ? sigma * (double)g_custom_scale_f32((float)p->x) : sigma;
+    float delta = (float)(0.0 + s_f * z);                          /* :177; the field converts */
+    double logq_forward = log_proposal_density_f32(delta, s_f);    /* :178 */
     float e1, e2, beta = (float)p->beta;
     perform_action_f32(p, delta, pot, &e1, &e2);                   /* :179 */
     float dlogp = delta_log_target_density_f32(e1, e2, beta);      /* :180 */
     delta = -delta;                                                /* :181 */
-    double logq_backward = log_proposal_density_f32(delta, sigma); /* :182 */
+    double s_b = g_custom_scale_f32 ? sigma * (double)g_custom_scale_f32((float)p->x) : sigma;
+    double logq_backward = log_proposal_density_f32(delta, s_b);   /* :182 */
     double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_backward - logq_forward)); /* :183 */
     m->delta = (double)delta;
     if (alpha > u)                                                 /* :184 */

@@ -72,6 +72,10 @@ int    amo_mc_step_explicit_f32(int pot, float beta, double sigma, double z, dou
 float  amo_potential_f32(int pot, float x);
 void   amo_set_custom_potential_f32(float (*fn)(float));
 void   amo_set_custom_reward_f32(double (*fn)(float delta, float x_new));
+/* State-dependent proposal width sigma * scale(x) (a script-defined policy of the Gaussian-displacement family):
+ * forward density at the old state, backward density at the new one.  NULL: scale == 1 (StandardGaussian). */
+void   amo_set_custom_scale(double (*fn)(double x));
+void   amo_set_custom_scale_f32(float (*fn)(float x));
 double amo_log_proposal_density(double delta, double sigma);
 double amo_grad_log_proposal_density(double delta, double sigma);
 int    amo_categorical(const double *weights, int K, double r);

@@ -55,6 +55,8 @@ def load() -> C.CDLL:
         "amo_set_custom_potential_f32": (None, [C.c_void_p]),
         "amo_set_custom_reward_f32": (None, [C.c_void_p]),
         "amo_set_state_f32": (None, [C.c_void_p, C.c_int]),
+        "amo_set_custom_scale": (None, [C.c_void_p]),
+        "amo_set_custom_scale_f32": (None, [C.c_void_p]),
         "amo_potential_f32": (C.c_float, [C.c_int, C.c_float]),
         "amo_mc_step_explicit_f32": (C.c_int, [C.c_int, C.c_float, C.c_double, C.c_double, C.c_double,
                                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -226,6 +228,31 @@ def install_custom_reward(expr: Optional[str]) -> None:
     lib.amo_set_custom_reward_f32(C.cast(_custom_libs[key].amo_user_reward_f32, C.c_void_p))
 
 
+def install_custom_scale(expr: Optional[str]) -> None:
+    """The oracle's global proposal-width scale(x) (ScaledGaussian policy): None restores scale == 1."""
+    import hashlib
+    import tempfile
+    lib = load()
+    if expr is None:
+        lib.amo_set_custom_scale(None)
+        lib.amo_set_custom_scale_f32(None)
+        return
+    key = "s" + hashlib.sha1(expr.encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_scale_")
+        src, so = os.path.join(d, "scale.c"), os.path.join(d, f"scale_{key}.so")
+        with open(src, "w") as f:
+            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
+                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+                    f"double amo_user_scale(double x) {{ return ({expr}); }}\n"
+                    f"float amo_user_scale_f32(float x) {{ return (float)({expr}); }}\n")
+        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    lib.amo_set_custom_scale(C.cast(_custom_libs[key].amo_user_scale, C.c_void_p))
+    lib.amo_set_custom_scale_f32(C.cast(_custom_libs[key].amo_user_scale_f32, C.c_void_p))
+
+
 def _potential_id(potential) -> int:
     expr = getattr(potential, "expr", None)
     if expr is not None:
@@ -238,9 +265,10 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64"):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None):
         self.lib = load()
         self.dtype = dtype
+        install_custom_scale(scale_expr)            # process-global like the potential: one simulation at a time
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
@@ -342,12 +370,13 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None, reward_expr=None, dtype="f64"):
+                 stream=None, reward_expr=None, dtype="f64", scale_expr=None):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
         self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
-                             weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype)
+                             weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype,
+                             scale_expr=scale_expr)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 
