@@ -66,7 +66,7 @@ mutable struct HIPMetropolis{P} <: Arianna.AriannaAlgorithm
     K::Int
 end
 
-function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing,
+function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing, scale=nothing,
                        chain_offset=0, n_chains_global=length(chains), per_chain_counters=true, extras...)
     pools = [deepcopy(pool) for _ in chains]                       # metropolis.jl:289
     sigma = Float64[move.parameters.σ for move in pool]
@@ -81,7 +81,14 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
                         Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL,
                         Int32(eltype_of_state(chains) === Float32 ? 1 : 0), Int32(0))
-        if reward isa AbstractString
+        if scale isa AbstractString
+            # a policy whose width depends on the state: delta ~ Normal(0, sigma * scale(system.x)); the expression is the
+            # C restatement of what the script's sample_action! / log_proposal_density do with `system`
+            pot = potential isa AbstractString ? potential : C_NULL
+            rew = reward isa AbstractString ? reward : C_NULL
+            check(ccall((:amc_create_policy_model, libamc), Cint, (Ref{AmcConfig}, Cstring, Cstring, Cstring, Ref{Ptr{Cvoid}}),
+                        cfg, pot, rew, scale, handle))
+        elseif reward isa AbstractString
             # script-defined reward(action, system) (particle_1d.jl:42-44) as an expression in delta and the new x
             pot = potential isa AbstractString ? potential : C_NULL
             check(ccall((:amc_create_model, libamc), Cint, (Ref{AmcConfig}, Cstring, Cstring, Ref{Ptr{Cvoid}}),
