@@ -9,7 +9,8 @@ constructing ``Metropolis`` raises.
 from ._capi import AmcError, HipEngine, SplitEngine, device_count
 from .metropolis import Metropolis, callback_acceptance, callback_energy, callback_moments
 from .policy_guided import (ANPG, BLANPG, BLAPG, BLPG, NPG, VPG, GradientData, PolicyGradientEstimator,
-                            PolicyGradientUpdate, Static, average, initialise_gradient_data, learning_step)
+                            PolicyGradientUpdate, Static, average, initialise_gradient_data, learning_step,
+                            log_proposal_density, withgrad_log_proposal_density)
 from .sharding import allreduce_sum, shard_range
 from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
                          build_schedule, julia_repr, run)
@@ -23,6 +24,7 @@ __all__ = [
     "Metropolis", "callback_acceptance", "callback_energy", "callback_moments",
     "ANPG", "BLANPG", "BLAPG", "BLPG", "NPG", "VPG", "Static", "GradientData", "PolicyGradientEstimator",
     "PolicyGradientUpdate", "average", "initialise_gradient_data", "learning_step",
+    "log_proposal_density", "withgrad_log_proposal_density",
     "allreduce_sum", "shard_range",
     "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
     "build_schedule", "julia_repr", "run",

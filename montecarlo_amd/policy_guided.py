@@ -97,6 +97,34 @@ def optimiser_code(opt: PolicyGradient):
     raise TypeError(f"No learning_step! is defined for {type(opt).__name__}")
 
 
+def _sigma_of(parameters) -> float:
+    if isinstance(parameters, dict):
+        return float(parameters["sigma"])
+    return float(np.atleast_1d(np.asarray(parameters, dtype=np.float64))[0])
+
+
+def log_proposal_density(action, policy, parameters, system=None, device: int = 0) -> float:
+    """log_proposal_density(action, policy, parameters, system) for the particle_1d model (particle_1d.jl:52-54),
+    evaluated ON THE DEVICE by the estimator's own code (amc_selftest_math, fn 9): there is no host arithmetic for the
+    path in this package.  StandardGaussian only (a ScaledGaussian's density needs the system's position)."""
+    if type(policy).__name__ != "StandardGaussian":
+        raise NotImplementedError("No log_proposal_density is defined for this policy on the host side")      # metropolis.jl:62
+    from . import _capi
+    return float(_capi.selftest_math("log_proposal_density", [float(action.delta)], [_sigma_of(parameters)], device)[0])
+
+
+def withgrad_log_proposal_density(grad_out, action, policy, parameters, system=None, device: int = 0) -> float:
+    """withgrad_log_proposal_density!(∇logq, action, policy, parameters, system, backend) (gradients.jl:28-33): returns
+    logq and writes d logq / d sigma into grad_out[0] -- the value ForwardDiff / Zygote / Enzyme all produce
+    (test/ad_backends_test.jl:31-32), computed by the device code the estimator kernel runs."""
+    if type(policy).__name__ != "StandardGaussian":
+        raise NotImplementedError("No log_proposal_density is defined for this policy on the host side")
+    from . import _capi
+    d, s = [float(action.delta)], [_sigma_of(parameters)]
+    grad_out[0] = float(_capi.selftest_math("grad_log_proposal_density", d, s, device)[0])
+    return float(_capi.selftest_math("log_proposal_density", d, s, device)[0])
+
+
 def initialise_gradient_data(parameters: np.ndarray) -> GradientData:            # gradients.jl:54-61
     z = np.zeros_like(np.asarray(parameters, dtype=np.float64))
     return GradientData(0.0, z.copy(), z.copy(), np.outer(z, z), 0)

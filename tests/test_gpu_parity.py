@@ -79,6 +79,23 @@ def test_log_proposal_density_and_gradient_known_answers(gpu, oracle):
     assert np.allclose(gotg, delta ** 2 / sig ** 3 - 1 / sig, rtol=1e-10, atol=1e-12)
 
 
+def test_ad_backends_test_of_the_reference(gpu):
+    """test/ad_backends_test.jl, line for line on this package's names: the value and the sigma-gradient of
+    log_proposal_density for action = Displacement(0.0), parameters = (sigma = 0.2) -- there the three AD backends must
+    agree to 1e-10; here the device's closed form must agree with the value they agree on."""
+    import montecarlo_amd as ma
+    action = ma.Displacement(0.0)
+    policy = ma.StandardGaussian()
+    parameters = {"sigma": 0.2}
+    grad = np.zeros(1)
+    logq = ma.withgrad_log_proposal_density(grad, action, policy, parameters)
+    assert logq == pytest.approx(0.6904993792294276, abs=1e-10)
+    assert grad[0] == pytest.approx(-5.0, abs=1e-10)
+    assert ma.log_proposal_density(action, policy, parameters) == logq
+    with pytest.raises(NotImplementedError, match="No log_proposal_density is defined"):
+        ma.log_proposal_density(action, ma.ScaledGaussian("1.0 + x*x"), parameters)
+
+
 def test_reciprocal_correction_division_is_ieee(gpu):
     """The sweep kernel divides by den = 2 sigma^2 with a precomputed reciprocal and two Markstein
     corrections (amc_kernels.h div_by_const); it must equal the IEEE quotient for every input."""
