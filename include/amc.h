@@ -152,8 +152,8 @@ int  amc_create_model(const amc_config *cfg, const char *potential_expr, const c
  *     log_proposal_density = -(delta)^2 / (2 (sigma_k scale(x))^2) - log(2 pi (sigma_k scale(x))^2) / 2
  * with the forward density evaluated at the old state and the backward density at the new one, as mc_step! does
  * (metropolis.jl:178,182): the proposal ratio no longer cancels and enters the acceptance.  scale_expr NULL: scale = 1,
- * the reference's StandardGaussian (amc_create_model).  The policy-gradient estimator entries refuse such a handle
- * (AMC_ERR_STATE): their closed-form gradient is the StandardGaussian's. */
+ * the reference's StandardGaussian (amc_create_model).  The policy-gradient estimator then takes the forward density
+ * and its sigma-derivative at the old state and the backward ones at the new state (gradients.jl:97,102,106). */
 int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
                              const char *scale_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */

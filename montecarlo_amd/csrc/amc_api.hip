@@ -1369,9 +1369,6 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false)
 {
-    if (h->scaled_policy)
-        return fail(AMC_ERR_STATE, "%s: the policy-gradient estimator is written for the StandardGaussian policy; this handle "
-                                   "was created with a state-dependent proposal width (amc_create_policy_model)", who);
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
     if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)

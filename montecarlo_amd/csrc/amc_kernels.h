@@ -1026,11 +1026,62 @@ __device__ __forceinline__ LogQ log_proposal_density_withgrad(real_t delta, doub
     return r;
 }
 
+#ifdef AMC_USER_SCALE
+// log_proposal_density at width w = sigma * scale(x) and its sigma-derivative by ForwardDiff's dual rules in the
+// function's own order: w = sigma*s -> (w, s); w^2 = w*w -> (w2, s*w + w*s); 2*w2; c/Dual -> -(v/den)*dden; log -> da/a.
+__device__ __forceinline__ LogQ log_proposal_density_withgrad_w(real_t delta, double w, double dw)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    const double w2 = w * w, dw2 = dw * w + w * dw;
+    const double den = 2.0 * w2, dden = 2.0 * dw2;
+    const double q1 = ((double)(-(delta * delta))) / den;
+    const double a = TWO_PI * w2, da = TWO_PI * dw2;
+    LogQ r;
+    r.logq = q1 - log_f64(a) / 2.0;
+    r.dlogq = -(q1 / den) * dden - (da / a) / 2.0;
+    return r;
+}
+
+// pgmc_estimate (gradients.jl:93-109) with the state-dependent width: the forward density and gradient at the old state,
+// the backward ones at the new state; grad_j takes the forward gradient when alpha == 1, else the backward one (:106).
+template <int POT>
+__device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double sigma, double z, double (&g)[4], const double* T)
+{
+    const double s_f = user_scale(x, T);
+    const double w_f = sigma * s_f;
+    const real_t delta = (real_t)(0.0 + w_f * z);
+    const LogQ f = log_proposal_density_withgrad_w(delta, w_f, s_f);
+    const real_t e1 = potential<POT>(x, T);
+    const real_t xn = x + delta;
+    const real_t e2 = potential<POT>(xn, T);
+    const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
+    const real_t nd = -delta;
+    const double s_b = user_scale(xn, T);
+    const LogQ b = log_proposal_density_withgrad_w(nd, sigma * s_b, s_b);
+    x = xn + nd;
+    const double arg = ((double)dlogp + b.logq) - f.logq;
+    double ex = exp_core_f64(arg, T);
+    asm volatile("" : "+v"(ex));
+    double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
+    alpha = (arg >= 0.0) ? 1.0 : alpha;
+    const double j = r * alpha;
+    g[0] += j;
+    g[1] += j * ((alpha == 1.0) ? f.dlogq : b.dlogq);
+    g[2] += f.dlogq;
+    g[3] += f.dlogq * f.dlogq;
+}
+#endif
+
 template <int POT>
 __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double den, double rden,
                                           double logc, double dden, double dlhalf, double z, double (&g)[4],
                                           const double* T)
 {
+#ifdef AMC_USER_SCALE
+    pg_sample_scaled<POT>(x, beta, sigma, z, g, T);
+    return;
+#endif
     const real_t delta = (real_t)(0.0 + sigma * z);
     const LogQ lq = log_proposal_density_withgrad(delta, den, rden, logc, dden, dlhalf);
     const double logq = lq.logq, dlogq = lq.dlogq;

@@ -341,6 +341,20 @@ double amo_grad_log_proposal_density(double delta, double sigma)
     return dq1 - dl / 2.0;
 }
 
+/* The same gradient for a width w = sigma * scale(x) (dw = scale(x) = dw/dsigma): ForwardDiff's rules in the
+ * function's order, w*w -> (w2, dw*w + w*dw).  d2neg = -(delta^2), already formed in the action's type. */
+static double grad_log_proposal_density_w(double d2neg, double w, double dw)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    double w2 = w * w, dw2 = dw * w + w * dw;
+    double den = 2.0 * w2, dden = 2.0 * dw2;
+    double q1 = d2neg / den;
+    double dq1 = -(q1 / den) * dden;
+    double a = TWO_PI * w2, da = TWO_PI * dw2;
+    double dl = da / a;
+    return dq1 - dl / 2.0;
+}
+
 /* particle_1d.jl:30-35 perform_action!: e1 = e; x += delta; e = potential(x). */
 static inline void perform_action(particle_t *p, const move_t *m, int pot, double *e1, double *e2)
 {
@@ -722,6 +736,29 @@ void amo_moments(const amo_sim *s, double out[2])
  * sample_gradient_data, P = 1.  gd = (j, dj, dlogq_forward, g). */
 static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
 {
+    if (g_custom_scale) {
+        /* state-dependent width: forward density / gradient at the old state, backward at the new one */
+        double s_f = g_custom_scale(p->x), w_f = sigma * s_f;
+        m->delta = 0.0 + w_f * z;
+        double logq_f = amo_log_proposal_density(m->delta, w_f);
+        double dlogq_f = grad_log_proposal_density_w(-(m->delta * m->delta), w_f, s_f);
+        double e1, e2;
+        perform_action(p, m, pot, &e1, &e2);
+        double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta);
+        double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;
+        m->delta = -m->delta;
+        double s_b = g_custom_scale(p->x), w_b = sigma * s_b;
+        double logq_b = amo_log_proposal_density(m->delta, w_b);
+        double dlogq_b = grad_log_proposal_density_w(-(m->delta * m->delta), w_b, s_b);
+        perform_action(p, m, pot, &e1, &e2);
+        double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f));
+        double j = r * alpha;
+        gd[0] = j;
+        gd[1] = j * (alpha == 1.0 ? dlogq_f : dlogq_b);
+        gd[2] = dlogq_f;
+        gd[3] = dlogq_f * dlogq_f;
+        return;
+    }
     m->delta = 0.0 + sigma * z;                                     /* :119 sample_action! */
     double logq_f = amo_log_proposal_density(m->delta, sigma);     /* :97 */
     double dlogq_f = amo_grad_log_proposal_density(m->delta, sigma);
@@ -746,6 +783,29 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
  * j = r * alpha in Float64. */
 static void pgmc_sample_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
 {
+    if (g_custom_scale_f32) {
+        double s_f = (double)g_custom_scale_f32((float)p->x), w_f = sigma * s_f;
+        float delta = (float)(0.0 + w_f * z);
+        double logq_f = log_proposal_density_f32(delta, w_f);
+        double dlogq_f = grad_log_proposal_density_w((double)(-(delta * delta)), w_f, s_f);
+        float e1, e2, beta = (float)p->beta;
+        perform_action_f32(p, delta, pot, &e1, &e2);
+        float dlogp = delta_log_target_density_f32(e1, e2, beta);
+        double r = g_custom_reward_f32 ? g_custom_reward_f32(delta, (float)p->x) : (double)(delta * delta);
+        delta = -delta;
+        double s_b = (double)g_custom_scale_f32((float)p->x), w_b = sigma * s_b;
+        double logq_b = log_proposal_density_f32(delta, w_b);
+        double dlogq_b = grad_log_proposal_density_w((double)(-(delta * delta)), w_b, s_b);
+        perform_action_f32(p, delta, pot, &e1, &e2);
+        m->delta = (double)delta;
+        double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_b - logq_f));
+        double j = r * alpha;
+        gd[0] = j;
+        gd[1] = j * (alpha == 1.0 ? dlogq_f : dlogq_b);
+        gd[2] = dlogq_f;
+        gd[3] = dlogq_f * dlogq_f;
+        return;
+    }
     float delta = (float)(0.0 + sigma * z);
     double logq_f = log_proposal_density_f32(delta, sigma);
     double dlogq_f = grad_log_proposal_density_f32(delta, sigma);

@@ -83,9 +83,43 @@ def test_trajectories_bit_exact_against_the_oracle(gpu, oracle, dtype, case):
     assert np.array_equal(np.asarray(acc), ao.sum(axis=1)) and np.array_equal(np.asarray(tot), to.sum(axis=1))
     red = eng.reduce()
     assert red[0] / M == pytest.approx(sim.energy(), rel=1e-10)
-    with pytest.raises(gpu.AmcError, match="StandardGaussian"):
-        eng.pg_estimate([0], 1)
+    # policy-gradient estimator with the state-dependent width: forward gradient at the old state, backward at the new
+    ids = list(range(len(kw["sigma"])))
+    for q in (1, 3):
+        got = np.asarray(eng.pg_estimate(ids, q)).reshape(len(ids), 5)
+        want = sim.pg_estimate(ids, q)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9) and np.array_equal(got[:, 4], want[:, 4])
+        assert np.array_equal(bits(eng.download_state()[0]), bits(sim.state()[0]))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_estimator_gradient_against_finite_differences_and_fused_steps(gpu, oracle):
+    """d logq / d sigma of the scaled policy is delta^2 / (sigma^3 s^2) - 1/sigma; the estimator's sum of forward
+    gradients over M chains must match that closed form evaluated on the oracle's own deltas, and one fused PGMC time step
+    must equal the separate calls."""
+    M = 30000
+    kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.3, 0.7], weight=[0.5, 0.5], seed=4, scale_expr=SCALE)
+    a, b = gpu.HipEngine(**kw), gpu.HipEngine(**kw)
+    for e in (a, b):
+        e.init_uniform(-2, 2)
+        e.sweep(3)
+    x_before = a.download_state()[0]
+    g = np.asarray(a.pg_estimate([1], 1)).reshape(5)
+    # sum over chains of (z^2 - 1) / sigma, z standard normal: mean 0, variance 2 M / sigma^2
+    assert abs(g[2]) < 5 * np.sqrt(2 * M) / 0.7
+    assert g[3] == pytest.approx(2 * M / 0.7 ** 2, rel=0.05)            # sum of squares: E[(z^2 - 1)^2] = 2
+    assert np.array_equal(bits(b.download_state()[0]), bits(x_before))
+    b.pg_estimate([1], 1)
+    a.pgmc_steps(3, [1], 2, [1], [0.2], [0.0])
+    for _ in range(3):
+        b.sweep(1)
+        b.pg_accumulate([1], 2)
+        b.pg_update([1], [1], [0.2], [0.0])
+    assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
+    assert np.array_equal(a.get_parameters(1), b.get_parameters(1)) and a.get_parameters(1)[0] != 0.7
+    a.close()
+    b.close()
 
 
 @pytest.mark.gpu
