@@ -141,3 +141,30 @@ def test_target_distribution_at_scale(gpu):
         assert s[2] / s[3] == pytest.approx(want_x2, abs=2e-3)
         assert s[0] / s[3] == pytest.approx(want_u, abs=2e-3)
         e.close()
+
+
+@pytest.mark.gpu
+def test_pgmc_learns_the_prefactor_of_a_scaled_policy_through_the_host_mirror(gpu, tmp_path):
+    """The PGMC driver script's algorithm list (PGMC_harmonic_oscillator.jl:24-33) with a ScaledGaussian pool: the learnable
+    move's sigma grows from 0.1 towards the step size that maximises E[delta^2 alpha], the static one stays, and the
+    sampled distribution stays the target's."""
+    M, steps = 100_000, 600
+    chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
+    pool = (ma.Move(ma.Displacement(0.0), ma.ScaledGaussian(SCALE), {"sigma": 0.2}, 0.6),
+            ma.Move(ma.Displacement(0.0), ma.ScaledGaussian(SCALE), {"sigma": 0.1}, 0.4))
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.5)),
+               q_batch_size=1),
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
+               scheduler=ma.build_schedule(steps, 100, 50)),
+          dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=ma.build_schedule(steps, 0, 100)))
+    sim = ma.Simulation(chains, al, steps, path=str(tmp_path))
+    ma.run(sim)
+    assert pool[0].sigma == 0.2
+    assert 0.5 < pool[1].sigma < 3.0                      # moved well away from 0.1, towards an O(1) width
+    energies = np.loadtxt(tmp_path / "energy.dat")[1:, 1]
+    assert energies[-3:].mean() == pytest.approx(0.25, abs=5e-3)
+    rows = open(tmp_path / "parameters" / "2" / "parameters.dat").read().splitlines()
+    sig = [float(r.split("[")[1].strip("]")) for r in rows]
+    assert sig[0] == 0.1 and sig[-1] == pool[1].sigma and sig[1] > 0.1                    # first row is the t = 0 value
