@@ -66,7 +66,9 @@ typedef enum amc_potential {
  * normal variate, log_proposal_density, the acceptance probability and the uniforms stay Float64.  The state then crosses
  * HBM as 4 + 4 bytes per update; the kernels are the same sources, compiled at run time (hiprtc) on first use.  Host
  * buffers of this ABI stay `double` whatever the state type: uploads are rounded to Float32 (round to nearest even),
- * downloads are exact. */
+ * downloads are exact.  Script-defined expressions then see x (and delta) as `float`: arithmetic against double literals
+ * promotes as in Julia (2.0*x is Float64), overloaded calls take their float form (sqrt(x), fabs(x), fma(x, x, c) are
+ * Float32 operations, as Julia's would be), and the value is converted to Float32 where the model stores it. */
 typedef enum amc_state_dtype {
     AMC_DTYPE_F64 = 0,
     AMC_DTYPE_F32 = 1

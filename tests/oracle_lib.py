@@ -174,6 +174,11 @@ def learning_step(opt: str, h0: float, h1: float, theta: float, gd4) -> float:
 
 
 _custom_libs = {}
+# The expressions are compiled as C++ like the kernels' (hiprtc): with Float32 state an overloaded call such as sqrt(x) or
+# fabs(x) then takes its float form on both sides -- Julia's sqrt(x::Float32) is Float32 too; C would promote to double.
+_CUSTOM_PROLOGUE = ("#include <cmath>\nusing std::sqrt; using std::fabs; using std::fma;\n"
+                    "extern \"C\" {\ndouble amo_exp(double); double amo_log(double);\n"
+                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n")
 
 
 def install_custom_potential(expr: str) -> None:
@@ -186,15 +191,14 @@ def install_custom_potential(expr: str) -> None:
     key = hashlib.sha1(expr.encode()).hexdigest()[:16]
     if key not in _custom_libs:
         d = tempfile.mkdtemp(prefix="amo_pot_")
-        src, so = os.path.join(d, "pot.c"), os.path.join(d, f"pot_{key}.so")
+        src, so = os.path.join(d, "pot.cpp"), os.path.join(d, f"pot_{key}.so")
         with open(src, "w") as f:
-            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
-                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+            f.write(_CUSTOM_PROLOGUE +
                     f"double amo_user_potential(double x) {{ return ({expr}); }}\n"
                     # Float32 state: the same text with x::Float32 (C's usual arithmetic conversions promote against
                     # double literals like Julia's do); the value is converted to Float32 on return (Particle.e::T)
-                    f"float amo_user_potential_f32(float x) {{ return (float)({expr}); }}\n")
-        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                    f"float amo_user_potential_f32(float x) {{ return (float)({expr}); }}\n}}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     fn = C.cast(_custom_libs[key].amo_user_potential, C.c_void_p)
@@ -215,13 +219,12 @@ def install_custom_reward(expr: Optional[str]) -> None:
     key = "r" + hashlib.sha1(expr.encode()).hexdigest()[:16]
     if key not in _custom_libs:
         d = tempfile.mkdtemp(prefix="amo_rew_")
-        src, so = os.path.join(d, "rew.c"), os.path.join(d, f"rew_{key}.so")
+        src, so = os.path.join(d, "rew.cpp"), os.path.join(d, f"rew_{key}.so")
         with open(src, "w") as f:
-            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
-                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+            f.write(_CUSTOM_PROLOGUE +
                     f"double amo_user_reward(double delta, double x) {{ return ({expr}); }}\n"
-                    f"double amo_user_reward_f32(float delta, float x) {{ return (double)({expr}); }}\n")
-        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                    f"double amo_user_reward_f32(float delta, float x) {{ return (double)({expr}); }}\n}}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     lib.amo_set_custom_reward(C.cast(_custom_libs[key].amo_user_reward, C.c_void_p))
@@ -240,13 +243,12 @@ def install_custom_scale(expr: Optional[str]) -> None:
     key = "s" + hashlib.sha1(expr.encode()).hexdigest()[:16]
     if key not in _custom_libs:
         d = tempfile.mkdtemp(prefix="amo_scale_")
-        src, so = os.path.join(d, "scale.c"), os.path.join(d, f"scale_{key}.so")
+        src, so = os.path.join(d, "scale.cpp"), os.path.join(d, f"scale_{key}.so")
         with open(src, "w") as f:
-            f.write("#include <math.h>\ndouble amo_exp(double); double amo_log(double);\n"
-                    "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n"
+            f.write(_CUSTOM_PROLOGUE +
                     f"double amo_user_scale(double x) {{ return ({expr}); }}\n"
-                    f"float amo_user_scale_f32(float x) {{ return (float)({expr}); }}\n")
-        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                    f"float amo_user_scale_f32(float x) {{ return (float)({expr}); }}\n}}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     lib.amo_set_custom_scale(C.cast(_custom_libs[key].amo_user_scale, C.c_void_p))

@@ -141,6 +141,24 @@ def test_custom_potential_promotes_like_julia(gpu, oracle):
     eng.close()
 
 
+def test_overloaded_math_takes_its_float32_form(gpu, oracle):
+    """sqrt(x), fabs(x), fma(x, x, c) with x::Float32 are Float32 operations in the kernels (C++ overloads), as they
+    would be in Julia; amc_log takes and returns Float64.  The oracle compiles the same text as C++."""
+    from montecarlo_amd import CustomPotential
+    M = 8001
+    pot = CustomPotential("sqrt(fabs(x) + 1.0f) * x * x + fma(x, x, 0.125f) - amc_log(1.0 + x*x)")
+    eng, sim = make_pair(gpu, oracle, M, potential=pot, beta=1.2, sigma=[0.6], weight=[1.0])
+    eng.init_uniform(-2, 2)
+    sim.init_uniform(-2, 2)
+    for n in (1, 12):
+        eng.sweep(n)
+        sim.make_steps(n)
+    x, e = eng.download_state()
+    xo, eo = sim.state()
+    assert np.array_equal(bits(x), bits(xo)) and np.array_equal(bits(e), bits(eo))
+    eng.close()
+
+
 @pytest.mark.parametrize("potential", ["harmonic", "double_well"])
 def test_policy_gradient_estimator(gpu, oracle, potential):
     M = 20000
