@@ -127,6 +127,31 @@ def test_slice_of_full_size_run_matches_oracle(gpu, oracle):
     e.close()
 
 
+def test_ensemble_beyond_2_to_the_32_chains(gpu, oracle):
+    """Maximum sizes: 2^32 + 2^20 + 1 chains on one device (34 GB of state out of 288) -- chain and pair indices pass
+    2^31 and 2^32, the last chain is a lone one.  Slices at the start, across the 2^32 boundary and at the very end must
+    equal the oracle's runs of the same global chains, bit for bit; the callback sums stay consistent."""
+    M = (1 << 32) + (1 << 20) + 1
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.3], weight=[1.0], seed=77)
+    e = gpu.HipEngine(n_chains=M, per_chain_counters=False, **kw)
+    e.init_uniform(-2, 2)
+    for n in (1, 1, 6):                      # single-step launches and a fused one
+        e.sweep(n)
+    for off, cnt in ((0, 1024), ((1 << 32) - 512, 1024), (M - 1025, 1025)):
+        assert off % 2 == 0
+        o = oracle.OracleSim(cnt, chain_offset=off, **kw)
+        o.init_uniform(-2, 2)
+        o.make_steps(8, threads=4)
+        assert np.array_equal(bits(e.download_strided(off, 1, cnt)), bits(o.state()[0]))
+    red = e.reduce()
+    assert red[3] == float(M)
+    assert red[0] / M == pytest.approx(red[2] / M, rel=1e-12)                   # harmonic: e = x^2
+    assert 0.2 < red[0] / M < 1.4 and 0.5 < red[4] / M < 1.0                    # far from equilibrium after 8 sweeps, but sane
+    acc, tot = e.counter_totals()
+    assert int(tot[0]) == 8 * M and int(acc[0]) == int(round(red[4] * 8))
+    e.close()
+
+
 # ---- the host driver on the device -------------------------------------------------------------------------------
 def _run_config1(engine_factory, path, steps=3000):
     chains = ma.ParticleChains.uniform(10, 2.0, -2.0, 2.0)
