@@ -109,13 +109,17 @@ class _PerChainFiles(AriannaAlgorithm):
         start, _ = self.metropolis.shard
         beta = self.chains.beta_array
         tname = "Float32" if dtype == "f32" else "Float64"
+
+        def show(v):          # `show` of a field inside the struct: Float32 literals carry their f0 / f-5 suffix
+            r = _repr_state(v, dtype)
+            return r if dtype != "f32" or "f" in r or r.endswith("32") else r + "f0"
+
         rows = []
         for i in sel:
             b = self.chains.beta if beta is None else beta[start + i]
             if dtype == "f32":
                 b = float(np.float32(b))
-            rows.append(f"{t}, Particle{{{tname}}}({_repr_state(xs[i], dtype)}, {_repr_state(b, dtype)}, "
-                        f"{_repr_state(es[i], dtype)})\n")
+            rows.append(f"{t}, Particle{{{tname}}}({show(xs[i])}, {show(b)}, {show(es[i])})\n")
         return rows
 
 

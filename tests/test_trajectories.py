@@ -70,6 +70,19 @@ def test_txt_format_prints_the_struct(oracle, tmp_path):
     assert x == chains.x[1] and beta == 2.0 and e == chains.e[1]
 
 
+def test_txt_format_float32_fields_print_as_literals(oracle, tmp_path):
+    chains = ma.ParticleChains.uniform(2, 2.0, -2.0, 2.0, dtype="f32")
+    pool = [ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), [0.1], 1.0)]
+    sim = ma.Simulation(chains, [dict(algorithm=ma.Metropolis, pool=pool, seed=1, engine_factory=oracle.OracleEngine),
+                                 dict(algorithm=ma.StoreLastFrames, fmt=ma.TXT(), scheduler=[3])], 3, path=str(tmp_path))
+    ma.run(sim)
+    row = open(tmp_path / "trajectories" / "1" / "lastframe.txt").read().strip()
+    assert row.startswith("3, Particle{Float32}(") and ", 2.0f0, " in row              # show(2.0f0) inside a struct
+    fields = row[row.index("(") + 1:-1].split(", ")
+    assert all("f" in f for f in fields)
+    assert float(np.float32(fields[0].replace("f0", "").replace("f", "e"))) == chains.x[0]
+
+
 def test_large_ensembles_need_an_explicit_selection(oracle, tmp_path):
     sim, _ = build(oracle, 5000, 2, tmp_path, [dict(algorithm=ma.StoreTrajectories, scheduler=[1, 2])])
     with pytest.raises(ValueError, match="one file each"):
