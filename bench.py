@@ -110,6 +110,14 @@ def cpu_baseline(budget_s: float = 10.0):
     }
 
 
+def pmc_valu_busy():
+    """VALUBusy of the sweep kernel from the same committed PMC passes (which wall was hit)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("sweep_kernel_valu_busy")
+    except Exception:
+        return None
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -239,7 +247,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "valu_busy": pmc_valu_busy(),
                 "kernel": "amc::sweep_kernel<harmonic, K=1, pool-wide counter>",
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * (stop - start),
                 "avg_launch_us": launch_s * 1e6,

@@ -36,6 +36,7 @@ def check_line(d, n_gpus, cb_every):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 16 * M
+    assert rf["valu_busy"] is None or 0.3 < rf["valu_busy"] < 1.0      # from the committed PMC passes (profiles/)
     # value = chains x steps / wall; the event-timed launches cannot take longer than the wall clock around them
     assert abs(d["value"] - M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
     assert rf["avg_launch_us"] <= d["ms_per_step"] * 1e3 * 1.05

@@ -38,7 +38,14 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     summary["_traffic"] = {"fetch_bytes_corrected_x2": 2 * fetch_kb * 1024, "write_bytes": write_kb * 1024,
                            "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 16 * 10_000_000,
                            "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled"}
-    json.dump({"sweep_kernel_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_summary.json"},
+    extra = {}
+    if "SQ_ACTIVE_INST_VALU" in summary and "GRBM_GUI_ACTIVE" in summary:
+        # rocprof's VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE; rocprofv3 reports GRBM_GUI_ACTIVE summed over
+        # the 8 XCDs (MI355X_MICROARCH.md, DVFS note), so the per-XCD busy cycles are 1/8 of it.  256 CUs x 4 SIMDs.
+        busy = summary["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / (summary["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
+        summary["_valu_busy"] = {"frac": busy, "formula": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)"}
+        extra["sweep_kernel_valu_busy"] = busy
+    json.dump({"sweep_kernel_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_summary.json", **extra},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
