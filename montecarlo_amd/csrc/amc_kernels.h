@@ -500,6 +500,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
     unsigned long long wave_acc = 0;   // wave-uniform
+    // REDUCE with the pool-wide counter: the row's last column is the accepted total this block can see -- its own slot
+    // (plus the slots beyond this launch's grid, filled by launches with a larger one).  Launches are ordered on the
+    // stream and only block b touches slot b inside a launch, so the old values are read HERE, under the first load,
+    // instead of by a returning atomic at the very end of the block.
+    unsigned long long slots_before = 0;
+    if (REDUCE && !LOG && !MULTI && threadIdx.x == 0)
+        for (int sl = (int)blockIdx.x; sl < a.n_slots; sl += (int)gridDim.x) slots_before += a.acc_total[sl];
 
     // Memory schedule.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` at the top of a loop that carries a
     // prefetched load across its back edge while stores are pending: vmcnt counts loads and stores together
@@ -597,11 +604,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (REDUCE && !LOG) {
                 // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
                 // value after this launch (exact in a double below 2^53); the rows are summed by the host
-                unsigned long long now =
-                    __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
-                // slots beyond this launch's grid were filled by launches with a larger one (nobody writes them now)
-                for (int sl = (int)blockIdx.x + (int)gridDim.x; sl < a.n_slots; sl += (int)gridDim.x) now += a.acc_total[sl];
-                a.red_partials[(int64_t)blockIdx.x * a.red_stride + 4] = (double)now;
+                if (t != 0) __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.red_partials[(int64_t)blockIdx.x * a.red_stride + 4] = (double)(slots_before + t);
             } else if (t != 0) {
                 // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
                 __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
