@@ -720,12 +720,14 @@ def test_randomised_configurations_against_the_oracle(gpu, oracle):
             e.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("K,counters", [(1, False), (2, True)])
-def test_split_engine_equals_single_engine(gpu, K, counters):
+def test_split_engine_equals_single_engine(gpu, K, counters, dtype):
     """SplitEngine: the shard as sub-shards on separate streams (their launches overlap).  Per-chain results are those
     of one engine bit for bit (global chain ids); reductions and gradient sums agree to rounding."""
     sigma, weight = POOLS[K]
-    kw = dict(n_chains=100_003, potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=8, per_chain_counters=counters)
+    kw = dict(n_chains=100_003, potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=8, per_chain_counters=counters,
+              dtype=dtype)
     one = gpu.HipEngine(**kw)
     parts = gpu.SplitEngine(n_parts=3, **kw)
     assert [p.n_chains for p in parts.parts] == [33334, 33334, 33335] and sum(p.n_chains for p in parts.parts) == 100_003
