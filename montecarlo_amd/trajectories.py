@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 
@@ -56,10 +56,14 @@ def _repr_state(v: float, dtype: str) -> str:
 
 class _PerChainFiles(AriannaAlgorithm):
     def __init__(self, chains, path=None, fmt=None, max_chains: int = 4096,
-                 select: Optional[Tuple[int, int, int]] = None, **extras):
+                 select: Optional[Tuple[int, int, int]] = None,
+                 row: Optional[Callable[[int, float, float, float], str]] = None, **extras):
         if path is None:
             raise ValueError(f"{type(self).__name__} needs path=")
         self.fmt = fmt if fmt is not None else DAT()
+        # store_trajectory(io, system, t, fmt) is the method a model overrides (src/algorithms.jl:182-189;
+        # particle_1d.jl:63-66 does): `row(t, x, beta, e)` returns the line (without the newline) for one chain
+        self.row = row
         self.chains = chains
         self.root = os.path.join(path, "trajectories")
         self.select = select
@@ -100,6 +104,13 @@ class _PerChainFiles(AriannaAlgorithm):
         eng = self.metropolis.engine
         dtype = getattr(self.chains, "dtype", "f64")
         t = simulation.t
+        if self.row is not None:
+            xs, es = eng.download_state(want_e=True)
+            start, _ = self.metropolis.shard
+            beta = self.chains.beta_array
+            sel = self.local_first + self.local_stride * np.arange(self.local_count)
+            return [self.row(t, float(xs[i]), float(self.chains.beta if beta is None else beta[start + i]), float(es[i])) + "\n"
+                    for i in sel]
         if isinstance(self.fmt, DAT):
             x = eng.download_strided(self.local_first, self.local_stride, self.local_count)
             return [f"{t} {_repr_state(v, dtype)}\n" for v in x]

@@ -83,6 +83,16 @@ def test_txt_format_float32_fields_print_as_literals(oracle, tmp_path):
     assert float(np.float32(fields[0].replace("f0", "").replace("f", "e"))) == chains.x[0]
 
 
+def test_a_model_can_define_its_own_row(oracle, tmp_path):
+    """The reference's models override store_trajectory (particle_1d.jl:63-66 does); here that is `row=`."""
+    sim, chains = build(oracle, 4, 6, tmp_path, [dict(algorithm=ma.StoreTrajectories, scheduler=[2, 4, 6], store_first=False,
+                                                      row=lambda t, x, beta, e: f"{t};{x!r};{e!r};{beta}")])
+    ma.run(sim)
+    rows = open(tmp_path / "trajectories" / "3" / "trajectory.dat").read().splitlines()
+    assert [r.split(";")[0] for r in rows] == ["2", "4", "6"] and rows[-1].endswith(";2.0")
+    assert float(rows[-1].split(";")[1]) == chains.x[2] and float(rows[-1].split(";")[2]) == chains.e[2]
+
+
 def test_large_ensembles_need_an_explicit_selection(oracle, tmp_path):
     sim, _ = build(oracle, 5000, 2, tmp_path, [dict(algorithm=ma.StoreTrajectories, scheduler=[1, 2])])
     with pytest.raises(ValueError, match="one file each"):
