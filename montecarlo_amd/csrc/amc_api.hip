@@ -258,6 +258,7 @@ int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int
 {
     if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1>(h, a, sw, grid);
     if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2>(h, a, sw, grid);
+    if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3>(h, a, sw, grid);
     switch (nl_cap) {
     case 1: return launch_pg_nls<POT, 1, 0>(h, a, sw, grid);
     case 2: return launch_pg_nls<POT, 2, 0>(h, a, sw, grid);
@@ -1409,8 +1410,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     if (grid > h->red_blocks) grid = h->red_blocks;
     int sweep = 0;
     if (with_sweep) {
-        if (h->log_fill == h->log_depth) { const int rcf = fold_log(h); if (rcf != AMC_OK) return rcf; }
-        sweep = h->K > 1 ? 2 : 1;
+        if (h->d_log && h->log_fill == h->log_depth) { const int rcf = fold_log(h); if (rcf != AMC_OK) return rcf; }
+        sweep = h->K > 1 ? 2 : (h->d_log ? 1 : 3);
     }
     amc::SweepArgs sw = make_sweep_args(h, 1);
     const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep)
@@ -1420,7 +1421,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     if (with_sweep) {
         h->t += 1;
         h->t_counted += 1;
-        h->log_fill += 1;
+        if (h->d_log) h->log_fill += 1;
     }
     // the launch itself left sum_{blocks} partials[grid][nl][4] in d_out[nl*4] (in-kernel final reduction)
     h->t_est += 1;
@@ -1529,9 +1530,9 @@ int amc_pgmc_steps(amc_handle* h, int64_t n_steps, int n_learn, const int* learn
     }
     // the three make_step!s of one time step (src/simulation.jl:185-190), n_steps times, from one host call: two
     // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
-    // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, per-chain counters
-    // (step log), at most two learnable moves (the kernel forms offered with a leading sweep)
-    const bool fused = h->sweepstep == 1 && h->d_log != nullptr && n_learn >= 1 && n_learn <= 2 &&
+    // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
+    // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
+    const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);

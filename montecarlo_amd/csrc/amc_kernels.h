@@ -1131,7 +1131,7 @@ __device__ __forceinline__ double ordered_column_sum(const double* rows, int n_r
 
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
 // SWEEP != 0: the launch first performs ONE make_step!(::Metropolis) of sweepstep = 1 on the pair it has just loaded
-// (1: K == 1, 2: K > 1; per-chain counters through the step log in both) -- run! calls the two algorithms back to
+// (1: K == 1, 2: K > 1, per-chain counters through the step log in both; 3: K == 1 with the pool-wide counter only) -- run! calls the two algorithms back to
 // back at the same t (src/simulation.jl:185-190), and x then makes one HBM round trip for both instead of two.
 // Per chain the operations and their order are those of the two separate launches.
 // (96-104 VGPRs: 4-5 waves per SIMD.  Capping the registers for 6-8 waves spills and is slower: 104 -> 111 / 155 /
@@ -1160,9 +1160,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     // one mc_step! of the pair (mc_sweep! with mc_steps = 1), its step-log byte pair stored right away
     auto mh = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, int64_t p, bool v0, bool v1) {
         uint32_t lw = 0;
-        pair_steps<POT, SWEEP == 2, true, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_math, sw_sigma1, sw_den1,
-                                                sw_rden1, sw_logc1, wave_acc, lw);
-        if (v0) store_log_pair(sw, sw.log_pos, p, lw);
+        // SWEEP == 3: K == 1 with the pool-wide counter only -- no step log
+        pair_steps<POT, SWEEP == 2, SWEEP != 3, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_math, sw_sigma1, sw_den1,
+                                                      sw_rden1, sw_logc1, wave_acc, lw);
+        if (SWEEP != 3 && v0) store_log_pair(sw, sw.log_pos, p, lw);
     };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
@@ -1234,7 +1235,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
         }
     }
-    if (SWEEP == 1) add_block_accepts(sw.acc_total, wave_acc);   // K == 1: the pool-wide accepted total (counter_totals)
+    if (SWEEP == 1 || SWEEP == 3) add_block_accepts(sw.acc_total, wave_acc);   // K == 1: the pool-wide accepted total (counter_totals)
     // Block partial sums -> row blockIdx.x of partials[grid][NL][4].  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
     // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /

@@ -575,7 +575,7 @@ def test_fused_sweep_and_callback_reduction(gpu, oracle, M, n, counters, K):
 
 
 @pytest.mark.parametrize("do_update", [False, True])
-@pytest.mark.parametrize("case", ["k3", "k1", "k2_beta", "k5_wide", "custom"])
+@pytest.mark.parametrize("case", ["k3", "k1", "k1_pooled", "k2_beta", "k5_wide", "custom"])
 def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update, case):
     """amc_pgmc_steps(n) == n x [amc_sweep(1); amc_pg_accumulate; amc_pg_update] bit for bit
     (src/simulation.jl:185-190 runs the three algorithms back to back at every t).  With per-chain counters and at most
@@ -586,9 +586,11 @@ def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update, case):
     kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1, 0.3], weight=[0.5, 0.25, 0.25], seed=19)
     ids, kinds, h0, h1 = [1, 2], [1, 4], [0.5, 0.01], [0.0, 1e-6]            # VPG(0.5), NPG(0.01, 1e-6)
     beta = None
-    if case == "k1":
+    if case in ("k1", "k1_pooled"):
         kw.update(sigma=[0.15], weight=[1.0])
         ids, kinds, h0, h1 = [0], [2], [0.3], [0.0]                          # BLPG(0.3)
+        if case == "k1_pooled":                                              # pool-wide counter only: no step log to ride on
+            kw.update(per_chain_counters=False)
     elif case == "k2_beta":
         kw.update(sigma=[0.2, 0.4], weight=[0.5, 0.5], potential="double_well")
         ids, kinds, h0, h1 = [1], [1], [0.2], [0.0]
@@ -620,10 +622,12 @@ def test_pgmc_steps_one_call_equals_separate_calls(gpu, do_update, case):
         assert a.get_parameters(k)[0] == b.get_parameters(k)[0]
     if do_update:
         assert a.get_parameters(ids[0])[0] != kw["sigma"][ids[0]]
-    acc_a, tot_a = a.download_counters()
-    acc_b, tot_b = b.download_counters()
-    assert np.array_equal(acc_a, acc_b) and np.array_equal(tot_a, tot_b)
+    if case != "k1_pooled":
+        acc_a, tot_a = a.download_counters()
+        acc_b, tot_b = b.download_counters()
+        assert np.array_equal(acc_a, acc_b) and np.array_equal(tot_a, tot_b)
     assert np.array_equal(a.counter_totals()[0], b.counter_totals()[0])
+    assert np.array_equal(a.counter_totals()[1], b.counter_totals()[1])
     assert a.step == b.step == 2 + n and a.estimator_step == b.estimator_step == n
     np.testing.assert_allclose(a.reduce(), b.reduce(), rtol=1e-13, equal_nan=True)
     a.close(); b.close()
