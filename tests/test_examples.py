@@ -45,3 +45,15 @@ def test_pgmc_harmonic_oscillator_example(gpu, tmp_path, capsys):
     assert pool[0].sigma == 0.2 and pool[1].sigma == pytest.approx(1.2, abs=0.2)          # pgmc_test.jl:45,50
     rows = open(tmp_path / "pgmc" / "parameters" / "2" / "parameters.dat").read().splitlines()
     assert rows[0] == "0 [0.1]" and rows[-1].startswith("1500 [")
+
+
+def test_mc_example_with_float32_state(gpu, tmp_path, capsys):
+    """`--dtype f32`: Particle{Float32} through the same driver script (summary, trajectory rows in Float32 digits)."""
+    import mc_harmonic_oscillator as ex
+    sim = ex.main(["--chains", "5000", "--steps", "1500", "--dtype", "f32", "--path", str(tmp_path / "mc32")])
+    capsys.readouterr()
+    assert "Particle{Float32} x 5000" in open(tmp_path / "mc32" / "summary.log").read()
+    assert sim.algorithms[2].std == pytest.approx(0.5, abs=1e-2)
+    rows = [ln.split() for ln in open(tmp_path / "mc32" / "trajectories" / "1" / "trajectory.dat")]
+    assert all(float(np.float32(float(r[1]))) == pytest.approx(float(r[1]), rel=1e-7) and len(r[1]) <= 14 for r in rows)
+    assert float(np.float32(float(rows[-1][1]))) == sim.chains.x[0]
