@@ -10,11 +10,17 @@ HBM round trip, so bytes/update is well defined.  Workload = BAS
 particle_1d harmonic, beta = 2, one Gaussian displacement sigma = 0.1, M = 1e7 chains per GPU, f64,
 synthetic ensemble x0 ~ U(-2, 2) generated on device (inputs resident in HBM before the timed region).
 For N > 1 (configs[3]) the ensemble is N x 1e7 chains sharded by global chain id (weak scaling) and
-the energy/acceptance callbacks are all-reduced over RCCL every 10 sweeps inside the timed region.
+the energy/acceptance callbacks are all-reduced over RCCL every 10 sweeps inside the timed region -- by the engines' own
+communicator (amc_comm_init / amc_allreduce_sum on the engine's stream); the launcher's TCP store carries the
+ncclUniqueId, the barriers and the max over ranks.  No torch process group, no torch tensors.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      algorithmic HBM bytes (16 B/update: read x + write x) / average launch duration measured
-                with HIP events on the engine's stream over the timed region, vs 8 TB/s.
+                with HIP events on the engine's stream over the timed region, vs 8 TB/s; `regime` says which memory
+                level serves the state at this size, `ladder` repeats the measurement at 4e7 and 1.6e8 chains
+                (state >> the 256 MiB Infinity Cache); `traffic` / `valu_busy` come from committed rocprofv3 PMC passes
+                and carry their source, commit and whether the kernel sources changed since.
+  repeat        the K-step block repeated (untimed by `value`): min / median ms per step.
   cpu_baseline  the CPU oracle (C restatement of the reference path, kind "port": the reference is Julia,
                 not runnable here) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -110,21 +116,64 @@ def cpu_baseline(budget_s: float = 10.0):
     }
 
 
-def pmc_valu_busy():
-    """VALUBusy of the sweep kernel from the same committed PMC passes (which wall was hit)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("sweep_kernel_valu_busy")
-    except Exception:
-        return None
+def kernel_source_hash():
+    """Hash of the kernel sources: tells whether a committed PMC figure was taken on the kernels being timed now."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("amc_kernels.h", "amc_math.h", "amc_tables.h"):
+        h.update(open(os.path.join(ROOT, "montecarlo_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def pmc_profile():
+    """HBM bytes per launch and VALUBusy of the headline kernel from the committed rocprofv3 PMC passes (profiles/):
+    bench.py cannot collect counters itself (they need the profiler around the process), so these are STATIC figures
+    and say so: source file, the commit they were taken at, and whether the kernel sources have changed since."""
     try:
-        return json.load(open(p)).get("sweep_kernel_bytes_per_launch")
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return None
+    now = kernel_source_hash()
+    return {"traffic": d.get("sweep_kernel_bytes_per_launch"), "valu_busy": d.get("sweep_kernel_valu_busy"),
+            "source": d.get("source"), "commit": d.get("commit"), "kernel_source_hash": d.get("kernel_source_hash"),
+            "kernel_sources_unchanged_since": d.get("kernel_source_hash") == now}
+
+
+def regime_of(m_chains):
+    state_mb = 8 * m_chains / 1e6
+    return ("infinity-cache resident: %.0f MB of state < 256 MiB MALL (a launch re-reads what the previous one wrote)" % state_mb
+            if 2 * state_mb < 256 * 1.048576 else
+            "HBM: %.0f MB of state >> 256 MiB MALL" % state_mb)
+
+
+def ladder(A, sizes, device, reps=5):
+    """The same single-sweep launch at larger ensembles (HIP events; min over `reps` blocks): the fraction of the HBM
+    roofline where the state no longer fits the Infinity Cache."""
+    rows = []
+    for m in sizes:
+        try:
+            e = A.HipEngine(n_chains=m, potential="harmonic", beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1,
+                            per_chain_counters=False, device=device)
+        except A.AmcError as err:
+            rows.append({"chains": m, "error": str(err)[:120]})
+            continue
+        e.init_uniform(-2.0, 2.0)
+        n = max(10, min(200, int(2_000_000_000 // m)))
+        for _ in range(n):
+            e.sweep(1)
+        e.sync()
+        ts = []
+        for _ in range(reps):
+            e.timing_begin()
+            for _ in range(n):
+                e.sweep(1)
+            ts.append(e.timing_end() * 1e3 / n)
+        e.close()
+        us = min(ts)
+        rows.append({"chains": m, "launches_per_block": n, "us_per_launch_min": us, "us_per_launch_median": sorted(ts)[len(ts) // 2],
+                     "achieved_GBps": BYTES_PER_UPDATE * m / us / 1e3, "frac": BYTES_PER_UPDATE * m / us / 1e3 / HBM_PEAK_GBS,
+                     "regime": regime_of(m)})
+    return rows
 
 
 def main():
@@ -137,6 +186,8 @@ def main():
                          "~0.1-0.5 s of load to reach its sustained clock (65 -> 56 us/sweep measured)")
     ap.add_argument("--chains-per-gpu", type=int, default=M_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step block for min / median (not part of value)")
+    ap.add_argument("--no-ladder", action="store_true", help="skip the 4e7 / 1.6e8-chain launches behind roofline.ladder")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: RCCL / the HIP runtime may print banners to fd 1 (e.g. RCCL's version block at
@@ -148,23 +199,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
     force_dist = os.environ.get("AMC_BENCH_FORCE_DIST") == "1"      # exercise the N > 1 code path on one GPU
+    from montecarlo_amd import sharding
+    grp = None
     if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # The first collective builds the communicator (tens to hundreds of ms with the GPU idle).  Do it HERE: if it
-        # happened in the barrier in front of the timed region, the steps would start on a clock that has fallen back
-        # (measured on one rank: 31.1 instead of 29.6 us per sweep over 2000 steps).
-        dist.barrier()
-        torch.cuda.synchronize()
+        if "MASTER_PORT" not in os.environ:                          # forced on one rank, started by hand
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        grp = sharding.init_store_group(rank, world)                 # the launcher's store: before any GPU call
+        grp.barrier()
 
     from montecarlo_amd import _capi as A
-    from montecarlo_amd import sharding
 
     m_local = args.chains_per_gpu
     m_global = m_local * world
@@ -173,7 +225,14 @@ def main():
                       beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1, per_chain_counters=False,
                       device=local_rank)
     eng.init_uniform(-2.0, 2.0)
-    cb_every = CALLBACK_EVERY_MULTI if (world > 1 or force_dist) else 0
+    if grp is not None:
+        # the shards' RCCL communicator (ncclUniqueId over the store), built HERE and used once: the first collective
+        # costs tens to hundreds of ms with the GPU idle; inside the barrier in front of the timed region it would start
+        # the steps on a clock that has fallen back (measured on one rank: 31.1 instead of 29.6 us per sweep)
+        assert sharding.connect_engine(eng)
+        eng.allreduce_sum([0.0])
+        grp.barrier()
+    cb_every = CALLBACK_EVERY_MULTI if grp is not None else 0
     if os.environ.get("AMC_BENCH_CB_EVERY"):                 # developer knob: separate the cost of the callbacks from the process group's
         cb_every = int(os.environ["AMC_BENCH_CB_EVERY"])
 
@@ -183,7 +242,7 @@ def main():
         """all-reduce the callback sums enqueued one period ago (the host never drains the sweep queue)."""
         if pending[0]:
             pending[0] = False
-            return sharding.allreduce_sum(eng.reduce_end())   # callback_energy + callback_acceptance, ONE all-reduce
+            return sharding.allreduce_sum(eng.reduce_end(), eng)   # callback_energy + callback_acceptance, ONE ncclAllReduce
         return None
 
     def step(i):
@@ -195,11 +254,9 @@ def main():
             eng.sweep(1)
 
     def barrier():
-        eng.sync()
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+        eng.sync()                           # everything this rank has queued is done (all work is on the engine's stream)
+        if grp is not None:
+            grp.barrier()
 
     t_spin = time.perf_counter()                 # clock ramp (untimed), then the W warm-up steps
     while time.perf_counter() - t_spin < args.spinup_s:
@@ -218,17 +275,33 @@ def main():
     event_ms = eng.timing_end()            # HIP events on the engine's stream, bracketing exactly the K launches
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, event_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, event_ms = float(t[0]), float(t[1])
+    if grp is not None:
+        both = grp.allgather((elapsed, event_ms))              # max over ranks
+        elapsed, event_ms = max(b[0] for b in both), max(b[1] for b in both)
 
-    red = sharding.allreduce_sum(eng.reduce())
+    # the same K-step block, repeated (not part of `value`): a 20-step driver run is 0.7 ms of timed region, and one slow
+    # launch moves it by 5 %
+    rep_ms = []
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        r0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        finish_callback()
+        barrier()
+        rep_ms.append((time.perf_counter() - r0) * 1e3 / args.steps)
+    if grp is not None and rep_ms:
+        rep_ms = [max(col) for col in zip(*grp.allgather(rep_ms))]
+
+    red = sharding.allreduce_sum(eng.reduce(), eng)
     n = red[3]
     energy, acceptance = red[0] / n, red[4] / n
 
+    ladder_rows = None
+    if rank == 0 and world == 1 and not args.no_ladder and args.chains_per_gpu == M_PER_GPU:
+        ladder_rows = ladder(A, (4 * M_PER_GPU, 16 * M_PER_GPU), local_rank)
     if rank == 0:
+        prof = pmc_profile()
         updates = m_global * args.steps
         launch_s = event_ms * 1e-3 / args.steps
         achieved = BYTES_PER_UPDATE * (stop - start) / launch_s / 1e9
@@ -251,15 +324,27 @@ def main():
                 "chains_per_gpu": m_local, "chains_total": m_global, "sweepstep": 1,
                 "callbacks_allreduce_every": cb_every,
                 "sharding": "contiguous global chain ids per rank; no data-path collective",
+                "multi_gpu_note": "N > 1: callbacks all-reduced by the engines' own RCCL communicator (amc_allreduce_sum), unique id "
+                                  "and barriers over the launcher's TCP store; measured on hardware only by the driver's SCALE runs",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(), "valu_busy": pmc_valu_busy(),
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (prof or {}).get("traffic"), "valu_busy": (prof or {}).get("valu_busy"),
+                "traffic_provenance": None if prof is None else {
+                    "measured_in_this_run": False, "source": prof["source"], "commit": prof["commit"],
+                    "kernel_sources_unchanged_since": prof["kernel_sources_unchanged_since"],
+                    "note": "rocprofv3 PMC passes need the profiler around the process: static figures from the committed profile"},
                 "kernel": "amc::sweep_kernel<harmonic, K=1, pool-wide counter>",
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * (stop - start),
                 "avg_launch_us": launch_s * 1e6,
+                "regime": regime_of(stop - start),
+                "ladder": ladder_rows,
                 "note": "f64 VALU-bound in practice (Philox + Box-Muller + exp per update), see DESIGN.md §6",
             },
+            "repeat": None if not rep_ms else {
+                "blocks": len(rep_ms), "steps_per_block": args.steps, "ms_per_step_min": min(rep_ms),
+                "ms_per_step_median": sorted(rep_ms)[len(rep_ms) // 2], "ms_per_step_all": rep_ms},
             "check": {"mean_energy": energy, "acceptance": acceptance},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -267,8 +352,8 @@ def main():
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if grp is not None:
+        grp.barrier()
 
 
 if __name__ == "__main__":

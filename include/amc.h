@@ -246,6 +246,10 @@ int  amc_pg_accumulate(amc_handle *h, int n_learn, const int *learn_ids, int q_b
 int  amc_pg_update(amc_handle *h, int n_learn, const int *learn_ids, const int *optimiser,
                    const double *hyper0, const double *hyper1);
 int  amc_pg_get_accumulated(amc_handle *h, int n_learn, const int *learn_ids, double *out);
+/* Resume: replace the running sums of the moves learn_ids[] by in[n_learn*AMC_GD_STRIDE] (what amc_pg_get_accumulated
+ * returned when the run was checkpointed) -- gradients_data of estimator.jl:84 is part of the state whenever
+ * PolicyGradientUpdate is scheduled less often than the estimator. */
+int  amc_pg_set_accumulated(amc_handle *h, int n_learn, const int *learn_ids, const double *in);
 /* n_steps x [ make_step!(::Metropolis); make_step!(::PolicyGradientEstimator); make_step!(::PolicyGradientUpdate)
  * if do_update ] -- the three algorithms run! calls back to back at one time step (src/simulation.jl:185-190,
  * PGMC_harmonic_oscillator.jl:24-33) -- enqueued by ONE host call: amc_sweep(h, 1), amc_pg_accumulate, amc_pg_update

@@ -9,7 +9,8 @@
 #   callback_energy                      example/particle_1d/particle_1d.jl:68-70
 #   PolicyGradientEstimator / Update     src/PolicyGuided/estimator.jl:103-134, update.jl:43-57
 # Every ccall below names the C entry point and its argument types exactly as include/amc.h
-# declares them.
+# declares them; tests/test_julia_binding_static.py parses this file and checks the AmcConfig field
+# list and every ccall signature against the header (names, order, widths, argument counts).
 module AriannaHIP
 
 using Arianna
@@ -52,33 +53,78 @@ function check(rc::Cint)
 end
 
 """
-    HIPMetropolis(chains; pool, sweepstep=1, seed=1, device=0, potential=:harmonic | :double_well | "C expression in x", ...)
+    LazyPools(pool, M)
+
+`Metropolis.pools` (src/metropolis.jl:233) without M deep copies.  The reference deep-copies the pool once per chain
+(:289) and then makes every chain's `policy` / `parameters` refer to the objects of `pools[1]` (:252-260); what differs
+between chains is `action` (scratch) and the two counters.  Here ONE copy of the pool (`template`) holds the shared
+policy / parameters objects, the per-chain counters live in two M x K matrices filled by `finalise` (or
+`refresh_counters!`), and `pools[c]` materialises chain c's pool on demand: same `parameters` OBJECT for every c, so an
+in-place `learning_step!` on `pools[1][k].parameters` is seen through every `pools[c]`, as in the reference.  Dependants
+that only read `pools[1]` (StoreParameters, src/metropolis.jl:423) get the template itself.
+"""
+struct LazyPools{P} <: AbstractVector{P}
+    template::P
+    n_chains::Int
+    accepted::Matrix{Int64}       # (M, K) after finalise / refresh_counters!; (0, K) before
+    total::Matrix{Int64}
+end
+
+Base.size(p::LazyPools) = (p.n_chains,)
+Base.IndexStyle(::Type{<:LazyPools}) = IndexLinear()
+
+function Base.getindex(p::LazyPools, c::Int)
+    @boundscheck checkbounds(p, c)
+    c == 1 && size(p.accepted, 1) == 0 && return p.template
+    pool = map(enumerate(p.template)) do (k, move)
+        m = Move(deepcopy(move.action), move.policy, move.parameters, move.weight)      # shared policy / parameters
+        if size(p.accepted, 1) == p.n_chains
+            m.accepted_calls = p.accepted[c, k]
+            m.total_calls = p.total[c, k]
+        end
+        m
+    end
+    return pool
+end
+
+"""
+    HIPMetropolis(chains; pool, sweepstep=1, seed=1, device=0, potential=:harmonic | :double_well | "C expression in x",
+                  chain_offset=0, n_chains_global=length(chains), rank=0, n_ranks=1, unique_id=nothing, ...)
 
 Drop-in for `Metropolis` (src/metropolis.jl:232-291) on one MI355X.  `chains` is the usual
 `Vector{Particle}`; the pool must hold `Displacement` moves with a `StandardGaussian` policy.
+Sharded runs (one process per GPU): `chains` is this rank's slice, `chain_offset` the global id of its first chain
+(even), `n_chains_global` the ensemble size, and `unique_id` the 128 bytes rank 0 obtained from `comm_unique_id()` and
+sent to the other ranks (MPI.jl / Distributed / a file): the callbacks and the estimator then sum over all shards.
 """
 mutable struct HIPMetropolis{P} <: Arianna.AriannaAlgorithm
     handle::Ptr{Cvoid}
-    pools::Vector{P}        # kept so dependants (StoreParameters, estimator) find `.pools`, `.seed`
+    pools::LazyPools{P}     # kept so dependants (StoreParameters, estimator) find `.pools`, `.seed`
     sweepstep::Int
     seed::Int
     n_chains::Int
     K::Int
+    n_ranks::Int
+    red_t::Int              # simulation.t the cached reduction belongs to (-1: none)
+    red::Vector{Float64}
 end
 
 function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing, scale=nothing,
-                       chain_offset=0, n_chains_global=length(chains), per_chain_counters=true, extras...)
-    pools = [deepcopy(pool) for _ in chains]                       # metropolis.jl:289
-    sigma = Float64[move.parameters.σ for move in pool]
-    weight = Float64[move.weight for move in pool]
-    # same checks as metropolis.jl:249-251 (identical parameters/weights across chains hold by construction)
+                       chain_offset=0, n_chains_global=length(chains), per_chain_counters=true,
+                       rank=0, n_ranks=1, unique_id=nothing, extras...)
+    template = deepcopy(pool)                                      # ONE copy (metropolis.jl:289 makes M), see LazyPools
+    K = length(template)
+    pools = LazyPools(template, length(chains), Matrix{Int64}(undef, 0, K), Matrix{Int64}(undef, 0, K))
+    sigma = Float64[move.parameters.σ for move in template]
+    weight = Float64[move.weight for move in template]
+    # the asserts of metropolis.jl:249-251 (identical parameters / weights across chains) hold by construction
     handle = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve sigma weight begin
         pot_id = potential isa AbstractString ? POTENTIAL_CUSTOM :
                  potential === :double_well ? POTENTIAL_DOUBLE_WELL : POTENTIAL_HARMONIC
         cfg = AmcConfig(UInt32(sizeof(AmcConfig)), Int32(device), length(chains), chain_offset, n_chains_global,
                         pot_id,
-                        Int32(length(pool)), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
+                        Int32(K), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL,
                         Int32(eltype_of_state(chains) === Float32 ? 1 : 0), Int32(0))
         if scale isa AbstractString
@@ -101,9 +147,27 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
             check(ccall((:amc_create, libamc), Cint, (Ref{AmcConfig}, Ref{Ptr{Cvoid}}), cfg, handle))
         end
     end
-    alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), length(pool))
+    alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), K, n_ranks, -1, Float64[])
     finalizer(a -> ccall((:amc_destroy, libamc), Cint, (Ptr{Cvoid},), a.handle), alg)
+    n_ranks > 1 && comm_init!(alg, rank, n_ranks, unique_id)
     return alg
+end
+
+# ncclUniqueId for the shards' communicator: call on rank 0, ship the 128 bytes to every rank
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:amc_comm_unique_id, libamc), Cint, (Ptr{Cvoid},), id))
+    return id
+end
+
+# RCCL communicator over the shards (one rank per GPU); without it amc_allreduce_sum is the identity
+function comm_init!(alg::HIPMetropolis, rank::Integer, n_ranks::Integer, unique_id)
+    unique_id isa AbstractVector{UInt8} && length(unique_id) == 128 ||
+        error("HIPMetropolis: n_ranks > 1 needs the 128-byte unique_id of comm_unique_id() (made on rank 0)")
+    id = Vector{UInt8}(unique_id)
+    check(ccall((:amc_comm_init, libamc), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), alg.handle, rank, n_ranks, id))
+    alg.n_ranks = n_ranks
+    return nothing
 end
 
 # initialise: upload chains[c].x (and per-chain beta)                         src/algorithms.jl:13
@@ -113,28 +177,38 @@ function initialise(alg::HIPMetropolis, simulation::Simulation)
     βptr = all(==(β[1]), β) ? Ptr{Float64}(C_NULL) : pointer(β)
     GC.@preserve x β check(ccall((:amc_upload_state, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                                  alg.handle, x, βptr))
+    alg.red_t = -1
     return nothing
 end
 
 # make_step!: one sweep of every chain                                        src/metropolis.jl:302-309
 function make_step!(::Simulation, alg::HIPMetropolis)
     check(ccall((:amc_sweep, libamc), Cint, (Ptr{Cvoid}, Int64), alg.handle, 1))
+    alg.red_t = -1
     return nothing
 end
 
-# finalise: chains[c].x / .e and pools[c][k] counters back into the reference's objects
-function finalise(alg::HIPMetropolis, simulation::Simulation)
+# pools[c][k].accepted_calls / total_calls of every chain, as two (M, K) matrices behind `alg.pools` (two bulk copies,
+# no per-move Julia objects)
+function refresh_counters!(alg::HIPMetropolis)
     M, K = alg.n_chains, alg.K
-    x = Vector{Float64}(undef, M); e = Vector{Float64}(undef, M)
-    check(ccall((:amc_download_state, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), alg.handle, x, e))
     acc = Matrix{Int64}(undef, M, K); tot = Matrix{Int64}(undef, M, K)       # move-major == column-major (M, K)
     check(ccall((:amc_download_counters, libamc), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), alg.handle, acc, tot))
-    for c in 1:M
-        simulation.chains[c].x = x[c]; simulation.chains[c].e = e[c]
-        for k in 1:K
-            alg.pools[c][k].accepted_calls = acc[c, k]; alg.pools[c][k].total_calls = tot[c, k]
-        end
+    alg.pools = LazyPools(alg.pools.template, M, acc, tot)
+    return nothing
+end
+
+# finalise: chains[c].x / .e back into the reference's objects (one pass over the M Particles, which the caller owns
+# anyway), the counters behind alg.pools
+function finalise(alg::HIPMetropolis, simulation::Simulation)
+    M = alg.n_chains
+    x = Vector{Float64}(undef, M); e = Vector{Float64}(undef, M)
+    check(ccall((:amc_download_state, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), alg.handle, x, e))
+    chains = simulation.chains
+    @inbounds for c in 1:M
+        chains[c].x = x[c]; chains[c].e = e[c]
     end
+    refresh_counters!(alg)
     return nothing
 end
 
@@ -143,21 +217,25 @@ function write_algorithm(io, alg::HIPMetropolis, scheduler)
     println(io, "\t\tCalls: $(length(filter(x -> 0 < x ≤ scheduler[end], scheduler)))")
     println(io, "\t\tMC steps per simulation step: $(alg.sweepstep)")
     println(io, "\t\tSeed: $(alg.seed)")
+    println(io, "\t\tShards: $(alg.n_ranks)")
 end
 
 hip_algorithm(simulation) = only(filter(a -> isa(a, HIPMetropolis), simulation.algorithms))
 
-# out = [Σe, Σx, Σx², count, Σ_c acc_ck/tot_ck ...]   (AMC_RED_* in amc.h)
-function reduce(alg::HIPMetropolis)
+# out = [Σe, Σx, Σx², count, Σ_c acc_ck/tot_ck ...]   (AMC_RED_* in amc.h), summed over the shards; ONE reduction and
+# ONE all-reduce per simulation.t however many callbacks read it (StoreCallbacks calls them back to back, algorithms.jl:97-102)
+function reduce(alg::HIPMetropolis, t::Int)
+    alg.red_t == t && return alg.red
     out = Vector{Float64}(undef, 4 + alg.K)
     check(ccall((:amc_reduce, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), alg.handle, out))
     check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.handle, out, length(out)))
+    alg.red_t = t; alg.red = out
     return out
 end
 
 # callbacks with the reference's names/values                                 particle_1d.jl:68-70, metropolis.jl:319-321
-callback_energy(simulation) = (r = reduce(hip_algorithm(simulation)); r[1] / r[4])
-callback_acceptance(simulation) = (r = reduce(hip_algorithm(simulation)); r[5:end] ./ r[4])
+callback_energy(simulation) = (r = reduce(hip_algorithm(simulation), simulation.t); r[1] / r[4])
+callback_acceptance(simulation) = (r = reduce(hip_algorithm(simulation), simulation.t); r[5:end] ./ r[4])
 
 """
     HIPPolicyGradientEstimator(chains; dependencies=(HIPMetropolis,), optimisers, q_batch_size=1)
@@ -168,11 +246,12 @@ gradients.jl:93-121 runs in the kernel, the `+` fold is its reduction (+ all-red
 `PolicyGradientUpdate`'s `learning_step!` (learning.jl) can be reused; after it, push sigma with
 `set_parameters!`.
 """
-mutable struct HIPPolicyGradientEstimator{O,VG} <: Arianna.AriannaAlgorithm
+mutable struct HIPPolicyGradientEstimator{O,VP,VG} <: Arianna.AriannaAlgorithm
     metropolis::HIPMetropolis
     optimisers::O
     learn_ids::Vector{Int}
     q_batch_size::Int
+    parameters_list::VP           # the shared Move.parameters objects (estimator.jl:74), aliased with metropolis.pools
     gradients_data::VG
     objectives::Vector{Float64}
 end
@@ -184,6 +263,7 @@ function make_step!(::Simulation, alg::HIPPolicyGradientEstimator)
     check(ccall((:amc_pg_estimate, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Ptr{Float64}),
                 alg.metropolis.handle, n, ids, alg.q_batch_size, out))
     check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.metropolis.handle, out, length(out)))
+    alg.metropolis.red_t = -1                                                 # every sample moves x to (x + δ) - δ
     for k in 1:n
         gd = PolicyGuided.GradientData(out[1, k], [out[2, k]], [out[3, k]], fill(out[4, k], 1, 1), Int(out[5, k]))
         alg.gradients_data[k] = alg.gradients_data[k] + gd                    # estimator.jl:130
@@ -205,9 +285,9 @@ function HIPPolicyGradientEstimator(chains; dependencies=missing, optimisers=mis
     metropolis = dependencies[1]
     @assert length(optimisers) == metropolis.K                                   # estimator.jl:70
     learn_ids = [k for k in eachindex(optimisers) if !isa(optimisers[k], PolicyGuided.Static)]   # :72
-    parameters_list = [move.parameters for move in metropolis.pools[1]]
+    parameters_list = [move.parameters for move in metropolis.pools.template]    # :74 -- the shared objects themselves
     gradients_data = map(k -> PolicyGuided.initialise_gradient_data(parameters_list[k]), learn_ids)   # :84
-    return HIPPolicyGradientEstimator(metropolis, optimisers, learn_ids, q_batch_size, gradients_data,
+    return HIPPolicyGradientEstimator(metropolis, optimisers, learn_ids, q_batch_size, parameters_list, gradients_data,
                                       zeros(Float64, length(learn_ids)))
 end
 
@@ -229,10 +309,10 @@ end
 
 function make_step!(::Simulation, alg::HIPPolicyGradientUpdate)
     est = alg.estimator
-    parameters_list = [move.parameters for move in est.metropolis.pools[1]]     # aliased across chains, metropolis.jl:252-260
+    parameters_list = est.parameters_list          # ONE object per move, seen through every pools[c] (metropolis.jl:252-260)
     for (k, lid) in enumerate(est.learn_ids)
         gd = PolicyGuided.average(est.gradients_data[k])                         # update.jl:52
-        PolicyGuided.learning_step!(parameters_list[lid], gd, est.optimisers[lid])   # :53
+        PolicyGuided.learning_step!(parameters_list[lid], gd, est.optimisers[lid])   # :53, in place
         est.gradients_data[k] = PolicyGuided.initialise_gradient_data(parameters_list[lid])   # :54
         set_parameters!(est.metropolis, lid, parameters_list[lid])
     end
@@ -240,13 +320,42 @@ function make_step!(::Simulation, alg::HIPPolicyGradientUpdate)
 end
 
 # Device-resident alternative for long PGMC runs: n x [sweep; estimator; update] from ONE ccall (amc_pgmc_steps):
-# gradients_data and the learning step stay on the GPU.  optimiser ids / hyper-parameters as in amc.h (amc_optimiser).
+# gradients_data and the learning step stay on the GPU (all-reduced over the shards when comm_init! was called).
+# optimiser ids / hyper-parameters as in amc.h (amc_optimiser).  pull_parameters! afterwards refreshes the host objects.
 function pgmc_steps!(metropolis::HIPMetropolis, n::Integer, learn_ids::Vector{Int}, q_batch::Integer,
                      optimiser::Vector{Cint}, hyper0::Vector{Float64}, hyper1::Vector{Float64})
     ids = Cint[k - 1 for k in learn_ids]
     check(ccall((:amc_pgmc_steps, libamc), Cint,
                 (Ptr{Cvoid}, Int64, Cint, Ptr{Cint}, Cint, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
                 metropolis.handle, n, length(ids), ids, q_batch, 1, optimiser, hyper0, hyper1))
+    metropolis.red_t = -1
+    return nothing
+end
+
+# sigma_k of the device copy back into the shared Move.parameters objects (after pgmc_steps!)
+function pull_parameters!(metropolis::HIPMetropolis)
+    p = Vector{Float64}(undef, 1)
+    for (k, move) in enumerate(metropolis.pools.template)
+        check(ccall((:amc_get_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), metropolis.handle, k - 1, p, 1))
+        move.parameters.σ = p[1]
+    end
+    return nothing
+end
+
+# running (j, ∇j, ∇logq, g, n) of the device-resident estimator, 5 x n_learn; and its counterpart for a resume
+function pg_get_accumulated(metropolis::HIPMetropolis, learn_ids::Vector{Int})
+    ids = Cint[k - 1 for k in learn_ids]
+    out = Matrix{Float64}(undef, 5, length(ids))
+    check(ccall((:amc_pg_get_accumulated, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Float64}),
+                metropolis.handle, length(ids), ids, out))
+    return out
+end
+
+function pg_set_accumulated!(metropolis::HIPMetropolis, learn_ids::Vector{Int}, rows::Matrix{Float64})
+    ids = Cint[k - 1 for k in learn_ids]
+    @assert size(rows) == (5, length(ids))
+    check(ccall((:amc_pg_set_accumulated, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Float64}),
+                metropolis.handle, length(ids), ids, rows))
     return nothing
 end
 

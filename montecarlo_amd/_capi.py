@@ -105,6 +105,7 @@ def load() -> C.CDLL:
         "amc_pg_accumulate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int]),
         "amc_pg_update": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]),
         "amc_pg_get_accumulated": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), dp]),
+        "amc_pg_set_accumulated": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), dp]),
         "amc_pgmc_steps": (C.c_int, [H, C.c_int64, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int),
                                      dp, dp]),
         "amc_sync": (C.c_int, [H]),
@@ -369,6 +370,13 @@ class HipEngine:
         out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
         _check(self._lib.amc_pg_get_accumulated(self._h, n, ids, _dptr(out)))
         return out
+
+    def pg_set_accumulated(self, learn_ids: Sequence[int], rows: np.ndarray) -> None:
+        """Resume: replace the device-resident gradients_data of the moves learn_ids by rows[n][5] (j, grad_j, grad_logq, g, n)."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        a = np.ascontiguousarray(rows, dtype=np.float64).reshape(n, AMC_GD_STRIDE)
+        _check(self._lib.amc_pg_set_accumulated(self._h, n, ids, _dptr(a)))
 
     def sync(self) -> None:
         _check(self._lib.amc_sync(self._h))

@@ -96,7 +96,8 @@ struct amc_handle {
     double* h_ratio = nullptr;       // pinned [n_slots][RATIO_STRIDE]: acceptance-ratio partials of a fold (K <= 4)
     int red_ratio_rows = 0;          // rows of h_ratio that belong to the reduction in flight (0: none)
     double* d_out = nullptr;
-    double* h_out = nullptr;    // pinned
+    double* h_out = nullptr;    // pinned: result of a wide (K > 4) reduction between amc_reduce_begin and _end
+    double* h_pg_out = nullptr; // pinned: result of amc_pg_estimate (its own buffer: a reduction may be in flight in h_out)
     int red_blocks = 0;
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
@@ -110,6 +111,9 @@ struct amc_handle {
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
     double* d_pg_groups = nullptr;      // [groups][AMC_MAX_LEARN * 4]
+    amc::PgTail* d_pg_tail = nullptr;   // the estimator kernel's per-configuration record (see amc::PgTail)
+    amc::PgTail pg_tail_host;           // ... and what it holds now (rewritten only when it changes)
+    bool pg_tail_valid = false;
     Rccl rccl;
     bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
@@ -691,6 +695,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMalloc(&h->d_partials2, (size_t)32 * (4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
     AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
     AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double), 0));
+    AMC_TRY(hipHostMalloc((void**)&h->h_pg_out, (size_t)AMC_MAX_LEARN * 4 * sizeof(double), 0));
     AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * 5 * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
@@ -700,6 +705,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         AMC_TRY(hipMalloc(&h->d_pg_tickets, (groups + 1) * sizeof(uint32_t)));
         AMC_TRY(hipMemsetAsync(h->d_pg_tickets, 0, (groups + 1) * sizeof(uint32_t), h->stream));
         AMC_TRY(hipMalloc(&h->d_pg_groups, groups * AMC_MAX_LEARN * 4 * sizeof(double)));
+        AMC_TRY(hipMalloc(&h->d_pg_tail, sizeof(amc::PgTail)));
     }
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
@@ -794,6 +800,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_pg_tickets);
     (void)hipFree(h->d_pg_groups);
+    (void)hipFree(h->d_pg_tail);
     (void)hipFree(h->d_x);
     (void)hipFree(h->d_x64);
     (void)hipFree(h->d_beta);
@@ -809,6 +816,7 @@ int amc_destroy(amc_handle* h)
     if (h->h_ratio) (void)hipHostFree(h->h_ratio);
     (void)hipFree(h->d_out);
     if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_pg_out) (void)hipHostFree(h->h_pg_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_red) (void)hipEventDestroy(h->ev_red);
@@ -1395,16 +1403,28 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.key1 = (uint32_t)(h->seed >> 32);
     a.beta = h->beta;
     a.tail_mode = tail;
-    a.n_moves = h->K;
-    a.tickets = h->d_pg_tickets;
-    a.group_sums = h->d_pg_groups;
-    a.out = h->d_out;
-    a.gd_acc = h->d_gd_acc;
-    a.ptab_rw = h->d_ptab;
-    a.status = h->d_status;
-    a.n_samples = (double)h->M * (double)q_batch;
-    if (opt) a.opt = *opt;
-    else for (int l = 0; l < AMC_MAX_LEARN; ++l) { a.opt.kind[l] = 0; a.opt.h0[l] = 0.0; a.opt.h1[l] = 0.0; }
+    {
+        amc::PgTail tl;
+        std::memset(&tl, 0, sizeof(tl));          // padding included: the record is compared bytewise below
+        tl.tickets = h->d_pg_tickets;
+        tl.group_sums = h->d_pg_groups;
+        tl.out = h->d_out;
+        tl.gd_acc = h->d_gd_acc;
+        tl.ptab_rw = h->d_ptab;
+        tl.status = h->d_status;
+        tl.n_samples = (double)h->M * (double)q_batch;
+        tl.n_moves = h->K;
+        for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
+        if (opt) tl.opt = *opt;
+        if (!h->pg_tail_valid || std::memcmp(&tl, &h->pg_tail_host, sizeof(tl)) != 0) {
+            // stream-ordered: launches already queued read the old record; hipMemcpyAsync from pageable memory has
+            // taken its copy of `tl` when it returns
+            AMC_HIP(hipMemcpyAsync(h->d_pg_tail, &tl, sizeof(tl), hipMemcpyHostToDevice, h->stream));
+            h->pg_tail_host = tl;
+            h->pg_tail_valid = true;
+        }
+        a.tail = h->d_pg_tail;
+    }
     const int nl = nl_capacity(n_learn);
     int grid = grid_for(h, (h->M + 1) / 2);
     if (grid > h->red_blocks) grid = h->red_blocks;
@@ -1435,10 +1455,10 @@ int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batc
     int nl = 0;
     const int rc = pg_launch(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &nl);
     if (rc != AMC_OK || n_learn == 0) return rc;
-    AMC_HIP(hipMemcpyAsync(h->h_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipMemcpyAsync(h->h_pg_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
     for (int l = 0; l < n_learn; ++l) {
-        for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_out[l * 4 + i];
+        for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_pg_out[l * 4 + i];
         out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
     }
     return AMC_OK;
@@ -1558,6 +1578,23 @@ int amc_pg_get_accumulated(amc_handle* h, int n_learn, const int* learn_ids, dou
     }
     if (status != 0)
         return fail(AMC_ERR_STATE, "a learning step produced a sigma outside [1e-100, 1e100] (or NaN) and was not applied");
+    return AMC_OK;
+}
+
+int amc_pg_set_accumulated(amc_handle* h, int n_learn, const int* learn_ids, const double* in)
+{
+    if (!h || (n_learn > 0 && (!learn_ids || !in))) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: NULL argument");
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    for (int l = 0; l < n_learn; ++l) {
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: learn_ids[%d] out of range", l);
+        const double n = in[l * AMC_GD_STRIDE + AMC_GD_N];
+        if (!(n >= 0.0) || n != std::floor(n)) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: n of move %d is not a sample count", learn_ids[l]);
+    }
+    AMC_HIP(hipSetDevice(h->device));
+    for (int l = 0; l < n_learn; ++l)
+        AMC_HIP(hipMemcpyAsync(h->d_gd_acc + (size_t)learn_ids[l] * 5, in + (size_t)l * AMC_GD_STRIDE, 5 * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));      // the caller's buffer is only valid during the call
     return AMC_OK;
 }
 

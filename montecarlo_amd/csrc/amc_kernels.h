@@ -41,7 +41,7 @@ typedef double2 real2;
 
 // Rows of the per-move parameter table.
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
-       PT_RDEN = 7, PT_ROWS = 8 };
+       PT_RDEN = 7, PT_C3HI = 8, PT_C3LO = 9, PT_ROWS = 10 };
 
 // a / b, correctly rounded, for a divisor b whose reciprocal y = RN(1/b) is precomputed
 // (b = 2 sigma^2 is one value per move).  Two Markstein corrections: q1 is a faithful rounding of
@@ -739,6 +739,16 @@ __device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
         const double av = TWO_PI * s2;
         ptab[PT_LOGC * AMC_MAX_MOVES + k] = log_f64(av) / 2.0;
         ptab[PT_DLHALF * AMC_MAX_MOVES + k] = ((TWO_PI * ds2) / av) / 2.0;
+        {
+            // dden / den^2 (= 1/sigma^3) as an unevaluated sum hi + lo: the coefficient of delta^2 in the estimator's
+            // d logq / d sigma (pg_sample), good to ~2^-100 so that no rounding of a CONSTANT biases a sum over 1e7+ samples
+            const double den = 2.0 * s2, dden = 2.0 * ds2;
+            const double d_hi = den * den, d_lo = __builtin_fma(den, den, -d_hi);
+            const double c_hi = dden / d_hi;
+            const double res = __builtin_fma(-c_hi, d_hi, dden) - c_hi * d_lo;
+            ptab[PT_C3HI * AMC_MAX_MOVES + k] = c_hi;
+            ptab[PT_C3LO * AMC_MAX_MOVES + k] = res / d_hi;
+        }
         const double w = ptab[PT_WEIGHT * AMC_MAX_MOVES + k];
         cp = (k == 0) ? w : cp + w;
         ptab[PT_CUM * AMC_MAX_MOVES + k] = cp;
@@ -986,11 +996,31 @@ __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_
     }
 }
 
+// What the estimator launch needs besides the chains.  Only what varies from launch to launch travels as kernel
+// arguments; everything that is fixed for a handle and an estimator configuration (the tail's buffers, optimiser
+// settings, learnable-move ids) sits in a PgTail record in device memory that the host rewrites when it changes --
+// kernel arguments are loaded into SGPRs at entry and stay live across the sampling loop, and the 350 bytes this
+// struct used to have cost the fused sweep + estimator kernel ~70 v_readlane / v_writelane spill instructions per loop trip.
+struct PgTail {
+    uint32_t* tickets;            // [1 + n_groups], zero between launches
+    double* group_sums;           // [n_groups][NL*4]
+    double* out;
+    double* gd_acc;               // [AMC_MAX_MOVES][5]
+    double* ptab_rw;              // == ptab (written by the update)
+    int* status;
+    double n_samples;
+    int32_t n_moves;
+    int32_t pad_;
+    int32_t learn_ids[AMC_MAX_LEARN];
+    PgOpts opt;
+};
+
 struct PgArgs {
     real_t* x;
     const real_t* beta_arr;
     const double* ptab;
     double* partials;             // [grid][NL][4]
+    const PgTail* tail;           // device memory
     int64_t n_chains;
     uint64_t pair0;
     uint64_t t_est;               // estimator call index
@@ -1003,15 +1033,6 @@ struct PgArgs {
     // dependent-launch gap on this part).  tail_mode 0: block partials only; 1: + their fixed-order sum in `out`
     // [NL*4]; 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
-    int32_t n_moves;
-    uint32_t* tickets;            // [1 + n_groups], zero between launches
-    double* group_sums;           // [n_groups][NL*4]
-    double* out;
-    double* gd_acc;               // [AMC_MAX_MOVES][5]
-    double* ptab_rw;              // == ptab (written by the update)
-    int* status;
-    double n_samples;
-    PgOpts opt;
 };
 enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kernel final reduction
 
@@ -1077,37 +1098,46 @@ __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double 
 }
 #endif
 
+// One pgmc_estimate sample of the StandardGaussian policy.  What leaves this function per chain is (a) the position,
+// x = (x + delta) + (-delta) in the reference's operations (bit-exact against the oracle), and (b) four SUMMANDS of
+// GradientData (j, grad j, grad logq, g: gradients.jl:104-108), which the reference folds with `+` over 1e7 chains in
+// whatever order its reducer takes (foldxl / foldxt, estimator.jl:94,113) and which are compared with the oracle at
+// rtol 1e-10.  The summands therefore need not repeat the reference's rounding sequence operation for operation, and
+// two parts of it that cost 19 of the 46 f64 operations per sample are replaced by forms that agree to a few ulp:
+//   * alpha = min(1, exp((dlogp + logq_b) - logq_f)) with logq_b == logq_f bit for bit: the detour through logq moves
+//     the argument by at most 2^-53 (2|dlogp| + |logq|), i.e. alpha by a relative 1e-16 |logq| -- alpha = min(1, exp(dlogp)),
+//     and log_proposal_density itself (a division by 2 sigma^2 and log(2 pi sigma^2)/2) is not formed at all;
+//   * d logq / d sigma, which ForwardDiff forms as -((-(d^2)/den)/den) dden - dlhalf (two IEEE divisions), is the
+//     polynomial d^2 (dden/den^2) - dlhalf: one fma with the coefficient split hi + lo (prepare_params) so that no
+//     constant's rounding biases the sum, and a second fma for the lo part.
+// The CPU restatement the tests compare with keeps the reference's operation order; test_pg_sample_summands_within_ulps
+// pins the per-sample difference at a few ulp of each summand's terms, the sums at rtol 1e-10 as before.
 template <int POT>
-__device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double den, double rden,
-                                          double logc, double dden, double dlhalf, double z, double (&g)[4],
-                                          const double* T)
+__device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double c3hi, double c3lo, double c1,
+                                          double z, double (&g)[4], const double* T)
 {
-#ifdef AMC_USER_SCALE
-    pg_sample_scaled<POT>(x, beta, sigma, z, g, T);
-    return;
-#endif
     const real_t delta = (real_t)(0.0 + sigma * z);
-    const LogQ lq = log_proposal_density_withgrad(delta, den, rden, logc, dden, dlhalf);
-    const double logq = lq.logq, dlogq = lq.dlogq;
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = x + delta;
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
-    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);   // reward, particle_1d.jl:42-44 (in T)
+    const real_t d2t = delta * delta;                              // (delta)^2 in T (particle_1d.jl:43,53)
+    const double d2 = (double)d2t;
+    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : d2;   // reward, particle_1d.jl:42-44 (in T)
     x = xn + (-delta);
-    // alpha = min(1, exp(arg)) with Julia's NaN-propagating min, without the generic guards: exp(arg >= 0) >= 1 and
-    // exp(arg <= 0) <= 1 hold exactly for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);
-    // arg < -708 -> 0;  NaN -> NaN.  Bit-identical to Julia's NaN-propagating min(1.0, exp(arg)) on the full-domain exp, 9 instead of 18 select/compare ops.
-    const double arg = ((double)dlogp + logq) - logq;
+    const double dlogq = __builtin_fma(d2, c3hi, __builtin_fma(d2, c3lo, -c1));
+    // alpha = min(1, exp(arg)) with Julia's NaN-propagating min: exp(arg >= 0) >= 1 and exp(arg <= 0) <= 1 hold exactly
+    // for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);  arg < -708 -> 0;  NaN -> NaN
+    const double arg = (double)dlogp;
     double ex = exp_core_f64(arg, T);
     asm volatile("" : "+v"(ex));          // keep the exp unconditional: no divergent branch around it
     double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
     alpha = (arg >= 0.0) ? 1.0 : alpha;
     const double j = r * alpha;
     g[0] += j;
-    g[1] += j * dlogq;            // forward and backward gradients are bit-identical here
+    g[1] = __builtin_fma(j, dlogq, g[1]);          // forward and backward gradients coincide for this policy (gradients.jl:106)
     g[2] += dlogq;
-    g[3] += dlogq * dlogq;
+    g[3] = __builtin_fma(dlogq, dlogq, g[3]);
 }
 
 // Column sums, in row order, of rows[n_rows][NV] that OTHER blocks wrote (agent-scope loads, one per thread and
@@ -1176,25 +1206,40 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
     // padded), the ragged last iteration peeled.
+    // per-move constants of the learnable moves: wave-uniform, read once (s_load) before the loop when they fit in
+    // SGPRs (NL <= 2: 8 doubles), inside the trip otherwise
+    constexpr bool HOIST = NL <= 2;
+    double c_sg[NL], c_hi[NL], c_lo[NL], c_c1[NL];
+    auto move_consts = [&](int l) {
+        const int lid = a.learn_ids[l];
+        c_sg[l] = a.ptab[PT_SIGMA * AMC_MAX_MOVES + lid];
+        c_hi[l] = a.ptab[PT_C3HI * AMC_MAX_MOVES + lid];
+        c_lo[l] = a.ptab[PT_C3LO * AMC_MAX_MOVES + lid];
+        c_c1[l] = a.ptab[PT_DLHALF * AMC_MAX_MOVES + lid];
+    };
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        c_sg[l] = c_hi[l] = c_lo[l] = c_c1[l] = 0.0;
+        if (HOIST && l < a.n_learn) move_consts(l);
+    }
     auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v1) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (l < a.n_learn) {
-                const int lid = a.learn_ids[l];
-                const double sigma = a.ptab[PT_SIGMA * AMC_MAX_MOVES + lid];
-                const double den = a.ptab[PT_DEN * AMC_MAX_MOVES + lid];
-                const double rden = a.ptab[PT_RDEN * AMC_MAX_MOVES + lid];
-                const double logc = a.ptab[PT_LOGC * AMC_MAX_MOVES + lid];
-                const double dden = a.ptab[PT_DDEN * AMC_MAX_MOVES + lid];
-                const double dlhalf = a.ptab[PT_DLHALF * AMC_MAX_MOVES + lid];
+                if (!HOIST) move_consts(l);
                 for (int q = 0; q < a.q_batch; ++q) {
                     double z0, z1;
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1, s_math);
-                    pg_sample<POT>(xv.x, b0, sigma, den, rden, logc, dden, dlhalf, z0, g[l], s_math);
-                    if (v1) pg_sample<POT>(xv.y, b1, sigma, den, rden, logc, dden, dlhalf, z1, g[l], s_math);
+#ifdef AMC_USER_SCALE
+                    pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
+                    if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);
+#else
+                    pg_sample<POT>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[l], s_math);
+                    if (v1) pg_sample<POT>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[l], s_math);
+#endif
                 }
             }
         }
@@ -1250,6 +1295,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             for (int i = 0; i < 4; ++i) __hip_atomic_store(row + l * 4 + i, r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (a.tail_mode == 0) return;
+    const PgTail* const tl = a.tail;       // loaded here, not at kernel entry (see PgArgs)
 
     // In-kernel final reduction, two levels of "the last one to arrive sums": the last block of each group of
     // PG_GROUP consecutive blocks adds the group's rows in row order, the last group to finish adds the group sums in
@@ -1264,7 +1310,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const int n_rows = ((int)gridDim.x - r0 < PG_GROUP) ? (int)gridDim.x - r0 : PG_GROUP;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t prev = __hip_atomic_fetch_add(a.tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t prev = __hip_atomic_fetch_add(tl->tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_rows - 1u) ? 1 : 0;
     }
     __syncthreads();
@@ -1273,31 +1319,31 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     {
         const double t = ordered_column_sum<NV>(a.partials + (int64_t)r0 * NV, n_rows, s_math, CAP_ROWS);
         if (threadIdx.x < NV) {
-            __hip_atomic_store(a.group_sums + grp * NV + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tl->group_sums + grp * NV + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();                                   // NV <= 32: the stores above all belong to wave 0, now complete
     if (threadIdx.x == 0) {
-        __hip_atomic_store(a.tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        const uint32_t prev = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tl->tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const uint32_t prev = __hip_atomic_fetch_add(tl->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_groups - 1u) ? 2 : 0;
     }
     __syncthreads();
     if (s_role != 2) return;
     {
-        const double t = ordered_column_sum<NV>(a.group_sums, n_groups, s_math, CAP_ROWS);
+        const double t = ordered_column_sum<NV>(tl->group_sums, n_groups, s_math, CAP_ROWS);
         if (threadIdx.x < NV) {
-            a.out[threadIdx.x] = t;
+            tl->out[threadIdx.x] = t;
             s_tot[threadIdx.x] = t;
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tl->tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.tail_mode >= 2) {
-            for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, a.learn_ids[l], a.n_samples, a.gd_acc);
-            if (a.tail_mode >= 3) pg_update_all(a.ptab_rw, a.gd_acc, a.n_learn, a.learn_ids, a.opt, a.n_moves, a.status);
+            for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, tl->learn_ids[l], tl->n_samples, tl->gd_acc);
+            if (a.tail_mode >= 3) pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status);
         }
     }
 }
@@ -1395,7 +1441,10 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
         const LogQ lq = log_proposal_density_withgrad((real_t)v, tab[PT_DEN * AMC_MAX_MOVES], tab[PT_RDEN * AMC_MAX_MOVES],
                                                       tab[PT_LOGC * AMC_MAX_MOVES], tab[PT_DDEN * AMC_MAX_MOVES],
                                                       tab[PT_DLHALF * AMC_MAX_MOVES]);
-        r = fn == 9 ? lq.logq : lq.dlogq;
+        // 9: the reference-ordered log density; 10: d logq / d sigma as the estimator kernel forms it (pg_sample)
+        const double d2 = (double)((real_t)v * (real_t)v);
+        const double dq = __builtin_fma(d2, tab[PT_C3HI * AMC_MAX_MOVES], __builtin_fma(d2, tab[PT_C3LO * AMC_MAX_MOVES], -tab[PT_DLHALF * AMC_MAX_MOVES]));
+        r = fn == 9 ? lq.logq : dq;
         break;
     }
     default: break;

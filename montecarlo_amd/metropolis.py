@@ -77,6 +77,9 @@ class Metropolis(AriannaAlgorithm):
                               sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],
                               seed=self.seed, sweepstep=self.sweepstep,
                               per_chain_counters=bool(per_chain_counters) or len(self.pool) > 1, device=device)
+        # sharded on GPUs: the engine gets an RCCL communicator of its own (callback sums and the estimator's fold are then
+        # ONE ncclAllReduce on its stream); otherwise (one rank, or a CPU test double) sums go through sharding.allreduce_sum
+        self._comm_connected = self.world_size > 1 and sharding.connect_engine(self.engine)
         self._epoch = 0          # bumped whenever the device state changes
         self._red_key = None
         self._red_val = None
@@ -130,7 +133,7 @@ class Metropolis(AriannaAlgorithm):
             x, e = self.engine.download_state(want_e=True)
             self.chains.x, self.chains.e = x, e        # this rank's shard, like chains[c].x / .e
         acc, tot = self.engine.counter_totals()
-        tot_all = sharding.allreduce_sum(np.concatenate([acc, tot]).astype(np.float64))
+        tot_all = sharding.allreduce_sum(np.concatenate([acc, tot]).astype(np.float64), self.engine)
         K = len(self.pool)
         for k, move in enumerate(self.pool):
             move.accepted_calls = int(tot_all[k])
@@ -181,7 +184,7 @@ class Metropolis(AriannaAlgorithm):
         else:
             self._drop_pending_reduction()
             local = self.engine.reduce()
-        red = sharding.allreduce_sum(local)
+        red = sharding.allreduce_sum(local, self.engine)
         n = red[3]
         val = {
             "energy": red[0] / n,                      # mean(system.e for system in chains)

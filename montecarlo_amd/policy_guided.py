@@ -210,21 +210,8 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         met = self.metropolis
         if getattr(met, "_comm_connected", False):
             return True
-        eng = met.engine
-        if not (hasattr(eng, "comm_init") and hasattr(eng, "comm_unique_id")):
-            return False
-        import sys
-        if "torch" not in sys.modules:
-            return False
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
-            return False
-        rank, world = dist.get_rank(), dist.get_world_size()
-        box = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        eng.comm_init(rank, world, box[0])
-        met._comm_connected = True
-        return True
+        met._comm_connected = sharding.connect_engine(met.engine)
+        return met._comm_connected
 
     def refresh(self) -> None:
         """Device-resident mode: pull the running gradients_data / objectives to the host (synchronises)."""
@@ -245,7 +232,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
             return
         local = self.metropolis.engine.pg_estimate(self.learn_ids, self.q_batch_size)
         self.metropolis.invalidate_reductions()      # every sample leaves x at (x+d)-d (gradients.jl:103)
-        total = sharding.allreduce_sum(local.reshape(-1)).reshape(local.shape)
+        total = sharding.allreduce_sum(local.reshape(-1), self.metropolis.engine).reshape(local.shape)
         for k in range(len(self.learn_ids)):
             gd = GradientData(float(total[k, 0]), np.array([total[k, 1]]), np.array([total[k, 2]]),
                               np.array([[total[k, 3]]]), int(round(total[k, 4])))

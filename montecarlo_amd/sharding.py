@@ -5,19 +5,123 @@ mutable state), so rank r of W owns a contiguous range of GLOBAL chain ids and s
 collective.  Information crosses chains in exactly two places, both tiny sums:
   * the callbacks (callback_energy particle_1d.jl:68-70, callback_acceptance metropolis.jl:319-321)
   * the GradientData `+` fold of the estimator (src/PolicyGuided/estimator.jl:113-129)
-These become ONE all-reduce(sum, f64) of a few dozen bytes: torch.distributed
-(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in CPU tests).  The Philox counter uses the
-global chain id, so results do not depend on W (shard invariance is tested).
+These become ONE all-reduce(sum, f64) of a few dozen bytes.  On GPUs it runs through the engine's own RCCL
+communicator (amc_comm_init / amc_allreduce_sum: RCCL over xGMI, on the engine's stream, no torch tensors involved);
+the launcher's TCP store carries the 128-byte ncclUniqueId and the run's barriers (`StoreGroup`: no process group, no
+second RCCL instance in the process).  A torch.distributed process group, if the script has one, is used the same way
+("gloo" in CPU tests; "nccl" only to ship the unique id).  The Philox counter uses the global chain id, so results do
+not depend on W (shard invariance is tested).
 """
 from __future__ import annotations
 
-from typing import Tuple
+import os
+import pickle
+from typing import List, Optional, Tuple
 
 import numpy as np
 
 
+class StoreGroup:
+    """The ranks of one launch, tied together by the launcher's key-value store only.
+
+    `python -m torch.distributed.run` hands every worker RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT and hosts a
+    TCPStore on that port (TORCHELASTIC_USE_AGENT_STORE=True); started by hand, rank 0 hosts it.  That store is all
+    this path needs from torch: barrier, all-gather of small Python objects (timings, the ncclUniqueId), and a
+    deterministic host-side sum for engines without a communicator (CPU tests).  No init_process_group, hence no
+    torch-side NCCL/RCCL communicator and no torch CUDA context."""
+
+    def __init__(self, rank: int, world_size: int, host: str, port: int, agent_store: bool, timeout_s: float = 600.0):
+        from datetime import timedelta
+        from torch.distributed import TCPStore         # torch first, then libamc.so (one HIP runtime per process)
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.store = TCPStore(host, int(port), self.world_size, is_master=(self.rank == 0 and not agent_store),
+                              timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+        self._n = 0
+
+    def _key(self, what: str) -> str:
+        self._n += 1
+        return f"amc/{what}/{self._n}"
+
+    def barrier(self) -> None:
+        key = self._key("barrier")
+        if self.store.add(key, 1) == self.world_size:
+            self.store.set(key + "/done", b"1")
+        self.store.wait([key + "/done"])
+
+    def allgather(self, obj) -> List:
+        """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable objects)."""
+        key = self._key("gather")
+        self.store.set(f"{key}/{self.rank}", pickle.dumps(obj))
+        return [pickle.loads(self.store.get(f"{key}/{r}")) for r in range(self.world_size)]
+
+    def broadcast(self, obj, src: int = 0):
+        key = self._key("bcast")
+        if self.rank == src:
+            self.store.set(key, pickle.dumps(obj))
+        return pickle.loads(self.store.get(key))
+
+    def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
+        """Host-side sum in rank order (deterministic); for engines without a communicator of their own."""
+        parts = self.allgather(np.ascontiguousarray(values, dtype=np.float64))
+        total = parts[0].copy()
+        for p in parts[1:]:
+            total = total + p
+        return total
+
+
+_group: Optional[StoreGroup] = None
+
+
+def init_store_group(rank: Optional[int] = None, world_size: Optional[int] = None) -> StoreGroup:
+    """Join the launch's ranks through the launcher's store (environment of torch.distributed.run, or RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set by hand).  Call before building the Simulation, in place of
+    torch.distributed.init_process_group."""
+    global _group
+    if _group is not None:
+        return _group
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+    _group = StoreGroup(rank, world_size, host, port, agent)
+    return _group
+
+
+def group() -> Optional[StoreGroup]:
+    return _group
+
+
+def connect_engine(engine) -> bool:
+    """Give the engine of this rank's shard an RCCL communicator over all ranks (amc_comm_init); the ncclUniqueId made on
+    rank 0 travels over the store group or, failing that, over the script's torch.distributed process group.  True when
+    the engine is connected afterwards (its allreduce_sum / device-resident estimator then span the shards)."""
+    if getattr(engine, "comm_connected", False):
+        return True
+    if not (hasattr(engine, "comm_init") and hasattr(engine, "comm_unique_id")):
+        return False
+    rank, size = world()
+    if _group is not None:
+        uid = _group.broadcast(engine.comm_unique_id() if rank == 0 else None)
+    else:
+        import sys
+        if "torch" not in sys.modules:
+            return False
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return False
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    engine.comm_init(rank, size, uid)
+    engine.comm_connected = True
+    return True
+
+
 def world() -> Tuple[int, int]:
-    """(rank, world_size) of the default process group, (0, 1) when not initialised."""
+    """(rank, world_size): of the store group if one was joined, else of the default torch process group, else (0, 1)."""
+    if _group is not None:
+        return _group.rank, _group.world_size
     # A process group can only exist if the caller has imported torch already; never import it from here:
     # torch bundles its own HIP runtime, and loading it AFTER libamc.so has bound the system one puts two
     # HIP runtimes in the process (the C-ABI RCCL path then fails).  Multi-GPU scripts import torch and call
@@ -49,12 +153,17 @@ def shard_range(n_global: int, rank: int, world_size: int) -> Tuple[int, int]:
     return min(2 * p0, n_global), min(2 * p1, n_global)
 
 
-def allreduce_sum(values: np.ndarray) -> np.ndarray:
-    """Sum a small f64 vector over all ranks (no-op for a single process)."""
+def allreduce_sum(values: np.ndarray, engine=None) -> np.ndarray:
+    """Sum a small f64 vector over all ranks (no-op for a single process).  `engine`: this rank's engine; when it holds a
+    communicator (connect_engine) the sum is ONE ncclAllReduce on its stream."""
     rank, size = world()
     values = np.ascontiguousarray(values, dtype=np.float64)
+    if engine is not None and getattr(engine, "comm_connected", False):
+        return engine.allreduce_sum(values)
     if size == 1:
         return values
+    if _group is not None:
+        return _group.allreduce_sum(values)
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(values.copy())
@@ -66,6 +175,8 @@ def allreduce_sum(values: np.ndarray) -> np.ndarray:
 
 def barrier() -> None:
     _, size = world()
-    if size > 1:
+    if _group is not None:
+        _group.barrier()
+    elif size > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -152,6 +152,14 @@ def restore(metropolis: Metropolis, path: str, estimator=None) -> None:
         from .policy_guided import GradientData
         estimator.gradients_data = [GradientData(float(r[0]), np.array([r[1]]), np.array([r[2]]), np.array([[r[3]]]), int(r[4]))
                                     for r in d["gd"]]
+        if estimator.device_resident and estimator.learn_ids:
+            # the running sums live in the engine (amc_pg_accumulate adds to them there): without this the first update
+            # after the resume would average the post-resume samples only
+            if not hasattr(eng, "pg_set_accumulated"):
+                if any(int(r[4]) != 0 for r in d["gd"]):
+                    raise ValueError("restore: this engine cannot take over non-empty device-resident gradients_data")
+            else:
+                eng.pg_set_accumulated(estimator.learn_ids, np.asarray(d["gd"], dtype=np.float64))
     metropolis.chains.x = None                      # initialise() must not overwrite the restored state
     metropolis.restored = True
     metropolis.invalidate_reductions()

@@ -496,6 +496,11 @@ class OracleEngine:
         acc = self.__dict__.setdefault("_gd_acc", {})
         return np.array([acc.get(k, np.zeros(5)) for k in learn_ids]).reshape(len(learn_ids), 5)
 
+    def pg_set_accumulated(self, learn_ids, rows):
+        acc = self.__dict__.setdefault("_gd_acc", {})
+        for k, row in zip(learn_ids, np.asarray(rows, dtype=np.float64).reshape(len(learn_ids), 5)):
+            acc[k] = row.copy()
+
     def pgmc_steps(self, n_steps, learn_ids, q_batch, kinds=None, hyper0=(), hyper1=()):
         self.pgmc_calls = getattr(self, "pgmc_calls", 0) + 1
         for _ in range(int(n_steps)):

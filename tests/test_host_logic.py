@@ -212,6 +212,37 @@ def test_histogram_snapshots_and_exact_resume(oracle, tmp_path):
         ma.restore(other.algorithms[0], str(tmp_path / "ckpt"))
 
 
+def test_resume_keeps_gradient_accumulators_when_updates_are_sparser_than_the_estimator(oracle, tmp_path):
+    """PolicyGradientUpdate every 7 steps, estimator every step (update.jl:50-57 averages everything accumulated since the
+    last update): a checkpoint that falls between two updates must carry the device-resident gradients_data, or the
+    first update after the resume averages the post-resume samples only and sigma leaves the uninterrupted run."""
+    pool = lambda: (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
+                    ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+    def build(path, steps, p, updates):
+        chains = ma.ParticleChains.uniform(200, 2.0)
+        al = (dict(algorithm=ma.Metropolis, pool=p, seed=3, engine_factory=oracle.OracleEngine),
+              dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.05)), q_batch_size=2),
+              dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=updates))
+        return ma.Simulation(chains, al, steps, path=str(path))
+    p_full = pool()
+    full = build(tmp_path / "full", 60, p_full, list(range(7, 57, 7)) + [60])     # updates at t = 7, 14, ..., 56, 60
+    ma.run(full)
+    p_a = pool()
+    a = build(tmp_path / "a", 25, p_a, [7, 14, 21])          # the first 25 steps of the same run
+    ma.run(a)
+    est_a = a.algorithms[1]
+    assert est_a.device_resident
+    est_a.refresh()
+    assert est_a.gradients_data[0].n == 4 * 200 * 2          # steps 22..25 are pending in the accumulator
+    ma.checkpoint(a.algorithms[0], str(tmp_path / "ckpt"), estimator=est_a)
+    p_b = pool()
+    b = build(tmp_path / "b", 35, p_b, list(range(3, 32, 7)) + [35])              # t' = 3, ..., 31, 35 <-> t = 28, ..., 56, 60
+    ma.restore(b.algorithms[0], str(tmp_path / "ckpt"), estimator=b.algorithms[1])
+    ma.run(b)
+    assert np.array_equal(b.chains.x, full.chains.x)
+    assert [m.sigma for m in p_b] == [m.sigma for m in p_full] and p_b[1].sigma != 0.1
+
+
 def _pgmc_sim(oracle, path, steps, update_sched=None, factory=None):
     chains = ma.ParticleChains.uniform(12, 2.0, -2.0, 2.0)
     pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),

@@ -1,0 +1,175 @@
+"""Static check of the Julia binding (julia/AriannaHIP.jl) against the C header (include/amc.h).
+
+There is no Julia in this image or on the GPU box, so the ccall stub cannot be executed.  What CAN be checked without
+Julia is everything a ccall gets wrong silently: the field list of the `AmcConfig` mirror (names, order, widths) against
+`struct amc_config`, and for every `ccall((:amc_..., libamc), ...)` the entry point's existence, its return type, its
+argument types (C type -> the Julia types that are ABI-compatible with it) and the number of values actually passed.
+"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = os.path.join(ROOT, "julia", "AriannaHIP.jl")
+HDR = os.path.join(ROOT, "include", "amc.h")
+
+# C type (normalised: no `const`, single spaces, `*` attached) -> Julia types with the same calling-convention class
+C_TO_JULIA = {
+    "amc_handle*": {"Ptr{Cvoid}"},
+    "amc_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "amc_config*": {"Ref{AmcConfig}", "Ptr{AmcConfig}"},
+    "char*": {"Cstring", "Ptr{UInt8}", "Ptr{Cchar}"},
+    "double*": {"Ptr{Float64}", "Ref{Float64}"},
+    "double": {"Float64", "Cdouble"},
+    "float": {"Float32", "Cfloat"},
+    "int": {"Cint", "Int32"},
+    "int*": {"Ptr{Cint}", "Ref{Cint}", "Ptr{Int32}"},
+    "int64_t": {"Int64"},
+    "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
+    "uint64_t": {"UInt64"},
+    "uint64_t*": {"Ptr{UInt64}", "Ref{UInt64}"},
+    "uint32_t": {"UInt32"},
+    "uint32_t*": {"Ptr{UInt32}"},
+    "void*": {"Ptr{Cvoid}"},
+    "void**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+}
+C_FIELD_TO_JULIA = {"uint32_t": "UInt32", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "double": "Float64",
+                    "double*": "Ptr{Float64}", "void*": "Ptr{Cvoid}"}
+C_RET_TO_JULIA = {"int": {"Cint", "Int32"}, "char*": {"Cstring", "Ptr{UInt8}"}}
+
+
+def _strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def _norm_ctype(t):
+    t = re.sub(r"\bconst\b", " ", t)
+    t = re.sub(r"\s*\*\s*", "*", t.strip())
+    return re.sub(r"\s+", " ", t).strip()
+
+
+def header_prototypes():
+    text = _strip_c_comments(open(HDR).read())
+    protos = {}
+    for m in re.finditer(r"^\s*(const\s+char\s*\*\s*|int\s+)(amc_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.M | re.S):
+        ret, name, args = _norm_ctype(m.group(1)), m.group(2), m.group(3).strip()
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"(.*?)(\w+)$", a, flags=re.S)            # last identifier is the parameter name
+                params.append(_norm_ctype(mm.group(1)))
+        protos[name] = (ret, params)
+    return protos
+
+
+def header_config_fields():
+    text = _strip_c_comments(open(HDR).read())
+    body = re.search(r"typedef\s+struct\s+amc_config\s*\{(.*?)\}\s*amc_config\s*;", text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        mm = re.match(r"(.*?)(\w+)$", decl, flags=re.S)
+        fields.append((mm.group(2), _norm_ctype(mm.group(1))))
+    return fields
+
+
+def _split_top(s):
+    """Split on commas that are not inside (), {} or []."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def julia_ccalls():
+    text = re.sub(r"#[^\n]*", "", open(JL).read())           # Julia line comments (no '#' inside the strings used there)
+    calls = []
+    for m in re.finditer(r"ccall\(", text):
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[j], 0)
+            j += 1
+        parts = _split_top(text[i:j - 1])
+        target = re.match(r"\(\s*:(\w+)\s*,\s*libamc\s*\)", parts[0])
+        assert target, f"ccall target not of the form (:amc_x, libamc): {parts[0]}"
+        argt = parts[2].strip()
+        assert argt.startswith("(") and argt.endswith(")"), argt
+        types = _split_top(argt[1:-1])
+        calls.append(dict(name=target.group(1), ret=parts[1].strip(), types=[t for t in types if t], values=parts[3:]))
+    return calls
+
+
+def julia_config_fields():
+    text = open(JL).read()
+    body = re.search(r"^struct AmcConfig\n(.*?)^end", text, flags=re.S | re.M).group(1)
+    fields = []
+    for line in body.splitlines():
+        line = line.split("#")[0].strip()
+        if line:
+            name, typ = line.split("::")
+            fields.append((name.strip(), typ.strip()))
+    return fields
+
+
+def test_amc_config_mirror_matches_the_header_field_for_field():
+    c_fields, j_fields = header_config_fields(), julia_config_fields()
+    assert [n for n, _ in j_fields] == [n for n, _ in c_fields], "AmcConfig: field names / order differ from struct amc_config"
+    for (name, ctype), (_, jtype) in zip(c_fields, j_fields):
+        assert C_FIELD_TO_JULIA[ctype] == jtype, f"AmcConfig.{name}: {jtype} does not mirror C `{ctype}`"
+    # the ABI guard the library checks (struct_size) is what sizeof gives for this layout: 16 fields, natural alignment
+    size = {"UInt32": 4, "Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "Ptr{Float64}": 8, "Ptr{Cvoid}": 8}
+    off = 0
+    for _, t in j_fields:
+        off = (off + size[t] - 1) // size[t] * size[t] + size[t]
+    from montecarlo_amd import _capi
+    import ctypes
+    assert (off + 7) // 8 * 8 == ctypes.sizeof(_capi.AmcConfig)
+
+
+def test_every_ccall_matches_its_prototype():
+    protos = header_prototypes()
+    assert len(protos) >= 40 and "amc_sweep" in protos and "amc_last_error" in protos
+    calls = julia_ccalls()
+    assert len(calls) >= 15
+    for c in calls:
+        assert c["name"] in protos, f"ccall to :{c['name']}, which include/amc.h does not declare"
+        ret, params = protos[c["name"]]
+        assert c["ret"] in C_RET_TO_JULIA[ret], f":{c['name']} returns C `{ret}`, the ccall says {c['ret']}"
+        assert len(c["types"]) == len(params), f":{c['name']} takes {len(params)} arguments, the ccall declares {len(c['types'])}"
+        assert len(c["values"]) == len(params), f":{c['name']}: {len(c['values'])} values passed for {len(params)} parameters"
+        for k, (ctype, jtype) in enumerate(zip(params, c["types"])):
+            assert jtype in C_TO_JULIA[ctype], f":{c['name']} argument {k + 1}: C `{ctype}` bound as {jtype}"
+
+
+def test_binding_covers_the_entry_points_a_run_needs():
+    used = {c["name"] for c in julia_ccalls()}
+    need = {"amc_create", "amc_create_custom", "amc_create_model", "amc_create_policy_model", "amc_destroy",
+            "amc_upload_state", "amc_sweep", "amc_download_state", "amc_download_counters", "amc_reduce",
+            "amc_allreduce_sum", "amc_comm_unique_id", "amc_comm_init", "amc_pg_estimate", "amc_set_parameters",
+            "amc_get_parameters", "amc_pgmc_steps", "amc_pg_get_accumulated", "amc_pg_set_accumulated", "amc_last_error"}
+    assert need <= used, sorted(need - used)
+
+
+def test_shards_are_connected_and_pools_are_not_deep_copied_per_chain():
+    """The two defects of the first stub: no amc_comm_init anywhere (amc_allreduce_sum was a no-op on N > 1) and one
+    deepcopy of the pool per chain (1e7 copies at the headline size; metropolis.jl:289 does that, but the engine keeps
+    the per-chain part on the device)."""
+    text = re.sub(r"#[^\n]*", "", open(JL).read())
+    assert "comm_init!(alg, rank, n_ranks, unique_id)" in text
+    assert not re.search(r"\[\s*deepcopy\(pool\)\s+for\s+\w+\s+in\s+chains\s*\]", text)
+    assert text.count("deepcopy(pool)") == 1                    # the one template copy
+    # one parameters object per move, shared by the update and every materialised pools[c]
+    assert "move.policy, move.parameters, move.weight" in text and "est.parameters_list" in text

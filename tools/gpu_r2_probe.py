@@ -29,10 +29,10 @@ if what in ("all", "ladder"):
         res[f"k1_M{M}"] = (mn, md)
         print(f"K=1 M={M:>11d}: min {mn:8.1f} us median {md:8.1f} us  {16*M/mn/1e3:7.1f} GB/s ({16*M/mn/1e3/8000*100:5.1f}% of 8 TB/s)", flush=True)
         e.close()
-if what in ("all", "bpc"):
+if what in ("all", "bpc", "quick"):
     M = 10_000_000
-    for bpc in (4, 5, 6, 7, 8, 10, 12):
-        os.environ["AMC_BLOCKS_PER_CU"] = str(bpc)
+    for bpc in ((4, 5, 6, 7, 8, 10, 12) if what != "quick" else (0,)):
+        if bpc: os.environ["AMC_BLOCKS_PER_CU"] = str(bpc)
         e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
         e.init_uniform(-2, 2); spin(e)
         mn, md = best_of(e, lambda n: [e.sweep(1) for _ in range(n)], 96)
@@ -47,4 +47,4 @@ if what in ("all", "bpc"):
         mn4, md4 = best_of(e, lambda n: [e.sweep(1) for _ in range(n)], 200)
         e.close()
         print(f"blocks/CU {bpc:2d}: K=2 sweep {mn:6.1f}/{md:6.1f}  pgmc fused step {mn2:6.1f}/{md2:6.1f}  estimator alone {mn3:6.1f}/{md3:6.1f}  K=1 sweep {mn4:6.1f}/{md4:6.1f} us (min/median)", flush=True)
-    os.environ.pop("AMC_BLOCKS_PER_CU")
+    os.environ.pop("AMC_BLOCKS_PER_CU", None)

@@ -10,7 +10,11 @@ def blocks(lines):
     bl = []; cur = ['entry:']
     for l in lines:
         if re.match(r'^\.LBB\d+_\d+:', l): bl.append(cur); cur = [l]
-        else: cur.append(l)
+        else:
+            cur.append(l)
+            t = l.strip()
+            if t.startswith(('s_cbranch', 's_branch', 's_endpgm')):      # a basic block ends at every branch
+                bl.append(cur); cur = ['  (fallthrough after ' + t.split()[0] + ' ' + (t.split()[1] if len(t.split()) > 1 else '') + '):']
     bl.append(cur); return bl
 def ins(b): return [l.split()[0] for l in b if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
 def cls(k):
@@ -31,9 +35,9 @@ for pat in names:
         print('==', dn)
         for b in blocks(kern(name)):
             I = ins(b)
-            if len(I) < 15: continue
+            if len(I) < (1 if '-a' in sys.argv else 15): continue
             c = collections.Counter(cls(k) for k in I)
-            print('  ', b[0].split(':')[0].ljust(10), len(I), dict(c))
+            print('  ', b[0].split(':')[0].ljust(44), len(I), dict(c), (b[-1].strip() if b[-1].strip().startswith(('s_cbranch','s_branch')) else ''))
             if '-v' in sys.argv:
                 h = collections.Counter(I)
                 print('      ', ', '.join(f'{k}:{v}' for k, v in h.most_common(30)))
