@@ -85,6 +85,7 @@ struct amc_handle {
     int log_depth = 32;         // rows of the step log (env AMC_LOG_DEPTH, 1..256)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
     double* d_ptab = nullptr;
+    uint8_t* d_pick = nullptr;  // [AMC_PICK_CELLS] move pick by the 12 leading bits of the pick uniform (K > 1)
     unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
     unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
     int n_slots = 0;
@@ -150,6 +151,11 @@ int push_params(amc_handle* h, const double* sigma, const double* weight)
     AMC_HIP(hipStreamSynchronize(h->stream));   // tab is a stack-scoped host buffer
     hipLaunchKernelGGL(amc::prepare_params_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->K);
     AMC_HIP(hipGetLastError());
+    if (weight && h->K > 1) {      // the cumulative weights changed: rebuild the 12-bit move-pick table from them
+        hipLaunchKernelGGL(amc::prepare_pick_kernel, dim3(AMC_PICK_CELLS / AMC_BLOCK), dim3(AMC_BLOCK), 0, h->stream, h->d_ptab, h->K,
+                           h->d_pick);
+        AMC_HIP(hipGetLastError());
+    }
     return AMC_OK;
 }
 
@@ -679,6 +685,8 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     }
     AMC_TRY(hipMalloc(&h->d_ptab, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_ptab, 0, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double), h->stream));
+    AMC_TRY(hipMalloc(&h->d_pick, AMC_PICK_CELLS));
+    AMC_TRY(hipMemsetAsync(h->d_pick, 0, AMC_PICK_CELLS, h->stream));
     AMC_TRY(hipMalloc(&h->d_totals, 2 * AMC_MAX_MOVES * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
     h->n_slots = h->n_cu * h->blocks_per_cu;
@@ -808,6 +816,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_tot);
     (void)hipFree(h->d_log);
     (void)hipFree(h->d_ptab);
+    (void)hipFree(h->d_pick);
     (void)hipFree(h->d_totals);
     (void)hipFree(h->d_acc_slots);
     (void)hipFree(h->d_partials);
@@ -1003,6 +1012,7 @@ static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
     a.log = h->d_log;
     a.log_pos = h->log_fill;
     a.ptab = h->d_ptab;
+    a.pick_tab = h->d_pick;
     a.acc_total = h->d_acc_slots;
     a.n_chains = h->M;
     a.m_stride = h->M_pad;

@@ -161,9 +161,8 @@ __device__ __forceinline__ bool accept_exact(real_t delta, real_t dlogp, double 
     return c_pos | (c_rng & c_exp);
 }
 
-// Filter.  Inputs: dlogp (exact, f64) and k = the top B bits of u's 52-bit significand, so k 2^-B <= u < (k+1) 2^-B with
-// both ends exact floats (B = 12: the bits the normal draw supplies, spec v4; B = 24 once the accept draw is at hand).
-// Error budget of the estimate
+// Filter.  Inputs: dlogp (exact, f64) and k = the top 12 bits of u's 52-bit significand -- the bits the step's normal
+// draw supplies (spec v5) --, so k 2^-12 <= u < (k+1) 2^-12 with both ends exact floats.  Error budget of the estimate
 // ex = v_exp_f32(log2e * float(dlogp)) against the spec's exp(arg), for -17 <= dlogp < 1e-12 (relative):
 //   arg vs dlogp      arg = fl(fl(dlogp + logq) - logq), |arg - dlogp| <= 2^-53 (2|dlogp| + |logq|) with
 //                     |logq| <= z^2/2 (1 + 2^-50) + |log(2 pi s^2)/2| <= 37 + 231 (|z| <= 8.5, 1e-100 <= s <= 1e100)
@@ -175,8 +174,8 @@ __device__ __forceinline__ bool accept_exact(real_t delta, real_t dlogp, double 
 //   * (1 -+ eps)      one float rounding                                                                    6e-8
 // total < 3.1e-6; eps = 2^-16 = 1.5e-5 leaves a factor 5.  Outside the range: dlogp > 1e-12 -> arg > 0 -> accept;
 // dlogp < -17 -> the clamped estimate is an upper bound only.  NaN compares false everywhere -> undecided.
-// Undecided when u's cell touches the interval (B = 12: ~1.2e-4 per chain-step, B = 24: ~3e-5); then the whole wave
-// takes accept_exact.
+// Undecided when u's cell touches the interval (~1.2e-4 per chain-step, ~1.5 % of wave-steps); then the whole wave
+// forms the accept draw and takes accept_exact.
 #define AMC_FILTER_EPS 0x1.0p-16f
 // The five primitive comparisons of one chain; the decision masks are formed from their ballots on the scalar unit
 // (a ballot of a COMPOUND bool goes through a 0/1 VGPR and a second compare).  The sign tests use the float t:
@@ -186,24 +185,21 @@ struct FilterCmp {
     bool pos, neg, rng, lo, hi;
 };
 
-// k: the top BITS bits of u's significand (u in [k, k+1) 2^-BITS; 12 when only the normal draw is at hand, 24 with
-// the accept draw as well).
-template <int BITS>
 __device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
 {
     const float t = (float)dlogp;
     const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
-    const float kf = (float)k;                                             // exact: k < 2^24
-    constexpr float SCALE = (float)(1u << BITS);
-    // lower / upper bound of exp(arg) 2^BITS, the lower one already minus 1: one rounding each (in the budget)
+    const float kf = (float)k;                                             // exact: k < 2^12
+    constexpr float SCALE = 4096.0f;
+    // lower / upper bound of exp(arg) 2^12, the lower one already minus 1: one rounding each (in the budget)
     const float lo1 = __builtin_fmaf(ex, (1.0f - AMC_FILTER_EPS) * SCALE, -1.0f);
     const float hi = ex * ((1.0f + AMC_FILTER_EPS) * SCALE);
     FilterCmp c;
     c.pos = t > 2e-12f;                 // arg > 0: accept whatever u is
     c.neg = t < -2e-12f;                // arg < 0
     c.rng = t >= -17.0f;                // the estimate is two-sided
-    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-BITS > u
-    c.hi = hi < kf;                     // exp(arg) < k 2^-BITS <= u
+    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-12 > u
+    c.hi = hi < kf;                     // exp(arg) < k 2^-12 <= u
     return c;
 }
 
@@ -234,35 +230,41 @@ __device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, 
 }
 #endif
 
+// What the exact decision of a chain needs from its move besides sigma: den = 2 sigma^2, RN(1/den), log(2 pi sigma^2)/2.
+// K == 1: the pool's only move, wave-uniform scalars.  K > 1: read from the LDS copy of the move table by the chain's
+// move index -- inside the undecided arm only, the common path reads sigma alone.
+struct MoveExact {
+    double dn, rd, lc;
+};
+
 // One mc_step! of both chains of a pair.  force_mask (wave-uniform, all ones or zero; tests) sends every wave through
 // accept_exact.  acc_bits: bit 0 = even chain accepted, bit 8 = odd chain accepted (the step-log word's accept bits).
-// LAZY (K == 1): the accept draw is not formed up front.  The top 12 bits of u come from the normal draw (spec v4),
-// which brackets u to 2^-12: the decision is settled without the second Philox call unless exp(arg) falls into u's
-// cell (~1.2e-4 per chain-step, ~1.5 % of wave-steps); `pu` is then formed here.  !LAZY (K > 1: the move pick needs
-// the accept draw anyway): 24-bit bracket.
-template <int POT, bool LAZY>
-__device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double sg0, double sg1, double dn0, double dn1,
-                                        double rd0, double rd1, double lc0, double lc1, double z0, double z1,
-                                        u32x4 pn, u32x4 pu, u32x4 accept_ctr, uint32_t key0, uint32_t key1,
-                                        const double* T, unsigned long long force_mask, uint32_t& acc_bits,
-                                        unsigned long long& m0, unsigned long long& m1)
+// The accept draw is not formed up front: the top 12 bits of u come from the normal draw (spec v5), which brackets u
+// to 2^-12, and the decision is settled without the second Philox call unless exp(arg) falls into u's cell (~1.2e-4
+// per chain-step, ~1.5 % of wave-steps).  `pu` / `have_pu` (wave-uniform): the accept draw, if the move pick of this
+// step already needed it (pair_steps).
+template <int POT, bool MULTI>
+__device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double sg0, double sg1, int k0, int k1,
+                                        const double* s_tab, MoveExact m1, double z0, double z1, u32x4 pn, u32x4 pu,
+                                        bool have_pu, u32x4 accept_ctr, uint32_t key0, uint32_t key1, const double* T,
+                                        unsigned long long force_mask, uint32_t& acc_bits, unsigned long long& m0,
+                                        unsigned long long& m1_out)
 {
+    const uint32_t a0_12 = spare_accept12(pn, 0), a1_12 = spare_accept12(pn, 1);
 #ifdef AMC_USER_SCALE
     {
-        if (LAZY) pu = philox4x32_10(accept_ctr, key0, key1);
-        const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(pn.x, pu.x, pu.y), T);
-        const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(pn.z, pu.z, pu.w), T);
+        if (!have_pu) pu = philox4x32_10(accept_ctr, key0, key1);
+        const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
+        const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
         m0 = __builtin_amdgcn_ballot_w64(a0);
-        m1 = __builtin_amdgcn_ballot_w64(a1);
+        m1_out = __builtin_amdgcn_ballot_w64(a1);
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
         return;
     }
 #endif
     const Proposal p0 = propose<POT>(xv.x, b0, sg0, z0, T), p1 = propose<POT>(xv.y, b1, sg1, z1, T);
     const real_t xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
-    const uint32_t a0_12 = pn.x & 0xFFFu, a1_12 = pn.z & 0xFFFu;      // even chain: words (x, y), odd: (z, w)
-    const FilterCmp c0 = LAZY ? accept_filter<12>(p0.dlogp, a0_12) : accept_filter<24>(p0.dlogp, (a0_12 << 12) | (pu.y >> 20));
-    const FilterCmp c1 = LAZY ? accept_filter<12>(p1.dlogp, a1_12) : accept_filter<24>(p1.dlogp, (a1_12 << 12) | (pu.w >> 20));
+    const FilterCmp c0 = accept_filter(p0.dlogp, a0_12), c1 = accept_filter(p1.dlogp, a1_12);
 #define AMC_B(c) __builtin_amdgcn_ballot_w64(c)
     const unsigned long long acc0 = AMC_B(c0.pos) | (AMC_B(c0.rng) & AMC_B(c0.lo)), rej0 = AMC_B(c0.neg) & AMC_B(c0.hi);
     const unsigned long long acc1 = AMC_B(c1.pos) | (AMC_B(c1.rng) & AMC_B(c1.lo)), rej1 = AMC_B(c1.neg) & AMC_B(c1.hi);
@@ -270,21 +272,26 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
 #undef AMC_B
     if ((undecided | force_mask) != 0ull) {
         // the reference-ordered arithmetic decides (it agrees with the filter wherever the filter decided)
-        if (LAZY) {
+        if (!have_pu) {
             asm volatile("" : "+v"(accept_ctr.z));       // pins the second Philox call inside this arm (no speculation)
             pu = philox4x32_10(accept_ctr, key0, key1);
         }
-        const bool a0 = accept_exact(p0.delta, p0.dlogp, dn0, rd0, lc0, uniform_accept(pn.x, pu.x, pu.y), T);
-        const bool a1 = accept_exact(p1.delta, p1.dlogp, dn1, rd1, lc1, uniform_accept(pn.z, pu.z, pu.w), T);
+        MoveExact e0 = m1, e1 = m1;
+        if (MULTI) {
+            e0.dn = s_tab[AMC_MAX_MOVES + k0]; e0.lc = s_tab[2 * AMC_MAX_MOVES + k0]; e0.rd = s_tab[4 * AMC_MAX_MOVES + k0];
+            e1.dn = s_tab[AMC_MAX_MOVES + k1]; e1.lc = s_tab[2 * AMC_MAX_MOVES + k1]; e1.rd = s_tab[4 * AMC_MAX_MOVES + k1];
+        }
+        const bool a0 = accept_exact(p0.delta, p0.dlogp, e0.dn, e0.rd, e0.lc, uniform_accept(a0_12, pu.x, pu.y), T);
+        const bool a1 = accept_exact(p1.delta, p1.dlogp, e1.dn, e1.rd, e1.lc, uniform_accept(a1_12, pu.z, pu.w), T);
         m0 = __builtin_amdgcn_ballot_w64(a0);
-        m1 = __builtin_amdgcn_ballot_w64(a1);
+        m1_out = __builtin_amdgcn_ballot_w64(a1);
         xv.x = a0 ? p0.xn : xr0;
         xv.y = a1 ? p1.xn : xr1;
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
     } else {
         const bool a0 = c0.pos | (c0.rng & c0.lo), a1 = c1.pos | (c1.rng & c1.lo);
         m0 = acc0;
-        m1 = acc1;
+        m1_out = acc1;
         xv.x = a0 ? p0.xn : xr0;
         xv.y = a1 ? p1.xn : xr1;
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
@@ -366,6 +373,7 @@ struct SweepArgs {
     const real_t* beta_arr;       // nullptr unless per-chain beta
     uint8_t* log;                 // [log_depth][m_stride] per-chain step log (LOG launches), else nullptr
     const double* ptab;           // [PT_ROWS][AMC_MAX_MOVES]
+    const uint8_t* pick_tab;      // [AMC_PICK_CELLS] move pick by the 12 leading bits of the pick uniform (K > 1), see prepare_pick_kernel
     unsigned long long* acc_total;  // pool-wide accepted count (K == 1)
     int64_t n_chains;             // local chains
     int64_t m_stride;             // padded length of per-chain arrays
@@ -383,22 +391,40 @@ struct SweepArgs {
     int32_t n_slots;              // length of acc_total (launches of different grids share it)
 };
 
-// The Philox results of one MH step of a pair (normal draw; for K > 1 also the accept draw, whose low bits are the
-// move pick): pure functions of (seed, pair, step), so they can be formed before the pair's state has arrived from
-// memory.
+// The Philox result every MH step of a pair needs -- its normal draw: a pure function of (seed, pair, step), so it can
+// be formed before the pair's state has arrived from memory.  (Its spare bits lead the accept and pick uniforms; the
+// accept draw itself is formed only where those 12-bit brackets leave something open.)
 struct StepDraws {
-    u32x4 normal, accept;
+    u32x4 normal;
 };
 
-template <bool MULTI>
 __device__ __forceinline__ StepDraws step_draws(const SweepArgs& a, uint64_t pair, uint64_t t)
 {
     StepDraws d;
     d.normal = philox4x32_10(draw_counter(pair, t, DRAW_NORMAL, STREAM_METROPOLIS), a.key0, a.key1);
-    // K == 1: the accept draw is formed only for the waves whose decision the normal draw's 12 bits do not settle
-    if (MULTI) d.accept = philox4x32_10(draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1);
-    else d.accept = u32x4{0u, 0u, 0u, 0u};
     return d;
+}
+
+// rand(rng, Categorical(weights)) (metropolis.jl:206) from the 12 leading bits of the pick uniform.  The walk of
+// Distributions.jl's sampler, #(cum[i] <= r), is monotone in r, so every r of the cell [c, c+1) 2^-12 picks the same
+// move unless a cumulative weight lies inside the cell: AMC_PICK_CELLS bytes, entry = the move index, or
+// AMC_PICK_OPEN for the <= K-1 cells that hold a boundary (then the accept draw supplies 24 more bits and the walk
+// runs on the 36-bit uniform).  Built on the device from the same cum[] the walk uses (prepare_pick_kernel).
+#define AMC_PICK_CELLS 4096
+#define AMC_PICK_OPEN 0xFFu
+
+// Copy the pick table into this block's LDS: 256 threads x 16 bytes (visible after the block's next barrier).
+__device__ __forceinline__ void stage_pick_table(uint8_t* lds, const uint8_t* tab)
+{
+    for (int i = threadIdx.x; i < AMC_PICK_CELLS / 16; i += AMC_BLOCK)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(tab)[i];
+}
+
+__device__ __forceinline__ int categorical_walk(const double* s_tab, int K, double r)
+{
+    int k = 0;
+    for (int i = 0; i < K - 1; ++i) k += (s_tab[3 * AMC_MAX_MOVES + i] <= r) ? 1 : 0;     // cp = w1; while cp <= r && i < K: cp += w[i+1]
+    return k;
 }
 
 // Per-chain Move.accepted_calls / total_calls (metropolis.jl:208-209) are not read-modify-written by the sweep:
@@ -417,43 +443,49 @@ __device__ __forceinline__ void store_log_pair(const SweepArgs& a, int row, int6
 // with x), multi-step launches store one word per step right away.
 template <int POT, bool MULTI, bool LOG, bool SINGLE, bool PRE = false>
 __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t b0, real_t b1, uint64_t pair,
-                                           int64_t p, bool v0, bool v1, const double* s_tab, const double* s_math,
-                                           double sigma1, double den1, double rden1, double logc1,
+                                           int64_t p, bool v0, bool v1, const double* s_tab, const uint8_t* s_pick,
+                                           const double* s_math, double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& log_word,
                                            const StepDraws* pre = nullptr)
 {
     static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
     const int K = a.n_moves;
     const int n_steps = SINGLE ? 1 : a.n_steps;      // SINGLE: the sweepstep = 1 launch, straight-line code
+    const unsigned long long force_mask = a.exact_accept ? ~0ull : 0ull;
+    const MoveExact m1 = {den1, rden1, logc1};
     for (int s = 0; s < n_steps; ++s) {
         const uint64_t t = a.t0 + (uint64_t)s;
-        const StepDraws dr = PRE ? *pre : step_draws<MULTI>(a, pair, t);
-        double sg0 = sigma1, sg1 = sigma1, dn0 = den1, dn1 = den1, lc0 = logc1, lc1 = logc1;
-        double rd0 = rden1, rd1 = rden1;
+        const StepDraws dr = PRE ? *pre : step_draws(a, pair, t);
+        const u32x4 accept_ctr = draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS);
+        double sg0 = sigma1, sg1 = sigma1;
         int k0 = 0, k1 = 0;
+        u32x4 pu = {0u, 0u, 0u, 0u};
+        bool have_pu = false;                        // wave-uniform
         if (MULTI) {
-            // rand(rng, Categorical(weights)) metropolis.jl:206: Distributions.jl walk
-            // cp = w1; while cp <= r && i < K: cp += w[i+1]  ==  #(cum[i] <= r), i < K-1
-            const double r0 = uniform_pick(dr.accept.x), r1 = uniform_pick(dr.accept.z);
-            for (int i = 0; i < K - 1; ++i) {
-                const double c = s_tab[3 * AMC_MAX_MOVES + i];
-                k0 += (c <= r0) ? 1 : 0;
-                k1 += (c <= r1) ? 1 : 0;
+            // rand(rng, Categorical(weights)) metropolis.jl:206
+            const uint32_t q0 = spare_pick12(dr.normal, 0), q1 = spare_pick12(dr.normal, 1);
+            k0 = s_pick[q0];
+            k1 = s_pick[q1];
+            const bool open = ((k0 | k1) & 0x80) != 0;
+            if ((__builtin_amdgcn_ballot_w64(open) | force_mask) != 0ull) {
+                // some chain's cell holds a cumulative weight: the accept draw supplies the pick's low 24 bits, and
+                // every chain of the wave walks the full 36-bit uniform (equal to its table entry where that was closed)
+                pu = philox4x32_10(accept_ctr, a.key0, a.key1);
+                have_pu = true;
+                k0 = categorical_walk(s_tab, K, uniform_pick(q0, pu.x));
+                k1 = categorical_walk(s_tab, K, uniform_pick(q1, pu.z));
             }
-            sg0 = s_tab[k0]; dn0 = s_tab[AMC_MAX_MOVES + k0]; lc0 = s_tab[2 * AMC_MAX_MOVES + k0];
-            sg1 = s_tab[k1]; dn1 = s_tab[AMC_MAX_MOVES + k1]; lc1 = s_tab[2 * AMC_MAX_MOVES + k1];
-            rd0 = s_tab[4 * AMC_MAX_MOVES + k0]; rd1 = s_tab[4 * AMC_MAX_MOVES + k1];
+            sg0 = s_tab[k0];
+            sg1 = s_tab[k1];
         }
         double z0, z1;
         box_muller(dr.normal, z0, z1, s_math);
-        const u32x4 pu = dr.accept;
-        unsigned long long m0, m1;
+        unsigned long long m0, m1m;
         uint32_t acc_bits;
-        mh_pair<POT, !MULTI>(xv, b0, b1, sg0, sg1, dn0, dn1, rd0, rd1, lc0, lc1, z0, z1, dr.normal, pu,
-                             draw_counter(pair, t, DRAW_ACCEPT, STREAM_METROPOLIS), a.key0, a.key1, s_math,
-                             a.exact_accept ? ~0ull : 0ull, acc_bits, m0, m1);
+        mh_pair<POT, MULTI>(xv, b0, b1, sg0, sg1, k0, k1, s_tab, m1, z0, z1, dr.normal, pu, have_pu, accept_ctr, a.key0,
+                            a.key1, s_math, force_mask, acc_bits, m0, m1m);
         // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
-        if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1 & __builtin_amdgcn_ballot_w64(v1));
+        if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1m & __builtin_amdgcn_ballot_w64(v1));
         if (LOG) {
             // Move.accepted_calls += accepted; Move.total_calls += 1 (metropolis.jl:208-209), deferred: see above
             log_word = acc_bits | ((uint32_t)k0 << 1) | ((uint32_t)k1 << 9);
@@ -478,9 +510,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pick[MULTI ? AMC_PICK_CELLS : 16];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
     const int K = a.n_moves;
     if (MULTI) {
+        stage_pick_table(s_pick, a.pick_tab);
         for (int i = threadIdx.x; i < K; i += AMC_BLOCK) {
             s_tab[0 * AMC_MAX_MOVES + i] = a.ptab[PT_SIGMA * AMC_MAX_MOVES + i];
             s_tab[1 * AMC_MAX_MOVES + i] = a.ptab[PT_DEN * AMC_MAX_MOVES + i];
@@ -531,7 +565,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // instructions per wave would otherwise start only after both have landed).
     constexpr bool AHEAD = SINGLE;
     StepDraws dr_nxt = {};
-    if (AHEAD && first < n_pairs) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
+    if (AHEAD && first < n_pairs) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load; ends in a barrier
     // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
     // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
@@ -553,10 +587,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
         const StepDraws dr = dr_nxt;
         uint32_t lw = 0;
-        pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_math,
+        pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_pick, s_math,
                                                    sigma1, den1, rden1, logc1, wave_acc, lw, &dr);
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
-        if (AHEAD) dr_nxt = step_draws<MULTI>(a, a.pair0 + (uint64_t)(p + stride), a.t0);
+        if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
         if (REDUCE) {      // the sums are Float64 whatever the state type (a Float32 sum over 1e7 chains keeps no digits)
             const double x0 = xv.x, x1 = xv.y;
             red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
@@ -579,7 +613,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
         uint32_t lw = 0;
         pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
-                                                   s_tab, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt);
+                                                   s_tab, s_pick, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt);
         // a lone last chain (odd n_chains) writes its whole pair (x and log): the odd slot is padding
         if (v0) {
             store_pair_block_writethrough(a.x + 2 * base, xv);
@@ -759,6 +793,24 @@ __global__ void prepare_params_kernel(double* ptab, int n_moves)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     prepare_params(ptab, n_moves);
+}
+
+// The move-pick table (see AMC_PICK_CELLS): cell c covers the pick uniforms r in [c, c+1) 2^-12 (both ends exact).
+// The walk's count #(cum[i] <= r), i < K-1, is monotone in r, so it is the same for every r of the cell iff it is the
+// same at the two ends: #(cum[i] <= c 2^-12) == #(cum[i] < (c+1) 2^-12).  Launched after prepare_params (same stream)
+// whenever the weights change.
+__global__ __launch_bounds__(AMC_BLOCK) void prepare_pick_kernel(const double* ptab, int n_moves, uint8_t* pick_tab)
+{
+    const int c = (int)(blockIdx.x * AMC_BLOCK + threadIdx.x);
+    if (c >= AMC_PICK_CELLS) return;
+    const double lo = (double)c * 0x1.0p-12, hi = (double)(c + 1) * 0x1.0p-12;
+    int n_lo = 0, n_hi = 0;
+    for (int i = 0; i < n_moves - 1; ++i) {
+        const double cum = ptab[PT_CUM * AMC_MAX_MOVES + i];
+        n_lo += (cum <= lo) ? 1 : 0;
+        n_hi += (cum < hi) ? 1 : 0;
+    }
+    pick_tab[c] = (n_lo == n_hi) ? (uint8_t)n_lo : (uint8_t)AMC_PICK_OPEN;
 }
 
 // ---- device-resident policy-gradient bookkeeping (src/PolicyGuided/estimator.jl:130-131, update.jl:50-57) ----
@@ -1173,7 +1225,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     constexpr int SCRATCH = (PG_GROUP * NL * 4 > TAB_DOUBLES) ? PG_GROUP * NL * 4 : TAB_DOUBLES;
     __shared__ double s_math[SCRATCH];
     __shared__ double s_tab[SWEEP == 2 ? 5 * AMC_MAX_MOVES : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pick[SWEEP == 2 ? AMC_PICK_CELLS : 16];
     if (SWEEP == 2) {
+        stage_pick_table(s_pick, sw.pick_tab);
         for (int i = threadIdx.x; i < sw.n_moves; i += AMC_BLOCK) {
             s_tab[0 * AMC_MAX_MOVES + i] = sw.ptab[PT_SIGMA * AMC_MAX_MOVES + i];
             s_tab[1 * AMC_MAX_MOVES + i] = sw.ptab[PT_DEN * AMC_MAX_MOVES + i];
@@ -1191,7 +1245,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     auto mh = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, int64_t p, bool v0, bool v1) {
         uint32_t lw = 0;
         // SWEEP == 3: K == 1 with the pool-wide counter only -- no step log
-        pair_steps<POT, SWEEP == 2, SWEEP != 3, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_math, sw_sigma1, sw_den1,
+        pair_steps<POT, SWEEP == 2, SWEEP != 3, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_pick, s_math, sw_sigma1, sw_den1,
                                                       sw_rden1, sw_logc1, wave_acc, lw);
         if (SWEEP != 3 && v0) store_log_pair(sw, sw.log_pos, p, lw);
     };

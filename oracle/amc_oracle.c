@@ -82,32 +82,49 @@ double amo_uniform_oc(uint32_t lo, uint32_t hi)      /* (0,1]: 2 - d (Box-Muller
     return 2.0 - bits_to_12(lo, hi, 0x3ff0000000000000ull);
 }
 
-double amo_angle_oc2(uint32_t lo, uint32_t hi)       /* (0,2]: 4 - d', d' in [2,4) (Box-Muller angle / pi) */
+/* Arithmetic spec v5.  How the 128 bits (x, y, z, w) of a step's NORMAL draw are used:
+ *   radius  u in (0,1]   the top 52 bits of (y:x)                          (unchanged since v2)
+ *   angle   w in (0,2]   the top 28 bits of word w: 2 - (w >> 4) 2^-27.  2^28 equally spaced angles: the two normals
+ *                        s sin(pi w), s cos(pi w) keep a continuous radius, and an average over equally spaced angles is
+ *                        the trapezoid rule on a periodic integrand -- exact for every Fourier mode below 2^28 --, so the
+ *                        marginals are Gaussian to far below anything 10^20 samples could resolve
+ *   spare   48 bits      x[11:0], z[31:0], w[3:0]: per chain of the pair 12 bits that lead its ACCEPT uniform and 12
+ *                        bits that lead its move-PICK uniform
+ *                          even chain: accept12 = x & 0xFFF          pick12 = z & 0xFFF
+ *                          odd  chain: accept12 = (z >> 12) & 0xFFF  pick12 = (z >> 24) | ((w & 0xF) << 8)
+ * and the chain's 64-bit word W of the step's ACCEPT draw (even: (y:x), odd: (w:z)):
+ *   accept uniform (rand(rng), metropolis.jl:184): 52-bit significand = accept12, then the top 40 bits of W -- Julia's
+ *                        rand(Float64) construction (d in [1,2) minus 1) on it
+ *   pick uniform (rand(rng, Categorical(weights)), :206): (pick12 2^24 + (W & 0xFFFFFF)) 2^-36
+ * Both uniforms are thus known to 2^-12 from the normal draw alone; the kernels form the accept draw only for the waves
+ * in which that bracket leaves an accept decision or a move pick open. */
+double amo_angle28(uint32_t w)                       /* (0,2]: Box-Muller angle / pi */
 {
-    return 4.0 - bits_to_12(lo, hi, 0x4000000000000000ull);
+    return 2.0 - (double)(w >> 4) * 0x1.0p-27;
 }
 
-/* Arithmetic spec v4: the accept uniform of rand(rng) in metropolis.jl:184 and the uniform
- * of rand(rng, Categorical(weights)) in :206, for one chain of a pair.
- *   normal_lo : the chain's LOW word of the step's NORMAL draw (even chain: x, odd: z); its low 12 bits are not
- *               used by the 52-bit Box-Muller maps
- *   (hi:lo)   : the chain's 64-bit word W of the step's ACCEPT draw (even: (y:x), odd: (w:z))
- * accept uniform: 52 bits, the TOP 12 from normal_lo, the other 40 the top 40 bits of W -- Julia's
- *               rand(Float64) construction (d in [1,2) minus 1) on that significand.  The kernels can bracket u from
- *               the normal draw alone and need the accept draw only when the bracket does not settle the decision.
- * move pick   : the low 24 bits of W. */
-double amo_uniform_accept(uint32_t normal_lo, uint32_t lo, uint32_t hi)
+uint32_t amo_spare_accept12(const uint32_t v[4], int half)
 {
-    uint64_t m = ((uint64_t)(normal_lo & 0xFFFu) << 40) | ((((uint64_t)hi << 32) | lo) >> 24);
+    return half ? ((v[2] >> 12) & 0xFFFu) : (v[0] & 0xFFFu);
+}
+
+uint32_t amo_spare_pick12(const uint32_t v[4], int half)
+{
+    return half ? ((v[2] >> 24) | ((v[3] & 0xFu) << 8)) : (v[2] & 0xFFFu);
+}
+
+double amo_uniform_accept(uint32_t accept12, uint32_t lo, uint32_t hi)
+{
+    uint64_t m = ((uint64_t)(accept12 & 0xFFFu) << 40) | ((((uint64_t)hi << 32) | lo) >> 24);
     uint64_t b = 0x3ff0000000000000ull | m;
     double d;
     memcpy(&d, &b, sizeof d);
     return d - 1.0;
 }
 
-double amo_uniform_pick(uint32_t lo)
+double amo_uniform_pick(uint32_t pick12, uint32_t lo)
 {
-    return (double)(lo & 0xFFFFFFu) * 0x1.0p-24;
+    return (double)(((uint64_t)(pick12 & 0xFFFu) << 24) | (uint64_t)(lo & 0xFFFFFFu)) * 0x1.0p-36;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -240,12 +257,12 @@ void amo_sincospi(double w, double *sp, double *cp)
  * (particle_1d.jl:57), i.e. Distributions.jl 0.25 `mu + sigma * randn(rng)`.
  * Julia's ziggurat is replaced by a Box-Muller pair in the shape of rocRAND's
  * box_muller_double(uint4) (rocrand_normal.h:78-98): u in (0,1] from words (x,y), w in (0,2]
- * from (z,w), z = sqrt(-2 log u) * (sinpi w, cospi w), with 52-bit uniforms and the table-driven
- * log / sincospi above.  One call serves a chain PAIR. */
+ * from word w, z = sqrt(-2 log u) * (sinpi w, cospi w), with a 52-bit radius uniform, a 28-bit angle
+ * (amo_angle28) and the table-driven log / sincospi above.  One call serves a chain PAIR. */
 void amo_box_muller(const uint32_t v[4], double z[2])
 {
     double u = amo_uniform_oc(v[0], v[1]);          /* (0,1] */
-    double w = amo_angle_oc2(v[2], v[3]);           /* (0,2] */
+    double w = amo_angle28(v[3]);                   /* (0,2] */
     double s = sqrt(-2.0 * amo_logbm(u));
     double sn, cs;
     amo_sincospi(w, &sn, &cs);
@@ -548,10 +565,10 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         draw4(s, pair, t, AMO_DRAW_NORMAL, AMO_STREAM_METROPOLIS, v);
         draw4(s, pair, t, AMO_DRAW_ACCEPT, AMO_STREAM_METROPOLIS, va);
         if (s->K > 1)                                              /* :206 */
-            id = amo_categorical(weights, s->K, amo_uniform_pick(va[2 * half]));
+            id = amo_categorical(weights, s->K, amo_uniform_pick(amo_spare_pick12(v, half), va[2 * half]));
         double zz[2];
         amo_box_muller(v, zz);
-        double u = amo_uniform_accept(v[2 * half], va[2 * half], va[2 * half + 1]);
+        double u = amo_uniform_accept(amo_spare_accept12(v, half), va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
         move->accepted_calls += s->f32 ? mc_step_f32(p, move, s->sigma[id], s->pot, zz[half], u)
                                        : mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */

@@ -56,9 +56,11 @@ void   amo_box_muller(const uint32_t v[4], double z[2]);
 double amo_logbm(double u);                         /* table-driven log for the Box-Muller radius */
 double amo_uniform_co(uint32_t lo, uint32_t hi);    /* [0,1), 52 bits: Julia's rand(Float64) construction */
 double amo_uniform_oc(uint32_t lo, uint32_t hi);    /* (0,1] */
-double amo_angle_oc2(uint32_t lo, uint32_t hi);     /* (0,2] */
-double amo_uniform_accept(uint32_t normal_lo, uint32_t lo, uint32_t hi);   /* [0,1), 52 bits: top 12 from the normal draw */
-double amo_uniform_pick(uint32_t lo);                /* [0,1), 24 bits: categorical move pick */
+double amo_angle28(uint32_t w);                      /* (0,2], the top 28 bits of the word */
+uint32_t amo_spare_accept12(const uint32_t v[4], int half);   /* spare bits of a normal draw: lead the chain's accept uniform */
+uint32_t amo_spare_pick12(const uint32_t v[4], int half);     /* ... and its move-pick uniform */
+double amo_uniform_accept(uint32_t accept12, uint32_t lo, uint32_t hi);   /* [0,1), 52 bits: top 12 from the normal draw */
+double amo_uniform_pick(uint32_t pick12, uint32_t lo);       /* [0,1), 36 bits: categorical move pick */
 double amo_potential(int pot, double x);
 /* AMO_POT_CUSTOM: `potential` is a free GLOBAL function of the driver script in the reference
  * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,

@@ -67,8 +67,10 @@ def load() -> C.CDLL:
         "amo_logbm": (C.c_double, [C.c_double]),
         "amo_uniform_co": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_uniform_oc": (C.c_double, [C.c_uint32, C.c_uint32]),
-        "amo_angle_oc2": (C.c_double, [C.c_uint32, C.c_uint32]),
-        "amo_uniform_pick": (C.c_double, [C.c_uint32]),
+        "amo_angle28": (C.c_double, [C.c_uint32]),
+        "amo_spare_accept12": (C.c_uint32, [u32p, C.c_int]),
+        "amo_spare_pick12": (C.c_uint32, [u32p, C.c_int]),
+        "amo_uniform_pick": (C.c_double, [C.c_uint32, C.c_uint32]),
         "amo_uniform_accept": (C.c_double, [C.c_uint32, C.c_uint32, C.c_uint32]),
         "amo_potential": (C.c_double, [C.c_int, C.c_double]),
         "amo_log_proposal_density": (C.c_double, [C.c_double, C.c_double]),
@@ -137,6 +139,12 @@ def sincospi(w):
     s, c = C.c_double(), C.c_double()
     load().amo_sincospi(w, C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def spare12(v, half):
+    """(accept12, pick12) of one chain of the pair from the words of its step's normal draw (spec v5)."""
+    a = (C.c_uint32 * 4)(*[int(x) for x in v])
+    return int(load().amo_spare_accept12(a, int(half))), int(load().amo_spare_pick12(a, int(half)))
 
 
 def box_muller(v):

@@ -1,6 +1,7 @@
 """bench.py's contract with the driver, on a real GPU: ONE JSON line with the agreed keys, for the single-process
-form and for the N > 1 code path (torch.distributed over RCCL, callbacks all-reduced every 10 sweeps) forced onto one
-rank -- the 8-GPU runs are the driver's, so this is the only place that path meets a device before round end."""
+form and for the N > 1 code path (ranks joined over the launcher's TCP store, callbacks all-reduced every 10 sweeps by the
+engine's own RCCL communicator) forced onto one rank -- the 8-GPU runs are the driver's, so this is the only place that
+path meets a device before round end."""
 import json
 import os
 import subprocess
@@ -17,7 +18,7 @@ M = 400_000
 def run_bench(extra_env, *args):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--spinup-s", "0.05",
-           "--chains-per-gpu", str(M), *args]
+           "--repeats", "3", "--chains-per-gpu", str(M), *args]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -36,7 +37,14 @@ def check_line(d, n_gpus, cb_every):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 16 * M
-    assert rf["valu_busy"] is None or 0.3 < rf["valu_busy"] < 1.0      # from the committed PMC passes (profiles/)
+    assert rf["valu_busy"] is None or 0.3 < rf["valu_busy"] < 1.0      # from the committed PMC passes (profiles/) ...
+    if rf["traffic"] is not None:                                      # ... and labelled as such
+        pv = rf["traffic_provenance"]
+        assert pv["measured_in_this_run"] is False and pv["source"].startswith("profiles/") and pv["commit"]
+        assert isinstance(pv["kernel_sources_unchanged_since"], bool)
+    assert "regime" in rf and ("infinity-cache" in rf["regime"] or "HBM" in rf["regime"])
+    rp = d["repeat"]
+    assert rp["blocks"] == 3 and rp["ms_per_step_min"] <= rp["ms_per_step_median"] and len(rp["ms_per_step_all"]) == 3
     # value = chains x steps / wall; the event-timed launches cannot take longer than the wall clock around them
     assert abs(d["value"] - M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
     assert rf["avg_launch_us"] <= d["ms_per_step"] * 1e3 * 1.05
@@ -55,3 +63,26 @@ def test_distributed_path_on_one_rank():
            "LOCAL_RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     d = run_bench(env, "--gpus", "1", "--no-cpu-baseline")
     check_line(d, 1, 10)
+
+
+def test_gpus_flag_without_a_launcher_is_an_error():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr
+
+
+def test_default_size_line_carries_the_ladder():
+    """At the default ensemble size the line also holds the M-ladder (4e7 and 1.6e8 chains: state far beyond the 256 MiB
+    Infinity Cache) next to the headline figure and its regime."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--spinup-s", "0.2", "--repeats", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    rf = d["roofline"]
+    assert "infinity-cache" in rf["regime"]
+    rows = rf["ladder"]
+    assert [row["chains"] for row in rows] == [40_000_000, 160_000_000]
+    for row in rows:
+        assert row["regime"].startswith("HBM") and 0.2 < row["frac"] < 1.0
+        assert abs(row["achieved_GBps"] - 16 * row["chains"] / row["us_per_launch_min"] / 1e3) < 1e-6 * row["achieved_GBps"]

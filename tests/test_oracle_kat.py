@@ -39,8 +39,9 @@ def test_draw_schedule_golden(oracle):
         lib = oracle.load()
         assert lib.amo_uniform_co(w[0], w[1]) == float.fromhex(d["u_co"][0])
         assert lib.amo_uniform_co(w[2], w[3]) == float.fromhex(d["u_co"][1])
-        assert lib.amo_uniform_pick(w[0]) == float.fromhex(d["pick"])
-        assert lib.amo_uniform_accept(w[3], w[0], w[1]) == float.fromhex(d["u_accept"])
+        assert [list(oracle.spare12(w, h)) for h in (0, 1)] == d["spare12"]
+        assert lib.amo_uniform_pick(d["spare12"][0][1], w[0]) == float.fromhex(d["pick"])
+        assert lib.amo_uniform_accept(d["spare12"][1][0], w[2], w[3]) == float.fromhex(d["u_accept"])
 
 
 def test_counter_packing_is_rocrand_layout(oracle):
@@ -65,11 +66,19 @@ def test_uniform_maps(oracle):
     assert lib.amo_uniform_co(0, 1 << 31) == 0.5 and lib.amo_uniform_co(1 << 12, 0) == 2.0 ** -52
     assert lib.amo_uniform_co((1 << 12) - 1, 0) == 0.0                       # low 12 bits of the low word unused
     assert lib.amo_uniform_oc(0, 0) == 1.0 and lib.amo_uniform_oc(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -52   # (0, 1]
-    assert lib.amo_angle_oc2(0, 0) == 2.0 and lib.amo_angle_oc2(0xFFFFFFFF, 0xFFFFFFFF) == 2.0 ** -51     # (0, 2]
-    # spec v4.  Move pick: the low 24 bits of the chain's accept-draw word.  Accept uniform: 52-bit significand whose
-    # top 12 bits are the normal draw's spare bits and whose other 40 are the top 40 bits of the accept-draw word.
-    assert lib.amo_uniform_pick(0) == 0.0 and lib.amo_uniform_pick(0xFFFFFFFF) == 1.0 - 2.0 ** -24
-    assert lib.amo_uniform_pick(0xFF000000) == 0.0 and lib.amo_uniform_pick(0x800000) == 0.5 and lib.amo_uniform_pick(1) == 2.0 ** -24
+    # spec v5.  Box-Muller angle: the top 28 bits of ONE word, 2 - (w >> 4) 2^-27 in (0, 2]
+    assert lib.amo_angle28(0) == 2.0 and lib.amo_angle28(0xFFFFFFFF) == 2.0 ** -27 and lib.amo_angle28(0xF) == 2.0
+    assert lib.amo_angle28(0x10) == 2.0 - 2.0 ** -27 and lib.amo_angle28(1 << 31) == 1.0
+    # spare bits of the normal draw (x[11:0], z, w[3:0]) -> (accept12, pick12) of the even and the odd chain
+    assert oracle.spare12([0xABCDE123, 0, 0, 0], 0) == (0x123, 0) and oracle.spare12([0, 0xFFFFFFFF, 0x00000456, 0xFFFFFFF0], 0) == (0, 0x456)
+    assert oracle.spare12([0xFFFFFFFF, 0xFFFFFFFF, 0x00789000, 0xFFFFFFF0], 1) == (0x789, 0)
+    assert oracle.spare12([0, 0, 0xBC000000, 0x0000000A], 1) == (0, 0xABC) and oracle.spare12([0] * 4, 1) == (0, 0)
+    assert oracle.spare12([0xFFFFFFFF] * 4, 0) == (0xFFF, 0xFFF) and oracle.spare12([0xFFFFFFFF] * 4, 1) == (0xFFF, 0xFFF)
+    # Move pick: 36 bits, pick12 on top of the low 24 bits of the chain's accept-draw word.  Accept uniform: 52-bit
+    # significand whose top 12 bits are accept12 and whose other 40 are the top 40 bits of the accept-draw word.
+    assert lib.amo_uniform_pick(0, 0) == 0.0 and lib.amo_uniform_pick(0xFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -36
+    assert lib.amo_uniform_pick(0, 0xFF000000) == 0.0 and lib.amo_uniform_pick(0x800, 0) == 0.5 and lib.amo_uniform_pick(0, 1) == 2.0 ** -36
+    assert lib.amo_uniform_pick(1, 0) == 2.0 ** -12 and lib.amo_uniform_pick(0xFFFFF001, 0) == 2.0 ** -12      # 12 bits taken
     assert lib.amo_uniform_accept(0, 0, 0) == 0.0 and lib.amo_uniform_accept(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -52
     assert lib.amo_uniform_accept(0x800, 0, 0) == 0.5 and lib.amo_uniform_accept(0xFFFFF001, 0, 0) == 2.0 ** -12
     assert lib.amo_uniform_accept(0, 1 << 24, 0) == 2.0 ** -52 and lib.amo_uniform_accept(0, (1 << 24) - 1, 0) == 0.0   # W's low 24 bits: the pick's
@@ -79,10 +88,11 @@ def test_uniform_maps(oracle):
         lo, hi = rnd.getrandbits(32), rnd.getrandbits(32)
         m = ((hi << 32) | lo) >> 12
         assert lib.amo_uniform_co(lo, hi) == m * 2.0 ** -52
+        assert lib.amo_uniform_oc(lo, hi) == 1.0 - m * 2.0 ** -52
         a = rnd.getrandbits(32)
         assert lib.amo_uniform_accept(a, lo, hi) == (((a & 0xFFF) << 40) | (((hi << 32) | lo) >> 24)) * 2.0 ** -52
-        assert lib.amo_uniform_oc(lo, hi) == 1.0 - m * 2.0 ** -52
-        assert lib.amo_angle_oc2(lo, hi) == 2.0 - m * 2.0 ** -51
+        assert lib.amo_uniform_pick(a, lo) == (((a & 0xFFF) << 24) | (lo & 0xFFFFFF)) * 2.0 ** -36
+        assert lib.amo_angle28(hi) == 2.0 - (hi >> 4) * 2.0 ** -27
 
 
 def test_box_muller_map(oracle):
@@ -93,7 +103,7 @@ def test_box_muller_map(oracle):
     for _ in range(3000):
         v = [rnd.getrandbits(32) for _ in range(4)]
         u = lib.amo_uniform_oc(v[0], v[1])
-        w = lib.amo_angle_oc2(v[2], v[3])
+        w = lib.amo_angle28(v[3])
         s = math.sqrt(-2.0 * math.log(u))
         z0, z1 = oracle.box_muller(v)
         r = math.fmod(w, 2.0)
@@ -157,7 +167,7 @@ def test_logbm_accuracy_sign_and_exact_zero(oracle):
 def test_sincospi_accuracy_and_quadrants(oracle):
     rnd = random.Random(4)
     for _ in range(50000):
-        w = oracle.load().amo_angle_oc2(rnd.getrandbits(32), rnd.getrandbits(32))
+        w = oracle.load().amo_angle28(rnd.getrandbits(32))
         s, c = oracle.sincospi(w)
         r = math.fmod(w, 2.0)
         assert abs(s - math.sin(math.pi * r)) < 1e-15 and abs(c - math.cos(math.pi * r)) < 1e-15
@@ -307,9 +317,9 @@ class _PhiloxCalls:
     """The per-chain generator of julia/PhiloxRNG.jl restated in Python: the reference's mc_sweep! makes three calls
     per mc_step! -- rand(rng, Categorical(w)), randn via Normal(0, sigma), rand(rng) (metropolis.jl:206,
     particle_1d.jl:57, metropolis.jl:184) -- and the n-th call of chain c maps to (step, kind) = divmod(n, 3):
-      kind 0  move pick      low 24 bits of the chain's word of draw 1
+      kind 0  move pick      12 spare bits of draw 0 on top of the low 24 bits of the chain's word of draw 1
       kind 1  normal         the chain's half of the Box-Muller pair of draw 0
-      kind 2  accept uniform 12 spare bits of draw 0 on top of the top 40 bits of the chain's word of draw 1"""
+      kind 2  accept uniform 12 (other) spare bits of draw 0 on top of the top 40 bits of the chain's word of draw 1"""
 
     def __init__(self, oracle, seed, chain):
         self.o, self.lib, self.seed, self.chain, self.calls = oracle, oracle.load(), seed, chain, 0
@@ -324,10 +334,10 @@ class _PhiloxCalls:
         t, kind = self._next((0, 2))
         pair, odd = self.chain >> 1, self.chain & 1
         va = self.o.draw_words(self.seed, pair, t, 1, 1)
+        accept12, pick12 = self.o.spare12(self.o.draw_words(self.seed, pair, t, 0, 1), odd)
         if kind == 0:
-            return self.lib.amo_uniform_pick(va[2 * odd])
-        vn = self.o.draw_words(self.seed, pair, t, 0, 1)
-        return self.lib.amo_uniform_accept(vn[2 * odd], va[2 * odd], va[2 * odd + 1])
+            return self.lib.amo_uniform_pick(pick12, va[2 * odd])
+        return self.lib.amo_uniform_accept(accept12, va[2 * odd], va[2 * odd + 1])
 
     def randn(self):
         t, _ = self._next((1,))

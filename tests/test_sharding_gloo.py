@@ -26,9 +26,15 @@ import montecarlo_amd as ma
 import oracle_lib as O
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
-if world > 1:
+use_store = os.environ.get("AMC_TEST_GROUP") == "store"       # the launcher's TCP store only: no process group at all
+if world > 1 and use_store:
+    from montecarlo_amd import sharding
+    rank = sharding.init_store_group().rank
+elif world > 1:
     dist.init_process_group("gloo")
-rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank()
+else:
+    rank = 0
 out = sys.argv[1]
 M, steps = 37, 60
 chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
@@ -47,7 +53,9 @@ res = dict(rank=rank, shard=list(sim.algorithms[0].shard), x=[v.hex() for v in c
            energy=[(t, float(v)) for t, v in cb.rows[0]], acceptance=[(t, [float(a) for a in v]) for t, v in cb.rows[1]],
            sigma=[float(m.sigma) for m in pool], accepted=[m.accepted_calls for m in pool], total=[m.total_calls for m in pool])
 json.dump(res, open(os.path.join(out, f"rank{{rank}}.json"), "w"))
-if world > 1:
+if world > 1 and use_store:
+    sharding.barrier()
+elif world > 1:
     dist.destroy_process_group()
 '''
 
@@ -58,12 +66,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(tmp_path, world, learn=True):
-    out = tmp_path / f"w{world}{'L' if learn else 'S'}"
+def run_world(tmp_path, world, learn=True, group="gloo"):
+    out = tmp_path / f"w{world}{'L' if learn else 'S'}{group}"
     out.mkdir()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, OMP_NUM_THREADS="1", AMC_TEST_LEARN="1" if learn else "0")
+    env = dict(os.environ, OMP_NUM_THREADS="1", AMC_TEST_LEARN="1" if learn else "0", AMC_TEST_GROUP=group)
     if world == 1:
         cmd = [sys.executable, str(script), str(out)]
     else:
@@ -105,3 +113,60 @@ def test_two_ranks_bit_exact_without_learning(tmp_path):
     assert two[0]["x"] + two[1]["x"] == one["x"]
     for r in two:
         assert r["sigma"] == [0.2, 0.1] and r["accepted"] == one["accepted"] and r["total"] == one["total"]
+
+
+@pytest.mark.slow
+def test_two_ranks_over_the_launchers_store_only(tmp_path):
+    """The same sharded run with NO process group: ranks meet through torch.distributed.run's TCP store
+    (sharding.init_store_group), sums of engines without a communicator are added on the host in rank order.  This is
+    the plumbing bench.py uses for N > 1 (there the sums go through the engines' own RCCL communicator)."""
+    one = run_world(tmp_path, 1, learn=False)[0]
+    two = run_world(tmp_path, 2, learn=False, group="store")
+    assert two[0]["shard"] == [0, 20] and two[1]["shard"] == [20, 37]
+    assert two[0]["x"] + two[1]["x"] == one["x"]
+    for r in two:
+        np.testing.assert_allclose([v for _, v in r["energy"]], [v for _, v in one["energy"]], rtol=1e-13)
+        assert r["accepted"] == one["accepted"] and r["total"] == one["total"]
+    assert two[0]["energy"] == two[1]["energy"]
+    learned = run_world(tmp_path, 2, learn=True, group="store")
+    ref = run_world(tmp_path, 2, learn=True)
+    for a, b in zip(learned, ref):
+        np.testing.assert_allclose(a["sigma"], b["sigma"], rtol=1e-12)       # gloo tree sum vs rank-order host sum
+
+
+def test_store_group_primitives_two_processes(tmp_path):
+    """barrier / allgather / broadcast / allreduce_sum of StoreGroup with rank 0 hosting the store (no torchrun)."""
+    script = tmp_path / "sg.py"
+    script.write_text(f"""
+import os, sys, json
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from montecarlo_amd import sharding
+g = sharding.init_store_group()
+assert sharding.world() == (g.rank, 2)
+g.barrier()
+got = g.allgather(dict(rank=g.rank, v=[g.rank] * 3))
+assert [d["rank"] for d in got] == [0, 1]
+uid = g.broadcast(bytes(range(128)) if g.rank == 0 else None)
+assert uid == bytes(range(128))
+s = sharding.allreduce_sum(np.array([1.0 + g.rank, 0.5, -g.rank]))
+assert list(s) == [3.0, 1.0, -1.0]
+sharding.barrier()
+json.dump(dict(ok=True), open(os.path.join({str(tmp_path)!r}, f"sg{{g.rank}}.json"), "w"))
+""")
+    # (a) under the driver's launcher: the agent hosts the store, the workers are its clients
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert all(json.load(open(tmp_path / f"sg{k}.json"))["ok"] for k in range(2))
+    for k in range(2):
+        os.remove(tmp_path / f"sg{k}.json")
+    # (b) started by hand: rank 0 hosts the store
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                                                     MASTER_PORT=str(port)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+    assert all(json.load(open(tmp_path / f"sg{r}.json"))["ok"] for r in range(2))
