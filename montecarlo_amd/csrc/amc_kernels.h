@@ -173,16 +173,18 @@ __device__ __forceinline__ bool accept_exact(real_t delta, real_t dlogp, double 
 //   spec exp vs exp   2 ulp f64                                                                            4e-16
 //   * (1 -+ eps)      one float rounding                                                                    6e-8
 // total < 3.1e-6; eps = 2^-16 = 1.5e-5 leaves a factor 5.  Outside the range: dlogp > 1e-12 -> arg > 0 -> accept;
-// dlogp < -17 -> the clamped estimate is an upper bound only.  NaN compares false everywhere -> undecided.
+// dlogp < -17 -> the clamped estimate e^-17 is an upper bound only, and serves as one: its "lower bound minus one" is
+// negative, so it can never claim an accept.  dlogp >= 0 gives ex >= 1, whose upper bound 4096 (1 + eps) exceeds every
+// k, so it can never claim a reject.  NaN compares false everywhere -> undecided.
 // Undecided when u's cell touches the interval (~1.2e-4 per chain-step, ~1.5 % of wave-steps); then the whole wave
 // forms the accept draw and takes accept_exact.
 #define AMC_FILTER_EPS 0x1.0p-16f
-// The five primitive comparisons of one chain; the decision masks are formed from their ballots on the scalar unit
-// (a ballot of a COMPOUND bool goes through a 0/1 VGPR and a second compare).  The sign tests use the float t:
-// |t| > 2e-12 implies |dlogp| > 1e-12 with room to spare (t = RN(dlogp), relative 6e-8); a dlogp that underflows to
+// The three primitive comparisons of one chain; the decision masks are formed from their ballots on the scalar unit
+// (a ballot of a COMPOUND bool goes through a 0/1 VGPR and a second compare).  The sign test uses the float t:
+// t > 2e-12 implies dlogp > 1e-12 with room to spare (t = RN(dlogp), relative 6e-8); a dlogp that underflows to
 // t = 0 simply is not settled by its sign.
 struct FilterCmp {
-    bool pos, neg, rng, lo, hi;
+    bool pos, lo, hi;
 };
 
 __device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
@@ -196,10 +198,8 @@ __device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
     const float hi = ex * ((1.0f + AMC_FILTER_EPS) * SCALE);
     FilterCmp c;
     c.pos = t > 2e-12f;                 // arg > 0: accept whatever u is
-    c.neg = t < -2e-12f;                // arg < 0
-    c.rng = t >= -17.0f;                // the estimate is two-sided
-    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-12 > u
-    c.hi = hi < kf;                     // exp(arg) < k 2^-12 <= u
+    c.lo = lo1 > kf;                    // exp(arg) > (k+1) 2^-12 > u   (never true below -17: lo1 < 0)
+    c.hi = hi < kf;                     // exp(arg) < k 2^-12 <= u      (never true for arg >= 0: hi > 4096)
     return c;
 }
 
@@ -266,8 +266,8 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
     const real_t xr0 = p0.xn + (-p0.delta), xr1 = p1.xn + (-p1.delta);
     const FilterCmp c0 = accept_filter(p0.dlogp, a0_12), c1 = accept_filter(p1.dlogp, a1_12);
 #define AMC_B(c) __builtin_amdgcn_ballot_w64(c)
-    const unsigned long long acc0 = AMC_B(c0.pos) | (AMC_B(c0.rng) & AMC_B(c0.lo)), rej0 = AMC_B(c0.neg) & AMC_B(c0.hi);
-    const unsigned long long acc1 = AMC_B(c1.pos) | (AMC_B(c1.rng) & AMC_B(c1.lo)), rej1 = AMC_B(c1.neg) & AMC_B(c1.hi);
+    const unsigned long long acc0 = AMC_B(c0.pos) | AMC_B(c0.lo), rej0 = AMC_B(c0.hi);
+    const unsigned long long acc1 = AMC_B(c1.pos) | AMC_B(c1.lo), rej1 = AMC_B(c1.hi);
     const unsigned long long undecided = AMC_B(true) & ~((acc0 | rej0) & (acc1 | rej1));
 #undef AMC_B
     if ((undecided | force_mask) != 0ull) {
@@ -289,7 +289,7 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
         xv.y = a1 ? p1.xn : xr1;
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
     } else {
-        const bool a0 = c0.pos | (c0.rng & c0.lo), a1 = c1.pos | (c1.rng & c1.lo);
+        const bool a0 = c0.pos | c0.lo, a1 = c1.pos | c1.lo;
         m0 = acc0;
         m1_out = acc1;
         xv.x = a0 ? p0.xn : xr0;

@@ -13,22 +13,23 @@ CHILD = r"""
 import os, sys, time
 sys.path.insert(0, sys.argv[1])
 from montecarlo_amd import _capi as A
-M = int(os.environ.get("M", 10_000_000)); K = int(os.environ.get("K", 1))
-sigma = [0.1, 1.0][:K]; weight = [[1.0], [0.5, 0.5]][K - 1]
-e = A.HipEngine(n_chains=M, potential="harmonic" if K == 1 else "double_well", beta=2.0, sigma=sigma, weight=weight,
-                seed=1, per_chain_counters=(K > 1))
-e.init_uniform(-2, 2)
-t0 = time.time()
-while time.time() - t0 < 0.6:
-    for _ in range(200): e.sweep(1)
-    e.sync()
-best = 1e9
-for rep in range(4):
-    e.timing_begin()
-    for _ in range(1000): e.sweep(1)
-    best = min(best, e.timing_end())
-print(f"{best:.2f}")
-e.close()
+M = int(os.environ.get("M", 10_000_000))
+def timed(e, f, n=400, reps=4):
+    t0 = time.time()
+    while time.time() - t0 < 0.5:
+        f(100); e.sync()
+    best = 1e9
+    for rep in range(reps):
+        e.timing_begin(); f(n); best = min(best, e.timing_end() / n * 1e3)
+    return best
+out = []
+e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=1, per_chain_counters=False)
+e.init_uniform(-2, 2); out.append(timed(e, lambda n: [e.sweep(1) for _ in range(n)])); e.close()
+e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
+e.init_uniform(-2, 2); out.append(timed(e, lambda n: [e.sweep(1) for _ in range(n)])); e.close()
+e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=1)
+e.init_uniform(-2, 2); out.append(timed(e, lambda n: e.pgmc_steps(n, [1], 1, [1], [1e-3], [0.0]), 200)); e.close()
+print(" ".join(f"{v:6.2f}" for v in out))
 """
 
 if sys.argv[1] == "snapshot":
@@ -45,5 +46,6 @@ else:
         for n in names:
             out = subprocess.run([sys.executable, "-c", CHILD, os.path.join(VAR, n)], capture_output=True, text=True)
             res[n].append(out.stdout.strip() or out.stderr.strip()[-120:])
+    print("us per launch at 1e7 chains: K=1 sweep, K=2 double-well sweep, fused PGMC step (config 5); one column group per round")
     for n in names:
-        print(f"{n:24s} " + "  ".join(res[n]), flush=True)
+        print(f"{n:24s} " + "  |  ".join(res[n]), flush=True)
