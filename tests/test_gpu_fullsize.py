@@ -242,6 +242,122 @@ def test_device_resident_learning_matches_host_path_and_oracle(gpu, oracle, tmp_
     assert eng.get_parameters(1)[0] == pool_d[1].sigma                           # the bad step was not applied
 
 
+def test_config4_eight_shards_of_1e7_on_one_device(gpu, oracle):
+    """BASELINE config 4 (particle_1d harmonic, 8 x 1e7 chains sharded over 8 GPUs, energy / acceptance callbacks
+    all-reduced every 10 sweeps; the reference maps mc_sweep! over eachindex(chains), src/metropolis.jl:302-309) with the
+    eight shards as eight handles on ONE device: chain_offset = r 1e7, n_chains_global = 8e7, the callback sums formed in
+    the sweep launches and added in rank order (what sharding.allreduce_sum does across processes).  Checks: slices of
+    every shard equal the oracle's run of the same GLOBAL chain ids bit for bit; the sharded ensemble equals ONE handle
+    holding all 8e7 chains -- positions bit for bit, accepted totals exactly, callback sums to the reduction tolerance --;
+    and the callbacks themselves sit on the analytic values."""
+    from montecarlo_amd import sharding
+    W, M_SHARD, sweeps, cb_every = 8, M_FULL, 30, 10
+    M_GLOBAL = W * M_SHARD
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=1, per_chain_counters=False)
+    shards = []
+    for r in range(W):
+        start, stop = sharding.shard_range(M_GLOBAL, r, W)
+        assert (start, stop) == (r * M_SHARD, (r + 1) * M_SHARD)
+        e = gpu.HipEngine(n_chains=stop - start, chain_offset=start, n_chains_global=M_GLOBAL, **kw)
+        e.init_uniform(-2.0, 2.0)
+        shards.append(e)
+    big = gpu.HipEngine(n_chains=M_GLOBAL, **kw)
+    big.init_uniform(-2.0, 2.0)
+    rows_sharded, rows_big = [], []
+    for t in range(1, sweeps + 1):
+        if t % cb_every == 0:
+            for e in shards:
+                e.sweep_reduce_begin(1)                   # sums formed inside the sweep launch, as in bench.py
+            parts = [e.reduce_end() for e in shards]
+            total = parts[0].copy()
+            for p_ in parts[1:]:
+                total = total + p_                        # rank order: sharding.StoreGroup.allreduce_sum
+            rows_sharded.append(total)
+            big.sweep_reduce_begin(1)
+            rows_big.append(big.reduce_end())
+        else:
+            for e in shards:
+                e.sweep(1)
+            big.sweep(1)
+    for got, want in zip(rows_sharded, rows_big):
+        assert got[3] == want[3] == M_GLOBAL
+        np.testing.assert_allclose(got, want, rtol=1e-11)
+        assert got[4] == pytest.approx(want[4], rel=1e-15)       # accepted totals / steps counted: integers, one rounding
+    # the callbacks' values 30 sweeps after U(-2,2): <e> on its way down from 4/3 to 1/(2 beta), the acceptance of the
+    # outlying chains (0.7 at |x| = 2) still pulls the cumulative ratio below its equilibrium 0.9365
+    assert 0.85 < rows_sharded[-1][4] / M_GLOBAL < 0.94 and 0.25 < rows_sharded[-1][0] / M_GLOBAL < 4.0 / 3.0
+    acc_total = sum(int(e.counter_totals()[0][0]) for e in shards)
+    assert acc_total == int(big.counter_totals()[0][0])
+    for r, e in enumerate(shards):
+        for off in (0, 5_000_000 - 2048, M_SHARD - 4096):
+            got = e.download_strided(off, 1, 4096)
+            assert np.array_equal(bits(got), bits(big.download_strided(r * M_SHARD + off, 1, 4096)))
+            o = oracle.OracleSim(4096, chain_offset=r * M_SHARD + off, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=1)
+            o.init_uniform(-2.0, 2.0)
+            o.make_steps(sweeps, threads=4)
+            assert np.array_equal(bits(got), bits(o.state()[0])), (r, off)
+            o.close()
+    for e in shards + [big]:
+        e.close()
+
+
+def test_config5_pgmc_at_1e7_chains_through_pgmc_steps(gpu, oracle):
+    """BASELINE config 5 at its full size: PolicyGuided MC on particle_1d, M = 1e7 chains, pool sigma = (0.2, 0.1),
+    w = (0.6, 0.4), optimisers (Static, VPG), q_batch_size = 1, sampler + estimator + update every time step
+    (PGMC_harmonic_oscillator.jl:14-33; src/PolicyGuided/estimator.jl:111-134), issued through amc_pgmc_steps (one fused
+    sweep + estimator launch per step, learning step in the launch's tail).
+      1. 16 steps one call at a time.  Oracle runs of three 4096-chain slices (same global chain ids) take the sweep and
+         the estimator's always-reverted samples per step with sigma set to what the device learned (the learned sigma
+         depends on 1e7-term sums whose order differs): positions and per-chain counters bit for bit after every step.
+      2. The device's sigma trajectory against a FULL 1e7-chain oracle run (its own sequential fold + learning_step!)
+         over the first 3 steps: rtol 1e-10.
+      3. 400 more steps in one call: sigma_2 -> 1.2 +- 0.2, sigma_1 stays 0.2 exactly, <e> = 0.25 (pgmc_test.jl:45,50)."""
+    eta, n_follow, n_full = 0.5, 16, 3
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
+    e = gpu.HipEngine(n_chains=M_FULL, **kw)
+    e.init_uniform(-2.0, 2.0)
+    offs = (0, 4_999_998, M_FULL - 4096)
+    slices = []
+    for off in offs:
+        o = oracle.OracleSim(4096, chain_offset=off, **kw)
+        o.init_uniform(-2.0, 2.0)
+        slices.append(o)
+    full = oracle.OracleSim(M_FULL, **kw)
+    full.init_uniform(-2.0, 2.0)
+    sig_dev, sig_full = [], []
+    for t in range(n_follow):
+        e.pgmc_steps(1, [1], 1, [1], [eta], [0.0])          # optimiser id 1 = VPG
+        s1 = float(e.get_parameters(1)[0])
+        sig_dev.append(s1)
+        assert e.get_parameters(0)[0] == 0.2
+        for o, off in zip(slices, offs):
+            o.make_steps(1)
+            o.pg_estimate([1], 1)                           # moves x to (x + d) - d like the reference
+            o.set_sigma(1, s1)
+            assert np.array_equal(bits(e.download_strided(off, 1, 4096)), bits(o.state()[0])), (t, off)
+        if t < n_full:
+            full.make_steps(1, threads=16)
+            gd = full.pg_estimate([1], 1)[0]
+            full.set_sigma(1, oracle.learning_step("VPG", eta, 0.0, full.get_sigma(1), list(gd[:4] / gd[4])))
+            sig_full.append(full.get_sigma(1))
+    np.testing.assert_allclose(sig_dev[:n_full], sig_full, rtol=1e-10)
+    assert sig_dev[0] != 0.1 and all(b > a for a, b in zip(sig_dev, sig_dev[1:]))      # sigma grows towards 1.2
+    acc, tot = e.download_counters()
+    for o, off in zip(slices, offs):
+        ao, to = o.counters()
+        assert np.array_equal(acc[:, off:off + 4096], ao) and np.array_equal(tot[:, off:off + 4096], to)
+        o.close()
+    full.close()
+    del acc, tot
+    e.pgmc_steps(400, [1], 1, [1], [eta], [0.0])
+    assert e.get_parameters(0)[0] == 0.2
+    assert float(e.get_parameters(1)[0]) == pytest.approx(KATS["pgmc"]["sigma_star"], abs=KATS["pgmc"]["sigma_atol"])
+    red = e.reduce()
+    assert red[0] / M_FULL == pytest.approx(0.25, abs=2e-3)
+    assert np.all(e.pg_get_accumulated([1])[:, 4] == 0)     # every step ended in an update: accumulators are empty
+    e.close()
+
+
 def test_pgmc_example_learning_curve_on_device(gpu):
     """The reference's published PGMC learning curve (learning.png of PGMC_harmonic_oscillator.jl):
     VPG eta = 1e-3 takes sigma_2 from 0.1 to ~0.33 at t = 1e3.  Same configuration on the device with 2e5 chains (the

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Developer tool, run on the GPU box (gpurun -- 'bash tools/gpu_profile_r2.sh'): rocprofv3 kernel-trace summaries and
+# PMC passes (own runs, counters only) of bench.py and of the round-2 workloads; tools/summarize_profiles_r2.py turns
+# what lands in gpurun_out/r02/ into the committed files under profiles/.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r02
+rm -rf $O; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats -d $O/bench_trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-ladder > $O/bench_prof.json 2> $O/bench_prof.err
+echo "bench trace done"
+W="python3 $R/tools/gpu_r2_workload.py"
+for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "est"; do
+  tag=$(echo $wl | tr ' ' '_')
+  rocprofv3 --kernel-trace --stats -d $O/$tag/trace --output-format csv -- $W $wl > $O/$tag.log 2>&1
+  LAUNCHES=120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$tag/pmc_fetch --output-format csv -- $W $wl > /dev/null 2>&1
+  LAUNCHES=120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$tag/pmc_write --output-format csv -- $W $wl > /dev/null 2>&1
+  LAUNCHES=120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/$tag/pmc_sq --output-format csv -- $W $wl > /dev/null 2>&1
+  LAUNCHES=120 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace -d $O/$tag/pmc_sq2 --output-format csv -- $W $wl > /dev/null 2>&1
+  echo "$tag done: $(cat $O/$tag.log | tail -1)"
+done
+# keep the merge small: the per-dispatch traces are large, the summaries are what is needed
+find $O -name "*_kernel_trace.csv" -size +2M -delete
+find $O -name "*.db" -delete
+du -sh $O
+cat $O/bench_n1.json

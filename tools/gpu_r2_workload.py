@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Developer tool (round 2): the workloads profiled under rocprofv3 for profiles/r02_*.
+
+  ladder <M>   single-sweep launches of the headline kernel (harmonic, K = 1, pool-wide counter) at M chains
+  k2           BASELINE config 3 shape: double well, K = 2 (sigma 0.1 / 1.0), one launch per sweep, callbacks every 10
+  pgmc         BASELINE config 5: amc_pgmc_steps at 1e7 chains (fused sweep + estimator + update per step), callbacks every 10
+  est          the estimator launch alone (amc_pg_accumulate) on the config-5 pool
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from montecarlo_amd import _capi as A
+
+mode = sys.argv[1]
+n = int(os.environ.get("LAUNCHES", "300"))
+
+
+def spin(e, seconds=0.5):
+    """the GPU needs ~0.1-0.5 s of load to reach its sustained clock (same spin-up as bench.py)"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            e.sweep(1)
+        e.sync()
+
+
+if mode == "ladder":
+    M = int(sys.argv[2])
+    e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1], weight=[1.0], seed=1, per_chain_counters=False)
+    e.init_uniform(-2, 2)
+    spin(e)
+    n = max(20, min(n, int(3_000_000_000 // M)))
+    for rep in range(2):
+        e.timing_begin()
+        for _ in range(n):
+            e.sweep(1)
+        us = e.timing_end() * 1e3 / n
+    print(f"ladder M={M}: {us:.2f} us per launch, {16 * M / us / 1e3:.1f} GB/s")
+elif mode == "k2":
+    M = 10_000_000
+    e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
+    e.init_uniform(-2, 2)
+    spin(e)
+    for rep in range(2):
+        e.timing_begin()
+        for i in range(n):
+            if (i + 1) % 10 == 0:
+                e.sweep_reduce_begin(1); e.reduce_end()
+            else:
+                e.sweep(1)
+        us = e.timing_end() * 1e3 / n
+    print(f"k2 (config 3 shape): {us:.2f} us per time step incl. callbacks every 10")
+elif mode in ("pgmc", "est"):
+    M = 10_000_000
+    e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
+    e.init_uniform(-2, 2)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        (e.pgmc_steps(20, [1], 1, [1], [0.0], [0.0]) if mode == "pgmc" else [e.pg_accumulate([1], 1) for _ in range(20)])
+        e.sync()
+    for rep in range(2):
+        e.timing_begin()
+        if mode == "pgmc":
+            for i in range(n // 10):
+                e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0])
+                e.reduce()
+        else:
+            for _ in range(n):
+                e.pg_accumulate([1], 1)
+        us = e.timing_end() * 1e3 / (n // 10 * 10 if mode == "pgmc" else n)
+    print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}; sigma = {e.get_parameters(1)[0]:.4f}")
+e.close()
