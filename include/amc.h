@@ -158,6 +158,22 @@ int  amc_create_model(const amc_config *cfg, const char *potential_expr, const c
  * and its sigma-derivative at the old state and the backward ones at the new state (gradients.jl:97,102,106). */
 int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
                              const char *scale_expr, amc_handle **out);
+/* A script-defined PROPOSAL in full: the model's own sample_action! and log_proposal_density (the generic functions of
+ * src/metropolis.jl:35-62; example/particle_1d/particle_1d.jl:52-59 are the particle_1d model's methods), each as ONE C
+ * expression, compiled at run time like the potential:
+ *     sample_expr   delta = f(z, x, sigma): the displacement from one standard normal variate `z` (the engine's
+ *                   Box-Muller draw of the step), the current position `x` and the move's parameter `sigma`
+ *                   -- e.g. a drifted (Langevin) proposal "-sigma*sigma*x + sigma*z"
+ *     logq_expr     log q(delta | x, sigma), the log-density of what sample_expr returns (normalisation included where it
+ *                   depends on x or sigma); mc_step! evaluates it for the forward action at the old state and for the
+ *                   inverted action (-delta) at the new state (metropolis.jl:178,182)
+ *     dlogq_expr    d logq / d sigma -- what the reference obtains from ForwardDiff / Enzyme / Zygote
+ *                   (src/PolicyGuided/gradients.jl:28-33); NULL: the handle runs sweeps, the estimator entry points
+ *                   return AMC_ERR_STATE
+ * Variables: z, x, sigma, delta; vocabulary as for amc_create_custom.  potential_expr NULL: cfg->potential's built-in.
+ * Float64 state only.  Every accept decision takes the reference-ordered arithmetic (no accept filter). */
+int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
+                               const char *sample_expr, const char *logq_expr, const char *dlogq_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
 int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);
 

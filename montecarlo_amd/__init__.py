@@ -17,7 +17,7 @@ from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCall
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
 from .trajectories import DAT, TXT, StoreBackups, StoreLastFrames, StoreTrajectories
 from .system import Action, AriannaSystem, Policy
-from .system import CustomPotential, Displacement, Move, ParticleChains, ScaledGaussian, StandardGaussian, potential
+from .system import CustomPotential, Displacement, Move, ParticleChains, ScaledGaussian, ScriptPolicy, StandardGaussian, potential
 
 __all__ = [
     "AmcError", "HipEngine", "SplitEngine", "device_count",
@@ -30,5 +30,5 @@ __all__ = [
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
     "DAT", "TXT", "StoreBackups", "StoreLastFrames", "StoreTrajectories",
-    "Action", "AriannaSystem", "Policy", "CustomPotential", "Displacement", "Move", "ParticleChains", "ScaledGaussian", "StandardGaussian", "potential",
+    "Action", "AriannaSystem", "Policy", "CustomPotential", "Displacement", "Move", "ParticleChains", "ScaledGaussian", "ScriptPolicy", "StandardGaussian", "potential",
 ]

@@ -79,6 +79,8 @@ def load() -> C.CDLL:
         "amc_create_custom": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.POINTER(H)]),
         "amc_create_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_create_policy_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(H)]),
+        "amc_create_proposal_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                                C.POINTER(H)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -163,7 +165,8 @@ class HipEngine:
                  potential="harmonic", beta: float = 1.0, sigma: Sequence[float] = (1.0,),
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
-                 reward_expr: Optional[str] = None, dtype: str = "f64", scale_expr: Optional[str] = None):
+                 reward_expr: Optional[str] = None, dtype: str = "f64", scale_expr: Optional[str] = None,
+                 proposal: Optional[Sequence[Optional[str]]] = None):
         lib = load()
         if str(dtype) not in STATE_DTYPES:
             raise AmcError(f"unknown state dtype {dtype!r}; one of {sorted(STATE_DTYPES)}")
@@ -194,7 +197,17 @@ class HipEngine:
         cfg.state_dtype = STATE_DTYPES[self.dtype]
         self._lib = lib
         self._h = C.c_void_p()
-        if scale_expr is not None:
+        enc = lambda t: None if t is None else str(t).encode()
+        if proposal is not None:
+            # script-defined sample_action! / log_proposal_density (/ its sigma-derivative): (sample, logq, dlogq or None)
+            if scale_expr is not None:
+                raise AmcError("a script-defined proposal and a ScaledGaussian scale cannot be combined")
+            sample, logq, dlogq = (list(proposal) + [None])[:3]
+            if expr is None:
+                cfg.potential = POTENTIALS[potential]
+            _check(lib.amc_create_proposal_model(C.byref(cfg), enc(expr), enc(reward_expr), enc(sample), enc(logq), enc(dlogq),
+                                                 C.byref(self._h)))
+        elif scale_expr is not None:
             # script-defined policy of the Gaussian-displacement family: proposal width sigma * scale(x)
             if expr is None:
                 cfg.potential = POTENTIALS[potential]

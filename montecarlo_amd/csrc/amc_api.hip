@@ -119,7 +119,9 @@ struct amc_handle {
     bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
     bool f32 = false;             // state_dtype == AMC_DTYPE_F32: d_x / d_beta hold floats
-    bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model): no estimator kernels
+    bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model)
+    bool script_policy = false;   // sample_action! / log_proposal_density are script-defined expressions (amc_create_proposal_model)
+    bool script_dlogq = false;    // ... and so is d logq / d sigma: the estimator is available
     bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
     double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
@@ -434,17 +436,24 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCo
         }
     }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
-    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] ]
+    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ] ] ]
     const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
     const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
     std::string expr = expr_full;
     std::string src;
     if (f32) src += "#define AMC_STATE_F32 1\n";
-    const size_t cut_scale = expr.find('\x03');          // ... [ '\x03' proposal-width scale ]
-    if (cut_scale != std::string::npos) {
-        src += "#define AMC_USER_SCALE(x) (" + expr.substr(cut_scale + 1) + ")\n";
-        expr.erase(cut_scale);
-    }
+    auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
+        const size_t at = expr.find(mark);
+        if (at == std::string::npos) return std::string();
+        const std::string tail = expr.substr(at + 1);
+        expr.erase(at);
+        return tail;
+    };
+    const std::string e_dlogq = cut_tail('\x06'), e_logq = cut_tail('\x05'), e_sample = cut_tail('\x04'), e_scale = cut_tail('\x03');
+    if (!e_sample.empty()) src += "#define AMC_USER_SAMPLE(z, x, sigma) (" + e_sample + ")\n";
+    if (!e_logq.empty()) src += "#define AMC_USER_LOGQ(delta, x, sigma) (" + e_logq + ")\n";
+    if (!e_dlogq.empty()) src += "#define AMC_USER_DLOGQ(delta, x, sigma) (" + e_dlogq + ")\n";
+    if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
     const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
@@ -551,8 +560,10 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
+struct ProposalExprs { const char *sample, *logq, *dlogq; };
+
 static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
-                       const char* scale_expr = nullptr)
+                       const char* scale_expr = nullptr, const ProposalExprs* proposal = nullptr)
 {
     if (!cfg || !out) return fail(AMC_ERR_BAD_ARG, "amc_create: NULL argument");
     *out = nullptr;
@@ -583,6 +594,14 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         if (scale_expr) {
             const int rc_sc = validate_potential_expr(scale_expr, "proposal-width scale", "x");
             if (rc_sc != AMC_OK) return rc_sc;
+        }
+        if (proposal) {
+            int rc_p = validate_potential_expr(proposal->sample, "sample_action expression", "z");
+            if (rc_p == AMC_OK) rc_p = validate_potential_expr(proposal->logq, "log_proposal_density expression", "delta");
+            if (rc_p == AMC_OK && proposal->dlogq) rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "sigma");
+            if (rc_p != AMC_OK) return rc_p;
+            if (state_dtype != AMC_DTYPE_F64)
+                return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: script-defined proposals are offered for Float64 state");
         }
     } else if (potential_expr) {
         return fail(AMC_ERR_BAD_ARG, "amc_create_custom: cfg->potential must be AMC_POTENTIAL_CUSTOM");
@@ -642,6 +661,12 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (potential_expr) h->pot_expr += potential_expr;
     if (potential_expr && reward_expr) h->pot_expr += std::string("\x01") + reward_expr;
     if (potential_expr && scale_expr) { h->pot_expr += std::string("\x03") + scale_expr; h->scaled_policy = true; }
+    if (potential_expr && proposal) {
+        h->pot_expr += std::string("\x04") + proposal->sample + std::string("\x05") + proposal->logq;
+        if (proposal->dlogq) h->pot_expr += std::string("\x06") + proposal->dlogq;
+        h->script_policy = true;
+        h->script_dlogq = proposal->dlogq != nullptr;
+    }
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
     h->counters = cfg->per_chain_counters != 0 || cfg->n_moves > 1;
@@ -780,6 +805,26 @@ int amc_create_policy_model(const amc_config* cfg, const char* potential_expr, c
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
     c2.potential = AMC_POTENTIAL_CUSTOM;
     return create_impl(&c2, pot, out, reward_expr, scale_expr);
+}
+
+int amc_create_proposal_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* sample_expr,
+                              const char* logq_expr, const char* dlogq_expr, amc_handle** out)
+{
+    if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: NULL argument");
+    if (!sample_expr || !logq_expr)
+        return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: sample_expr and logq_expr are both required (No sample_action! / log_proposal_density is defined)");
+    const char* pot = potential_expr;
+    if (!pot) {
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: potential_expr is NULL and cfg->potential names no built-in");
+    }
+    amc_config c2;
+    std::memset(&c2, 0, sizeof(c2));
+    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
+    c2.potential = AMC_POTENTIAL_CUSTOM;
+    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr};
+    return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 
 int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
@@ -1396,6 +1441,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         if (learn_ids[l] < 0 || learn_ids[l] >= h->K)
             return fail(AMC_ERR_BAD_ARG, "%s: learn_ids[%d] = %d out of range", who, l, learn_ids[l]);
     *nl_out = 0;
+    if (h->script_policy && !h->script_dlogq && n_learn > 0)
+        return fail(AMC_ERR_STATE, "%s: this handle's script-defined proposal came without d logq / d sigma (dlogq_expr): "
+                                   "No withgrad_log_proposal_density! is defined", who);
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;

@@ -100,6 +100,34 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
     return (double)(real_t)(AMC_USER_SCALE(x));      // a function of the system returns T; sigma * scale promotes
 }
 #endif
+// A script-defined PROPOSAL in full (amc_create_proposal_model): the model's own sample_action! and
+// log_proposal_density (example/particle_1d/particle_1d.jl:52-59 are the particle_1d model's; src/metropolis.jl:35-62
+// only declare the generic functions), each as one expression:
+//   AMC_USER_SAMPLE(z, x, sigma)      delta, from ONE standard normal variate z (the engine's Box-Muller draw of the
+//                                     step), the current position x and the move's parameter sigma
+//   AMC_USER_LOGQ(delta, x, sigma)    log q(delta | x, sigma): the density of what AMC_USER_SAMPLE returns
+//   AMC_USER_DLOGQ(delta, x, sigma)   its derivative with respect to sigma (what the reference gets from ForwardDiff /
+//                                     Enzyme / Zygote, gradients.jl:28-33); optional, needed by the estimator only
+// mc_step! (metropolis.jl:176-190) evaluates the forward density at the old state and the backward one, of the
+// inverted action, at the new state; nothing cancels, every decision takes the reference-ordered arithmetic.
+#ifdef AMC_USER_LOGQ
+__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_)
+{
+    return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
+}
+__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_)
+{
+    return (double)(AMC_USER_LOGQ(delta, x, sigma));
+}
+__device__ __forceinline__ double user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_)
+{
+#ifdef AMC_USER_DLOGQ
+    return (double)(AMC_USER_DLOGQ(delta, x, sigma));
+#else
+    return __builtin_nan("");                         // the host refuses the estimator for such a handle
+#endif
+}
+#endif
 #undef amc_exp
 #undef amc_log
 
@@ -230,6 +258,28 @@ __device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, 
 }
 #endif
 
+#ifdef AMC_USER_LOGQ
+// One mc_step! with a script-defined proposal (see user_sample / user_logq), in the reference's operation order
+// (metropolis.jl:176-190).
+template <int POT>
+__device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, double z, double u, const double* T)
+{
+    const real_t delta = user_sample(z, x, sigma, T);                    // :177 sample_action!
+    const double logq_f = user_logq(delta, x, sigma, T);                 // :178
+    const real_t e1 = potential<POT>(x, T);
+    const real_t xn = x + delta;                                         // :179 perform_action!
+    const real_t e2 = potential<POT>(xn, T);
+    const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
+    const real_t nd = -delta;                                            // :181 invert_action!
+    const double logq_b = user_logq(nd, xn, sigma, T);                   // :182
+    const double arg = ((double)dlogp + logq_b) - logq_f;                // :183
+    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
+    const bool acc = c_pos | (c_rng & c_exp);
+    x = acc ? xn : (real_t)(xn + nd);                                    // :187 perform_action_cached!
+    return acc;
+}
+#endif
+
 // What the exact decision of a chain needs from its move besides sigma: den = 2 sigma^2, RN(1/den), log(2 pi sigma^2)/2.
 // K == 1: the pool's only move, wave-uniform scalars.  K > 1: read from the LDS copy of the move table by the chain's
 // move index -- inside the undecided arm only, the common path reads sigma alone.
@@ -251,11 +301,16 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
                                         unsigned long long& m1_out)
 {
     const uint32_t a0_12 = spare_accept12(pn, 0), a1_12 = spare_accept12(pn, 1);
-#ifdef AMC_USER_SCALE
+#if defined(AMC_USER_SCALE) || defined(AMC_USER_LOGQ)
     {
         if (!have_pu) pu = philox4x32_10(accept_ctr, key0, key1);
+#ifdef AMC_USER_LOGQ
+        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
+        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
+#else
         const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
         const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
+#endif
         m0 = __builtin_amdgcn_ballot_w64(a0);
         m1_out = __builtin_amdgcn_ballot_w64(a1);
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
@@ -1150,6 +1205,36 @@ __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double 
 }
 #endif
 
+#ifdef AMC_USER_LOGQ
+// pgmc_estimate (gradients.jl:93-109) with a script-defined proposal: value and sigma-derivative of the forward density
+// at the old state (:97), of the backward density at the new state (:102); grad_j takes the forward gradient when
+// alpha == 1, else the backward one (:106).
+template <int POT>
+__device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[4], const double* T)
+{
+    const real_t delta = user_sample(z, x, sigma, T);
+    const double logq_f = user_logq(delta, x, sigma, T), dlogq_f = user_dlogq(delta, x, sigma, T);
+    const real_t e1 = potential<POT>(x, T);
+    const real_t xn = x + delta;
+    const real_t e2 = potential<POT>(xn, T);
+    const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
+    const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
+    const real_t nd = -delta;
+    const double logq_b = user_logq(nd, xn, sigma, T), dlogq_b = user_dlogq(nd, xn, sigma, T);
+    x = xn + nd;
+    const double arg = ((double)dlogp + logq_b) - logq_f;
+    double ex = exp_core_f64(arg, T);
+    asm volatile("" : "+v"(ex));
+    double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
+    alpha = (arg >= 0.0) ? 1.0 : alpha;
+    const double j = r * alpha;
+    g[0] += j;
+    g[1] += j * ((alpha == 1.0) ? dlogq_f : dlogq_b);
+    g[2] += dlogq_f;
+    g[3] += dlogq_f * dlogq_f;
+}
+#endif
+
 // One pgmc_estimate sample of the StandardGaussian policy.  What leaves this function per chain is (a) the position,
 // x = (x + delta) + (-delta) in the reference's operations (bit-exact against the oracle), and (b) four SUMMANDS of
 // GradientData (j, grad j, grad logq, g: gradients.jl:104-108), which the reference folds with `+` over 1e7 chains in
@@ -1287,7 +1372,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1, s_math);
-#ifdef AMC_USER_SCALE
+#if defined(AMC_USER_LOGQ)
+                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
+                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);
+#elif defined(AMC_USER_SCALE)
                     pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);
 #else

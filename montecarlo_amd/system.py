@@ -134,6 +134,26 @@ class ScaledGaussian(Policy):
         return {"sigma": 1.0}
 
 
+@dataclass(frozen=True)
+class ScriptPolicy(Policy):
+    """A policy whose ``sample_action!`` and ``log_proposal_density`` are the script's own (the reference's generic
+    functions, src/metropolis.jl:35-62; example/particle_1d/particle_1d.jl:52-59 are the Gaussian displacement's methods),
+    each as one C expression compiled for the GPU at run time:
+      ``sample``  delta = f(z, x, sigma) from ONE standard normal variate ``z``, the position ``x`` and the parameter ``sigma``
+      ``logq``    log q(delta | x, sigma), the log-density of what ``sample`` returns
+      ``dlogq``   d logq / d sigma (the reference's AD backends, gradients.jl:28-33) -- needed by the estimator only
+    e.g. a drifted Gaussian (Langevin) proposal for U = x^2, beta = 2:
+      ScriptPolicy("-2.0*sigma*sigma*x + sigma*z", "-(delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x)/(2.0*sigma*sigma) - amc_log(sigma)", ...)
+    All moves of a pool share the policy."""
+    sample: str = "sigma*z"
+    logq: str = "-(delta*delta)/(2.0*sigma*sigma) - amc_log(sigma)"
+    dlogq: Optional[str] = None
+
+    @staticmethod
+    def setup_parameters() -> Dict[str, float]:
+        return {"sigma": 1.0}
+
+
 @dataclass
 class Move:
     """Move(action, policy, parameters, weight) (src/metropolis.jl:140-162).
@@ -156,8 +176,8 @@ class Move:
         self.parameters = np.atleast_1d(np.asarray(p, dtype=np.float64)).copy()
         if self.parameters.shape != (1,):
             raise ValueError("StandardGaussian has exactly one parameter (sigma)")
-        if not isinstance(self.action, Displacement) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian)):
-            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian or ScaledGaussian policy only")
+        if not isinstance(self.action, Displacement) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian, ScriptPolicy)):
+            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian, ScaledGaussian or ScriptPolicy policy only")
         self.weight = float(self.weight)
 
     @property

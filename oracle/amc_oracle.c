@@ -292,6 +292,19 @@ static float (*g_custom_scale_f32)(float) = 0;
 void amo_set_custom_scale(double (*fn)(double)) { g_custom_scale = fn; }
 void amo_set_custom_scale_f32(float (*fn)(float)) { g_custom_scale_f32 = fn; }
 
+/* A script-defined proposal in full: the model's own sample_action! / log_proposal_density (generic functions of
+ * src/metropolis.jl:35-62) and, for the estimator, d logq / d sigma (what ForwardDiff returns, gradients.jl:28-33), as
+ * functions compiled from the script's expressions: sample(z, x, sigma), logq(delta, x, sigma), dlogq(delta, x, sigma).
+ * 0: the particle_1d model's Gaussian displacement. */
+static double (*g_custom_sample)(double, double, double) = 0;
+static double (*g_custom_logq)(double, double, double) = 0;
+static double (*g_custom_dlogq)(double, double, double) = 0;
+void amo_set_custom_proposal(double (*sample)(double, double, double), double (*logq)(double, double, double),
+                             double (*dlogq)(double, double, double))
+{
+    g_custom_sample = sample; g_custom_logq = logq; g_custom_dlogq = dlogq;
+}
+
 double amo_potential(int pot, double x)
 {
     if (pot == AMO_POT_CUSTOM) return g_custom_potential ? g_custom_potential(x) : (0.0 / 0.0);
@@ -393,6 +406,19 @@ static inline double julia_min(double a, double b)
  * fed an explicit standard normal z and the accept uniform u. */
 static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
 {
+    if (g_custom_logq) {                                           /* script-defined proposal */
+        m->delta = g_custom_sample(z, p->x, sigma);                    /* :177 sample_action! */
+        double logq_f = g_custom_logq(m->delta, p->x, sigma);          /* :178 at the old state */
+        double e1c, e2c;
+        perform_action(p, m, pot, &e1c, &e2c);                         /* :179 */
+        double dlogp_c = delta_log_target_density(e1c, p->beta, e2c, p->beta); /* :180 */
+        m->delta = -m->delta;                                          /* :181 */
+        double logq_b = g_custom_logq(m->delta, p->x, sigma);          /* :182 at the new state */
+        double alpha_c = julia_min(1.0, amo_exp(dlogp_c + logq_b - logq_f)); /* :183 */
+        if (alpha_c > u) return 1;                                     /* :184 */
+        perform_action(p, m, pot, &e1c, &e2c);                         /* :187 */
+        return 0;
+    }
     /* the policy's width at the state it is asked about: the old one for sample_action! and the forward density, the
      * new one for the backward density (system has moved by then) */
     double s_f = g_custom_scale ? sigma * g_custom_scale(p->x) : sigma;
@@ -753,6 +779,28 @@ void amo_moments(const amo_sim *s, double out[2])
  * sample_gradient_data, P = 1.  gd = (j, dj, dlogq_forward, g). */
 static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
 {
+    if (g_custom_logq) {
+        /* script-defined proposal: value and sigma-derivative of the forward density at the old state (:97), of the
+         * backward density at the new state (:102) */
+        m->delta = g_custom_sample(z, p->x, sigma);
+        double logq_f = g_custom_logq(m->delta, p->x, sigma);
+        double dlogq_f = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
+        double e1, e2;
+        perform_action(p, m, pot, &e1, &e2);
+        double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta);
+        double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;
+        m->delta = -m->delta;
+        double logq_b = g_custom_logq(m->delta, p->x, sigma);
+        double dlogq_b = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
+        perform_action(p, m, pot, &e1, &e2);
+        double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f));
+        double j = r * alpha;
+        gd[0] = j;
+        gd[1] = j * (alpha == 1.0 ? dlogq_f : dlogq_b);
+        gd[2] = dlogq_f;
+        gd[3] = dlogq_f * dlogq_f;
+        return;
+    }
     if (g_custom_scale) {
         /* state-dependent width: forward density / gradient at the old state, backward at the new one */
         double s_f = g_custom_scale(p->x), w_f = sigma * s_f;

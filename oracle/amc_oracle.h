@@ -61,6 +61,8 @@ uint32_t amo_spare_accept12(const uint32_t v[4], int half);   /* spare bits of a
 uint32_t amo_spare_pick12(const uint32_t v[4], int half);     /* ... and its move-pick uniform */
 double amo_uniform_accept(uint32_t accept12, uint32_t lo, uint32_t hi);   /* [0,1), 52 bits: top 12 from the normal draw */
 double amo_uniform_pick(uint32_t pick12, uint32_t lo);       /* [0,1), 36 bits: categorical move pick */
+void   amo_set_custom_proposal(double (*sample)(double, double, double), double (*logq)(double, double, double),
+                               double (*dlogq)(double, double, double));   /* script-defined sample_action! / log_proposal_density */
 double amo_potential(int pot, double x);
 /* AMO_POT_CUSTOM: `potential` is a free GLOBAL function of the driver script in the reference
  * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,

@@ -263,6 +263,35 @@ def install_custom_scale(expr: Optional[str]) -> None:
     lib.amo_set_custom_scale_f32(C.cast(_custom_libs[key].amo_user_scale_f32, C.c_void_p))
 
 
+def install_custom_proposal(proposal) -> None:
+    """The oracle's global script-defined proposal: None restores the particle_1d Gaussian displacement; else
+    (sample, logq, dlogq or None) as C expressions in (z, x, sigma) / (delta, x, sigma), compiled by gcc."""
+    import hashlib
+    import tempfile
+    lib = load()
+    lib.amo_set_custom_proposal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.amo_set_custom_proposal.restype = None
+    if proposal is None:
+        lib.amo_set_custom_proposal(None, None, None)
+        return
+    sample, logq, dlogq = (list(proposal) + [None])[:3]
+    key = "p" + hashlib.sha1(repr((sample, logq, dlogq)).encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_prop_")
+        src, so = os.path.join(d, "prop.cpp"), os.path.join(d, f"prop_{key}.so")
+        with open(src, "w") as f:
+            f.write(_CUSTOM_PROLOGUE +
+                    f"double amo_user_sample(double z, double x, double sigma) {{ return ({sample}); }}\n"
+                    f"double amo_user_logq(double delta, double x, double sigma) {{ return ({logq}); }}\n" +
+                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else "") + "}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    L = _custom_libs[key]
+    lib.amo_set_custom_proposal(C.cast(L.amo_user_sample, C.c_void_p), C.cast(L.amo_user_logq, C.c_void_p),
+                                C.cast(L.amo_user_dlogq, C.c_void_p) if dlogq else None)
+
+
 def _potential_id(potential) -> int:
     expr = getattr(potential, "expr", None)
     if expr is not None:
@@ -275,10 +304,11 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None, proposal=None):
         self.lib = load()
         self.dtype = dtype
         install_custom_scale(scale_expr)            # process-global like the potential: one simulation at a time
+        install_custom_proposal(proposal)
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
@@ -380,13 +410,13 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None, reward_expr=None, dtype="f64", scale_expr=None):
+                 stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
         self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
                              weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype,
-                             scale_expr=scale_expr)
+                             scale_expr=scale_expr, proposal=proposal)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 

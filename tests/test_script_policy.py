@@ -1,0 +1,158 @@
+"""A script-defined PROPOSAL in full (ScriptPolicy; amc_create_proposal_model): the model's own sample_action! and
+log_proposal_density -- the reference declares them as generic functions the user overloads (src/metropolis.jl:35-62;
+example/particle_1d/particle_1d.jl:52-59 are the Gaussian displacement's methods) -- given as C expressions and compiled
+for gfx950 at run time, with the oracle evaluating the same expressions compiled by gcc.  The example policy is a
+drifted Gaussian (Langevin / MALA) proposal for U = x^2, beta = 2: its mean depends on the state, so log q_backward -
+log q_forward is the whole point of mc_step!'s acceptance ratio (metropolis.jl:183)."""
+import numpy as np
+import pytest
+
+import montecarlo_amd as ma
+
+BETA = 2.0
+# delta ~ Normal(-beta sigma^2 x, sigma): (sigma^2 / 2) grad log p(x) + sigma z with log p = -beta x^2
+SAMPLE = "-2.0*sigma*sigma*x + sigma*z"
+LOGQ = "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)"
+DLOGQ = ("((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(sigma*sigma*sigma) "
+         "- 4.0*x*(delta + 2.0*sigma*sigma*x)/sigma - 1.0/sigma")
+MALA = (SAMPLE, LOGQ, DLOGQ)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_oracle_keeps_the_target_distribution_with_a_drifted_proposal(oracle):
+    s = oracle.OracleSim(4000, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=5, proposal=MALA)
+    s.init_uniform(-2, 2)
+    n, sx, sxx, _ = s.run_pooled_moments(2500, 300, 10, threads=8)
+    assert sx / n == pytest.approx(0.0, abs=5e-3) and sxx / n == pytest.approx(1 / (2 * BETA), abs=4e-3)
+    acc_mala = s.acceptance()[0]
+    # without the drift's density ratio (symmetric random walk of the same width) the acceptance is far lower: the
+    # Langevin drift is what keeps sigma = 0.6 above 90 %
+    t = oracle.OracleSim(4000, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=5)
+    t.init_uniform(-2, 2)
+    t.make_steps(300, 8)
+    assert acc_mala > t.acceptance()[0] + 0.1
+    # a WRONG density (drift left out of logq) visibly breaks the stationary distribution: the ratio is really used
+    wrong = oracle.OracleSim(4000, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=5,
+                             proposal=(SAMPLE, "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(sigma)", None))
+    wrong.init_uniform(-2, 2)
+    n, sx, sxx, _ = wrong.run_pooled_moments(2500, 300, 10, threads=8)
+    assert abs(sxx / n - 0.25) > 0.02
+    oracle.install_custom_proposal(None)
+
+
+def test_host_mirror_passes_the_script_policy_to_the_engine(oracle, tmp_path):
+    chains = ma.ParticleChains.uniform(64, BETA, -2.0, 2.0)
+    pol = ma.ScriptPolicy(*MALA)
+    pool = [ma.Move(ma.Displacement(0.0), pol, [0.3], 0.5), ma.Move(ma.Displacement(0.0), pol, [0.7], 0.5)]
+    sim = ma.Simulation(chains, [dict(algorithm=ma.Metropolis, pool=pool, seed=3, engine_factory=oracle.OracleEngine)], 20,
+                        path=str(tmp_path))
+    ma.run(sim)
+    o = oracle.OracleSim(64, potential="harmonic", beta=BETA, sigma=[0.3, 0.7], weight=[0.5, 0.5], seed=3, proposal=MALA)
+    o.init_uniform(-2, 2)
+    o.make_steps(20)
+    assert np.array_equal(bits(chains.x), bits(o.state()[0]))
+    mixed = [ma.Move(ma.Displacement(0.0), pol, [0.3], 0.5), ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), [0.9], 0.5)]
+    with pytest.raises(ValueError, match="share one policy"):
+        ma.Metropolis(ma.ParticleChains.uniform(8, BETA), pool=mixed, engine_factory=oracle.OracleEngine)
+    oracle.install_custom_proposal(None)
+
+
+def test_argument_validation_needs_no_gpu(amc):
+    kw = dict(n_chains=10, potential="harmonic", beta=BETA, sigma=[0.5], weight=[1.0])
+    with pytest.raises(amc.AmcError, match="both required"):
+        amc.HipEngine(proposal=(SAMPLE, None, None), **kw)
+    with pytest.raises(amc.AmcError, match="does not mention z"):
+        amc.HipEngine(proposal=("sigma*x", LOGQ, None), **kw)
+    with pytest.raises(amc.AmcError, match="does not mention delta"):
+        amc.HipEngine(proposal=(SAMPLE, "x*x", None), **kw)
+    with pytest.raises(amc.AmcError, match="Float64 state"):
+        amc.HipEngine(proposal=MALA, dtype="f32", **kw)
+    with pytest.raises(amc.AmcError, match="not allowed"):
+        amc.HipEngine(proposal=(SAMPLE + "; }", LOGQ, None), **kw)
+    with pytest.raises(amc.AmcError, match="cannot be combined"):
+        amc.HipEngine(proposal=MALA, scale_expr="1.0 + x*x", **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["k1", "k2_beta", "custom_potential"])
+def test_trajectories_bit_exact_against_the_oracle(gpu, oracle, case):
+    M = 20001
+    kw = dict(potential="harmonic", beta=BETA, sigma=[0.4], weight=[1.0], seed=11, proposal=MALA)
+    beta = None
+    if case == "k1":
+        kw["per_chain_counters"] = False
+    elif case == "k2_beta":
+        kw.update(potential="double_well", sigma=[0.2, 0.6], weight=[0.4, 0.6])
+        beta = np.random.default_rng(1).uniform(0.5, 3.0, M)
+    else:
+        kw.update(potential=ma.CustomPotential("x*x*x*x - 2.0*x*x + 0.25*x"),
+                  proposal=("sigma*z*(0.5 + fabs(x))", "-(delta*delta)/(2.0*(sigma*(0.5 + fabs(x)))*(sigma*(0.5 + fabs(x)))) - amc_log(sigma*(0.5 + fabs(x)))",
+                            "(delta*delta)/((sigma*sigma*sigma)*(0.5 + fabs(x))*(0.5 + fabs(x))) - 1.0/sigma"))
+    eng = gpu.HipEngine(n_chains=M, **kw)
+    sim = oracle.OracleSim(M, **{k: v for k, v in kw.items() if k != "per_chain_counters"})
+    x0 = np.random.default_rng(2).uniform(-2, 2, M)
+    eng.upload_state(x0, beta)
+    if beta is not None:
+        sim.set_beta(beta)
+    sim.set_x(x0)
+    for n in (1, 1, 9, 1, 30):
+        eng.sweep(n)
+        sim.make_steps(n)
+        x, e = eng.download_state()
+        xo, eo = sim.state()
+        assert np.array_equal(bits(x), bits(xo)) and np.array_equal(bits(e), bits(eo))
+    acc, tot = eng.counter_totals()
+    ao, to = sim.counters()
+    assert np.array_equal(np.asarray(acc), ao.sum(axis=1)) and np.array_equal(np.asarray(tot), to.sum(axis=1))
+    ids = list(range(len(kw["sigma"])))
+    for q in (1, 3):
+        got = np.asarray(eng.pg_estimate(ids, q)).reshape(len(ids), 5)
+        want = sim.pg_estimate(ids, q)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-9) and np.array_equal(got[:, 4], want[:, 4])
+        assert np.array_equal(bits(eng.download_state()[0]), bits(sim.state()[0]))
+    eng.close()
+    oracle.install_custom_proposal(None)
+
+
+@pytest.mark.gpu
+def test_estimator_needs_the_sigma_derivative_and_target_distribution_at_scale(gpu):
+    M = 2_000_000
+    e = gpu.HipEngine(n_chains=M, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=21, proposal=(SAMPLE, LOGQ, None),
+                      per_chain_counters=False)
+    e.init_uniform(-2, 2)
+    with pytest.raises(gpu.AmcError, match="No withgrad_log_proposal_density"):
+        e.pg_estimate([0], 1)
+    e.sweep(400)
+    s = np.zeros(4)
+    for _ in range(30):
+        e.sweep(20)
+        s += e.reduce()[:4]
+    assert s[1] / s[3] == pytest.approx(0.0, abs=2e-3) and s[2] / s[3] == pytest.approx(0.25, abs=2e-3)
+    red = e.reduce()
+    assert red[4] / M > 0.8                                   # a random walk of this width accepts 66 %, the Langevin drift 86 %
+    e.close()
+    # with the derivative: E[d logq / d sigma] = 0 under the proposal, E[(d logq / d sigma)^2] is the Fisher information 2/sigma^2 + 16 sigma^2 <x^2>
+    f = gpu.HipEngine(n_chains=M, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=22, proposal=MALA)
+    f.init_uniform(-2, 2)
+    f.sweep(300)
+    x = f.download_state()[0]
+    g = np.asarray(f.pg_estimate([0], 1)).reshape(5)
+    # d logq / d sigma = (eps^2 - 1)/sigma - 4 x eps with eps standard normal: variance 2/sigma^2 + 16 <x^2>
+    fisher = 2 / 0.6 ** 2 + 16 * float(np.mean(x * x))
+    assert abs(g[2]) < 6 * np.sqrt(M * fisher) and g[3] / M == pytest.approx(fisher, rel=0.02)
+    # one fused PGMC call (sweep + estimator + learning step per launch) equals the separate calls, bit for bit
+    h = gpu.HipEngine(n_chains=M, potential="harmonic", beta=BETA, sigma=[0.6], weight=[1.0], seed=22, proposal=MALA)
+    h.upload_state(f.download_state()[0])
+    h.step, h.estimator_step = f.step, f.estimator_step
+    f.pgmc_steps(3, [0], 2, [1], [0.05], [0.0])
+    for _ in range(3):
+        h.sweep(1)
+        h.pg_accumulate([0], 2)
+        h.pg_update([0], [1], [0.05], [0.0])
+    assert np.array_equal(bits(f.download_state()[0]), bits(h.download_state()[0]))
+    assert f.get_parameters(0)[0] == h.get_parameters(0)[0] != 0.6
+    f.close()
+    h.close()
