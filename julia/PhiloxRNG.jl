@@ -9,10 +9,12 @@
 # The reference builds `rngs[c] = R(seed + c - 1)` (metropolis.jl:262-263): the constructor argument minus the
 # seed (a type parameter here, because `R` must be a DataType) is the zero-based GLOBAL chain id.
 # Per mc_step! the reference draws, in this order (metropolis.jl:206, particle_1d.jl:57, metropolis.jl:184):
-#   rand(rng, Categorical(w)) -> one Float64 uniform      = low 24 bits of the chain's word of draw 1 (uniform_pick)
-#   rand(rng, Normal(0, s))   -> one randn(rng, Float64)  = the chain's half of draw 0 (Box-Muller pair)
-#   rand(rng)                 -> one Float64 uniform      = 12 spare bits of draw 0 + top 40 bits of the chain's word
-#                                                           of draw 1 (uniform_accept, spec v4)
+#   rand(rng, Categorical(w)) -> one Float64 uniform      = 12 spare bits of draw 0 + low 24 bits of the chain's word of
+#                                                           draw 1 (uniform_pick, spec v5: 36 bits)
+#   rand(rng, Normal(0, s))   -> one randn(rng, Float64)  = the chain's half of draw 0 (Box-Muller pair: 52-bit radius
+#                                                           uniform from words (x, y), 28-bit angle from word w)
+#   rand(rng)                 -> one Float64 uniform      = 12 (other) spare bits of draw 0 + top 40 bits of the chain's
+#                                                           word of draw 1 (uniform_accept)
 # so the n-th call of a chain's generator is (step, kind) = divrem(n, 3).  The estimator stream (STREAM = 2)
 # draws one randn per sample: call n is draw n of estimator step `est_step` (set it before each make_step!).
 module PhiloxRNGs
@@ -51,12 +53,15 @@ end
 bits12(lo::UInt32, hi::UInt32, expo::UInt64) = reinterpret(Float64, expo | (((UInt64(hi) << 32) | lo) >> 12))
 uniform_co(lo, hi) = bits12(lo, hi, 0x3ff0000000000000) - 1.0      # [0,1): Julia's own rand(Float64) construction
 uniform_oc(lo, hi) = 2.0 - bits12(lo, hi, 0x3ff0000000000000)      # (0,1]
-angle_oc2(lo, hi) = 4.0 - bits12(lo, hi, 0x4000000000000000)       # (0,2]
-# spec v4: move pick = low 24 bits of the chain's accept-draw word; accept uniform = 52-bit significand with the 12
-# spare bits of the normal draw's low word on top and the top 40 bits of the accept-draw word below
-uniform_pick(lo::UInt32) = Float64(lo & 0x00ffffff) * 2.0^-24
-function uniform_accept(normal_lo::UInt32, lo::UInt32, hi::UInt32)
-    m = (UInt64(normal_lo & 0x00000fff) << 40) | (((UInt64(hi) << 32) | lo) >> 24)
+angle28(w::UInt32) = 2.0 - Float64(w >> 4) * 2.0^-27               # (0,2]: the top 28 bits of ONE word (spec v5)
+# spec v5: the spare bits of a normal draw (x[11:0], z, w[3:0]) lead the accept and the pick uniform of the pair's chains
+spare_accept12(v::NTuple{4,UInt32}, odd) = odd == 0 ? v[1] & 0x00000fff : (v[3] >> 12) & 0x00000fff
+spare_pick12(v::NTuple{4,UInt32}, odd) = odd == 0 ? v[3] & 0x00000fff : (v[3] >> 24) | ((v[4] & 0x0000000f) << 8)
+# move pick = pick12 on top of the low 24 bits of the chain's accept-draw word (36 bits); accept uniform = 52-bit
+# significand with accept12 on top and the top 40 bits of the accept-draw word below
+uniform_pick(pick12::UInt32, lo::UInt32) = Float64((UInt64(pick12 & 0x00000fff) << 24) | UInt64(lo & 0x00ffffff)) * 2.0^-36
+function uniform_accept(accept12::UInt32, lo::UInt32, hi::UInt32)
+    m = (UInt64(accept12 & 0x00000fff) << 40) | (((UInt64(hi) << 32) | lo) >> 24)
     return reinterpret(Float64, 0x3ff0000000000000 | m) - 1.0
 end
 
@@ -99,7 +104,7 @@ end
 
 function box_muller(v::NTuple{4,UInt32})
     s = sqrt(-2.0 * logbm(uniform_oc(v[1], v[2])))
-    sn, cs = sincospi_tab(angle_oc2(v[3], v[4]))
+    sn, cs = sincospi_tab(angle28(v[4]))
     return sn * s, cs * s
 end
 
@@ -113,13 +118,11 @@ end
 function Random.rand(rng::PhiloxRNG{SEED,1}, ::Random.SamplerTrivial{Random.CloseOpen01{Float64}}) where {SEED}
     t, kind = divrem(next_call!(rng), UInt64(3))
     pair, odd = rng.chain >> 1, rng.chain & 1
-    if kind == 0
-        va = draw_words(UInt64(SEED), pair, t, 1, 1)
-        return odd == 0 ? uniform_pick(va[1]) : uniform_pick(va[3])
-    elseif kind == 2
+    if kind == 0 || kind == 2
         vn = draw_words(UInt64(SEED), pair, t, 0, 1)
         va = draw_words(UInt64(SEED), pair, t, 1, 1)
-        return odd == 0 ? uniform_accept(vn[1], va[1], va[2]) : uniform_accept(vn[3], va[3], va[4])
+        lo, hi = odd == 0 ? (va[1], va[2]) : (va[3], va[4])
+        return kind == 0 ? uniform_pick(spare_pick12(vn, odd), lo) : uniform_accept(spare_accept12(vn, odd), lo, hi)
     end
     error("PhiloxRNG: rand() called where the draw schedule expects randn() (call $(rng.calls - 1))")
 end

@@ -25,6 +25,10 @@
 #include "amc_kernels.h"
 #include "amc_rtc_sources.gen.h"   // the three kernel headers as string literals (Makefile), for hiprtc
 
+#ifndef AMC_BUILD_ARCH
+#define AMC_BUILD_ARCH "gfx950"      // the Makefile passes the arch the offline kernels were compiled for
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -117,6 +121,7 @@ struct amc_handle {
     bool pg_tail_valid = false;
     Rccl rccl;
     bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
+    std::string arch = AMC_BUILD_ARCH;   // the device's ISA name (gcnArchName up to its first ':'): what hiprtc compiles for
     std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
     bool f32 = false;             // state_dtype == AMC_DTYPE_F32: d_x / d_beta hold floats
     bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model)
@@ -310,6 +315,7 @@ struct Hiprtc {
     int (*GetCode)(void*, char*) = nullptr;
     int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
     int (*DestroyProgram)(void**) = nullptr;
+    int (*Version)(int*, int*) = nullptr;
 };
 
 std::mutex g_rtc_mu;
@@ -338,6 +344,7 @@ int load_hiprtc(Hiprtc& r)
     AMC_RTC_SYM(GetCode, "hiprtcGetCode");
     AMC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
     AMC_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+    AMC_RTC_SYM(Version, "hiprtcVersion");
 #undef AMC_RTC_SYM
     return AMC_OK;
 }
@@ -373,12 +380,14 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
-std::string rtc_cache_path(const std::string& expr, const std::string& inst)
+std::string rtc_cache_path(const std::string& expr, const std::string& inst, const std::string& arch, const std::string& toolchain)
 {
     const char* dir = std::getenv("AMC_RTC_CACHE_DIR");
     if (!dir || !*dir) return std::string();
     uint64_t h = fnv1a(expr);
     h = fnv1a(inst, h ^ 0x9E3779B97F4A7C15ull);
+    h = fnv1a(arch, h ^ 0xC2B2AE3D27D4EB4Full);          // a code object is good for one ISA ...
+    h = fnv1a(toolchain, h);                              // ... and one compiler release
     h = fnv1a(AMC_RTC_SRC_KERNELS, h);
     h = fnv1a(AMC_RTC_SRC_MATH, h);
     h = fnv1a(AMC_RTC_SRC_TABLES, h);
@@ -420,13 +429,16 @@ void rtc_cache_store(const std::string& path, const RtcCode& rc)
 
 // Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
 // Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
-int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCode** out, std::string* log_out)
+int rtc_compile(const std::string& expr_in, const std::string& inst, const std::string& arch, const RtcCode** out, std::string* log_out)
 {
     std::lock_guard<std::mutex> lock(g_rtc_mu);
-    const std::string key = expr_in + "\n" + inst;
+    const std::string key = arch + "\n" + expr_in + "\n" + inst;
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
-    const std::string cache_file = rtc_cache_path(expr_in, inst);
+    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
+    int rtc_major = 0, rtc_minor = 0;
+    (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
+    const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor));
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -435,7 +447,6 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCo
             return AMC_OK;
         }
     }
-    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ] ] ]
     const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
     const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
@@ -466,7 +477,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const RtcCo
     e = g_hiprtc.AddNameExpression(prog, inst.c_str());
     if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
     // the flags of the offline build (Makefile): only the explicit fma()s may fuse
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    const std::string arch_opt = "--offload-arch=" + arch;
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
     e = g_hiprtc.CompileProgram(prog, 5, opts);
     std::string log;
     size_t ls = 0;
@@ -503,7 +515,7 @@ int rtc_function(amc_handle* h, const std::string& inst, hipFunction_t* fn)
     auto it = h->rtc_fn.find(inst);
     if (it != h->rtc_fn.end()) { *fn = it->second; return AMC_OK; }
     const RtcCode* code = nullptr;
-    { const int rc = rtc_compile(h->pot_expr, inst, &code, nullptr); if (rc != AMC_OK) return rc; }
+    { const int rc = rtc_compile(h->pot_expr, inst, h->arch, &code, nullptr); if (rc != AMC_OK) return rc; }
     hipModule_t mod = nullptr;
     AMC_HIP(hipModuleLoadData(&mod, code->code.data()));
     h->rtc_mods.push_back(mod);
@@ -639,6 +651,19 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (!h) return fail(AMC_ERR_OOM, "amc_create: host allocation failed");
     h->device = cfg->device;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // "gfx950:sramecc+:xnack-" -> "gfx950": run-time compiled kernels target the device they will run on; the offline
+        // kernels of this library were built for AMC_BUILD_ARCH and cannot run anywhere else
+        std::string arch(prop.gcnArchName);
+        const size_t colon = arch.find(':');
+        if (colon != std::string::npos) arch.erase(colon);
+        if (!arch.empty()) h->arch = arch;
+        if (h->arch != AMC_BUILD_ARCH) {
+            delete h;
+            return fail(AMC_ERR_NO_DEVICE, "amc_create: device %d is %s, this libamc.so was built for %s (make ARCH=%s)", cfg->device,
+                        arch.c_str(), AMC_BUILD_ARCH, arch.c_str());
+        }
+    }
     // 8 resident blocks per CU; the single-step launch of the K = 1 pool-wide-counter sweep (no step log) measures 5 %
     // faster with 6 (29.4 vs 31.2 us at 1e7 chains; its fused launches and all other forms are fastest at 8)
     h->blocks_per_cu = 8;
@@ -833,7 +858,7 @@ int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
     { const int rc = validate_potential_expr(potential_expr); if (rc != AMC_OK) return rc; }
     const RtcCode* code = nullptr;
     std::string text;
-    const int rc = rtc_compile(potential_expr, "amc::energy_kernel<2>", &code, &text);
+    const int rc = rtc_compile(potential_expr, "amc::energy_kernel<2>", AMC_BUILD_ARCH, &code, &text);
     if (log && log_capacity > 0) {
         std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
         log[log_capacity - 1] = 0;

@@ -173,3 +173,19 @@ def test_shards_are_connected_and_pools_are_not_deep_copied_per_chain():
     assert text.count("deepcopy(pool)") == 1                    # the one template copy
     # one parameters object per move, shared by the update and every materialised pools[c]
     assert "move.policy, move.parameters, move.weight" in text and "est.parameters_list" in text
+
+
+def test_philox_rng_stub_follows_the_current_arithmetic_spec():
+    """julia/PhiloxRNG.jl restates the draw schedule for the reference's R= hook; it cannot run here, so at least its
+    bit-field constants must be the ones the oracle implements (spec v5: 28-bit angle, 12 + 12 spare bits per chain,
+    36-bit pick uniform, 12 + 40-bit accept uniform) -- a spec change that forgets the Julia file fails here."""
+    text = re.sub(r"#[^\n]*", "", open(os.path.join(ROOT, "julia", "PhiloxRNG.jl")).read())
+    src = open(os.path.join(ROOT, "oracle", "amc_oracle.c")).read()
+    for jl, c in [("Float64(w >> 4) * 2.0^-27", "(double)(w >> 4) * 0x1.0p-27"),
+                  ("(v[3] >> 12) & 0x00000fff", "((v[2] >> 12) & 0xFFFu)"),
+                  ("(v[3] >> 24) | ((v[4] & 0x0000000f) << 8)", "((v[2] >> 24) | ((v[3] & 0xFu) << 8))"),
+                  ("(UInt64(pick12 & 0x00000fff) << 24) | UInt64(lo & 0x00ffffff)) * 2.0^-36", "0x1.0p-36"),
+                  ("(UInt64(accept12 & 0x00000fff) << 40) | (((UInt64(hi) << 32) | lo) >> 24)", "<< 40) | ((((uint64_t)hi << 32) | lo) >> 24)")]:
+        assert jl in text, jl
+        assert c in src, c
+    assert "angle_oc2" not in text and "sincospi_tab(angle28(v[4]))" in text
