@@ -86,7 +86,7 @@ struct amc_handle {
     uint32_t* d_acc = nullptr;
     uint32_t* d_tot = nullptr;
     uint8_t* d_log = nullptr;   // [log_depth][M_pad] step log: (move << 1) | accepted per chain and MH step
-    int log_depth = 32;         // rows of the step log (env AMC_LOG_DEPTH, 1..256)
+    int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
     double* d_ptab = nullptr;
     uint8_t* d_pick = nullptr;  // [AMC_PICK_CELLS] move pick by the 12 leading bits of the pick uniform (K > 1)
@@ -197,7 +197,12 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
 {
     if (!h->d_log || (h->log_fill == 0 && !with_ratio)) return AMC_OK;
-    const int grid = grid_for(h, (h->M + 3) / 4);
+    // tiles of AMC_FOLD_TILE chains, dealt evenly: every block takes the same number of tiles (a grid of 2048 over 2442
+    // tiles would leave 80 % of the blocks idle for the second half of the launch)
+    const int64_t n_tiles = (h->M + AMC_FOLD_TILE - 1) / AMC_FOLD_TILE;
+    const int64_t cap = (int64_t)h->n_cu * h->blocks_per_cu;
+    const int64_t rounds = (n_tiles + cap - 1) / cap;
+    const int grid = (int)((n_tiles + rounds - 1) / rounds);
 #define AMC_FOLD(KS, RATIO)                                                                                           \
     hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
                        h->d_log, h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
@@ -726,9 +731,15 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
             AMC_TRY(hipMalloc(&h->d_tot, n * sizeof(uint32_t)));
             AMC_TRY(hipMemsetAsync(h->d_tot, 0, n * sizeof(uint32_t), h->stream));
         }
-        if (const char* env = std::getenv("AMC_LOG_DEPTH")) {     // tuning knob, 1..256
+        // One byte per chain and MH step; folding costs a read-modify-write of every counter (16 K bytes per chain), so a
+        // deeper log amortises it over more steps: 128 rows where they fit in 2 GiB (1.28 GB at 1e7 chains), never below 16.
+        {
+            const int64_t fit = (int64_t)(2147483648ll / h->M_pad);
+            h->log_depth = (int)(fit > 128 ? 128 : (fit < 16 ? 16 : fit));
+        }
+        if (const char* env = std::getenv("AMC_LOG_DEPTH")) {     // tuning knob, 1..255
             const int v = std::atoi(env);
-            if (v >= 1 && v <= 256) h->log_depth = v;
+            if (v >= 1 && v <= 255) h->log_depth = v;
         }
         AMC_TRY(hipMalloc(&h->d_log, (size_t)h->log_depth * (size_t)h->M_pad));
         AMC_TRY(hipMemsetAsync(h->d_log, 0, (size_t)h->log_depth * (size_t)h->M_pad, h->stream));

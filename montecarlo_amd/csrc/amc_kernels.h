@@ -718,13 +718,21 @@ __device__ __forceinline__ void add_block_accepts(unsigned long long* acc_total,
 }
 
 // Adds `n_rows` rows of the step log into the per-chain u32 counters acc[K][m_stride] / tot[K][m_stride]
-// (tot == nullptr when K == 1: total_calls is the step count).  KS > 0: K == KS <= 4, four chains per thread with
-// the deltas in registers (u32 log loads, 16-byte counter accesses); KS == 0: any K, one chain per thread, one
-// read-modify-write per logged step.  Entries of the padding behind n_chains are never interpreted as moves.
+// (tot == nullptr when K == 1: total_calls is the step count).  Entries of the padding behind n_chains are never
+// read back as counts.
+// KS > 0: K == KS <= 4.  A block works on tiles of 4096 adjacent chains.  Log side: a thread owns SIXTEEN adjacent
+// chains -- one 16-byte load per row (the block reads 4 KiB of every row) -- and accumulates the rows bytewise in
+// packed registers: the accept bit and the move bits of four chains are masked out of a 32-bit word at once and added
+// as four 8-bit counters (n_rows <= 255), ~2 VALU operations per chain and row instead of 6 K.  Counter side: the
+// packed words go through LDS so that lane t updates the quad of chains 4 (i 256 + t), i = 0..3 -- 16-byte
+// read-modify-writes that are contiguous across the wave (a thread updating its own sixteen chains would touch 16 bytes
+// in every 64).
+// KS == 0: any K, one chain per thread, one read-modify-write per logged step.
 // RATIO (KS > 0): the counters are in registers right after the update, so the launch also forms
 // callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
 // 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
 // total_ck is t_counted on every chain when K == 1 (tot == nullptr).
+#define AMC_FOLD_TILE (16 * AMC_BLOCK)
 template <int KS, bool RATIO = false>
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, uint32_t* acc,
                                                               uint32_t* tot, int64_t n_chains, int64_t m_stride,
@@ -732,55 +740,84 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                                                               int rp_stride)
 {
     static_assert(!RATIO || KS > 0, "ratio sums ride on the register-resident fold");
-    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     if (KS > 0) {
-        double ratio[KS > 0 ? KS : 1];
+        constexpr int KK = KS > 0 ? KS : 1;
+        constexpr uint32_t ONES = 0x01010101u;
+        __shared__ __attribute__((aligned(16))) uint32_t s_pk[2 * KK][4 * AMC_BLOCK];   // [k: accepted, total][quad of the tile]
+        double ratio[KK];
 #pragma unroll
-        for (int k = 0; k < KS; ++k) ratio[k] = 0.0;
-        const int64_t n_quads = (n_chains + 3) >> 2;          // m_stride is a multiple of 4 with >= 4 of padding
-        for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
-            uint32_t da[KS > 0 ? KS : 1][4], dt[KS > 0 ? KS : 1][4];
+        for (int k = 0; k < KK; ++k) ratio[k] = 0.0;
+        const int64_t n_tiles = (n_chains + AMC_FOLD_TILE - 1) / AMC_FOLD_TILE;
+        for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            const int64_t c_tile = tile * AMC_FOLD_TILE;
+            const int64_t c_mine = c_tile + 16 * (int64_t)threadIdx.x;   // first of this thread's 16 chains (log side)
+            // every per-chain array is m_stride long (a multiple of 256, >= n_chains + 520): indices below m_stride are
+            // readable and writable, what lies behind n_chains is padding
+            const bool log_ok = c_mine < m_stride;
+            uint32_t pa[KK][4], pt[KK][4];                     // packed 8-bit counters: word j = chains c_mine + 4 j .. + 3
 #pragma unroll
-            for (int k = 0; k < KS; ++k)
+            for (int k = 0; k < KK; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) da[k][j] = dt[k][j] = 0u;
-            for (int r = 0; r < n_rows; ++r) {
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(log + (int64_t)r * m_stride + 4 * q);
+                for (int j = 0; j < 4; ++j) pa[k][j] = pt[k][j] = 0u;
+            if (log_ok) {
+                for (int r = 0; r < n_rows; ++r) {
+                    const uint4 w4 = *reinterpret_cast<const uint4*>(log + (int64_t)r * m_stride + c_mine);
+                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t b = (w >> (8 * j)) & 0xFFu;
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t a = w[j] & ONES;                       // accepted
+                        const uint32_t b0 = (w[j] >> 1) & ONES, b1 = (w[j] >> 2) & ONES;      // move index bits
+                        uint32_t eq[4];
+                        if (KS == 1) { eq[0] = ONES; }
+                        else if (KS == 2) { eq[1] = b0; eq[0] = b0 ^ ONES; }
+                        else { eq[0] = (b0 | b1) ^ ONES; eq[1] = b0 & ~b1; eq[2] = b1 & ~b0; eq[3] = b0 & b1; }
 #pragma unroll
-                    for (int k = 0; k < KS; ++k) {
-                        const uint32_t hit = ((b >> 1) == (uint32_t)k) ? 1u : 0u;
-                        dt[k][j] += hit;
-                        da[k][j] += hit & b;
+                        for (int k = 0; k < KK; ++k) {
+                            pt[k][j] += eq[k];
+                            pa[k][j] += eq[k] & a;
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                uint4* pa = reinterpret_cast<uint4*>(acc + (int64_t)k * m_stride + 4 * q);
-                uint4 va = *pa;
-                va.x += da[k][0]; va.y += da[k][1]; va.z += da[k][2]; va.w += da[k][3];
-                *pa = va;
-                uint4 vt = {0u, 0u, 0u, 0u};
-                if (tot) {
-                    uint4* pt = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + 4 * q);
-                    vt = *pt;
-                    vt.x += dt[k][0]; vt.y += dt[k][1]; vt.z += dt[k][2]; vt.w += dt[k][3];
-                    *pt = vt;
-                }
-                if (RATIO) {
-                    const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
+            for (int k = 0; k < KK; ++k) {
+                reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = uint4{pa[k][0], pa[k][1], pa[k][2], pa[k][3]};
+                reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = uint4{pt[k][0], pt[k][1], pt[k][2], pt[k][3]};
+            }
+            __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (4 * q + j < n_chains)             // the padding behind the last chain has no ratio
-                            ratio[k] += (double)a4[j] / (tot ? (double)t4[j] : (double)t_counted);
+            for (int k = 0; k < KK; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int quad = i * AMC_BLOCK + (int)threadIdx.x;
+                    const int64_t c0 = c_tile + 4 * (int64_t)quad;
+                    if (c0 >= m_stride) continue;
+                    const uint32_t wa = s_pk[2 * k][quad], wt = s_pk[2 * k + 1][quad];
+                    uint4* p_a = reinterpret_cast<uint4*>(acc + (int64_t)k * m_stride + c0);
+                    uint4 va = *p_a;
+                    va.x += wa & 0xFFu; va.y += (wa >> 8) & 0xFFu; va.z += (wa >> 16) & 0xFFu; va.w += wa >> 24;
+                    *p_a = va;
+                    uint4 vt = {0u, 0u, 0u, 0u};
+                    if (tot) {
+                        uint4* p_t = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + c0);
+                        vt = *p_t;
+                        vt.x += wt & 0xFFu; vt.y += (wt >> 8) & 0xFFu; vt.z += (wt >> 16) & 0xFFu; vt.w += wt >> 24;
+                        *p_t = vt;
+                    }
+                    if (RATIO) {
+                        const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
+                                ratio[k] += (double)a4[e] / (tot ? (double)t4[e] : (double)t_counted);
+                    }
                 }
             }
+            __syncthreads();                                   // the next tile overwrites s_pk
         }
-        if (RATIO) block_sum_store<(KS > 0 ? KS : 1)>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
+        if (RATIO) block_sum_store<KK>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
     } else {
+        const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
         for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
             for (int r = 0; r < n_rows; ++r) {
                 const uint32_t b = log[(int64_t)r * m_stride + c];

@@ -208,7 +208,7 @@ def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
     e.close()
 
 
-@pytest.mark.parametrize("depth", [1, 3, 256])
+@pytest.mark.parametrize("depth", [1, 3, 255])
 @pytest.mark.parametrize("K,fused", [(1, False), (2, False), (2, True), (7, True)])
 def test_step_log_depths(gpu, oracle, monkeypatch, depth, K, fused):
     """Per-chain counters go through the step log (one byte per chain and MH step) and are folded into acc/tot on

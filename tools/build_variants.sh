@@ -3,7 +3,7 @@
 # tools/_variants/<name> for tools/gpu_ab.py (same-box A/B timing); restores the plain build at the end.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAMC_BUILD_ARCH=\"gfx950\""
+BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 rm -rf "$R/tools/_variants"
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}

@@ -20,8 +20,10 @@ for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "es
   LAUNCHES=120 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace -d $O/$tag/pmc_sq2 --output-format csv -- $W $wl > /dev/null 2>&1
   echo "$tag done: $(cat $O/$tag.log | tail -1)"
 done
-# keep the merge small: the per-dispatch traces are large, the summaries are what is needed
-find $O -name "*_kernel_trace.csv" -size +2M -delete
-find $O -name "*.db" -delete
-du -sh $O
-cat $O/bench_n1.json
+# the per-dispatch traces and counter tables are large (gpurun merges at most 64 MiB back): summarise them here, keep
+# the summaries (gpurun_out/r02_out/ -> copied into profiles/ by hand) and drop the raw tables
+AMC_PROFILE_OUT=$R/gpurun_out/r02_out python3 $R/tools/summarize_profiles_r2.py
+cp $O/*.log $O/bench_n1.err $R/gpurun_out/r02_out/ 2>/dev/null
+rm -rf $O
+du -sh $R/gpurun_out/r02_out
+cat $R/gpurun_out/r02_out/r02_bench_n1.json

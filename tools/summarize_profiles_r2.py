@@ -14,7 +14,8 @@
 import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out", "r02")
-OUT = os.path.join(ROOT, "profiles")
+OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
+os.makedirs(OUT, exist_ok=True)
 TAG = "r02"
 ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
               "k2": 17 * 10_000_000, "pgmc": 17 * 10_000_000, "est": 16 * 10_000_000}
@@ -102,7 +103,7 @@ for wl in ALGO_BYTES:
     if os.path.exists(log):
         entry["workload_line"] = [ln.strip() for ln in open(log) if ln.startswith(("ladder", "k2", "pgmc", "est"))][-1:]
     summary[wl] = entry
-commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+commit = os.environ.get("AMC_COMMIT") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 summary["_meta"] = dict(commit=commit, kernel_source_hash=kernel_hash(),
                         notes=["FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled",
                                "PMC passes are separate runs (counters only, 120 launches, first quarter dropped); durations come from the --kernel-trace --stats run",
