@@ -223,14 +223,26 @@ def main():
     start, stop = sharding.shard_range(m_global, rank, world)
     eng = A.HipEngine(n_chains=stop - start, chain_offset=start, n_chains_global=m_global, potential="harmonic",
                       beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1, per_chain_counters=False,
-                      device=local_rank)
+                      device=int(os.environ.get("AMC_BENCH_DEVICE", local_rank)))
     eng.init_uniform(-2.0, 2.0)
+    allreduce_via = "none (single process)"
     if grp is not None:
         # the shards' RCCL communicator (ncclUniqueId over the store), built HERE and used once: the first collective
         # costs tens to hundreds of ms with the GPU idle; inside the barrier in front of the timed region it would start
         # the steps on a clock that has fallen back (measured on one rank: 31.1 instead of 29.6 us per sweep)
-        assert sharding.connect_engine(eng)
-        eng.allreduce_sum([0.0])
+        try:
+            ok = sharding.connect_engine(eng)
+            eng.allreduce_sum([0.0])
+        except A.AmcError as err:
+            ok = False
+            print(f"[bench rank {rank}] RCCL communicator not available ({err}); callback sums go over the launcher's store",
+                  file=sys.stderr)
+            eng.comm_connected = False
+        # every rank must take the same route: one that failed sends all of them to the host-side sum over the store
+        all_ok = all(grp.allgather(bool(ok)))
+        if not all_ok:
+            eng.comm_connected = False
+        allreduce_via = "rccl (amc_allreduce_sum on the engine's stream)" if all_ok else "launcher's TCP store (host-side sum: RCCL communicator unavailable)"
         grp.barrier()
     cb_every = CALLBACK_EVERY_MULTI if grp is not None else 0
     if os.environ.get("AMC_BENCH_CB_EVERY"):                 # developer knob: separate the cost of the callbacks from the process group's
@@ -322,7 +334,7 @@ def main():
                 "workload": "particle_1d Harmonic, beta=2.0, Gaussian Displacement sigma=0.1 (K=1), Metropolis, "
                             f"sweepstep=1, M={m_local} chains per GPU ({m_global} total), x0~U(-2,2), seed=1",
                 "chains_per_gpu": m_local, "chains_total": m_global, "sweepstep": 1,
-                "callbacks_allreduce_every": cb_every,
+                "callbacks_allreduce_every": cb_every, "callbacks_allreduce_via": allreduce_via,
                 "sharding": "contiguous global chain ids per rank; no data-path collective",
                 "multi_gpu_note": "N > 1: callbacks all-reduced by the engines' own RCCL communicator (amc_allreduce_sum), unique id "
                                   "and barriers over the launcher's TCP store; measured on hardware only by the driver's SCALE runs",

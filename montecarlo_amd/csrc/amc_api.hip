@@ -1770,8 +1770,12 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
     struct Id { char b[128]; } id;
     std::memcpy(&id, id128, sizeof(id));
     typedef int (*init_fn)(void**, int, Id, int);
+    if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
     const int e = ((init_fn)(void*)h->rccl.CommInitRank)(&h->comm, n_ranks, id, rank);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    if (e != 0) {
+        h->comm = nullptr;         // the handle stays a single shard: amc_allreduce_sum is the identity again
+        return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    }
     AMC_HIP(hipMalloc(&h->d_comm, 256 * sizeof(double)));
     return AMC_OK;
 }

@@ -113,6 +113,7 @@ def connect_engine(engine) -> bool:
         box = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+    engine.comm_connected = False
     engine.comm_init(rank, size, uid)
     engine.comm_connected = True
     return True

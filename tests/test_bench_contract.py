@@ -86,3 +86,29 @@ def test_default_size_line_carries_the_ladder():
     for row in rows:
         assert row["regime"].startswith("HBM") and 0.2 < row["frac"] < 1.0
         assert abs(row["achieved_GBps"] - 16 * row["chains"] / row["us_per_launch_min"] / 1e3) < 1e-6 * row["achieved_GBps"]
+
+
+def test_two_ranks_on_one_device_fall_back_to_the_store():
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with two
+    ranks, both pointed at the one GPU this box has: RCCL refuses two ranks on one device, so the communicator cannot be
+    built -- the run must not die there (a crashed bench leaves no scaling record at all) but say so and sum the callbacks
+    over the launcher's store.  What this exercises on hardware: the store group under the real launcher, sharding by
+    global chain id over two processes, the pipelined callbacks, max over ranks, ONE JSON line from rank 0."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, AMC_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = ["timeout", "-k", "10", "300", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40",
+           "--warmup", "10", "--spinup-s", "0.05", "--repeats", "3", "--chains-per-gpu", str(M)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["chains_total"] == 2 * M and d["config"]["callbacks_allreduce_every"] == 10
+    assert "store" in d["config"]["callbacks_allreduce_via"] or "rccl" in d["config"]["callbacks_allreduce_via"]
+    assert 0.90 < d["check"]["acceptance"] < 0.97
+    # whole-job value: both shards' updates over the slowest rank's wall time
+    assert abs(d["value"] - 2 * M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
