@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
-rm -rf "$R/tools/_variants"
+[ -n "$KEEP" ] || rm -rf "$R/tools/_variants"
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}
   make -C "$R/montecarlo_amd/csrc" -B HIPFLAGS="$BASE $f" 2>&1 | grep -E " error|Error" || true
