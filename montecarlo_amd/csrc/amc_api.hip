@@ -112,6 +112,7 @@ struct amc_handle {
     uint64_t red_t_counted = 0;
     void* comm = nullptr;
     double* d_comm = nullptr;
+    hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
@@ -882,7 +883,9 @@ int amc_destroy(amc_handle* h)
     if (!h) return AMC_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (hipModule_t m : h->rtc_mods) (void)hipModuleUnload(m);
     (void)hipFree(h->d_comm);
     (void)hipFree(h->d_gd_acc);
@@ -1511,9 +1514,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
         if (!h->pg_tail_valid || std::memcmp(&tl, &h->pg_tail_host, sizeof(tl)) != 0) {
-            // stream-ordered: launches already queued read the old record; hipMemcpyAsync from pageable memory has
-            // taken its copy of `tl` when it returns
-            AMC_HIP(hipMemcpyAsync(h->d_pg_tail, &tl, sizeof(tl), hipMemcpyHostToDevice, h->stream));
+            // stream-ordered, the record travels as a kernel argument: launches already queued read the old one
+            hipLaunchKernelGGL(amc::pg_tail_store_kernel, dim3(1), dim3(64), 0, h->stream, tl, h->d_pg_tail);
+            AMC_HIP(hipGetLastError());
             h->pg_tail_host = tl;
             h->pg_tail_valid = true;
         }
@@ -1777,6 +1780,7 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
         return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
     }
     AMC_HIP(hipMalloc(&h->d_comm, 256 * sizeof(double)));
+    AMC_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     return AMC_OK;
 }
 
@@ -1786,11 +1790,15 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
     if (n < 0 || n > 256) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, 256]");
     if (!h->comm) return AMC_OK;   // single shard: the local sum is the global sum
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipMemcpyAsync(h->d_comm, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    // The values are the caller's (host) numbers: nothing here depends on work queued on the engine's stream, so the
+    // collective runs on a stream of its own and the host waits for THAT only -- on the engine's stream the wait would
+    // drain every sweep queued behind the callback (bench.py keeps ten in flight).  Every rank must call this in the
+    // same order relative to its other collectives on this communicator (the estimator's in-place all-reduce).
+    AMC_HIP(hipMemcpyAsync(h->d_comm, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
+    const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->comm_stream);
     if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    AMC_HIP(hipMemcpyAsync(buf, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    AMC_HIP(hipStreamSynchronize(h->stream));
+    AMC_HIP(hipMemcpyAsync(buf, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
+    AMC_HIP(hipStreamSynchronize(h->comm_stream));
     return AMC_OK;
 }
 

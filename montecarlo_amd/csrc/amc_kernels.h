@@ -1181,6 +1181,13 @@ struct PgArgs {
     // [NL*4]; 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
 };
+// Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
+// to outlive the call and launches already queued keep reading the old record until they are done.
+__global__ void pg_tail_store_kernel(PgTail value, PgTail* dst)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
+}
+
 enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kernel final reduction
 
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
