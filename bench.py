@@ -284,9 +284,10 @@ def main():
     for i in range(args.steps):
         step(i)
     finish_callback()                      # the last callback's all-reduce belongs to the timed region
-    event_ms = eng.timing_end()            # HIP events on the engine's stream, bracketing exactly the K launches
+    eng.timing_mark()                      # end event behind the K-th launch (asynchronous) ...
     barrier()
     elapsed = time.perf_counter() - t0
+    event_ms = eng.timing_end()            # ... HIP events on the engine's stream, bracketing exactly the K launches
     if grp is not None:
         both = grp.allgather((elapsed, event_ms))              # max over ranks
         elapsed, event_ms = max(b[0] for b in both), max(b[1] for b in both)

@@ -281,6 +281,9 @@ int  amc_get_stream(amc_handle *h, void **stream);
  * one, waits for it and returns the elapsed device time between the two in ms. */
 int  amc_timing_begin(amc_handle *h);
 int  amc_timing_end(amc_handle *h, double *elapsed_ms);
+/* Optional: records the END event now, without waiting (amc_timing_end then only waits and reads), so that a host can
+ * put its own synchronisation point between the two without paying for two blocking waits. */
+int  amc_timing_mark(amc_handle *h);
 
 /* Cross-shard sum over RCCL (xGMI) for hosts without torch.distributed (Julia):
  * nccl_unique_id is the 128-byte ncclUniqueId made by amc_comm_unique_id on rank 0

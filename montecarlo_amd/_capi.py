@@ -114,6 +114,7 @@ def load() -> C.CDLL:
         "amc_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
         "amc_timing_begin": (C.c_int, [H]),
         "amc_timing_end": (C.c_int, [H, dp]),
+        "amc_timing_mark": (C.c_int, [H]),
         "amc_comm_unique_id": (C.c_int, [C.c_void_p]),
         "amc_comm_init": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "amc_allreduce_sum": (C.c_int, [H, dp, C.c_int]),
@@ -407,6 +408,10 @@ class HipEngine:
         ms = C.c_double(0.0)
         _check(self._lib.amc_timing_end(self._h, C.byref(ms)))
         return ms.value
+
+    def timing_mark(self) -> None:
+        """Record the end event now (asynchronous); timing_end then waits for it and returns the elapsed device time."""
+        _check(self._lib.amc_timing_mark(self._h))
 
     # -- RCCL through the C ABI (what the Julia binding uses) ----------------------
     @staticmethod

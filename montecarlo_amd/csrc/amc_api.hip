@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cmath>
@@ -109,6 +110,7 @@ struct amc_handle {
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
     bool red_pending = false;
+    bool ev1_marked = false;    // amc_timing_mark recorded the end event already
     uint64_t red_t_counted = 0;
     void* comm = nullptr;
     double* d_comm = nullptr;
@@ -1695,11 +1697,31 @@ int amc_pg_set_accumulated(amc_handle* h, int n_learn, const int* learn_ids, con
     return AMC_OK;
 }
 
+// Wait for everything queued on the stream.  The runtime's blocking wait parks the thread on an interrupt after a
+// short spin and wakes it tens of microseconds after the device is done -- as long as a whole sweep; a host that steps
+// the engine (callbacks, short timed regions) sees that latency on every hand-over.  So: poll the stream for up to 5 ms
+// (a query is a read of the queue's completion signal), then fall back to the blocking wait.
+static hipError_t wait_stream(hipStream_t stream)
+{
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63) == 63) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 5000000ll) break;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
 int amc_sync(amc_handle* h)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sync: NULL handle");
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipStreamSynchronize(h->stream));
+    AMC_HIP(wait_stream(h->stream));
     return AMC_OK;
 }
 
@@ -1718,11 +1740,22 @@ int amc_timing_begin(amc_handle* h)
     return AMC_OK;
 }
 
+int amc_timing_mark(amc_handle* h)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_timing_mark: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipEventRecord(h->ev1, h->stream));
+    h->ev1_marked = true;
+    return AMC_OK;
+}
+
 int amc_timing_end(amc_handle* h, double* elapsed_ms)
 {
     if (!h || !elapsed_ms) return fail(AMC_ERR_BAD_ARG, "amc_timing_end: NULL argument");
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->ev1_marked) AMC_HIP(hipEventRecord(h->ev1, h->stream));
+    h->ev1_marked = false;
+    AMC_HIP(wait_stream(h->stream));           // the end event has completed once the stream has drained up to it
     AMC_HIP(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     AMC_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
