@@ -564,6 +564,43 @@ int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid
 
 }  // namespace
 
+// Wait for everything queued on the stream.  The runtime's blocking wait parks the thread on an interrupt after a
+// short spin and wakes it tens of microseconds after the device is done -- as long as a whole sweep; a host that steps
+// the engine (callbacks, short timed regions) sees that latency on every hand-over.  So: poll the stream for up to 5 ms
+// (a query is a read of the queue's completion signal), then fall back to the blocking wait.
+static hipError_t wait_stream(hipStream_t stream)
+{
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63) == 63) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 5000000ll) break;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
+static hipError_t wait_event(hipEvent_t ev)
+{
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63) == 63) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 5000000ll) break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+
+
 extern "C" {
 
 const char* amc_last_error(void) { return g_last_error.c_str(); }
@@ -1404,7 +1441,7 @@ int amc_reduce_end(amc_handle* h, double* out)
     if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce_end: NULL argument");
     if (!h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_end: no reduction in flight (call amc_reduce_begin)");
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipEventSynchronize(h->ev_red));     // waits for the reduction only, not for work queued after it
+    AMC_HIP(wait_event(h->ev_red));              // waits for the reduction only, not for work queued after it
     h->red_pending = false;
     const int n_vals = 4 + h->K;
     double slot_total;
@@ -1555,7 +1592,7 @@ int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batc
     const int rc = pg_launch(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &nl);
     if (rc != AMC_OK || n_learn == 0) return rc;
     AMC_HIP(hipMemcpyAsync(h->h_pg_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    AMC_HIP(hipStreamSynchronize(h->stream));
+    AMC_HIP(wait_stream(h->stream));
     for (int l = 0; l < n_learn; ++l) {
         for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_pg_out[l * 4 + i];
         out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
@@ -1695,26 +1732,6 @@ int amc_pg_set_accumulated(amc_handle* h, int n_learn, const int* learn_ids, con
                                hipMemcpyHostToDevice, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));      // the caller's buffer is only valid during the call
     return AMC_OK;
-}
-
-// Wait for everything queued on the stream.  The runtime's blocking wait parks the thread on an interrupt after a
-// short spin and wakes it tens of microseconds after the device is done -- as long as a whole sweep; a host that steps
-// the engine (callbacks, short timed regions) sees that latency on every hand-over.  So: poll the stream for up to 5 ms
-// (a query is a read of the queue's completion signal), then fall back to the blocking wait.
-static hipError_t wait_stream(hipStream_t stream)
-{
-    timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e != hipErrorNotReady) return e;
-        if ((spins & 63) == 63) {
-            timespec t1;
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 5000000ll) break;
-        }
-    }
-    return hipStreamSynchronize(stream);
 }
 
 int amc_sync(amc_handle* h)

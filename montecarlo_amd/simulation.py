@@ -244,12 +244,19 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
                     sim.t = t + n - 1
                     t += advance
                     continue
-            if fuse and len(due) in (2, 3):
-                n = _pgmc_group(sim, due, t)
+            if fuse and len(due) >= 2:
+                # [Metropolis, estimator(, update)] as ONE engine call for as many time steps as schedule nothing else --
+                # and through the step at which later algorithms of the list (callbacks, StoreParameters) are due as well:
+                # they run after the three at that t (list order, src/simulation.jl:185-190) and see the same state
+                m, n = _pgmc_group(sim, due, t)
                 if n:
-                    for k in due:
+                    for k in due[:m]:
                         sim.counters[k] += n
                     sim.t = t + n - 1
+                    for k in range(n_alg):                                          # the others due at the group's last step
+                        if k not in due[:m] and _due(sim, k) == sim.t:
+                            sim.algorithms[k].make_step(sim)
+                            sim.counters[k] += 1
                     t += n
                     continue
             for i, k in enumerate(due):                                             # :185-190
@@ -274,28 +281,32 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
         sim._finalise_summary()
 
 
-def _pgmc_group(simulation: Simulation, due: Sequence[int], t: int) -> int:
-    """If the algorithms due at ``t`` are exactly [fusable Metropolis, its device-resident estimator(, that
-    estimator's update)] in this order, issue the next n time steps with the same pattern (and nothing else due) as
-    ONE engine call and return n; 0 when the pattern does not apply."""
+def _pgmc_group(simulation: Simulation, due: Sequence[int], t: int):
+    """If the algorithms due at ``t`` START with [fusable Metropolis, its device-resident estimator(, that estimator's
+    update)] in this order, issue the next n time steps with that pattern as ONE engine call and return (m, n): m = how
+    many leading entries of ``due`` the pattern covers.  The group runs up to and including the first step at which
+    any other algorithm is due, provided every algorithm due there comes AFTER the pattern in the list (it then runs
+    after the group and observes the state it leaves, exactly as when stepping one by one); otherwise it stops the step
+    before.  (0, 0) when the pattern does not apply."""
     sim = simulation
     algs = [sim.algorithms[k] for k in due]
     if not getattr(algs[0], "fusable", False) or getattr(algs[1], "pgmc_role", None) != "estimator":
-        return 0
+        return 0, 0
     est = algs[1]
-    if getattr(est, "metropolis", None) is not algs[0]:
-        return 0
-    upd = None
-    if len(due) == 3:
-        upd = algs[2]
-        if getattr(upd, "pgmc_role", None) != "update" or getattr(upd, "estimator", None) is not est:
-            return 0
-    others = [d for j in range(len(sim.algorithms)) if j not in due for d in [_due(sim, j)] if d is not None]
-    t_last = min((min(others) - 1) if others else sim.steps, sim.steps)
-    n = min(_consecutive(sim.schedulers[k], sim.counters[k], t, t_last) for k in due)
-    if n < 1 or not hasattr(est, "make_steps_grouped"):
-        return 0
-    return n if est.make_steps_grouped(sim, n, upd) else 0
+    if getattr(est, "metropolis", None) is not algs[0] or not hasattr(est, "make_steps_grouped"):
+        return 0, 0
+    m, upd = 2, None
+    if len(due) >= 3 and getattr(algs[2], "pgmc_role", None) == "update" and getattr(algs[2], "estimator", None) is est:
+        m, upd = 3, algs[2]
+    head = list(due[:m])
+    others = [(j, d) for j in range(len(sim.algorithms)) if j not in head for d in [_due(sim, j)] if d is not None]
+    s_other = min((d for _, d in others), default=sim.steps + 1)
+    after = all(j > head[-1] for j, d in others if d == s_other)
+    t_last = min(s_other if after else s_other - 1, sim.steps)
+    n = min(_consecutive(sim.schedulers[k], sim.counters[k], t, t_last) for k in head)
+    if n < 1:
+        return 0, 0
+    return (m, n) if est.make_steps_grouped(sim, n, upd) else (0, 0)
 
 
 def _observed_next(simulation: Simulation, later: Sequence[int]) -> bool:

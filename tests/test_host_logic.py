@@ -287,5 +287,6 @@ def test_grouped_pgmc_issues_few_engine_calls(oracle, tmp_path):
 
     sim, _ = _pgmc_sim(oracle, tmp_path, 100, factory=Counting)
     ma.run(sim)
-    # callbacks at 20, 45, 70, 95, 100 cut the run into groups that end right before an observed step
-    assert sum(calls) == 100 - 5 and max(calls) == 24 and len(calls) <= 6
+    # callbacks at 20, 45, 70, 95, 100 cut the run into groups that END WITH the observed step: StoreCallbacks comes after
+    # the three in the list, so it runs behind the group and sees the state it leaves
+    assert calls == [20, 25, 25, 25, 5]
