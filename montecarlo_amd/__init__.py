@@ -11,7 +11,8 @@ from .metropolis import Metropolis, callback_acceptance, callback_energy, callba
 from .policy_guided import (ANPG, BLANPG, BLAPG, BLPG, NPG, VPG, GradientData, PolicyGradientEstimator,
                             PolicyGradientUpdate, Static, average, initialise_gradient_data, learning_step,
                             log_proposal_density, withgrad_log_proposal_density)
-from .sharding import allreduce_sum, shard_range
+from . import sharding
+from .sharding import allreduce_sum, init_store_group, shard_range
 from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCallbacks, StoreParameters,
                          build_schedule, julia_repr, run)
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
@@ -25,7 +26,7 @@ __all__ = [
     "ANPG", "BLANPG", "BLAPG", "BLPG", "NPG", "VPG", "Static", "GradientData", "PolicyGradientEstimator",
     "PolicyGradientUpdate", "average", "initialise_gradient_data", "learning_step",
     "log_proposal_density", "withgrad_log_proposal_density",
-    "allreduce_sum", "shard_range",
+    "allreduce_sum", "init_store_group", "shard_range", "sharding",
     "AriannaAlgorithm", "PrintTimeSteps", "Simulation", "StoreCallbacks", "StoreParameters",
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",

@@ -12,8 +12,14 @@ import torch                      # first: libamc.so then shares torch's HIP run
 import torch.distributed as dist
 import montecarlo_amd as ma
 
-torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+USE_STORE = os.environ.get("AMC_TEST_GROUP") == "store"        # ranks joined over the launcher's TCP store only
+if USE_STORE:
+    grp = ma.sharding.init_store_group()
+    WORLD, RANK = grp.world_size, grp.rank
+else:
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    WORLD, RANK = dist.get_world_size(), dist.get_rank()
 out = {}
 for mode in ("comm", "host"):
     chains = ma.ParticleChains.uniform(60_000, 2.0, -2.0, 2.0)
@@ -26,13 +32,16 @@ for mode in ("comm", "host"):
     with tempfile.TemporaryDirectory() as d:
         sim = ma.Simulation(chains, al, 120, path=d, verbose=False)
         est = sim.algorithms[1]
-        if mode == "comm" and dist.get_world_size() == 1:
+        if mode == "comm" and WORLD == 1:
             # one rank: the automatic choice is the plain device-resident path; take the communicator route explicitly
             assert est.connect_shards()
             est.device_resident = True
         ma.run(sim)
     out[mode] = dict(sigma=[m.sigma for m in pool], device_resident=est.device_resident,
                      connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]))
-if dist.get_rank() == 0:
+if RANK == 0:
     print(json.dumps(out))
-dist.destroy_process_group()
+if USE_STORE:
+    ma.sharding.barrier()
+else:
+    dist.destroy_process_group()

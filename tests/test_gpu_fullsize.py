@@ -390,14 +390,16 @@ def test_accept_filter_soak_at_full_size(gpu, monkeypatch):
     assert rate == pytest.approx(KATS["analytic"]["acceptance"]["beta=2.0,sigma=0.1"], abs=1e-4)
 
 
-def test_sharded_pgmc_device_resident_over_rccl():
-    """PGMC inside a torch.distributed NCCL (= RCCL) process group: PolicyGradientEstimator.connect_shards() hands the
-    engines a communicator of their own, the fold is all-reduced in place on the device and the learning step stays
-    there; the learned sigma equals the host path's (pg_estimate + torch all-reduce).  One rank here (the GPU box has
-    one GPU); the code path is the N-rank one."""
+@pytest.mark.parametrize("group", ["nccl", "store"])
+def test_sharded_pgmc_device_resident_over_rccl(group):
+    """PGMC with the shards connected: PolicyGradientEstimator.connect_shards() hands the engines a communicator of
+    their own (the ncclUniqueId travels over a torch.distributed NCCL process group, or over the launcher's TCP store
+    alone -- sharding.init_store_group, no process group), the fold is all-reduced in place on the device and the
+    learning step stays there; the learned sigma equals the host path's (pg_estimate + host-side sum).  One rank here
+    (the GPU box has one GPU); the code path is the N-rank one."""
     import json, subprocess, sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if group == "nccl" else "29543", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AMC_TEST_GROUP=group)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "pgmc_comm_worker.py")],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
