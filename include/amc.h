@@ -174,6 +174,17 @@ int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, 
  * Float64 state only.  Every accept decision takes the reference-ordered arithmetic (no accept filter). */
 int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
                                const char *sample_expr, const char *logq_expr, const char *dlogq_expr, amc_handle **out);
+/* The same with a script-defined ACTION -- the reference's Action interface (src/metropolis.jl:15-119; the displacement's
+ * methods are example/particle_1d/particle_1d.jl:30-40) for a one-parameter action on the position:
+ *     perform_expr   the position after perform_action!(system, action), from `x` and `delta`      (displacement: x + delta)
+ *     invert_expr    the parameter of the inverted action, invert_action!(action, system), from `delta` and the NEW
+ *                    position `x`                                                                 (displacement: -delta)
+ * A rejected step re-applies the inverted action (perform_action_cached!, metropolis.jl:119,187).  Both NULL: the
+ * displacement (= amc_create_proposal_model); they come together.  log_proposal_density must be the density of the move
+ * in state space where the action is not a translation (e.g. scaling x -> x exp(delta): logq carries -log|x exp(delta)|). */
+int  amc_create_action_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
+                             const char *sample_expr, const char *logq_expr, const char *dlogq_expr,
+                             const char *perform_expr, const char *invert_expr, amc_handle **out);
 /* Compile-only check of a potential expression (needs no GPU); the compiler log, if any, is copied to log. */
 int  amc_potential_check(const char *potential_expr, char *log, int log_capacity);
 

@@ -18,7 +18,7 @@ from .simulation import (AriannaAlgorithm, PrintTimeSteps, Simulation, StoreCall
 from .storage import StoreHistogram, StoreSnapshots, checkpoint, restore
 from .trajectories import DAT, TXT, StoreBackups, StoreLastFrames, StoreTrajectories
 from .system import Action, AriannaSystem, Policy
-from .system import CustomPotential, Displacement, Move, ParticleChains, ScaledGaussian, ScriptPolicy, StandardGaussian, potential
+from .system import CustomPotential, Displacement, Move, ParticleChains, ScaledGaussian, ScriptAction, ScriptPolicy, StandardGaussian, potential
 
 __all__ = [
     "AmcError", "HipEngine", "SplitEngine", "device_count",
@@ -31,5 +31,5 @@ __all__ = [
     "build_schedule", "julia_repr", "run",
     "StoreHistogram", "StoreSnapshots", "checkpoint", "restore",
     "DAT", "TXT", "StoreBackups", "StoreLastFrames", "StoreTrajectories",
-    "Action", "AriannaSystem", "Policy", "CustomPotential", "Displacement", "Move", "ParticleChains", "ScaledGaussian", "ScriptPolicy", "StandardGaussian", "potential",
+    "Action", "AriannaSystem", "Policy", "CustomPotential", "Displacement", "Move", "ParticleChains", "ScaledGaussian", "ScriptAction", "ScriptPolicy", "StandardGaussian", "potential",
 ]

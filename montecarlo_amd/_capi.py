@@ -81,6 +81,8 @@ def load() -> C.CDLL:
         "amc_create_policy_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_create_proposal_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                                 C.POINTER(H)]),
+        "amc_create_action_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                              C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -200,14 +202,15 @@ class HipEngine:
         self._h = C.c_void_p()
         enc = lambda t: None if t is None else str(t).encode()
         if proposal is not None:
-            # script-defined sample_action! / log_proposal_density (/ its sigma-derivative): (sample, logq, dlogq or None)
+            # script-defined sample_action! / log_proposal_density (/ its sigma-derivative) and, optionally, the action's
+            # perform_action! / invert_action!: (sample, logq, dlogq or None[, perform, invert])
             if scale_expr is not None:
                 raise AmcError("a script-defined proposal and a ScaledGaussian scale cannot be combined")
-            sample, logq, dlogq = (list(proposal) + [None])[:3]
+            sample, logq, dlogq, perform, invert = (list(proposal) + [None] * 4)[:5]
             if expr is None:
                 cfg.potential = POTENTIALS[potential]
-            _check(lib.amc_create_proposal_model(C.byref(cfg), enc(expr), enc(reward_expr), enc(sample), enc(logq), enc(dlogq),
-                                                 C.byref(self._h)))
+            _check(lib.amc_create_action_model(C.byref(cfg), enc(expr), enc(reward_expr), enc(sample), enc(logq), enc(dlogq),
+                                               enc(perform), enc(invert), C.byref(self._h)))
         elif scale_expr is not None:
             # script-defined policy of the Gaussian-displacement family: proposal width sigma * scale(x)
             if expr is None:

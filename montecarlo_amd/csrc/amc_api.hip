@@ -455,7 +455,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
             return AMC_OK;
         }
     }
-    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ] ] ]
+    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ]
+    //             [ '\x07' perform ] [ '\x08' invert ] ] ]
     const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
     const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
     std::string expr = expr_full;
@@ -468,7 +469,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         expr.erase(at);
         return tail;
     };
+    const std::string e_invert = cut_tail('\x08'), e_perform = cut_tail('\x07');
     const std::string e_dlogq = cut_tail('\x06'), e_logq = cut_tail('\x05'), e_sample = cut_tail('\x04'), e_scale = cut_tail('\x03');
+    if (!e_perform.empty()) src += "#define AMC_USER_PERFORM(x, delta) (" + e_perform + ")\n";
+    if (!e_invert.empty()) src += "#define AMC_USER_INVERT(delta, x) (" + e_invert + ")\n";
     if (!e_sample.empty()) src += "#define AMC_USER_SAMPLE(z, x, sigma) (" + e_sample + ")\n";
     if (!e_logq.empty()) src += "#define AMC_USER_LOGQ(delta, x, sigma) (" + e_logq + ")\n";
     if (!e_dlogq.empty()) src += "#define AMC_USER_DLOGQ(delta, x, sigma) (" + e_dlogq + ")\n";
@@ -617,7 +621,7 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-struct ProposalExprs { const char *sample, *logq, *dlogq; };
+struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; };
 
 static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
                        const char* scale_expr = nullptr, const ProposalExprs* proposal = nullptr)
@@ -656,6 +660,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
             int rc_p = validate_potential_expr(proposal->sample, "sample_action expression", "z");
             if (rc_p == AMC_OK) rc_p = validate_potential_expr(proposal->logq, "log_proposal_density expression", "delta");
             if (rc_p == AMC_OK && proposal->dlogq) rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "sigma");
+            if (rc_p == AMC_OK && (proposal->perform != nullptr) != (proposal->invert != nullptr))
+                rc_p = fail(AMC_ERR_BAD_ARG, "amc_create_action_model: perform_expr and invert_expr come together (No invert_action! is defined)");
+            if (rc_p == AMC_OK && proposal->perform) rc_p = validate_potential_expr(proposal->perform, "perform_action expression", "delta");
+            if (rc_p == AMC_OK && proposal->invert) rc_p = validate_potential_expr(proposal->invert, "invert_action expression", "delta");
             if (rc_p != AMC_OK) return rc_p;
             if (state_dtype != AMC_DTYPE_F64)
                 return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: script-defined proposals are offered for Float64 state");
@@ -734,6 +742,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (potential_expr && proposal) {
         h->pot_expr += std::string("\x04") + proposal->sample + std::string("\x05") + proposal->logq;
         if (proposal->dlogq) h->pot_expr += std::string("\x06") + proposal->dlogq;
+        if (proposal->perform) h->pot_expr += std::string("\x07") + proposal->perform + std::string("\x08") + proposal->invert;
         h->script_policy = true;
         h->script_dlogq = proposal->dlogq != nullptr;
     }
@@ -883,8 +892,19 @@ int amc_create_policy_model(const amc_config* cfg, const char* potential_expr, c
     return create_impl(&c2, pot, out, reward_expr, scale_expr);
 }
 
+int amc_create_action_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* sample_expr,
+                            const char* logq_expr, const char* dlogq_expr, const char* perform_expr, const char* invert_expr,
+                            amc_handle** out);
+
 int amc_create_proposal_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* sample_expr,
                               const char* logq_expr, const char* dlogq_expr, amc_handle** out)
+{
+    return amc_create_action_model(cfg, potential_expr, reward_expr, sample_expr, logq_expr, dlogq_expr, nullptr, nullptr, out);
+}
+
+int amc_create_action_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* sample_expr,
+                            const char* logq_expr, const char* dlogq_expr, const char* perform_expr, const char* invert_expr,
+                            amc_handle** out)
 {
     if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: NULL argument");
     if (!sample_expr || !logq_expr)
@@ -899,7 +919,7 @@ int amc_create_proposal_model(const amc_config* cfg, const char* potential_expr,
     std::memset(&c2, 0, sizeof(c2));
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
     c2.potential = AMC_POTENTIAL_CUSTOM;
-    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr};
+    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 

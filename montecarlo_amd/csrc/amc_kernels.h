@@ -110,7 +110,27 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
 //                                     Enzyme / Zygote, gradients.jl:28-33); optional, needed by the estimator only
 // mc_step! (metropolis.jl:176-190) evaluates the forward density at the old state and the backward one, of the
 // inverted action, at the new state; nothing cancels, every decision takes the reference-ordered arithmetic.
+// ... and a script-defined ACTION (the reference's Action interface, src/metropolis.jl:15-119: perform_action!,
+// invert_action!, perform_action_cached!; example/particle_1d/particle_1d.jl:30-40 are the displacement's methods), for a
+// one-parameter action on the position:
+//   AMC_USER_PERFORM(x, delta)    the position after perform_action!(system, action)        (displacement: x + delta)
+//   AMC_USER_INVERT(delta, x)     the parameter of the inverted action, given the NEW state (displacement: -delta)
+// perform_action_cached! (the revert) re-applies the inverted action, as the reference does (metropolis.jl:119,187).
 #ifdef AMC_USER_LOGQ
+#ifndef AMC_USER_PERFORM
+#define AMC_USER_PERFORM(x, delta) ((x) + (delta))
+#endif
+#ifndef AMC_USER_INVERT
+#define AMC_USER_INVERT(delta, x) (-(delta))
+#endif
+__device__ __forceinline__ real_t user_perform(real_t x, real_t delta, const double* amc_tables_)
+{
+    return (real_t)(AMC_USER_PERFORM(x, delta));
+}
+__device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const double* amc_tables_)
+{
+    return (real_t)(AMC_USER_INVERT(delta, x));
+}
 __device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_)
 {
     return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
@@ -270,15 +290,15 @@ __device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, 
     const real_t delta = user_sample(z, x, sigma, T);                    // :177 sample_action!
     const double logq_f = user_logq(delta, x, sigma, T);                 // :178
     const real_t e1 = potential<POT>(x, T);
-    const real_t xn = x + delta;                                         // :179 perform_action!
+    const real_t xn = user_perform(x, delta, T);                         // :179 perform_action!
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
-    const real_t nd = -delta;                                            // :181 invert_action!
+    const real_t nd = user_invert(delta, xn, T);                         // :181 invert_action!
     const double logq_b = user_logq(nd, xn, sigma, T);                   // :182
     const double arg = ((double)dlogp + logq_b) - logq_f;                // :183
     const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
     const bool acc = c_pos | (c_rng & c_exp);
-    x = acc ? xn : (real_t)(xn + nd);                                    // :187 perform_action_cached!
+    x = acc ? xn : user_perform(xn, nd, T);                              // :187 perform_action_cached!
     return acc;
 }
 #endif
@@ -1262,13 +1282,13 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     const real_t delta = user_sample(z, x, sigma, T);
     const double logq_f = user_logq(delta, x, sigma, T), dlogq_f = user_dlogq(delta, x, sigma, T);
     const real_t e1 = potential<POT>(x, T);
-    const real_t xn = x + delta;
+    const real_t xn = user_perform(x, delta, T);
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
-    const real_t nd = -delta;
+    const real_t nd = user_invert(delta, xn, T);
     const double logq_b = user_logq(nd, xn, sigma, T), dlogq_b = user_dlogq(nd, xn, sigma, T);
-    x = xn + nd;
+    x = user_perform(xn, nd, T);
     const double arg = ((double)dlogp + logq_b) - logq_f;
     double ex = exp_core_f64(arg, T);
     asm volatile("" : "+v"(ex));

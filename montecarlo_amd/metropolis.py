@@ -72,10 +72,12 @@ class Metropolis(AriannaAlgorithm):
             if len(scales) != 1:
                 raise ValueError("all moves of a pool must share one policy: either StandardGaussian or one ScaledGaussian(scale)")
             extra["scale_expr"] = scales.pop()
-        scripts = {(m.policy.sample, m.policy.logq, m.policy.dlogq) if hasattr(m.policy, "logq") else None for m in self.pool}
+        scripts = {((m.policy.sample, m.policy.logq, m.policy.dlogq) +
+                    ((m.action.perform, m.action.invert) if hasattr(m.action, "perform") else (None, None)))
+                   if hasattr(m.policy, "logq") else None for m in self.pool}
         if scripts != {None}:
             if len(scripts) != 1:
-                raise ValueError("all moves of a pool must share one policy: one ScriptPolicy, or none")
+                raise ValueError("all moves of a pool must share one policy (and one action): one ScriptPolicy, or none")
             extra["proposal"] = scripts.pop()
         self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains), **extra,
                               potential=chains.potential, beta=chains.beta,

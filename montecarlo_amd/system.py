@@ -111,6 +111,19 @@ class Displacement(Action):
     delta: float = 0.0
 
 
+@dataclass
+class ScriptAction(Action):
+    """A script-defined one-parameter action on the position -- the reference's Action interface
+    (src/metropolis.jl:15-119; Displacement's methods are example/particle_1d/particle_1d.jl:30-40) as two C expressions:
+      ``perform``  the position after perform_action!(system, action), from ``x`` and ``delta``   (Displacement: "x + delta")
+      ``invert``   the parameter of the inverted action, from ``delta`` and the NEW position ``x`` (Displacement: "-delta")
+    A rejected step re-applies the inverted action, like perform_action_cached!.  Used with a ScriptPolicy, whose ``logq``
+    must be the density of the move in state space (for a scaling x -> x exp(delta) it carries -log|x exp(delta)|)."""
+    perform: str = "x + delta"
+    invert: str = "-delta"
+    delta: float = 0.0
+
+
 @dataclass(frozen=True)
 class StandardGaussian(Policy):
     """Policy: delta ~ Normal(0, sigma) (particle_1d.jl:48-59)."""
@@ -176,8 +189,10 @@ class Move:
         self.parameters = np.atleast_1d(np.asarray(p, dtype=np.float64)).copy()
         if self.parameters.shape != (1,):
             raise ValueError("StandardGaussian has exactly one parameter (sigma)")
-        if not isinstance(self.action, Displacement) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian, ScriptPolicy)):
-            raise TypeError("the HIP engine supports Displacement actions with a StandardGaussian, ScaledGaussian or ScriptPolicy policy only")
+        if not isinstance(self.action, (Displacement, ScriptAction)) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian, ScriptPolicy)):
+            raise TypeError("the HIP engine supports Displacement / ScriptAction actions with a StandardGaussian, ScaledGaussian or ScriptPolicy policy only")
+        if isinstance(self.action, ScriptAction) and not isinstance(self.policy, ScriptPolicy):
+            raise TypeError("a ScriptAction needs a ScriptPolicy: No log_proposal_density is defined for it otherwise")
         self.weight = float(self.weight)
 
     @property

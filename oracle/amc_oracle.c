@@ -305,6 +305,16 @@ void amo_set_custom_proposal(double (*sample)(double, double, double), double (*
     g_custom_sample = sample; g_custom_logq = logq; g_custom_dlogq = dlogq;
 }
 
+/* A script-defined ACTION (the reference's Action interface, src/metropolis.jl:15-119; particle_1d.jl:30-40 are the
+ * displacement's methods): perform(x, delta) = the position after perform_action!, invert(delta, x_new) = the parameter of
+ * the inverted action.  0: the displacement (x + delta, -delta).  Used together with a script-defined proposal. */
+static double (*g_custom_perform)(double, double) = 0;
+static double (*g_custom_invert)(double, double) = 0;
+void amo_set_custom_action(double (*perform)(double, double), double (*invert)(double, double))
+{
+    g_custom_perform = perform; g_custom_invert = invert;
+}
+
 double amo_potential(int pot, double x)
 {
     if (pot == AMO_POT_CUSTOM) return g_custom_potential ? g_custom_potential(x) : (0.0 / 0.0);
@@ -394,6 +404,15 @@ static inline void perform_action(particle_t *p, const move_t *m, int pot, doubl
     *e2 = p->e;
 }
 
+/* perform_action! of a script-defined action (amo_set_custom_action); the displacement when none is set. */
+static inline void script_perform_action(particle_t *p, const move_t *m, int pot, double *e1, double *e2)
+{
+    *e1 = p->e;
+    p->x = g_custom_perform ? g_custom_perform(p->x, m->delta) : p->x + m->delta;
+    p->e = amo_potential(pot, p->x);
+    *e2 = p->e;
+}
+
 /* Julia's min(a, b): NaN if either is NaN (C fmin would return the non-NaN). */
 static inline double julia_min(double a, double b)
 {
@@ -410,13 +429,13 @@ static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, doubl
         m->delta = g_custom_sample(z, p->x, sigma);                    /* :177 sample_action! */
         double logq_f = g_custom_logq(m->delta, p->x, sigma);          /* :178 at the old state */
         double e1c, e2c;
-        perform_action(p, m, pot, &e1c, &e2c);                         /* :179 */
+        script_perform_action(p, m, pot, &e1c, &e2c);                  /* :179 */
         double dlogp_c = delta_log_target_density(e1c, p->beta, e2c, p->beta); /* :180 */
-        m->delta = -m->delta;                                          /* :181 */
+        m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;  /* :181 invert_action!(action, system) */
         double logq_b = g_custom_logq(m->delta, p->x, sigma);          /* :182 at the new state */
         double alpha_c = julia_min(1.0, amo_exp(dlogp_c + logq_b - logq_f)); /* :183 */
         if (alpha_c > u) return 1;                                     /* :184 */
-        perform_action(p, m, pot, &e1c, &e2c);                         /* :187 */
+        script_perform_action(p, m, pot, &e1c, &e2c);                  /* :187 perform_action_cached! */
         return 0;
     }
     /* the policy's width at the state it is asked about: the old one for sample_action! and the forward density, the
@@ -786,13 +805,13 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
         double logq_f = g_custom_logq(m->delta, p->x, sigma);
         double dlogq_f = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
         double e1, e2;
-        perform_action(p, m, pot, &e1, &e2);
+        script_perform_action(p, m, pot, &e1, &e2);
         double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta);
         double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;
-        m->delta = -m->delta;
+        m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;
         double logq_b = g_custom_logq(m->delta, p->x, sigma);
         double dlogq_b = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
-        perform_action(p, m, pot, &e1, &e2);
+        script_perform_action(p, m, pot, &e1, &e2);
         double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f));
         double j = r * alpha;
         gd[0] = j;

@@ -63,6 +63,7 @@ double amo_uniform_accept(uint32_t accept12, uint32_t lo, uint32_t hi);   /* [0,
 double amo_uniform_pick(uint32_t pick12, uint32_t lo);       /* [0,1), 36 bits: categorical move pick */
 void   amo_set_custom_proposal(double (*sample)(double, double, double), double (*logq)(double, double, double),
                                double (*dlogq)(double, double, double));   /* script-defined sample_action! / log_proposal_density */
+void   amo_set_custom_action(double (*perform)(double, double), double (*invert)(double, double));   /* script-defined perform_action! / invert_action! */
 double amo_potential(int pot, double x);
 /* AMO_POT_CUSTOM: `potential` is a free GLOBAL function of the driver script in the reference
  * (MC_harmonic_oscillator.jl:4); the tests install the same C expression they hand to amc_create_custom,

@@ -271,11 +271,14 @@ def install_custom_proposal(proposal) -> None:
     lib = load()
     lib.amo_set_custom_proposal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.amo_set_custom_proposal.restype = None
+    lib.amo_set_custom_action.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amo_set_custom_action.restype = None
     if proposal is None:
         lib.amo_set_custom_proposal(None, None, None)
+        lib.amo_set_custom_action(None, None)
         return
-    sample, logq, dlogq = (list(proposal) + [None])[:3]
-    key = "p" + hashlib.sha1(repr((sample, logq, dlogq)).encode()).hexdigest()[:16]
+    sample, logq, dlogq, perform, invert = (list(proposal) + [None] * 4)[:5]
+    key = "p" + hashlib.sha1(repr((sample, logq, dlogq, perform, invert)).encode()).hexdigest()[:16]
     if key not in _custom_libs:
         d = tempfile.mkdtemp(prefix="amo_prop_")
         src, so = os.path.join(d, "prop.cpp"), os.path.join(d, f"prop_{key}.so")
@@ -283,13 +286,19 @@ def install_custom_proposal(proposal) -> None:
             f.write(_CUSTOM_PROLOGUE +
                     f"double amo_user_sample(double z, double x, double sigma) {{ return ({sample}); }}\n"
                     f"double amo_user_logq(double delta, double x, double sigma) {{ return ({logq}); }}\n" +
-                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else "") + "}\n")
+                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else "") +
+                    (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
+                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     L = _custom_libs[key]
     lib.amo_set_custom_proposal(C.cast(L.amo_user_sample, C.c_void_p), C.cast(L.amo_user_logq, C.c_void_p),
                                 C.cast(L.amo_user_dlogq, C.c_void_p) if dlogq else None)
+    if perform:
+        lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
+    else:
+        lib.amo_set_custom_action(None, None)
 
 
 def _potential_id(potential) -> int:

@@ -156,3 +156,86 @@ def test_estimator_needs_the_sigma_derivative_and_target_distribution_at_scale(g
     assert f.get_parameters(0)[0] == h.get_parameters(0)[0] != 0.6
     f.close()
     h.close()
+
+
+# ---- a script-defined ACTION: multiplicative scaling x -> x exp(delta) ------------------------------------------------
+# perform_action!: x exp(delta); invert_action!: -delta; delta ~ Normal(0, sigma).  The move's density in state space is
+# q(x' | x) = N(delta; 0, sigma) / |x'|, so log_proposal_density carries -log|x exp(delta)| (its backward / forward
+# difference is the Jacobian +delta).  Chains never change sign: started on x > 0 they sample the half-Gaussian
+# p(x) ~ exp(-beta x^2), x > 0, whose <x^2> = 1/(2 beta) and <x> = 1/sqrt(pi beta).
+SCALING = ("sigma*z",
+           "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(sigma) - amc_log(fabs(x)) - delta",
+           "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma",
+           "x*amc_exp(delta)", "-delta")
+
+
+def test_oracle_scaling_action_samples_the_half_gaussian(oracle):
+    s = oracle.OracleSim(4000, potential="harmonic", beta=BETA, sigma=[0.8], weight=[1.0], seed=9, proposal=SCALING)
+    s.set_x(np.random.default_rng(3).uniform(0.1, 2.0, 4000))
+    n, sx, sxx, _ = s.run_pooled_moments(3000, 400, 10, threads=8)
+    assert sxx / n == pytest.approx(0.25, abs=4e-3) and sx / n == pytest.approx(1 / np.sqrt(np.pi * BETA), abs=4e-3)
+    # without the Jacobian term in logq the chain samples exp(-beta x^2) / x instead: <x^2> comes out far lower
+    wrong = oracle.OracleSim(4000, potential="harmonic", beta=BETA, sigma=[0.8], weight=[1.0], seed=9,
+                             proposal=(SCALING[0], "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(sigma)", None, SCALING[3], SCALING[4]))
+    wrong.set_x(np.random.default_rng(3).uniform(0.1, 2.0, 4000))
+    n, sx, sxx, _ = wrong.run_pooled_moments(3000, 400, 10, threads=8)
+    assert sxx / n < 0.2
+    oracle.install_custom_proposal(None)
+
+
+def test_script_action_travels_through_the_host_mirror(oracle, tmp_path):
+    chains = ma.ParticleChains(64, BETA, x=np.random.default_rng(5).uniform(0.2, 1.5, 64))
+    move = ma.Move(ma.ScriptAction(perform=SCALING[3], invert=SCALING[4]), ma.ScriptPolicy(*SCALING[:3]), [0.5], 1.0)
+    sim = ma.Simulation(chains, [dict(algorithm=ma.Metropolis, pool=[move], seed=8, engine_factory=oracle.OracleEngine)], 15,
+                        path=str(tmp_path))
+    ma.run(sim)
+    o = oracle.OracleSim(64, potential="harmonic", beta=BETA, sigma=[0.5], weight=[1.0], seed=8, proposal=SCALING)
+    o.set_x(np.random.default_rng(5).uniform(0.2, 1.5, 64))
+    o.make_steps(15)
+    assert np.array_equal(bits(chains.x), bits(o.state()[0])) and np.all(chains.x > 0)
+    with pytest.raises(TypeError, match="needs a ScriptPolicy"):
+        ma.Move(ma.ScriptAction(), ma.StandardGaussian(), [0.5], 1.0)
+    oracle.install_custom_proposal(None)
+
+
+def test_action_expressions_come_together(amc):
+    kw = dict(n_chains=10, potential="harmonic", beta=BETA, sigma=[0.5], weight=[1.0])
+    with pytest.raises(amc.AmcError, match="come together"):
+        amc.HipEngine(proposal=(SCALING[0], SCALING[1], None, SCALING[3], None), **kw)
+    with pytest.raises(amc.AmcError, match="does not mention delta"):
+        amc.HipEngine(proposal=(SCALING[0], SCALING[1], None, "x*2.0", "-delta"), **kw)
+
+
+@pytest.mark.gpu
+def test_scaling_action_bit_exact_and_half_gaussian_on_the_device(gpu, oracle):
+    M = 20001
+    kw = dict(potential="harmonic", beta=BETA, sigma=[0.3, 0.9], weight=[0.5, 0.5], seed=14, proposal=SCALING)
+    x0 = np.random.default_rng(6).uniform(0.1, 2.0, M)
+    eng = gpu.HipEngine(n_chains=M, **kw)
+    sim = oracle.OracleSim(M, **kw)
+    eng.upload_state(x0)
+    sim.set_x(x0)
+    for n in (1, 1, 7, 20):
+        eng.sweep(n)
+        sim.make_steps(n)
+        x, e = eng.download_state()
+        xo, eo = sim.state()
+        assert np.array_equal(bits(x), bits(xo)) and np.array_equal(bits(e), bits(eo))
+    acc, tot = eng.download_counters()
+    ao, to = sim.counters()
+    assert np.array_equal(acc, ao) and np.array_equal(tot, to)
+    got, want = np.asarray(eng.pg_estimate([0, 1], 2)).reshape(2, 5), sim.pg_estimate([0, 1], 2)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(bits(eng.download_state()[0]), bits(sim.state()[0]))         # revert = perform(x', invert(delta))
+    eng.close()
+    oracle.install_custom_proposal(None)
+    big = gpu.HipEngine(n_chains=2_000_000, potential="harmonic", beta=BETA, sigma=[0.8], weight=[1.0], seed=15, proposal=SCALING,
+                        per_chain_counters=False)
+    big.upload_state(np.random.default_rng(7).uniform(0.1, 2.0, 2_000_000))
+    big.sweep(500)
+    s = np.zeros(4)
+    for _ in range(30):
+        big.sweep(20)
+        s += big.reduce()[:4]
+    assert s[2] / s[3] == pytest.approx(0.25, abs=2e-3) and s[1] / s[3] == pytest.approx(1 / np.sqrt(np.pi * BETA), abs=2e-3)
+    big.close()
