@@ -1,7 +1,9 @@
 # PhiloxRNG.jl -- the engine's draw schedule (DESIGN.md §3) as a Julia AbstractRNG, for the reference's
 # public `R=` plug point (src/metropolis.jl:245,263; src/PolicyGuided/estimator.jl:63,92).
 #
-# NOT EXECUTED IN THIS REPOSITORY'S ENVIRONMENT (no Julia in the image or on the GPU box).  Purpose: on a
+# NOT LOADED BY JULIA IN THIS REPOSITORY'S ENVIRONMENT (no Julia in the image or on the GPU box); its arithmetic is executed
+# from this text by tests/julia_subset.py (a Julia-subset interpreter) and compared with the oracle bit for bit
+# (tests/test_julia_philox.py) -- keep to the subset that interpreter models when editing.  Purpose: on a
 # machine that has Julia, stock `Metropolis(chains; pool, seed, R=PhiloxRNG{seed,1})` consumes exactly the
 # random numbers libamc.so / the oracle use, so the unmodified reference and the GPU path can be compared
 # accept-for-accept (residual: Julia's exp/log vs the spec's, <= 2 ulp, expected flip rate ~1e-16 per update).
