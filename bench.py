@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 (state >> the 256 MiB Infinity Cache); `traffic` / `valu_busy` come from committed rocprofv3 PMC passes
                 and carry their source, commit and whether the kernel sources changed since.
   repeat        the K-step block repeated (untimed by `value`): min / median ms per step.
+  fused_sweepstep16  the same ensemble with 16 MH steps per launch (reported separately, no roofline fraction).
   cpu_baseline  the CPU oracle (C restatement of the reference path, kind "port": the reference is Julia,
                 not runnable here) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -316,6 +317,24 @@ def main():
     n = red[3]
     energy, acceptance = red[0] / n, red[4] / n
 
+    # the sweepstep = 16 form, reported separately -- the state stays in registers between the 16 MH steps of a
+    # launch, so bytes per update fall to 1 and a fraction of the HBM roofline means nothing there
+    fused = None
+    if world == 1:
+        for _ in range(5):
+            eng.sweep(16)
+        eng.sync()
+        fts = []
+        for _ in range(3):
+            eng.timing_begin()
+            for _ in range(20):
+                eng.sweep(16)
+            fts.append(eng.timing_end() * 1e3 / (20 * 16))
+        fused = {"mh_steps_per_launch": 16, "us_per_sweep_min": min(fts), "us_per_sweep_median": sorted(fts)[1],
+                 "chain_updates_per_s": (stop - start) / (min(fts) * 1e-6),
+                 "note": "one launch = 16 mc_step! per chain with x in registers (amc_sweep(h, 16)); not the headline: no HBM "
+                         "round trip per sweep, roofline fraction not meaningful"}
+
     ladder_rows = None
     if rank == 0 and world == 1 and not args.no_ladder and args.chains_per_gpu == M_PER_GPU:
         ladder_rows = ladder(A, (4 * M_PER_GPU, 16 * M_PER_GPU), local_rank)
@@ -365,6 +384,7 @@ def main():
                 "blocks": len(rep_ms), "steps_per_block": args.steps, "ms_per_step_min": min(rep_ms),
                 "ms_per_step_median": sorted(rep_ms)[len(rep_ms) // 2], "ms_per_step_all": rep_ms},
             "check": {"mean_energy": energy, "acceptance": acceptance},
+            "fused_sweepstep16": fused,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()

@@ -50,6 +50,10 @@ def check_line(d, n_gpus, cb_every):
     assert rf["avg_launch_us"] <= d["ms_per_step"] * 1e3 * 1.05
     # the chains sample exp(-2 x^2) poorly after 50 sweeps from U(-2,2), but acceptance is already at its plateau
     assert 0.90 < d["check"]["acceptance"] < 0.97 and 0.2 < d["check"]["mean_energy"] < 1.5
+    if n_gpus == 1 and cb_every == 0:
+        fz = d["fused_sweepstep16"]           # the sweepstep = 16 form, next to the headline, never instead of it
+        assert fz["mh_steps_per_launch"] == 16 and 0 < fz["us_per_sweep_min"] <= fz["us_per_sweep_median"]
+        assert fz["us_per_sweep_min"] < rf["avg_launch_us"]                # no HBM round trip and no launch per sweep
 
 
 def test_single_process_line():
