@@ -390,6 +390,31 @@ def test_accept_filter_soak_at_full_size(gpu, monkeypatch):
     assert rate == pytest.approx(KATS["analytic"]["acceptance"]["beta=2.0,sigma=0.1"], abs=1e-4)
 
 
+def test_pick_table_and_filter_soak_mixed_pool_at_full_size(gpu, monkeypatch):
+    """The K = 2 counterpart: 1e7 chains x 1000 steps of the double well with weights (0.3, 0.7) -- the cumulative weight
+    0.3 is no multiple of 2^-12, so one cell of the pick table is open and ~2.4e-4 of the picks (one wave-step in 32) take
+    the accept draw's 24 low bits and the full categorical walk -- once on the common path (12-bit pick table, accept
+    filter) and once with every wave sent through the walk and the reference-ordered accept (AMC_EXACT_ACCEPT=1): positions
+    and every per-chain, per-move counter must be identical."""
+    kw = dict(n_chains=M_FULL, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.3, 0.7], seed=11)
+    runs = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("AMC_EXACT_ACCEPT", exact)
+        e = gpu.HipEngine(**kw)
+        e.init_uniform(-2, 2)
+        for _ in range(100):
+            e.sweep(1)                   # single-step launches (pre-formed draws) ...
+        e.sweep(900)                     # ... and the multi-step form
+        acc, tot = e.download_counters()
+        runs.append((e.download_state(want_e=False)[0], acc, tot))
+        e.close()
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    tot = runs[0][2]
+    assert np.all(tot.sum(axis=0) == 1000)
+    assert tot[0].sum() / (1000 * M_FULL) == pytest.approx(0.3, abs=2e-5)       # 1e10 picks: sd 4.6e-6
+
+
 @pytest.mark.parametrize("group", ["nccl", "store"])
 def test_sharded_pgmc_device_resident_over_rccl(group):
     """PGMC with the shards connected: PolicyGradientEstimator.connect_shards() hands the engines a communicator of
