@@ -524,7 +524,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
                                            int64_t p, bool v0, bool v1, const double* s_tab, const uint8_t* s_pick,
                                            const double* s_math, double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& log_word,
-                                           const StepDraws* pre = nullptr)
+                                           const StepDraws* pre = nullptr, const MathK& mk = math_k_literal())
 {
     static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
     const int K = a.n_moves;
@@ -557,7 +557,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
             sg1 = s_tab[k1];
         }
         double z0, z1;
-        box_muller(dr.normal, z0, z1, s_math);
+        box_muller(dr.normal, z0, z1, s_math, mk);
         unsigned long long m0, m1m;
         uint32_t acc_bits;
         mh_pair<POT, MULTI>(xv, b0, b1, sg0, sg1, k0, k1, s_tab, m1, z0, z1, dr.normal, pu, have_pu, accept_ctr, a.key0,
@@ -1332,11 +1332,17 @@ __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, 
     const double dlogq = __builtin_fma(d2, c3hi, __builtin_fma(d2, c3lo, -c1));
     // alpha = min(1, exp(arg)) with Julia's NaN-propagating min: exp(arg >= 0) >= 1 and exp(arg <= 0) <= 1 hold exactly
     // for the spec's exp, so  arg >= 0 -> 1;  -708 <= arg < 0 -> exp(arg);  arg < -708 -> 0;  NaN -> NaN
+    // Formed as exp(min(arg, 0)): exp_core(0) == 1.0 exactly (k = 0, r = 0, table entry 2^0), and min maps +inf and every
+    // arg > 0 there (one v_min_f64 instead of a compare and two selects).  The two remaining cases -- NaN, which min turns
+    // into 0, and arg < -708 -- are looked for with one compare and repaired inside a wave-uniform branch almost no wave takes.
     const double arg = (double)dlogp;
-    double ex = exp_core_f64(arg, T);
-    asm volatile("" : "+v"(ex));          // keep the exp unconditional: no divergent branch around it
-    double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
-    alpha = (arg >= 0.0) ? 1.0 : alpha;
+    double alpha = exp_core_f64(__builtin_fmin(arg, 0.0), T);
+    asm volatile("" : "+v"(alpha));       // keep the exp unconditional: no divergent branch around it
+    const bool rare = !(arg >= -708.0);   // arg < -708 or NaN
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+        asm volatile("" : "+v"(alpha));   // not speculatable: the repair stays inside the branch (it was flattened into selects otherwise)
+        alpha = rare ? ((arg != arg) ? arg : 0.0) : alpha;
+    }
     const double j = r * alpha;
     g[0] += j;
     g[1] = __builtin_fma(j, dlogq, g[1]);          // forward and backward gradients coincide for this policy (gradients.jl:106)
@@ -1393,12 +1399,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
     const double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
     unsigned long long wave_acc = 0;
+    // the Box-Muller polynomials' addend coefficients as live 64-bit VGPR values (amc_math.h, MathK): this kernel has no scalar
+    // registers to spare, and a literal addend costs a v_mov_b64 per fma here (18 per pair-iteration before)
+    const MathK mk = math_k_pinned();
     // one mc_step! of the pair (mc_sweep! with mc_steps = 1), its step-log byte pair stored right away
     auto mh = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, int64_t p, bool v0, bool v1) {
         uint32_t lw = 0;
         // SWEEP == 3: K == 1 with the pool-wide counter only -- no step log
         pair_steps<POT, SWEEP == 2, SWEEP != 3, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_pick, s_math, sw_sigma1, sw_den1,
-                                                      sw_rden1, sw_logc1, wave_acc, lw);
+                                                      sw_rden1, sw_logc1, wave_acc, lw, nullptr, mk);
         if (SWEEP != 3 && v0) store_log_pair(sw, sw.log_pos, p, lw);
     };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
@@ -1438,7 +1447,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
-                               z0, z1, s_math);
+                               z0, z1, s_math, mk);
 #if defined(AMC_USER_LOGQ)
                     pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
                     if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);

@@ -425,6 +425,38 @@ def test_pg_estimate_parity(gpu, oracle, M, learn, q):
     e.close()
 
 
+def test_pg_estimate_extreme_arguments(gpu, oracle):
+    """alpha = min(1, exp(arg)) at the ends of its domain (gradients.jl:100-104 with Julia's min): wide moves from large |x|
+    send arg far below -708 (alpha = 0 exactly in the arithmetic spec), arg > 0 gives exactly 1, and chains at NaN / +-inf
+    propagate NaN into the sums like the reference does.  The kernel forms exp(min(arg, 0)) and repairs the two rare cases
+    inside a wave-uniform branch; the oracle keeps the three-way case distinction."""
+    M = 4099
+    kw = dict(potential="harmonic", beta=2.0, sigma=[12.0, 0.3], weight=[0.5, 0.5], seed=17)
+    e, o = gpu.HipEngine(n_chains=M, **kw), oracle.OracleSim(M, **kw)
+    x0 = np.linspace(-40.0, 40.0, M)
+    x0[[7, 100, 2000]] = [0.0, -0.0, 1e-160]
+    e.upload_state(x0)
+    o.set_x(x0)
+    for _ in range(3):
+        g, go = e.pg_estimate([0, 1], 4), o.pg_estimate([0, 1], 4)
+        scale = np.abs(go).max(axis=0) + 1.0
+        assert np.all(np.isfinite(go)) and np.all(np.abs(g - go) <= 1e-10 * scale * np.sqrt(M * 4))
+        assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    # a third of the wide move's samples must have hit the alpha == 0 arm: |delta| ~ 12, e grows by > 354 easily
+    x = o.state()[0]
+    assert np.mean(np.abs(x) > 20) > 0.3
+    # non-finite states: the reward sums that touch them are NaN on both sides, the other chains' positions still agree bit for bit
+    x1 = x.copy()
+    x1[[1, 64, 65, 4098]] = [np.nan, np.inf, -np.inf, 1e200]
+    e.upload_state(x1)
+    o.set_x(x1)
+    g, go = e.pg_estimate([0, 1], 2), o.pg_estimate([0, 1], 2)
+    assert np.array_equal(np.isnan(g), np.isnan(go)) and np.isnan(go[:, :2]).all()          # j and grad j; the policy's own sums stay finite
+    np.testing.assert_allclose(g[:, 2:], go[:, 2:], rtol=1e-10)
+    assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    e.close()
+
+
 def test_pg_estimate_seven_move_pool(gpu, oracle):
     """pgmc_test.jl shape: 7 moves, 6 learnable, q_batch_size 10."""
     sigma, weight = POOLS[7]

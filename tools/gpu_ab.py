@@ -28,7 +28,10 @@ e.init_uniform(-2, 2); out.append(timed(e, lambda n: [e.sweep(1) for _ in range(
 e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
 e.init_uniform(-2, 2); out.append(timed(e, lambda n: [e.sweep(1) for _ in range(n)])); e.close()
 e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=1)
-e.init_uniform(-2, 2); out.append(timed(e, lambda n: e.pgmc_steps(n, [1], 1, [1], [1e-3], [0.0]), 200)); e.close()
+e.init_uniform(-2, 2); out.append(timed(e, lambda n: e.pgmc_steps(n, [1], 1, [1], [1e-3], [0.0]), 200))
+out.append(timed(e, lambda n: [e.pg_accumulate([1], 1) for _ in range(n)], 200)); e.close()
+e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2], weight=[1.0], seed=1, per_chain_counters=False)
+e.init_uniform(-2, 2); out.append(timed(e, lambda n: e.pgmc_steps(n, [0], 1, [1], [1e-3], [0.0]), 200)); e.close()
 print(" ".join(f"{v:6.2f}" for v in out))
 """
 
@@ -46,6 +49,6 @@ else:
         for n in names:
             out = subprocess.run([sys.executable, "-c", CHILD, os.path.join(VAR, n)], capture_output=True, text=True)
             res[n].append(out.stdout.strip() or out.stderr.strip()[-120:])
-    print("us per launch at 1e7 chains: K=1 sweep, K=2 double-well sweep, fused PGMC step (config 5); one column group per round")
+    print("us per launch at 1e7 chains: K=1 sweep, K=2 double-well sweep, fused PGMC step (config 5), estimator launch alone, fused PGMC step with K=1; one column group per round")
     for n in names:
         print(f"{n:24s} " + "  |  ".join(res[n]), flush=True)
