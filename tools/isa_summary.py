@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Developer tool: regenerates profiles/r02_isa_summary.txt from montecarlo_amd/csrc/amc_api.gfx950.s (make -C montecarlo_amd/csrc asm):
+register and spill counts of the kernels the round-2 profiles name, and their per-block instruction mixes (tools/isa_blocks.py)."""
+import os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S = open(os.path.join(ROOT, "montecarlo_amd/csrc/amc_api.gfx950.s")).read()
+NAMED = ["sweep_kernel<0, false, false, false, true, false>", "sweep_kernel<1, true, true, false, true, false>",
+         "sweep_kernel<1, true, true, false, true, true>", "pg_estimate_kernel<0, 1, false, 2>", "pg_estimate_kernel<0, 1, false, 0>",
+         "fold_log_kernel<2, true>", "fold_log_kernel<2, false>", "reduce_kernel<0>"]
+
+
+def meta(sym):
+    k = S.index(".amdhsa_kernel " + sym)
+    m = S[k:S.index(".end_amdhsa_kernel", k)]
+    j = S.index("; Kernel info:", S.index(sym + ":"))
+    tail = S[j:j + 1500]
+    y = S.index("    .name:           " + sym)                       # the code-object metadata record of this kernel
+    rec = S[S.rindex("  - .agpr_count", 0, y):S.index(".wavefront_size", y)]
+    g = lambda pat, txt: int(re.search(pat, txt).group(1))
+    return dict(vgpr=g(r"\.amdhsa_next_free_vgpr (\d+)", m), sgpr=g(r"; TotalNumSgprs: (\d+)", tail), sspill=g(r"\.sgpr_spill_count: (\d+)", rec),
+                vspill=g(r"; ScratchSize: (\d+)", tail), lds=g(r"\.amdhsa_group_segment_fixed_size (\d+)", m))
+
+
+syms = re.findall(r"^(_ZN3amc[^:\s]*):", S, re.M)
+dem = {n: subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip() for n in syms}
+rows = []
+for want in NAMED:
+    for n, d in dem.items():
+        if want in d:
+            rows.append((d, meta(n)))
+sw = [meta(n)["sspill"] for n, d in dem.items() if "sweep_kernel<" in d]
+out = []
+out.append("ISA summary of the kernels the round-2 profiles name (hipcc ROCm 7.2, -O3 --offload-arch=gfx950 -ffp-contract=off; `make -C montecarlo_amd/csrc asm`")
+out.append("writes the full listing, which is not tracked; this file: tools/isa_summary.py).  Loop instruction mixes: tools/isa_blocks.py; counters: r02_pmc_summary.json.")
+out.append("")
+out.append("%-70s %4s %4s %10s %12s %9s" % ("kernel", "vgpr", "sgpr", "sgpr_spill", "scratch_bytes", "lds_bytes"))
+for d, m in rows:
+    out.append("%-70s %4d %4d %10d %12d %9d" % (d[:70], m["vgpr"], m["sgpr"], m["sspill"], m["vspill"], m["lds"]))
+out.append("")
+out.append("sweep_kernel, all %d instantiations: SGPR spills min %d / max %d (round 1: 8..45)." % (len(sw), min(sw), max(sw)))
+out.append(open(os.path.join(ROOT, "tools", "isa_summary_notes.txt")).read().rstrip())
+out.append("")
+out.append("Instruction mix per basic block (>= 15 instructions; tools/isa_blocks.py): f64 = f64-class VALU, mad64 = v_mad_u64_u32 (Philox), v32 = other VALU,")
+out.append("lane = v_readlane / v_writelane (SGPR spill traffic), salu / lds / vmem.  The sampling loops are the blocks with mad64 / f64 counts.")
+for want in NAMED[:5]:
+    out.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_blocks.py"), want], capture_output=True, text=True).stdout.rstrip())
+open(os.path.join(ROOT, "profiles", "r02_isa_summary.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[:16]))
