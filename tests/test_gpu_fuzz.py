@@ -1,0 +1,129 @@
+"""Differential fuzz of the HIP path against the CPU oracle: random configurations, random sequences of operations.
+
+The parity tests elsewhere pick their shapes by hand (BASELINE configs, boundary sizes, edge values); this one draws them:
+pool size 1..8 with arbitrary (normalised) weights -- cumulative weights that are no multiples of 2^-12 open cells of the
+pick table --, sigma over four decades, beta over two, both potentials, ragged ensemble sizes, shards that start at an
+arbitrary EVEN global chain id far from 0, sweepstep 1..4, Float64 and Float32 state, K = 1 with and without per-chain
+counters; then a random walk over {single-step launch, multi-step launch, callback reduction, estimator call, parameter
+update, counter download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
+reductions within RED_RTOL.  AMC_FUZZ_CASES (default 40, ~15 s) and AMC_FUZZ_SEED widen or move the sample.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RED_RTOL = 1e-10
+N_CASES = int(os.environ.get("AMC_FUZZ_CASES", "40"))
+SEED = int(os.environ.get("AMC_FUZZ_SEED", "20260304"))
+
+
+def bits(a, dtype):
+    return np.ascontiguousarray(a, dtype=np.float64).astype(np.float32).view(np.uint32) if dtype == "f32" \
+        else np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def draw_case(rng):
+    K = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 8]))
+    w = rng.dirichlet(np.ones(K) * rng.choice([0.5, 1.0, 5.0]))
+    if rng.random() < 0.3:                                   # weights on the 2^-12 grid: every cell of the pick table closed
+        w = np.maximum(1, np.round(w * 4096)) / 4096
+        w[-1] += 1.0 - w.sum()
+        if w[-1] <= 0:
+            w = np.full(K, 1.0 / K)
+    w = w / w.sum()
+    M = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 513, 1000, 2049, 4099, 6001]))
+    return dict(
+        n_chains=M,
+        chain_offset=int(rng.choice([0, 2, 254, 256, 2 ** 20 + 2, 2 ** 33 + 6, 2 ** 40])),
+        potential=str(rng.choice(["harmonic", "double_well"])),
+        beta=float(np.exp(rng.uniform(np.log(0.2), np.log(20.0)))),
+        sigma=[float(np.exp(rng.uniform(np.log(1e-3), np.log(10.0)))) for _ in range(K)],
+        weight=[float(v) for v in w],
+        seed=int(rng.integers(0, 2 ** 63)),
+        sweepstep=int(rng.choice([1, 1, 1, 2, 4])),
+        dtype=str(rng.choice(["f64", "f64", "f32"])),
+        per_chain_counters=bool(K > 1 or rng.random() < 0.5),
+    )
+
+
+def check_state(e, o, case, where):
+    x, en = e.download_state()
+    xo, eo = o.download_state()
+    dt = case["dtype"]
+    assert np.array_equal(bits(x, dt), bits(xo, dt)), f"{where}: positions differ\n{case}"
+    assert np.array_equal(bits(en, dt), bits(eo, dt)), f"{where}: energies differ\n{case}"
+
+
+def check_counters(e, o, case, where):
+    if case["per_chain_counters"]:
+        a, t = e.download_counters()
+        ao, to = o.download_counters()
+        assert np.array_equal(a, ao) and np.array_equal(t, to), f"{where}: per-chain counters differ\n{case}"
+    else:
+        a, t = e.counter_totals()
+        ao, to = o.counter_totals()
+        assert np.array_equal(a, ao) and np.array_equal(t, to), f"{where}: counter totals differ\n{case}"
+
+
+@pytest.mark.parametrize("index", range(N_CASES))
+def test_random_configuration_random_operations(gpu, oracle, index):
+    rng = np.random.default_rng([SEED, index])
+    case = draw_case(rng)
+    kw = {k: v for k, v in case.items() if k != "per_chain_counters"}
+    e = gpu.HipEngine(per_chain_counters=case["per_chain_counters"], n_chains_global=case["chain_offset"] + case["n_chains"], **kw)
+    o = oracle.OracleEngine(**kw)
+    if rng.random() < 0.5:
+        lo = float(rng.uniform(-3, 0))
+        e.init_uniform(lo, -lo)
+        o.init_uniform(lo, -lo)
+    else:
+        x0 = rng.normal(0.0, 1.5, case["n_chains"])
+        if case["dtype"] == "f32":
+            x0 = x0.astype(np.float32).astype(np.float64)
+        e.upload_state(x0)
+        o.upload_state(x0)
+    check_state(e, o, case, "start")
+    K = len(case["sigma"])
+    for op_index in range(int(rng.integers(6, 16))):
+        op = rng.choice(["single", "single", "multi", "reduce", "estimate", "sigma", "counters"])
+        where = f"case {index}, operation {op_index} ({op})"
+        if op == "single":
+            for _ in range(int(rng.integers(1, 6))):
+                e.sweep(1)
+                o.sweep(1)
+        elif op == "multi":
+            n = int(rng.integers(2, 40))
+            e.sweep(n)
+            o.sweep(n)
+        elif op == "reduce":
+            r, ro = e.reduce(), o.reduce()
+            scale = np.maximum(np.abs(ro), 1.0)
+            assert np.all((np.abs(r - ro) <= RED_RTOL * scale * np.sqrt(case["n_chains"])) | (np.isnan(r) & np.isnan(ro))), \
+                f"{where}: reduction differs\n{r}\n{ro}\n{case}"
+            continue
+        elif op == "estimate":
+            learn = sorted(int(v) for v in rng.choice(K, size=int(rng.integers(1, min(K, 3) + 1)), replace=False))
+            q = int(rng.choice([1, 1, 2, 5]))
+            g, go = e.pg_estimate(learn, q), o.pg_estimate(learn, q)
+            scale = np.abs(go).max(axis=0) + 1.0
+            # Float32 state: the reference-ordered summands are compared to a few ulp of Float32-derived quantities
+            tol = (1e-10 if case["dtype"] == "f64" else 1e-9) * scale * np.sqrt(case["n_chains"] * q)
+            assert np.all(np.abs(g - go) <= tol), f"{where}: estimator sums differ\n{g}\n{go}\n{case}"
+        elif op == "sigma":
+            k = int(rng.integers(0, K))
+            s = float(np.exp(rng.uniform(np.log(1e-3), np.log(10.0))))
+            e.set_parameters(k, [s])
+            o.set_parameters(k, [s])
+            continue
+        elif op == "counters":
+            check_counters(e, o, case, where)
+            continue
+        check_state(e, o, case, where)
+    check_state(e, o, case, f"case {index}, end")
+    check_counters(e, o, case, f"case {index}, end")
+    assert e.step == o.step
+    e.close()
+    o.close()
