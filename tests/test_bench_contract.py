@@ -37,11 +37,9 @@ def check_line(d, n_gpus, cb_every):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 16 * M
-    assert rf["valu_busy"] is None or 0.3 < rf["valu_busy"] < 1.0      # from the committed PMC passes (profiles/) ...
-    if rf["traffic"] is not None:                                      # ... and labelled as such
-        pv = rf["traffic_provenance"]
-        assert pv["measured_in_this_run"] is False and pv["source"].startswith("profiles/") and pv["commit"]
-        assert isinstance(pv["kernel_sources_unchanged_since"], bool)
+    assert rf["valu_busy"] is None                                     # from the committed PMC passes (profiles/) ...
+    assert rf["traffic"] is None                                       # ... taken at 1e7 chains per launch: not quoted for this size
+    assert isinstance(rf["traffic_provenance"]["kernel_sources_unchanged_since"], bool)
     assert "regime" in rf and ("infinity-cache" in rf["regime"] or "HBM" in rf["regime"])
     rp = d["repeat"]
     assert rp["blocks"] == 3 and rp["ms_per_step_min"] <= rp["ms_per_step_median"] and len(rp["ms_per_step_all"]) == 3
@@ -85,6 +83,11 @@ def test_default_size_line_carries_the_ladder():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     rf = d["roofline"]
     assert "infinity-cache" in rf["regime"]
+    # the committed PMC figures belong to this size: quoted here, with where they come from (and only here: check_line's runs
+    # at another size get null)
+    pv = rf["traffic_provenance"]
+    assert rf["traffic"] is not None and 0.99 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.05
+    assert pv["measured_in_this_run"] is False and pv["source"].startswith("profiles/") and pv["commit"]
     rows = rf["ladder"]
     assert [row["chains"] for row in rows] == [40_000_000, 160_000_000]
     for row in rows:
