@@ -13,6 +13,7 @@ from montecarlo_amd import _capi as A
 
 mode = sys.argv[1]
 n = int(os.environ.get("LAUNCHES", "300"))
+PIPELINED = os.environ.get("PIPELINED", "0") == "1"     # read a callback's sums while the next period's launches are queued
 
 
 def spin(e, seconds=0.5):
@@ -43,13 +44,21 @@ elif mode == "k2":
     spin(e)
     for rep in range(2):
         e.timing_begin()
+        pending = False
         for i in range(n):
             if (i + 1) % 10 == 0:
-                e.sweep_reduce_begin(1); e.reduce_end()
+                if PIPELINED and pending:
+                    e.reduce_end()                    # the previous callback's sums: its launches finished ten sweeps ago
+                e.sweep_reduce_begin(1)
+                pending = True
+                if not PIPELINED:
+                    e.reduce_end(); pending = False
             else:
                 e.sweep(1)
+        if pending:
+            e.reduce_end()
         us = e.timing_end() * 1e3 / n
-    print(f"k2 (config 3 shape): {us:.2f} us per time step incl. callbacks every 10")
+    print(f"k2 (config 3 shape): {us:.2f} us per time step incl. callbacks every 10{' (callback read one period later)' if PIPELINED else ''}")
 elif mode in ("pgmc", "est"):
     M = 10_000_000
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
@@ -61,12 +70,20 @@ elif mode in ("pgmc", "est"):
     for rep in range(2):
         e.timing_begin()
         if mode == "pgmc":
+            pending = False
             for i in range(n // 10):
                 e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0])
-                e.reduce()
+                if PIPELINED and pending:
+                    e.reduce_end()
+                e.reduce_begin()
+                pending = True
+                if not PIPELINED:
+                    e.reduce_end(); pending = False
+            if pending:
+                e.reduce_end()
         else:
             for _ in range(n):
                 e.pg_accumulate([1], 1)
         us = e.timing_end() * 1e3 / (n // 10 * 10 if mode == "pgmc" else n)
-    print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}; sigma = {e.get_parameters(1)[0]:.4f}")
+    print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}{' (callback read one period later)' if PIPELINED and mode == 'pgmc' else ''}; sigma = {e.get_parameters(1)[0]:.4f}")
 e.close()
