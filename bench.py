@@ -200,6 +200,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RCCL's peer-to-peer set-up between the ranks' processes needs dmabuf IPC on this pool's driver (the legacy mode fails
+    # with hipIpcGetMemHandle: invalid argument); the launcher's environment normally carries this already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and world == 1:
         raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with `python -m torch.distributed.run --nnodes=1 "
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
