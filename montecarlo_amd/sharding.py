@@ -79,6 +79,9 @@ def init_store_group(rank: Optional[int] = None, world_size: Optional[int] = Non
     global _group
     if _group is not None:
         return _group
+    # RCCL between the ranks' processes: this pool's driver only supports dmabuf IPC (legacy mode: hipIpcGetMemHandle fails);
+    # must be in the environment before the HIP runtime starts, i.e. before the first engine is created
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
