@@ -25,7 +25,7 @@ def bits(a, dtype):
         else np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-def draw_case(rng):
+def draw_case(rng, sizes=(1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 513, 1000, 2049, 4099, 6001)):
     K = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 8]))
     w = rng.dirichlet(np.ones(K) * rng.choice([0.5, 1.0, 5.0]))
     if rng.random() < 0.3:                                   # weights on the 2^-12 grid: every cell of the pick table closed
@@ -34,7 +34,7 @@ def draw_case(rng):
         if w[-1] <= 0:
             w = np.full(K, 1.0 / K)
     w = w / w.sum()
-    M = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 513, 1000, 2049, 4099, 6001]))
+    M = int(rng.choice(sizes))
     return dict(
         n_chains=M,
         chain_offset=int(rng.choice([0, 2, 254, 256, 2 ** 20 + 2, 2 ** 33 + 6, 2 ** 40])),
@@ -68,13 +68,29 @@ def check_counters(e, o, case, where):
         assert np.array_equal(a, ao) and np.array_equal(t, to), f"{where}: counter totals differ\n{case}"
 
 
+# ensembles that give every block of a full grid (256 CUs x 6..8 blocks x 512 chains) more than one tile, some of them ragged
+LARGE = (786_433, 1_000_003, 1_572_865, 2_000_001, 3_145_729)
+N_LARGE = int(os.environ.get("AMC_FUZZ_LARGE_CASES", "6"))
+
+
+@pytest.mark.parametrize("index", range(N_LARGE))
+def test_random_configuration_large_ensemble(gpu, oracle, index):
+    """The same walk over ensembles of 0.8 - 3.1 million chains: grid-stride loops with several tiles per block, the peeled
+    ragged iteration, the multi-block reductions and the estimator's two-level tail all take part."""
+    run_case(gpu, oracle, np.random.default_rng([SEED, 10_000 + index]), f"large {index}", LARGE, threads=8, max_ops=6, max_multi=12)
+
+
 @pytest.mark.parametrize("index", range(N_CASES))
 def test_random_configuration_random_operations(gpu, oracle, index):
-    rng = np.random.default_rng([SEED, index])
-    case = draw_case(rng)
+    run_case(gpu, oracle, np.random.default_rng([SEED, index]), index)
+
+
+def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_multi=40):
+    case = draw_case(rng) if sizes is None else draw_case(rng, sizes)
     kw = {k: v for k, v in case.items() if k != "per_chain_counters"}
     e = gpu.HipEngine(per_chain_counters=case["per_chain_counters"], n_chains_global=case["chain_offset"] + case["n_chains"], **kw)
     o = oracle.OracleEngine(**kw)
+    o.threads = threads
     if rng.random() < 0.5:
         lo = float(rng.uniform(-3, 0))
         e.init_uniform(lo, -lo)
@@ -87,7 +103,7 @@ def test_random_configuration_random_operations(gpu, oracle, index):
         o.upload_state(x0)
     check_state(e, o, case, "start")
     K = len(case["sigma"])
-    for op_index in range(int(rng.integers(6, 16))):
+    for op_index in range(int(rng.integers(min(6, max_ops - 1), max_ops))):
         op = rng.choice(["single", "single", "multi", "reduce", "estimate", "sigma", "counters"])
         where = f"case {index}, operation {op_index} ({op})"
         if op == "single":
@@ -95,7 +111,7 @@ def test_random_configuration_random_operations(gpu, oracle, index):
                 e.sweep(1)
                 o.sweep(1)
         elif op == "multi":
-            n = int(rng.integers(2, 40))
+            n = int(rng.integers(2, max_multi))
             e.sweep(n)
             o.sweep(n)
         elif op == "reduce":
