@@ -4,8 +4,9 @@ The parity tests elsewhere pick their shapes by hand (BASELINE configs, boundary
 pool size 1..8 with arbitrary (normalised) weights -- cumulative weights that are no multiples of 2^-12 open cells of the
 pick table --, sigma over four decades, beta over two, both potentials, ragged ensemble sizes, shards that start at an
 arbitrary EVEN global chain id far from 0, sweepstep 1..4, Float64 and Float32 state, K = 1 with and without per-chain
-counters; then a random walk over {single-step launch, multi-step launch, callback reduction, estimator call, parameter
-update, counter download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
+counters; then a random walk over {single-step launch, multi-step launch, callback reduction, sweep with the reduction
+formed in the launch, estimator call, [Metropolis, estimator, update] steps in one engine call, parameter update, counter
+download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
 reductions within RED_RTOL.  AMC_FUZZ_CASES (default 40, ~15 s) and AMC_FUZZ_SEED widen or move the sample.
 """
 import os
@@ -104,7 +105,7 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
     check_state(e, o, case, "start")
     K = len(case["sigma"])
     for op_index in range(int(rng.integers(min(6, max_ops - 1), max_ops))):
-        op = rng.choice(["single", "single", "multi", "reduce", "estimate", "sigma", "counters"])
+        op = rng.choice(["single", "single", "multi", "reduce", "sweep_reduce", "estimate", "pgmc", "sigma", "counters"])
         where = f"case {index}, operation {op_index} ({op})"
         if op == "single":
             for _ in range(int(rng.integers(1, 6))):
@@ -114,12 +115,29 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
             n = int(rng.integers(2, max_multi))
             e.sweep(n)
             o.sweep(n)
-        elif op == "reduce":
-            r, ro = e.reduce(), o.reduce()
+        elif op in ("reduce", "sweep_reduce"):
+            if op == "sweep_reduce":                   # make_step! and the callbacks that follow it at the same t: one launch
+                e.sweep_reduce_begin(1)
+                o.sweep_reduce_begin(1)
+                r, ro = e.reduce_end(), o.reduce_end()
+            else:
+                r, ro = e.reduce(), o.reduce()
             scale = np.maximum(np.abs(ro), 1.0)
             assert np.all((np.abs(r - ro) <= RED_RTOL * scale * np.sqrt(case["n_chains"])) | (np.isnan(r) & np.isnan(ro))), \
                 f"{where}: reduction differs\n{r}\n{ro}\n{case}"
-            continue
+            if op == "reduce":
+                continue
+        elif op == "pgmc":
+            # [Metropolis, estimator, update] per time step in ONE engine call (fused launches where the engine has them); the
+            # learning rate is 0, so sigma stays what it is and the chains can still be compared bit for bit afterwards
+            learn = sorted(int(v) for v in rng.choice(K, size=int(rng.integers(1, min(K, 2) + 1)), replace=False))
+            n, q = int(rng.integers(1, 6)), int(rng.choice([1, 1, 2]))
+            vpg = [oracle.OPTIMISERS["VPG"]] * len(learn)
+            e.pgmc_steps(n, learn, q, vpg, [0.0] * len(learn), [0.0] * len(learn))
+            o.pgmc_steps(n, learn, q, vpg, [0.0] * len(learn), [0.0] * len(learn))
+            for k in learn:
+                assert e.get_parameters(k)[0] == o.get_parameters(k)[0], f"{where}: sigma moved\n{case}"
+            assert np.all(e.pg_get_accumulated(learn) == 0.0) and e.estimator_step == o.estimator_step
         elif op == "estimate":
             learn = sorted(int(v) for v in rng.choice(K, size=int(rng.integers(1, min(K, 3) + 1)), replace=False))
             q = int(rng.choice([1, 1, 2, 5]))
