@@ -24,6 +24,19 @@
 #include <vector>
 
 #include "amc_kernels.h"
+// defined in amc_pg_fused.hip (compiled with other code-generation options, see there): not instantiated here
+namespace amc {
+#define AMC_PG_FUSED(POT, NL, BETA) extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2>(const PgArgs, const SweepArgs)
+AMC_PG_FUSED(POT_HARMONIC, 1, false);
+AMC_PG_FUSED(POT_HARMONIC, 1, true);
+AMC_PG_FUSED(POT_HARMONIC, 2, false);
+AMC_PG_FUSED(POT_HARMONIC, 2, true);
+AMC_PG_FUSED(POT_DOUBLE_WELL, 1, false);
+AMC_PG_FUSED(POT_DOUBLE_WELL, 1, true);
+AMC_PG_FUSED(POT_DOUBLE_WELL, 2, false);
+AMC_PG_FUSED(POT_DOUBLE_WELL, 2, true);
+#undef AMC_PG_FUSED
+}  // namespace amc
 #include "amc_rtc_sources.gen.h"   // the three kernel headers as string literals (Makefile), for hiprtc
 
 #ifndef AMC_BUILD_ARCH

@@ -25,6 +25,13 @@ namespace amc {
 
 enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1, POT_CUSTOM = 2 };
 
+// Linkage of the kernels that are no templates.  The header is compiled into more than one object (amc_pg_fused.hip holds some
+// instantiations of pg_estimate_kernel, built with other code-generation options); an object that only wants template
+// instantiations defines this as `static` and, not using them, emits none of these kernels.
+#ifndef AMC_KERNEL_LINKAGE
+#define AMC_KERNEL_LINKAGE
+#endif
+
 // State type.  The reference's Particle{T} / Displacement{T} are generic in T <: AbstractFloat (particle_1d.jl:9,26);
 // Float64 is what its scripts use and what the offline build of this header compiles.  A handle created with
 // state_dtype = AMC_DTYPE_F32 gets the SAME kernel sources compiled at run time with AMC_STATE_F32 defined: x, beta, e,
@@ -855,7 +862,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 }
 
 // K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
-__global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int64_t n_chains, uint64_t pair0,
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int64_t n_chains, uint64_t pair0,
                                                                   uint32_t key0, uint32_t key1, double lo,
                                                                   double hi)
 {
@@ -904,7 +911,7 @@ __device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
     }
 }
 
-__global__ void prepare_params_kernel(double* ptab, int n_moves)
+AMC_KERNEL_LINKAGE __global__ void prepare_params_kernel(double* ptab, int n_moves)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     prepare_params(ptab, n_moves);
@@ -914,7 +921,7 @@ __global__ void prepare_params_kernel(double* ptab, int n_moves)
 // The walk's count #(cum[i] <= r), i < K-1, is monotone in r, so it is the same for every r of the cell iff it is the
 // same at the two ends: #(cum[i] <= c 2^-12) == #(cum[i] < (c+1) 2^-12).  Launched after prepare_params (same stream)
 // whenever the weights change.
-__global__ __launch_bounds__(AMC_BLOCK) void prepare_pick_kernel(const double* ptab, int n_moves, uint8_t* pick_tab)
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void prepare_pick_kernel(const double* ptab, int n_moves, uint8_t* pick_tab)
 {
     const int c = (int)(blockIdx.x * AMC_BLOCK + threadIdx.x);
     if (c >= AMC_PICK_CELLS) return;
@@ -942,7 +949,7 @@ __device__ __forceinline__ void pg_accumulate_one(const double* red, int l, int 
     a[4] += n_samples;
 }
 
-__global__ void pg_accumulate_kernel(const double* red, int n_learn, PgIds ids, double n_samples, double* acc)
+AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* red, int n_learn, PgIds ids, double n_samples, double* acc)
 {
     const int l = threadIdx.x;
     if (l >= n_learn) return;
@@ -999,7 +1006,7 @@ __device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_l
     prepare_params(ptab, n_moves);
 }
 
-__global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
+AMC_KERNEL_LINKAGE __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
@@ -1066,7 +1073,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
 // 0 when slots == nullptr).  Launched twice when there are many rows -- 32 blocks, then one block over their 32
 // rows with the slot column as an ordinary column -- because one CU alone streams 2048 rows from far memory in
 // ~10 us; once (gridDim = 1) otherwise.  Either way the order of additions depends on the row count only.
-__global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_rows, int n_vals,
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_rows, int n_vals,
                                                                   double* out, const unsigned long long* slots,
                                                                   int n_slots, int rows_per_block, int slots_per_block)
 {
@@ -1123,7 +1130,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* p
 
 // Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].  16-byte loads, one atomic per
 // block and value (same-address atomics serialise at ~13 ns each: per-wave atomics from a full grid cost 0.2 ms here).
-__global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_t* acc, const uint32_t* tot,
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_t* acc, const uint32_t* tot,
                                                                     int64_t n_chains, int64_t m_stride,
                                                                     int n_moves, unsigned long long* out_acc,
                                                                     unsigned long long* out_tot)
@@ -1203,7 +1210,7 @@ struct PgArgs {
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
 // to outlive the call and launches already queued keep reading the old record until they are done.
-__global__ void pg_tail_store_kernel(PgTail value, PgTail* dst)
+AMC_KERNEL_LINKAGE __global__ void pg_tail_store_kernel(PgTail value, PgTail* dst)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
 }
@@ -1570,7 +1577,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 // histogram of the chain positions over half-open bins [lo + i w, lo + (i+1) w), i < n_bins, with
 // bin = floor((x - lo) * inv_w) in this exact f64 form; counts[n_bins..n_bins+2] = below lo, >= hi, NaN.
 // Per-block LDS histogram (u32 LDS atomics), flushed with one u64 global atomic per non-empty bin.
-__global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, int64_t n_chains, double lo, double hi,
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, int64_t n_chains, double lo, double hi,
                                                                double inv_w, int n_bins, unsigned long long* counts)
 {
     extern __shared__ unsigned int s_hist[];
@@ -1609,20 +1616,20 @@ __global__ __launch_bounds__(AMC_BLOCK) void energy_kernel(const real_t* x, int6
 // Float32 state (AMC_STATE_F32 builds only): the C ABI moves positions as doubles whatever the state type, so uploads
 // are narrowed (T(x), round to nearest even -- what Particle(Float32(x), ...) does) and downloads widened (exact).
 // The kernels that only READ positions for host-side consumers (histogram, strided snapshots) run on the widened copy.
-__global__ __launch_bounds__(AMC_BLOCK) void narrow_state_kernel(const double* in, int64_t n, real_t* out)
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void narrow_state_kernel(const double* in, int64_t n, real_t* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (real_t)in[i];
 }
 
-__global__ __launch_bounds__(AMC_BLOCK) void widen_state_kernel(const real_t* in, int64_t n, double* out)
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void widen_state_kernel(const real_t* in, int64_t n, double* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (double)in[i];
 }
 
 // Strided snapshot: out[i] = x[first + i*stride] (binary stand-in for a subset of trajectory files).
-__global__ __launch_bounds__(AMC_BLOCK) void gather_strided_kernel(const double* x, int64_t first, int64_t stride,
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void gather_strided_kernel(const double* x, int64_t first, int64_t stride,
                                                                     int64_t count, double* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
@@ -1630,7 +1637,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void gather_strided_kernel(const double*
 }
 
 // Parity-test hooks (amc_selftest_*): the arithmetic-spec primitives, one value per thread.
-__global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
+AMC_KERNEL_LINKAGE __global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
 {
     __shared__ double s_math[TAB_DOUBLES];
     stage_math_tables(s_math, threadIdx.x, blockDim.x);
@@ -1673,7 +1680,7 @@ __global__ void selftest_math_kernel(int fn, const double* a, const double* b, d
 // Exhaustive check of the accept filter's float estimate (accept_filter): for EVERY float t with bit pattern in
 // [bits_lo, bits_hi] the relative deviation of v_exp_f32(max(t, -17) * log2e) from the spec's f64 exp(t); the maximum
 // over the range lands in out_max_bits (bits of a non-negative double compare like integers).
-__global__ __launch_bounds__(256) void selftest_filter_kernel(uint32_t bits_lo, uint64_t count, unsigned long long* out_max_bits)
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(256) void selftest_filter_kernel(uint32_t bits_lo, uint64_t count, unsigned long long* out_max_bits)
 {
     __shared__ double s_math[TAB_DOUBLES];
     stage_math_tables(s_math, threadIdx.x, 256);
@@ -1693,7 +1700,7 @@ __global__ __launch_bounds__(256) void selftest_filter_kernel(uint32_t bits_lo, 
     if ((threadIdx.x & 63) == 0) atomicMax(out_max_bits, (unsigned long long)__double_as_longlong(worst));
 }
 
-__global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,
+AMC_KERNEL_LINKAGE __global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,
                                        uint32_t draw, uint32_t stream, uint32_t* out4, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
