@@ -459,7 +459,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     int rtc_major = 0, rtc_minor = 0;
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
-    const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor));
+    // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
+    const bool licm_off = inst.rfind("amc::pg_estimate_kernel<", 0) == 0 && inst.size() > 3 && inst.compare(inst.size() - 3, 3, ",2>") == 0;
+    const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+                                                                           (licm_off ? " licm-off" : ""));
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -503,8 +506,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
     // the flags of the offline build (Makefile): only the explicit fma()s may fuse
     const std::string arch_opt = "--offload-arch=" + arch;
-    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-    e = g_hiprtc.CompileProgram(prog, 5, opts);
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm"};
+    e = g_hiprtc.CompileProgram(prog, licm_off ? 7 : 5, opts);
+    // (-disable-machine-licm is one of LLVM's generic code-generation options; a back end without it would not return an error
+    // here but end the process in its option parser, so there is nothing to fall back from)
     std::string log;
     size_t ls = 0;
     if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
