@@ -72,7 +72,7 @@ def cpu_baseline(budget_s: float = 10.0):
     O.build()
     visible, quota = cpu_allotment()
     visible = min(visible, O.load().amo_max_threads())
-    m = 1_000_000
+    m = M_PER_GPU                    # the workload's own ensemble: 1e7 chains do not fit the host's caches either
 
     def timed(threads, budget, cap=4000):
         sim = O.OracleSim(m, potential="harmonic", beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED)
@@ -80,8 +80,8 @@ def cpu_baseline(budget_s: float = 10.0):
         sim.make_steps(1, threads)                       # warm-up / first touch
         sweeps, t0 = 0, time.perf_counter()
         while True:
-            sim.make_steps(16, threads)
-            sweeps += 16
+            sim.make_steps(4, threads)
+            sweeps += 4
             dt = time.perf_counter() - t0
             if dt >= budget or sweeps >= cap:
                 break
@@ -108,7 +108,7 @@ def cpu_baseline(budget_s: float = 10.0):
         "value": out["all"][0], "unit": "chain-updates/s", "cores": cores, "kind": "port",
         "reference_runtime": f"julia at {julia} (reference not timed: no package depot offline)" if julia else
                              "julia not found on this host: the reference (pure Julia) cannot be timed here",
-        "sample": f"oracle/amc_oracle.c (C restatement of mc_sweep!, OpenMP over chains), M=1e6 chains x "
+        "sample": f"oracle/amc_oracle.c (C restatement of mc_sweep!, OpenMP over chains), M=1e7 chains x "
                   f"{out['all'][1]} sweeps in {out['all'][2]:.1f} s on {cores} threads; same workload otherwise",
         "single_thread_value": out["single"][0], "cpu_model": cpu_model,
         "cpus_visible": visible, "cpu_quota": quota,
@@ -246,8 +246,24 @@ def main():
         all_ok = all(grp.allgather(bool(ok)))
         if not all_ok:
             eng.comm_connected = False
-        allreduce_via = "rccl (amc_allreduce_sum on the engine's stream)" if all_ok else "launcher's TCP store (host-side sum: RCCL communicator unavailable)"
+        allreduce_via = ("rccl (amc_allreduce_sum: one ncclAllReduce on the engine's communication stream)" if all_ok else
+                         "launcher's TCP store (host-side sum: RCCL communicator unavailable)")
         grp.barrier()
+    # what this process really runs on, for a line that verifies itself: the communicator's own rank count (ncclCommCount),
+    # the librccl and HIP runtime files bound (under the launcher torch is imported first, so libamc.so binds torch's
+    # bundled ROCm; a bare single-process run binds /opt/rocm)
+    rt = A.runtime_info()
+    ci = eng.comm_info() if getattr(eng, "comm_connected", False) else None
+    stack = {"hip_runtime_version": rt["hip_runtime_version"], "hip_runtime": rt["hip_runtime"],
+             "rccl_ranks": None if ci is None else ci["n_ranks"], "rccl_rank": None if ci is None else ci["rank"],
+             "rccl_version": None if ci is None else ci["rccl_version"], "librccl": None if ci is None else ci["librccl"]}
+    if grp is not None:
+        stacks = grp.allgather(stack)
+        counts = [st["rccl_ranks"] for st in stacks]
+        # every rank's communicator must report the whole world; anything else is shown, not hidden
+        stack["rccl_ranks"] = None if any(c is None for c in counts) else min(counts)
+        stack["rccl_ranks_by_rank"] = counts
+        stack["hip_runtime_versions_by_rank"] = [st["hip_runtime_version"] for st in stacks]
     cb_every = CALLBACK_EVERY_MULTI if grp is not None else 0
     if os.environ.get("AMC_BENCH_CB_EVERY"):                 # developer knob: separate the cost of the callbacks from the process group's
         cb_every = int(os.environ["AMC_BENCH_CB_EVERY"])
@@ -364,9 +380,12 @@ def main():
                             f"sweepstep=1, M={m_local} chains per GPU ({m_global} total), x0~U(-2,2), seed=1",
                 "chains_per_gpu": m_local, "chains_total": m_global, "sweepstep": 1,
                 "callbacks_allreduce_every": cb_every, "callbacks_allreduce_via": allreduce_via,
+                **stack,
                 "sharding": "contiguous global chain ids per rank; no data-path collective",
                 "multi_gpu_note": "N > 1: callbacks all-reduced by the engines' own RCCL communicator (amc_allreduce_sum), unique id "
-                                  "and barriers over the launcher's TCP store; measured on hardware only by the driver's SCALE runs",
+                                  "and barriers over the launcher's TCP store; rccl_ranks is ncclCommCount of that communicator "
+                                  "(null: no communicator); this repository's own GPU runs have one device, so N > 1 has never "
+                                  "been run by the builder",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

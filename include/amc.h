@@ -197,13 +197,17 @@ int  amc_upload_state(amc_handle *h, const double *x, const double *beta_or_null
 int  amc_init_uniform(amc_handle *h, double lo, double hi);
 /* finalise(): chains[c].x / chains[c].e back to the host (either may be NULL). */
 int  amc_download_state(amc_handle *h, double *x, double *e);
-/* pools[c][k].accepted_calls / total_calls, move-major [k*n_chains + c]. */
+/* pools[c][k].accepted_calls / total_calls, move-major [k*n_chains + c].  Int (Int64) in the reference
+ * (src/metropolis.jl:145-146); the device keeps them as u32 per chain, so a handle with per-chain counters counts at most
+ * 2^32 - 1 MH steps: the call that would go beyond returns AMC_ERR_STATE before launching anything (download the
+ * counters, amc_upload_counters zeros, continue).  The pool-wide count of a K = 1 handle without them is 64-bit. */
 int  amc_download_counters(amc_handle *h, int64_t *accepted, int64_t *total);
 /* Pool-wide sums over local chains: accepted[k], total[k] (exact integers). */
 int  amc_counter_totals(amc_handle *h, int64_t *accepted, int64_t *total);
 
 /* Resume: restore pools[c][k].accepted_calls / total_calls ([k*n_chains + c], total may be NULL for
- * K = 1) on a handle with per-chain counters; or, for a K = 1 handle without them, the pool-wide
+ * K = 1) on a handle with per-chain counters -- the total_calls of a chain must add up to the same number of steps on
+ * every chain, as they do in the reference, where every chain takes the same steps (mc_sweep!, metropolis.jl:205-210); or, for a K = 1 handle without them, the pool-wide
  * accepted total and the number of counted steps.  Together with amc_upload_state, amc_set_step,
  * amc_set_estimator_step and amc_set_parameters this restores a run exactly (the reference's
  * StoreBackups, src/algorithms.jl:264-303, is write-only and saves neither RNG state nor counters). */
@@ -239,8 +243,9 @@ int  amc_reduce(amc_handle *h, double *out);
  * and the device->host copy and returns; _end waits for THAT copy only (sweeps queued after _begin keep
  * running) and returns the values as of _begin.  One reduction may be in flight per handle. */
 int  amc_reduce_begin(amc_handle *h);
-/* n make_step!s followed by amc_reduce_begin of the resulting state; for K = 1 handles without per-chain
- * counters the sums are formed inside the last sweep launch (no second pass over the chains). */
+/* n make_step!s followed by amc_reduce_begin of the resulting state.  The sums over x are formed inside the last sweep
+ * launch (K <= 4: no second pass over the chains); with per-chain counters the acceptance ratios come from the fold of the
+ * step log that follows it. */
 int  amc_sweep_reduce_begin(amc_handle *h, int64_t n_sweeps);
 int  amc_reduce_end(amc_handle *h, double *out);
 
@@ -284,6 +289,14 @@ int  amc_pg_set_accumulated(amc_handle *h, int n_learn, const int *learn_ids, co
  * ctypes) would otherwise exceed the ~0.1 ms of device work per step. */
 int  amc_pgmc_steps(amc_handle *h, int64_t n_steps, int n_learn, const int *learn_ids, int q_batch,
                     int do_update, const int *optimiser, const double *hyper0, const double *hyper1);
+/* The same followed by amc_reduce_begin of the state the last time step leaves -- what callback_energy / callback_acceptance
+ * scheduled at that t observe: run! calls them after the three algorithms (src/simulation.jl:185-190;
+ * PGMC_harmonic_oscillator.jl:34 lists StoreCallbacks behind them).  When the time step is ONE launch (sweepstep = 1, at most
+ * two learnable moves, K <= 4) that launch also forms the sums over x, and the acceptance ratios come from the fold of the
+ * step log that follows it: no pass re-reads the chains, and amc_reduce_end returns the values as of this call however
+ * many time steps have been queued since. */
+int  amc_pgmc_steps_reduce_begin(amc_handle *h, int64_t n_steps, int n_learn, const int *learn_ids, int q_batch,
+                                 int do_update, const int *optimiser, const double *hyper0, const double *hyper1);
 
 int  amc_sync(amc_handle *h);
 /* hipStream_t the handle launches on (for event timing / graph capture by the host). */
@@ -301,14 +314,29 @@ int  amc_timing_mark(amc_handle *h);
  * and shipped to the other ranks by the caller. */
 int  amc_comm_unique_id(void *id128);
 int  amc_comm_init(amc_handle *h, int rank, int n_ranks, const void *id128);
+/* The sum runs on a stream of its own (the host waits for it without draining the sweeps queued on the engine's stream),
+ * ordered behind the collectives the estimator has queued on the engine's stream with the same communicator. */
 int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
+/* Drop the communicator: the handle is a single shard again (a later amc_comm_init may give it a new one).  For ranks whose
+ * amc_comm_init succeeded in a launch where another rank's failed. */
+int  amc_comm_destroy(amc_handle *h);
+/* What the communicator says about itself (ncclCommCount, ncclCommUserRank), the RCCL version (ncclGetVersion) and the file
+ * the RCCL symbols were resolved from -- so that a multi-GPU result can show that RCCL really spanned N ranks and which
+ * library carried it.  Without a communicator: 1 rank, rank 0, version 0, empty path.  Any output pointer may be NULL. */
+int  amc_comm_info(amc_handle *h, int *n_ranks, int *rank, int *rccl_version, char *librccl_path, int path_capacity);
+/* hipRuntimeGetVersion of the HIP runtime this library is bound to in this process, and the file it was loaded from: a
+ * process that imported torch first binds torch's bundled runtime, a bare one the system's (/opt/rocm). */
+int  amc_runtime_info(int *hip_runtime_version, char *hip_runtime_path, int path_capacity);
 
 /* Parity-test hooks: evaluate arithmetic-spec primitives on the device.
  * fn: 0 exp(a), 1 log(a), 2 sinpi(a), 3 cospi(a), 4 sqrt(a), 5 a/b (IEEE), 6 a/b by the kernel's
  * reciprocal-correction sequence (must equal 5 bit for bit), 7 the Box-Muller log, 8 the Box-Muller
  * radius sqrt (must equal 4 bit for bit on {0} U [2^-52, 80]); 9 log_proposal_density(delta = a, sigma = b)
- * (particle_1d.jl:52-54) and 10 its derivative with respect to sigma (withgrad_log_proposal_density!, gradients.jl:28-33)
- * through the estimator's own code -- the values test/ad_backends_test.jl:31-32 pins.  Host buffers. */
+ * (particle_1d.jl:52-54) and 10 its derivative with respect to sigma (withgrad_log_proposal_density!, gradients.jl:28-33),
+ * both in the reference's operation order (ForwardDiff's dual rules written out) -- the values test/ad_backends_test.jl:31-32
+ * pins, and what the host-side withgrad_log_proposal_density returns; 11 the same derivative as the estimator KERNEL forms
+ * it (one fma chain with a split coefficient, within a few ulp of 10: the estimator's summands are tolerance-matched,
+ * DESIGN.md section 3.6b).  Host buffers. */
 int  amc_selftest_math(int device, int fn, const double *a, const double *b_or_null,
                        double *out, int64_t n);
 /* The sweep kernel settles most accept decisions from a float estimate of exp(dlogp) whose error interval is rigorous

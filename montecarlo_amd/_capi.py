@@ -112,6 +112,8 @@ def load() -> C.CDLL:
         "amc_pg_set_accumulated": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), dp]),
         "amc_pgmc_steps": (C.c_int, [H, C.c_int64, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int),
                                      dp, dp]),
+        "amc_pgmc_steps_reduce_begin": (C.c_int, [H, C.c_int64, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                  dp, dp]),
         "amc_sync": (C.c_int, [H]),
         "amc_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
         "amc_timing_begin": (C.c_int, [H]),
@@ -120,6 +122,9 @@ def load() -> C.CDLL:
         "amc_comm_unique_id": (C.c_int, [C.c_void_p]),
         "amc_comm_init": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "amc_allreduce_sum": (C.c_int, [H, dp, C.c_int]),
+        "amc_comm_destroy": (C.c_int, [H]),
+        "amc_comm_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+        "amc_runtime_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_int]),
         "amc_selftest_math": (C.c_int, [C.c_int, C.c_int, dp, dp, dp, C.c_int64]),
         "amc_selftest_accept_filter": (C.c_int, [C.c_int, C.c_float, C.c_float, dp]),
         "amc_selftest_philox": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -131,6 +136,14 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def runtime_info() -> dict:
+    """The HIP runtime libamc.so is bound to in this process: hipRuntimeGetVersion and the file it came from."""
+    v = C.c_int(0)
+    path = C.create_string_buffer(1024)
+    _check(load().amc_runtime_info(C.byref(v), path, 1024))
+    return {"hip_runtime_version": v.value, "hip_runtime": path.value.decode()}
 
 
 def _check(rc: int) -> None:
@@ -371,15 +384,18 @@ class HipEngine:
         _check(self._lib.amc_pg_update(self._h, n, ids, kd, h0, h1))
 
     def pgmc_steps(self, n_steps: int, learn_ids: Sequence[int], q_batch: int, kinds: Optional[Sequence[int]] = None,
-                   hyper0: Sequence[float] = (), hyper1: Sequence[float] = ()) -> None:
-        """n x [sweep(1); pg_accumulate; pg_update if kinds is given] enqueued by one call (asynchronous)."""
+                   hyper0: Sequence[float] = (), hyper1: Sequence[float] = (), reduce_begin: bool = False) -> None:
+        """n x [sweep(1); pg_accumulate; pg_update if kinds is given] enqueued by one call (asynchronous).
+        ``reduce_begin``: followed by reduce_begin() of the state the last step leaves -- the callback sums then ride in that
+        step's launch (amc_pgmc_steps_reduce_begin); fetch them with reduce_end()."""
         n = len(learn_ids)
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
         do_update = kinds is not None
         kd = (C.c_int * max(n, 1))(*[int(k) for k in (kinds or [0] * n)])
         h0 = (C.c_double * max(n, 1))(*[float(v) for v in (hyper0 if do_update else [0.0] * n)])
         h1 = (C.c_double * max(n, 1))(*[float(v) for v in (hyper1 if do_update else [0.0] * n)])
-        _check(self._lib.amc_pgmc_steps(self._h, int(n_steps), n, ids, int(q_batch), 1 if do_update else 0, kd, h0, h1))
+        fn = self._lib.amc_pgmc_steps_reduce_begin if reduce_begin else self._lib.amc_pgmc_steps
+        _check(fn(self._h, int(n_steps), n, ids, int(q_batch), 1 if do_update else 0, kd, h0, h1))
 
     def pg_get_accumulated(self, learn_ids: Sequence[int]) -> np.ndarray:
         n = len(learn_ids)
@@ -431,6 +447,17 @@ class HipEngine:
         a = np.ascontiguousarray(a, dtype=np.float64).copy()
         _check(self._lib.amc_allreduce_sum(self._h, _dptr(a), int(a.size)))
         return a
+
+    def comm_destroy(self) -> None:
+        """Drop the communicator: a single shard again."""
+        _check(self._lib.amc_comm_destroy(self._h))
+
+    def comm_info(self) -> dict:
+        """What RCCL reports about this engine's communicator: ranks it spans, this rank, RCCL version, the librccl file."""
+        n, r, v = C.c_int(0), C.c_int(0), C.c_int(0)
+        path = C.create_string_buffer(1024)
+        _check(self._lib.amc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(v), path, 1024))
+        return {"n_ranks": n.value, "rank": r.value, "rccl_version": v.value, "librccl": path.value.decode()}
 
 
 class SplitEngine:
@@ -575,7 +602,8 @@ class SplitEngine:
 def selftest_math(fn: str, a: np.ndarray, b: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
     """Evaluate one arithmetic-spec primitive on the GPU (parity tests only)."""
     ids = {"exp": 0, "log": 1, "sinpi": 2, "cospi": 3, "sqrt": 4, "div": 5, "div_by_const": 6, "logbm": 7,
-           "sqrt_radius": 8, "log_proposal_density": 9, "grad_log_proposal_density": 10}
+           "sqrt_radius": 8, "log_proposal_density": 9, "grad_log_proposal_density": 10,
+           "grad_log_proposal_density_kernel_form": 11}
     a = np.ascontiguousarray(a, dtype=np.float64)
     if b is not None:
         b = np.ascontiguousarray(b, dtype=np.float64)

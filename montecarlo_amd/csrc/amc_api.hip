@@ -26,7 +26,9 @@
 #include "amc_kernels.h"
 // defined in amc_pg_fused.hip (compiled with other code-generation options, see there): not instantiated here
 namespace amc {
-#define AMC_PG_FUSED(POT, NL, BETA) extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2>(const PgArgs, const SweepArgs)
+#define AMC_PG_FUSED(POT, NL, BETA)                                                                             \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false>(const PgArgs, const SweepArgs); \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, true>(const PgArgs, const SweepArgs)
 AMC_PG_FUSED(POT_HARMONIC, 1, false);
 AMC_PG_FUSED(POT_HARMONIC, 1, true);
 AMC_PG_FUSED(POT_HARMONIC, 2, false);
@@ -75,6 +77,9 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;       // optional: what the communicator says about itself (amc_comm_info)
+    int (*CommUserRank)(void*, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
 };
 
 }  // namespace
@@ -128,6 +133,8 @@ struct amc_handle {
     void* comm = nullptr;
     double* d_comm = nullptr;
     hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
+    hipEvent_t ev_comm_main = nullptr;   // behind the last collective queued on the engine's stream (the estimator's all-reduce)
+    bool comm_main_pending = false;      // ... which comm_stream has not been ordered behind yet
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
@@ -210,6 +217,10 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 // replaces d_acc / d_tot calls this first.
 // with_ratio (K <= 4): the launch also leaves callback_acceptance's per-move sums as block partials in h_ratio
 // (rows = its grid; *ratio_rows receives the count) and runs even when no log row is pending.
+// (Round 3 measured the callback's fold on a second stream beside the sweeps queued after it, the log a ring of rows:
+// no gain -- config 3: 37.3 against 37.6 us per time step with the callback read a period late, 41.0 against 38.9 read at
+// once; config 5: 72.7 against 70.7 either way.  The fold's waves do not fit beside five 96-register waves of the fused
+// kernel, so they take whole wave slots from it, and the cross-stream events cost more than the overlap returns.)
 int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
 {
     if (!h->d_log || (h->log_fill == 0 && !with_ratio)) return AMC_OK;
@@ -246,6 +257,17 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     return AMC_OK;
 }
 
+// Makes room for at least one more row of the step log (a full log is folded first); *rows = how many fit.
+int log_room(amc_handle* h, int* rows)
+{
+    if (h->log_fill == h->log_depth) {
+        const int rc = fold_log(h);
+        if (rc != AMC_OK) return rc;
+    }
+    *rows = h->log_depth - h->log_fill;
+    return AMC_OK;
+}
+
 template <int POT, bool MULTI, bool LOG>
 int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
@@ -278,22 +300,29 @@ int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
     return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
 }
 
-template <int POT, int NL, int SWEEP>
+template <int POT, int NL, int SWEEP, bool REDUCE = false>
 int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid)
 {
     if (h->beta_arr)
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP, REDUCE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     else
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false, SWEEP>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false, SWEEP, REDUCE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     AMC_HIP(hipGetLastError());
     return AMC_OK;
 }
 
-// sweep: 0 = estimator only; 1 / 2 = preceded by one make_step!(::Metropolis) in the same launch (K == 1 / K > 1;
-// offered for up to 2 learnable moves, see pg_fusable)
+// sweep: 0 = estimator only; 1 / 2 / 3 = preceded by one make_step!(::Metropolis) in the same launch (K == 1 with the step
+// log / K > 1 / K == 1 with the pool-wide counter; offered for up to 2 learnable moves, see pg_fusable)
+// reduce (sweep != 0): the launch also leaves the callback sums of the state it stores (pg_estimate_kernel<.., REDUCE>)
 template <int POT>
-int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep)
+int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce)
 {
+    if (reduce) {
+        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, true>(h, a, sw, grid);
+        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, true>(h, a, sw, grid);
+        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, true>(h, a, sw, grid);
+        return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on the fused time step only");
+    }
     if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1>(h, a, sw, grid);
     if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2>(h, a, sw, grid);
     if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3>(h, a, sw, grid);
@@ -460,7 +489,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     int rtc_major = 0, rtc_minor = 0;
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
     // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
-    const bool licm_off = inst.rfind("amc::pg_estimate_kernel<", 0) == 0 && inst.size() > 3 && inst.compare(inst.size() - 3, 3, ",2>") == 0;
+    const bool licm_off = inst.rfind("amc::pg_estimate_kernel<", 0) == 0 &&
+                          (inst.find(",2,false>") != std::string::npos || inst.find(",2,true>") != std::string::npos);
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : ""));
     {
@@ -576,10 +606,10 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
     return rtc_launch(h, inst, grid, params);
 }
 
-int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep)
+int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce)
 {
     const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
-                             std::to_string(sweep) + ">";
+                             std::to_string(sweep) + "," + tf(reduce) + ">";
     void* params[] = {&a, &sw};
     return rtc_launch(h, inst, grid, params);
 }
@@ -794,9 +824,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         const size_t n = (size_t)h->K * (size_t)h->M_pad;
         AMC_TRY(hipMalloc(&h->d_acc, n * sizeof(uint32_t)));
         AMC_TRY(hipMemsetAsync(h->d_acc, 0, n * sizeof(uint32_t), h->stream));
-        if (h->K > 1) {
-            AMC_TRY(hipMalloc(&h->d_tot, n * sizeof(uint32_t)));
-            AMC_TRY(hipMemsetAsync(h->d_tot, 0, n * sizeof(uint32_t), h->stream));
+        if (h->K > 1) {      // K - 1 rows: the last move's total_calls is the step count minus the others (fold_log_kernel)
+            const size_t nt = (size_t)(h->K - 1) * (size_t)h->M_pad;
+            AMC_TRY(hipMalloc(&h->d_tot, nt * sizeof(uint32_t)));
+            AMC_TRY(hipMemsetAsync(h->d_tot, 0, nt * sizeof(uint32_t), h->stream));
         }
         // One byte per chain and MH step; folding costs a read-modify-write of every counter (16 K bytes per chain), so a
         // deeper log amortises it over more steps: 128 rows where they fit in 2 GiB (1.28 GB at 1e7 chains), never below 16.
@@ -955,16 +986,15 @@ int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
     return rc;
 }
 
+static void comm_release(amc_handle* h);
+
 int amc_destroy(amc_handle* h)
 {
     if (!h) return AMC_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    comm_release(h);
     for (hipModule_t m : h->rtc_mods) (void)hipModuleUnload(m);
-    (void)hipFree(h->d_comm);
     (void)hipFree(h->d_gd_acc);
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_pg_tickets);
@@ -1125,13 +1155,18 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
             for (int64_t c = 0; c < h->M; ++c) accepted[(int64_t)k * h->M + c] = buf[(size_t)c];
         }
         if (total) {
-            if (h->K > 1) {
+            if (k + 1 < h->K) {
                 AMC_HIP(hipMemcpyAsync(buf.data(), h->d_tot + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t),
                                        hipMemcpyDeviceToHost, h->stream));
                 AMC_HIP(hipStreamSynchronize(h->stream));
                 for (int64_t c = 0; c < h->M; ++c) total[(int64_t)k * h->M + c] = buf[(size_t)c];
             } else {
-                for (int64_t c = 0; c < h->M; ++c) total[c] = (int64_t)h->t_counted;
+                // the last move: every chain has taken t_counted steps, its total_calls is what the other moves left
+                for (int64_t c = 0; c < h->M; ++c) {
+                    int64_t others = 0;
+                    for (int j = 0; j + 1 < h->K; ++j) others += total[(int64_t)j * h->M + c];
+                    total[(int64_t)k * h->M + c] = (int64_t)h->t_counted - others;
+                }
             }
         }
     }
@@ -1158,11 +1193,27 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
         if (rc != AMC_OK) return rc;
         host[0] = acc;
     }
+    unsigned long long others = 0;
     for (int k = 0; k < h->K; ++k) {
         if (accepted) accepted[k] = (int64_t)host[k];
-        if (total) total[k] = (h->K > 1) ? (int64_t)host[AMC_MAX_MOVES + k] : (int64_t)(h->t_counted * (uint64_t)h->M);
+        // the last move's total: all counted steps of all chains minus the other moves' (its per-chain array does not exist)
+        const unsigned long long tk = (k + 1 < h->K) ? host[AMC_MAX_MOVES + k] : h->t_counted * (uint64_t)h->M - others;
+        others += tk;
+        if (total) total[k] = (int64_t)tk;
     }
     return AMC_OK;
+}
+
+// Move.accepted_calls / total_calls are Int (Int64) in the reference (src/metropolis.jl:145-146); the per-chain copies on
+// the device are u32.  No chain's counter can exceed the number of counted steps, so the call that would take that number
+// past 2^32 - 1 is refused as a whole (nothing is launched) instead of letting a counter wrap silently.  The pool-wide
+// counter of a K = 1 handle without per-chain counters is 64-bit and has no such limit.
+static int counter_room(const amc_handle* h, const char* who, uint64_t steps)
+{
+    if (!h->counters || h->t_counted + steps <= 0xFFFFFFFFull) return AMC_OK;
+    return fail(AMC_ERR_STATE, "%s: the per-chain counters are 32-bit and hold %llu counted steps, %llu more would wrap them: download "
+                               "the counters and restart the count (amc_upload_counters with zeros) first",
+                who, (unsigned long long)h->t_counted, (unsigned long long)steps);
 }
 
 static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
@@ -1197,17 +1248,17 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
 {
     AMC_HIP(hipSetDevice(h->device));
     int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
+    { const int rc = counter_room(h, "amc_sweep", (uint64_t)remaining); if (rc != AMC_OK) return rc; }
     // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
     const int grid = grid_for(h, (h->M + 1) / 2, remaining == 1 ? h->blocks_per_cu_single : 0);
     if (grid_out) *grid_out = grid;
     while (remaining > 0) {
         int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
         if (h->d_log) {      // per-chain counters: one log row per MH step; a full log is folded before it is reused
-            if (h->log_fill == h->log_depth) {
-                const int rc = fold_log(h);
-                if (rc != AMC_OK) return rc;
-            }
-            if (chunk > h->log_depth - h->log_fill) chunk = h->log_depth - h->log_fill;
+            int room = 0;
+            const int rc = log_room(h, &room);
+            if (rc != AMC_OK) return rc;
+            if (chunk > room) chunk = room;
         }
         amc::SweepArgs a = make_sweep_args(h, chunk);
         const bool last = remaining == chunk;
@@ -1244,6 +1295,24 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
         return fail(AMC_ERR_STATE, "amc_upload_counters: handle was created with per_chain_counters = 0 "
                                    "(use amc_set_counter_totals)");
     if (h->K > 1 && !total) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: total is required when K > 1");
+    // Every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210), so sum_k total_calls_ck is ONE number
+    // for all chains: the count of steps taken.  The device keeps that number and K - 1 of the K total arrays.
+    uint64_t steps = h->t_counted;
+    if (total) {
+        for (int64_t c = 0; c < h->M; ++c) {
+            int64_t sum = 0;
+            for (int k = 0; k < h->K; ++k) {
+                const int64_t v = total[(int64_t)k * h->M + c];
+                if (v < 0 || v > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
+                sum += v;
+            }
+            if (c == 0) steps = (uint64_t)sum;
+            else if ((uint64_t)sum != steps)
+                return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: the total_calls of a chain must add up to the same step count on "
+                                             "every chain (chain 0: %llu, chain %lld: %lld)", (unsigned long long)steps, (long long)c, (long long)sum);
+        }
+        if (steps > 0xFFFFFFFFull) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: step count out of u32 range");
+    }
     AMC_HIP(hipSetDevice(h->device));
     h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
     std::vector<uint32_t> buf((size_t)h->M);
@@ -1252,7 +1321,7 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
         for (int pass = 0; pass < 2; ++pass) {
             const int64_t* src = pass == 0 ? accepted : total;
             uint32_t* dst = pass == 0 ? h->d_acc : h->d_tot;
-            if (!src || !dst) continue;
+            if (!src || !dst || (pass == 1 && k + 1 == h->K)) continue;     // the last move's totals have no array
             for (int64_t c = 0; c < h->M; ++c) {
                 const int64_t v = src[(int64_t)k * h->M + c];
                 if (v < 0 || v > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
@@ -1264,13 +1333,8 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
             AMC_HIP(hipStreamSynchronize(h->stream));
         }
     }
+    h->t_counted = steps;
     if (h->K == 1) {
-        // total_calls is the same on every chain for K = 1: it IS the number of counted steps
-        if (total) {
-            for (int64_t c = 1; c < h->M; ++c)
-                if (total[c] != total[0]) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: K = 1 totals must be uniform");
-            h->t_counted = (uint64_t)total[0];
-        }
         AMC_HIP(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
         AMC_HIP(hipMemcpyAsync(h->d_acc_slots, &acc_sum, sizeof(acc_sum), hipMemcpyHostToDevice, h->stream));
         AMC_HIP(hipStreamSynchronize(h->stream));
@@ -1447,6 +1511,24 @@ int amc_reduce_begin(amc_handle* h)
     return AMC_OK;
 }
 
+// Second half of a reduction whose sums over x were formed by the launch that has just been queued (rows in
+// h_partials[grid][8]): with per-chain counters the fold of the step log (pending rows incl. that launch's) forms the ratio
+// sums -- no pass re-reads x or the counters.
+static int finish_fused_reduce(amc_handle* h, int grid)
+{
+    h->red_ratio_rows = 0;
+    if (h->counters) {
+        const int rc2 = fold_log(h, true, &h->red_ratio_rows);
+        if (rc2 != AMC_OK) return rc2;
+    }
+    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
+    h->red_pending = true;
+    h->red_host = true;
+    h->red_rows = grid;
+    h->red_t_counted = h->t_counted;
+    return AMC_OK;
+}
+
 int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
@@ -1459,19 +1541,7 @@ int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
     int grid = 0;
     const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote the sums over x to h_partials[grid][8]
     if (rc != AMC_OK) return rc;
-    h->red_ratio_rows = 0;
-    if (h->counters) {
-        // per-chain counters: the fold of the step log (pending rows incl. this sweep's) forms the ratio sums -- no
-        // pass re-reads x or the counters
-        const int rc2 = fold_log(h, true, &h->red_ratio_rows);
-        if (rc2 != AMC_OK) return rc2;
-    }
-    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
-    h->red_pending = true;
-    h->red_host = true;
-    h->red_rows = grid;
-    h->red_t_counted = h->t_counted;
-    return AMC_OK;
+    return finish_fused_reduce(h, grid);
 }
 
 int amc_reduce_end(amc_handle* h, double* out)
@@ -1546,8 +1616,10 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 // move in h->d_out[l*4 + i] (device, on the stream).  Shared by the host- and device-resident estimator paths.
 // tail: 1 = sums only, 2 = + gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
 // with_sweep: the launch first does one make_step!(::Metropolis) (caller checked pg_fusable).
+// reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in h_partials[*grid_out][8].
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
-                     int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false)
+                     int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false, bool reduce = false,
+                     int* grid_out = nullptr)
 {
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
@@ -1604,13 +1676,16 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     if (grid > h->red_blocks) grid = h->red_blocks;
     int sweep = 0;
     if (with_sweep) {
-        if (h->d_log && h->log_fill == h->log_depth) { const int rcf = fold_log(h); if (rcf != AMC_OK) return rcf; }
+        { const int rcc = counter_room(h, who, 1); if (rcc != AMC_OK) return rcc; }
+        if (h->d_log) { int room = 0; const int rcf = log_room(h, &room); if (rcf != AMC_OK) return rcf; }
         sweep = h->K > 1 ? 2 : (h->d_log ? 1 : 3);
     }
+    if (grid_out) *grid_out = grid;
     amc::SweepArgs sw = make_sweep_args(h, 1);
-    const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep)
-                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep)
-                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep);
+    const bool red = reduce && with_sweep;
+    const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep, red)
+                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep, red)
+                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep, red);
     if (rc != AMC_OK) return rc;
     if (with_sweep) {
         h->t += 1;
@@ -1650,16 +1725,19 @@ static amc::PgIds make_ids(int n_learn, const int* learn_ids)
 // takes the learning step).  Shards connected by amc_comm_init: estimator launch, in-place all-reduce, then the
 // small accumulate (and update) kernels.
 static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, const amc::PgOpts* opt,
-                              bool with_sweep = false)
+                              bool with_sweep = false, bool reduce = false, int* grid_out = nullptr)
 {
     int nl = 0;
     const int tail = h->comm ? 1 : (opt ? 3 : 2);
-    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep);
+    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep, reduce, grid_out);
     if (rc != AMC_OK || n_learn == 0) return rc;
     if (!h->comm) return AMC_OK;
     // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
     const int e = h->rccl.AllReduce(h->d_out, h->d_out, (size_t)nl * 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    // one communicator, two streams: a collective amc_allreduce_sum queues on comm_stream later must start after this one
+    AMC_HIP(hipEventRecord(h->ev_comm_main, h->stream));
+    h->comm_main_pending = true;
     const double n_samples = (double)h->M_global * (double)q_batch;
     hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
                        n_samples, h->d_gd_acc);
@@ -1709,32 +1787,54 @@ int amc_pg_update(amc_handle* h, int n_learn, const int* learn_ids, const int* o
     return AMC_OK;
 }
 
-int amc_pgmc_steps(amc_handle* h, int64_t n_steps, int n_learn, const int* learn_ids, int q_batch, int do_update,
-                   const int* optimiser, const double* hyper0, const double* hyper1)
+// reduce: after the last time step, begin a reduction of the state it leaves (see amc_pgmc_steps_reduce_begin)
+static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int n_learn, const int* learn_ids, int q_batch,
+                           int do_update, const int* optimiser, const double* hyper0, const double* hyper1, bool reduce)
 {
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: NULL handle");
-    if (n_steps < 0) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: n_steps < 0");
-    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (!h) return fail(AMC_ERR_BAD_ARG, "%s: NULL handle", who);
+    if (n_steps < 0) return fail(AMC_ERR_BAD_ARG, "%s: n_steps < 0", who);
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
     if (n_learn > 0 && (!learn_ids || (do_update && (!optimiser || !hyper0 || !hyper1))))
-        return fail(AMC_ERR_BAD_ARG, "amc_pgmc_steps: NULL argument");
+        return fail(AMC_ERR_BAD_ARG, "%s: NULL argument", who);
+    if (reduce && n_steps < 1) return fail(AMC_ERR_BAD_ARG, "%s: n_steps must be >= 1", who);
+    if (reduce && h->red_pending) return fail(AMC_ERR_STATE, "%s: a reduction is already in flight (call amc_reduce_end)", who);
     amc::PgOpts opt;
     if (do_update && n_learn > 0) {
         const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt);
         if (rc != AMC_OK) return rc;
     }
+    { const int rc = counter_room(h, who, (uint64_t)n_steps * (uint64_t)h->sweepstep); if (rc != AMC_OK) return rc; }
     // the three make_step!s of one time step (src/simulation.jl:185-190), n_steps times, from one host call: two
     // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
+    const bool fused_reduce = reduce && fused && h->K <= 4;
+    int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);
         if (rc == AMC_OK)
-            rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr, fused);
+            rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr, fused,
+                                    fused_reduce && i + 1 == n_steps, &grid);
         if (rc != AMC_OK) return rc;
     }
-    return AMC_OK;
+    if (!reduce) return AMC_OK;
+    return fused_reduce ? finish_fused_reduce(h, grid) : amc_reduce_begin(h);
+}
+
+int amc_pgmc_steps(amc_handle* h, int64_t n_steps, int n_learn, const int* learn_ids, int q_batch, int do_update,
+                   const int* optimiser, const double* hyper0, const double* hyper1)
+{
+    return pgmc_steps_impl(h, "amc_pgmc_steps", n_steps, n_learn, learn_ids, q_batch, do_update, optimiser, hyper0, hyper1, false);
+}
+
+int amc_pgmc_steps_reduce_begin(amc_handle* h, int64_t n_steps, int n_learn, const int* learn_ids, int q_batch, int do_update,
+                                const int* optimiser, const double* hyper0, const double* hyper1)
+{
+    return pgmc_steps_impl(h, "amc_pgmc_steps_reduce_begin", n_steps, n_learn, learn_ids, q_batch, do_update, optimiser, hyper0,
+                           hyper1, true);
 }
 
 int amc_pg_get_accumulated(amc_handle* h, int n_learn, const int* learn_ids, double* out)
@@ -1832,10 +1932,15 @@ static int load_rccl(Rccl& r)
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
     r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.CommCount = (int (*)(void*, int*))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (int (*)(void*, int*))dlsym(r.lib, "ncclCommUserRank");
+    r.GetVersion = (int (*)(int*))dlsym(r.lib, "ncclGetVersion");
     void* init = dlsym(r.lib, "ncclCommInitRank");
     r.CommInitRank = (int (*)(void**, int, const void*, int))init;
-    if (!r.GetUniqueId || !r.AllReduce || !r.CommDestroy || !init)
+    if (!r.GetUniqueId || !r.AllReduce || !r.CommDestroy || !init) {
+        r.lib = nullptr;
         return fail(AMC_ERR_COMM, "librccl is missing a required symbol");
+    }
     return AMC_OK;
 }
 
@@ -1850,6 +1955,21 @@ int amc_comm_unique_id(void* id128)
     return AMC_OK;
 }
 
+// Back to a single shard: the communicator and what was allocated for it.
+static void comm_release(amc_handle* h)
+{
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    h->comm_stream = nullptr;
+    if (h->ev_comm_main) (void)hipEventDestroy(h->ev_comm_main);
+    h->ev_comm_main = nullptr;
+    h->comm_main_pending = false;
+    (void)hipFree(h->d_comm);
+    h->d_comm = nullptr;
+}
+
 int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
 {
     if (!h || !id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: NULL argument");
@@ -1857,18 +1977,80 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
     AMC_HIP(hipSetDevice(h->device));
     const int rc = load_rccl(h->rccl);
     if (rc != AMC_OK) return rc;
+    if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
+    // everything the communicator's users need exists BEFORE the communicator does: a failure below leaves the handle
+    // a clean single shard (amc_allreduce_sum the identity again, a later amc_comm_init welcome)
+    hipError_t he = hipMalloc(&h->d_comm, 256 * sizeof(double));
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&h->ev_comm_main, hipEventDisableTiming);
+    if (he != hipSuccess) {
+        comm_release(h);
+        return fail(he == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "amc_comm_init: %s", hipGetErrorString(he));
+    }
     // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId /* 128-byte struct BY VALUE */, int rank)
     struct Id { char b[128]; } id;
     std::memcpy(&id, id128, sizeof(id));
     typedef int (*init_fn)(void**, int, Id, int);
-    if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
     const int e = ((init_fn)(void*)h->rccl.CommInitRank)(&h->comm, n_ranks, id, rank);
     if (e != 0) {
-        h->comm = nullptr;         // the handle stays a single shard: amc_allreduce_sum is the identity again
+        h->comm = nullptr;
+        comm_release(h);
         return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
     }
-    AMC_HIP(hipMalloc(&h->d_comm, 256 * sizeof(double)));
-    AMC_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    return AMC_OK;
+}
+
+int amc_comm_destroy(amc_handle* h)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_comm_destroy: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    if (h->stream) AMC_HIP(hipStreamSynchronize(h->stream));      // the estimator's collectives run there
+    comm_release(h);
+    return AMC_OK;
+}
+
+static void copy_path_of(const void* symbol, char* out, int capacity)
+{
+    if (!out || capacity < 1) return;
+    out[0] = 0;
+    Dl_info info;
+    if (symbol && dladdr(symbol, &info) && info.dli_fname) {
+        std::strncpy(out, info.dli_fname, (size_t)capacity - 1);
+        out[capacity - 1] = 0;
+    }
+}
+
+int amc_comm_info(amc_handle* h, int* n_ranks, int* rank, int* rccl_version, char* librccl_path, int path_capacity)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_comm_info: NULL handle");
+    if (n_ranks) *n_ranks = 1;
+    if (rank) *rank = 0;
+    if (rccl_version) *rccl_version = 0;
+    if (librccl_path && path_capacity > 0) librccl_path[0] = 0;
+    if (!h->comm) return AMC_OK;
+    // asked of RCCL itself, not remembered from amc_comm_init's arguments: the point is what the communicator spans
+    if (!h->rccl.CommCount || !h->rccl.CommUserRank)
+        return fail(AMC_ERR_COMM, "amc_comm_info: this librccl exports no ncclCommCount / ncclCommUserRank");
+    int v = 0;
+    int e = h->rccl.CommCount(h->comm, &v);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommCount failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    if (n_ranks) *n_ranks = v;
+    e = h->rccl.CommUserRank(h->comm, &v);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommUserRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    if (rank) *rank = v;
+    if (rccl_version && h->rccl.GetVersion && h->rccl.GetVersion(&v) == 0) *rccl_version = v;
+    copy_path_of((const void*)h->rccl.AllReduce, librccl_path, path_capacity);
+    return AMC_OK;
+}
+
+int amc_runtime_info(int* hip_runtime_version, char* hip_runtime_path, int path_capacity)
+{
+    if (hip_runtime_version) {
+        int v = 0;
+        AMC_HIP(hipRuntimeGetVersion(&v));
+        *hip_runtime_version = v;
+    }
+    copy_path_of((const void*)&hipRuntimeGetVersion, hip_runtime_path, path_capacity);
     return AMC_OK;
 }
 
@@ -1878,10 +2060,17 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
     if (n < 0 || n > 256) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, 256]");
     if (!h->comm) return AMC_OK;   // single shard: the local sum is the global sum
     AMC_HIP(hipSetDevice(h->device));
-    // The values are the caller's (host) numbers: nothing here depends on work queued on the engine's stream, so the
-    // collective runs on a stream of its own and the host waits for THAT only -- on the engine's stream the wait would
-    // drain every sweep queued behind the callback (bench.py keeps ten in flight).  Every rank must call this in the
-    // same order relative to its other collectives on this communicator (the estimator's in-place all-reduce).
+    // The values are the caller's (host) numbers: nothing here depends on the sweeps queued on the engine's stream, so the
+    // collective runs on comm_stream and the host waits for THAT only (bench.py keeps ten sweeps in flight behind a
+    // callback).  One communicator serves both streams, and RCCL wants its collectives issued and run in one order on
+    // every rank: a collective queued on the engine's stream earlier (the estimator's in-place all-reduce) is waited for
+    // here first -- which drains the engine's stream up to that point, the price of sharing the communicator; with no
+    // estimator in the run nothing is pending and nothing waits.  The other direction needs no event: this call returns
+    // only when its collective is complete.  Every rank calls in the same order (same host program).
+    if (h->comm_main_pending) {
+        AMC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_comm_main, 0));
+        h->comm_main_pending = false;
+    }
     AMC_HIP(hipMemcpyAsync(h->d_comm, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
     const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->comm_stream);
     if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
@@ -1893,7 +2082,7 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
 // ---- parity-test hooks ----------------------------------------------------------------
 int amc_selftest_math(int device, int fn, const double* a, const double* b_or_null, double* out, int64_t n)
 {
-    if (!a || !out || n < 0 || fn < 0 || fn > 10 || ((fn == 5 || fn == 6 || fn == 9 || fn == 10) && !b_or_null))
+    if (!a || !out || n < 0 || fn < 0 || fn > 11 || ((fn == 5 || fn == 6 || fn == 9 || fn == 10 || fn == 11) && !b_or_null))
         return fail(AMC_ERR_BAD_ARG, "amc_selftest_math: bad argument");
     if (n == 0) return AMC_OK;
     AMC_HIP(hipSetDevice(device));

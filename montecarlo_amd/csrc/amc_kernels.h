@@ -4,7 +4,8 @@
 //   x[M_pad]                      chain positions (Particle.x); e is NOT stored: it is
 //                                 potential(x) by construction (particle_1d.jl:13-15,33)
 //   beta[M_pad]      (optional)   per-chain Particle.beta
-//   acc[K][M_pad], tot[K][M_pad]  u32 Move.accepted_calls / total_calls (when kept)
+//   acc[K][M_pad], tot[K-1][M_pad]  u32 Move.accepted_calls / total_calls (when kept; the last move's total_calls is the
+//                                 step count minus the other moves': every chain takes the same number of steps)
 //   ptab[PT_ROWS][AMC_MAX_MOVES]  per-move derived parameters (device-computed)
 // One lane owns TWO adjacent chains (one global "pair"): 16-byte loads/stores, one
 // Box-Muller and one accept-uniform Philox call serve both chains.
@@ -734,22 +735,26 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 }
 
 // The same pool-wide bookkeeping for kernels that run an MH step without being the sweep kernel (K == 1 only).
-__device__ __forceinline__ void add_block_accepts(unsigned long long* acc_total, unsigned long long wave_acc)
+// Returns the block's count (valid in thread 0).
+__device__ __forceinline__ unsigned long long add_block_accepts(unsigned long long* acc_total, unsigned long long wave_acc)
 {
     __shared__ unsigned long long s_acc2[AMC_BLOCK / 64];
     if ((threadIdx.x & 63) == 0) s_acc2[threadIdx.x >> 6] = wave_acc;
     __syncthreads();
+    unsigned long long t = 0;
     if (threadIdx.x == 0) {
-        unsigned long long t = 0;
         for (int w = 0; w < AMC_BLOCK / 64; ++w) t += s_acc2[w];
         if (t != 0) __hip_atomic_fetch_add(acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    return t;
 }
 
-// Adds `n_rows` rows of the step log into the per-chain u32 counters acc[K][m_stride] / tot[K][m_stride]
-// (tot == nullptr when K == 1: total_calls is the step count).  Entries of the padding behind n_chains are never
-// read back as counts.
+// Adds `n_rows` rows of the step log into the per-chain u32 counters acc[K][m_stride] / tot[K - 1][m_stride].
+// total_calls of the LAST move has no array: every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210),
+// so sum_k total_calls_ck == t_counted on every chain and the last move's count is t_counted minus the others -- one
+// read-modify-write array of four less at K = 2 (K == 1: none at all, total_calls is the step count).  Entries of the
+// padding behind n_chains are never read back as counts.
 // KS > 0: K == KS <= 4.  A block works on tiles of 4096 adjacent chains.  Log side: a thread owns SIXTEEN adjacent
 // chains -- one 16-byte load per row (the block reads 4 KiB of every row) -- and accumulates the rows bytewise in
 // packed registers: the accept bit and the move bits of four chains are masked out of a 32-bit word at once and added
@@ -761,7 +766,7 @@ __device__ __forceinline__ void add_block_accepts(unsigned long long* acc_total,
 // RATIO (KS > 0): the counters are in registers right after the update, so the launch also forms
 // callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
 // 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
-// total_ck is t_counted on every chain when K == 1 (tot == nullptr).
+// t_counted: MH steps counted per chain INCLUDING the rows of this launch (< 2^32: the host refuses to count further).
 #define AMC_FOLD_TILE (16 * AMC_BLOCK)
 template <int KS, bool RATIO = false>
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, uint32_t* acc,
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                         else { eq[0] = (b0 | b1) ^ ONES; eq[1] = b0 & ~b1; eq[2] = b1 & ~b0; eq[3] = b0 & b1; }
 #pragma unroll
                         for (int k = 0; k < KK; ++k) {
-                            pt[k][j] += eq[k];
+                            if (k < KK - 1) pt[k][j] += eq[k];            // the last move's total has no array
                             pa[k][j] += eq[k] & a;
                         }
                     }
@@ -812,34 +817,40 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
                 reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = uint4{pa[k][0], pa[k][1], pa[k][2], pa[k][3]};
-                reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = uint4{pt[k][0], pt[k][1], pt[k][2], pt[k][3]};
+                if (k < KK - 1) reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = uint4{pt[k][0], pt[k][1], pt[k][2], pt[k][3]};
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < KK; ++k) {
+            for (int i = 0; i < 4; ++i) {
+                const int quad = i * AMC_BLOCK + (int)threadIdx.x;
+                const int64_t c0 = c_tile + 4 * (int64_t)quad;
+                if (c0 >= m_stride) continue;
+                uint32_t tsum[4] = {0u, 0u, 0u, 0u};           // total_calls of the moves before k, per chain of the quad
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int quad = i * AMC_BLOCK + (int)threadIdx.x;
-                    const int64_t c0 = c_tile + 4 * (int64_t)quad;
-                    if (c0 >= m_stride) continue;
-                    const uint32_t wa = s_pk[2 * k][quad], wt = s_pk[2 * k + 1][quad];
+                for (int k = 0; k < KK; ++k) {
+                    const uint32_t wa = s_pk[2 * k][quad];
                     uint4* p_a = reinterpret_cast<uint4*>(acc + (int64_t)k * m_stride + c0);
                     uint4 va = *p_a;
                     va.x += wa & 0xFFu; va.y += (wa >> 8) & 0xFFu; va.z += (wa >> 16) & 0xFFu; va.w += wa >> 24;
                     *p_a = va;
-                    uint4 vt = {0u, 0u, 0u, 0u};
-                    if (tot) {
+                    uint4 vt;
+                    if (k < KK - 1) {
+                        const uint32_t wt = s_pk[2 * k + 1][quad];
                         uint4* p_t = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + c0);
                         vt = *p_t;
                         vt.x += wt & 0xFFu; vt.y += (wt >> 8) & 0xFFu; vt.z += (wt >> 16) & 0xFFu; vt.w += wt >> 24;
                         *p_t = vt;
+                        tsum[0] += vt.x; tsum[1] += vt.y; tsum[2] += vt.z; tsum[3] += vt.w;
+                    } else {
+                        const uint32_t tc = (uint32_t)t_counted;
+                        vt = uint4{tc - tsum[0], tc - tsum[1], tc - tsum[2], tc - tsum[3]};
                     }
                     if (RATIO) {
                         const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
-                                ratio[k] += (double)a4[e] / (tot ? (double)t4[e] : (double)t_counted);
+                                ratio[k] += (double)a4[e] / (double)t4[e];
                     }
                 }
             }
@@ -854,7 +865,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                 const uint32_t k = b >> 1;
                 if (k < (uint32_t)n_moves) {
                     acc[(int64_t)k * m_stride + c] += b & 1u;
-                    if (tot) tot[(int64_t)k * m_stride + c] += 1u;
+                    if (k + 1 < (uint32_t)n_moves) tot[(int64_t)k * m_stride + c] += 1u;
                 }
             }
         }
@@ -1052,7 +1063,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
             double r[1] = {0.0};
             for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
                 const double a = (double)acc[(int64_t)k * m_stride + c];
-                const double n = (ratio_mode == 2) ? (double)tot[(int64_t)k * m_stride + c] : (double)t_steps;
+                double n = (double)t_steps;
+                if (ratio_mode == 2) {
+                    // total_calls of the last move has no array: the step count minus the other moves' (fold_log_kernel)
+                    if (k + 1 < n_moves) {
+                        n = (double)tot[(int64_t)k * m_stride + c];
+                    } else {
+                        uint64_t others = 0;
+                        for (int j = 0; j + 1 < n_moves; ++j) others += tot[(int64_t)j * m_stride + c];
+                        n = (double)(t_steps - others);
+                    }
+                }
                 r[0] += a / n;    // Int/Int -> Float64 division; 0/0 = NaN like the reference
             }
             block_sum_store<1>(r, out + 4 + k);
@@ -1142,7 +1163,8 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_k
         unsigned long long sa = 0, st = 0;
         for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
             const uint4 va = *reinterpret_cast<const uint4*>(acc + (int64_t)k * m_stride + 4 * q);
-            const uint4 vt = tot ? *reinterpret_cast<const uint4*>(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
+            // tot has n_moves - 1 rows (the last move's totals are the step count minus the others: the host completes them)
+            const uint4 vt = (tot && k + 1 < n_moves) ? *reinterpret_cast<const uint4*>(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
             const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1383,9 +1405,19 @@ __device__ __forceinline__ double ordered_column_sum(const double* rows, int n_r
 // Per chain the operations and their order are those of the two separate launches.
 // (96-104 VGPRs: 4-5 waves per SIMD.  Capping the registers for 6-8 waves spills and is slower: 104 -> 111 / 155 /
 // 194 us per config-5 step, measured.)
-template <int POT, int NL, bool BETA, int SWEEP = 0>
+// REDUCE (with SWEEP): the launch also leaves the callback sums (sum e, sum x, sum x^2, count; SWEEP == 3: and the pool-wide
+// accepted total) of the state it stores -- AFTER the estimator's samples, which is what a callback scheduled at the same t
+// observes (run! calls Metropolis, estimator, update, then the callbacks: src/simulation.jl:185-190) -- as one row per block in
+// sw.red_partials, like sweep_kernel<.., REDUCE>: a callback after a fused time step needs no pass over x.
+template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
+    static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
+    double red[4] = {0.0, 0.0, 0.0, 0.0};
+    // the pool-wide accepted total this block can see before the launch (see sweep_kernel)
+    unsigned long long slots_before = 0;
+    if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
+        for (int sl = (int)blockIdx.x; sl < sw.n_slots; sl += (int)gridDim.x) slots_before += sw.acc_total[sl];
     // the math tables; after the sampling loop the same LDS stages the rows of the in-kernel final reduction
     constexpr int SCRATCH = (PG_GROUP * NL * 4 > TAB_DOUBLES) ? PG_GROUP * NL * 4 : TAB_DOUBLES;
     __shared__ double s_math[SCRATCH];
@@ -1490,6 +1522,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
         samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true);
+        if (REDUCE) {      // Float64 sums whatever the state type
+            const double x0 = xv.x, x1 = xv.y;
+            red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
+            red[1] += x0 + x1;
+            red[2] += x0 * x0 + x1 * x1;
+            red[3] += 2.0;
+        }
         x_done = xv;
         base_done = base;
     }
@@ -1504,8 +1543,19 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, v1);
             store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
         }
+        if (REDUCE) {
+            const double x0 = xv.x, x1 = xv.y;
+            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; red[2] += x0 * x0; red[3] += 1.0; }
+            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; red[2] += x1 * x1; red[3] += 1.0; }
+        }
     }
-    if (SWEEP == 1 || SWEEP == 3) add_block_accepts(sw.acc_total, wave_acc);   // K == 1: the pool-wide accepted total (counter_totals)
+    if (REDUCE) block_sum_store<4>(red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
+    if (SWEEP == 1 || SWEEP == 3) {      // K == 1: the pool-wide accepted total (counter_totals)
+        const unsigned long long t = add_block_accepts(sw.acc_total, wave_acc);
+        // column 4 of this block's row: the slot's value after this launch (exact in a double below 2^53)
+        if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
+            sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + 4] = (double)(slots_before + t);
+    }
     // Block partial sums -> row blockIdx.x of partials[grid][NL][4].  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
     // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /
@@ -1656,7 +1706,8 @@ AMC_KERNEL_LINKAGE __global__ void selftest_math_kernel(int fn, const double* a,
     case 7: r = logbm_f64(v, s_math); break;
     case 8: r = sqrt_radius_f64(v); break;
     case 9:
-    case 10: {
+    case 10:
+    case 11: {
         // log_proposal_density(delta = a, sigma = b) / its sigma-derivative, through the code the estimator runs:
         // prepare_params for a one-move pool, then log_proposal_density_withgrad
         double tab[PT_ROWS * AMC_MAX_MOVES];
@@ -1666,10 +1717,11 @@ AMC_KERNEL_LINKAGE __global__ void selftest_math_kernel(int fn, const double* a,
         const LogQ lq = log_proposal_density_withgrad((real_t)v, tab[PT_DEN * AMC_MAX_MOVES], tab[PT_RDEN * AMC_MAX_MOVES],
                                                       tab[PT_LOGC * AMC_MAX_MOVES], tab[PT_DDEN * AMC_MAX_MOVES],
                                                       tab[PT_DLHALF * AMC_MAX_MOVES]);
-        // 9: the reference-ordered log density; 10: d logq / d sigma as the estimator kernel forms it (pg_sample)
+        // 9: the reference-ordered log density; 10: d logq / d sigma in the reference's order (ForwardDiff's dual rules:
+        // what withgrad_log_proposal_density! returns); 11: d logq / d sigma as the estimator kernel forms it (pg_sample)
         const double d2 = (double)((real_t)v * (real_t)v);
         const double dq = __builtin_fma(d2, tab[PT_C3HI * AMC_MAX_MOVES], __builtin_fma(d2, tab[PT_C3LO * AMC_MAX_MOVES], -tab[PT_DLHALF * AMC_MAX_MOVES]));
-        r = fn == 9 ? lq.logq : dq;
+        r = fn == 9 ? lq.logq : (fn == 10 ? lq.dlogq : dq);
         break;
     }
     default: break;

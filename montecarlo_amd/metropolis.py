@@ -90,6 +90,7 @@ class Metropolis(AriannaAlgorithm):
         self._epoch = 0          # bumped whenever the device state changes
         self._red_key = None
         self._red_val = None
+        self._claimed = None     # the Reduction a callback holds whose sums have not been fetched from the engine yet
 
     # ---- plugin protocol ---------------------------------------------------------------
     def initialise(self, simulation: Simulation) -> None:
@@ -116,7 +117,8 @@ class Metropolis(AriannaAlgorithm):
         schedule), so the sums are formed inside the sweep launch instead of by a second pass over the chains."""
         self._drop_pending_reduction()
         if with_reductions and hasattr(self.engine, "sweep_reduce_begin"):
-            self.engine.sweep_reduce_begin(1)
+            self._settle_claimed()              # one reduction in flight per engine: the previous callback's is fetched now,
+            self.engine.sweep_reduce_begin(1)   # a whole callback period after it was queued -- no wait
             self._pending_red_epoch = self._epoch + 1
         else:
             self.engine.sweep(1)
@@ -127,6 +129,10 @@ class Metropolis(AriannaAlgorithm):
             self.engine.reduce_end()            # nobody asked for it: discard
             self._pending_red_epoch = None
 
+    def _settle_claimed(self) -> None:
+        if self._claimed is not None:
+            self._claimed.result()
+
     def make_steps(self, simulation: Simulation, n: int) -> None:
         """n consecutive make_step!s fused in one launch (state stays in registers)."""
         self._drop_pending_reduction()
@@ -134,6 +140,8 @@ class Metropolis(AriannaAlgorithm):
         self._epoch += 1
 
     def finalise(self, simulation: Simulation) -> None:
+        self._drop_pending_reduction()
+        self._settle_claimed()
         if getattr(self, "device_params_dirty", False):
             self.pull_parameters()
         if self.download_on_finalise:
@@ -182,30 +190,63 @@ class Metropolis(AriannaAlgorithm):
     # ---- reductions behind the callbacks ---------------------------------------------------
     def reductions(self) -> dict:
         """One device reduction + ONE all-reduce per observation point, shared by all callbacks."""
+        return self.reductions_async().result()
+
+    def reductions_async(self) -> "Reduction":
+        """The reduction of the CURRENT state as a ticket: ``result()`` fetches the sums (and all-reduces them over the
+        shards) when somebody needs the numbers.  The engine forms them in stream order -- inside the sweep launch that
+        produced the state when run() saw the callback coming -- so a caller that asks late (StoreCallbacks writes a
+        callback's row when the next one is due) never makes the host wait for the device, and the sweeps queued in
+        between are not held back by it.  Values are those of the state at the time of this call either way."""
         key = self._epoch
         if self._red_key == key and self._red_val is not None:
             return self._red_val
+        ticket = Reduction(self)
         if getattr(self, "_pending_red_epoch", None) == self._epoch:
-            local = self.engine.reduce_end()    # formed inside the sweep launch (make_step(with_reductions=True))
-            self._pending_red_epoch = None
-        else:
+            self._pending_red_epoch = None      # formed inside the launch (make_step(with_reductions=True)): claim it
+            self._claimed = ticket
+        elif hasattr(self.engine, "reduce_begin"):
             self._drop_pending_reduction()
-            local = self.engine.reduce()
-        red = sharding.allreduce_sum(local, self.engine)
+            self._settle_claimed()
+            self.engine.reduce_begin()
+            self._claimed = ticket
+        else:
+            ticket._finish(self.engine.reduce())
+        self._red_key, self._red_val = key, ticket
+        return ticket
+
+    def _fetch(self, ticket: "Reduction") -> None:
+        assert self._claimed is ticket
+        self._claimed = None
+        ticket._finish(self.engine.reduce_end())
+
+    def invalidate_reductions(self) -> None:
+        """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
+        self._epoch += 1
+
+
+class Reduction:
+    """The callback sums of one observation point (see Metropolis.reductions_async)."""
+
+    def __init__(self, metropolis: Metropolis):
+        self._met = metropolis
+        self._val = None
+
+    def _finish(self, local: np.ndarray) -> None:
+        red = sharding.allreduce_sum(local, self._met.engine)
         n = red[3]
-        val = {
+        self._val = {
             "energy": red[0] / n,                      # mean(system.e for system in chains)
             "mean_x": red[1] / n,
             "mean_x2": red[2] / n,
             "n_chains": int(round(n)),
             "acceptance": red[AMC_RED_HEADER:] / n,    # mean over chains of accepted/total per move
         }
-        self._red_key, self._red_val = key, val
-        return val
 
-    def invalidate_reductions(self) -> None:
-        """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
-        self._epoch += 1
+    def result(self) -> dict:
+        if self._val is None:
+            self._met._fetch(self)
+        return self._val
 
 
 def _find_metropolis(simulation: Simulation):
@@ -220,17 +261,32 @@ def _find_metropolis(simulation: Simulation):
     return found[0]
 
 
+def _deferrable(pick):
+    """A callback f(simulation) over the engine's reduction, plus ``f.deferred(simulation)``: the same value as a thunk over
+    the reduction ticket of the current state, for StoreCallbacks to evaluate when it writes the row."""
+    def wrap(fn):
+        def deferred(simulation: Simulation):
+            ticket = _find_metropolis(simulation).reductions_async()
+            return lambda: pick(ticket.result())
+        fn.deferred = deferred
+        return fn
+    return wrap
+
+
+@_deferrable(lambda r: float(r["energy"]))
 def callback_energy(simulation: Simulation) -> float:
     """callback_energy, example/particle_1d/particle_1d.jl:68-70: mean energy over all chains."""
     return float(_find_metropolis(simulation).reductions()["energy"])
 
 
+@_deferrable(lambda r: np.array(r["acceptance"], dtype=np.float64))
 def callback_acceptance(simulation: Simulation) -> np.ndarray:
     """callback_acceptance, src/metropolis.jl:319-321: per move, mean over chains of
     accepted_calls/total_calls (NaN before the first step, like the reference's 0/0)."""
     return np.array(_find_metropolis(simulation).reductions()["acceptance"], dtype=np.float64)
 
 
+@_deferrable(lambda r: np.array([r["mean_x"], r["mean_x2"]]))
 def callback_moments(simulation: Simulation) -> np.ndarray:
     """[mean(x), mean(x^2)] over all chains: the statistic test/distribution_test.jl:36-37 checks."""
     r = _find_metropolis(simulation).reductions()

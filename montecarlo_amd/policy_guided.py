@@ -239,23 +239,31 @@ class PolicyGradientEstimator(AriannaAlgorithm):
             self.gradients_data[k] = self.gradients_data[k] + gd                   # :130
             self.objectives[k] = self.gradients_data[k].j / self.gradients_data[k].n   # :131
 
-    def make_steps_grouped(self, simulation: Simulation, n: int, update: Optional["PolicyGradientUpdate"]) -> bool:
+    def make_steps_grouped(self, simulation: Simulation, n: int, update: Optional["PolicyGradientUpdate"],
+                           with_reductions: bool = False) -> bool:
         """n time steps that schedule exactly [Metropolis, this estimator(, update)] (PGMC_harmonic_oscillator.jl:24-33
         has them every t) as ONE engine call: same launches in the same order, without ~6 host calls per step.
         False when this configuration cannot be grouped (the caller then steps the algorithms one by one)."""
         eng = self.metropolis.engine
         if not (self.device_resident and self.learn_ids and hasattr(eng, "pgmc_steps")):
             return False
-        self.metropolis._drop_pending_reduction()
+        met = self.metropolis
+        met._drop_pending_reduction()
+        # with_reductions: a callback observes the state these steps leave -- the sums ride in the last step's launch
+        red = bool(with_reductions) and hasattr(eng, "reduce_end")
+        if red:
+            met._settle_claimed()            # one reduction in flight per engine
         if update is not None:
             codes = [optimiser_code(self.optimisers[lid]) for lid in self.learn_ids]
             eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, [c[0] for c in codes], [c[1] for c in codes],
-                           [c[2] for c in codes])
-            self.metropolis.device_params_dirty = True
+                           [c[2] for c in codes], **({"reduce_begin": True} if red else {}))
+            met.device_params_dirty = True
         else:
-            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size)
-        self.metropolis._epoch += 1
-        self.metropolis.invalidate_reductions()
+            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, **({"reduce_begin": True} if red else {}))
+        met._epoch += 1
+        met.invalidate_reductions()
+        if red:
+            met._pending_red_epoch = met._epoch
         return True
 
     def write_algorithm(self, io, scheduler) -> None:                              # :136-147

@@ -6,7 +6,7 @@ collective.  Information crosses chains in exactly two places, both tiny sums:
   * the callbacks (callback_energy particle_1d.jl:68-70, callback_acceptance metropolis.jl:319-321)
   * the GradientData `+` fold of the estimator (src/PolicyGuided/estimator.jl:113-129)
 These become ONE all-reduce(sum, f64) of a few dozen bytes.  On GPUs it runs through the engine's own RCCL
-communicator (amc_comm_init / amc_allreduce_sum: RCCL over xGMI, on the engine's stream, no torch tensors involved);
+communicator (amc_comm_init / amc_allreduce_sum: RCCL over xGMI, on a stream of the engine's own, no torch tensors involved);
 the launcher's TCP store carries the 128-byte ncclUniqueId and the run's barriers (`StoreGroup`: no process group, no
 second RCCL instance in the process).  A torch.distributed process group, if the script has one, is used the same way
 ("gloo" in CPU tests; "nccl" only to ship the unique id).  The Philox counter uses the global chain id, so results do
@@ -37,28 +37,49 @@ class StoreGroup:
         self.store = TCPStore(host, int(port), self.world_size, is_master=(self.rank == 0 and not agent_store),
                               timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
         self._n = 0
+        self._old: List[str] = []        # rank 0: keys of finished rounds, deleted once every rank is known to be past them
 
     def _key(self, what: str) -> str:
         self._n += 1
         return f"amc/{what}/{self._n}"
+
+    def _retire(self, keys: List[str], all_arrived: bool) -> None:
+        """Rank 0 keeps the launcher's store from growing with the run (one round of keys per callback otherwise).  A round's
+        keys may go once EVERY rank has finished it; rank 0 knows that of all earlier rounds when it completes a round in
+        which it has seen every rank arrive (all-gather, barrier) -- a rank arrives at round n only after finishing n - 1."""
+        if self.rank != 0:
+            return
+        if all_arrived:
+            for k in self._old:
+                try:
+                    self.store.delete_key(k)
+                except Exception:          # a store without delete_key: keep the keys, nothing else depends on it
+                    pass
+            self._old = []
+        self._old.extend(keys)
 
     def barrier(self) -> None:
         key = self._key("barrier")
         if self.store.add(key, 1) == self.world_size:
             self.store.set(key + "/done", b"1")
         self.store.wait([key + "/done"])
+        self._retire([key, key + "/done"], all_arrived=True)
 
     def allgather(self, obj) -> List:
         """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable objects)."""
         key = self._key("gather")
         self.store.set(f"{key}/{self.rank}", pickle.dumps(obj))
-        return [pickle.loads(self.store.get(f"{key}/{r}")) for r in range(self.world_size)]
+        out = [pickle.loads(self.store.get(f"{key}/{r}")) for r in range(self.world_size)]
+        self._retire([f"{key}/{r}" for r in range(self.world_size)], all_arrived=True)
+        return out
 
     def broadcast(self, obj, src: int = 0):
         key = self._key("bcast")
         if self.rank == src:
             self.store.set(key, pickle.dumps(obj))
-        return pickle.loads(self.store.get(key))
+        out = pickle.loads(self.store.get(key))
+        self._retire([key], all_arrived=False)       # the source does not learn here who has read the key
+        return out
 
     def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
         """Host-side sum in rank order (deterministic); for engines without a communicator of their own."""
@@ -97,15 +118,17 @@ def group() -> Optional[StoreGroup]:
 
 def connect_engine(engine) -> bool:
     """Give the engine of this rank's shard an RCCL communicator over all ranks (amc_comm_init); the ncclUniqueId made on
-    rank 0 travels over the store group or, failing that, over the script's torch.distributed process group.  True when
-    the engine is connected afterwards (its allreduce_sum / device-resident estimator then span the shards)."""
+    rank 0 travels over the store group or, failing that, over the script's torch.distributed process group.  A COLLECTIVE:
+    every rank calls it, every rank consumes the same store rounds whatever fails where, and every rank gets the same
+    answer -- True only when ALL engines are connected (their allreduce_sum / device-resident estimator then span the
+    shards); otherwise every engine is left a single shard and the callers' sums go over the host."""
     if getattr(engine, "comm_connected", False):
         return True
-    if not (hasattr(engine, "comm_init") and hasattr(engine, "comm_unique_id")):
-        return False
     rank, size = world()
+    capable = hasattr(engine, "comm_init") and hasattr(engine, "comm_unique_id")
     if _group is not None:
-        uid = _group.broadcast(engine.comm_unique_id() if rank == 0 else None)
+        bcast = _group.broadcast
+        gather = _group.allgather
     else:
         import sys
         if "torch" not in sys.modules:
@@ -113,13 +136,48 @@ def connect_engine(engine) -> bool:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
             return False
-        box = [engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-    engine.comm_connected = False
-    engine.comm_init(rank, size, uid)
-    engine.comm_connected = True
-    return True
+
+        def bcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        def gather(obj):
+            out = [None] * size
+            dist.all_gather_object(out, obj)
+            return out
+    # round 1: the unique id, or the reason rank 0 has none -- rank 0 ALWAYS broadcasts, so no rank waits for a key that
+    # never comes
+    record = None
+    if rank == 0:
+        try:
+            record = ("uid", engine.comm_unique_id()) if capable else ("error", "engine has no comm_init")
+        except Exception as err:                       # librccl not loadable, ncclGetUniqueId failed
+            record = ("error", str(err))
+    record = bcast(record)
+    ok, why = False, None
+    if record[0] == "uid" and capable:
+        try:
+            engine.comm_init(rank, size, record[1])
+            ok = True
+        except Exception as err:
+            why = str(err)
+    else:
+        why = record[1] if record[0] == "error" else "engine has no comm_init"
+    # round 2: all or none
+    flags = gather((bool(ok), why))
+    all_ok = all(f[0] for f in flags)
+    if ok and not all_ok and hasattr(engine, "comm_destroy"):
+        try:
+            engine.comm_destroy()                      # connected here, not there: back to a single shard
+        except Exception:
+            pass
+    engine.comm_connected = all_ok
+    if not all_ok and rank == 0:
+        import sys
+        reasons = "; ".join(f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0])
+        print(f"[montecarlo_amd] no RCCL communicator over the shards ({reasons}): sums go over the host", file=sys.stderr)
+    return all_ok
 
 
 def world() -> Tuple[int, int]:
@@ -159,7 +217,7 @@ def shard_range(n_global: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 def allreduce_sum(values: np.ndarray, engine=None) -> np.ndarray:
     """Sum a small f64 vector over all ranks (no-op for a single process).  `engine`: this rank's engine; when it holds a
-    communicator (connect_engine) the sum is ONE ncclAllReduce on its stream."""
+    communicator (connect_engine) the sum is ONE ncclAllReduce on the engine's communication stream."""
     rank, size = world()
     values = np.ascontiguousarray(values, dtype=np.float64)
     if engine is not None and getattr(engine, "comm_connected", False):

@@ -306,7 +306,9 @@ def _pgmc_group(simulation: Simulation, due: Sequence[int], t: int):
     n = min(_consecutive(sim.schedulers[k], sim.counters[k], t, t_last) for k in head)
     if n < 1:
         return 0, 0
-    return (m, n) if est.make_steps_grouped(sim, n, upd) else (0, 0)
+    # a callback scheduled at the group's last step observes the state the group leaves: its sums ride in the last launch
+    observed = after and t + n - 1 == s_other and _observed_next(sim, sorted(j for j, d in others if d == s_other))
+    return (m, n) if est.make_steps_grouped(sim, n, upd, with_reductions=observed) else (0, 0)
 
 
 def _observed_next(simulation: Simulation, later: Sequence[int]) -> bool:
@@ -337,12 +339,22 @@ def _consecutive(scheduler, counter: int, t: int, t_last: int) -> int:
 # StoreCallbacks, src/algorithms.jl:62-109
 # ---------------------------------------------------------------------------------------
 class StoreCallbacks(AriannaAlgorithm):
+    """StoreCallbacks (src/algorithms.jl:62-109): one file per callback, one row "$t $(callback(simulation))" per scheduled t.
+
+    ``defer`` (default on): when every callback of the list knows how to hand out its value as a thunk (``f.deferred``: the
+    engine-backed callback_energy / callback_acceptance / callback_moments), the row of time t is WRITTEN when the next
+    scheduled time comes (or at finalise): the sums are formed on the device in stream order at t, and the host reads
+    them a callback period later instead of stalling the sweep loop for them.  Rows, values and their order in the files
+    are the same; only ``rows`` / the files lag one entry behind during the run."""
+
     wants_reductions = True
 
     def __init__(self, chains, path=None, callbacks=None, store_first: bool = True, store_last: bool = False,
-                 **extras):
+                 defer: bool = True, **extras):
         self.callbacks = tuple(callbacks or ())
         self.store_first, self.store_last = store_first, store_last
+        self.defer = bool(defer) and len(self.callbacks) > 0 and all(hasattr(cb, "deferred") for cb in self.callbacks)
+        self._pending = None                # (t, [thunk per callback]) of the row not written yet
         self.rank, _ = sharding.world()
         self.paths = [os.path.join(path, cb.__name__.replace("callback_", "") + ".dat") for cb in self.callbacks]
         self.files: List[Any] = []
@@ -356,17 +368,32 @@ class StoreCallbacks(AriannaAlgorithm):
         if self.store_first:                                                        # :93
             self.make_step(simulation)
 
-    def make_step(self, simulation: Simulation) -> None:                            # :97-102
-        for i, cb in enumerate(self.callbacks):
-            value = cb(simulation)          # every rank calls: the callback all-reduces
-            self.rows[i].append((simulation.t, value))
+    def _write(self, t: int, values) -> None:
+        for i, value in enumerate(values):
+            self.rows[i].append((t, value))
             if self.rank == 0:
-                self.files[i].write(f"{simulation.t} {julia_repr(value)}\n")
+                self.files[i].write(f"{t} {julia_repr(value)}\n")
                 self.files[i].flush()
+
+    def flush(self) -> None:
+        """Write the row still held back (deferred mode)."""
+        if self._pending is not None:
+            t, thunks = self._pending
+            self._pending = None
+            self._write(t, [thunk() for thunk in thunks])     # every rank evaluates: the reduction all-reduces
+
+    def make_step(self, simulation: Simulation) -> None:                            # :97-102
+        if self.defer:
+            thunks = [cb.deferred(simulation) for cb in self.callbacks]    # claims the reduction of the state at this t
+            self.flush()                                                     # the previous row: its sums are long there
+            self._pending = (simulation.t, thunks)
+            return
+        self._write(simulation.t, [cb(simulation) for cb in self.callbacks])   # every rank calls: the callback all-reduces
 
     def finalise(self, simulation: Simulation) -> None:
         if self.store_last:
             self.make_step(simulation)
+        self.flush()
         for f in self.files:
             f.close()
         self.files = []

@@ -548,13 +548,15 @@ class OracleEngine:
         for k, row in zip(learn_ids, np.asarray(rows, dtype=np.float64).reshape(len(learn_ids), 5)):
             acc[k] = row.copy()
 
-    def pgmc_steps(self, n_steps, learn_ids, q_batch, kinds=None, hyper0=(), hyper1=()):
+    def pgmc_steps(self, n_steps, learn_ids, q_batch, kinds=None, hyper0=(), hyper1=(), reduce_begin=False):
         self.pgmc_calls = getattr(self, "pgmc_calls", 0) + 1
         for _ in range(int(n_steps)):
             self.sweep(1)
             self.pg_accumulate(learn_ids, q_batch)
             if kinds is not None:
                 self.pg_update(learn_ids, kinds, hyper0, hyper1)
+        if reduce_begin:                      # amc_pgmc_steps_reduce_begin: the sums of the state the last step leaves
+            self.reduce_begin()
 
     def sync(self):
         pass

@@ -58,6 +58,10 @@ def test_single_process_line():
     d = run_bench({}, "--no-cpu-baseline")
     check_line(d, 1, 0)
     assert "cpu_baseline" not in d
+    c = d["config"]
+    # no communicator in a single process; the HIP runtime libamc.so is bound to is named with its file
+    assert c["rccl_ranks"] is None and c["librccl"] is None
+    assert c["hip_runtime_version"] > 60000000 and "libamdhip64" in c["hip_runtime"]
 
 
 def test_distributed_path_on_one_rank():
@@ -65,6 +69,12 @@ def test_distributed_path_on_one_rank():
            "LOCAL_RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     d = run_bench(env, "--gpus", "1", "--no-cpu-baseline")
     check_line(d, 1, 10)
+    c = d["config"]
+    # the communicator itself says how many ranks it spans (ncclCommCount): a SCALE line shows "RCCL saw N ranks" by itself
+    assert c["rccl_ranks"] == 1 and c["rccl_rank"] == 0 and c["rccl_ranks_by_rank"] == [1]
+    assert "librccl" in c["librccl"] and c["rccl_version"] > 20000
+    assert c["callbacks_allreduce_via"].startswith("rccl")
+    assert c["hip_runtime_versions_by_rank"] == [c["hip_runtime_version"]]
 
 
 def test_gpus_flag_without_a_launcher_is_an_error():
@@ -116,6 +126,10 @@ def test_two_ranks_on_one_device_fall_back_to_the_store():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["chains_total"] == 2 * M and d["config"]["callbacks_allreduce_every"] == 10
     assert "store" in d["config"]["callbacks_allreduce_via"] or "rccl" in d["config"]["callbacks_allreduce_via"]
+    if "store" in d["config"]["callbacks_allreduce_via"]:       # all or none: no rank kept a communicator the other lacks
+        assert d["config"]["rccl_ranks"] is None and d["config"]["rccl_ranks_by_rank"] == [None, None]
+    else:
+        assert d["config"]["rccl_ranks"] == 2
     assert 0.90 < d["check"]["acceptance"] < 0.97
     # whole-job value: both shards' updates over the slowest rank's wall time
     assert abs(d["value"] - 2 * M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]

@@ -59,13 +59,14 @@ def test_device_sqrt_and_division_are_ieee(gpu):
 
 def test_log_proposal_density_and_gradient_known_answers(gpu, oracle):
     """test/ad_backends_test.jl:19-32 on the device: delta = 0, sigma = 0.2 -> logq = 0.6904993792294276, d logq / d sigma
-    = -5.0 (atol 1e-10, the reference's own tolerance).  logq in the reference's operation order: bit for bit against the
-    oracle on random arguments.  d logq / d sigma through the estimator kernel's own coefficients (prepare_params; one fma
-    chain d^2 (dden/den^2) - dlhalf instead of ForwardDiff's two divisions, amc_kernels.h pg_sample): within 4 ulp of the two
-    terms it subtracts, against the oracle's ForwardDiff-ordered value."""
+    = -5.0 (atol 1e-10, the reference's own tolerance).  logq and d logq / d sigma in the reference's operation order
+    (ForwardDiff's dual rules; what the host-side withgrad_log_proposal_density returns): bit for bit against the oracle on
+    random arguments.  The derivative as the estimator KERNEL forms it (prepare_params' split coefficient; one fma chain
+    d^2 (dden/den^2) - dlhalf instead of two divisions, amc_kernels.h pg_sample): within 4 ulp of the two terms it subtracts."""
     logq = gpu.selftest_math("log_proposal_density", [0.0], [0.2])[0]
     dlogq = gpu.selftest_math("grad_log_proposal_density", [0.0], [0.2])[0]
-    assert abs(logq - 0.6904993792294276) < 1e-10 and abs(dlogq - (-5.0)) < 1e-10
+    dlogq_k = gpu.selftest_math("grad_log_proposal_density_kernel_form", [0.0], [0.2])[0]
+    assert abs(logq - 0.6904993792294276) < 1e-10 and abs(dlogq - (-5.0)) < 1e-10 and abs(dlogq_k - (-5.0)) < 1e-10
     rng = np.random.default_rng(8)
     n = 200000
     sig = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n))
@@ -75,12 +76,15 @@ def test_log_proposal_density_and_gradient_known_answers(gpu, oracle):
     wantg = np.array([lib.amo_grad_log_proposal_density(d, s) for d, s in zip(delta[:20000], sig[:20000])])
     got = gpu.selftest_math("log_proposal_density", delta, sig)
     gotg = gpu.selftest_math("grad_log_proposal_density", delta, sig)
+    gotk = gpu.selftest_math("grad_log_proposal_density_kernel_form", delta, sig)
     assert np.array_equal(bits(got[:20000]), bits(want))
+    assert np.array_equal(bits(gotg[:20000]), bits(wantg))
     terms = delta[:20000] ** 2 / sig[:20000] ** 3 + 1 / sig[:20000]
-    assert np.all(np.abs(gotg[:20000] - wantg) <= 4 * 2.0 ** -52 * terms)
+    assert np.all(np.abs(gotk[:20000] - wantg) <= 4 * 2.0 ** -52 * terms)
     # closed forms (particle_1d.jl:53 and its sigma-derivative delta^2/sigma^3 - 1/sigma)
     assert np.allclose(got, -delta ** 2 / (2 * sig ** 2) - np.log(2 * np.pi * sig ** 2) / 2, rtol=1e-12, atol=1e-12)
     assert np.allclose(gotg, delta ** 2 / sig ** 3 - 1 / sig, rtol=1e-10, atol=1e-12)
+    assert np.allclose(gotk, delta ** 2 / sig ** 3 - 1 / sig, rtol=1e-10, atol=1e-12)
 
 
 def test_ad_backends_test_of_the_reference(gpu):
@@ -911,3 +915,166 @@ def test_split_engine_snapshots_and_pool_totals(gpu):
     parts.set_counter_totals(1234, 5)
     assert parts.counter_totals()[0][0] == 1234 and parts.counter_totals()[1][0] == 5 * 10_001
     one.close(); parts.close()
+
+
+# ---- round 3: callback sums inside the fused PGMC launch, K - 1 total arrays, 32-bit counter guard -------------------
+@pytest.mark.parametrize("case", ["k2", "k1", "k1_pooled", "k2_beta", "k5_wide", "custom"])
+def test_pgmc_steps_reduce_begin_equals_steps_then_reduce(gpu, case):
+    """amc_pgmc_steps_reduce_begin(n) == amc_pgmc_steps(n); amc_reduce_begin: the callback observes the state AFTER the
+    estimator's samples (run! order, src/simulation.jl:185-190).  Fused forms (<= 2 learnable moves) form the sums over
+    x inside the last launch and the ratios in the fold of the step log behind it; "k5_wide" takes the plain passes.  x, GradientData, sigma, counters bit for bit; the sums to reduction tolerance; work queued behind the
+    reduction does not disturb it."""
+    from montecarlo_amd import CustomPotential
+    M = 40_003
+    kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=23)
+    ids, kinds, h0, h1 = [1], [1], [0.3], [0.0]
+    beta = None
+    if case in ("k1", "k1_pooled"):
+        kw.update(sigma=[0.15], weight=[1.0], per_chain_counters=(case == "k1"))
+        ids = [0]
+    elif case == "k2_beta":
+        kw.update(potential="double_well")
+        ids, kinds, h0, h1 = [0, 1], [1, 2], [0.2, 0.2], [0.0, 0.0]
+        beta = np.random.default_rng(5).uniform(0.5, 3.0, M)
+    elif case == "k5_wide":
+        kw.update(sigma=[0.2, 0.1, 0.3, 0.25, 0.5], weight=[0.2] * 5)
+        ids, kinds, h0, h1 = [0, 2, 4], [1, 1, 6], [0.1, 0.1, 1e-6], [0.0, 0.0, 1e-6]
+    elif case == "custom":
+        kw.update(potential=CustomPotential("x*x*x*x - 2.0*x*x + 0.25*x"))
+    a, b = gpu.HipEngine(**kw), gpu.HipEngine(**kw)
+    x0 = np.random.default_rng(6).uniform(-2, 2, M)
+    for e in (a, b):
+        e.upload_state(x0, beta)
+        e.sweep(3)
+    for n in (1, 7):
+        a.pgmc_steps(n, ids, 2, kinds, h0, h1, reduce_begin=True)
+        a.pgmc_steps(2, ids, 2, kinds, h0, h1)            # queued behind the reduction
+        red_a = a.reduce_end()
+        b.pgmc_steps(n, ids, 2, kinds, h0, h1)
+        red_b = b.reduce()
+        b.pgmc_steps(2, ids, 2, kinds, h0, h1)
+        assert red_a[3] == red_b[3] == M
+        np.testing.assert_allclose(red_a, red_b, rtol=1e-12, equal_nan=True)
+    assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
+    assert np.array_equal(bits(a.pg_get_accumulated(ids)), bits(b.pg_get_accumulated(ids)))
+    assert [a.get_parameters(k)[0] for k in range(len(kw["sigma"]))] == [b.get_parameters(k)[0] for k in range(len(kw["sigma"]))]
+    assert np.array_equal(a.counter_totals()[0], b.counter_totals()[0]) and np.array_equal(a.counter_totals()[1], b.counter_totals()[1])
+    if case != "k1_pooled":
+        ca, cb = a.download_counters(), b.download_counters()
+        assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
+        assert np.all(ca[1].sum(axis=0) == 3 + 8 + 4)          # every chain took every step
+    with pytest.raises(gpu.AmcError, match="already in flight"):
+        a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)
+        a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)
+    a.reduce_end()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("depth", [2, 5, 16])
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_callback_folds_interleaved_with_queued_sweeps(gpu, oracle, monkeypatch, depth, K):
+    """A callback's fold of the step log (amc_sweep_reduce_begin) with sweeps queued behind it before its sums are read:
+    callbacks read one period late (the pipelined form StoreCallbacks uses) and at once, small log depths so that full
+    logs are folded in between; counters and sums against the oracle throughout."""
+    monkeypatch.setenv("AMC_LOG_DEPTH", str(depth))
+    M = 9001
+    sigma, weight = POOLS[K]
+    kw = dict(potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=31)
+    e = gpu.HipEngine(n_chains=M, per_chain_counters=True, **kw)
+    o = oracle.OracleSim(M, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    expect, got = [], []
+    pending = False
+    for i, n in enumerate([1, 3, 1, 4, 2, 7, 1, 1, 5, 3, 2, 6]):
+        e.sweep(n)
+        o.make_steps(n, 4)
+        if pending:
+            got.append(e.reduce_end())                    # the previous callback's sums, a period late
+        e.sweep_reduce_begin(1 + i % 2)
+        o.make_steps(1 + i % 2, 4)
+        expect.append((o.energy(), o.moments(), o.acceptance()))
+        pending = True
+        if i % 4 == 3:
+            got.append(e.reduce_end())                    # ... or at once
+            pending = False
+            if i == 7:
+                a2, t2 = e.download_counters()            # a reader of the counters between two callbacks
+                ao, to = o.counters()
+                assert np.array_equal(a2, ao) and np.array_equal(t2, to)
+    if pending:
+        got.append(e.reduce_end())
+    assert len(got) == len(expect)
+    for red, (en, mom, acc) in zip(got, expect):
+        assert red[3] == M
+        np.testing.assert_allclose(red[0] / M, en, rtol=RED_RTOL)
+        np.testing.assert_allclose(red[2], mom[1], rtol=RED_RTOL)
+        np.testing.assert_allclose(red[4:] / M, acc, rtol=RED_RTOL, equal_nan=True)
+    assert_same(e, o)
+    e.close()
+
+
+@pytest.mark.parametrize("K", [1, 2])
+def test_per_chain_counters_refuse_to_wrap(gpu, K):
+    """Move.accepted_calls / total_calls are Int64 in the reference (src/metropolis.jl:145-146), u32 per chain on the
+    device: the call that would count step 2^32 returns AMC_ERR_STATE before anything is launched."""
+    M = 1001
+    sigma, weight = POOLS[K]
+    e = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5, per_chain_counters=True)
+    e.init_uniform(-2, 2)
+    limit = 2 ** 32 - 1
+    acc = np.zeros((K, M), dtype=np.int64)
+    tot = np.zeros((K, M), dtype=np.int64)
+    tot[0] = limit - 5                                      # 5 steps of room
+    acc[0] = limit - 7
+    e.upload_counters(acc, tot)
+    e.sweep(3)
+    with pytest.raises(gpu.AmcError, match="32-bit"):
+        e.sweep(3)
+    assert e.step == 3                                      # nothing was launched by the refused call
+    with pytest.raises(gpu.AmcError, match="32-bit"):
+        e.pgmc_steps(3, [0], 1)
+    e.sweep(2)
+    a2, t2 = e.download_counters()
+    assert np.all(t2.sum(axis=0) == limit) and np.all(a2[0] >= limit - 7) and np.all(a2 <= t2)
+    with pytest.raises(gpu.AmcError, match="32-bit"):
+        e.sweep(1)
+    e.upload_counters(acc * 0, tot * 0)                     # restart the count
+    e.sweep(4)
+    assert np.all(e.download_counters()[1].sum(axis=0) == 4)
+    # the pool-wide counter of a K = 1 handle without per-chain counters is 64-bit
+    if K == 1:
+        p = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5, per_chain_counters=False)
+        p.init_uniform(-2, 2)
+        p.set_counter_totals(7 * 2 ** 40, 2 ** 41)
+        p.sweep(5)
+        a, t = p.counter_totals()
+        assert t[0] == (2 ** 41 + 5) * M and 7 * 2 ** 40 <= a[0] <= 7 * 2 ** 40 + 5 * M
+        p.close()
+    e.close()
+
+
+def test_uploaded_totals_must_add_up_to_one_step_count(gpu):
+    """Every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210): sum_k total_calls is one number
+    for all chains, and the device keeps K - 1 of the K total arrays."""
+    M, K = 501, 3
+    sigma, weight = POOLS[K]
+    e = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5)
+    e.init_uniform(-2, 2)
+    rng = np.random.default_rng(1)
+    tot = rng.multinomial(1000, weight, size=M).T.astype(np.int64)
+    acc = (tot * rng.uniform(0, 1, tot.shape)).astype(np.int64)
+    e.upload_counters(acc, tot)
+    a2, t2 = e.download_counters()
+    assert np.array_equal(a2, acc) and np.array_equal(t2, tot)
+    assert np.array_equal(e.counter_totals()[1], tot.sum(axis=1))
+    red = e.reduce()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        np.testing.assert_allclose(red[4:], (acc / tot).sum(axis=1), rtol=1e-12, equal_nan=True)
+    e.sweep(5)
+    assert np.all(e.download_counters()[1].sum(axis=0) == 1005)
+    bad = tot.copy()
+    bad[1, 7] += 1
+    with pytest.raises(gpu.AmcError, match="same step count"):
+        e.upload_counters(acc, bad)
+    e.close()

@@ -170,3 +170,66 @@ json.dump(dict(ok=True), open(os.path.join({str(tmp_path)!r}, f"sg{{g.rank}}.jso
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0, err[-3000:]
     assert all(json.load(open(tmp_path / f"sg{r}.json"))["ok"] for r in range(2))
+
+
+def test_connect_engine_is_all_or_none_and_store_keys_are_retired(tmp_path):
+    """sharding.connect_engine is a collective: whatever fails on whichever rank (no librccl on rank 0, ncclCommInitRank
+    failing on one rank only), every rank consumes the same store rounds, gets the same answer and is left a single shard,
+    and the host-side sums that follow stay in step.  Also: the launcher's store does not grow with the number of sums."""
+    script = tmp_path / "ce.py"
+    script.write_text(f"""
+import os, sys, json
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from montecarlo_amd import sharding
+g = sharding.init_store_group()
+
+class Double:
+    def __init__(self, uid_fails=False, init_fails_on=None):
+        self.uid_fails, self.init_fails_on, self.destroyed, self.inited = uid_fails, init_fails_on, 0, 0
+    def comm_unique_id(self):
+        if self.uid_fails:
+            raise RuntimeError("cannot dlopen librccl")
+        return bytes(128)
+    def comm_init(self, rank, size, uid):
+        assert uid == bytes(128) and size == 2
+        if self.init_fails_on == rank:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.inited += 1
+    def comm_destroy(self):
+        self.destroyed += 1
+    def allreduce_sum(self, v):
+        raise AssertionError("a disconnected engine must not be asked")
+
+# (a) rank 0 cannot even make the id: nobody waits for a key that never comes
+e = Double(uid_fails=True)
+assert sharding.connect_engine(e) is False and e.comm_connected is False and e.inited == 0
+assert list(sharding.allreduce_sum(np.array([1.0 + g.rank]), e)) == [3.0]          # same round on both ranks
+# (b) comm_init fails on rank 1 only: rank 0 drops the communicator it got
+e = Double(init_fails_on=1)
+assert sharding.connect_engine(e) is False and e.comm_connected is False
+assert (e.inited, e.destroyed) == ((1, 1) if g.rank == 0 else (0, 0))
+assert list(sharding.allreduce_sum(np.array([2.0 * g.rank]), e)) == [2.0]
+# (c) everything works: connected on both
+e = Double()
+assert sharding.connect_engine(e) is True and e.comm_connected is True and e.destroyed == 0
+# (d) an engine that cannot hold a communicator at all (CPU test doubles)
+assert sharding.connect_engine(object.__new__(type("Bare", (), {{}}))) is False
+# the store holds a bounded number of keys however many sums have passed
+g.barrier()
+before = g.store.num_keys()
+for i in range(200):
+    s = g.allreduce_sum(np.array([float(i), 1.0]))
+    assert list(s) == [2.0 * i, 2.0]
+    if i % 50 == 0:
+        assert g.broadcast(i if g.rank == 0 else None) == i
+g.barrier()
+after = g.store.num_keys()
+assert after <= before + 16, (before, after)
+json.dump(dict(ok=True, keys=[before, after]), open(os.path.join({str(tmp_path)!r}, f"ce{{g.rank}}.json"), "w"))
+g.barrier()
+""")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert all(json.load(open(tmp_path / f"ce{k}.json"))["ok"] for k in range(2))

@@ -1,19 +1,24 @@
 #!/bin/bash
-# Developer tool, run on the GPU box (gpurun -- 'bash tools/gpu_profile_r2.sh'): rocprofv3 kernel-trace summaries and
-# PMC passes (own runs, counters only) of bench.py and of the round-2 workloads; tools/summarize_profiles_r2.py turns
-# what lands in gpurun_out/r02/ into the committed files under profiles/.
+# Developer tool, run on the GPU box (gpurun -- 'bash tools/gpu_profile.sh'): rocprofv3 kernel-trace summaries and
+# PMC passes (own runs, counters only) of bench.py and of the workloads of tools/gpu_workload.py; tools/summarize_profiles.py
+# turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r03).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+TAG=${AMC_ROUND_TAG:-r03}
+export AMC_ROUND_TAG=$TAG
+O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats -d $O/bench_trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-ladder > $O/bench_prof.json 2> $O/bench_prof.err
 echo "bench trace done"
-W="python3 $R/tools/gpu_r2_workload.py"
+W="python3 $R/tools/gpu_workload.py"
+export PIPELINED=1      # callbacks read one period late, as the host mirror's StoreCallbacks does; the at-once figure is logged next to it
 for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "est"; do
   tag=$(echo $wl | tr ' ' '_')
   rocprofv3 --kernel-trace --stats -d $O/$tag/trace --output-format csv -- $W $wl > $O/$tag.log 2>&1
+  case $wl in k2|pgmc) PIPELINED=0 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled, callback read at once: /' >> $O/$tag.log
+                       PIPELINED=1 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled: /' >> $O/$tag.log;; esac
   LAUNCHES=120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$tag/pmc_fetch --output-format csv -- $W $wl > /dev/null 2>&1
   LAUNCHES=120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$tag/pmc_write --output-format csv -- $W $wl > /dev/null 2>&1
   LAUNCHES=120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/$tag/pmc_sq --output-format csv -- $W $wl > /dev/null 2>&1
@@ -21,9 +26,9 @@ for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "es
   echo "$tag done: $(cat $O/$tag.log | tail -1)"
 done
 # the per-dispatch traces and counter tables are large (gpurun merges at most 64 MiB back): summarise them here, keep
-# the summaries (gpurun_out/r02_out/ -> copied into profiles/ by hand) and drop the raw tables
-AMC_PROFILE_OUT=$R/gpurun_out/r02_out python3 $R/tools/summarize_profiles_r2.py
-cp $O/*.log $O/bench_n1.err $R/gpurun_out/r02_out/ 2>/dev/null
+# the summaries (gpurun_out/${TAG}_out/ -> copied into profiles/ by hand) and drop the raw tables
+AMC_PROFILE_OUT=$R/gpurun_out/${TAG}_out python3 $R/tools/summarize_profiles.py
+cp $O/*.log $O/bench_n1.err $R/gpurun_out/${TAG}_out/ 2>/dev/null
 rm -rf $O
-du -sh $R/gpurun_out/r02_out
-cat $R/gpurun_out/r02_out/r02_bench_n1.json
+du -sh $R/gpurun_out/${TAG}_out
+cat $R/gpurun_out/${TAG}_out/${TAG}_bench_n1.json

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (round 2): the workloads profiled under rocprofv3 for profiles/r02_*.
+"""Developer tool (rounds 2-3): the workloads profiled under rocprofv3 for profiles/r02_* / r03_*.
 
   ladder <M>   single-sweep launches of the headline kernel (harmonic, K = 1, pool-wide counter) at M chains
   k2           BASELINE config 3 shape: double well, K = 2 (sigma 0.1 / 1.0), one launch per sweep, callbacks every 10
@@ -72,10 +72,10 @@ elif mode in ("pgmc", "est"):
         if mode == "pgmc":
             pending = False
             for i in range(n // 10):
-                e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0])
                 if PIPELINED and pending:
-                    e.reduce_end()
-                e.reduce_begin()
+                    e.reduce_end()                    # the previous callback's sums: queued ten time steps ago
+                # ten time steps; the tenth launch also forms the callback sums, the ratio fold runs on the second stream
+                e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0], reduce_begin=True)
                 pending = True
                 if not PIPELINED:
                     e.reduce_end(); pending = False

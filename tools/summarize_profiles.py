@@ -1,51 +1,123 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs merged into gpurun_out/ into the committed summaries under profiles/.
+"""Turns the rocprofv3 outputs of tools/gpu_profile.sh (merged into gpurun_out/<tag>/; tag = AMC_ROUND_TAG, default r03) into the committed summaries:
 
-  profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of `bench.py`
-  profiles/<tag>_pmc_summary.json    per-launch averages of the PMC passes for the sweep kernel
-  profiles/pmc_traffic.json          HBM bytes per sweep launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                                     read by bench.py for roofline.traffic
+  profiles/<tag>_bench_kernel_stats.csv            rocprofv3 --kernel-trace --stats of `python3 bench.py` (the headline command)
+  profiles/<tag>_<workload>_kernel_stats.csv       the same for the ladder sizes, the K = 2 sweep (config 3 shape), the fused
+                                                 PGMC step (config 5) and the estimator launch alone
+  profiles/<tag>_pmc_summary.json                  per workload and kernel: per-launch means of the PMC passes and what follows
+                                                 from them (HBM bytes with the gfx950 FETCH_SIZE x2 correction, VALUBusy, VALU
+                                                 instructions per wave, wait fractions, LDS bank-conflict cycles)
+  profiles/pmc_traffic.json                      headline kernel: bytes per launch + VALUBusy, with commit and kernel-source hash
+                                                 (bench.py quotes it as a static figure with that provenance)
+  profiles/<tag>_bench_n1.json                     the bench line of the same box
 """
-import csv, glob, json, os, shutil, sys, collections
+import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out = os.path.join(ROOT, "profiles"); os.makedirs(out, exist_ok=True)
-g = os.path.join(ROOT, "gpurun_out")
-def newest(pattern):
-    """gpurun merges every call's files into gpurun_out/: take the latest run's."""
-    files = sorted(glob.glob(pattern), key=os.path.getmtime)
-    return files[-1:]
+TAG = os.environ.get("AMC_ROUND_TAG", "r03")
+G = os.path.join(ROOT, "gpurun_out", TAG)
+OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
+os.makedirs(OUT, exist_ok=True)
+ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
+              "k2": 17 * 10_000_000, "pgmc": 17 * 10_000_000, "est": 16 * 10_000_000}
+MAIN = {"ladder": "sweep_kernel<0, false, false, false, true, false>", "k2": "sweep_kernel<1, true, true, false, true",
+        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false>"}
 
 
-for f in newest(os.path.join(g, "prof", "*", "*_kernel_stats.csv")):
-    shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
-    print(open(f).read()[:900])
+def one(pattern):
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+def kernel_hash():
+    h = hashlib.sha256()
+    for fn in ("amc_kernels.h", "amc_math.h", "amc_tables.h"):
+        h.update(open(os.path.join(ROOT, "montecarlo_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 summary = collections.OrderedDict()
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in newest(os.path.join(g, d, "*", "*counter_collection.csv")):
+f = one(os.path.join(G, "bench_trace", "*", "*_kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(OUT, f"{TAG}_bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(G, "bench_n1.json")):
+    shutil.copy(os.path.join(G, "bench_n1.json"), os.path.join(OUT, f"{TAG}_bench_n1.json"))
+for wl in ALGO_BYTES:
+    f = one(os.path.join(G, wl, "trace", "*", "*_kernel_stats.csv"))
+    if not f:
+        continue
+    shutil.copy(f, os.path.join(OUT, f"{TAG}_{wl}_kernel_stats.csv"))
+    main = MAIN[wl.split("_")[0]]
+    entry = collections.OrderedDict()
+    rows = [r for r in csv.DictReader(open(f)) if main in r["Name"]]
+    if rows:
+        # (the K = 2 workload launches two forms of the sweep kernel: plain, and with the callback sums every 10th step)
+        entry["kernel"] = [r["Name"] for r in rows] if len(rows) > 1 else rows[0]["Name"]
+        entry["launches_traced"] = sum(int(r["Calls"]) for r in rows)
+        entry["avg_us_kernel_trace"] = sum(float(r["TotalDurationNs"]) for r in rows) / entry["launches_traced"] / 1e3
+        entry["min_us_kernel_trace"] = min(float(r["MinNs"]) for r in rows) / 1e3
+    counters = {}
+    meta = None
+    for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+        cf = one(os.path.join(G, wl, d, "*", "*counter_collection.csv"))
+        if not cf:
+            continue
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if "sweep_kernel" in r["Kernel_Name"]:
+        for r in csv.DictReader(open(cf)):
+            if main in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                meta = (r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"])
+                meta = dict(grid=int(r["Grid_Size"]), workgroup=int(r["Workgroup_Size"]), vgpr=int(r["VGPR_Count"]),
+                            sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]))
         for k, v in agg.items():
-            summary[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-        if agg:
-            summary["_kernel"] = dict(zip(("name", "grid", "workgroup", "vgpr", "sgpr", "lds"), meta))
-if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
-    fetch_kb, write_kb = summary["FETCH_SIZE"]["mean_per_launch"], summary["WRITE_SIZE"]["mean_per_launch"]
-    traffic = (2.0 * fetch_kb + write_kb) * 1024.0
-    summary["_traffic"] = {"fetch_bytes_corrected_x2": 2 * fetch_kb * 1024, "write_bytes": write_kb * 1024,
-                           "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 16 * 10_000_000,
-                           "note": "FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled"}
-    extra = {}
-    if "SQ_ACTIVE_INST_VALU" in summary and "GRBM_GUI_ACTIVE" in summary:
+            v = v[len(v) // 4:]                               # skip the first quarter: clock ramp / first-touch launches
+            counters[k] = sum(v) / len(v)
+    entry["launch"] = meta
+    entry["counters_mean_per_launch"] = counters
+    d = collections.OrderedDict()
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        d["hbm_bytes_per_launch"] = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+        d["fetch_bytes_x2_gfx950"] = 2.0 * counters["FETCH_SIZE"] * 1024.0
+        d["write_bytes"] = counters["WRITE_SIZE"] * 1024.0
+        d["algorithmic_bytes_per_launch"] = ALGO_BYTES[wl]
+        d["traffic_over_algorithmic"] = d["hbm_bytes_per_launch"] / ALGO_BYTES[wl]
+    if "SQ_ACTIVE_INST_VALU" in counters and "GRBM_GUI_ACTIVE" in counters:
         # rocprof's VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE; rocprofv3 reports GRBM_GUI_ACTIVE summed over
         # the 8 XCDs (MI355X_MICROARCH.md, DVFS note), so the per-XCD busy cycles are 1/8 of it.  256 CUs x 4 SIMDs.
-        busy = summary["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / (summary["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
-        summary["_valu_busy"] = {"frac": busy, "formula": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)"}
-        extra["sweep_kernel_valu_busy"] = busy
-    json.dump({"sweep_kernel_bytes_per_launch": traffic, "source": f"profiles/{tag}_pmc_summary.json", **extra},
-              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+        d["valu_busy"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (counters["GRBM_GUI_ACTIVE"] / 8.0)
+        d["wait_inst_any_over_wave_cycles"] = counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
+        d["wait_any_over_wave_cycles"] = counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
+    if "SQ_INSTS_VALU" in counters and meta:
+        m_pairs = ALGO_BYTES[wl] // (16 if wl != "k2" and wl != "pgmc" else 17) // 2
+        d["valu_insts_per_pair_step"] = counters["SQ_INSTS_VALU"] * 64.0 / m_pairs / 64.0 * 64.0 / 64.0 * 1.0
+        d["valu_insts_per_wave_iteration"] = counters["SQ_INSTS_VALU"] / (m_pairs / 64.0)
+        for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+            if k in counters:
+                d[k.lower().replace("sq_", "") + "_per_wave_iteration"] = counters[k] / (m_pairs / 64.0)
+        if "SQ_LDS_BANK_CONFLICT" in counters and counters.get("SQ_INSTS_LDS"):
+            d["lds_bank_conflict_cycles_per_lds_inst"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_INSTS_LDS"]
+    d.pop("valu_insts_per_pair_step", None)
+    if entry.get("avg_us_kernel_trace"):
+        d["achieved_GBps_algorithmic"] = ALGO_BYTES[wl] / entry["avg_us_kernel_trace"] / 1e3
+        d["frac_of_8TBps"] = d["achieved_GBps_algorithmic"] / 8000.0
+    entry["derived"] = d
+    log = os.path.join(G, wl + ".log")
+    if os.path.exists(log):
+        entry["workload_line"] = [ln.strip() for ln in open(log) if ln.startswith(("ladder", "k2", "pgmc", "est"))][-1:]
+    summary[wl] = entry
+commit = os.environ.get("AMC_COMMIT") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+summary["_meta"] = dict(commit=commit, kernel_source_hash=kernel_hash(),
+                        notes=["FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM): doubled",
+                               "PMC passes are separate runs (counters only, 120 launches, first quarter dropped); durations come from the --kernel-trace --stats run",
+                               "k2 / pgmc algorithmic bytes: 16 B (x read + write) + 1 B step-log byte per chain and step"])
+json.dump(summary, open(os.path.join(OUT, f"{TAG}_pmc_summary.json"), "w"), indent=1)
+head = summary.get("ladder_10000000", {}).get("derived", {})
+if "hbm_bytes_per_launch" in head:
+    json.dump({"sweep_kernel_bytes_per_launch": head["hbm_bytes_per_launch"], "sweep_kernel_valu_busy": head.get("valu_busy"),
+               "source": f"profiles/{TAG}_pmc_summary.json", "commit": commit, "kernel_source_hash": kernel_hash()},
+              open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
+for wl, e in summary.items():
+    if wl.startswith("_"):
+        continue
+    d = e["derived"]
+    print(f"{wl:18s} {e.get('avg_us_kernel_trace') or 0:8.2f} us  frac {d.get('frac_of_8TBps', 0):.3f}  traffic/algo {d.get('traffic_over_algorithmic', 0):.3f}  "
+          f"VALUBusy {d.get('valu_busy', 0):.3f}  VALU/wave-iter {d.get('valu_insts_per_wave_iteration', 0):.1f}  "
+          f"waitInst {d.get('wait_inst_any_over_wave_cycles', 0):.2f}  LDSconf/inst {d.get('lds_bank_conflict_cycles_per_lds_inst', 0):.1f}")
