@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Developer tool: regenerates profiles/r02_isa_summary.txt from montecarlo_amd/csrc/amc_api.gfx950.s (make -C montecarlo_amd/csrc asm):
-register and spill counts of the kernels the round-2 profiles name, and their per-block instruction mixes (tools/isa_blocks.py)."""
+"""Developer tool: regenerates profiles/<tag>_isa_summary.txt (tag = AMC_ROUND_TAG, default r03) from montecarlo_amd/csrc/amc_api.gfx950.s (make -C montecarlo_amd/csrc asm):
+register and spill counts of the kernels the profiles name, and their per-block instruction mixes (tools/isa_blocks.py)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = os.environ.get("AMC_ROUND_TAG", "r03")
 S = open(os.path.join(ROOT, "montecarlo_amd/csrc/amc_api.gfx950.s")).read()
 NAMED = ["sweep_kernel<0, false, false, false, true, false>", "sweep_kernel<1, true, true, false, true, false>",
-         "sweep_kernel<1, true, true, false, true, true>", "pg_estimate_kernel<0, 1, false, 2>", "pg_estimate_kernel<0, 1, false, 0>",
+         "sweep_kernel<1, true, true, false, true, true>", "pg_estimate_kernel<0, 1, false, 2, false>", "pg_estimate_kernel<0, 1, false, 2, true>",
+         "pg_estimate_kernel<0, 1, false, 0, false>",
          "fold_log_kernel<2, true>", "fold_log_kernel<2, false>", "reduce_kernel<0>"]
 
 
@@ -30,8 +32,8 @@ for want in NAMED:
             rows.append((d, meta(n)))
 sw = [meta(n)["sspill"] for n, d in dem.items() if "sweep_kernel<" in d]
 out = []
-out.append("ISA summary of the kernels the round-2 profiles name (hipcc ROCm 7.2, -O3 --offload-arch=gfx950 -ffp-contract=off; `make -C montecarlo_amd/csrc asm`")
-out.append("writes the full listing, which is not tracked; this file: tools/isa_summary.py).  Loop instruction mixes: tools/isa_blocks.py; counters: r02_pmc_summary.json.")
+out.append("ISA summary of the kernels the profiles name (hipcc ROCm 7.2, -O3 --offload-arch=gfx950 -ffp-contract=off; `make -C montecarlo_amd/csrc asm`")
+out.append("writes the full listing, which is not tracked; this file: tools/isa_summary.py).  Loop instruction mixes: tools/isa_blocks.py; counters: " + TAG + "_pmc_summary.json.")
 out.append("")
 out.append("%-70s %4s %4s %10s %12s %9s" % ("kernel", "vgpr", "sgpr", "sgpr_spill", "scratch_bytes", "lds_bytes"))
 for d, m in rows:
@@ -42,7 +44,7 @@ out.append(open(os.path.join(ROOT, "tools", "isa_summary_notes.txt")).read().rst
 out.append("")
 out.append("Instruction mix per basic block (>= 15 instructions; tools/isa_blocks.py): f64 = f64-class VALU, mad64 = v_mad_u64_u32 (Philox), v32 = other VALU,")
 out.append("lane = v_readlane / v_writelane (SGPR spill traffic), salu / lds / vmem.  The sampling loops are the blocks with mad64 / f64 counts.")
-for want in NAMED[:5]:
+for want in NAMED[:6]:
     out.append(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_blocks.py"), want], capture_output=True, text=True).stdout.rstrip())
-open(os.path.join(ROOT, "profiles", "r02_isa_summary.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(ROOT, "profiles", TAG + "_isa_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[:16]))

@@ -101,6 +101,126 @@ __global__ __launch_bounds__(256) void k_cvt_f64_u32(double* out, double a, doub
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// round 3: the select and compare forms the kernels really use, and the 32-bit / conversion opcodes of their loops that
+// the first table priced by class
+KERNEL_U32_3(k_and_b32, "v_and_b32 %0, %0, %1")
+KERNEL_U32_3(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+KERNEL_U32_3(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+KERNEL_U32_3(k_add3_u32, "v_add3_u32 %0, %0, %1, %2")
+KERNEL_U32_3(k_bfe_u32, "v_bfe_u32 %0, %0, 3, 12")
+KERNEL_U32_3(k_bfi_b32, "v_bfi_b32 %0, %1, %2, %0")
+KERNEL_U32_3(k_perm_b32, "v_perm_b32 %0, %0, %1, %2")
+KERNEL_U32_3(k_or3_b32, "v_or3_b32 %0, %0, %1, %2")
+KERNEL_U32_3(k_mul_f32, "v_mul_f32 %0, %0, %1")
+KERNEL_U32_3(k_max_f32, "v_max_f32 %0, %0, %1")
+KERNEL_F64_3(k_fmac_f64, "v_fmac_f64 %0, %1, %2")
+KERNEL_F64_3(k_min_f64, "v_min_f64 %0, %0, %1")
+
+// v_cndmask_b32 with the lane mask in an SGPR pair (the VOP3 form the compiler emits for selects on a ballot) ...
+__global__ __launch_bounds__(256) void k_cndmask_sgpr(double* out, double ad, double bd)
+{
+    unsigned a = (unsigned)ad, b = (unsigned)bd;
+    unsigned r[8];
+    unsigned long long m = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0);
+    for (int i = 0; i < 8; ++i) r[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "s"(m));
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// ... with vcc written once before the loop by a VALU compare (the VOP2 form) ...
+__global__ __launch_bounds__(256) void k_cndmask_vcc_set(double* out, double ad, double bd)
+{
+    unsigned a = (unsigned)ad, b = (unsigned)bd;
+    unsigned r[8];
+    for (int i = 0; i < 8; ++i) r[i] = a + i + threadIdx.x;
+    asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\ts_nop 4" ::"v"(r[1]), "v"(r[2]) : "vcc");
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(b));
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// ... and the pair the kernels' selects consist of: a compare into an SGPR pair followed by the select on it
+__global__ __launch_bounds__(256) void k_cmp_cndmask_pair(double* out, double ad, double bd)
+{
+    unsigned a = (unsigned)ad, b = (unsigned)bd;
+    unsigned r[8];
+    for (int i = 0; i < 8; ++i) r[i] = a + i + threadIdx.x;
+    for (int it = 0; it < ITER / 2; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long m;
+            asm volatile("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(r[i]), "v"(b));
+            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "s"(m));
+        }
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// compares into SGPR pairs
+__global__ __launch_bounds__(256) void k_cmp_f32_sgpr(double* out, double ad, double bd)
+{
+    float a = (float)ad + threadIdx.x, b = (float)bd;
+    unsigned long long acc = 0;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long m;
+            asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+            acc ^= m;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (double)acc;
+}
+__global__ __launch_bounds__(256) void k_cmp_f64_sgpr(double* out, double a, double b)
+{
+    a += threadIdx.x;
+    unsigned long long acc = 0;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long m;
+            asm volatile("v_cmp_lt_f64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+            acc ^= m;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (double)acc;
+}
+__global__ __launch_bounds__(256) void k_cvt_f32_f64(double* out, double a, double b)
+{
+    float r[8];
+    a += threadIdx.x;
+    for (int i = 0; i < 8; ++i) r[i] = 0;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[i]) : "v"(a));
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_readlane(double* out, double ad, double bd)
+{
+    unsigned a = (unsigned)ad + threadIdx.x;
+    unsigned acc = 0;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned sv;
+            asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sv) : "v"(a));
+            acc ^= sv;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 typedef void (*kfn)(double*, double, double);
 
 int main()
@@ -125,6 +245,12 @@ int main()
         {"v_cndmask_b32", k_cndmask_b32}, {"v_lshl_or_b32", k_lshl_or_b32}, {"v_alignbit_b32", k_alignbit_b32},
         {"v_mov_b32", k_mov_b32}, {"v_fma_f32", k_fma_f32}, {"v_exp_f32", k_exp_f32}, {"v_log_f32", k_log_f32},
         {"v_rcp_f32", k_rcp_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_sin_f32", k_sin_f32}, {"v_cvt_f32_u32", k_cvt_f32_u32},
+        {"v_cndmask_b32_sgpr", k_cndmask_sgpr}, {"v_cndmask_b32_vcc_set", k_cndmask_vcc_set}, {"v_cmp+v_cndmask_pair", k_cmp_cndmask_pair},
+        {"v_cmp_gt_f32_sgpr", k_cmp_f32_sgpr}, {"v_cmp_lt_f64_sgpr", k_cmp_f64_sgpr}, {"v_cvt_f32_f64", k_cvt_f32_f64},
+        {"v_readlane_b32", k_readlane}, {"v_and_b32", k_and_b32}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_lshlrev_b32", k_lshlrev_b32},
+        {"v_add3_u32", k_add3_u32}, {"v_bfe_u32", k_bfe_u32}, {"v_bfi_b32", k_bfi_b32}, {"v_perm_b32", k_perm_b32},
+        {"v_or3_b32", k_or3_b32}, {"v_mul_f32", k_mul_f32}, {"v_max_f32", k_max_f32}, {"v_fmac_f64", k_fmac_f64},
+        {"v_min_f64", k_min_f64},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
