@@ -28,7 +28,11 @@ for mode in ("comm", "host"):
     al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
           dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.3)),
                q_batch_size=2, device_resident=(None if mode == "comm" else False)),
-          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)))
+          dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+          # callbacks between the grouped time steps: their sums are all-reduced on the engine's communication stream
+          # (amc_allreduce_sum) while the estimator's all-reduces sit on its main stream -- one communicator, two streams
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
+               scheduler=ma.build_schedule(120, 10, 10)))
     with tempfile.TemporaryDirectory() as d:
         sim = ma.Simulation(chains, al, 120, path=d, verbose=False)
         est = sim.algorithms[1]
@@ -37,8 +41,12 @@ for mode in ("comm", "host"):
             assert est.connect_shards()
             est.device_resident = True
         ma.run(sim)
+    eng = sim.algorithms[0].engine
     out[mode] = dict(sigma=[m.sigma for m in pool], device_resident=est.device_resident,
-                     connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]))
+                     connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]),
+                     energy=[[t, float(v)] for t, v in sim.algorithms[3].rows[0]],
+                     acceptance=[[t, [float(a) for a in v]] for t, v in sim.algorithms[3].rows[1]],
+                     comm=(eng.comm_info() if hasattr(eng, "comm_info") else None), world=WORLD)
 if RANK == 0:
     print(json.dumps(out))
 if USE_STORE:

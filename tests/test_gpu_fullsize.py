@@ -433,3 +433,39 @@ def test_sharded_pgmc_device_resident_over_rccl(group):
     assert out["comm"]["sigma"][0] == out["host"]["sigma"][0] == 0.2
     assert out["comm"]["sigma"][1] == pytest.approx(out["host"]["sigma"][1], rel=1e-12) and out["comm"]["sigma"][1] > 0.5
     assert out["comm"]["x0"] == pytest.approx(out["host"]["x0"], abs=1e-9)
+    _check_comm_rows(out, 1)
+
+
+def _check_comm_rows(out, world):
+    """Callbacks interleaved with the grouped PGMC time steps: their all-reduce runs on the engine's communication stream,
+    the estimator's on its main stream, both on one communicator -- same rows as the host path, and the communicator
+    itself reports the ranks it spans."""
+    assert out["comm"]["comm"]["n_ranks"] == world and "librccl" in out["comm"]["comm"]["librccl"]
+    assert [t for t, _ in out["comm"]["energy"]] == [t for t, _ in out["host"]["energy"]] == [0] + list(range(10, 121, 10))
+    np.testing.assert_allclose([v for _, v in out["comm"]["energy"]], [v for _, v in out["host"]["energy"]], rtol=1e-9)
+    np.testing.assert_allclose(np.array([v for _, v in out["comm"]["acceptance"]]), np.array([v for _, v in out["host"]["acceptance"]]),
+                               rtol=1e-9, equal_nan=True)
+
+
+def test_two_gpus_callbacks_interleaved_with_pgmc_steps(gpu):
+    """The same worker on TWO ranks, one GPU each, under the driver's launcher: RCCL over xGMI carries the estimator's
+    in-place all-reduce (engine stream) and the callbacks' sums (communication stream) of one communicator.  Needs two
+    devices: skipped on the one-GPU boxes this repository's own runs get (the N > 1 path has never run on hardware
+    here); on a multi-GPU node it is the hardware check of that path."""
+    import json, socket, subprocess, sys
+    if gpu.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AMC_TEST_GROUP="store")
+    cmd = ["timeout", "-k", "10", "600", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(os.path.abspath(__file__)), "aux", "pgmc_comm_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["comm"]["world"] == 2 and out["comm"]["connected"] and out["comm"]["device_resident"]
+    assert out["comm"]["sigma"][0] == out["host"]["sigma"][0] == 0.2
+    assert out["comm"]["sigma"][1] == pytest.approx(out["host"]["sigma"][1], rel=1e-10) and out["comm"]["sigma"][1] > 0.5
+    _check_comm_rows(out, 2)

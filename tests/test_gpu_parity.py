@@ -615,7 +615,12 @@ def test_rccl_through_the_c_abi_single_rank(gpu, oracle):
     o.make_steps(3)
     uid = gpu.HipEngine.comm_unique_id()
     assert len(uid) == 128
+    assert e.comm_info() == {"n_ranks": 1, "rank": 0, "rccl_version": 0, "librccl": ""}      # no communicator yet
     e.comm_init(0, 1, uid)
+    info = e.comm_info()                         # what RCCL itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion)
+    assert info["n_ranks"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000 and "librccl" in info["librccl"]
+    with pytest.raises(gpu.AmcError, match="already has a communicator"):
+        e.comm_init(0, 1, uid)
     a = np.array([1.5, -2.0, 3.25, 1e300])
     assert np.array_equal(e.allreduce_sum(a), a)
     e.pg_accumulate([1], 2)
@@ -623,6 +628,17 @@ def test_rccl_through_the_c_abi_single_rank(gpu, oracle):
     want = o.pg_estimate([1], 2)
     np.testing.assert_allclose(acc, want, rtol=1e-10)
     assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
+    # one communicator, two streams: host-side sums (communication stream) between estimator all-reduces (engine stream)
+    for i in range(20):
+        e.pgmc_steps(3, [1], 1, [1], [0.01], [0.0])
+        assert np.array_equal(e.allreduce_sum(a + i), a + i)
+    # back to a single shard, and connected again
+    e.comm_destroy()
+    assert e.comm_info()["librccl"] == "" and np.array_equal(e.allreduce_sum(a), a)
+    e.comm_init(0, 1, gpu.HipEngine.comm_unique_id())
+    assert e.comm_info()["n_ranks"] == 1 and np.array_equal(e.allreduce_sum(a), a)
+    rt = gpu.runtime_info()
+    assert rt["hip_runtime_version"] > 60000000 and "libamdhip64" in rt["hip_runtime"]
     e.close()
 
 

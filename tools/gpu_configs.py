@@ -9,6 +9,7 @@ import montecarlo_amd as ma
 
 M = int(os.environ.get("M", 10_000_000)); steps = int(os.environ.get("STEPS", 1000))
 which = sys.argv[1] if len(sys.argv) > 1 else "3"
+DEFER = os.environ.get("DEFER", "1") == "1"     # StoreCallbacks writes a row when the next one is due (default) / at once
 
 
 def timed(chains, al, label, pool):
@@ -30,8 +31,8 @@ if which == "3":
             ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 1.0}, 0.5))
     al = (dict(algorithm=ma.Metropolis, pool=pool, seed=1, download_on_finalise=False),
           dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
-               scheduler=ma.build_schedule(steps, 100, 10)))
-    timed(chains, al, "config 3 (double well, K=2, callbacks every 10)", pool)
+               scheduler=ma.build_schedule(steps, 100, 10), defer=DEFER))
+    timed(chains, al, f"config 3 (double well, K=2, callbacks every 10, rows {'deferred' if DEFER else 'at once'})", pool)
 else:
     # config 5: PGMC_harmonic_oscillator.jl:14-33 at M = 1e7: estimator + update every step, callbacks every 10
     chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
@@ -41,5 +42,5 @@ else:
           dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.5)), q_batch_size=1),
           dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
           dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
-               scheduler=ma.build_schedule(steps, 100, 10)))
-    timed(chains, al, "config 5 (PGMC, K=2, estimator+update every step, callbacks every 10)", pool)
+               scheduler=ma.build_schedule(steps, 100, 10), defer=DEFER))
+    timed(chains, al, f"config 5 (PGMC, K=2, estimator+update every step, callbacks every 10, rows {'deferred' if DEFER else 'at once'})", pool)

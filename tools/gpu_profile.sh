@@ -7,6 +7,8 @@ TAG=${AMC_ROUND_TAG:-r03}
 export AMC_ROUND_TAG=$TAG
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
+# the GPU box has no .git: the caller leaves the commit in .profile_commit (git rev-parse --short HEAD > .profile_commit)
+[ -f $R/.profile_commit ] && export AMC_COMMIT=$(cat $R/.profile_commit)
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 echo "bench done"
