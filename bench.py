@@ -11,8 +11,9 @@ particle_1d harmonic, beta = 2, one Gaussian displacement sigma = 0.1, M = 1e7 c
 synthetic ensemble x0 ~ U(-2, 2) generated on device (inputs resident in HBM before the timed region).
 For N > 1 (configs[3]) the ensemble is N x 1e7 chains sharded by global chain id (weak scaling) and
 the energy/acceptance callbacks are all-reduced over RCCL every 10 sweeps inside the timed region -- by the engines' own
-communicator (amc_comm_init / amc_allreduce_sum on the engine's stream); the launcher's TCP store carries the
-ncclUniqueId, the barriers and the max over ranks.  No torch process group, no torch tensors.
+communicator (amc_comm_init / amc_allreduce_sum, on a communication stream of the engine's own); the launcher's TCP store
+carries the ncclUniqueId, the barriers and the max over ranks.  No torch process group, no torch tensors.  config.rccl_ranks is
+what ncclCommCount reports for that communicator; the RCCL / HIP runtime versions and files really bound are in the line too.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      algorithmic HBM bytes (16 B/update: read x + write x) / average launch duration measured
@@ -286,7 +287,7 @@ def main():
             eng.sweep(1)
 
     def barrier():
-        eng.sync()                           # everything this rank has queued is done (all work is on the engine's stream)
+        eng.sync()                           # everything this rank has queued is done (sweeps: engine's stream; the callback sums' all-reduce is host-synchronous)
         if grp is not None:
             grp.barrier()
 

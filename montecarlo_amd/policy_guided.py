@@ -202,7 +202,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
 
     def connect_shards(self) -> bool:
         """Sharded runs: give the engines an RCCL communicator of their own (amc_comm_init), so that the estimator's
-        fold is ONE in-place all-reduce of 4 n_learn doubles on each engine's stream and gradients_data / the learning
+        fold is ONE in-place all-reduce of 4 n_learn doubles on each engine's main stream and gradients_data / the learning
         step stay on the devices -- no host round trip per step.  The 128-byte ncclUniqueId travels over the process
         group the script already has.  libamc.so resolves RCCL with dlopen by soname, i.e. it shares the instance
         torch.distributed has loaded.  False (host path via pg_estimate + torch all-reduce) when there is no NCCL

@@ -290,3 +290,90 @@ def test_grouped_pgmc_issues_few_engine_calls(oracle, tmp_path):
     # callbacks at 20, 45, 70, 95, 100 cut the run into groups that END WITH the observed step: StoreCallbacks comes after
     # the three in the list, so it runs behind the group and sees the state it leaves
     assert calls == [20, 25, 25, 25, 5]
+
+
+def test_deferred_callback_rows_are_the_same_rows_written_one_period_later(oracle, tmp_path):
+    """StoreCallbacks(defer=True, the default for the engine-backed callbacks): the row of time t is written when the next
+    scheduled time comes (or at finalise); the reduction is claimed at t (a ticket) and fetched later.  Files and rows are
+    those of defer=False; during the run the rows lag one entry; only one reduction is ever in flight on the engine."""
+    in_flight = []
+
+    class Watching(oracle.OracleEngine):
+        def sweep_reduce_begin(self, n=1):
+            assert getattr(self, "_pending", None) is None, "a reduction was begun while another was in flight"
+            super().sweep_reduce_begin(n)
+            in_flight.append("begin")
+
+        def reduce_begin(self):
+            assert getattr(self, "_pending", None) is None, "a reduction was begun while another was in flight"
+            super().reduce_begin()
+            in_flight.append("begin")
+
+        def reduce_end(self):
+            in_flight.append("end")
+            return super().reduce_end()
+
+    out = []
+    for i, defer in enumerate((False, True)):
+        chains = ma.ParticleChains.uniform(8, 2.0)
+        pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.7), ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.6], 0.3))
+        al = (dict(algorithm=ma.Metropolis, pool=pool, seed=9, engine_factory=Watching),
+              dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance, ma.callback_moments),
+                   scheduler=ma.build_schedule(90, 10, 10), defer=defer, store_last=True))
+        sim = ma.Simulation(chains, al, 90, path=str(tmp_path / str(i)))
+        cb = sim.algorithms[1]
+        assert cb.defer is defer
+        seen = []
+        orig = cb.make_step
+
+        def spy(simulation, orig=orig, cb=cb, seen=seen):
+            orig(simulation)
+            seen.append((simulation.t, len(cb.rows[0])))
+        cb.make_step = spy
+        del in_flight[:]
+        ma.run(sim)
+        files = [open(tmp_path / str(i) / f).read() for f in ("energy.dat", "acceptance.dat", "moments.dat")]
+        out.append((files, [list(r) for r in cb.rows], seen, list(in_flight)))
+    assert out[0][0] == out[1][0]                                     # byte-identical files
+    assert [len(r) for r in out[1][1]] == [11, 11, 11]                # t = 0, 10 .. 90, store_last at 90
+    # rows written by the time make_step(t) returns: at once = all up to t; deferred = one behind
+    assert [n for _, n in out[0][2]] == list(range(1, 12)) and [n for _, n in out[1][2]] == list(range(0, 11))
+    # deferred: every begun reduction was fetched before the next one began, and nothing was thrown away unread
+    assert out[1][3].count("begin") == out[1][3].count("end") == 10   # t = 0, then the nine scheduled times (store_last re-reads t = 90's)
+    assert all(a != b for a, b in zip(out[1][3], out[1][3][1:]))      # begin, end, begin, end, ...
+    # a callback without a deferred form keeps the whole list at-once
+    sim = ma.Simulation(ma.ParticleChains.uniform(4, 2.0), (dict(algorithm=ma.Metropolis, pool=pool, engine_factory=oracle.OracleEngine),
+                        dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, lambda s: 1.0), scheduler=[5])), 5,
+                        path=str(tmp_path / "mixed"))
+    assert sim.algorithms[1].defer is False
+
+
+def test_grouped_pgmc_steps_carry_the_callback_sums_of_their_last_step(oracle, tmp_path):
+    """A callback scheduled at the last step of a [Metropolis, estimator, update] group observes the state the group leaves:
+    run() asks the engine for the sums with the group (pgmc_steps(..., reduce_begin=True) = amc_pgmc_steps_reduce_begin), no
+    separate reduction pass; rows equal the stepwise run's."""
+    calls = []
+
+    class Counting(oracle.OracleEngine):
+        def pgmc_steps(self, n, *a, reduce_begin=False, **k):
+            calls.append((n, reduce_begin))
+            super().pgmc_steps(n, *a, reduce_begin=reduce_begin, **k)
+
+        def reduce(self):
+            calls.append("reduce")
+            return super().reduce()
+
+        def reduce_begin(self):
+            calls.append("reduce_begin")
+            super().reduce_begin()
+
+    sim, pool = _pgmc_sim(oracle, tmp_path / "g", 100, factory=Counting)
+    ma.run(sim)
+    grouped = [c for c in calls if isinstance(c, tuple)]
+    assert grouped == [(20, True), (25, True), (25, True), (25, True), (5, True)]
+    # the only reductions outside the groups: t = 0 (store_first) -- OracleEngine.pgmc_steps itself calls reduce_begin -> reduce
+    assert calls.count("reduce_begin") == 5 + 1
+    ref, _ = _pgmc_sim(oracle, tmp_path / "s", 100)
+    ma.run(ref, fuse=False)
+    assert open(tmp_path / "g" / "energy.dat").read() == open(tmp_path / "s" / "energy.dat").read()
+    assert open(tmp_path / "g" / "acceptance.dat").read() == open(tmp_path / "s" / "acceptance.dat").read()
