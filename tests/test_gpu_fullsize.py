@@ -349,11 +349,21 @@ def test_config5_pgmc_at_1e7_chains_through_pgmc_steps(gpu, oracle):
         o.close()
     full.close()
     del acc, tot
-    e.pgmc_steps(400, [1], 1, [1], [eta], [0.0])
+    # the last ten of the 400 with the callback sums formed in the tenth launch (amc_pgmc_steps_reduce_begin) and ten more
+    # queued behind them before the sums are read -- the pipelined form of config 5's callbacks every 10
+    e.pgmc_steps(390, [1], 1, [1], [eta], [0.0])
+    e.pgmc_steps(10, [1], 1, [1], [eta], [0.0], reduce_begin=True)
+    x_then = e.download_strided(0, 997, 10_000)
+    e.pgmc_steps(10, [1], 1, [1], [eta], [0.0])
+    red = e.reduce_end()
     assert e.get_parameters(0)[0] == 0.2
     assert float(e.get_parameters(1)[0]) == pytest.approx(KATS["pgmc"]["sigma_star"], abs=KATS["pgmc"]["sigma_atol"])
+    assert red[3] == M_FULL and red[0] / M_FULL == pytest.approx(0.25, abs=2e-3)
+    assert np.mean(x_then ** 2) == pytest.approx(red[0] / M_FULL, abs=2e-2)            # the sums are those of the state at t = 416
+    acc_tot = e.counter_totals()
+    # callback_acceptance: mean of per-chain ratios (from the fold of the step log) vs the ratio of the pool totals
+    assert red[4:] / M_FULL == pytest.approx(acc_tot[0] / acc_tot[1], abs=1e-2)
     red = e.reduce()
-    assert red[0] / M_FULL == pytest.approx(0.25, abs=2e-3)
     assert np.all(e.pg_get_accumulated([1])[:, 4] == 0)     # every step ended in an update: accumulators are empty
     e.close()
 
