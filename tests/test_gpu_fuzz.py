@@ -5,8 +5,8 @@ pool size 1..8 with arbitrary (normalised) weights -- cumulative weights that ar
 pick table --, sigma over four decades, beta over two, both potentials, ragged ensemble sizes, shards that start at an
 arbitrary EVEN global chain id far from 0, sweepstep 1..4, Float64 and Float32 state, K = 1 with and without per-chain
 counters; then a random walk over {single-step launch, multi-step launch, callback reduction, sweep with the reduction
-formed in the launch, estimator call, [Metropolis, estimator, update] steps in one engine call, parameter update, counter
-download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
+formed in the launch (read at once or with sweeps queued behind it), estimator call, [Metropolis, estimator, update] steps in
+one engine call with and without the callback sums of their last step, parameter update, counter download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
 reductions within RED_RTOL.  AMC_FUZZ_CASES (default 40, ~15 s) and AMC_FUZZ_SEED widen or move the sample.
 """
 import os
@@ -105,7 +105,7 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
     check_state(e, o, case, "start")
     K = len(case["sigma"])
     for op_index in range(int(rng.integers(min(6, max_ops - 1), max_ops))):
-        op = rng.choice(["single", "single", "multi", "reduce", "sweep_reduce", "estimate", "pgmc", "sigma", "counters"])
+        op = rng.choice(["single", "single", "multi", "reduce", "sweep_reduce", "estimate", "pgmc", "pgmc_reduce", "sigma", "counters"])
         where = f"case {index}, operation {op_index} ({op})"
         if op == "single":
             for _ in range(int(rng.integers(1, 6))):
@@ -119,7 +119,12 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
             if op == "sweep_reduce":                   # make_step! and the callbacks that follow it at the same t: one launch
                 e.sweep_reduce_begin(1)
                 o.sweep_reduce_begin(1)
+                behind = int(rng.integers(0, 3))       # sweeps queued behind the callback before its sums are read
+                if behind:
+                    e.sweep(behind)
                 r, ro = e.reduce_end(), o.reduce_end()
+                if behind:
+                    o.sweep(behind)
             else:
                 r, ro = e.reduce(), o.reduce()
             scale = np.maximum(np.abs(ro), 1.0)
@@ -127,6 +132,19 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
                 f"{where}: reduction differs\n{r}\n{ro}\n{case}"
             if op == "reduce":
                 continue
+        elif op == "pgmc_reduce":
+            # the same time steps with a callback at the last one: the sums of the state the group leaves ride in its last launch
+            # (amc_pgmc_steps_reduce_begin; K <= 4 and <= 2 learnable moves, the plain passes otherwise)
+            learn = sorted(int(v) for v in rng.choice(K, size=int(rng.integers(1, min(K, 3) + 1)), replace=False))
+            n, q = int(rng.integers(1, 5)), int(rng.choice([1, 2]))
+            vpg = [oracle.OPTIMISERS["VPG"]] * len(learn)
+            e.pgmc_steps(n, learn, q, vpg, [0.0] * len(learn), [0.0] * len(learn), reduce_begin=True)
+            o.pgmc_steps(n, learn, q, vpg, [0.0] * len(learn), [0.0] * len(learn), reduce_begin=True)
+            r, ro = e.reduce_end(), o.reduce_end()
+            scale = np.maximum(np.abs(ro), 1.0)
+            assert np.all((np.abs(r - ro) <= RED_RTOL * scale * np.sqrt(case["n_chains"])) | (np.isnan(r) & np.isnan(ro))), \
+                f"{where}: reduction of the grouped time steps differs\n{r}\n{ro}\n{case}"
+            assert np.all(e.pg_get_accumulated(learn) == 0.0) and e.estimator_step == o.estimator_step
         elif op == "pgmc":
             # [Metropolis, estimator, update] per time step in ONE engine call (fused launches where the engine has them); the
             # learning rate is 0, so sigma stays what it is and the chains can still be compared bit for bit afterwards
