@@ -934,7 +934,7 @@ def test_split_engine_snapshots_and_pool_totals(gpu):
 
 
 # ---- round 3: callback sums inside the fused PGMC launch, K - 1 total arrays, 32-bit counter guard -------------------
-@pytest.mark.parametrize("case", ["k2", "k1", "k1_pooled", "k2_beta", "k5_wide", "custom"])
+@pytest.mark.parametrize("case", ["k2", "k1", "k1_pooled", "k2_beta", "k5_wide", "custom", "f32", "scaled", "script"])
 def test_pgmc_steps_reduce_begin_equals_steps_then_reduce(gpu, case):
     """amc_pgmc_steps_reduce_begin(n) == amc_pgmc_steps(n); amc_reduce_begin: the callback observes the state AFTER the
     estimator's samples (run! order, src/simulation.jl:185-190).  Fused forms (<= 2 learnable moves) form the sums over
@@ -957,8 +957,19 @@ def test_pgmc_steps_reduce_begin_equals_steps_then_reduce(gpu, case):
         ids, kinds, h0, h1 = [0, 2, 4], [1, 1, 6], [0.1, 0.1, 1e-6], [0.0, 0.0, 1e-6]
     elif case == "custom":
         kw.update(potential=CustomPotential("x*x*x*x - 2.0*x*x + 0.25*x"))
+    elif case == "f32":                       # Particle{Float32}: the same sources compiled at run time for the other state type
+        kw.update(dtype="f32")
+    elif case == "scaled":                    # state-dependent width sigma * scale(x): every decision in the reference's arithmetic
+        kw.update(scale_expr="0.5 + x*x")
+    elif case == "script":                    # a script-defined proposal (Langevin step) with its sigma-derivative
+        kw.update(proposal=("-2.0*sigma*sigma*x + sigma*z",
+                            "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)",
+                            "((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(sigma*sigma*sigma) "
+                            "- 4.0*x*(delta + 2.0*sigma*sigma*x)/sigma - 1.0/sigma"))
     a, b = gpu.HipEngine(**kw), gpu.HipEngine(**kw)
     x0 = np.random.default_rng(6).uniform(-2, 2, M)
+    if case == "f32":
+        x0 = x0.astype(np.float32).astype(np.float64)
     for e in (a, b):
         e.upload_state(x0, beta)
         e.sweep(3)
