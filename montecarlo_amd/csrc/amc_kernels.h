@@ -520,7 +520,12 @@ __device__ __forceinline__ int categorical_walk(const double* s_tab, int K, doub
 // (every line of every move's array is touched); the log costs 1.
 __device__ __forceinline__ void store_log_pair(const SweepArgs& a, int row, int64_t p, uint32_t word)
 {
-    *reinterpret_cast<uint16_t*>(a.log + (int64_t)row * a.m_stride + 2 * p) = (uint16_t)word;
+    // write-through (sc1) like the positions: 10 MB of plain 2-byte stores per sweep stay dirty in the XCDs' L2s until the
+    // kernel boundary writes them back (K = 2 sweep 35.8 -> 35.2 us per launch incl. amortised folds, same-box A/B, round 3).
+    // The address lives on the scalar unit: p - threadIdx.x is block-uniform.
+    uint8_t* base = a.log + (int64_t)row * a.m_stride + 2 * (p - (int64_t)threadIdx.x);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)word, r, threadIdx.x * 2, 0, 16);
 }
 
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
