@@ -332,6 +332,40 @@ function pgmc_steps!(metropolis::HIPMetropolis, n::Integer, learn_ids::Vector{In
     return nothing
 end
 
+# The same n time steps when callbacks are scheduled at the LAST of them (simulation.t = t): the fused launch of that step
+# also forms the callback sums of the state it leaves (amc_pgmc_steps_reduce_begin) and callback_energy / callback_acceptance at
+# t then read them without another pass over the chains (run! calls the callbacks after the three algorithms,
+# src/simulation.jl:185-190).
+function pgmc_steps_observed!(metropolis::HIPMetropolis, n::Integer, learn_ids::Vector{Int}, q_batch::Integer,
+                              optimiser::Vector{Cint}, hyper0::Vector{Float64}, hyper1::Vector{Float64}, t::Int)
+    ids = Cint[k - 1 for k in learn_ids]
+    check(ccall((:amc_pgmc_steps_reduce_begin, libamc), Cint,
+                (Ptr{Cvoid}, Int64, Cint, Ptr{Cint}, Cint, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
+                metropolis.handle, n, length(ids), ids, q_batch, 1, optimiser, hyper0, hyper1))
+    out = Vector{Float64}(undef, 4 + metropolis.K)
+    check(ccall((:amc_reduce_end, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), metropolis.handle, out))
+    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), metropolis.handle, out, length(out)))
+    metropolis.red_t = t; metropolis.red = out
+    return nothing
+end
+
+# What the shards' communicator reports about itself (ncclCommCount, ncclCommUserRank, RCCL version, library file); the
+# HIP runtime libamc.so is bound to.  For result files that say what they really ran on.
+function comm_info(alg::HIPMetropolis)
+    n = Ref{Cint}(0); r = Ref{Cint}(0); v = Ref{Cint}(0)
+    path = zeros(UInt8, 1024)
+    check(ccall((:amc_comm_info, libamc), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ptr{UInt8}, Cint),
+                alg.handle, n, r, v, path, length(path)))
+    return (n_ranks=Int(n[]), rank=Int(r[]), rccl_version=Int(v[]), librccl=unsafe_string(pointer(path)))
+end
+
+function runtime_info()
+    v = Ref{Cint}(0)
+    path = zeros(UInt8, 1024)
+    check(ccall((:amc_runtime_info, libamc), Cint, (Ref{Cint}, Ptr{UInt8}, Cint), v, path, length(path)))
+    return (hip_runtime_version=Int(v[]), hip_runtime=unsafe_string(pointer(path)))
+end
+
 # sigma_k of the device copy back into the shared Move.parameters objects (after pgmc_steps!)
 function pull_parameters!(metropolis::HIPMetropolis)
     p = Vector{Float64}(undef, 1)
