@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 and carry their source, commit and whether the kernel sources changed since.
   repeat        the K-step block repeated (untimed by `value`): min / median ms per step.
   fused_sweepstep16  the same ensemble with 16 MH steps per launch (reported separately, no roofline fraction).
+  other_configs BASELINE configs 3 (double well, K = 2) and 5 (PGMC) end to end, us per time step with callbacks every 10.
   cpu_baseline  the CPU oracle (C restatement of the reference path, kind "port": the reference is Julia,
                 not runnable here) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -178,6 +179,55 @@ def ladder(A, sizes, device, reps=5):
     return rows
 
 
+def other_configs(A, m, device, periods=40):
+    """BASELINE configs 3 and 5 end to end at this ensemble size, next to the headline (never part of `value`): one launch per
+    time step, callbacks (energy + acceptance) every 10 time steps, each callback's sums read one period late -- the form
+    the host mirror's StoreCallbacks uses.  HIP events over `periods` callback periods, after as many untimed."""
+    out = {}
+
+    def run(e, period):
+        e.init_uniform(-2.0, 2.0)
+        for timed in (False, True):
+            pending = False
+            if timed:
+                e.timing_begin()
+            for _ in range(periods):
+                if pending:
+                    e.reduce_end()
+                period(e)
+                pending = True
+            if pending:
+                e.reduce_end()
+            if timed:
+                return e.timing_end() * 1e3 / (10 * periods)
+            e.sync()
+
+    def k2_period(e):
+        for _ in range(9):
+            e.sweep(1)                                                 # one launch per sweep, like the headline
+        e.sweep_reduce_begin(1)                                        # the tenth forms the callback sums
+
+    def pgmc_period(e):
+        e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0], reduce_begin=True)   # VPG on move 2; the tenth launch forms the sums
+
+    try:
+        e = A.HipEngine(n_chains=m, potential="double_well", beta=BETA, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=SEED, device=device)
+        out["config3_double_well_K2"] = {"us_per_time_step": run(e, k2_period), "algorithmic_bytes_per_update": 17,
+                                         "workload": "U = (x^2-1)^2, sigma = (0.1, 1.0), w = (0.5, 0.5), per-chain counters (step log)"}
+        e.close()
+        e = A.HipEngine(n_chains=m, potential="harmonic", beta=BETA, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42, device=device)
+        us = run(e, pgmc_period)
+        out["config5_pgmc"] = {"us_per_time_step": us, "algorithmic_bytes_per_update": 17, "sigma_2_after": float(e.get_parameters(1)[0]),
+                               "workload": "PGMC_harmonic_oscillator.jl pool sigma = (0.2, 0.1), w = (0.6, 0.4), optimisers (Static, VPG(0.02)), "
+                                           "q_batch_size = 1; sweep + estimator + learning step in ONE launch per time step"}
+        e.close()
+    except A.AmcError as err:
+        out["error"] = str(err)[:200]
+    out["note"] = ("callbacks (callback_energy + callback_acceptance) every 10 time steps, each read one period late; chains x time steps "
+                   "/ time = chain-updates/s of these configurations; not part of `value`")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +240,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step block for min / median (not part of value)")
     ap.add_argument("--no-ladder", action="store_true", help="skip the 4e7 / 1.6e8-chain launches behind roofline.ladder")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 / config-5 end-to-end figures")
     args = ap.parse_args()
 
     # ONE JSON line on stdout: RCCL / the HIP runtime may print banners to fd 1 (e.g. RCCL's version block at
@@ -358,6 +409,9 @@ def main():
     ladder_rows = None
     if rank == 0 and world == 1 and not args.no_ladder and args.chains_per_gpu == M_PER_GPU:
         ladder_rows = ladder(A, (4 * M_PER_GPU, 16 * M_PER_GPU), local_rank)
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        others = other_configs(A, stop - start, local_rank)
     if rank == 0:
         prof = pmc_profile()
         updates = m_global * args.steps
@@ -410,6 +464,7 @@ def main():
                 "ms_per_step_median": sorted(rep_ms)[len(rep_ms) // 2], "ms_per_step_all": rep_ms},
             "check": {"mean_energy": energy, "acceptance": acceptance},
             "fused_sweepstep16": fused,
+            "other_configs": others,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()

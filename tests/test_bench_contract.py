@@ -62,6 +62,10 @@ def test_single_process_line():
     # no communicator in a single process; the HIP runtime libamc.so is bound to is named with its file
     assert c["rccl_ranks"] is None and c["librccl"] is None
     assert c["hip_runtime_version"] > 60000000 and "libamdhip64" in c["hip_runtime"]
+    # BASELINE configs 3 and 5 end to end next to the headline, never instead of it
+    oc = d["other_configs"]
+    assert "error" not in oc and 0 < oc["config3_double_well_K2"]["us_per_time_step"] < oc["config5_pgmc"]["us_per_time_step"]
+    assert 0.1 < oc["config5_pgmc"]["sigma_2_after"] < 2.0 and oc["config5_pgmc"]["sigma_2_after"] != 0.1      # it learned
 
 
 def test_distributed_path_on_one_rank():
