@@ -479,3 +479,53 @@ def test_two_gpus_callbacks_interleaved_with_pgmc_steps(gpu):
     assert out["comm"]["sigma"][0] == out["host"]["sigma"][0] == 0.2
     assert out["comm"]["sigma"][1] == pytest.approx(out["host"]["sigma"][1], rel=1e-10) and out["comm"]["sigma"][1] > 0.5
     _check_comm_rows(out, 2)
+
+
+@pytest.mark.parametrize("case", ["harmonic_K1", "double_well_K2", "harmonic_f32"])
+def test_stationary_density_goodness_of_fit_at_full_size(gpu, case):
+    """The statistic behind test/distribution_test.jl:33-37 (pooled positions against the target), as sharp as 1e7
+    INDEPENDENT chains allow: after burn-in the positions at one time are 1e7 independent draws from the target, so a
+    200-bin histogram (amc_histogram, device side) must fit exp(-beta U) with chi^2 / dof = 1 +- a few sqrt(2 / dof).
+    The reference's own tolerance (1e-3 on mean and std of ~1e7 correlated samples) sees a bias of 1e-3; this sees a relative
+    density error of ~3e-3 in ANY bin, i.e. anything the 12-bit accept brackets, the 28-bit Box-Muller angle, the float
+    accept filter or the table-driven exp / log could have bent.  Harmonic K = 1 (configs 2 / 4), double well K = 2
+    (config 3), and the Float32 state type."""
+    from scipy import integrate, stats
+    beta, n_bins = 2.0, 200
+    if case == "double_well_K2":
+        kw = dict(potential="double_well", sigma=[0.1, 1.0], weight=[0.5, 0.5])
+        lo, hi, burn = -2.0, 2.0, 3000
+        logp = lambda x: -beta * (x * x - 1.0) ** 2
+    else:
+        kw = dict(potential="harmonic", sigma=[0.1], weight=[1.0], per_chain_counters=False)
+        lo, hi, burn = -2.0, 2.0, 6000                      # integrated autocorrelation ~80 sweeps at sigma = 0.1: 75 of them
+        logp = lambda x: -beta * x * x
+        if case == "harmonic_f32":
+            kw.update(dtype="f32")
+    e = gpu.HipEngine(n_chains=M_FULL, beta=beta, seed=20260304, **kw)
+    e.init_uniform(-2, 2)
+    e.sweep(burn)
+    counts = e.histogram(lo, hi, n_bins).astype(np.float64)
+    assert counts[n_bins + 2] == 0 and counts.sum() == M_FULL          # no NaN; every chain counted once
+    edges = np.linspace(lo, hi, n_bins + 1)
+    z = integrate.quad(lambda x: np.exp(logp(x)), -8, 8, epsabs=1e-14, epsrel=1e-13)[0]
+    if case == "double_well_K2":
+        p_in = np.array([integrate.quad(lambda x: np.exp(logp(x)), a, b, epsabs=1e-15, epsrel=1e-12)[0] for a, b in zip(edges[:-1], edges[1:])]) / z
+        p_lo = integrate.quad(lambda x: np.exp(logp(x)), -8, lo, epsabs=1e-16)[0] / z
+    else:
+        cdf = stats.norm(0.0, 1.0 / np.sqrt(2 * beta)).cdf
+        p_in = np.diff(cdf(edges))
+        p_lo = cdf(lo)
+    p = np.concatenate([p_in, [p_lo, p_lo]])                           # symmetric targets: the two tails are equal
+    expect = p * M_FULL
+    obs = counts[:n_bins + 2]
+    # Float32 positions sit on a grid; bin edges at multiples of 0.02 are not grid points in general, fine at this bin width
+    keep = expect >= 20
+    chi2 = float(np.sum((obs[keep] - expect[keep]) ** 2 / expect[keep]))
+    dof = int(keep.sum()) - 1
+    assert dof >= 150
+    assert abs(chi2 - dof) < 5.0 * np.sqrt(2.0 * dof), (case, chi2, dof)    # 5 sigma of the chi^2 distribution
+    # the same numbers as a mean / variance statement, tighter than the reference's 1e-3
+    r = e.reduce()
+    assert r[1] / M_FULL == pytest.approx(0.0, abs=6e-4)
+    e.close()
