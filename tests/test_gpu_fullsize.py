@@ -529,3 +529,43 @@ def test_stationary_density_goodness_of_fit_at_full_size(gpu, case):
     r = e.reduce()
     assert r[1] / M_FULL == pytest.approx(0.0, abs=6e-4)
     e.close()
+
+
+@pytest.mark.parametrize("sigma", [0.6, 1.2, 2.0])
+def test_policy_gradient_sums_against_quadrature_at_full_size(gpu, sigma):
+    """What test/pgmc_test.jl pins loosely (sigma -> 1.2 +- 0.2), taken apart and pinned to four digits: with the chains at
+    stationarity (x ~ N(0, 1/(2 beta))) the estimator's sums over 1e7 chains are Monte-Carlo estimates of closed-form
+    integrals (gradients.jl:93-109 with the model's reward delta^2, particle_1d.jl:42-44):
+        j / n            -> J(sigma) = E[delta^2 min(1, exp(dlogp))]           (the objective the optimisers climb)
+        grad_j / n       -> dJ/dsigma                                          (score-function identity)
+        grad_logq / n    -> 0,    g / n -> 2 / sigma^2                         (Fisher information of the Gaussian scale)
+    J and dJ/dsigma by a 2-D quadrature on the host; tolerances are 6 standard errors of 1e7 samples."""
+    beta = 2.0
+    e = gpu.HipEngine(n_chains=M_FULL, potential="harmonic", beta=beta, sigma=[sigma], weight=[1.0], seed=77, per_chain_counters=False)
+    e.init_uniform(-2, 2)
+    e.sweep(400)                                              # steps of this size decorrelate in a few sweeps
+    g = e.pg_estimate([0], 1)[0]
+    n = g[4]
+    assert n == M_FULL
+
+    def J(s):
+        x = np.linspace(-3.5, 3.5, 2801)[:, None]             # 7 sigma_x; exact to ~1e-9 on this grid but for the kink of min()
+        d = np.linspace(-8.0 * s, 8.0 * s, 6401)[None, :]
+        px = np.exp(-beta * x * x)
+        px = px / np.trapezoid(px[:, 0], x[:, 0])
+        qd = np.exp(-d * d / (2 * s * s)) / np.sqrt(2 * np.pi * s * s)
+        alpha = np.minimum(1.0, np.exp(-beta * ((x + d) ** 2 - x * x)))
+        inner = np.trapezoid(qd * d * d * alpha, d[0], axis=1)
+        return float(np.trapezoid(px[:, 0] * inner, x[:, 0]))
+
+    j_true = J(sigma)
+    dj_true = (J(sigma + 1e-3) - J(sigma - 1e-3)) / 2e-3
+    se_j = 1.5 * sigma ** 2 / np.sqrt(n)                       # sd(delta^2 alpha) < sd(delta^2) = sqrt(2) sigma^2
+    se_dj = 4.0 * sigma / np.sqrt(n)                           # sd(j grad_logq) ~ a few sigma
+    assert g[0] / n == pytest.approx(j_true, abs=6 * se_j + 2e-5)
+    assert g[1] / n == pytest.approx(dj_true, abs=6 * se_dj + 1e-4)
+    assert g[2] / n == pytest.approx(0.0, abs=6 * np.sqrt(2.0) / sigma / np.sqrt(n))
+    assert g[3] / n == pytest.approx(2.0 / sigma ** 2, rel=6 * np.sqrt(28.0) / 2.0 / np.sqrt(n))    # var of (z^2 - 1)^2 = 60 - 4 -> sd/mean = sqrt(56)/2
+    if sigma == 1.2:
+        assert abs(dj_true) < 5e-3 and j_true == pytest.approx(0.18597, abs=2e-4)      # the optimum the reference's test looks for (SURVEY section 4)
+    e.close()
