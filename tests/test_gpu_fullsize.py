@@ -568,4 +568,20 @@ def test_policy_gradient_sums_against_quadrature_at_full_size(gpu, sigma):
     assert g[3] / n == pytest.approx(2.0 / sigma ** 2, rel=6 * np.sqrt(28.0) / 2.0 / np.sqrt(n))    # var of (z^2 - 1)^2 = 60 - 4 -> sd/mean = sqrt(56)/2
     if sigma == 1.2:
         assert abs(dj_true) < 5e-3 and j_true == pytest.approx(0.18597, abs=2e-4)      # the optimum the reference's test looks for
+    # the SWEEP's own dynamics against the same integral: one mc_step! moves a chain by delta with probability alpha, so the
+    # mean squared displacement of one sweep is E[delta^2 alpha] = J(sigma) too (and ties the estimator's objective to what the
+    # sampler really does); 1e6 chains sampled before and after one make_step!
+    m = 1_000_000
+    before = e.download_strided(0, 10, m)
+    acc0, tot0 = e.counter_totals()
+    e.sweep(1)
+    after = e.download_strided(0, 10, m)
+    acc1, tot1 = e.counter_totals()
+    msd = float(np.mean((after - before) ** 2))
+    assert msd == pytest.approx(j_true, abs=6 * 1.5 * sigma ** 2 / np.sqrt(m) + 2e-5)
+    # accepted <=> moved by more than rounding: a rejected chain is put back by re-adding the negated action, x = (x + d) + (-d),
+    # which differs from x in the last bits for a good part of the rejects (metropolis.jl:187)
+    moved = float(np.mean(np.abs(after - before) > 1e-9))
+    assert moved == pytest.approx((acc1[0] - acc0[0]) / (tot1[0] - tot0[0]), abs=6 * 0.5 / np.sqrt(m))
+    assert 0.05 < float(np.mean((after != before) & (np.abs(after - before) <= 1e-9))) < 0.5      # the quirk is there
     e.close()
