@@ -1922,10 +1922,17 @@ int amc_timing_end(amc_handle* h, double* elapsed_ms)
 static int load_rccl(Rccl& r)
 {
     if (r.lib) return AMC_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) break;
+    // AMC_RCCL_LIBRARY=<file>: that library and no other (a site's own RCCL build; the tests' shared-memory stand-in that
+    // lets several ranks share the one GPU of a test box, tests/aux/fake_rccl.c)
+    if (const char* forced = std::getenv("AMC_RCCL_LIBRARY")) {
+        r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) return fail(AMC_ERR_COMM, "cannot dlopen AMC_RCCL_LIBRARY=%s: %s", forced, dlerror());
+    } else {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
     }
     if (!r.lib) return fail(AMC_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
     r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");

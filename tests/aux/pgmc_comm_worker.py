@@ -25,7 +25,9 @@ for mode in ("comm", "host"):
     chains = ma.ParticleChains.uniform(60_000, 2.0, -2.0, 2.0)
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
             ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
-    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42),
+    # AMC_TEST_DEVICE: every rank on that device (the shared-memory RCCL stand-in of tests/aux/fake_rccl.c lets ranks share a GPU)
+    dev = {} if "AMC_TEST_DEVICE" not in os.environ else {"device": int(os.environ["AMC_TEST_DEVICE"])}
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, **dev),
           dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.3)),
                q_batch_size=2, device_resident=(None if mode == "comm" else False)),
           dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
@@ -46,7 +48,8 @@ for mode in ("comm", "host"):
                      connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]),
                      energy=[[t, float(v)] for t, v in sim.algorithms[3].rows[0]],
                      acceptance=[[t, [float(a) for a in v]] for t, v in sim.algorithms[3].rows[1]],
-                     comm=(eng.comm_info() if hasattr(eng, "comm_info") else None), world=WORLD)
+                     comm=(eng.comm_info() if hasattr(eng, "comm_info") else None), world=WORLD,
+                     x_head=[float(v).hex() for v in chains.x[:8]], shard=list(sim.algorithms[0].shard))
 if RANK == 0:
     print(json.dumps(out))
 if USE_STORE:

@@ -1,0 +1,93 @@
+"""The engine's N > 1 code paths with TWO ranks on the one GPU of the test box.
+
+RCCL refuses two ranks on one device and the GPU boxes have one, so nothing under `amc_comm_init` had ever met a second rank.
+`tests/aux/fake_rccl.c` (test infrastructure) exports the RCCL entry points libamc.so resolves and carries all-reduce(sum)
+over shared memory between the ranks' processes; `AMC_RCCL_LIBRARY` points the library at it.  What this exercises with real
+kernels on a real device: shards keyed by global chain id in two processes, `sharding.connect_engine` over the launcher's
+store, the estimator's in-place all-reduce on the engine's stream with n_samples of the GLOBAL ensemble, the callbacks' sums
+on the communication stream between them, `amc_comm_info`, and bench.py's `--gpus 2` route end to end.  What it does not
+exercise: RCCL itself and xGMI (the stand-in says version 1 so that nobody mistakes a line for the real thing).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AUX = os.path.join(ROOT, "tests", "aux")
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory, gpu):
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    r = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", os.path.join(AUX, "fake_rccl.c"), "-o", out, "-ldl", "-lrt", "-pthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(script_args, world, env):
+    cmd = ["timeout", "-k", "10", "400", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + script_args
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def test_two_ranks_share_one_gpu_pgmc_with_callbacks(fake_rccl):
+    """PGMC (device-resident estimator / update over the communicator) with callbacks every 10 time steps, two ranks of 30 000
+    chains each on device 0, against the same worker on ONE rank (its own one-rank communicator): per-chain results do not
+    depend on the sharding up to the learned sigma (sums in another order: rtol 1e-10), callback rows agree, the
+    communicator reports two ranks, and the host path (sums over the same communicator, learning step on the host) agrees."""
+    env = dict(AMC_TEST_GROUP="store", AMC_RCCL_LIBRARY=fake_rccl, AMC_TEST_DEVICE="0")
+    worker = [os.path.join(AUX, "pgmc_comm_worker.py")]
+    two = json.loads([ln for ln in launch(worker, 2, env).stdout.splitlines() if ln.startswith("{")][-1])
+    one = json.loads([ln for ln in launch(worker, 1, env).stdout.splitlines() if ln.startswith("{")][-1])
+    for out, world in ((two, 2), (one, 1)):
+        c = out["comm"]
+        assert c["world"] == world and c["connected"] and c["device_resident"] and not out["host"]["device_resident"]
+        assert c["comm"]["n_ranks"] == world and c["comm"]["rank"] == 0 and c["comm"]["rccl_version"] == 1
+        assert c["comm"]["librccl"] == fake_rccl
+        assert c["sigma"][0] == out["host"]["sigma"][0] == 0.2 and c["sigma"][1] > 0.5
+        assert c["sigma"][1] == pytest.approx(out["host"]["sigma"][1], rel=1e-10)
+        np.testing.assert_allclose([v for _, v in c["energy"]], [v for _, v in out["host"]["energy"]], rtol=1e-9)
+    assert two["comm"]["shard"] == [0, 30_000] and one["comm"]["shard"] == [0, 60_000]      # rank 0 reports
+    # two shards against one: the same global ensemble
+    assert two["comm"]["sigma"][1] == pytest.approx(one["comm"]["sigma"][1], rel=1e-10)
+    assert [t for t, _ in two["comm"]["energy"]] == [t for t, _ in one["comm"]["energy"]]
+    np.testing.assert_allclose([v for _, v in two["comm"]["energy"]], [v for _, v in one["comm"]["energy"]], rtol=1e-9)
+    np.testing.assert_allclose(np.array([v for _, v in two["comm"]["acceptance"]]), np.array([v for _, v in one["comm"]["acceptance"]]),
+                               rtol=1e-9, equal_nan=True)
+    # positions of the first chains (rank 0's shard starts at global chain 0 in both runs): equal to rounding of sigma
+    x2 = np.array([float.fromhex(v) for v in two["comm"]["x_head"]]); x1 = np.array([float.fromhex(v) for v in one["comm"]["x_head"]])
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-8)
+
+
+def test_bench_gpus_2_over_the_stand_in(fake_rccl):
+    """bench.py under the driver's launch line with two ranks on device 0: the RCCL route (not the store fallback), callbacks
+    all-reduced every 10 sweeps, max over ranks, ONE JSON line whose config says what the communicator reported."""
+    M = 400_000
+    r = launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10", "--spinup-s", "0.05", "--repeats", "2",
+                "--chains-per-gpu", str(M)], 2, dict(AMC_RCCL_LIBRARY=fake_rccl, AMC_BENCH_DEVICE="0"))
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["chains_total"] == 2 * M and c["callbacks_allreduce_every"] == 10
+    assert c["callbacks_allreduce_via"].startswith("rccl") and c["rccl_ranks"] == 2 and c["rccl_ranks_by_rank"] == [2, 2]
+    assert c["rccl_version"] == 1 and c["librccl"] == fake_rccl                  # the stand-in names itself
+    assert 0.90 < d["check"]["acceptance"] < 0.97
+    assert abs(d["value"] - 2 * M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
+    assert "other_configs" in d and d["other_configs"] is None                  # single-process extras stay out of N > 1 lines
