@@ -32,6 +32,9 @@ def fake_rccl(tmp_path_factory, gpu):
     return out
 
 
+ENERGY_AFTER_BENCH = {}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -75,19 +78,22 @@ def test_two_ranks_share_one_gpu_pgmc_with_callbacks(fake_rccl):
     np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-8)
 
 
-def test_bench_gpus_2_over_the_stand_in(fake_rccl):
-    """bench.py under the driver's launch line with two ranks on device 0: the RCCL route (not the store fallback), callbacks
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_gpus_n_over_the_stand_in(fake_rccl, world):
+    """bench.py under the driver's launch line with N ranks on device 0: the RCCL route (not the store fallback), callbacks
     all-reduced every 10 sweeps, max over ranks, ONE JSON line whose config says what the communicator reported."""
     M = 400_000
-    r = launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10", "--spinup-s", "0.05", "--repeats", "2",
-                "--chains-per-gpu", str(M)], 2, dict(AMC_RCCL_LIBRARY=fake_rccl, AMC_BENCH_DEVICE="0"))
+    r = launch([os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "40", "--warmup", "10", "--spinup-s", "0.05", "--repeats", "2",
+                "--chains-per-gpu", str(M)], world, dict(AMC_RCCL_LIBRARY=fake_rccl, AMC_BENCH_DEVICE="0"))
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     c = d["config"]
-    assert d["n_gpus"] == 2 and c["chains_total"] == 2 * M and c["callbacks_allreduce_every"] == 10
-    assert c["callbacks_allreduce_via"].startswith("rccl") and c["rccl_ranks"] == 2 and c["rccl_ranks_by_rank"] == [2, 2]
+    assert d["n_gpus"] == world and c["chains_total"] == world * M and c["callbacks_allreduce_every"] == 10
+    assert c["callbacks_allreduce_via"].startswith("rccl") and c["rccl_ranks"] == world and c["rccl_ranks_by_rank"] == [world] * world
     assert c["rccl_version"] == 1 and c["librccl"] == fake_rccl                  # the stand-in names itself
     assert 0.90 < d["check"]["acceptance"] < 0.97
-    assert abs(d["value"] - 2 * M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
+    assert abs(d["value"] - world * M * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
+    # the ensemble is ONE ensemble whatever the number of shards: acceptance and energy of world x M chains keyed by global id
+    assert d["check"]["mean_energy"] == pytest.approx(ENERGY_AFTER_BENCH.setdefault("e", d["check"]["mean_energy"]), rel=0.2)
     assert "other_configs" in d and d["other_configs"] is None                  # single-process extras stay out of N > 1 lines
