@@ -127,3 +127,6 @@ def test_plain_c_client_links_and_runs(tmp_path):
     f32 = dict(zip(lines[2].split()[2::2], map(float, lines[2].split()[3::2])))     # "f32 harmonic mean_U .. acc .."
     assert f32["mean_U"] == pytest.approx(0.25, abs=5e-3) and f32["acc"] == pytest.approx(0.9365, abs=5e-3)
     assert "n_moves must be in" in lines[3]
+    pg = dict(zip(lines[4].split()[1::2], map(float, lines[4].split()[2::2])))     # "pgmc sigma2 .. mean_e .. acc0 .. acc1 .. hip .."
+    assert pg["sigma2"] == pytest.approx(1.2, abs=0.2) and pg["mean_e"] == pytest.approx(0.25, abs=1e-2)      # pgmc_test.jl:45,50
+    assert pg["acc0"] > pg["acc1"] > 0.3 and pg["hip"] > 60000000
