@@ -312,6 +312,9 @@ int  amc_timing_mark(amc_handle *h);
 /* Cross-shard sum over RCCL (xGMI) for hosts without torch.distributed (Julia):
  * nccl_unique_id is the 128-byte ncclUniqueId made by amc_comm_unique_id on rank 0
  * and shipped to the other ranks by the caller. */
+/* RCCL is resolved with dlopen at the first of these calls (librccl.so.1, as any RCCL the host process has loaded already);
+ * AMC_RCCL_LIBRARY=<file> names the library to use instead -- a site's own build, or the shared-memory stand-in of the
+ * tests that lets several ranks share one GPU (tests/aux/fake_rccl.c). */
 int  amc_comm_unique_id(void *id128);
 int  amc_comm_init(amc_handle *h, int rank, int n_ranks, const void *id128);
 /* The sum runs on a stream of its own (the host waits for it without draining the sweeps queued on the engine's stream),
