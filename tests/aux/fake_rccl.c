@@ -28,6 +28,14 @@
 #define FAKE_MAX_COUNT 256
 #define FAKE_TIMEOUT_S 60.0
 
+/* AMC_FAKE_RCCL_TIMEOUT_S: how long a rank waits for the others; AMC_FAKE_RCCL_FAIL_RANK: that rank's ncclCommInitRank fails
+ * (the others then time out waiting for it, the way a real communicator set-up hangs or fails when one rank is missing) */
+static double timeout_s(void)
+{
+    const char* e = getenv("AMC_FAKE_RCCL_TIMEOUT_S");
+    return (e && atof(e) > 0.0) ? atof(e) : FAKE_TIMEOUT_S;
+}
+
 typedef struct {
     _Atomic int arrived;      /* barrier: ranks that have arrived in the current generation */
     _Atomic int generation;
@@ -81,7 +89,7 @@ static int barrier(comm_t* c)
     const double t0 = now_s();
     while (atomic_load(&c->sh->generation) == gen) {
         sched_yield();
-        if (now_s() - t0 > FAKE_TIMEOUT_S) return 1;
+        if (now_s() - t0 > timeout_s()) return 1;
     }
     return 0;
 }
@@ -103,6 +111,7 @@ int ncclCommInitRank(void** comm, int n_ranks, unique_id_t id, int rank)
 {
     if (!comm || n_ranks < 1 || n_ranks > FAKE_MAX_RANKS || rank < 0 || rank >= n_ranks) return 4;
     if (resolve_hip() != 0) return 3;
+    { const char* bad = getenv("AMC_FAKE_RCCL_FAIL_RANK"); if (bad && atoi(bad) == rank) return 5; }
     int fd = shm_open(id.b, O_RDWR, 0600);
     if (fd < 0) return 2;
     shared_t* sh = (shared_t*)mmap(NULL, sizeof(shared_t), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
@@ -118,7 +127,7 @@ int ncclCommInitRank(void** comm, int n_ranks, unique_id_t id, int rank)
     const double t0 = now_s();
     while (atomic_load(&sh->attached) < n_ranks) {
         sched_yield();
-        if (now_s() - t0 > FAKE_TIMEOUT_S) { munmap(sh, sizeof(shared_t)); free(c); return 6; }
+        if (now_s() - t0 > timeout_s()) { munmap(sh, sizeof(shared_t)); free(c); return 6; }
     }
     *comm = c;
     return 0;
@@ -165,6 +174,7 @@ const char* ncclGetErrorString(int e)
     case 2: return "fake rccl: shared memory segment";
     case 3: return "fake rccl: HIP runtime not found in the process";
     case 4: return "fake rccl: invalid argument";
+    case 5: return "fake rccl: this rank was told to fail (AMC_FAKE_RCCL_FAIL_RANK)";
     case 6: return "fake rccl: timed out waiting for the other ranks";
     default: return "fake rccl: unknown error";
     }

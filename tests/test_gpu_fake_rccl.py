@@ -97,3 +97,22 @@ def test_bench_gpus_n_over_the_stand_in(fake_rccl, world):
     # the ensemble is ONE ensemble whatever the number of shards: acceptance and energy of world x M chains keyed by global id
     assert d["check"]["mean_energy"] == pytest.approx(ENERGY_AFTER_BENCH.setdefault("e", d["check"]["mean_energy"]), rel=0.2)
     assert "other_configs" in d and d["other_configs"] is None                  # single-process extras stay out of N > 1 lines
+
+
+def test_one_rank_cannot_join_everybody_falls_back_together(fake_rccl):
+    """ncclCommInitRank fails on rank 1 only (and rank 0, like with a real communicator, waits for it in vain): after
+    sharding.connect_engine NO rank holds a communicator, the sums of callbacks and estimator go over the launcher's store on
+    both, and the run still equals the one-shard run -- the rank-asymmetric failure that used to leave rank 0 blocked."""
+    env = dict(AMC_TEST_GROUP="store", AMC_RCCL_LIBRARY=fake_rccl, AMC_TEST_DEVICE="0", AMC_FAKE_RCCL_FAIL_RANK="1",
+               AMC_FAKE_RCCL_TIMEOUT_S="3")
+    worker = [os.path.join(AUX, "pgmc_comm_worker.py")]
+    r = launch(worker, 2, env)
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "told to fail" in r.stderr and "no RCCL communicator over the shards" in r.stderr
+    for mode in ("comm", "host"):
+        assert not two[mode]["connected"] and not two[mode]["device_resident"] and two[mode]["world"] == 2
+        assert two[mode]["comm"] == {"n_ranks": 1, "rank": 0, "rccl_version": 0, "librccl": ""}
+    one = json.loads([ln for ln in launch(worker, 1, dict(AMC_TEST_GROUP="store", AMC_RCCL_LIBRARY=fake_rccl, AMC_TEST_DEVICE="0")).stdout.splitlines()
+                      if ln.startswith("{")][-1])
+    assert two["comm"]["sigma"][1] == pytest.approx(one["comm"]["sigma"][1], rel=1e-10)
+    np.testing.assert_allclose([v for _, v in two["comm"]["energy"]], [v for _, v in one["comm"]["energy"]], rtol=1e-9)
