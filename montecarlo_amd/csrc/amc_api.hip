@@ -1739,14 +1739,14 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     AMC_HIP(hipEventRecord(h->ev_comm_main, h->stream));
     h->comm_main_pending = true;
     const double n_samples = (double)h->M_global * (double)q_batch;
-    hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
-                       n_samples, h->d_gd_acc);
-    AMC_HIP(hipGetLastError());
-    if (opt) {
-        hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
-                           make_ids(n_learn, learn_ids), *opt, h->K, h->d_status);
-        AMC_HIP(hipGetLastError());
+    if (opt) {      // gradients_data += gd and the learning step in ONE launch: both sit on the critical path of the next sweep
+        hipLaunchKernelGGL(amc::pg_accumulate_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->d_ptab, h->d_gd_acc, n_learn,
+                           make_ids(n_learn, learn_ids), n_samples, *opt, h->K, h->d_status);
+    } else {
+        hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
+                           n_samples, h->d_gd_acc);
     }
+    AMC_HIP(hipGetLastError());
     return AMC_OK;
 }
 

@@ -1028,6 +1028,16 @@ AMC_KERNEL_LINKAGE __global__ void pg_update_kernel(double* ptab, double* acc, i
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
 }
 
+// Both in one launch, for shards connected by a communicator: what follows the in-place all-reduce of the estimator's sums
+// when the time step also updates (estimator.jl:130, then update.jl:50-57) -- one tiny launch on the critical path instead of two.
+AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* red, double* ptab, double* acc, int n_learn, PgIds ids,
+                                                              double n_samples, PgOpts opt, int n_moves, int* status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int l = 0; l < n_learn; ++l) pg_accumulate_one(red, l, ids.v[l], n_samples, acc);
+    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
+}
+
 // K2a: callback reductions, pass 1.  partials[block][4 + K]:
 //   sum e (callback_energy particle_1d.jl:68-70), sum x, sum x^2 (distribution_test.jl:36-37),
 //   count, and per move sum_c accepted/total (callback_acceptance metropolis.jl:319-321).
