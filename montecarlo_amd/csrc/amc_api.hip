@@ -104,6 +104,11 @@ struct amc_handle {
     double* d_beta = nullptr;
     uint32_t* d_acc = nullptr;
     uint32_t* d_tot = nullptr;
+    // the same counters as u16 while fewer than 2^16 steps are counted (narrow == true: K <= 4 handles start that way, and
+    // counter_room() widens them once); exactly one of the two pairs is allocated
+    uint16_t* d_acc16 = nullptr;
+    uint16_t* d_tot16 = nullptr;
+    bool narrow = false;
     uint8_t* d_log = nullptr;   // [log_depth][M_pad] step log: (move << 1) | accepted per chain and MH step
     int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
@@ -230,9 +235,14 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     const int64_t cap = (int64_t)h->n_cu * h->blocks_per_cu;
     const int64_t rounds = (n_tiles + cap - 1) / cap;
     const int grid = (int)((n_tiles + rounds - 1) / rounds);
-#define AMC_FOLD(KS, RATIO)                                                                                           \
-    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
+#define AMC_FOLD_W(KS, RATIO)                                                                                         \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
                        h->d_log, h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+#define AMC_FOLD_N(KS, RATIO)                                                                                         \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint16_t>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream,       \
+                       h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+#define AMC_FOLD(KS, RATIO)                                                                                           \
+    do { if (h->narrow) AMC_FOLD_N(KS, RATIO); else AMC_FOLD_W(KS, RATIO); } while (0)
     if (with_ratio) {
         switch (h->K) {
         case 1: AMC_FOLD(1, true); break;
@@ -248,12 +258,65 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
         case 2: AMC_FOLD(2, false); break;
         case 3: AMC_FOLD(3, false); break;
         case 4: AMC_FOLD(4, false); break;
-        default: AMC_FOLD(0, false); break;
+        default: AMC_FOLD_W(0, false); break;
         }
     }
 #undef AMC_FOLD
+#undef AMC_FOLD_N
+#undef AMC_FOLD_W
     AMC_HIP(hipGetLastError());
     h->log_fill = 0;
+    return AMC_OK;
+}
+
+// (Re)allocates the per-chain counter arrays, zeroed, as u16 (narrow) or u32; whatever they held is dropped.
+static hipError_t alloc_counters(amc_handle* h, bool narrow)
+{
+    (void)hipFree(h->d_acc);   h->d_acc = nullptr;
+    (void)hipFree(h->d_tot);   h->d_tot = nullptr;
+    (void)hipFree(h->d_acc16); h->d_acc16 = nullptr;
+    (void)hipFree(h->d_tot16); h->d_tot16 = nullptr;
+    h->narrow = narrow;
+    const size_t width = narrow ? sizeof(uint16_t) : sizeof(uint32_t);
+    const size_t n = (size_t)h->K * (size_t)h->M_pad;
+    const size_t nt = (size_t)(h->K - 1) * (size_t)h->M_pad;      // K - 1 rows: the last move's total_calls is the step count
+    void *a = nullptr, *t = nullptr;                               // minus the others (fold_log_kernel)
+    hipError_t e = hipMalloc(&a, n * width);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * width, h->stream);
+    if (e == hipSuccess && nt) e = hipMalloc(&t, nt * width);
+    if (e == hipSuccess && nt) e = hipMemsetAsync(t, 0, nt * width, h->stream);
+    if (narrow) { h->d_acc16 = (uint16_t*)a; h->d_tot16 = (uint16_t*)t; }
+    else        { h->d_acc = (uint32_t*)a;   h->d_tot = (uint32_t*)t; }
+    return e;
+}
+
+// u16 counters suit a handle while no counter can pass 65 535: K <= 4 (the register-resident fold) and AMC_WIDE_COUNTERS unset
+static bool narrow_counters_allowed(const amc_handle* h)
+{
+    static const bool forced_wide = [] { const char* e = getenv("AMC_WIDE_COUNTERS"); return e && *e && *e != '0'; }();
+    return h->counters && h->K <= 4 && !forced_wide;
+}
+
+// The one widening of a handle's life: pending log rows are folded into the u16 arrays, u32 arrays take their values.
+static int widen_counters(amc_handle* h)
+{
+    if (!h->narrow) return AMC_OK;
+    { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
+    uint16_t *a16 = h->d_acc16, *t16 = h->d_tot16;
+    h->d_acc16 = h->d_tot16 = nullptr;                             // alloc_counters must not free them yet
+    hipError_t e = alloc_counters(h, false);
+    if (e == hipSuccess) {
+        const int64_t n = (int64_t)h->K * h->M_pad, nt = (int64_t)(h->K - 1) * h->M_pad;
+        hipLaunchKernelGGL(amc::widen_counters_kernel, dim3(grid_for(h, n)), dim3(AMC_BLOCK), 0, h->stream, a16, h->d_acc, n);
+        if (nt) hipLaunchKernelGGL(amc::widen_counters_kernel, dim3(grid_for(h, nt)), dim3(AMC_BLOCK), 0, h->stream, t16, h->d_tot, nt);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the u16 arrays are freed next
+    }
+    (void)hipFree(a16);
+    (void)hipFree(t16);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "widening the per-chain counters to 32 bits failed: %s",
+                    hipGetErrorString(e));
     return AMC_OK;
 }
 
@@ -821,14 +884,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMalloc(&h->d_x, (size_t)h->M_pad * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_x, 0, (size_t)h->M_pad * sizeof(double), h->stream));
     if (h->counters) {
-        const size_t n = (size_t)h->K * (size_t)h->M_pad;
-        AMC_TRY(hipMalloc(&h->d_acc, n * sizeof(uint32_t)));
-        AMC_TRY(hipMemsetAsync(h->d_acc, 0, n * sizeof(uint32_t), h->stream));
-        if (h->K > 1) {      // K - 1 rows: the last move's total_calls is the step count minus the others (fold_log_kernel)
-            const size_t nt = (size_t)(h->K - 1) * (size_t)h->M_pad;
-            AMC_TRY(hipMalloc(&h->d_tot, nt * sizeof(uint32_t)));
-            AMC_TRY(hipMemsetAsync(h->d_tot, 0, nt * sizeof(uint32_t), h->stream));
-        }
+        AMC_TRY(alloc_counters(h, narrow_counters_allowed(h)));
         // One byte per chain and MH step; folding costs a read-modify-write of every counter (16 K bytes per chain), so a
         // deeper log amortises it over more steps: 128 rows where they fit in 2 GiB (1.28 GB at 1e7 chains), never below 16.
         {
@@ -1005,6 +1061,8 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_beta);
     (void)hipFree(h->d_acc);
     (void)hipFree(h->d_tot);
+    (void)hipFree(h->d_acc16);
+    (void)hipFree(h->d_tot16);
     (void)hipFree(h->d_log);
     (void)hipFree(h->d_ptab);
     (void)hipFree(h->d_pick);
@@ -1147,19 +1205,29 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
     AMC_HIP(hipSetDevice(h->device));
     { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     std::vector<uint32_t> buf((size_t)h->M);
+    // one row of counters, whatever their width on the device, as int64
+    auto fetch_row = [&](const uint32_t* wide, const uint16_t* narrow, int k, int64_t* out) -> int {
+        if (h->narrow) {
+            uint16_t* b16 = reinterpret_cast<uint16_t*>(buf.data());
+            AMC_HIP(hipMemcpyAsync(b16, narrow + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+            AMC_HIP(hipStreamSynchronize(h->stream));
+            for (int64_t c = 0; c < h->M; ++c) out[c] = b16[(size_t)c];
+        } else {
+            AMC_HIP(hipMemcpyAsync(buf.data(), wide + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            AMC_HIP(hipStreamSynchronize(h->stream));
+            for (int64_t c = 0; c < h->M; ++c) out[c] = buf[(size_t)c];
+        }
+        return AMC_OK;
+    };
     for (int k = 0; k < h->K; ++k) {
         if (accepted) {
-            AMC_HIP(hipMemcpyAsync(buf.data(), h->d_acc + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, h->stream));
-            AMC_HIP(hipStreamSynchronize(h->stream));
-            for (int64_t c = 0; c < h->M; ++c) accepted[(int64_t)k * h->M + c] = buf[(size_t)c];
+            const int rc = fetch_row(h->d_acc, h->d_acc16, k, accepted + (int64_t)k * h->M);
+            if (rc != AMC_OK) return rc;
         }
         if (total) {
             if (k + 1 < h->K) {
-                AMC_HIP(hipMemcpyAsync(buf.data(), h->d_tot + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, h->stream));
-                AMC_HIP(hipStreamSynchronize(h->stream));
-                for (int64_t c = 0; c < h->M; ++c) total[(int64_t)k * h->M + c] = buf[(size_t)c];
+                const int rc = fetch_row(h->d_tot, h->d_tot16, k, total + (int64_t)k * h->M);
+                if (rc != AMC_OK) return rc;
             } else {
                 // the last move: every chain has taken t_counted steps, its total_calls is what the other moves left
                 for (int64_t c = 0; c < h->M; ++c) {
@@ -1181,8 +1249,12 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     if (h->K > 1) {
         AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(amc::counter_totals_kernel, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream, h->d_acc,
-                           h->d_tot, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
+        if (h->narrow)
+            hipLaunchKernelGGL(amc::counter_totals_kernel<uint16_t>, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream,
+                               h->d_acc16, h->d_tot16, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
+        else
+            hipLaunchKernelGGL(amc::counter_totals_kernel<uint32_t>, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream,
+                               h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
         AMC_HIP(hipGetLastError());
     }
     AMC_HIP(hipMemcpyAsync(host, h->d_totals, sizeof(host), hipMemcpyDeviceToHost, h->stream));
@@ -1208,9 +1280,15 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
 // the device are u32.  No chain's counter can exceed the number of counted steps, so the call that would take that number
 // past 2^32 - 1 is refused as a whole (nothing is launched) instead of letting a counter wrap silently.  The pool-wide
 // counter of a K = 1 handle without per-chain counters is 64-bit and has no such limit.
-static int counter_room(const amc_handle* h, const char* who, uint64_t steps)
+// Handles that still keep their counters as u16 are widened here, before the call that would count past 65 535 steps.
+static int counter_room(amc_handle* h, const char* who, uint64_t steps)
 {
-    if (!h->counters || h->t_counted + steps <= 0xFFFFFFFFull) return AMC_OK;
+    if (!h->counters) return AMC_OK;
+    if (h->narrow && h->t_counted + steps > 0xFFFFull) {
+        const int rc = widen_counters(h);
+        if (rc != AMC_OK) return rc;
+    }
+    if (h->t_counted + steps <= 0xFFFFFFFFull) return AMC_OK;
     return fail(AMC_ERR_STATE, "%s: the per-chain counters are 32-bit and hold %llu counted steps, %llu more would wrap them: download "
                                "the counters and restart the count (amc_upload_counters with zeros) first",
                 who, (unsigned long long)h->t_counted, (unsigned long long)steps);
@@ -1313,23 +1391,41 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
         }
         if (steps > 0xFFFFFFFFull) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: step count out of u32 range");
     }
+    int64_t acc_max = 0;
+    for (int64_t i = 0; i < (int64_t)h->K * h->M; ++i) {
+        if (accepted[i] < 0 || accepted[i] > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
+        acc_max = std::max(acc_max, accepted[i]);
+    }
     AMC_HIP(hipSetDevice(h->device));
     h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
+    {   // the arrays take the width the new values allow (u16 while no counter can pass 65 535, see counter_room)
+        const bool narrow = narrow_counters_allowed(h) && steps <= 0xFFFFull && (uint64_t)acc_max <= steps;
+        if (narrow != h->narrow) {
+            AMC_HIP(hipStreamSynchronize(h->stream));
+            const hipError_t e = alloc_counters(h, narrow);
+            if (e != hipSuccess)
+                return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "amc_upload_counters: %s", hipGetErrorString(e));
+        }
+    }
     std::vector<uint32_t> buf((size_t)h->M);
     unsigned long long acc_sum = 0;
     for (int k = 0; k < h->K; ++k) {
         for (int pass = 0; pass < 2; ++pass) {
             const int64_t* src = pass == 0 ? accepted : total;
-            uint32_t* dst = pass == 0 ? h->d_acc : h->d_tot;
-            if (!src || !dst || (pass == 1 && k + 1 == h->K)) continue;     // the last move's totals have no array
+            if (!src || (pass == 1 && k + 1 == h->K)) continue;             // the last move's totals have no array
+            uint16_t* b16 = reinterpret_cast<uint16_t*>(buf.data());
             for (int64_t c = 0; c < h->M; ++c) {
                 const int64_t v = src[(int64_t)k * h->M + c];
-                if (v < 0 || v > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
-                buf[(size_t)c] = (uint32_t)v;
+                if (h->narrow) b16[(size_t)c] = (uint16_t)v; else buf[(size_t)c] = (uint32_t)v;
                 if (pass == 0) acc_sum += (unsigned long long)v;
             }
-            AMC_HIP(hipMemcpyAsync(dst + (size_t)k * h->M_pad, buf.data(), (size_t)h->M * sizeof(uint32_t),
-                                   hipMemcpyHostToDevice, h->stream));
+            if (h->narrow) {
+                uint16_t* dst = (pass == 0 ? h->d_acc16 : h->d_tot16) + (size_t)k * h->M_pad;
+                AMC_HIP(hipMemcpyAsync(dst, b16, (size_t)h->M * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+            } else {
+                uint32_t* dst = (pass == 0 ? h->d_acc : h->d_tot) + (size_t)k * h->M_pad;
+                AMC_HIP(hipMemcpyAsync(dst, buf.data(), (size_t)h->M * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            }
             AMC_HIP(hipStreamSynchronize(h->stream));
         }
     }

@@ -772,13 +772,31 @@ __device__ __forceinline__ unsigned long long add_block_accepts(unsigned long lo
 // callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
 // 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
 // t_counted: MH steps counted per chain INCLUDING the rows of this launch (< 2^32: the host refuses to count further).
+// CT: the counters' storage type.  While fewer than 2^16 steps have been counted no counter exceeds 65 535, and handles with
+// K <= 4 keep them as u16 (the host widens the arrays to u32 once, before the step that would pass that mark): the callback's
+// fold is a bandwidth-bound read-modify-write of every counter, and half the bytes are half the time (22 instead of 34 bytes
+// per chain for ten rows at K = 2).
 #define AMC_FOLD_TILE (16 * AMC_BLOCK)
-template <int KS, bool RATIO = false>
-__global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, uint32_t* acc,
-                                                              uint32_t* tot, int64_t n_chains, int64_t m_stride,
+// four adjacent counters as one aligned access: 16 bytes of u32, 8 bytes of u16
+__device__ __forceinline__ uint4 load_counter_quad(const uint32_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load_counter_quad(const uint16_t* p)
+{
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return uint4{v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+}
+__device__ __forceinline__ void store_counter_quad(uint32_t* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ void store_counter_quad(uint16_t* p, uint4 v)
+{
+    *reinterpret_cast<uint2*>(p) = uint2{v.x | (v.y << 16), v.z | (v.w << 16)};       // every value < 2^16 (see above)
+}
+
+template <int KS, bool RATIO = false, typename CT = uint32_t>
+__global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, CT* acc,
+                                                              CT* tot, int64_t n_chains, int64_t m_stride,
                                                               int n_moves, uint64_t t_counted, double* ratio_partials,
                                                               int rp_stride)
 {
+    static_assert(KS > 0 || sizeof(CT) == 4, "16-bit counters come with the register-resident fold (K <= 4)");
     static_assert(!RATIO || KS > 0, "ratio sums ride on the register-resident fold");
     if (KS > 0) {
         constexpr int KK = KS > 0 ? KS : 1;
@@ -834,17 +852,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
                     const uint32_t wa = s_pk[2 * k][quad];
-                    uint4* p_a = reinterpret_cast<uint4*>(acc + (int64_t)k * m_stride + c0);
-                    uint4 va = *p_a;
+                    CT* p_a = acc + (int64_t)k * m_stride + c0;
+                    uint4 va = load_counter_quad(p_a);
                     va.x += wa & 0xFFu; va.y += (wa >> 8) & 0xFFu; va.z += (wa >> 16) & 0xFFu; va.w += wa >> 24;
-                    *p_a = va;
+                    store_counter_quad(p_a, va);
                     uint4 vt;
                     if (k < KK - 1) {
                         const uint32_t wt = s_pk[2 * k + 1][quad];
-                        uint4* p_t = reinterpret_cast<uint4*>(tot + (int64_t)k * m_stride + c0);
-                        vt = *p_t;
+                        CT* p_t = tot + (int64_t)k * m_stride + c0;
+                        vt = load_counter_quad(p_t);
                         vt.x += wt & 0xFFu; vt.y += (wt >> 8) & 0xFFu; vt.z += (wt >> 16) & 0xFFu; vt.w += wt >> 24;
-                        *p_t = vt;
+                        store_counter_quad(p_t, vt);
                         tsum[0] += vt.x; tsum[1] += vt.y; tsum[2] += vt.z; tsum[3] += vt.w;
                     } else {
                         const uint32_t tc = (uint32_t)t_counted;
@@ -875,6 +893,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
             }
         }
     }
+}
+
+// u16 counters -> u32 counters, once in a handle's life (before the step that would count past 65 535)
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void widen_counters_kernel(const uint16_t* in, uint32_t* out, int64_t n)
+{
+    const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = in[i];
 }
 
 // K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
@@ -1166,7 +1191,8 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_ker
 
 // Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].  16-byte loads, one atomic per
 // block and value (same-address atomics serialise at ~13 ns each: per-wave atomics from a full grid cost 0.2 ms here).
-AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const uint32_t* acc, const uint32_t* tot,
+template <typename CT>
+__global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc, const CT* tot,
                                                                     int64_t n_chains, int64_t m_stride,
                                                                     int n_moves, unsigned long long* out_acc,
                                                                     unsigned long long* out_tot)
@@ -1177,9 +1203,9 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_k
     for (int k = 0; k < n_moves; ++k) {
         unsigned long long sa = 0, st = 0;
         for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
-            const uint4 va = *reinterpret_cast<const uint4*>(acc + (int64_t)k * m_stride + 4 * q);
+            const uint4 va = load_counter_quad(acc + (int64_t)k * m_stride + 4 * q);
             // tot has n_moves - 1 rows (the last move's totals are the step count minus the others: the host completes them)
-            const uint4 vt = (tot && k + 1 < n_moves) ? *reinterpret_cast<const uint4*>(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
+            const uint4 vt = (tot && k + 1 < n_moves) ? load_counter_quad(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
             const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)

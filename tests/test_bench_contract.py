@@ -65,6 +65,8 @@ def test_single_process_line():
     # BASELINE configs 3 and 5 end to end next to the headline, never instead of it
     oc = d["other_configs"]
     assert "error" not in oc and 0 < oc["config3_double_well_K2"]["us_per_time_step"] < oc["config5_pgmc"]["us_per_time_step"]
+    for name in ("config3_double_well_K2", "config5_pgmc"):   # u16 counters for the first 65 535 steps: never slower than u32 by much
+        assert 0 < oc[name]["us_per_time_step_first_65535_steps"] < 1.5 * oc[name]["us_per_time_step"]
     assert 0.1 < oc["config5_pgmc"]["sigma_2_after"] < 2.0 and oc["config5_pgmc"]["sigma_2_after"] != 0.1      # it learned
 
 

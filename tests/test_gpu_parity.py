@@ -1081,6 +1081,71 @@ def test_per_chain_counters_refuse_to_wrap(gpu, K):
     e.close()
 
 
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_counters_across_the_16_bit_mark(gpu, oracle, K):
+    """Handles with K <= 4 keep their per-chain counters as u16 until the call that would count past 65 535 steps, then widen
+    them to u32 once (amc_api.hip counter_room): counts, acceptance sums and the states on both sides of the mark against
+    the oracle's increments, with neighbouring counters at 0xFFFF and 0 (the packing of the 16-bit quads)."""
+    M = 2051
+    sigma, weight = POOLS[K]
+    kw = dict(potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=11)
+    e = gpu.HipEngine(n_chains=M, per_chain_counters=True, **kw)
+    o = oracle.OracleSim(M, **kw)
+    e.init_uniform(-2, 2)
+    o.init_uniform(-2, 2)
+    base = 65530
+    rng = np.random.default_rng(2)
+    tot = rng.multinomial(base, weight, size=M).T.astype(np.int64)
+    tot[:, 0::4] = 0
+    tot[0, 0::4] = base                                     # every fourth chain: one counter at the top, the others at 0
+    acc = (tot * rng.uniform(0, 1, tot.shape)).astype(np.int64)
+    acc[0, 0::8] = base
+    e.upload_counters(acc, tot)
+    a1, t1 = e.download_counters()
+    assert np.array_equal(a1, acc) and np.array_equal(t1, tot)
+
+    def check(steps_done):
+        ao, to = o.counters()
+        a, t = e.download_counters()
+        assert np.array_equal(a, acc + ao) and np.array_equal(t, tot + to), steps_done
+        assert np.array_equal(e.counter_totals()[0], (acc + ao).sum(axis=1))
+        assert np.array_equal(e.counter_totals()[1], (tot + to).sum(axis=1))
+        red = e.reduce()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            np.testing.assert_allclose(red[4:], ((acc + ao) / (tot + to)).sum(axis=1), rtol=1e-12, equal_nan=True)
+        assert np.array_equal(e.download_state()[0].view(np.uint64), o.state()[0].view(np.uint64))
+
+    e.sweep(3); o.make_steps(3)                             # 65 533: still 16-bit
+    check(3)
+    e.sweep(2); o.make_steps(2)                             # 65 535: the last value u16 holds
+    check(5)
+    e.sweep(1); o.make_steps(1)                             # widened before this step
+    check(6)
+    e.sweep_reduce_begin(40); e.reduce_end(); o.make_steps(40)
+    check(46)
+    # a fused PGMC call that crosses the mark widens up front as well
+    e2 = gpu.HipEngine(n_chains=M, per_chain_counters=True, **kw)
+    o2 = oracle.OracleSim(M, **kw)
+    e2.init_uniform(-2, 2); o2.init_uniform(-2, 2)
+    e2.upload_counters(acc, tot)
+    e2.sweep(4); o2.make_steps(4)                           # rows waiting in the log when the widening happens
+    e2.pgmc_steps(3, [0], 1)
+    for _ in range(3):
+        o2.make_steps(1)
+        o2.pg_estimate([0], 1)
+    ao, to = o2.counters()
+    a, t = e2.download_counters()
+    assert np.array_equal(a, acc + ao) and np.array_equal(t, tot + to)
+    assert np.array_equal(e2.download_state()[0].view(np.uint64), o2.state()[0].view(np.uint64))
+    # counts that do not fit 16 bits go straight to the wide arrays, and back when the count restarts
+    e2.upload_counters(acc * 3, tot * 3)
+    assert np.array_equal(e2.download_counters()[1], tot * 3)
+    e2.upload_counters(acc * 0, tot * 0)
+    e2.sweep(7)
+    assert np.all(e2.download_counters()[1].sum(axis=0) == 7)
+    e.close(); e2.close()
+
+
 def test_uploaded_totals_must_add_up_to_one_step_count(gpu):
     """Every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210): sum_k total_calls is one number
     for all chains, and the device keeps K - 1 of the K total arrays."""
