@@ -272,11 +272,6 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
 // (Re)allocates the per-chain counter arrays, zeroed, as u16 (narrow) or u32; whatever they held is dropped.
 static hipError_t alloc_counters(amc_handle* h, bool narrow)
 {
-    (void)hipFree(h->d_acc);   h->d_acc = nullptr;
-    (void)hipFree(h->d_tot);   h->d_tot = nullptr;
-    (void)hipFree(h->d_acc16); h->d_acc16 = nullptr;
-    (void)hipFree(h->d_tot16); h->d_tot16 = nullptr;
-    h->narrow = narrow;
     const size_t width = narrow ? sizeof(uint16_t) : sizeof(uint32_t);
     const size_t n = (size_t)h->K * (size_t)h->M_pad;
     const size_t nt = (size_t)(h->K - 1) * (size_t)h->M_pad;      // K - 1 rows: the last move's total_calls is the step count
@@ -285,9 +280,19 @@ static hipError_t alloc_counters(amc_handle* h, bool narrow)
     if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * width, h->stream);
     if (e == hipSuccess && nt) e = hipMalloc(&t, nt * width);
     if (e == hipSuccess && nt) e = hipMemsetAsync(t, 0, nt * width, h->stream);
+    if (e != hipSuccess) {                                         // the handle keeps the arrays it had
+        (void)hipFree(a);
+        (void)hipFree(t);
+        return e;
+    }
+    (void)hipFree(h->d_acc);   h->d_acc = nullptr;
+    (void)hipFree(h->d_tot);   h->d_tot = nullptr;
+    (void)hipFree(h->d_acc16); h->d_acc16 = nullptr;
+    (void)hipFree(h->d_tot16); h->d_tot16 = nullptr;
+    h->narrow = narrow;
     if (narrow) { h->d_acc16 = (uint16_t*)a; h->d_tot16 = (uint16_t*)t; }
     else        { h->d_acc = (uint32_t*)a;   h->d_tot = (uint32_t*)t; }
-    return e;
+    return hipSuccess;
 }
 
 // u16 counters suit a handle while no counter can pass 65 535: K <= 4 (the register-resident fold) and AMC_WIDE_COUNTERS unset
@@ -312,11 +317,16 @@ static int widen_counters(amc_handle* h)
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the u16 arrays are freed next
     }
-    (void)hipFree(a16);
-    (void)hipFree(t16);
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        // the handle keeps its u16 counters (nothing has been counted past them yet): the caller's step is refused, not lost
+        (void)hipFree(h->d_acc); h->d_acc = nullptr;
+        (void)hipFree(h->d_tot); h->d_tot = nullptr;
+        h->d_acc16 = a16; h->d_tot16 = t16; h->narrow = true;
         return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "widening the per-chain counters to 32 bits failed: %s",
                     hipGetErrorString(e));
+    }
+    (void)hipFree(a16);
+    (void)hipFree(t16);
     return AMC_OK;
 }
 

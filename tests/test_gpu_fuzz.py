@@ -6,7 +6,8 @@ pick table --, sigma over four decades, beta over two, both potentials, ragged e
 arbitrary EVEN global chain id far from 0, sweepstep 1..4, Float64 and Float32 state, K = 1 with and without per-chain
 counters; then a random walk over {single-step launch, multi-step launch, callback reduction, sweep with the reduction
 formed in the launch (read at once or with sweeps queued behind it), estimator call, [Metropolis, estimator, update] steps in
-one engine call with and without the callback sums of their last step, parameter update, counter download}.  After every state-observing operation: positions and energies bit for bit, counters equal,
+one engine call with and without the callback sums of their last step, parameter update, counter download, counter upload
+around the 16-bit mark}.  After every state-observing operation: positions and energies bit for bit, counters equal,
 reductions within RED_RTOL.  AMC_FUZZ_CASES (default 40, ~15 s) and AMC_FUZZ_SEED widen or move the sample.
 """
 import os
@@ -105,7 +106,7 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
     check_state(e, o, case, "start")
     K = len(case["sigma"])
     for op_index in range(int(rng.integers(min(6, max_ops - 1), max_ops))):
-        op = rng.choice(["single", "single", "multi", "reduce", "sweep_reduce", "estimate", "pgmc", "pgmc_reduce", "sigma", "counters"])
+        op = rng.choice(["single", "single", "multi", "reduce", "sweep_reduce", "estimate", "pgmc", "pgmc_reduce", "sigma", "counters", "recount"])
         where = f"case {index}, operation {op_index} ({op})"
         if op == "single":
             for _ in range(int(rng.integers(1, 6))):
@@ -171,6 +172,18 @@ def run_case(gpu, oracle, rng, index, sizes=None, threads=1, max_ops=16, max_mul
             o.set_parameters(k, [s])
             continue
         elif op == "counters":
+            check_counters(e, o, case, where)
+            continue
+        elif op == "recount":
+            # resume with other counts (amc_upload_counters): step counts on both sides of the 16-bit mark, where K <= 4 handles
+            # switch the width of their counter arrays -- at the upload, or in the middle of the steps that follow
+            if not case["per_chain_counters"]:
+                continue
+            steps = int(rng.choice([0, 17, 65_500, 65_530, 65_535, 65_536, 70_000, 2 ** 20]))
+            tot = rng.multinomial(steps, case["weight"], size=case["n_chains"]).T.astype(np.int64)
+            acc = (tot * rng.uniform(0, 1, tot.shape)).astype(np.int64)
+            e.upload_counters(acc, tot)
+            o.upload_counters(acc, tot)
             check_counters(e, o, case, where)
             continue
         check_state(e, o, case, where)
