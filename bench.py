@@ -183,16 +183,16 @@ def other_configs(A, m, device, periods=40):
     """BASELINE configs 3 and 5 end to end at this ensemble size, next to the headline (never part of `value`): one launch per
     time step, callbacks (energy + acceptance) every 10 time steps, each callback's sums read one period late -- the form
     the host mirror's StoreCallbacks uses.  HIP events over `periods` callback periods, after as many untimed.
-    Two figures each: K <= 4 handles keep their per-chain counters as u16 for the first 65 535 counted steps (the callback's
-    fold moves 22 instead of 34 bytes per chain) and as u32 from then on; `us_per_time_step` is the u32 regime (what a long run
-    sees), `us_per_time_step_first_65535_steps` the u16 one."""
+    Two figures each: K <= 4 handles keep their per-chain counters as two u16 planes, and for the first 65 535 counted steps
+    the callback's fold leaves the (all-zero) high plane alone -- 17 bytes per chain against 23 afterwards;
+    `us_per_time_step` is the regime after the mark (what a long run sees), `us_per_time_step_first_65535_steps` the one before."""
     import numpy as np
     out = {}
 
     def run(e, period):
         e.init_uniform(-2.0, 2.0)
         early = measure(e, period)
-        # counts past the 16-bit mark: the handle switches to u32 counters for good (amc_upload_counters)
+        # counts past the 16-bit mark: the high counter planes take part from here on (amc_upload_counters)
         tot = np.zeros((2, m), dtype=np.int64)
         tot[0] = 70_000
         e.upload_counters(np.zeros((2, m), dtype=np.int64), tot)
@@ -226,12 +226,12 @@ def other_configs(A, m, device, periods=40):
     try:
         e = A.HipEngine(n_chains=m, potential="double_well", beta=BETA, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=SEED, device=device)
         us, early = run(e, k2_period)
-        out["config3_double_well_K2"] = {"us_per_time_step": us, "us_per_time_step_first_65535_steps": early, "algorithmic_bytes_per_update": 17,
+        out["config3_double_well_K2"] = {"us_per_time_step": us, "us_per_time_step_first_65535_steps": early, "algorithmic_bytes_per_update": 16.5,
                                          "workload": "U = (x^2-1)^2, sigma = (0.1, 1.0), w = (0.5, 0.5), per-chain counters (step log)"}
         e.close()
         e = A.HipEngine(n_chains=m, potential="harmonic", beta=BETA, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42, device=device)
         us, early = run(e, pgmc_period)
-        out["config5_pgmc"] = {"us_per_time_step": us, "us_per_time_step_first_65535_steps": early, "algorithmic_bytes_per_update": 17, "sigma_2_after": float(e.get_parameters(1)[0]),
+        out["config5_pgmc"] = {"us_per_time_step": us, "us_per_time_step_first_65535_steps": early, "algorithmic_bytes_per_update": 16.5, "sigma_2_after": float(e.get_parameters(1)[0]),
                                "workload": "PGMC_harmonic_oscillator.jl pool sigma = (0.2, 0.1), w = (0.6, 0.4), optimisers (Static, VPG(0.02)), "
                                            "q_batch_size = 1; sweep + estimator + learning step in ONE launch per time step"}
         e.close()

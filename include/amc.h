@@ -201,8 +201,8 @@ int  amc_download_state(amc_handle *h, double *x, double *e);
  * (src/metropolis.jl:145-146); the device keeps them as u32 per chain, so a handle with per-chain counters counts at most
  * 2^32 - 1 MH steps: the call that would go beyond returns AMC_ERR_STATE before launching anything (download the
  * counters, amc_upload_counters zeros, continue).  The pool-wide count of a K = 1 handle without them is 64-bit.
- * (Storage detail, invisible here: with K <= 4 the arrays are u16 until the call that would count step 65 536 and are
- * widened to u32 then, once; environment AMC_WIDE_COUNTERS=1 makes them u32 from the start.) */
+ * (Storage detail, invisible here: with K <= 4 a counter is two u16 halves in separate arrays, and the high halves take
+ * part in the folds only from the call that would count step 65 536 on; environment AMC_WIDE_COUNTERS=1 keeps plain u32.) */
 int  amc_download_counters(amc_handle *h, int64_t *accepted, int64_t *total);
 /* Pool-wide sums over local chains: accepted[k], total[k] (exact integers). */
 int  amc_counter_totals(amc_handle *h, int64_t *accepted, int64_t *total);

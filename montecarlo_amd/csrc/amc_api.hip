@@ -104,11 +104,15 @@ struct amc_handle {
     double* d_beta = nullptr;
     uint32_t* d_acc = nullptr;
     uint32_t* d_tot = nullptr;
-    // the same counters as u16 while fewer than 2^16 steps are counted (narrow == true: K <= 4 handles start that way, and
-    // counter_room() widens them once); exactly one of the two pairs is allocated
+    // K <= 4 handles (narrow == true) keep the counters as two u16 planes instead: low halves here, high halves in *_hi;
+    // the high planes stay all zero, and untouched by the folds, until counter_room() sets use_high before the call that
+    // would count step 65 536 (fold_log_kernel<.., HIGH>).  Exactly one of the two forms is allocated.
     uint16_t* d_acc16 = nullptr;
     uint16_t* d_tot16 = nullptr;
+    uint16_t* d_acc_hi = nullptr;
+    uint16_t* d_tot_hi = nullptr;
     bool narrow = false;
+    bool use_high = false;
     uint8_t* d_log = nullptr;   // [log_depth][M_pad] step log: (move << 1) | accepted per chain and MH step
     int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
@@ -194,26 +198,31 @@ int push_params(amc_handle* h, const double* sigma, const double* weight)
     return AMC_OK;
 }
 
+// The step log's form (store_log_pair): none without per-chain counters, two chains per byte while the move index fits two
+// bits, one byte per chain beyond.
+static int log_form(const amc_handle* h)
+{
+    return !h->counters ? AMC_LOG_NONE : (h->K <= AMC_PACKED_LOG_MOVES ? AMC_LOG_PACKED : AMC_LOG_BYTES);
+}
+
 template <int POT, bool SINGLE>
 int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     const bool multi = h->K > 1;
-    if (multi) {          // K > 1 always keeps per-chain counters (callback_acceptance is a mean of per-chain ratios)
-        if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, true, true, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-    } else if (h->counters) {
-        if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, true, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-    } else {
-        if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, false, false, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
-    }
+#define AMC_SWEEP(MULTI, LOG)                                                                                              \
+    do {                                                                                                                   \
+        if (h->beta_arr)                                                                                                   \
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, SINGLE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a); \
+    } while (0)
+    // K > 1 always keeps per-chain counters (callback_acceptance is a mean of per-chain ratios); the step log's form is
+    // part of the instantiation (log_form)
+    if (multi && log_form(h) == AMC_LOG_PACKED) AMC_SWEEP(true, AMC_LOG_PACKED);
+    else if (multi) AMC_SWEEP(true, AMC_LOG_BYTES);
+    else if (h->counters) AMC_SWEEP(false, AMC_LOG_PACKED);
+    else AMC_SWEEP(false, AMC_LOG_NONE);
+#undef AMC_SWEEP
     AMC_HIP(hipGetLastError());
     return AMC_OK;
 }
@@ -235,14 +244,20 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     const int64_t cap = (int64_t)h->n_cu * h->blocks_per_cu;
     const int64_t rounds = (n_tiles + cap - 1) / cap;
     const int grid = (int)((n_tiles + rounds - 1) / rounds);
+    uint16_t* const no_hi = nullptr;
 #define AMC_FOLD_W(KS, RATIO)                                                                                         \
-    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
-#define AMC_FOLD_N(KS, RATIO)                                                                                         \
-    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint16_t>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream,       \
-                       h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t, false>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, h->d_acc, h->d_tot, no_hi, no_hi, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+#define AMC_FOLD_N(KS, RATIO, HIGH)                                                                                   \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint16_t, HIGH>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->d_acc_hi, h->d_tot_hi, h->M, h->M_pad, h->K, h->t_counted, \
+                       h->h_ratio, RATIO_STRIDE)
 #define AMC_FOLD(KS, RATIO)                                                                                           \
-    do { if (h->narrow) AMC_FOLD_N(KS, RATIO); else AMC_FOLD_W(KS, RATIO); } while (0)
+    do {                                                                                                              \
+        if (!h->narrow) AMC_FOLD_W(KS, RATIO);                                                                        \
+        else if (h->use_high) AMC_FOLD_N(KS, RATIO, true);                                                            \
+        else AMC_FOLD_N(KS, RATIO, false);                                                                            \
+    } while (0)
     if (with_ratio) {
         switch (h->K) {
         case 1: AMC_FOLD(1, true); break;
@@ -269,65 +284,34 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     return AMC_OK;
 }
 
-// (Re)allocates the per-chain counter arrays, zeroed, as u16 (narrow) or u32; whatever they held is dropped.
+// Allocates the per-chain counter arrays, zeroed: two u16 planes per counter (narrow) or u32 arrays.
 static hipError_t alloc_counters(amc_handle* h, bool narrow)
 {
-    const size_t width = narrow ? sizeof(uint16_t) : sizeof(uint32_t);
     const size_t n = (size_t)h->K * (size_t)h->M_pad;
     const size_t nt = (size_t)(h->K - 1) * (size_t)h->M_pad;      // K - 1 rows: the last move's total_calls is the step count
-    void *a = nullptr, *t = nullptr;                               // minus the others (fold_log_kernel)
-    hipError_t e = hipMalloc(&a, n * width);
-    if (e == hipSuccess) e = hipMemsetAsync(a, 0, n * width, h->stream);
-    if (e == hipSuccess && nt) e = hipMalloc(&t, nt * width);
-    if (e == hipSuccess && nt) e = hipMemsetAsync(t, 0, nt * width, h->stream);
-    if (e != hipSuccess) {                                         // the handle keeps the arrays it had
-        (void)hipFree(a);
-        (void)hipFree(t);
-        return e;
+    h->narrow = narrow;                                            // minus the others (fold_log_kernel)
+    h->use_high = false;
+    auto zeroed = [&](void** p, size_t bytes) {
+        if (bytes == 0) return hipSuccess;
+        const hipError_t e = hipMalloc(p, bytes);
+        return e != hipSuccess ? e : hipMemsetAsync(*p, 0, bytes, h->stream);
+    };
+    hipError_t e;
+    if (!narrow) {
+        if ((e = zeroed((void**)&h->d_acc, n * sizeof(uint32_t))) != hipSuccess) return e;
+        return zeroed((void**)&h->d_tot, nt * sizeof(uint32_t));
     }
-    (void)hipFree(h->d_acc);   h->d_acc = nullptr;
-    (void)hipFree(h->d_tot);   h->d_tot = nullptr;
-    (void)hipFree(h->d_acc16); h->d_acc16 = nullptr;
-    (void)hipFree(h->d_tot16); h->d_tot16 = nullptr;
-    h->narrow = narrow;
-    if (narrow) { h->d_acc16 = (uint16_t*)a; h->d_tot16 = (uint16_t*)t; }
-    else        { h->d_acc = (uint32_t*)a;   h->d_tot = (uint32_t*)t; }
-    return hipSuccess;
+    if ((e = zeroed((void**)&h->d_acc16, n * sizeof(uint16_t))) != hipSuccess) return e;
+    if ((e = zeroed((void**)&h->d_acc_hi, n * sizeof(uint16_t))) != hipSuccess) return e;
+    if ((e = zeroed((void**)&h->d_tot16, nt * sizeof(uint16_t))) != hipSuccess) return e;
+    return zeroed((void**)&h->d_tot_hi, nt * sizeof(uint16_t));
 }
 
-// u16 counters suit a handle while no counter can pass 65 535: K <= 4 (the register-resident fold) and AMC_WIDE_COUNTERS unset
+// u16 planes suit a handle with K <= 4 (the register-resident fold); AMC_WIDE_COUNTERS=1 keeps plain u32 arrays (A/B, tests)
 static bool narrow_counters_allowed(const amc_handle* h)
 {
     static const bool forced_wide = [] { const char* e = getenv("AMC_WIDE_COUNTERS"); return e && *e && *e != '0'; }();
     return h->counters && h->K <= 4 && !forced_wide;
-}
-
-// The one widening of a handle's life: pending log rows are folded into the u16 arrays, u32 arrays take their values.
-static int widen_counters(amc_handle* h)
-{
-    if (!h->narrow) return AMC_OK;
-    { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
-    uint16_t *a16 = h->d_acc16, *t16 = h->d_tot16;
-    h->d_acc16 = h->d_tot16 = nullptr;                             // alloc_counters must not free them yet
-    hipError_t e = alloc_counters(h, false);
-    if (e == hipSuccess) {
-        const int64_t n = (int64_t)h->K * h->M_pad, nt = (int64_t)(h->K - 1) * h->M_pad;
-        hipLaunchKernelGGL(amc::widen_counters_kernel, dim3(grid_for(h, n)), dim3(AMC_BLOCK), 0, h->stream, a16, h->d_acc, n);
-        if (nt) hipLaunchKernelGGL(amc::widen_counters_kernel, dim3(grid_for(h, nt)), dim3(AMC_BLOCK), 0, h->stream, t16, h->d_tot, nt);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the u16 arrays are freed next
-    }
-    if (e != hipSuccess) {
-        // the handle keeps its u16 counters (nothing has been counted past them yet): the caller's step is refused, not lost
-        (void)hipFree(h->d_acc); h->d_acc = nullptr;
-        (void)hipFree(h->d_tot); h->d_tot = nullptr;
-        h->d_acc16 = a16; h->d_tot16 = t16; h->narrow = true;
-        return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "widening the per-chain counters to 32 bits failed: %s",
-                    hipGetErrorString(e));
-    }
-    (void)hipFree(a16);
-    (void)hipFree(t16);
-    return AMC_OK;
 }
 
 // Makes room for at least one more row of the step log (a full log is folded first); *rows = how many fit.
@@ -341,7 +325,7 @@ int log_room(amc_handle* h, int* rows)
     return AMC_OK;
 }
 
-template <int POT, bool MULTI, bool LOG>
+template <int POT, bool MULTI, int LOG>
 int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     if (a.n_steps == 1) {
@@ -362,9 +346,10 @@ int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
 template <int POT>
 int launch_sweep_reduce(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
-    if (h->K > 1) return launch_sweep_reduce_ml<POT, true, true>(h, a, grid);
-    if (h->counters) return launch_sweep_reduce_ml<POT, false, true>(h, a, grid);
-    return launch_sweep_reduce_ml<POT, false, false>(h, a, grid);
+    if (h->K > 1 && log_form(h) == AMC_LOG_PACKED) return launch_sweep_reduce_ml<POT, true, AMC_LOG_PACKED>(h, a, grid);
+    if (h->K > 1) return launch_sweep_reduce_ml<POT, true, AMC_LOG_BYTES>(h, a, grid);
+    if (h->counters) return launch_sweep_reduce_ml<POT, false, AMC_LOG_PACKED>(h, a, grid);
+    return launch_sweep_reduce_ml<POT, false, AMC_LOG_NONE>(h, a, grid);
 }
 
 template <int POT>
@@ -672,8 +657,8 @@ const char* tf(bool b) { return b ? "true" : "false"; }
 // sweep_kernel<POT_CUSTOM, MULTI, LOG, BETA, SINGLE, REDUCE> with the flags launch_sweep_s / launch_sweep_reduce pick
 int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
 {
-    const bool multi = h->K > 1, log = multi || h->counters;
-    const std::string inst = "amc::sweep_kernel<" + std::to_string(h->potential) + "," + tf(multi) + "," + tf(log) + "," + tf(h->beta_arr) + "," +
+    const bool multi = h->K > 1;
+    const std::string inst = "amc::sweep_kernel<" + std::to_string(h->potential) + "," + tf(multi) + "," + std::to_string(log_form(h)) + "," + tf(h->beta_arr) + "," +
                              tf(a.n_steps == 1) + "," + tf(reduce) + ">";
     void* params[] = {&a};
     return rtc_launch(h, inst, grid, params);
@@ -905,8 +890,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
             const int v = std::atoi(env);
             if (v >= 1 && v <= 255) h->log_depth = v;
         }
-        AMC_TRY(hipMalloc(&h->d_log, (size_t)h->log_depth * (size_t)h->M_pad));
-        AMC_TRY(hipMemsetAsync(h->d_log, 0, (size_t)h->log_depth * (size_t)h->M_pad, h->stream));
+        // K <= AMC_PACKED_LOG_MOVES: two chains per byte (store_log_pair)
+        const size_t row_bytes = log_form(h) == AMC_LOG_PACKED ? (size_t)h->M_pad / 2 : (size_t)h->M_pad;
+        AMC_TRY(hipMalloc(&h->d_log, (size_t)h->log_depth * row_bytes));
+        AMC_TRY(hipMemsetAsync(h->d_log, 0, (size_t)h->log_depth * row_bytes, h->stream));
     }
     AMC_TRY(hipMalloc(&h->d_ptab, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_ptab, 0, (size_t)amc::PT_ROWS * AMC_MAX_MOVES * sizeof(double), h->stream));
@@ -1073,6 +1060,8 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_tot);
     (void)hipFree(h->d_acc16);
     (void)hipFree(h->d_tot16);
+    (void)hipFree(h->d_acc_hi);
+    (void)hipFree(h->d_tot_hi);
     (void)hipFree(h->d_log);
     (void)hipFree(h->d_ptab);
     (void)hipFree(h->d_pick);
@@ -1216,12 +1205,17 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
     { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     std::vector<uint32_t> buf((size_t)h->M);
     // one row of counters, whatever their width on the device, as int64
-    auto fetch_row = [&](const uint32_t* wide, const uint16_t* narrow, int k, int64_t* out) -> int {
+    auto fetch_row = [&](const uint32_t* wide, const uint16_t* narrow, const uint16_t* high, int k, int64_t* out) -> int {
         if (h->narrow) {
             uint16_t* b16 = reinterpret_cast<uint16_t*>(buf.data());
             AMC_HIP(hipMemcpyAsync(b16, narrow + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
             AMC_HIP(hipStreamSynchronize(h->stream));
             for (int64_t c = 0; c < h->M; ++c) out[c] = b16[(size_t)c];
+            if (h->use_high) {
+                AMC_HIP(hipMemcpyAsync(b16, high + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+                AMC_HIP(hipStreamSynchronize(h->stream));
+                for (int64_t c = 0; c < h->M; ++c) out[c] |= (int64_t)b16[(size_t)c] << 16;
+            }
         } else {
             AMC_HIP(hipMemcpyAsync(buf.data(), wide + (size_t)k * h->M_pad, (size_t)h->M * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
             AMC_HIP(hipStreamSynchronize(h->stream));
@@ -1231,12 +1225,12 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
     };
     for (int k = 0; k < h->K; ++k) {
         if (accepted) {
-            const int rc = fetch_row(h->d_acc, h->d_acc16, k, accepted + (int64_t)k * h->M);
+            const int rc = fetch_row(h->d_acc, h->d_acc16, h->d_acc_hi, k, accepted + (int64_t)k * h->M);
             if (rc != AMC_OK) return rc;
         }
         if (total) {
             if (k + 1 < h->K) {
-                const int rc = fetch_row(h->d_tot, h->d_tot16, k, total + (int64_t)k * h->M);
+                const int rc = fetch_row(h->d_tot, h->d_tot16, h->d_tot_hi, k, total + (int64_t)k * h->M);
                 if (rc != AMC_OK) return rc;
             } else {
                 // the last move: every chain has taken t_counted steps, its total_calls is what the other moves left
@@ -1261,10 +1255,12 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
         AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
         if (h->narrow)
             hipLaunchKernelGGL(amc::counter_totals_kernel<uint16_t>, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream,
-                               h->d_acc16, h->d_tot16, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
+                               h->d_acc16, h->d_tot16, h->use_high ? h->d_acc_hi : nullptr, h->use_high ? h->d_tot_hi : nullptr, h->M,
+                               h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
         else
             hipLaunchKernelGGL(amc::counter_totals_kernel<uint32_t>, dim3(grid_for(h, (h->M + 3) / 4)), dim3(AMC_BLOCK), 0, h->stream,
-                               h->d_acc, h->d_tot, h->M, h->M_pad, h->K, h->d_totals, h->d_totals + AMC_MAX_MOVES);
+                               h->d_acc, h->d_tot, (const uint16_t*)nullptr, (const uint16_t*)nullptr, h->M, h->M_pad, h->K, h->d_totals,
+                               h->d_totals + AMC_MAX_MOVES);
         AMC_HIP(hipGetLastError());
     }
     AMC_HIP(hipMemcpyAsync(host, h->d_totals, sizeof(host), hipMemcpyDeviceToHost, h->stream));
@@ -1290,14 +1286,12 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
 // the device are u32.  No chain's counter can exceed the number of counted steps, so the call that would take that number
 // past 2^32 - 1 is refused as a whole (nothing is launched) instead of letting a counter wrap silently.  The pool-wide
 // counter of a K = 1 handle without per-chain counters is 64-bit and has no such limit.
-// Handles that still keep their counters as u16 are widened here, before the call that would count past 65 535 steps.
+// Handles with u16 planes bring the high planes into play here, before the call that would count past 65 535 steps (rows
+// still waiting in the log are then folded by the carrying form as well: it starts from high halves that are zero).
 static int counter_room(amc_handle* h, const char* who, uint64_t steps)
 {
     if (!h->counters) return AMC_OK;
-    if (h->narrow && h->t_counted + steps > 0xFFFFull) {
-        const int rc = widen_counters(h);
-        if (rc != AMC_OK) return rc;
-    }
+    if (h->narrow && h->t_counted + steps > 0xFFFFull) h->use_high = true;
     if (h->t_counted + steps <= 0xFFFFFFFFull) return AMC_OK;
     return fail(AMC_ERR_STATE, "%s: the per-chain counters are 32-bit and hold %llu counted steps, %llu more would wrap them: download "
                                "the counters and restart the count (amc_upload_counters with zeros) first",
@@ -1408,15 +1402,9 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
     }
     AMC_HIP(hipSetDevice(h->device));
     h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
-    {   // the arrays take the width the new values allow (u16 while no counter can pass 65 535, see counter_room)
-        const bool narrow = narrow_counters_allowed(h) && steps <= 0xFFFFull && (uint64_t)acc_max <= steps;
-        if (narrow != h->narrow) {
-            AMC_HIP(hipStreamSynchronize(h->stream));
-            const hipError_t e = alloc_counters(h, narrow);
-            if (e != hipSuccess)
-                return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "amc_upload_counters: %s", hipGetErrorString(e));
-        }
-    }
+    // u16 planes: the high halves take part from now on unless no counter can have reached 2^16 (see counter_room); both
+    // planes are always written, so that halves which do not take part yet are zero when they do
+    if (h->narrow) h->use_high = steps > 0xFFFFull || (uint64_t)acc_max > steps;
     std::vector<uint32_t> buf((size_t)h->M);
     unsigned long long acc_sum = 0;
     for (int k = 0; k < h->K; ++k) {
@@ -1426,11 +1414,15 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
             uint16_t* b16 = reinterpret_cast<uint16_t*>(buf.data());
             for (int64_t c = 0; c < h->M; ++c) {
                 const int64_t v = src[(int64_t)k * h->M + c];
-                if (h->narrow) b16[(size_t)c] = (uint16_t)v; else buf[(size_t)c] = (uint32_t)v;
+                if (h->narrow) b16[(size_t)c] = (uint16_t)(v & 0xFFFF); else buf[(size_t)c] = (uint32_t)v;
                 if (pass == 0) acc_sum += (unsigned long long)v;
             }
             if (h->narrow) {
                 uint16_t* dst = (pass == 0 ? h->d_acc16 : h->d_tot16) + (size_t)k * h->M_pad;
+                AMC_HIP(hipMemcpyAsync(dst, b16, (size_t)h->M * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+                AMC_HIP(hipStreamSynchronize(h->stream));
+                for (int64_t c = 0; c < h->M; ++c) b16[(size_t)c] = (uint16_t)(src[(int64_t)k * h->M + c] >> 16);
+                dst = (pass == 0 ? h->d_acc_hi : h->d_tot_hi) + (size_t)k * h->M_pad;
                 AMC_HIP(hipMemcpyAsync(dst, b16, (size_t)h->M * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
             } else {
                 uint32_t* dst = (pass == 0 ? h->d_acc : h->d_tot) + (size_t)k * h->M_pad;
@@ -1914,8 +1906,9 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
+    // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
     const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
-                       std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+                       log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
     const bool fused_reduce = reduce && fused && h->K <= 4;
     int grid = 0;

@@ -514,25 +514,39 @@ __device__ __forceinline__ int categorical_walk(const double* s_tab, int K, doub
 }
 
 // Per-chain Move.accepted_calls / total_calls (metropolis.jl:208-209) are not read-modify-written by the sweep:
-// every MH step appends ONE byte per chain, (move index << 1) | accepted, to a step log (2 bytes per lane, 128
-// contiguous bytes per wave), and fold_log_kernel adds a batch of log rows into the u32 counters when somebody
-// asks for them or the log is full.  The counters themselves cost 16 K bytes of HBM traffic per chain and pass
-// (every line of every move's array is touched); the log costs 1.
+// every MH step appends (move index << 1) | accepted per chain to a step log, and fold_log_kernel adds a batch of log
+// rows into the counters when somebody asks for them or the log is full.  The counters themselves cost 16 K bytes of HBM
+// traffic per chain and pass (every line of every move's array is touched); the log costs 1 byte per chain and step --
+// and half a byte where the move index fits two bits (K <= AMC_PACKED_LOG_MOVES): the two chains of a lane then share
+// ONE byte, chain 0 in the low nibble (rows of m_stride / 2 bytes, 64 contiguous bytes per wave); otherwise one byte per
+// chain (rows of m_stride bytes, 128 per wave).  What the callback's fold reads is halved with it.
+#define AMC_PACKED_LOG_MOVES 4
+#define AMC_LOG_NONE 0
+#define AMC_LOG_PACKED 1      // K <= AMC_PACKED_LOG_MOVES
+#define AMC_LOG_BYTES 2       // K > AMC_PACKED_LOG_MOVES
+template <int LOG>
 __device__ __forceinline__ void store_log_pair(const SweepArgs& a, int row, int64_t p, uint32_t word)
 {
-    // write-through (sc1) like the positions: 10 MB of plain 2-byte stores per sweep stay dirty in the XCDs' L2s until the
+    // write-through (sc1) like the positions: plain stores would stay dirty in the XCDs' L2s until the
     // kernel boundary writes them back (K = 2 sweep 35.8 -> 35.2 us per launch incl. amortised folds, same-box A/B, round 3).
-    // The address lives on the scalar unit: p - threadIdx.x is block-uniform.
-    uint8_t* base = a.log + (int64_t)row * a.m_stride + 2 * (p - (int64_t)threadIdx.x);
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)word, r, threadIdx.x * 2, 0, 16);
+    // The address lives on the scalar unit: p - threadIdx.x is block-uniform.  word: chain 0 in bits 0..7, chain 1 in 8..15.
+    // (The form is a template argument: chosen from a.n_moves at run time the two stores cost the K = 2 launches 0.7-3 %.)
+    if (LOG == AMC_LOG_PACKED) {
+        uint8_t* base = a.log + (int64_t)row * (a.m_stride >> 1) + (p - (int64_t)threadIdx.x);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(word | (word >> 4)), r, threadIdx.x, 0, 16);
+    } else {
+        uint8_t* base = a.log + (int64_t)row * a.m_stride + 2 * (p - (int64_t)threadIdx.x);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)word, r, threadIdx.x * 2, 0, 16);
+    }
 }
 
 // `n_steps` fused MH steps of one chain pair held in registers (the body of mc_sweep!, metropolis.jl:205-210).
 // PRE: the draws of the (single) step were formed ahead by the caller and come in `pre`.
 // LOG: the step-log word of the pair; SINGLE launches hand it back in `log_word` (the caller stores it together
 // with x), multi-step launches store one word per step right away.
-template <int POT, bool MULTI, bool LOG, bool SINGLE, bool PRE = false>
+template <int POT, bool MULTI, int LOG, bool SINGLE, bool PRE = false>
 __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t b0, real_t b1, uint64_t pair,
                                            int64_t p, bool v0, bool v1, const double* s_tab, const uint8_t* s_pick,
                                            const double* s_math, double sigma1, double den1, double rden1, double logc1,
@@ -580,20 +594,20 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
         if (LOG) {
             // Move.accepted_calls += accepted; Move.total_calls += 1 (metropolis.jl:208-209), deferred: see above
             log_word = acc_bits | ((uint32_t)k0 << 1) | ((uint32_t)k1 << 9);
-            if (!SINGLE && v0) store_log_pair(a, a.log_pos + s, p, log_word);
+            if (!SINGLE && v0) store_log_pair<LOG>(a, a.log_pos + s, p, log_word);
         }
     }
 }
 
 // K1: the sweep.  make_step!(::Metropolis) metropolis.jl:302-309 -> mc_sweep! :203-212.
 // MULTI: K > 1 (categorical move pick, parameter table staged in LDS)
-// LOG: per-chain counters are kept (always when K > 1): one step-log byte per chain and MH step
+// LOG: per-chain counters are kept (always when K > 1): AMC_LOG_PACKED / AMC_LOG_BYTES, the step log's form (store_log_pair)
 // BETA: per-chain beta array
 // SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
 // REDUCE: also leave the callback sums of the state AFTER the sweep in red_partials (sum e, sum x, sum x^2, count;
 //         and, pool-wide counter only, the accepted total), so a sweep that is followed by callback_energy /
 //         callback_acceptance needs no second pass over x
-template <int POT, bool MULTI, bool LOG, bool BETA, bool SINGLE, bool REDUCE = false>
+template <int POT, bool MULTI, int LOG, bool BETA, bool SINGLE, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     // REDUCE with LOG (per-chain counters): rows carry the sums over x only; the acceptance ratios of the same
@@ -674,7 +688,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) {
             store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-            if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
+            if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
         const StepDraws dr = dr_nxt;
         uint32_t lw = 0;
@@ -700,7 +714,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         real2 xv = x_nxt;
         if (base_done >= 0) {
             store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-            if (LOG && SINGLE) store_log_pair(a, a.log_pos, base_done + threadIdx.x, lw_done);
+            if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, base_done + threadIdx.x, lw_done);
         }
         uint32_t lw = 0;
         pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         // a lone last chain (odd n_chains) writes its whole pair (x and log): the odd slot is padding
         if (v0) {
             store_pair_block_writethrough(a.x + 2 * base, xv);
-            if (LOG && SINGLE) store_log_pair(a, a.log_pos, p, lw);
+            if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, p, lw);
         }
         if (REDUCE) {
             const double x0 = xv.x, x1 = xv.y;
@@ -760,10 +774,11 @@ __device__ __forceinline__ unsigned long long add_block_accepts(unsigned long lo
 // so sum_k total_calls_ck == t_counted on every chain and the last move's count is t_counted minus the others -- one
 // read-modify-write array of four less at K = 2 (K == 1: none at all, total_calls is the step count).  Entries of the
 // padding behind n_chains are never read back as counts.
-// KS > 0: K == KS <= 4.  A block works on tiles of 4096 adjacent chains.  Log side: a thread owns SIXTEEN adjacent
-// chains -- one 16-byte load per row (the block reads 4 KiB of every row) -- and accumulates the rows bytewise in
-// packed registers: the accept bit and the move bits of four chains are masked out of a 32-bit word at once and added
-// as four 8-bit counters (n_rows <= 255), ~2 VALU operations per chain and row instead of 6 K.  Counter side: the
+// KS > 0: K == KS <= 4 (the packed log: two chains per byte).  A block works on tiles of 4096 adjacent chains.  Log side:
+// a thread owns SIXTEEN adjacent chains -- one 8-byte load per row (the block reads 2 KiB of every row) -- and accumulates
+// the rows bytewise in packed registers: the accept bit and the move bits of the four even (then the four odd) chains of a
+// 32-bit word are masked out at once and added as four 8-bit counters (n_rows <= 255), ~2 VALU operations per chain and row
+// instead of 6 K; one byte permute per word pair puts the counts back into chain order.  Counter side: the
 // packed words go through LDS so that lane t updates the quad of chains 4 (i 256 + t), i = 0..3 -- 16-byte
 // read-modify-writes that are contiguous across the wave (a thread updating its own sixteen chains would touch 16 bytes
 // in every 64).
@@ -772,10 +787,12 @@ __device__ __forceinline__ unsigned long long add_block_accepts(unsigned long lo
 // callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
 // 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
 // t_counted: MH steps counted per chain INCLUDING the rows of this launch (< 2^32: the host refuses to count further).
-// CT: the counters' storage type.  While fewer than 2^16 steps have been counted no counter exceeds 65 535, and handles with
-// K <= 4 keep them as u16 (the host widens the arrays to u32 once, before the step that would pass that mark): the callback's
-// fold is a bandwidth-bound read-modify-write of every counter, and half the bytes are half the time (22 instead of 34 bytes
-// per chain for ten rows at K = 2).
+// CT / HIGH: the counters' storage.  The callback's fold is a read-modify-write of every counter from HBM, so handles with
+// K <= 4 keep them as two u16 planes: `acc` / `tot` hold the low halves, `acc_hi` / `tot_hi` the high halves.  No counter can
+// exceed the number of steps counted, so while that is below 2^16 the high planes are all zero and the launch leaves them
+// alone (HIGH = false: 4 bytes per counter and fold); afterwards it READS the high half and writes it only where a low half
+// has just carried (HIGH = true: 6 bytes, against 8 for a u32 counter).  At K = 2 and ten packed rows that is 17 / 23 / 29
+// bytes per chain.  CT = uint32_t (K > 4, or AMC_WIDE_COUNTERS): plain u32 arrays, no planes.
 #define AMC_FOLD_TILE (16 * AMC_BLOCK)
 // four adjacent counters as one aligned access: 16 bytes of u32, 8 bytes of u16
 __device__ __forceinline__ uint4 load_counter_quad(const uint32_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -790,13 +807,35 @@ __device__ __forceinline__ void store_counter_quad(uint16_t* p, uint4 v)
     *reinterpret_cast<uint2*>(p) = uint2{v.x | (v.y << 16), v.z | (v.w << 16)};       // every value < 2^16 (see above)
 }
 
-template <int KS, bool RATIO = false, typename CT = uint32_t>
+// adds the 8-bit increments of `w` to a quad of counters; returns the quad's full values
+template <bool HIGH, typename CT>
+__device__ __forceinline__ uint4 bump_counter_quad(CT* lo, uint16_t* hi, uint32_t w)
+{
+    uint4 v = load_counter_quad(lo);
+    v.x += w & 0xFFu; v.y += (w >> 8) & 0xFFu; v.z += (w >> 16) & 0xFFu; v.w += w >> 24;
+    if (!HIGH) {
+        store_counter_quad(lo, v);                         // u32, or u16 that cannot carry yet
+        return v;
+    }
+    uint4 h = load_counter_quad(hi);
+    if (((v.x | v.y | v.z | v.w) >> 16) != 0u) {           // a low half has carried: rare (n_rows in 65 536 folds per counter)
+        h.x += v.x >> 16; h.y += v.y >> 16; h.z += v.z >> 16; h.w += v.w >> 16;
+        store_counter_quad(hi, h);
+    }
+    v.x &= 0xFFFFu; v.y &= 0xFFFFu; v.z &= 0xFFFFu; v.w &= 0xFFFFu;
+    store_counter_quad(lo, v);
+    return uint4{v.x | (h.x << 16), v.y | (h.y << 16), v.z | (h.z << 16), v.w | (h.w << 16)};
+}
+
+template <int KS, bool RATIO = false, typename CT = uint32_t, bool HIGH = false>
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, CT* acc,
-                                                              CT* tot, int64_t n_chains, int64_t m_stride,
+                                                              CT* tot, uint16_t* acc_hi, uint16_t* tot_hi,
+                                                              int64_t n_chains, int64_t m_stride,
                                                               int n_moves, uint64_t t_counted, double* ratio_partials,
                                                               int rp_stride)
 {
     static_assert(KS > 0 || sizeof(CT) == 4, "16-bit counters come with the register-resident fold (K <= 4)");
+    static_assert(!HIGH || sizeof(CT) == 2, "high planes belong to 16-bit low planes");
     static_assert(!RATIO || KS > 0, "ratio sums ride on the register-resident fold");
     if (KS > 0) {
         constexpr int KK = KS > 0 ? KS : 1;
@@ -818,9 +857,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pa[k][j] = pt[k][j] = 0u;
             if (log_ok) {
+                const int64_t row_bytes = m_stride >> 1;
                 for (int r = 0; r < n_rows; ++r) {
-                    const uint4 w4 = *reinterpret_cast<const uint4*>(log + (int64_t)r * m_stride + c_mine);
-                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(log + (int64_t)r * row_bytes + (c_mine >> 1));
+                    // accumulator j: word j / 2 of the load, its even (j even: low nibbles) or odd chains
+                    const uint32_t w[4] = {w2.x, w2.x >> 4, w2.y, w2.y >> 4};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t a = w[j] & ONES;                       // accepted
@@ -837,10 +878,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                     }
                 }
             }
+            // (even chains 0 2 4 6, odd chains 1 3 5 7) of a word -> chains 0..3 and 4..7
+            auto in_chain_order = [](const uint32_t (&v)[4]) {
+                return uint4{__builtin_amdgcn_perm(v[1], v[0], 0x05010400u), __builtin_amdgcn_perm(v[1], v[0], 0x07030602u),
+                             __builtin_amdgcn_perm(v[3], v[2], 0x05010400u), __builtin_amdgcn_perm(v[3], v[2], 0x07030602u)};
+            };
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
-                reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = uint4{pa[k][0], pa[k][1], pa[k][2], pa[k][3]};
-                if (k < KK - 1) reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = uint4{pt[k][0], pt[k][1], pt[k][2], pt[k][3]};
+                reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = in_chain_order(pa[k]);
+                if (k < KK - 1) reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = in_chain_order(pt[k]);
             }
             __syncthreads();
 #pragma unroll
@@ -851,18 +897,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                 uint32_t tsum[4] = {0u, 0u, 0u, 0u};           // total_calls of the moves before k, per chain of the quad
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
-                    const uint32_t wa = s_pk[2 * k][quad];
-                    CT* p_a = acc + (int64_t)k * m_stride + c0;
-                    uint4 va = load_counter_quad(p_a);
-                    va.x += wa & 0xFFu; va.y += (wa >> 8) & 0xFFu; va.z += (wa >> 16) & 0xFFu; va.w += wa >> 24;
-                    store_counter_quad(p_a, va);
+                    const int64_t at = (int64_t)k * m_stride + c0;
+                    const uint4 va = bump_counter_quad<HIGH>(acc + at, HIGH ? acc_hi + at : nullptr, s_pk[2 * k][quad]);
                     uint4 vt;
                     if (k < KK - 1) {
-                        const uint32_t wt = s_pk[2 * k + 1][quad];
-                        CT* p_t = tot + (int64_t)k * m_stride + c0;
-                        vt = load_counter_quad(p_t);
-                        vt.x += wt & 0xFFu; vt.y += (wt >> 8) & 0xFFu; vt.z += (wt >> 16) & 0xFFu; vt.w += wt >> 24;
-                        store_counter_quad(p_t, vt);
+                        vt = bump_counter_quad<HIGH>(tot + at, HIGH ? tot_hi + at : nullptr, s_pk[2 * k + 1][quad]);
                         tsum[0] += vt.x; tsum[1] += vt.y; tsum[2] += vt.z; tsum[3] += vt.w;
                     } else {
                         const uint32_t tc = (uint32_t)t_counted;
@@ -893,13 +932,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
             }
         }
     }
-}
-
-// u16 counters -> u32 counters, once in a handle's life (before the step that would count past 65 535)
-AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void widen_counters_kernel(const uint16_t* in, uint32_t* out, int64_t n)
-{
-    const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = in[i];
 }
 
 // K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
@@ -1192,8 +1224,8 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_ker
 // Exact integer totals of the per-chain counters (K > 1): out[k] += sum_c a[k][c].  16-byte loads, one atomic per
 // block and value (same-address atomics serialise at ~13 ns each: per-wave atomics from a full grid cost 0.2 ms here).
 template <typename CT>
-__global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc, const CT* tot,
-                                                                    int64_t n_chains, int64_t m_stride,
+__global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc, const CT* tot, const uint16_t* acc_hi,
+                                                                    const uint16_t* tot_hi, int64_t n_chains, int64_t m_stride,
                                                                     int n_moves, unsigned long long* out_acc,
                                                                     unsigned long long* out_tot)
 {
@@ -1203,9 +1235,16 @@ __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc
     for (int k = 0; k < n_moves; ++k) {
         unsigned long long sa = 0, st = 0;
         for (int64_t q = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; q < n_quads; q += stride) {
-            const uint4 va = load_counter_quad(acc + (int64_t)k * m_stride + 4 * q);
+            const int64_t at = (int64_t)k * m_stride + 4 * q;
+            const uint4 z4 = uint4{0u, 0u, 0u, 0u};
+            uint4 va = load_counter_quad(acc + at);
             // tot has n_moves - 1 rows (the last move's totals are the step count minus the others: the host completes them)
-            const uint4 vt = (tot && k + 1 < n_moves) ? load_counter_quad(tot + (int64_t)k * m_stride + 4 * q) : uint4{0u, 0u, 0u, 0u};
+            uint4 vt = (tot && k + 1 < n_moves) ? load_counter_quad(tot + at) : z4;
+            if (acc_hi) {                                      // u16 planes in use: full value = low | high << 16
+                const uint4 ha = load_counter_quad(acc_hi + at), ht = (tot && k + 1 < n_moves) ? load_counter_quad(tot_hi + at) : z4;
+                va = uint4{va.x | (ha.x << 16), va.y | (ha.y << 16), va.z | (ha.z << 16), va.w | (ha.w << 16)};
+                vt = uint4{vt.x | (ht.x << 16), vt.y | (ht.y << 16), vt.z | (ht.z << 16), vt.w | (ht.w << 16)};
+            }
             const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1486,9 +1525,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     auto mh = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, int64_t p, bool v0, bool v1) {
         uint32_t lw = 0;
         // SWEEP == 3: K == 1 with the pool-wide counter only -- no step log
-        pair_steps<POT, SWEEP == 2, SWEEP != 3, true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_pick, s_math, sw_sigma1, sw_den1,
+        pair_steps<POT, SWEEP == 2, (SWEEP != 3 ? AMC_LOG_PACKED : AMC_LOG_NONE), true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_pick, s_math, sw_sigma1, sw_den1,
                                                       sw_rden1, sw_logc1, wave_acc, lw, nullptr, mk);
-        if (SWEEP != 3 && v0) store_log_pair(sw, sw.log_pos, p, lw);
+        if (SWEEP != 3 && v0) store_log_pair<AMC_LOG_PACKED>(sw, sw.log_pos, p, lw);
     };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;

@@ -1083,9 +1083,10 @@ def test_per_chain_counters_refuse_to_wrap(gpu, K):
 
 @pytest.mark.parametrize("K", [1, 2, 3])
 def test_counters_across_the_16_bit_mark(gpu, oracle, K):
-    """Handles with K <= 4 keep their per-chain counters as u16 until the call that would count past 65 535 steps, then widen
-    them to u32 once (amc_api.hip counter_room): counts, acceptance sums and the states on both sides of the mark against
-    the oracle's increments, with neighbouring counters at 0xFFFF and 0 (the packing of the 16-bit quads)."""
+    """Handles with K <= 4 keep their per-chain counters as two u16 planes; the high plane stays out of the folds until the call
+    that would count past 65 535 steps (amc_api.hip counter_room) and is written only where a low half carries: counts,
+    acceptance sums and the states on both sides of the mark against the oracle's increments, with neighbouring counters at
+    0xFFFF and 0 (the packing of the 16-bit quads, carries in some lanes of a quad only)."""
     M = 2051
     sigma, weight = POOLS[K]
     kw = dict(potential="double_well", beta=2.0, sigma=sigma, weight=weight, seed=11)

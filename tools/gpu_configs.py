@@ -9,6 +9,7 @@ import montecarlo_amd as ma
 
 M = int(os.environ.get("M", 10_000_000)); steps = int(os.environ.get("STEPS", 1000))
 which = sys.argv[1] if len(sys.argv) > 1 else "3"
+PRECOUNT = int(os.environ.get("PRECOUNT", "0"))  # MH steps already counted per chain when the run starts (0: a fresh count)
 DEFER = os.environ.get("DEFER", "1") == "1"     # StoreCallbacks writes a row when the next one is due (default) / at once
 
 
@@ -16,11 +17,16 @@ def timed(chains, al, label, pool):
     with tempfile.TemporaryDirectory() as d:
         sim = ma.Simulation(chains, al, steps, path=d)
         for alg in sim.algorithms:          # compile / allocate outside the timed region
-            pass
+            if PRECOUNT and hasattr(alg, "engine"):
+                # start the count beyond the 16-bit mark: the regime a long run is in (high counter planes in use)
+                import numpy as np
+                tot = np.zeros((len(pool), M), dtype=np.int64)
+                tot[0] = PRECOUNT
+                alg.engine.upload_counters(np.zeros_like(tot), tot)
         t0 = time.perf_counter(); ma.run(sim); dt = time.perf_counter() - t0
         rows = open(os.path.join(d, "energy.dat")).read().strip().splitlines()
         acc = open(os.path.join(d, "acceptance.dat")).read().strip().splitlines()
-    print(f"{label}: M={M} steps={steps}: {dt / steps * 1e6:.1f} us/step  {M * steps / dt:.3e} chain-updates/s  "
+    print(f"{label}{f' precount={PRECOUNT}' if PRECOUNT else ''}: M={M} steps={steps}: {dt / steps * 1e6:.1f} us/step  {M * steps / dt:.3e} chain-updates/s  "
           f"sigma={[round(m.sigma, 4) for m in pool]}  last energy row '{rows[-1]}'  acceptance '{acc[-1]}'", flush=True)
 
 

@@ -18,8 +18,8 @@ G = os.path.join(ROOT, "gpurun_out", TAG)
 OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
 os.makedirs(OUT, exist_ok=True)
 ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
-              "k2": 17 * 10_000_000, "pgmc": 17 * 10_000_000, "est": 16 * 10_000_000}
-MAIN = {"ladder": "sweep_kernel<0, false, false, false, true, false>", "k2": "sweep_kernel<1, true, true, false, true",
+              "k2": 165_000_000, "pgmc": 165_000_000, "est": 16 * 10_000_000}     # 16 B of state + half a step-log byte per update
+MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, false>", "k2": "sweep_kernel<1, true, 1, false, true",
         "pgmc": "pg_estimate_kernel<0, 1, false, 2, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false>"}
 
 
@@ -86,7 +86,7 @@ for wl in ALGO_BYTES:
         d["wait_inst_any_over_wave_cycles"] = counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
         d["wait_any_over_wave_cycles"] = counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
     if "SQ_INSTS_VALU" in counters and meta:
-        m_pairs = ALGO_BYTES[wl] // (16 if wl != "k2" and wl != "pgmc" else 17) // 2
+        m_pairs = (10_000_000 if wl in ("k2", "pgmc") else ALGO_BYTES[wl] // 16) // 2
         d["valu_insts_per_pair_step"] = counters["SQ_INSTS_VALU"] * 64.0 / m_pairs / 64.0 * 64.0 / 64.0 * 1.0
         d["valu_insts_per_wave_iteration"] = counters["SQ_INSTS_VALU"] / (m_pairs / 64.0)
         for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
