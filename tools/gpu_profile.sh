@@ -21,7 +21,8 @@ for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "es
   rocprofv3 --kernel-trace --stats -d $O/$tag/trace --output-format csv -- $W $wl > $O/$tag.log 2>&1
   case $wl in k2|pgmc) PIPELINED=0 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled, callback read at once: /' >> $O/$tag.log
                        PIPELINED=1 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled: /' >> $O/$tag.log
-                       AMC_WIDE_COUNTERS=1 PIPELINED=1 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled, u32 counters from the start (the regime after 65535 counted steps): /' >> $O/$tag.log;; esac
+                       PRECOUNT=70000 PIPELINED=1 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled, 70000 steps counted before (the regime after the 16-bit mark): /' >> $O/$tag.log
+                       PRECOUNT=70000 rocprofv3 --kernel-trace --stats -d $O/${tag}_late/trace --output-format csv -- $W $wl > /dev/null 2>&1;; esac
   LAUNCHES=120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/$tag/pmc_fetch --output-format csv -- $W $wl > /dev/null 2>&1
   LAUNCHES=120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/$tag/pmc_write --output-format csv -- $W $wl > /dev/null 2>&1
   LAUNCHES=120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/$tag/pmc_sq --output-format csv -- $W $wl > /dev/null 2>&1

@@ -13,7 +13,17 @@ from montecarlo_amd import _capi as A
 
 mode = sys.argv[1]
 n = int(os.environ.get("LAUNCHES", "300"))
+PRECOUNT = int(os.environ.get("PRECOUNT", "0"))       # MH steps already counted per chain (K = 2 workloads): 70000 = beyond the 16-bit mark
 PIPELINED = os.environ.get("PIPELINED", "0") == "1"     # read a callback's sums while the next period's launches are queued
+
+
+def precount(e, m):
+    """Start the count beyond the 16-bit mark (PRECOUNT=70000): the regime of a long run, high counter planes in use."""
+    if PRECOUNT:
+        import numpy as np
+        tot = np.zeros((2, m), dtype=np.int64)
+        tot[0] = PRECOUNT
+        e.upload_counters(np.zeros_like(tot), tot)
 
 
 def spin(e, seconds=0.5):
@@ -41,6 +51,7 @@ elif mode == "k2":
     M = 10_000_000
     e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
     e.init_uniform(-2, 2)
+    precount(e, M)
     spin(e)
     for rep in range(2):
         e.timing_begin()
@@ -63,6 +74,7 @@ elif mode in ("pgmc", "est"):
     M = 10_000_000
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
     e.init_uniform(-2, 2)
+    precount(e, M)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.5:
         (e.pgmc_steps(20, [1], 1, [1], [0.0], [0.0]) if mode == "pgmc" else [e.pg_accumulate([1], 1) for _ in range(20)])

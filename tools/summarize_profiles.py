@@ -46,6 +46,9 @@ for wl in ALGO_BYTES:
     if not f:
         continue
     shutil.copy(f, os.path.join(OUT, f"{TAG}_{wl}_kernel_stats.csv"))
+    late = one(os.path.join(G, wl + "_late", "trace", "*", "*_kernel_stats.csv"))      # the same workload past the 16-bit mark
+    if late:
+        shutil.copy(late, os.path.join(OUT, f"{TAG}_{wl}_late_kernel_stats.csv"))
     main = MAIN[wl.split("_")[0]]
     entry = collections.OrderedDict()
     rows = [r for r in csv.DictReader(open(f)) if main in r["Name"]]
