@@ -113,7 +113,7 @@ struct amc_handle {
     uint16_t* d_tot_hi = nullptr;
     bool narrow = false;
     bool use_high = false;
-    uint8_t* d_log = nullptr;   // [log_depth][M_pad] step log: (move << 1) | accepted per chain and MH step
+    uint8_t* d_log = nullptr;   // [log_depth][M_pad / 2 or M_pad] step log: (move << 1) | accepted per chain and MH step (log_form)
     int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
     double* d_ptab = nullptr;
@@ -880,8 +880,9 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMemsetAsync(h->d_x, 0, (size_t)h->M_pad * sizeof(double), h->stream));
     if (h->counters) {
         AMC_TRY(alloc_counters(h, narrow_counters_allowed(h)));
-        // One byte per chain and MH step; folding costs a read-modify-write of every counter (16 K bytes per chain), so a
-        // deeper log amortises it over more steps: 128 rows where they fit in 2 GiB (1.28 GB at 1e7 chains), never below 16.
+        // Half a byte (K <= 4) or one byte per chain and MH step; folding costs a read-modify-write of every counter, so a
+        // deeper log amortises it over more steps: 128 rows where rows of one byte per chain fit in 2 GiB (0.64 / 1.28 GB at
+        // 1e7 chains), never below 16.
         {
             const int64_t fit = (int64_t)(2147483648ll / h->M_pad);
             h->log_depth = (int)(fit > 128 ? 128 : (fit < 16 ? 16 : fit));

@@ -215,8 +215,9 @@ def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
 @pytest.mark.parametrize("depth", [1, 3, 255])
 @pytest.mark.parametrize("K,fused", [(1, False), (2, False), (2, True), (7, True)])
 def test_step_log_depths(gpu, oracle, monkeypatch, depth, K, fused):
-    """Per-chain counters go through the step log (one byte per chain and MH step) and are folded into acc/tot on
-    demand or when the log is full: every depth, single-step and multi-step launches, register and generic fold."""
+    """Per-chain counters go through the step log (a nibble per chain and MH step up to four moves, a byte beyond) and are
+    folded into acc/tot on demand or when the log is full: every depth, single-step and multi-step launches, register and
+    generic fold."""
     monkeypatch.setenv("AMC_LOG_DEPTH", str(depth))
     e, o = run_pair(gpu, oracle, 1001, K, "double_well", 11, sweepstep=2, fused=fused)
     assert_same(e, o)
