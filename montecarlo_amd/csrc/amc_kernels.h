@@ -858,8 +858,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                 for (int j = 0; j < 4; ++j) pa[k][j] = pt[k][j] = 0u;
             if (log_ok) {
                 const int64_t row_bytes = m_stride >> 1;
-                for (int r = 0; r < n_rows; ++r) {
-                    const uint2 w2 = *reinterpret_cast<const uint2*>(log + (int64_t)r * row_bytes + (c_mine >> 1));
+                const uint8_t* mine = log + (c_mine >> 1);
+                auto add_row = [&](const uint2 w2) {
                     // accumulator j: word j / 2 of the load, its even (j even: low nibbles) or odd chains
                     const uint32_t w[4] = {w2.x, w2.x >> 4, w2.y, w2.y >> 4};
 #pragma unroll
@@ -876,7 +876,21 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
                             pa[k][j] += eq[k] & a;
                         }
                     }
+                };
+                // Rows in flight per lane: with one, a wave has 512 bytes outstanding and the launch waits for latency (the full
+                // 128-row fold moved 0.76 GB in 202 us; four in flight: 154 us).  The callback's form needs its registers for
+                // the counter side (83 VGPRs with four): two in flight there (ten-row launch 35.0-35.7 -> 33.7 us before the
+                // 16-bit mark, 41.5 -> 39-40 after; same box).
+                constexpr int U = RATIO ? 2 : 4;
+                int r = 0;
+                for (; r + U <= n_rows; r += U) {
+                    uint2 w[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const uint2*>(mine + (int64_t)(r + u) * row_bytes);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) add_row(w[u]);
                 }
+                for (; r < n_rows; ++r) add_row(*reinterpret_cast<const uint2*>(mine + (int64_t)r * row_bytes));
             }
             // (even chains 0 2 4 6, odd chains 1 3 5 7) of a word -> chains 0..3 and 4..7
             auto in_chain_order = [](const uint32_t (&v)[4]) {
