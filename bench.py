@@ -182,7 +182,7 @@ def ladder(A, sizes, device, reps=5):
 def other_configs(A, m, device, periods=40):
     """BASELINE configs 3 and 5 end to end at this ensemble size, next to the headline (never part of `value`): one launch per
     time step, callbacks (energy + acceptance) every 10 time steps, each callback's sums read one period late -- the form
-    the host mirror's StoreCallbacks uses.  HIP events over `periods` callback periods, after as many untimed.
+    the host mirror's StoreCallbacks uses.  HIP events over `periods` callback periods, after at least as many (and 0.35 s) untimed.
     Two figures each: K <= 4 handles keep their per-chain counters as two u16 planes, and for the first 65 535 counted steps
     the callback's fold leaves the (all-zero) high plane alone -- 17 bytes per chain against 23 afterwards;
     `us_per_time_step` is the regime after the mark (what a long run sees), `us_per_time_step_first_65535_steps` the one before."""
@@ -199,16 +199,20 @@ def other_configs(A, m, device, periods=40):
         del tot
         return measure(e, period), early
 
-    def measure(e, period):
+    def measure(e, period, spinup_s=0.35):
         for timed in (False, True):
             pending = False
             if timed:
                 e.timing_begin()
-            for _ in range(periods):
+            n, t0 = 0, time.perf_counter()
+            # untimed: at least `periods`, and long enough for the clock to come back up after the idle seconds of set-up
+            # (allocation, the counter upload); a few thousand steps, far below the 65 535 of the first regime
+            while n < periods or (not timed and time.perf_counter() - t0 < spinup_s):
                 if pending:
                     e.reduce_end()
                 period(e)
                 pending = True
+                n += 1
             if pending:
                 e.reduce_end()
             if timed:
