@@ -11,8 +11,10 @@ particle_1d harmonic, beta = 2, one Gaussian displacement sigma = 0.1, M = 1e7 c
 synthetic ensemble x0 ~ U(-2, 2) generated on device (inputs resident in HBM before the timed region).
 For N > 1 (configs[3]) the ensemble is N x 1e7 chains sharded by global chain id (weak scaling) and
 the energy/acceptance callbacks are all-reduced over RCCL every 10 sweeps inside the timed region -- by the engines' own
-communicator (amc_comm_init / amc_allreduce_sum, on a communication stream of the engine's own); the launcher's TCP store
-carries the ncclUniqueId, the barriers and the max over ranks.  No torch process group, no torch tensors.  config.rccl_ranks is
+communicator (amc_comm_init / amc_allreduce_sum, on a communication stream of the engine's own), which also carries the barriers
+around the timed region (one 8-byte all-reduce each; every rank stamps its own K steps after its own synchronize, the
+job's time is the MAX over ranks); the launcher's TCP store carries the ncclUniqueId, the set-up barriers and the max over
+ranks.  No torch process group, no torch tensors.  config.rccl_ranks is
 what ncclCommCount reports for that communicator; the RCCL / HIP runtime versions and files really bound are in the line too.
 
 Rank 0 prints ONE JSON line.  Extra objects:
@@ -355,22 +357,37 @@ def main():
         else:
             eng.sweep(1)
 
-    def barrier():
+    def local_sync():
         eng.sync()                           # everything this rank has queued is done (sweeps: engine's stream; the callback sums' all-reduce is host-synchronous)
+
+    def barrier():
+        """torch.cuda.synchronize() + barrier of the contract: this rank's queue drained, then all ranks meet -- in ONE
+        tiny all-reduce of the engines' communicator where there is one (tens of microseconds), over the launcher's TCP
+        store otherwise (milliseconds: a 20-step timed region is 0.6 ms)."""
+        local_sync()
         if grp is not None:
-            grp.barrier()
+            if getattr(eng, "comm_connected", False):
+                eng.allreduce_sum([0.0])
+            else:
+                grp.barrier()
 
     t_spin = time.perf_counter()                 # clock ramp (untimed), then the W warm-up steps
-    while time.perf_counter() - t_spin < args.spinup_s:
-        for _ in range(200):
-            eng.sweep(1)
-        eng.sync()
-    if cb_every:
-        # one untimed callback cycle, whatever W is: the driver's W = 5 never reaches a callback step, and the first launch of
-        # the sum-forming kernel form and the first real all-reduce would otherwise fall into a 20-step timed region
-        eng.sweep_reduce_begin(1)
-        pending[0] = True
+    while True:
+        # with callbacks: the very steps of the timed loop, callbacks included -- whatever W is (the driver's W = 5 never
+        # reaches a callback step), the first launch of the sum-forming kernel form and the first real all-reduces happen here;
+        # so does a one-off of the runtime: some 200 of a process's first few hundred all-reduces beside a busy stream take
+        # ~0.2 ms longer each (40 ms in all, seen with RCCL and with the shared-memory stand-in alike, profiles/NOTES_r03.md)
+        for i in range(200):
+            step(i) if cb_every else eng.sweep(1)
         finish_callback()
+        eng.sync()
+        time_up = time.perf_counter() - t_spin >= args.spinup_s
+        if grp is None:
+            if time_up:
+                break
+        # every rank must leave after the same number of collectives: the ranks agree through one more of them
+        elif sharding.allreduce_sum([1.0 if time_up else 0.0], eng)[0] >= world:
+            break
     for i in range(args.warmup):
         step(i)
     finish_callback()
@@ -381,8 +398,9 @@ def main():
         step(i)
     finish_callback()                      # the last callback's all-reduce belongs to the timed region
     eng.timing_mark()                      # end event behind the K-th launch (asynchronous) ...
-    barrier()
-    elapsed = time.perf_counter() - t0
+    local_sync()
+    elapsed = time.perf_counter() - t0     # this rank's K steps, done; the MAX over ranks below is the job's time
+    barrier()                              # the closing barrier of the bracket (its own latency is no part of any rank's steps)
     event_ms = eng.timing_end()            # ... HIP events on the engine's stream, bracketing exactly the K launches
     if grp is not None:
         both = grp.allgather((elapsed, event_ms))              # max over ranks
@@ -397,7 +415,7 @@ def main():
         for i in range(args.steps):
             step(i)
         finish_callback()
-        barrier()
+        local_sync()
         rep_ms.append((time.perf_counter() - r0) * 1e3 / args.steps)
     if grp is not None and rep_ms:
         rep_ms = [max(col) for col in zip(*grp.allgather(rep_ms))]

@@ -141,6 +141,7 @@ struct amc_handle {
     uint64_t red_t_counted = 0;
     void* comm = nullptr;
     double* d_comm = nullptr;
+    double* h_comm = nullptr;            // pinned staging of amc_allreduce_sum's values (the caller's buffer is pageable)
     hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
     hipEvent_t ev_comm_main = nullptr;   // behind the last collective queued on the engine's stream (the estimator's all-reduce)
     bool comm_main_pending = false;      // ... which comm_stream has not been ordered behind yet
@@ -2075,6 +2076,8 @@ static void comm_release(amc_handle* h)
     h->comm_main_pending = false;
     (void)hipFree(h->d_comm);
     h->d_comm = nullptr;
+    (void)hipHostFree(h->h_comm);
+    h->h_comm = nullptr;
 }
 
 int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
@@ -2088,6 +2091,8 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
     // everything the communicator's users need exists BEFORE the communicator does: a failure below leaves the handle
     // a clean single shard (amc_allreduce_sum the identity again, a later amc_comm_init welcome)
     hipError_t he = hipMalloc(&h->d_comm, 256 * sizeof(double));
+    if (he == hipSuccess) he = hipHostMalloc(&h->h_comm, 256 * sizeof(double), hipHostMallocDefault);
+    // (a higher stream priority changes nothing for these few bytes between device-filling sweeps: measured, round 3)
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&h->ev_comm_main, hipEventDisableTiming);
     if (he != hipSuccess) {
@@ -2178,11 +2183,13 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
         AMC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_comm_main, 0));
         h->comm_main_pending = false;
     }
-    AMC_HIP(hipMemcpyAsync(h->d_comm, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
+    std::memcpy(h->h_comm, buf, (size_t)n * sizeof(double));
+    AMC_HIP(hipMemcpyAsync(h->d_comm, h->h_comm, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
     const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->comm_stream);
     if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    AMC_HIP(hipMemcpyAsync(buf, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
+    AMC_HIP(hipMemcpyAsync(h->h_comm, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
     AMC_HIP(hipStreamSynchronize(h->comm_stream));
+    std::memcpy(buf, h->h_comm, (size_t)n * sizeof(double));
     return AMC_OK;
 }
 
