@@ -386,7 +386,7 @@ def main():
             if time_up:
                 break
         # every rank must leave after the same number of collectives: the ranks agree through one more of them
-        elif sharding.allreduce_sum([1.0 if time_up else 0.0], eng)[0] >= world:
+        elif sharding.all_ranks(time_up, eng):
             break
     for i in range(args.warmup):
         step(i)

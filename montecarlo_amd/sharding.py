@@ -235,6 +235,14 @@ def allreduce_sum(values: np.ndarray, engine=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
+def all_ranks(flag: bool, engine=None) -> bool:
+    """True on every rank iff every rank passed a true flag -- ONE small sum over the ranks (the engine's communicator when it
+    has one).  For loops whose exit depends on something local, a clock say: every rank must leave after the same number of
+    collectives, so the ranks decide together."""
+    _, size = world()
+    return bool(allreduce_sum(np.array([1.0 if flag else 0.0]), engine)[0] >= size)
+
+
 def barrier() -> None:
     _, size = world()
     if _group is not None:

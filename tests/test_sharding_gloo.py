@@ -151,6 +151,13 @@ uid = g.broadcast(bytes(range(128)) if g.rank == 0 else None)
 assert uid == bytes(range(128))
 s = sharding.allreduce_sum(np.array([1.0 + g.rank, 0.5, -g.rank]))
 assert list(s) == [3.0, 1.0, -1.0]
+# a loop whose exit condition is local (bench.py's spin-up clock): the ranks leave after the same number of rounds
+rounds = 0
+while True:
+    rounds += 1
+    if sharding.all_ranks(rounds >= 2 + 3 * g.rank):
+        break
+assert g.allgather(rounds) == [5, 5]
 sharding.barrier()
 json.dump(dict(ok=True), open(os.path.join({str(tmp_path)!r}, f"sg{{g.rank}}.json"), "w"))
 """)
