@@ -375,8 +375,8 @@ def main():
     while True:
         # with callbacks: the very steps of the timed loop, callbacks included -- whatever W is (the driver's W = 5 never
         # reaches a callback step), the first launch of the sum-forming kernel form and the first real all-reduces happen here;
-        # so does a one-off of the runtime: some 200 of a process's first few hundred all-reduces beside a busy stream take
-        # ~0.2 ms longer each (40 ms in all, seen with RCCL and with the shared-memory stand-in alike, profiles/NOTES_r03.md)
+        # so does a one-off of the stack: some 0.1-0.2 s into a process's first callback-bearing steps the queue stands still
+        # once for 30-50 ms (one gap in the kernel trace, with or without a communicator; profiles/NOTES_r03.md)
         for i in range(200):
             step(i) if cb_every else eng.sweep(1)
         finish_callback()
