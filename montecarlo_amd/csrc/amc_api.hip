@@ -199,7 +199,7 @@ int push_params(amc_handle* h, const double* sigma, const double* weight)
     return AMC_OK;
 }
 
-// The step log's form (store_log_pair): none without per-chain counters, two chains per byte while the move index fits two
+// The step log's form (store_log_pair): none without per-chain counters, two chains per byte while the move index fits three
 // bits, one byte per chain beyond.
 static int log_form(const amc_handle* h)
 {
@@ -274,7 +274,25 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
         case 2: AMC_FOLD(2, false); break;
         case 3: AMC_FOLD(3, false); break;
         case 4: AMC_FOLD(4, false); break;
-        default: AMC_FOLD_W(0, false); break;
+        default:
+            if (log_form(h) == AMC_LOG_PACKED) {
+                // 5..8 moves: two passes with the registers of the four-move form (fold_log_kernel<.., HALF>)
+                uint32_t* const acc_hi4 = h->d_acc + 4 * (size_t)h->M_pad;
+                uint32_t* const tot_hi4 = h->d_tot + 4 * (size_t)h->M_pad;
+#define AMC_FOLD_HALF(KS, HALF, ACC, TOT)                                                                             \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, false, uint32_t, false, HALF>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, ACC, TOT, no_hi, no_hi, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+                AMC_FOLD_HALF(4, 1, h->d_acc, h->d_tot);
+                switch (h->K - 4) {
+                case 1: AMC_FOLD_HALF(1, 2, acc_hi4, tot_hi4); break;
+                case 2: AMC_FOLD_HALF(2, 2, acc_hi4, tot_hi4); break;
+                case 3: AMC_FOLD_HALF(3, 2, acc_hi4, tot_hi4); break;
+                default: AMC_FOLD_HALF(4, 2, acc_hi4, tot_hi4); break;
+                }
+#undef AMC_FOLD_HALF
+            } else
+                AMC_FOLD_W(0, false);
+            break;
         }
     }
 #undef AMC_FOLD
@@ -881,7 +899,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMemsetAsync(h->d_x, 0, (size_t)h->M_pad * sizeof(double), h->stream));
     if (h->counters) {
         AMC_TRY(alloc_counters(h, narrow_counters_allowed(h)));
-        // Half a byte (K <= 4) or one byte per chain and MH step; folding costs a read-modify-write of every counter, so a
+        // Half a byte (K <= 8) or one byte per chain and MH step; folding costs a read-modify-write of every counter, so a
         // deeper log amortises it over more steps: 128 rows where rows of one byte per chain fit in 2 GiB (0.64 / 1.28 GB at
         // 1e7 chains), never below 16.
         {

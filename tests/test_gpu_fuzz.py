@@ -1,7 +1,7 @@
 """Differential fuzz of the HIP path against the CPU oracle: random configurations, random sequences of operations.
 
 The parity tests elsewhere pick their shapes by hand (BASELINE configs, boundary sizes, edge values); this one draws them:
-pool size 1..8 with arbitrary (normalised) weights -- cumulative weights that are no multiples of 2^-12 open cells of the
+pool size 1..11 with arbitrary (normalised) weights -- cumulative weights that are no multiples of 2^-12 open cells of the
 pick table --, sigma over four decades, beta over two, both potentials, ragged ensemble sizes, shards that start at an
 arbitrary EVEN global chain id far from 0, sweepstep 1..4, Float64 and Float32 state, K = 1 with and without per-chain
 counters; then a random walk over {single-step launch, multi-step launch, callback reduction, sweep with the reduction
@@ -28,7 +28,7 @@ def bits(a, dtype):
 
 
 def draw_case(rng, sizes=(1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 513, 1000, 2049, 4099, 6001)):
-    K = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 8]))
+    K = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 6, 7, 8, 11]))      # register fold (<= 4), its two-pass form (5..8), generic fold (> 8)
     w = rng.dirichlet(np.ones(K) * rng.choice([0.5, 1.0, 5.0]))
     if rng.random() < 0.3:                                   # weights on the 2^-12 grid: every cell of the pick table closed
         w = np.maximum(1, np.round(w * 4096)) / 4096
