@@ -247,11 +247,11 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     const int grid = (int)((n_tiles + rounds - 1) / rounds);
     uint16_t* const no_hi = nullptr;
 #define AMC_FOLD_W(KS, RATIO)                                                                                         \
-    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t, false>), dim3(KS ? grid : h->red_blocks), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, h->d_acc, h->d_tot, no_hi, no_hi, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, h->d_acc, h->d_tot, no_hi, no_hi, h->M, h->M_pad, 0, h->t_counted, h->h_ratio, RATIO_STRIDE)
 #define AMC_FOLD_N(KS, RATIO, HIGH)                                                                                   \
     hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint16_t, HIGH>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->d_acc_hi, h->d_tot_hi, h->M, h->M_pad, h->K, h->t_counted, \
+                       h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->d_acc_hi, h->d_tot_hi, h->M, h->M_pad, 0, h->t_counted, \
                        h->h_ratio, RATIO_STRIDE)
 #define AMC_FOLD(KS, RATIO)                                                                                           \
     do {                                                                                                              \
@@ -274,25 +274,30 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
         case 2: AMC_FOLD(2, false); break;
         case 3: AMC_FOLD(3, false); break;
         case 4: AMC_FOLD(4, false); break;
-        default:
-            if (log_form(h) == AMC_LOG_PACKED) {
-                // 5..8 moves: two passes with the registers of the four-move form (fold_log_kernel<.., HALF>)
-                uint32_t* const acc_hi4 = h->d_acc + 4 * (size_t)h->M_pad;
-                uint32_t* const tot_hi4 = h->d_tot + 4 * (size_t)h->M_pad;
-#define AMC_FOLD_HALF(KS, HALF, ACC, TOT)                                                                             \
-    hipLaunchKernelGGL((amc::fold_log_kernel<KS, false, uint32_t, false, HALF>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, ACC, TOT, no_hi, no_hi, h->M, h->M_pad, h->K, h->t_counted, h->h_ratio, RATIO_STRIDE)
-                AMC_FOLD_HALF(4, 1, h->d_acc, h->d_tot);
-                switch (h->K - 4) {
-                case 1: AMC_FOLD_HALF(1, 2, acc_hi4, tot_hi4); break;
-                case 2: AMC_FOLD_HALF(2, 2, acc_hi4, tot_hi4); break;
-                case 3: AMC_FOLD_HALF(3, 2, acc_hi4, tot_hi4); break;
-                default: AMC_FOLD_HALF(4, 2, acc_hi4, tot_hi4); break;
-                }
-#undef AMC_FOLD_HALF
-            } else
-                AMC_FOLD_W(0, false);
+        default: {
+            // more than four moves: ceil(K / 4) passes of the four-move form, one per group of moves (fold_log_kernel<.., GROUP>)
+            const bool bytes = log_form(h) == AMC_LOG_BYTES;
+            const int n_groups = (h->K + 3) / 4;
+#define AMC_FOLD_GROUP(KS, GROUP, BYTES)                                                                              \
+    hipLaunchKernelGGL((amc::fold_log_kernel<KS, false, uint32_t, false, GROUP, BYTES>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
+                       h->d_log, h->log_fill, acc_g, tot_g, no_hi, no_hi, h->M, h->M_pad, g, h->t_counted, h->h_ratio, RATIO_STRIDE)
+#define AMC_FOLD_GROUPS(BYTES)                                                                                        \
+    for (int g = 0; g < n_groups; ++g) {                                                                              \
+        uint32_t* const acc_g = h->d_acc + 4 * (size_t)g * (size_t)h->M_pad;                                          \
+        uint32_t* const tot_g = h->d_tot + 4 * (size_t)g * (size_t)h->M_pad;                                          \
+        if (g + 1 < n_groups) AMC_FOLD_GROUP(4, 1, BYTES);                                                            \
+        else switch (h->K - 4 * g) {                                                                                  \
+            case 1: AMC_FOLD_GROUP(1, 2, BYTES); break;                                                               \
+            case 2: AMC_FOLD_GROUP(2, 2, BYTES); break;                                                               \
+            case 3: AMC_FOLD_GROUP(3, 2, BYTES); break;                                                               \
+            default: AMC_FOLD_GROUP(4, 2, BYTES); break;                                                              \
+        }                                                                                                             \
+    }
+            if (bytes) { AMC_FOLD_GROUPS(true) } else { AMC_FOLD_GROUPS(false) }
+#undef AMC_FOLD_GROUPS
+#undef AMC_FOLD_GROUP
             break;
+        }
         }
     }
 #undef AMC_FOLD

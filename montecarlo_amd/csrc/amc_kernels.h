@@ -774,16 +774,16 @@ __device__ __forceinline__ unsigned long long add_block_accepts(unsigned long lo
 // so sum_k total_calls_ck == t_counted on every chain and the last move's count is t_counted minus the others -- one
 // read-modify-write array of four less at K = 2 (K == 1: none at all, total_calls is the step count).  Entries of the
 // padding behind n_chains are never read back as counts.
-// KS > 0: K == KS <= 4 (the packed log: two chains per byte).  A block works on tiles of 4096 adjacent chains.  Log side:
-// a thread owns SIXTEEN adjacent chains -- one 8-byte load per row (the block reads 2 KiB of every row) -- and accumulates
-// the rows bytewise in packed registers: the accept bit and the move bits of the four even (then the four odd) chains of a
-// 32-bit word are masked out at once and added as four 8-bit counters (n_rows <= 255), ~2 VALU operations per chain and row
-// instead of 6 K; one byte permute per word pair puts the counts back into chain order.  Counter side: the
+// KS moves per launch (K == KS <= 4 in one pass; more moves: GROUP below).  A block works on tiles of 4096 adjacent chains.
+// Log side: a thread owns SIXTEEN adjacent chains -- one 8-byte load per row of the nibble log (the block reads 2 KiB of every
+// row), one 16-byte load of the byte log -- and accumulates the rows bytewise in packed registers: the accept bit and the move
+// bits of four chains (nibble log: the four even, then the four odd chains of a word) are masked out at once and added as
+// four 8-bit counters (n_rows <= 255), ~2 VALU operations per chain and row instead of 6 K; one byte permute per word pair
+// puts the nibble log's counts back into chain order.  Counter side: the
 // packed words go through LDS so that lane t updates the quad of chains 4 (i 256 + t), i = 0..3 -- 16-byte
 // read-modify-writes that are contiguous across the wave (a thread updating its own sixteen chains would touch 16 bytes
 // in every 64).
-// KS == 0: any K, one chain per thread, one read-modify-write per logged step.
-// RATIO (KS > 0): the counters are in registers right after the update, so the launch also forms
+// RATIO: the counters are in registers right after the update, so the launch also forms
 // callback_acceptance's sums  sum_c accepted_ck / total_ck  (metropolis.jl:319-321; Int/Int -> Float64 division,
 // 0/0 = NaN) -- block partials [grid][rp_stride] -- instead of a reduction pass re-reading 8 K bytes per chain.
 // t_counted: MH steps counted per chain INCLUDING the rows of this launch (< 2^32: the host refuses to count further).
@@ -827,134 +827,153 @@ __device__ __forceinline__ uint4 bump_counter_quad(CT* lo, uint16_t* hi, uint32_
     return uint4{v.x | (h.x << 16), v.y | (h.y << 16), v.z | (h.z << 16), v.w | (h.w << 16)};
 }
 
-// HALF (pools of 5..8 moves, whose move index has a third bit): the launch counts only the steps of moves 0..3 (HALF = 1, KS = 4:
-// every one of them has a total array) or of moves 4..K-1 (HALF = 2, KS = K - 4, acc / tot point at move 4's rows) -- two
-// passes over the log with the registers of the K <= 4 form, instead of one read-modify-write per chain and logged step
-// (KS = 0: 12 ms per 128 rows at 1e7 chains, 94 us per sweep).
-template <int KS, bool RATIO = false, typename CT = uint32_t, bool HIGH = false, int HALF = 0>
+// GROUP passes (pools of more than four moves): the register-resident form counts four moves per launch.  GROUP = 0: the whole
+// pool in one pass (K = KS <= 4).  GROUP = 1: moves 4 g .. 4 g + 3 of a larger pool (KS = 4; every one of them has a total
+// array), GROUP = 2: the pool's last moves 4 g .. K - 1 (KS = K - 4 g; the very last has no total array); `group` = g, and
+// acc / tot point at move 4 g's rows.  ceil(K / 4) passes over the log instead of one read-modify-write per chain and
+// logged step (that form took 12 ms per 128 rows at 1e7 chains: 94 us per sweep at K = 5, 159 at K = 8).
+// BYTES: the log holds one byte per chain (pools of more than eight moves) instead of a nibble.
+template <int KS, bool RATIO = false, typename CT = uint32_t, bool HIGH = false, int GROUP = 0, bool BYTES = false>
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, CT* acc,
                                                               CT* tot, uint16_t* acc_hi, uint16_t* tot_hi,
                                                               int64_t n_chains, int64_t m_stride,
-                                                              int n_moves, uint64_t t_counted, double* ratio_partials,
+                                                              int group, uint64_t t_counted, double* ratio_partials,
                                                               int rp_stride)
 {
-    static_assert(KS > 0 || sizeof(CT) == 4, "16-bit counters come with the register-resident fold (K <= 4)");
+    static_assert(KS >= 1 && KS <= 4, "four moves per pass");
     static_assert(!HIGH || sizeof(CT) == 2, "high planes belong to 16-bit low planes");
-    static_assert(!RATIO || (KS > 0 && HALF == 0), "ratio sums ride on the register-resident fold of up to four moves");
-    static_assert(HALF == 0 || (KS > 0 && (HALF != 1 || KS == 4)), "halves: moves 0..3, then 4..K-1");
-    if (KS > 0) {
-        constexpr int KK = KS > 0 ? KS : 1;
-        constexpr uint32_t ONES = 0x01010101u;
-        __shared__ __attribute__((aligned(16))) uint32_t s_pk[2 * KK][4 * AMC_BLOCK];   // [k: accepted, total][quad of the tile]
-        double ratio[KK];
+    static_assert(!RATIO || GROUP == 0, "ratio sums ride on the single pass of pools of up to four moves");
+    static_assert(GROUP != 1 || KS == 4, "inner groups are full");
+    static_assert(!BYTES || GROUP != 0, "pools of up to eight moves log nibbles");
+    constexpr int KK = KS;
+    constexpr uint32_t ONES = 0x01010101u;
+    constexpr bool ALL_TOT = GROUP == 1;                                         // every move of this pass has a total array
+    __shared__ __attribute__((aligned(16))) uint32_t s_pk[2 * KK][4 * AMC_BLOCK];   // [k: accepted, total][quad of the tile]
+    double ratio[KK];
 #pragma unroll
-        for (int k = 0; k < KK; ++k) ratio[k] = 0.0;
-        const int64_t n_tiles = (n_chains + AMC_FOLD_TILE - 1) / AMC_FOLD_TILE;
-        for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            const int64_t c_tile = tile * AMC_FOLD_TILE;
-            const int64_t c_mine = c_tile + 16 * (int64_t)threadIdx.x;   // first of this thread's 16 chains (log side)
-            // every per-chain array is m_stride long (a multiple of 256, >= n_chains + 520): indices below m_stride are
-            // readable and writable, what lies behind n_chains is padding
-            const bool log_ok = c_mine < m_stride;
-            uint32_t pa[KK][4], pt[KK][4];                     // packed 8-bit counters: word j = chains c_mine + 4 j .. + 3
+    for (int k = 0; k < KK; ++k) ratio[k] = 0.0;
+    // the group a step belongs to: bit 3 of a nibble (pools of 5..8), bits 3..6 of a byte (up to 64 moves)
+    const uint32_t group_field = BYTES ? 0x0F0F0F0Fu : ONES;
+    const uint32_t group_word = (uint32_t)group * ONES;
+    const int64_t n_tiles = (n_chains + AMC_FOLD_TILE - 1) / AMC_FOLD_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t c_tile = tile * AMC_FOLD_TILE;
+        const int64_t c_mine = c_tile + 16 * (int64_t)threadIdx.x;   // first of this thread's 16 chains (log side)
+        // every per-chain array is m_stride long (a multiple of 256, >= n_chains + 520): indices below m_stride are
+        // readable and writable, what lies behind n_chains is padding
+        const bool log_ok = c_mine < m_stride;
+        uint32_t pa[KK][4], pt[KK][4];                     // packed 8-bit counters of four chains each (see below for which)
 #pragma unroll
-            for (int k = 0; k < KK; ++k)
+        for (int k = 0; k < KK; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pa[k][j] = pt[k][j] = 0u;
-            if (log_ok) {
-                const int64_t row_bytes = m_stride >> 1;
-                const uint8_t* mine = log + (c_mine >> 1);
-                auto add_row = [&](const uint2 w2) {
-                    // accumulator j: word j / 2 of the load, its even (j even: low nibbles) or odd chains
-                    const uint32_t w[4] = {w2.x, w2.x >> 4, w2.y, w2.y >> 4};
+            for (int j = 0; j < 4; ++j) pa[k][j] = pt[k][j] = 0u;
+        if (log_ok) {
+            // w[j]: four chains' steps in the low bits of its four bytes -- nibble log: word j / 2 of the load, its even (j even)
+            // or odd chains; byte log: chains 4 j .. 4 j + 3
+            auto add_words = [&](const uint32_t (&w)[4]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t a = w[j] & ONES;                       // accepted
-                        const uint32_t b0 = (w[j] >> 1) & ONES, b1 = (w[j] >> 2) & ONES;      // move index bits
-                        uint32_t eq[4];
-                        if (KS == 1) { eq[0] = ONES; }
-                        else if (KS == 2) { eq[1] = b0; eq[0] = b0 ^ ONES; }
-                        else { eq[0] = (b0 | b1) ^ ONES; eq[1] = b0 & ~b1; eq[2] = b1 & ~b0; eq[3] = b0 & b1; }
-                        // the third bit of the move index picks the half of the pool this launch counts
-                        const uint32_t mine = HALF == 0 ? ONES : (HALF == 2 ? (w[j] >> 3) & ONES : ((w[j] >> 3) & ONES) ^ ONES);
-#pragma unroll
-                        for (int k = 0; k < KK; ++k) {
-                            const uint32_t hit = HALF == 0 ? eq[k] : (eq[k] & mine);
-                            if (HALF == 1 || k < KK - 1) pt[k][j] += hit;     // the pool's last move has no total array
-                            pa[k][j] += hit & a;
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = w[j] & ONES;                       // accepted
+                    const uint32_t b0 = (w[j] >> 1) & ONES, b1 = (w[j] >> 2) & ONES;      // move index within its group
+                    uint32_t eq[4];
+                    if (KS == 1) { eq[0] = ONES; }
+                    else if (KS == 2) { eq[1] = b0; eq[0] = b0 ^ ONES; }
+                    else { eq[0] = (b0 | b1) ^ ONES; eq[1] = b0 & ~b1; eq[2] = b1 & ~b0; eq[3] = b0 & b1; }
+                    uint32_t mine = ONES;
+                    if (GROUP != 0) {
+                        // bytes whose group field equals `group`: x = field ^ group is zero there and below 0x80 everywhere,
+                        // so bit 7 of x + 0x7F marks the others
+                        const uint32_t x = ((w[j] >> 3) & group_field) ^ group_word;
+                        mine = (((x + 0x7F7F7F7Fu) >> 7) & ONES) ^ ONES;
                     }
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        const uint32_t hit = GROUP == 0 ? eq[k] : (eq[k] & mine);
+                        if (ALL_TOT || k < KK - 1) pt[k][j] += hit;       // the pool's last move has no total array
+                        pa[k][j] += hit & a;
+                    }
+                }
+            };
+            // Rows in flight per lane: with one, a wave has 512 bytes outstanding and the launch waits for latency (the full
+            // 128-row fold moved 0.76 GB in 202 us; four in flight: 154 us).  The callback's form needs its registers for
+            // the counter side (83 VGPRs with four): two in flight there (ten-row launch 35.0-35.7 -> 33.7 us before the
+            // 16-bit mark, 41.5 -> 39-40 after; same box).
+            constexpr int U = RATIO ? 2 : 4;
+            if (!BYTES) {
+                const int64_t row_bytes = m_stride >> 1;
+                const uint8_t* mine_rows = log + (c_mine >> 1);
+                auto add_row = [&](const uint2 w2) {
+                    const uint32_t w[4] = {w2.x, w2.x >> 4, w2.y, w2.y >> 4};
+                    add_words(w);
                 };
-                // Rows in flight per lane: with one, a wave has 512 bytes outstanding and the launch waits for latency (the full
-                // 128-row fold moved 0.76 GB in 202 us; four in flight: 154 us).  The callback's form needs its registers for
-                // the counter side (83 VGPRs with four): two in flight there (ten-row launch 35.0-35.7 -> 33.7 us before the
-                // 16-bit mark, 41.5 -> 39-40 after; same box).
-                constexpr int U = RATIO ? 2 : 4;
                 int r = 0;
                 for (; r + U <= n_rows; r += U) {
                     uint2 w[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const uint2*>(mine + (int64_t)(r + u) * row_bytes);
+                    for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const uint2*>(mine_rows + (int64_t)(r + u) * row_bytes);
 #pragma unroll
                     for (int u = 0; u < U; ++u) add_row(w[u]);
                 }
-                for (; r < n_rows; ++r) add_row(*reinterpret_cast<const uint2*>(mine + (int64_t)r * row_bytes));
+                for (; r < n_rows; ++r) add_row(*reinterpret_cast<const uint2*>(mine_rows + (int64_t)r * row_bytes));
+            } else {
+                const uint8_t* mine_rows = log + c_mine;
+                auto add_row = [&](const uint4 w4) {
+                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+                    add_words(w);
+                };
+                int r = 0;
+                for (; r + 2 <= n_rows; r += 2) {
+                    const uint4 w0 = *reinterpret_cast<const uint4*>(mine_rows + (int64_t)r * m_stride);
+                    const uint4 w1 = *reinterpret_cast<const uint4*>(mine_rows + (int64_t)(r + 1) * m_stride);
+                    add_row(w0); add_row(w1);
+                }
+                for (; r < n_rows; ++r) add_row(*reinterpret_cast<const uint4*>(mine_rows + (int64_t)r * m_stride));
             }
-            // (even chains 0 2 4 6, odd chains 1 3 5 7) of a word -> chains 0..3 and 4..7
-            auto in_chain_order = [](const uint32_t (&v)[4]) {
-                return uint4{__builtin_amdgcn_perm(v[1], v[0], 0x05010400u), __builtin_amdgcn_perm(v[1], v[0], 0x07030602u),
-                             __builtin_amdgcn_perm(v[3], v[2], 0x05010400u), __builtin_amdgcn_perm(v[3], v[2], 0x07030602u)};
-            };
+        }
+        // nibble log: (even chains 0 2 4 6, odd chains 1 3 5 7) of a word -> chains 0..3 and 4..7
+        auto in_chain_order = [](const uint32_t (&v)[4]) {
+            if (BYTES) return uint4{v[0], v[1], v[2], v[3]};
+            return uint4{__builtin_amdgcn_perm(v[1], v[0], 0x05010400u), __builtin_amdgcn_perm(v[1], v[0], 0x07030602u),
+                         __builtin_amdgcn_perm(v[3], v[2], 0x05010400u), __builtin_amdgcn_perm(v[3], v[2], 0x07030602u)};
+        };
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = in_chain_order(pa[k]);
+            if (ALL_TOT || k < KK - 1) reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = in_chain_order(pt[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int quad = i * AMC_BLOCK + (int)threadIdx.x;
+            const int64_t c0 = c_tile + 4 * (int64_t)quad;
+            if (c0 >= m_stride) continue;
+            uint32_t tsum[4] = {0u, 0u, 0u, 0u};           // total_calls of the moves before k, per chain of the quad
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
-                reinterpret_cast<uint4*>(s_pk[2 * k])[threadIdx.x] = in_chain_order(pa[k]);
-                if (HALF == 1 || k < KK - 1) reinterpret_cast<uint4*>(s_pk[2 * k + 1])[threadIdx.x] = in_chain_order(pt[k]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int quad = i * AMC_BLOCK + (int)threadIdx.x;
-                const int64_t c0 = c_tile + 4 * (int64_t)quad;
-                if (c0 >= m_stride) continue;
-                uint32_t tsum[4] = {0u, 0u, 0u, 0u};           // total_calls of the moves before k, per chain of the quad
-#pragma unroll
-                for (int k = 0; k < KK; ++k) {
-                    const int64_t at = (int64_t)k * m_stride + c0;
-                    const uint4 va = bump_counter_quad<HIGH>(acc + at, HIGH ? acc_hi + at : nullptr, s_pk[2 * k][quad]);
-                    uint4 vt;
-                    if (HALF == 1 || k < KK - 1) {
-                        vt = bump_counter_quad<HIGH>(tot + at, HIGH ? tot_hi + at : nullptr, s_pk[2 * k + 1][quad]);
-                        tsum[0] += vt.x; tsum[1] += vt.y; tsum[2] += vt.z; tsum[3] += vt.w;
-                    } else {
-                        const uint32_t tc = (uint32_t)t_counted;
-                        vt = uint4{tc - tsum[0], tc - tsum[1], tc - tsum[2], tc - tsum[3]};
-                    }
-                    if (RATIO) {
-                        const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
-                                ratio[k] += (double)a4[e] / (double)t4[e];
-                    }
+                const int64_t at = (int64_t)k * m_stride + c0;
+                const uint4 va = bump_counter_quad<HIGH>(acc + at, HIGH ? acc_hi + at : nullptr, s_pk[2 * k][quad]);
+                uint4 vt;
+                if (ALL_TOT || k < KK - 1) {
+                    vt = bump_counter_quad<HIGH>(tot + at, HIGH ? tot_hi + at : nullptr, s_pk[2 * k + 1][quad]);
+                    tsum[0] += vt.x; tsum[1] += vt.y; tsum[2] += vt.z; tsum[3] += vt.w;
+                } else {
+                    const uint32_t tc = (uint32_t)t_counted;
+                    vt = uint4{tc - tsum[0], tc - tsum[1], tc - tsum[2], tc - tsum[3]};
                 }
-            }
-            __syncthreads();                                   // the next tile overwrites s_pk
-        }
-        if (RATIO) block_sum_store<KK>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
-    } else {
-        const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
-        for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
-            for (int r = 0; r < n_rows; ++r) {
-                const uint32_t b = log[(int64_t)r * m_stride + c];
-                const uint32_t k = b >> 1;
-                if (k < (uint32_t)n_moves) {
-                    acc[(int64_t)k * m_stride + c] += b & 1u;
-                    if (k + 1 < (uint32_t)n_moves) tot[(int64_t)k * m_stride + c] += 1u;
+                if (RATIO) {
+                    const uint32_t a4[4] = {va.x, va.y, va.z, va.w}, t4[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
+                            ratio[k] += (double)a4[e] / (double)t4[e];
                 }
             }
         }
+        __syncthreads();                                   // the next tile overwrites s_pk
     }
+    if (RATIO) block_sum_store<KK>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
 }
+
 
 // K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int64_t n_chains, uint64_t pair0,

@@ -149,7 +149,8 @@ POOLS = {1: ([0.1], [1.0]), 2: ([0.1, 1.0], [0.5, 0.5]), 3: ([0.1, 1.0, 0.3], [0
          5: ([0.1, 1.0, 0.3, 0.5, 0.2], [0.2, 0.3, 0.1, 0.25, 0.15]), 7: ([0.2] * 7, [0.4] + [0.1] * 6),
          8: ([0.1 * (k + 1) for k in range(8)], [0.125] * 8),
          # more than eight moves: one byte per chain in the step log and the generic (one chain per thread) fold
-         11: ([0.1 + 0.05 * k for k in range(11)], [0.2] + [0.08] * 10)}
+         11: ([0.1 + 0.05 * k for k in range(11)], [0.2] + [0.08] * 10),
+         33: ([0.05 * (k + 1) for k in range(33)], [1.0 / 33] * 33), 64: ([0.02 * (k + 1) for k in range(64)], [1.0 / 64] * 64)}
 
 
 def run_pair(gpu, oracle, M, K, potential, sweeps, sweepstep=1, counters=True, offset=0, fused=False,
@@ -216,7 +217,7 @@ def test_sweep_bit_exact(gpu, oracle, M, K, potential, sweeps, sweepstep):
 
 
 @pytest.mark.parametrize("depth", [1, 3, 255])
-@pytest.mark.parametrize("K,fused", [(1, False), (2, False), (2, True), (5, False), (7, True), (8, True), (11, True)])
+@pytest.mark.parametrize("K,fused", [(1, False), (2, False), (2, True), (5, False), (7, True), (8, True), (11, True), (33, False), (64, True)])
 def test_step_log_depths(gpu, oracle, monkeypatch, depth, K, fused):
     """Per-chain counters go through the step log (a nibble per chain and MH step up to four moves, a byte beyond) and are
     folded into acc/tot on demand or when the log is full: every depth, single-step and multi-step launches, register and

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from montecarlo_amd import _capi as A
 M = 10_000_000
-for K in (1, 2, 3, 4, 5, 7, 8):
+for K in (1, 2, 4, 5, 8, 9, 12, 16, 33):
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1 + 0.05 * k for k in range(K)], weight=[1.0 / K] * K, seed=1,
                     per_chain_counters=True)
     e.init_uniform(-2, 2)
