@@ -995,12 +995,11 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_ker
 // den = 2*(s*s); logc = log(2pi*(s*s))/2 (particle_1d.jl:53); cum = running sum of
 // weights in the order Distributions.jl accumulates them; dden, dlhalf: d/dsigma
 // pieces of gradients.jl:28-33 (ForwardDiff's dual rules written out).
-__device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
+// (the entries of move k that depend on its sigma alone)
+__device__ __forceinline__ void prepare_move_params(double* ptab, int k, double sigma)
 {
     const double TWO_PI = 0x1.921fb54442d18p+2;
-    double cp = 0.0;
-    for (int k = 0; k < n_moves; ++k) {
-        const double sigma = ptab[PT_SIGMA * AMC_MAX_MOVES + k];
+    {
         const double s2 = sigma * sigma;
         const double ds2 = sigma + sigma;
         ptab[PT_DEN * AMC_MAX_MOVES + k] = 2.0 * s2;
@@ -1019,6 +1018,14 @@ __device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
             ptab[PT_C3HI * AMC_MAX_MOVES + k] = c_hi;
             ptab[PT_C3LO * AMC_MAX_MOVES + k] = res / d_hi;
         }
+    }
+}
+
+__device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
+{
+    double cp = 0.0;
+    for (int k = 0; k < n_moves; ++k) {
+        prepare_move_params(ptab, k, ptab[PT_SIGMA * AMC_MAX_MOVES + k]);
         const double w = ptab[PT_WEIGHT * AMC_MAX_MOVES + k];
         cp = (k == 0) ? w : cp + w;
         ptab[PT_CUM * AMC_MAX_MOVES + k] = cp;
@@ -1074,50 +1081,64 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* red, int n
 // (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164; inv(g + eps I) is a scalar reciprocal), reset
 // the accumulators, refresh the derived parameter table.  A step that leaves sigma outside [1e-100, 1e100]
 // (or NaN) is not applied; status[0] is set instead.
-__device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_learn, const int32_t* ids,
-                                              const PgOpts& opt, int n_moves, int* status)
+// learning_step! of one move from its averaged GradientData (see below); `theta` is its sigma
+__device__ __forceinline__ double pg_learning_step(int kind, double h0, double h1, double theta, double j, double dj, double dlogq,
+                                                   double g)
 {
+    switch (kind) {
+    case OPT_VPG: return theta + h0 * dj;
+    case OPT_BLPG: return theta + h0 * (dj - j * dlogq);
+    case OPT_BLAPG: {
+        const double eta = __builtin_sqrt(2.0 * h0 / (dj * dj + h1));
+        return theta + eta * (dj - j * dlogq);
+    }
+    case OPT_NPG: {
+        const double finv = 1.0 / (g + h1 * 1.0);
+        return theta + h0 * finv * dj;
+    }
+    case OPT_ANPG: {
+        const double finv = 1.0 / (g + h1 * 1.0);
+        const double eta = __builtin_sqrt(2.0 * h0 / (dj * (finv * dj)));
+        return theta + eta * finv * dj;
+    }
+    case OPT_BLANPG: {
+        const double finv = 1.0 / (g + h1 * 1.0);
+        const double bj = dj - j * dlogq;
+        const double eta = __builtin_sqrt(2.0 * h0 / (bj * (finv * bj)));
+        return theta + eta * finv * bj;
+    }
+    default: return theta;
+    }
+}
+
+// One thread.  `red` != nullptr: first gradients_data[k] += the sums in red (pg_accumulate_one), in registers -- the
+// accumulators are read once, the new sigma and what derives from it are written from registers, and only the moves that
+// learned get their derived parameters refreshed (the cumulative weights do not depend on sigma): the few dependent round
+// trips to memory this thread makes are the tail of every PGMC time step (62.4 -> 61.4 us per fused step, same box).
+__device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_learn, const int32_t* ids,
+                                              const PgOpts& opt, int n_moves, int* status, const double* red = nullptr,
+                                              double n_samples = 0.0)
+{
+    (void)n_moves;
     for (int l = 0; l < n_learn; ++l) {
         const int k = ids[l];
         double* a = acc + k * 5;
-        const double n = a[4];
-        const double j = a[0] / n, dj = a[1] / n, dlogq = a[2] / n, g = a[3] / n;
+        double v[5] = {a[0], a[1], a[2], a[3], a[4]};
         const double theta = ptab[PT_SIGMA * AMC_MAX_MOVES + k];
-        const double h0 = opt.h0[l], h1 = opt.h1[l];
-        double next = theta;
-        switch (opt.kind[l]) {
-        case OPT_VPG: next = theta + h0 * dj; break;
-        case OPT_BLPG: next = theta + h0 * (dj - j * dlogq); break;
-        case OPT_BLAPG: {
-            const double eta = __builtin_sqrt(2.0 * h0 / (dj * dj + h1));
-            next = theta + eta * (dj - j * dlogq);
-            break;
+        if (red) {
+            for (int i = 0; i < 4; ++i) v[i] += red[l * 4 + i];
+            v[4] += n_samples;
         }
-        case OPT_NPG: {
-            const double finv = 1.0 / (g + h1 * 1.0);
-            next = theta + h0 * finv * dj;
-            break;
-        }
-        case OPT_ANPG: {
-            const double finv = 1.0 / (g + h1 * 1.0);
-            const double eta = __builtin_sqrt(2.0 * h0 / (dj * (finv * dj)));
-            next = theta + eta * finv * dj;
-            break;
-        }
-        case OPT_BLANPG: {
-            const double finv = 1.0 / (g + h1 * 1.0);
-            const double bj = dj - j * dlogq;
-            const double eta = __builtin_sqrt(2.0 * h0 / (bj * (finv * bj)));
-            next = theta + eta * finv * bj;
-            break;
-        }
-        default: break;
-        }
-        if (next >= 1e-100 && next <= 1e100) ptab[PT_SIGMA * AMC_MAX_MOVES + k] = next;
-        else status[0] = 1;
+        const double n = v[4];
+        const double j = v[0] / n, dj = v[1] / n, dlogq = v[2] / n, g = v[3] / n;
+        const double next = pg_learning_step(opt.kind[l], opt.h0[l], opt.h1[l], theta, j, dj, dlogq, g);
         for (int i = 0; i < 5; ++i) a[i] = 0.0;
+        if (next >= 1e-100 && next <= 1e100) {
+            ptab[PT_SIGMA * AMC_MAX_MOVES + k] = next;
+            prepare_move_params(ptab, k, next);
+        } else
+            status[0] = 1;
     }
-    prepare_params(ptab, n_moves);
 }
 
 AMC_KERNEL_LINKAGE __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
@@ -1132,8 +1153,7 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* red
                                                               double n_samples, PgOpts opt, int n_moves, int* status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int l = 0; l < n_learn; ++l) pg_accumulate_one(red, l, ids.v[l], n_samples, acc);
-    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
+    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, red, n_samples);
 }
 
 // K2a: callback reductions, pass 1.  partials[block][4 + K]:
@@ -1737,10 +1757,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(tl->tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.tail_mode >= 2) {
+        // (loading what the update reads BEFORE the last ticket, in every block that might draw it, was measured: slower,
+        // 62.4 against 61.4 us per fused time step -- the loads sit on the path from the group sums to the ticket)
+        if (a.tail_mode >= 3)
+            pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status, s_tot, tl->n_samples);
+        else if (a.tail_mode >= 2)
             for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, tl->learn_ids[l], tl->n_samples, tl->gd_acc);
-            if (a.tail_mode >= 3) pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status);
-        }
     }
 }
 

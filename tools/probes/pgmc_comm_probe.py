@@ -9,7 +9,7 @@ from montecarlo_amd import sharding
 grp = sharding.init_store_group(0, 1)
 from montecarlo_amd import _capi as A
 M = 10_000_000
-for connected in (False, True):
+for connected in ([bool(int(os.environ["ONLY"]))] if os.environ.get("ONLY") else (False, True)):
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
     e.init_uniform(-2, 2)
     if connected:
