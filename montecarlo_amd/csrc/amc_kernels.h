@@ -614,6 +614,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // callback come from the fold of the step log that follows (fold_log_kernel<KS, true>)
     static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
     double red[4] = {0.0, 0.0, 0.0, 0.0};
+    // the callback sums' registers cost a wave of occupancy (69 against 59, 79 against 70, 100 against 92 VGPRs): the count of
+    // full trips lives on the scalar unit, and with U = x^2 in Float64 sum x^2 IS sum e (the same products added in the same order)
+    int red_pairs = 0, red_ragged = 0;
+    constexpr bool RED_X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[MULTI ? AMC_PICK_CELLS : 16];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
@@ -700,8 +704,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             const double x0 = xv.x, x1 = xv.y;
             red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
             red[1] += x0 + x1;
-            red[2] += x0 * x0 + x1 * x1;
-            red[3] += 2.0;
+            if (!RED_X2_IS_E) red[2] += x0 * x0 + x1 * x1;
+            red_pairs += 1;
         }
         x_done = xv;
         lw_done = lw;
@@ -726,11 +730,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
         if (REDUCE) {
             const double x0 = xv.x, x1 = xv.y;
-            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; red[2] += x0 * x0; red[3] += 1.0; }
-            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; red[2] += x1 * x1; red[3] += 1.0; }
+            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; if (!RED_X2_IS_E) red[2] += x0 * x0; red_ragged += 1; }
+            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; if (!RED_X2_IS_E) red[2] += x1 * x1; red_ragged += 1; }
         }
     }
-    if (REDUCE) block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
+    if (REDUCE) {
+        red[3] = (double)(2 * red_pairs + red_ragged);     // full trips: two chains per lane each
+        if (RED_X2_IS_E) red[2] = red[0];
+        block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
+    }
     if (!MULTI) {
         // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
         // address at kernel end serialise at ~13 ns each; one address per block does not contend).
@@ -1555,6 +1563,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
     double red[4] = {0.0, 0.0, 0.0, 0.0};
+    // the callback sums' registers cost a wave of occupancy (69 against 59, 79 against 70, 100 against 92 VGPRs): the count of
+    // full trips lives on the scalar unit, and with U = x^2 in Float64 sum x^2 IS sum e (the same products added in the same order)
+    int red_pairs = 0, red_ragged = 0;
+    constexpr bool RED_X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
     // the pool-wide accepted total this block can see before the launch (see sweep_kernel)
     unsigned long long slots_before = 0;
     if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
@@ -1667,8 +1679,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             const double x0 = xv.x, x1 = xv.y;
             red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
             red[1] += x0 + x1;
-            red[2] += x0 * x0 + x1 * x1;
-            red[3] += 2.0;
+            if (!RED_X2_IS_E) red[2] += x0 * x0 + x1 * x1;
+            red_pairs += 1;
         }
         x_done = xv;
         base_done = base;
@@ -1686,11 +1698,15 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         }
         if (REDUCE) {
             const double x0 = xv.x, x1 = xv.y;
-            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; red[2] += x0 * x0; red[3] += 1.0; }
-            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; red[2] += x1 * x1; red[3] += 1.0; }
+            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; if (!RED_X2_IS_E) red[2] += x0 * x0; red_ragged += 1; }
+            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; if (!RED_X2_IS_E) red[2] += x1 * x1; red_ragged += 1; }
         }
     }
-    if (REDUCE) block_sum_store<4>(red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
+    if (REDUCE) {
+        red[3] = (double)(2 * red_pairs + red_ragged);     // full trips: two chains per lane each
+        if (RED_X2_IS_E) red[2] = red[0];
+        block_sum_store<4>(red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
+    }
     if (SWEEP == 1 || SWEEP == 3) {      // K == 1: the pool-wide accepted total (counter_totals)
         const unsigned long long t = add_block_accepts(sw.acc_total, wave_acc);
         // column 4 of this block's row: the slot's value after this launch (exact in a double below 2^53)

@@ -8,7 +8,7 @@
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.environ.get("AMC_PKG_ROOT", ROOT))      # A/B: a variant copy of the package (tools/gpu_ab.py snapshot)
 from montecarlo_amd import _capi as A
 
 mode = sys.argv[1]
