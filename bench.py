@@ -210,9 +210,9 @@ def other_configs(A, m, device, periods=40):
             # untimed: at least `periods`, and long enough for the clock to come back up after the idle seconds of set-up
             # (allocation, the counter upload); a few thousand steps, far below the 65 535 of the first regime
             while n < periods or (not timed and time.perf_counter() - t0 < spinup_s):
-                if pending:
-                    e.reduce_end()
-                period(e)
+                # nine time steps, then the previous callback's sums are read (one reduction in flight per engine), then the
+                # tenth step, which forms the next sums: the device works through the nine while the host reads
+                period(e, lambda: e.reduce_end() if pending else None)
                 pending = True
                 n += 1
             if pending:
@@ -221,13 +221,16 @@ def other_configs(A, m, device, periods=40):
                 return e.timing_end() * 1e3 / (10 * periods)
             e.sync()
 
-    def k2_period(e):
+    def k2_period(e, read_previous):
         for _ in range(9):
             e.sweep(1)                                                 # one launch per sweep, like the headline
+        read_previous()
         e.sweep_reduce_begin(1)                                        # the tenth forms the callback sums
 
-    def pgmc_period(e):
-        e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0], reduce_begin=True)   # VPG on move 2; the tenth launch forms the sums
+    def pgmc_period(e, read_previous):
+        e.pgmc_steps(9, [1], 1, [1], [0.02], [0.0])                    # VPG on move 2
+        read_previous()
+        e.pgmc_steps(1, [1], 1, [1], [0.02], [0.0], reduce_begin=True)    # the tenth launch forms the sums
 
     try:
         e = A.HipEngine(n_chains=m, potential="double_well", beta=BETA, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=SEED, device=device)

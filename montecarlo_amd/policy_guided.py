@@ -251,15 +251,22 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         met._drop_pending_reduction()
         # with_reductions: a callback observes the state these steps leave -- the sums ride in the last step's launch
         red = bool(with_reductions) and hasattr(eng, "reduce_end")
-        if red:
-            met._settle_claimed()            # one reduction in flight per engine
         if update is not None:
             codes = [optimiser_code(self.optimisers[lid]) for lid in self.learn_ids]
-            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, [c[0] for c in codes], [c[1] for c in codes],
-                           [c[2] for c in codes], **({"reduce_begin": True} if red else {}))
+            opt = ([c[0] for c in codes], [c[1] for c in codes], [c[2] for c in codes])
             met.device_params_dirty = True
         else:
-            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, **({"reduce_begin": True} if red else {}))
+            opt = ()
+        if red:
+            # One reduction in flight per engine: the previous callback's sums are fetched BEFORE the launch that forms the
+            # next ones -- but AFTER the n - 1 steps in front of it have been queued, so that the device works through them
+            # while the host reads (fetching first left the queue empty for a few microseconds every callback period).
+            if n > 1:
+                eng.pgmc_steps(n - 1, self.learn_ids, self.q_batch_size, *opt)
+            met._settle_claimed()
+            eng.pgmc_steps(1, self.learn_ids, self.q_batch_size, *opt, reduce_begin=True)
+        else:
+            eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, *opt)
         met._epoch += 1
         met.invalidate_reductions()
         if red:

@@ -288,8 +288,9 @@ def test_grouped_pgmc_issues_few_engine_calls(oracle, tmp_path):
     sim, _ = _pgmc_sim(oracle, tmp_path, 100, factory=Counting)
     ma.run(sim)
     # callbacks at 20, 45, 70, 95, 100 cut the run into groups that END WITH the observed step: StoreCallbacks comes after
-    # the three in the list, so it runs behind the group and sees the state it leaves
-    assert calls == [20, 25, 25, 25, 5]
+    # the three in the list, so it runs behind the group and sees the state it leaves.  A group is two engine calls: its
+    # first n - 1 steps, then -- after the previous callback's sums have been fetched -- the step that forms the next ones.
+    assert calls == [19, 1, 24, 1, 24, 1, 24, 1, 4, 1]
 
 
 def test_deferred_callback_rows_are_the_same_rows_written_one_period_later(oracle, tmp_path):
@@ -370,7 +371,8 @@ def test_grouped_pgmc_steps_carry_the_callback_sums_of_their_last_step(oracle, t
     sim, pool = _pgmc_sim(oracle, tmp_path / "g", 100, factory=Counting)
     ma.run(sim)
     grouped = [c for c in calls if isinstance(c, tuple)]
-    assert grouped == [(20, True), (25, True), (25, True), (25, True), (5, True)]
+    # each group: its first n - 1 steps, then the observed step with the sums (the previous sums are fetched in between)
+    assert grouped == [(19, False), (1, True), (24, False), (1, True), (24, False), (1, True), (24, False), (1, True), (4, False), (1, True)]
     # the only reductions outside the groups: t = 0 (store_first) -- OracleEngine.pgmc_steps itself calls reduce_begin -> reduce
     assert calls.count("reduce_begin") == 5 + 1
     ref, _ = _pgmc_sim(oracle, tmp_path / "s", 100)

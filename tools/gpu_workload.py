@@ -84,10 +84,12 @@ elif mode in ("pgmc", "est"):
         if mode == "pgmc":
             pending = False
             for i in range(n // 10):
+                # ten time steps; the tenth launch also forms the callback sums.  The previous callback's sums are read
+                # after the first nine have been queued (the host mirror's order, policy_guided.make_steps_grouped)
+                e.pgmc_steps(9, [1], 1, [1], [0.02], [0.0])
                 if PIPELINED and pending:
                     e.reduce_end()                    # the previous callback's sums: queued ten time steps ago
-                # ten time steps; the tenth launch also forms the callback sums, the ratio fold runs on the second stream
-                e.pgmc_steps(10, [1], 1, [1], [0.02], [0.0], reduce_begin=True)
+                e.pgmc_steps(1, [1], 1, [1], [0.02], [0.0], reduce_begin=True)
                 pending = True
                 if not PIPELINED:
                     e.reduce_end(); pending = False
