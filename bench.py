@@ -184,7 +184,7 @@ def ladder(A, sizes, device, reps=5):
 def other_configs(A, m, device, periods=40):
     """BASELINE configs 3 and 5 end to end at this ensemble size, next to the headline (never part of `value`): one launch per
     time step, callbacks (energy + acceptance) every 10 time steps, each callback's sums read one period late -- the form
-    the host mirror's StoreCallbacks uses.  HIP events over `periods` callback periods, after at least as many (and 0.35 s) untimed.
+    the host mirror's StoreCallbacks uses.  HIP events: the median of three blocks of `periods` callback periods, after at least as many (and 0.35 s) untimed.
     Two figures each: K <= 4 handles keep their per-chain counters as two u16 planes, and for the first 65 535 counted steps
     the callback's fold leaves the (all-zero) high plane alone -- 17 bytes per chain against 23 afterwards;
     `us_per_time_step` is the regime after the mark (what a long run sees), `us_per_time_step_first_65535_steps` the one before."""
@@ -201,8 +201,12 @@ def other_configs(A, m, device, periods=40):
         del tot
         return measure(e, period), early
 
-    def measure(e, period, spinup_s=0.35):
-        for timed in (False, True):
+    def measure(e, period, spinup_s=0.35, blocks=3):
+        """Median of `blocks` timed blocks of `periods` callback periods each (a block is 15-30 ms: one hiccup of a few
+        milliseconds moves a single block by 10 %), after an untimed phase."""
+        times = []
+        for block in range(-1, blocks):
+            timed = block >= 0
             pending = False
             if timed:
                 e.timing_begin()
@@ -218,8 +222,10 @@ def other_configs(A, m, device, periods=40):
             if pending:
                 e.reduce_end()
             if timed:
-                return e.timing_end() * 1e3 / (10 * periods)
-            e.sync()
+                times.append(e.timing_end() * 1e3 / (10 * periods))
+            else:
+                e.sync()
+        return sorted(times)[len(times) // 2]
 
     def k2_period(e, read_previous):
         for _ in range(9):
