@@ -255,6 +255,12 @@ int  amc_reduce_end(amc_handle *h, double *out);
  * sigma_k on the device copy, e.g. after learning_step! (update.jl:50-57). */
 int  amc_set_parameters(amc_handle *h, int k, const double *p, int n);
 int  amc_get_parameters(amc_handle *h, int k, double *p, int n);
+/* The same read without making the caller wait for the queued steps (StoreParameters on a schedule, metropolis.jl:433-440,
+ * beside device-resident learning steps): _begin queues a copy of sigma_0 .. sigma_{K-1} AS OF THIS POINT of the handle's
+ * stream into pinned memory, _end returns them (sigma[K]) once that copy is done -- typically a callback period later, when
+ * it long is.  One such read in flight per handle (AMC_ERR_STATE otherwise). */
+int  amc_parameters_begin(amc_handle *h);
+int  amc_parameters_end(amc_handle *h, double *sigma);
 
 /* make_step!(simulation, ::PolicyGradientEstimator) (estimator.jl:111-134) for the
  * moves learn_ids[0..n_learn) (0-based), q_batch samples per chain per move, in the

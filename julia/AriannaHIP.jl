@@ -376,6 +376,20 @@ function pull_parameters!(metropolis::HIPMetropolis)
     return nothing
 end
 
+# The same read without waiting for the queued steps: `parameters_begin!` queues a copy of every σ as of this point of the
+# stream, `parameters_end!` returns them later (a StoreParameters that writes the row of time t when the next one is due,
+# src/metropolis.jl:433-440).  One read in flight per handle.
+function parameters_begin!(metropolis::HIPMetropolis)
+    check(ccall((:amc_parameters_begin, libamc), Cint, (Ptr{Cvoid},), metropolis.handle))
+    return nothing
+end
+
+function parameters_end!(metropolis::HIPMetropolis)
+    σ = Vector{Float64}(undef, metropolis.K)
+    check(ccall((:amc_parameters_end, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), metropolis.handle, σ))
+    return σ
+end
+
 # running (j, ∇j, ∇logq, g, n) of the device-resident estimator, 5 x n_learn; and its counterpart for a resume
 function pg_get_accumulated(metropolis::HIPMetropolis, learn_ids::Vector{Int})
     ids = Cint[k - 1 for k in learn_ids]

@@ -105,6 +105,8 @@ def load() -> C.CDLL:
         "amc_reduce_end": (C.c_int, [H, dp]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
+        "amc_parameters_begin": (C.c_int, [H]),
+        "amc_parameters_end": (C.c_int, [H, dp]),
         "amc_pg_estimate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
         "amc_pg_accumulate": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int]),
         "amc_pg_update": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]),
@@ -358,6 +360,15 @@ class HipEngine:
     def get_parameters(self, k: int) -> np.ndarray:
         a = np.empty(1, dtype=np.float64)
         _check(self._lib.amc_get_parameters(self._h, int(k), _dptr(a), 1))
+        return a
+
+    def parameters_begin(self) -> None:
+        """Queue a read of every move's sigma as of this point of the stream (amc_parameters_begin); fetch with parameters_end()."""
+        _check(self._lib.amc_parameters_begin(self._h))
+
+    def parameters_end(self) -> np.ndarray:
+        a = np.empty(self.n_moves, dtype=np.float64)
+        _check(self._lib.amc_parameters_end(self._h, _dptr(a)))
         return a
 
     def pg_estimate(self, learn_ids: Sequence[int], q_batch: int) -> np.ndarray:

@@ -136,6 +136,9 @@ struct amc_handle {
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
+    hipEvent_t ev_params = nullptr;   // behind the copy queued by amc_parameters_begin
+    double* h_params = nullptr;       // pinned [AMC_MAX_MOVES]: its destination
+    bool params_pending = false;
     bool red_pending = false;
     bool ev1_marked = false;    // amc_timing_mark recorded the end event already
     uint64_t red_t_counted = 0;
@@ -955,6 +958,8 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
     AMC_TRY(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
+    AMC_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+    AMC_TRY(hipHostMalloc((void**)&h->h_params, AMC_MAX_MOVES * sizeof(double), 0));
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
@@ -1102,6 +1107,8 @@ int amc_destroy(amc_handle* h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_red) (void)hipEventDestroy(h->ev_red);
+    if (h->ev_params) (void)hipEventDestroy(h->ev_params);
+    if (h->h_params) (void)hipHostFree(h->h_params);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return AMC_OK;
@@ -1732,6 +1739,29 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
     AMC_HIP(hipSetDevice(h->device));
     AMC_HIP(hipMemcpyAsync(p, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+int amc_parameters_begin(amc_handle* h)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_parameters_begin: NULL handle");
+    if (h->params_pending) return fail(AMC_ERR_STATE, "amc_parameters_begin: a read is already in flight (call amc_parameters_end)");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(hipMemcpyAsync(h->h_params, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES, (size_t)h->K * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    AMC_HIP(hipEventRecord(h->ev_params, h->stream));
+    h->params_pending = true;
+    return AMC_OK;
+}
+
+int amc_parameters_end(amc_handle* h, double* sigma)
+{
+    if (!h || !sigma) return fail(AMC_ERR_BAD_ARG, "amc_parameters_end: NULL argument");
+    if (!h->params_pending) return fail(AMC_ERR_STATE, "amc_parameters_end: no read in flight (call amc_parameters_begin)");
+    AMC_HIP(hipSetDevice(h->device));
+    AMC_HIP(wait_event(h->ev_params));           // waits for that copy only, not for work queued after it
+    h->params_pending = false;
+    for (int k = 0; k < h->K; ++k) sigma[k] = h->h_params[k];
     return AMC_OK;
 }
 

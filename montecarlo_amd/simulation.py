@@ -409,8 +409,17 @@ class StoreCallbacks(AriannaAlgorithm):
 # StoreParameters, src/metropolis.jl:380-450
 # ---------------------------------------------------------------------------------------
 class StoreParameters(AriannaAlgorithm):
+    """StoreParameters(chains; dependencies=(Metropolis,), ids, store_first, store_last) (src/metropolis.jl:380-450): one row
+    ``t parameters`` per scheduled time and stored move.
+
+    ``defer`` (default): when the parameters live on the device (learning steps taken there, PolicyGradientUpdate), the read of
+    time t is QUEUED at t (engine.parameters_begin: a copy in stream order) and its row is written when the next scheduled
+    time comes, or at finalise -- the same rows in the same files, one entry late during the run.  Reading at once
+    (defer=False) makes the host wait for every queued step and leaves the queue empty behind it: 6.5 us per time step of the
+    reference's PGMC script at 1e7 chains (parameters stored on the callbacks' schedule)."""
+
     def __init__(self, chains, dependencies=None, path=None, ids=None, store_first: bool = True,
-                 store_last: bool = False, **extras):
+                 store_last: bool = False, defer: bool = True, **extras):
         assert dependencies is not None and len(dependencies) == 1
         metropolis = dependencies[0]
         pool = metropolis.pool
@@ -422,6 +431,8 @@ class StoreParameters(AriannaAlgorithm):
         self.paths = [os.path.join(path, "parameters", str(k + 1), "parameters.dat") for k in self.ids]  # 1-based dirs
         self.files: List[Any] = []
         self.rows: List[List[tuple]] = [[] for _ in self.ids]
+        self.defer = bool(defer)
+        self._pending_t: Optional[int] = None    # time of the read queued on the engine and not fetched yet
 
     def initialise(self, simulation: Simulation) -> None:
         if self.rank == 0:
@@ -431,18 +442,44 @@ class StoreParameters(AriannaAlgorithm):
         if self.store_first:
             self.make_step(simulation)
 
-    def make_step(self, simulation: Simulation) -> None:
-        if getattr(self.metropolis, "device_params_dirty", False):
-            self.metropolis.pull_parameters()       # sigma was updated by a device-resident learning step
-        for i, prm in enumerate(self.parameters_list):
-            self.rows[i].append((simulation.t, prm.copy()))
+    def _write(self, t: int, values) -> None:
+        for i, prm in enumerate(values):
+            self.rows[i].append((t, prm))
             if self.rank == 0:
-                self.files[i].write(f"{simulation.t} {julia_repr(prm)}\n")
+                self.files[i].write(f"{t} {julia_repr(prm)}\n")
                 self.files[i].flush()
 
+    def flush(self) -> None:
+        """Fetch the queued read, if any, and write its row."""
+        if self._pending_t is None:
+            return
+        sigma = self.metropolis.engine.parameters_end()
+        t, self._pending_t = self._pending_t, None
+        values = []
+        for k, prm in zip(self.ids, self.parameters_list):
+            v = prm.copy()
+            v[...] = sigma[k]
+            values.append(v)
+        self._write(t, values)
+
+    def make_step(self, simulation: Simulation) -> None:
+        met = self.metropolis
+        if getattr(met, "device_params_dirty", False):
+            if self.defer and hasattr(met.engine, "parameters_begin"):
+                self.flush()                        # one read in flight: the previous row first (queued a period ago)
+                met.engine.parameters_begin()       # sigma as of the steps queued so far
+                self._pending_t = simulation.t
+                return
+            met.pull_parameters()                   # sigma was updated by a device-resident learning step
+        self.flush()
+        self._write(simulation.t, [prm.copy() for prm in self.parameters_list])
+
     def finalise(self, simulation: Simulation) -> None:
+        self.flush()
         if self.store_last:
-            self.make_step(simulation)
+            if getattr(self.metropolis, "device_params_dirty", False):
+                self.metropolis.pull_parameters()
+            self._write(simulation.t, [prm.copy() for prm in self.parameters_list])
         for f in self.files:
             f.close()
         self.files = []

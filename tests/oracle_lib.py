@@ -518,6 +518,15 @@ class OracleEngine:
     def get_parameters(self, k):
         return np.array([self.sim.get_sigma(k)])
 
+    def parameters_begin(self):           # amc_parameters_begin: sigma as of now, fetched later
+        assert getattr(self, "_params_pending", None) is None, "a parameter read was begun while another was in flight"
+        self._params_pending = np.array([self.sim.get_sigma(k) for k in range(self.n_moves)])
+
+    def parameters_end(self):
+        out, self._params_pending = self._params_pending, None
+        assert out is not None, "no parameter read in flight"
+        return out
+
     def pg_estimate(self, learn_ids, q_batch):
         return self.sim.pg_estimate(learn_ids, q_batch)
 

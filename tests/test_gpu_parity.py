@@ -1152,6 +1152,31 @@ def test_counters_across_the_16_bit_mark(gpu, oracle, K):
     e.close(); e2.close()
 
 
+def test_parameters_read_in_stream_order_without_draining_the_queue(gpu, oracle):
+    """amc_parameters_begin / _end (StoreParameters beside device-resident learning steps, metropolis.jl:433-440): the read is a
+    copy queued at its point of the stream -- steps queued AFTER it do not show in it -- fetched later; one in flight."""
+    M = 4099
+    kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=3)
+    e = gpu.HipEngine(n_chains=M, **kw)
+    o = oracle.OracleEngine(n_chains=M, **kw)
+    e.init_uniform(-2, 2); o.init_uniform(-2, 2)
+    vpg = [oracle.OPTIMISERS["VPG"]]
+    e.pgmc_steps(5, [1], 2, vpg, [0.05], [0.0]); o.pgmc_steps(5, [1], 2, vpg, [0.05], [0.0])
+    e.parameters_begin()
+    with pytest.raises(gpu.AmcError, match="already in flight"):
+        e.parameters_begin()
+    e.pgmc_steps(7, [1], 2, vpg, [0.05], [0.0])                        # queued behind the read
+    s5 = e.parameters_end()
+    assert s5[0] == 0.2 and abs(s5[1] - o.get_parameters(1)[0]) < 1e-10 * s5[1] and s5[1] != 0.1
+    with pytest.raises(gpu.AmcError, match="no read in flight"):
+        e.parameters_end()
+    o.pgmc_steps(7, [1], 2, vpg, [0.05], [0.0])
+    e.parameters_begin()
+    s12 = e.parameters_end()
+    assert abs(s12[1] - o.get_parameters(1)[0]) < 1e-9 * s12[1] and s12[1] != s5[1] and s12[1] == e.get_parameters(1)[0]
+    e.close(); o.close()
+
+
 def test_uploaded_totals_must_add_up_to_one_step_count(gpu):
     """Every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210): sum_k total_calls is one number
     for all chains, and the device keeps K - 1 of the K total arrays."""

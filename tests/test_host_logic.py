@@ -293,6 +293,44 @@ def test_grouped_pgmc_issues_few_engine_calls(oracle, tmp_path):
     assert calls == [19, 1, 24, 1, 24, 1, 24, 1, 4, 1]
 
 
+def test_deferred_parameter_rows_are_the_same_rows_written_one_period_later(oracle, tmp_path):
+    """StoreParameters beside device-resident learning steps (the reference's PGMC script stores the parameters on the
+    callbacks' schedule, PGMC_harmonic_oscillator.jl:30): defer=True queues the read at t (engine.parameters_begin) and writes
+    the row when the next scheduled time comes or at finalise; files and rows are those of defer=False, and only one read is
+    ever in flight (the test double asserts it)."""
+    out = []
+    for i, defer in enumerate((False, True)):
+        steps, path = 100, str(tmp_path / str(i))
+        chains = ma.ParticleChains.uniform(12, 2.0, -2.0, 2.0)
+        pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6), ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+        reads = []
+
+        class Watching(oracle.OracleEngine):
+            def parameters_begin(self):
+                reads.append("begin")
+                super().parameters_begin()
+
+            def parameters_end(self):
+                reads.append("end")
+                return super().parameters_end()
+
+        al = (dict(algorithm=ma.Metropolis, pool=pool, seed=5, engine_factory=Watching),
+              dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.01)), q_batch_size=2),
+              dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+              dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy,), scheduler=ma.build_schedule(steps, 20, 25)),
+              dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=ma.build_schedule(steps, 20, 25), defer=defer,
+                   store_last=True))
+        sim = ma.Simulation(chains, al, steps, path=path)
+        ma.run(sim)
+        files = [open(os.path.join(path, "parameters", str(k + 1), "parameters.dat")).read() for k in range(2)]
+        rows = [[(t, float(v[0])) for t, v in r] for r in sim.algorithms[-1].rows]
+        out.append((files, rows, reads, pool[1].sigma))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert out[0][2] == [] and out[1][2] == ["begin", "end"] * 5          # times 20, 45, 70, 95, 100: one read in flight
+    assert len(out[1][1][1]) == 7 and out[1][1][1][0] == (0, 0.1) and out[1][1][1][-1][1] == out[1][3] != 0.1   # t = 0 row, five, store_last
+    assert out[0][3] == out[1][3]
+
+
 def test_deferred_callback_rows_are_the_same_rows_written_one_period_later(oracle, tmp_path):
     """StoreCallbacks(defer=True, the default for the engine-backed callbacks): the row of time t is written when the next
     scheduled time comes (or at finalise); the reduction is claimed at t (a ticket) and fetched later.  Files and rows are

@@ -6,7 +6,7 @@ import montecarlo_amd as ma
 M, steps = 10_000_000, 3000
 
 
-def run(label, est_every, upd_every, cb_every, q=1):
+def run(label, est_every, upd_every, cb_every, q=1, params_every=0):
     chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
             ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
@@ -18,12 +18,20 @@ def run(label, est_every, upd_every, cb_every, q=1):
     if cb_every:
         al.append(dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy, ma.callback_acceptance),
                        scheduler=ma.build_schedule(steps, 100, cb_every)))
+    if params_every:
+        al.append(dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=ma.build_schedule(steps, 100, params_every)))
     with tempfile.TemporaryDirectory() as d:
         sim = ma.Simulation(chains, tuple(al), steps, path=d)
         t0 = time.perf_counter(); ma.run(sim); dt = time.perf_counter() - t0
     print(f"{label:64s} {dt / steps * 1e6:8.1f} us per time step   sigma={[round(m.sigma, 3) for m in pool]}", flush=True)
 
 
+if os.environ.get("ONLY_PARAMS"):
+    run("config 5 (callbacks every 10)", 1, 1, 10)
+    run("config 5 + StoreParameters every 10 (the reference's script)", 1, 1, 10, params_every=10)
+    run("config 5 (callbacks every 10)", 1, 1, 10)
+    run("config 5 + StoreParameters every 10 (the reference's script)", 1, 1, 10, params_every=10)
+    sys.exit(0)
 run("sweeps only, no callbacks", 0, 0, 0)
 run("sweeps only, callbacks every 10", 0, 0, 10)
 run("sweeps only, callbacks every step", 0, 0, 1)
