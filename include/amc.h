@@ -221,6 +221,11 @@ int  amc_set_counter_totals(amc_handle *h, const int64_t *accepted, uint64_t ste
  * histogram over n_bins half-open bins of [lo, hi), bin = floor((x - lo) * (n_bins / (hi - lo)));
  * counts has n_bins + 3 entries: bins, then x < lo, x >= hi, NaN.  Local shard only (sum across shards). */
 int  amc_histogram(amc_handle *h, double lo, double hi, int n_bins, uint64_t *counts);
+/* The same histogram ACCUMULATED on the device over many calls (a density sampled every few sweeps): _accumulate queues one
+ * pass over the positions as of this point of the stream and returns at once; _fetch waits, returns the running counts
+ * (layout as above) and, with reset != 0, zeroes them.  The first _accumulate fixes (lo, hi, n_bins) until the next reset. */
+int  amc_histogram_accumulate(amc_handle *h, double lo, double hi, int n_bins);
+int  amc_histogram_fetch(amc_handle *h, uint64_t *counts, int n_bins, int reset);
 /* x[first + i*stride], i < count: a strided binary snapshot of this shard. */
 int  amc_download_strided(amc_handle *h, int64_t first, int64_t stride, int64_t count, double *x);
 

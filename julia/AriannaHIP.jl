@@ -376,6 +376,20 @@ function pull_parameters!(metropolis::HIPMetropolis)
     return nothing
 end
 
+# The pooled-position histogram accumulated on the device over the sample times (the density plot of
+# MC_harmonic_oscillator.jl:40-51 without trajectories): `histogram_accumulate!` queues one pass, `histogram_fetch!` returns
+# the running counts (n_bins bins, then below lo, at / above hi, NaN) and optionally resets them.
+function histogram_accumulate!(metropolis::HIPMetropolis, lo::Float64, hi::Float64, n_bins::Int)
+    check(ccall((:amc_histogram_accumulate, libamc), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cint), metropolis.handle, lo, hi, n_bins))
+    return nothing
+end
+
+function histogram_fetch!(metropolis::HIPMetropolis, n_bins::Int; reset::Bool=true)
+    counts = Vector{UInt64}(undef, n_bins + 3)
+    check(ccall((:amc_histogram_fetch, libamc), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Cint, Cint), metropolis.handle, counts, n_bins, reset ? 1 : 0))
+    return counts
+end
+
 # The same read without waiting for the queued steps: `parameters_begin!` queues a copy of every σ as of this point of the
 # stream, `parameters_end!` returns them later (a StoreParameters that writes the row of time t when the next one is due,
 # src/metropolis.jl:433-440).  One read in flight per handle.

@@ -93,6 +93,8 @@ def load() -> C.CDLL:
         "amc_upload_counters": (C.c_int, [H, i64p, i64p]),
         "amc_set_counter_totals": (C.c_int, [H, i64p, C.c_uint64]),
         "amc_histogram": (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_uint64)]),
+        "amc_histogram_accumulate": (C.c_int, [H, C.c_double, C.c_double, C.c_int]),
+        "amc_histogram_fetch": (C.c_int, [H, C.POINTER(C.c_uint64), C.c_int, C.c_int]),
         "amc_download_strided": (C.c_int, [H, C.c_int64, C.c_int64, C.c_int64, dp]),
         "amc_get_estimator_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "amc_set_estimator_step": (C.c_int, [H, C.c_uint64]),
@@ -304,6 +306,15 @@ class HipEngine:
         """counts[n_bins + 3]: the bins of [lo, hi), then below lo, at/above hi, NaN (this shard only)."""
         out = np.zeros(int(n_bins) + 3, dtype=np.uint64)
         _check(self._lib.amc_histogram(self._h, float(lo), float(hi), int(n_bins), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def histogram_accumulate(self, lo: float, hi: float, n_bins: int) -> None:
+        """Add the histogram of the positions as of this point of the stream to the running one on the device (asynchronous)."""
+        _check(self._lib.amc_histogram_accumulate(self._h, float(lo), float(hi), int(n_bins)))
+
+    def histogram_fetch(self, n_bins: int, reset: bool = True) -> np.ndarray:
+        out = np.zeros(int(n_bins) + 3, dtype=np.uint64)
+        _check(self._lib.amc_histogram_fetch(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(n_bins), 1 if reset else 0))
         return out
 
     def download_strided(self, first: int, stride: int, count: int) -> np.ndarray:

@@ -136,6 +136,9 @@ struct amc_handle {
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
+    unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]
+    int hist_bins = 0;
+    double hist_lo = 0.0, hist_hi = 0.0;
     hipEvent_t ev_params = nullptr;   // behind the copy queued by amc_parameters_begin
     double* h_params = nullptr;       // pinned [AMC_MAX_MOVES]: its destination
     bool params_pending = false;
@@ -1108,6 +1111,7 @@ int amc_destroy(amc_handle* h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_red) (void)hipEventDestroy(h->ev_red);
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
+    (void)hipFree(h->d_hist);
     if (h->h_params) (void)hipHostFree(h->h_params);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1507,6 +1511,46 @@ int amc_histogram(amc_handle* h, double lo, double hi, int n_bins, uint64_t* cou
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_counts);
     if (e != hipSuccess) return fail(AMC_ERR_HIP, "amc_histogram: %s", hipGetErrorString(e));
+    return AMC_OK;
+}
+
+int amc_histogram_accumulate(amc_handle* h, double lo, double hi, int n_bins)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_histogram_accumulate: NULL handle");
+    if (n_bins < 1 || n_bins > 8192 || !(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi))
+        return fail(AMC_ERR_BAD_ARG, "amc_histogram_accumulate: need 1 <= n_bins <= 8192 and finite lo < hi");
+    AMC_HIP(hipSetDevice(h->device));
+    if (h->d_hist && (n_bins != h->hist_bins || lo != h->hist_lo || hi != h->hist_hi))
+        return fail(AMC_ERR_STATE, "amc_histogram_accumulate: the running histogram has other bins (fetch it with reset first)");
+    if (!h->d_hist) {
+        const size_t bytes = (size_t)(n_bins + 3) * sizeof(unsigned long long);
+        AMC_HIP(hipMalloc(&h->d_hist, bytes));
+        AMC_HIP(hipMemsetAsync(h->d_hist, 0, bytes, h->stream));
+        h->hist_bins = n_bins; h->hist_lo = lo; h->hist_hi = hi;
+    }
+    const double inv_w = (double)n_bins / (hi - lo);
+    const double* d_pos = nullptr;
+    { const int rc = positions_f64(h, &d_pos); if (rc != AMC_OK) return rc; }
+    hipLaunchKernelGGL(amc::histogram_kernel, dim3(h->red_blocks), dim3(AMC_BLOCK), (size_t)(n_bins + 3) * sizeof(unsigned int),
+                       h->stream, d_pos, h->M, lo, hi, inv_w, n_bins, h->d_hist);
+    AMC_HIP(hipGetLastError());
+    return AMC_OK;
+}
+
+int amc_histogram_fetch(amc_handle* h, uint64_t* counts, int n_bins, int reset)
+{
+    if (!h || !counts) return fail(AMC_ERR_BAD_ARG, "amc_histogram_fetch: NULL argument");
+    if (!h->d_hist) return fail(AMC_ERR_STATE, "amc_histogram_fetch: nothing has been accumulated");
+    if (n_bins != h->hist_bins) return fail(AMC_ERR_BAD_ARG, "amc_histogram_fetch: the running histogram has %d bins", h->hist_bins);
+    AMC_HIP(hipSetDevice(h->device));
+    const size_t bytes = (size_t)(n_bins + 3) * sizeof(unsigned long long);
+    AMC_HIP(hipMemcpyAsync(counts, h->d_hist, bytes, hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(hipStreamSynchronize(h->stream));
+    if (reset) {
+        (void)hipFree(h->d_hist);
+        h->d_hist = nullptr;
+        h->hist_bins = 0;
+    }
     return AMC_OK;
 }
 

@@ -40,13 +40,40 @@ class StoreHistogram(AriannaAlgorithm):
         self.path = os.path.join(path, "histogram.dat")
         self.rank, _ = sharding.world()
 
+    def _settle(self) -> None:
+        """The moments of the previous sample (a reduction ticket claimed then) are fetched when the next one is due."""
+        ticket, self._ticket = getattr(self, "_ticket", None), None
+        if ticket is not None:
+            r = ticket.result()
+            n = r["n_chains"]
+            self.moments += np.array([n, r["mean_x"] * n, r["mean_x2"] * n])
+
     def make_step(self, simulation: Simulation) -> None:
-        self.counts += self.metropolis.engine.histogram(self.lo, self.hi, self.bins)
-        r = self.metropolis.reductions()
-        n = r["n_chains"]
-        self.moments += np.array([n, r["mean_x"] * n, r["mean_x2"] * n])
+        eng = self.metropolis.engine
+        self._settle()
+        on_device = hasattr(eng, "histogram_accumulate") and getattr(self, "_on_device", True)
+        if on_device:
+            # the counts stay on the device until finalise and the moments are read one sample late: nothing here makes the
+            # host wait for the queued sweeps (a histogram fetched at every sample time did, twice)
+            try:
+                eng.histogram_accumulate(self.lo, self.hi, self.bins)
+            except Exception:               # the engine's running histogram has other bins (a second StoreHistogram): fetch each time
+                if getattr(self, "_on_device", None):
+                    raise
+                on_device = False
+            self._on_device = on_device
+        if on_device:
+            self._ticket = self.metropolis.reductions_async()
+        else:
+            self.counts += eng.histogram(self.lo, self.hi, self.bins)
+            self._ticket = self.metropolis.reductions_async()
+            self._settle()
 
     def finalise(self, simulation: Simulation) -> None:
+        self._settle()
+        if getattr(self, "_on_device", False):
+            self.counts += self.metropolis.engine.histogram_fetch(self.bins, reset=True)
+            self._on_device = False
         total = sharding.allreduce_sum(self.counts.astype(np.float64))
         self.global_counts = np.rint(total).astype(np.uint64)
         n, sx, sxx = self.moments

@@ -489,6 +489,19 @@ class OracleEngine:
         out[n_bins], out[n_bins + 1], out[n_bins + 2] = below.sum(), above.sum(), nan.sum()
         return out
 
+    def histogram_accumulate(self, lo, hi, n_bins):
+        key = (float(lo), float(hi), int(n_bins))
+        assert getattr(self, "_hist_key", key) == key, "the running histogram has other bins"
+        self._hist_key = key
+        self._hist = getattr(self, "_hist", 0) + self.histogram(lo, hi, n_bins)
+
+    def histogram_fetch(self, n_bins, reset=True):
+        out = np.asarray(self._hist, dtype=np.uint64).copy()
+        assert out.shape[0] == n_bins + 3
+        if reset:
+            del self._hist, self._hist_key
+        return out
+
     def download_strided(self, first, stride, count):
         x, _ = self.sim.state()
         return x[first:first + count * stride:stride][:count].copy()

@@ -1152,6 +1152,34 @@ def test_counters_across_the_16_bit_mark(gpu, oracle, K):
     e.close(); e2.close()
 
 
+def test_histogram_accumulated_on_the_device(gpu, oracle):
+    """amc_histogram_accumulate / _fetch: the running histogram over several sample times equals the sum of the one-shot
+    histograms (and the oracle's), stays on the device between calls, and is re-binned only after a reset."""
+    M = 20_011
+    kw = dict(potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=4)
+    e = gpu.HipEngine(n_chains=M, **kw)
+    o = oracle.OracleEngine(n_chains=M, **kw)
+    e.init_uniform(-2.5, 2.5); o.init_uniform(-2.5, 2.5)
+    want = np.zeros(43, dtype=np.uint64)
+    for _ in range(4):
+        e.sweep(3); o.sweep(3)
+        e.histogram_accumulate(-2.0, 2.0, 40)
+        want += o.histogram(-2.0, 2.0, 40)
+    with pytest.raises(gpu.AmcError, match="other bins"):
+        e.histogram_accumulate(-2.0, 2.0, 41)
+    got = e.histogram_fetch(40, reset=False)
+    assert np.array_equal(got, want) and got.sum() == 4 * M
+    e.sweep(2); o.sweep(2)
+    e.histogram_accumulate(-2.0, 2.0, 40)
+    want += o.histogram(-2.0, 2.0, 40)
+    assert np.array_equal(e.histogram_fetch(40), want)                 # reset
+    with pytest.raises(gpu.AmcError, match="nothing has been accumulated"):
+        e.histogram_fetch(40)
+    e.histogram_accumulate(-1.0, 1.0, 8)                               # other bins after the reset
+    assert np.array_equal(e.histogram_fetch(8), o.histogram(-1.0, 1.0, 8)) and np.array_equal(e.histogram(-1.0, 1.0, 8), o.histogram(-1.0, 1.0, 8))
+    e.close(); o.close()
+
+
 def test_parameters_read_in_stream_order_without_draining_the_queue(gpu, oracle):
     """amc_parameters_begin / _end (StoreParameters beside device-resident learning steps, metropolis.jl:433-440): the read is a
     copy queued at its point of the stream -- steps queued AFTER it do not show in it -- fetched later; one in flight."""
