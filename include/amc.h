@@ -240,21 +240,42 @@ int  amc_set_step(amc_handle *h, uint64_t t);
 int  amc_get_estimator_step(amc_handle *h, uint64_t *t);
 int  amc_set_estimator_step(amc_handle *h, uint64_t t);
 
+/* Reproducible sums.  Everything that crosses chains on this path is a sum -- callback_energy (particle_1d.jl:68-70: mean),
+ * callback_acceptance (metropolis.jl:319-321: mean), the GradientData fold (estimator.jl:113-131: reducer(+, ...)) -- and the
+ * reference adds Float64s in whatever order its reducer takes.  Here each such sum is defined so that the order of the
+ * additions cannot enter the result (montecarlo_amd/csrc/amc_xsum.h): every summand is rounded once to
+ * a multiple of a power of two fixed by order-independent facts (the move's sigma; the largest magnitude among the
+ * summands), the multiples are added as integers, the total is rounded once to Float64.  The value is therefore the same
+ * for every grid, every split of the chains into shards and every number of GPUs, bit for bit.
+ * Between shards a partial sum travels as a RECORD of AMC_XSUM_WORDS doubles -- each word an integer below 2^53 in
+ * magnitude, so a record survives any f64 channel unchanged; all-zero words are the empty sum.  amc_xsum_merge adds
+ * records (into[i] += from[i], i < n_records), amc_xsum_round yields the Float64 of each; both are plain host functions.
+ * amc_allreduce_xsum (below, with the communicator) leaves on every shard the merged records of all shards. */
+#define AMC_XSUM_WORDS 12
+int  amc_xsum_merge(double *into, const double *from, int n_records);
+int  amc_xsum_round(const double *records, int n_records, double *out);
+
 /* callback_energy (particle_1d.jl:68-70) / callback_acceptance (metropolis.jl:319-321)
- * / position moments as LOCAL sums; deterministic (fixed summation order for a given grid): per-block
- * partial sums on the device, column sums by the host (K <= 4) or by two further device passes.
- * out: AMC_RED_HEADER + K doubles.  Divide by the global chain count after the
- * cross-shard sum. */
+ * / position moments as LOCAL sums (reproducible sums, above): per-block integer partial sums on the device, added up by the
+ * host.  out: AMC_RED_HEADER + K doubles.  For one shard these are the final sums; across shards exchange the RECORDS
+ * (amc_reduce_end_exact + amc_allreduce_xsum / amc_xsum_merge) -- adding the shards' rounded doubles would make the
+ * result depend on the split.  Divide by the global chain count. */
 int  amc_reduce(amc_handle *h, double *out);
 /* The same reduction split in two so the host need not drain the stream: _begin enqueues the kernels
- * and the device->host copy and returns; _end waits for THAT copy only (sweeps queued after _begin keep
- * running) and returns the values as of _begin.  One reduction may be in flight per handle. */
+ * and returns; _end waits for THAT reduction only (sweeps queued after _begin keep
+ * running) and returns the values as of _begin.  Up to TWO reductions may be in flight per handle; _end finishes the
+ * oldest (a host that writes a callback's row while the next callback's sums are being formed never waits). */
 int  amc_reduce_begin(amc_handle *h);
 /* n make_step!s followed by amc_reduce_begin of the resulting state.  The sums over x are formed inside the last sweep
  * launch (K <= 4: no second pass over the chains); with per-chain counters the acceptance ratios come from the fold of the
  * step log that follows it. */
 int  amc_sweep_reduce_begin(amc_handle *h, int64_t n_sweeps);
 int  amc_reduce_end(amc_handle *h, double *out);
+/* The same as records: (AMC_RED_HEADER + K) * AMC_XSUM_WORDS doubles, column order as above (the count is a record too).
+ * steps_counted (may be NULL) receives the MH steps counted per chain at _begin.  On a K = 1 handle without per-chain
+ * counters record AMC_RED_SUM_RATIO0 holds the pool-wide accepted TOTAL (an integer); sum_c accepted_c / total_c is its
+ * Float64 divided by steps_counted (every chain has the same total_calls). */
+int  amc_reduce_end_exact(amc_handle *h, double *records, uint64_t *steps_counted);
 
 /* Move.parameters (shared by all chains, metropolis.jl:252-260): read / replace
  * sigma_k on the device copy, e.g. after learning_step! (update.jl:50-57). */
@@ -273,11 +294,16 @@ int  amc_parameters_end(amc_handle *h, double *sigma);
  * leaves x at (x+delta)-delta (gradients.jl:98,103).  out: n_learn*AMC_GD_STRIDE. */
 int  amc_pg_estimate(amc_handle *h, int n_learn, const int *learn_ids, int q_batch,
                      double *out);
+/* The same fold as records (reproducible sums): n_learn * AMC_GD_STRIDE * AMC_XSUM_WORDS doubles, what shards exchange. */
+int  amc_pg_estimate_exact(amc_handle *h, int n_learn, const int *learn_ids, int q_batch,
+                           double *records);
 
 /* Device-resident variant of the estimator/update pair (no host round trip per step):
  *   amc_pg_accumulate  = make_step!(::PolicyGradientEstimator): the same kernel as amc_pg_estimate, then
- *                        (if amc_comm_init was called) ONE in-place RCCL all-reduce of 4*n_learn doubles on
- *                        the engine's stream, then gradients_data[k] += gd on the device (estimator.jl:130).
+ *                        (if amc_comm_init was called) ONE in-place RCCL all-reduce on the engine's stream that gathers
+ *                        the shards' records (4 n_learn AMC_XSUM_WORDS doubles per shard), then the integer merge, one
+ *                        rounding and gradients_data[k] += gd on the device (estimator.jl:130): the same bits on every
+ *                        shard as on a single shard holding all the chains.
  *   amc_pg_update      = make_step!(::PolicyGradientUpdate) (update.jl:50-57): average, learning_step! for
  *                        P = 1 with optimiser ids below and their two hyper-parameters (eta or delta, eps_id),
  *                        reset, refresh the device copy of sigma and its derived table.  Asynchronous.
@@ -333,6 +359,13 @@ int  amc_comm_init(amc_handle *h, int rank, int n_ranks, const void *id128);
 /* The sum runs on a stream of its own (the host waits for it without draining the sweeps queued on the engine's stream),
  * ordered behind the collectives the estimator has queued on the engine's stream with the same communicator. */
 int  amc_allreduce_sum(amc_handle *h, double *buf, int n);
+/* records[i] <- the merged records i of ALL shards (reproducible sums): one ncclAllReduce in which every shard fills its own
+ * slot of a zeroed buffer -- a gather that is exact whatever order RCCL adds in -- then amc_xsum_merge over the slots.
+ * Every shard ends with the same bits, those a single shard holding all the chains would have.  Identity without a communicator. */
+int  amc_allreduce_xsum(amc_handle *h, double *records, int n_records);
+/* *forced = 1 when the environment variable AMC_RCCL_LIBRARY replaced librccl in this process (a site's own build, or the
+ * tests' shared-memory stand-in): a multi-GPU figure obtained that way has to say so. */
+int  amc_comm_library_forced(int *forced);
 /* Drop the communicator: the handle is a single shard again (a later amc_comm_init may give it a new one).  For ranks whose
  * amc_comm_init succeeded in a launch where another rank's failed. */
 int  amc_comm_destroy(amc_handle *h);

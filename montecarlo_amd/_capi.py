@@ -19,6 +19,7 @@ AMC_MAX_MOVES = 64
 AMC_MAX_LEARN = 8
 AMC_RED_HEADER = 4
 AMC_GD_STRIDE = 5
+AMC_XSUM_WORDS = 12      # doubles per record of a reproducible sum (include/amc.h)
 
 POTENTIALS = {"harmonic": 0, "double_well": 1}
 AMC_POTENTIAL_CUSTOM = 2
@@ -105,6 +106,12 @@ def load() -> C.CDLL:
         "amc_reduce_begin": (C.c_int, [H]),
         "amc_sweep_reduce_begin": (C.c_int, [H, C.c_int64]),
         "amc_reduce_end": (C.c_int, [H, dp]),
+        "amc_reduce_end_exact": (C.c_int, [H, dp, C.POINTER(C.c_uint64)]),
+        "amc_xsum_merge": (C.c_int, [dp, dp, C.c_int]),
+        "amc_xsum_round": (C.c_int, [dp, C.c_int, dp]),
+        "amc_pg_estimate_exact": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amc_allreduce_xsum": (C.c_int, [H, dp, C.c_int]),
+        "amc_comm_library_forced": (C.c_int, [C.POINTER(C.c_int)]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_get_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
         "amc_parameters_begin": (C.c_int, [H]),
@@ -174,6 +181,41 @@ def _dptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+# ---- reproducible sums (include/amc.h "Reproducible sums"): records are rows of AMC_XSUM_WORDS doubles -----------------
+def xsum_merge(into: np.ndarray, other: np.ndarray) -> np.ndarray:
+    """into[i] += other[i] for records of shape (n, AMC_XSUM_WORDS); exact (integers), so the order of merges is immaterial."""
+    a = np.ascontiguousarray(into, dtype=np.float64).reshape(-1, AMC_XSUM_WORDS).copy()
+    b = np.ascontiguousarray(other, dtype=np.float64).reshape(-1, AMC_XSUM_WORDS)
+    if a.shape != b.shape:
+        raise AmcError(f"xsum_merge: record arrays of shapes {a.shape} and {b.shape}")
+    _check(load().amc_xsum_merge(_dptr(a), _dptr(b), a.shape[0]))
+    return a
+
+
+def xsum_round(records: np.ndarray) -> np.ndarray:
+    """The Float64 of each record: the integer total rounded once."""
+    a = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, AMC_XSUM_WORDS)
+    out = np.empty(a.shape[0], dtype=np.float64)
+    _check(load().amc_xsum_round(_dptr(a), a.shape[0], _dptr(out)))
+    return out
+
+
+def xsum_plain(values) -> np.ndarray:
+    """Records that hold plain numbers (counts: integers, exact under +)."""
+    v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+    rec = np.zeros((v.size, AMC_XSUM_WORDS))
+    rec[:, 0] = 3.0
+    rec[:, 11] = v
+    return rec
+
+
+def comm_library_forced() -> bool:
+    """True when AMC_RCCL_LIBRARY replaced librccl in this process (a site's own build, or the tests' stand-in)."""
+    f = C.c_int(0)
+    _check(load().amc_comm_library_forced(C.byref(f)))
+    return bool(f.value)
+
+
 class HipEngine:
     """One amc_handle: the device-resident shard of the chain ensemble.
 
@@ -197,6 +239,7 @@ class HipEngine:
                            "and CustomPotential(expr)")
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
+        self.per_chain_counters = bool(per_chain_counters) or self.n_moves > 1
         self._sigma = (C.c_double * self.n_moves)(*[float(s) for s in sigma])
         self._weight = (C.c_double * self.n_moves)(*[float(w) for w in weight])
         cfg = AmcConfig()
@@ -364,6 +407,28 @@ class HipEngine:
         _check(self._lib.amc_reduce_end(self._h, _dptr(out)))
         return out
 
+    def reduce_end_exact(self):
+        """The oldest reduction in flight as records, shape (AMC_RED_HEADER + K, AMC_XSUM_WORDS), and the MH steps counted per
+        chain when it was begun.  What shards exchange (sharding.allreduce_xsum); ``reduce_records_value`` turns merged
+        records into the numbers reduce_end() returns."""
+        rec = np.zeros((AMC_RED_HEADER + self.n_moves, AMC_XSUM_WORDS), dtype=np.float64)
+        steps = C.c_uint64(0)
+        _check(self._lib.amc_reduce_end_exact(self._h, _dptr(rec), C.byref(steps)))
+        return rec, int(steps.value)
+
+    def reduce_exact(self):
+        self.reduce_begin()
+        return self.reduce_end_exact()
+
+    def reduce_records_value(self, records: np.ndarray, steps_counted: int) -> np.ndarray:
+        """Merged records -> the sums (layout of amc_reduce).  A K = 1 engine without per-chain counters carries the pool-wide
+        accepted TOTAL in the ratio record: every chain has the same total_calls, the ratio sum is that total / steps."""
+        out = xsum_round(records)
+        if self.n_moves == 1 and not self.per_chain_counters:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out[AMC_RED_HEADER] = out[AMC_RED_HEADER] / np.float64(steps_counted)   # 0/0 = NaN before the first step
+        return out
+
     def set_parameters(self, k: int, p: Sequence[float]) -> None:
         a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
         _check(self._lib.amc_set_parameters(self._h, int(k), _dptr(a), int(a.size)))
@@ -387,6 +452,14 @@ class HipEngine:
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
         out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
         _check(self._lib.amc_pg_estimate(self._h, n, ids, int(q_batch), _dptr(out)))
+        return out
+
+    def pg_estimate_exact(self, learn_ids: Sequence[int], q_batch: int) -> np.ndarray:
+        """The same fold as records, shape (n_learn, AMC_GD_STRIDE, AMC_XSUM_WORDS): what shards exchange."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, AMC_GD_STRIDE, AMC_XSUM_WORDS), dtype=np.float64)
+        _check(self._lib.amc_pg_estimate_exact(self._h, n, ids, int(q_batch), _dptr(out)))
         return out
 
     def pg_accumulate(self, learn_ids: Sequence[int], q_batch: int) -> None:
@@ -470,6 +543,12 @@ class HipEngine:
         _check(self._lib.amc_allreduce_sum(self._h, _dptr(a), int(a.size)))
         return a
 
+    def allreduce_xsum(self, records: np.ndarray) -> np.ndarray:
+        """The merged records of all shards (amc_allreduce_xsum: one RCCL all-reduce used as a gather, then the integer merge)."""
+        a = np.ascontiguousarray(records, dtype=np.float64).copy()
+        _check(self._lib.amc_allreduce_xsum(self._h, _dptr(a), int(a.size // AMC_XSUM_WORDS)))
+        return a
+
     def comm_destroy(self) -> None:
         """Drop the communicator: a single shard again."""
         _check(self._lib.amc_comm_destroy(self._h))
@@ -488,7 +567,8 @@ class SplitEngine:
     A single-sweep launch spends ~3 us in its launch boundary and ~2 us waiting for far memory at its ends; sub-shards
     on separate streams overlap one's ends with the other's body (31.3 -> 28.7 us per sweep of 1e7 chains measured with
     two).  Chains keep their GLOBAL ids, so every per-chain result is identical to the unsplit engine's; sums
-    (reductions, gradient data) are added over the parts on the host, i.e. equal up to summation order.
+    (reductions, gradient data) are merged over the parts on the host as exact integer records (reproducible sums), i.e. they
+    are bit-identical to the unsplit engine's too.
     The device-resident estimator / update path (pg_accumulate, pg_update, pgmc_steps) is not offered: those keep
     per-engine state; PolicyGradientEstimator falls back to the host path (pg_estimate) on a split engine."""
 
@@ -579,9 +659,26 @@ class SplitEngine:
             p.estimator_step = t
 
     def reduce(self) -> np.ndarray:
-        for p in self.parts:
-            p.reduce_begin()
-        return np.sum([p.reduce_end() for p in self.parts], axis=0)
+        rec, steps = self.reduce_exact()
+        return self.parts[0].reduce_records_value(rec, steps)
+
+    def reduce_exact(self):
+        self.reduce_begin()
+        return self.reduce_end_exact()
+
+    def reduce_end_exact(self):
+        rec, steps = None, 0
+        for p in self.parts:          # integer merges: the split does not enter the result
+            r, steps = p.reduce_end_exact()
+            rec = r if rec is None else xsum_merge(rec, r)
+        return rec, steps
+
+    def reduce_records_value(self, records, steps_counted):
+        return self.parts[0].reduce_records_value(records, steps_counted)
+
+    @property
+    def per_chain_counters(self) -> bool:
+        return self.parts[0].per_chain_counters
 
     def reduce_begin(self) -> None:
         for p in self.parts:
@@ -592,7 +689,8 @@ class SplitEngine:
             p.sweep_reduce_begin(n_sweeps)
 
     def reduce_end(self) -> np.ndarray:
-        return np.sum([p.reduce_end() for p in self.parts], axis=0)
+        rec, steps = self.reduce_end_exact()
+        return self.parts[0].reduce_records_value(rec, steps)
 
     def set_parameters(self, k, p_) -> None:
         for p in self.parts:
@@ -601,8 +699,16 @@ class SplitEngine:
     def get_parameters(self, k):
         return self.parts[0].get_parameters(k)
 
+    def pg_estimate_exact(self, learn_ids, q_batch) -> np.ndarray:
+        rec = None
+        for p in self.parts:
+            r = p.pg_estimate_exact(learn_ids, q_batch)
+            rec = r if rec is None else xsum_merge(rec, r).reshape(r.shape)
+        return rec
+
     def pg_estimate(self, learn_ids, q_batch) -> np.ndarray:
-        return np.sum([p.pg_estimate(learn_ids, q_batch) for p in self.parts], axis=0)
+        rec = self.pg_estimate_exact(learn_ids, q_batch)
+        return xsum_round(rec).reshape(rec.shape[0], AMC_GD_STRIDE)
 
     def sync(self) -> None:
         for p in self.parts:

@@ -84,8 +84,24 @@ struct Rccl {
 
 }  // namespace
 
-static const int RED_HOST_STRIDE = 8;   // doubles per row of the host-summed partials (one 64-byte write)
-static const int RATIO_STRIDE = 4;      // doubles per row of the fold's acceptance-ratio partials (K <= 4)
+static const int RED_HOST_STRIDE = amc::RED_ROW_WORDS;   // 64-bit words per row of the callback sums' block rows (red_finish)
+static const int RATIO_STRIDE = 4;      // words per row of the fold's acceptance-ratio partials (K <= 4): one integer per move
+static const int PG_MAX_COLS = AMC_MAX_LEARN * 4;   // GradientData columns of one estimator call
+static const int RED_TICKETS = 2;       // reductions that may be in flight per handle (amc_reduce_begin .. amc_reduce_end)
+
+// One reduction in flight: where its block rows land and what amc_reduce_end needs to finish it.
+struct RedTicket {
+    bool pending = false;
+    int rows = 0;                    // block rows of the sums over x in h_rows
+    int ratio_rows = 0;              // rows of h_ratio that belong to it (0: none)
+    bool ratio_acc = false;          // the per-move ratio totals come from h_ratio_acc (K > 4)
+    uint64_t t_counted = 0;
+    hipEvent_t ev = nullptr;
+    amc::xs_word* h_rows = nullptr;      // pinned [n_slots][RED_HOST_STRIDE]
+    amc::xs_word* h_ratio = nullptr;     // pinned [n_slots][RATIO_STRIDE]
+    unsigned long long* d_ratio_acc = nullptr;   // [AMC_MAX_MOVES][3] (reduce_kernel, K > 4)
+    unsigned long long* h_ratio_acc = nullptr;   // pinned copy
+};
 
 struct amc_handle {
     int device = 0;
@@ -121,31 +137,27 @@ struct amc_handle {
     unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
     unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
     int n_slots = 0;
-    double* d_partials = nullptr;
-    double* d_partials2 = nullptr;   // [32][n_vals + 1]: first level of the final reduce
-    double* h_partials = nullptr;    // pinned [n_slots][RED_HOST_STRIDE]: block partials the HOST sums (4 + K <= 8)
-    int red_rows = 0;                // rows of the reduction in flight
-    bool red_host = false;           // ... and whether they sit in h_partials
-    double* h_ratio = nullptr;       // pinned [n_slots][RATIO_STRIDE]: acceptance-ratio partials of a fold (K <= 4)
-    int red_ratio_rows = 0;          // rows of h_ratio that belong to the reduction in flight (0: none)
-    double* d_out = nullptr;
-    double* h_out = nullptr;    // pinned: result of a wide (K > 4) reduction between amc_reduce_begin and _end
-    double* h_pg_out = nullptr; // pinned: result of amc_pg_estimate (its own buffer: a reduction may be in flight in h_out)
+    amc::xs_word* d_partials = nullptr;   // [red_blocks][PG_MAX_COLS][XS_ROW_R]: block rows of the estimator's fold
+    RedTicket red[RED_TICKETS];      // reductions in flight, oldest first from red_head
+    int red_head = 0, red_count = 0;
+    double* d_out = nullptr;    // records of the estimator's fold: [comm ranks][PG_MAX_COLS][XS_WORDS]
+    int d_out_ranks = 1;
+    double* h_pg_out = nullptr; // pinned: records of amc_pg_estimate
     int red_blocks = 0;
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_red = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]
     int hist_bins = 0;
     double hist_lo = 0.0, hist_hi = 0.0;
     hipEvent_t ev_params = nullptr;   // behind the copy queued by amc_parameters_begin
     double* h_params = nullptr;       // pinned [AMC_MAX_MOVES]: its destination
     bool params_pending = false;
-    bool red_pending = false;
     bool ev1_marked = false;    // amc_timing_mark recorded the end event already
-    uint64_t red_t_counted = 0;
     void* comm = nullptr;
+    int comm_rank = 0, comm_ranks = 1;   // this shard's slot in record gathers (amc_comm_init's arguments)
+    int comm_capacity = 0;               // doubles d_comm / h_comm hold
     double* d_comm = nullptr;
     double* h_comm = nullptr;            // pinned staging of amc_allreduce_sum's values (the caller's buffer is pageable)
     hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
@@ -154,7 +166,7 @@ struct amc_handle {
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
-    double* d_pg_groups = nullptr;      // [groups][AMC_MAX_LEARN * 4]
+    amc::xs_word* d_pg_groups = nullptr;   // [groups][PG_MAX_COLS][XS_ROW_R]
     amc::PgTail* d_pg_tail = nullptr;   // the estimator kernel's per-configuration record (see amc::PgTail)
     amc::PgTail pg_tail_host;           // ... and what it holds now (rewritten only when it changes)
     bool pg_tail_valid = false;
@@ -242,7 +254,7 @@ int launch_sweep_s(amc_handle* h, const amc::SweepArgs& a, int grid)
 // no gain -- config 3: 37.3 against 37.6 us per time step with the callback read a period late, 41.0 against 38.9 read at
 // once; config 5: 72.7 against 70.7 either way.  The fold's waves do not fit beside five 96-register waves of the fused
 // kernel, so they take whole wave slots from it, and the cross-stream events cost more than the overlap returns.)
-int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
+int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr, amc::xs_word* ratio_dst = nullptr)
 {
     if (!h->d_log || (h->log_fill == 0 && !with_ratio)) return AMC_OK;
     // tiles of AMC_FOLD_TILE chains, dealt evenly: every block takes the same number of tiles (a grid of 2048 over 2442
@@ -254,11 +266,11 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
     uint16_t* const no_hi = nullptr;
 #define AMC_FOLD_W(KS, RATIO)                                                                                         \
     hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint32_t, false>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, h->d_acc, h->d_tot, no_hi, no_hi, h->M, h->M_pad, 0, h->t_counted, h->h_ratio, RATIO_STRIDE)
+                       h->d_log, h->log_fill, h->d_acc, h->d_tot, no_hi, no_hi, h->M, h->M_pad, 0, h->t_counted, ratio_dst, RATIO_STRIDE)
 #define AMC_FOLD_N(KS, RATIO, HIGH)                                                                                   \
     hipLaunchKernelGGL((amc::fold_log_kernel<KS, RATIO, uint16_t, HIGH>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
                        h->d_log, h->log_fill, h->d_acc16, h->d_tot16, h->d_acc_hi, h->d_tot_hi, h->M, h->M_pad, 0, h->t_counted, \
-                       h->h_ratio, RATIO_STRIDE)
+                       ratio_dst, RATIO_STRIDE)
 #define AMC_FOLD(KS, RATIO)                                                                                           \
     do {                                                                                                              \
         if (!h->narrow) AMC_FOLD_W(KS, RATIO);                                                                        \
@@ -286,7 +298,7 @@ int fold_log(amc_handle* h, bool with_ratio = false, int* ratio_rows = nullptr)
             const int n_groups = (h->K + 3) / 4;
 #define AMC_FOLD_GROUP(KS, GROUP, BYTES)                                                                              \
     hipLaunchKernelGGL((amc::fold_log_kernel<KS, false, uint32_t, false, GROUP, BYTES>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, \
-                       h->d_log, h->log_fill, acc_g, tot_g, no_hi, no_hi, h->M, h->M_pad, g, h->t_counted, h->h_ratio, RATIO_STRIDE)
+                       h->d_log, h->log_fill, acc_g, tot_g, no_hi, no_hi, h->M, h->M_pad, g, h->t_counted, ratio_dst, RATIO_STRIDE)
 #define AMC_FOLD_GROUPS(BYTES)                                                                                        \
     for (int g = 0; g < n_groups; ++g) {                                                                              \
         uint32_t* const acc_g = h->d_acc + 4 * (size_t)g * (size_t)h->M_pad;                                          \
@@ -529,6 +541,7 @@ std::string rtc_cache_path(const std::string& expr, const std::string& inst, con
     h = fnv1a(AMC_RTC_SRC_KERNELS, h);
     h = fnv1a(AMC_RTC_SRC_MATH, h);
     h = fnv1a(AMC_RTC_SRC_TABLES, h);
+    h = fnv1a(AMC_RTC_SRC_XSUM, h);
     char name[64];
     std::snprintf(name, sizeof(name), "/amc_rtc_%016llx.bin", (unsigned long long)h);
     return std::string(dir) + name;
@@ -615,10 +628,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
     src += "#include \"amc_kernels.h\"\n";
-    const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES};
-    const char* names[] = {"amc_kernels.h", "amc_math.h", "amc_tables.h"};
+    const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES, AMC_RTC_SRC_XSUM};
+    const char* names[] = {"amc_kernels.h", "amc_math.h", "amc_tables.h", "amc_xsum.h"};
     void* prog = nullptr;
-    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", 3, headers, names);
+    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", 4, headers, names);
     if (e != 0) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", e);
     e = g_hiprtc.AddNameExpression(prog, inst.c_str());
     if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
@@ -936,17 +949,17 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMalloc(&h->d_acc_slots, (size_t)h->n_slots * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
     h->red_blocks = grid_for(h, h->M);
-    {
-        size_t per_block = (size_t)(4 + AMC_MAX_MOVES);
-        if (per_block < (size_t)AMC_MAX_LEARN * 4) per_block = (size_t)AMC_MAX_LEARN * 4;
-        AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * per_block * sizeof(double)));
+    AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));
+    for (int i = 0; i < RED_TICKETS; ++i) {
+        RedTicket& t = h->red[i];
+        AMC_TRY(hipHostMalloc((void**)&t.h_rows, (size_t)h->n_slots * RED_HOST_STRIDE * sizeof(amc::xs_word), 0));
+        AMC_TRY(hipHostMalloc((void**)&t.h_ratio, (size_t)h->n_slots * RATIO_STRIDE * sizeof(amc::xs_word), 0));
+        AMC_TRY(hipMalloc(&t.d_ratio_acc, (size_t)AMC_MAX_MOVES * 3 * sizeof(unsigned long long)));
+        AMC_TRY(hipHostMalloc((void**)&t.h_ratio_acc, (size_t)AMC_MAX_MOVES * 3 * sizeof(unsigned long long), 0));
+        AMC_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
     }
-    AMC_TRY(hipHostMalloc((void**)&h->h_partials, (size_t)h->n_cu * h->blocks_per_cu * RED_HOST_STRIDE * sizeof(double), 0));
-    AMC_TRY(hipHostMalloc((void**)&h->h_ratio, (size_t)h->n_cu * h->blocks_per_cu * RATIO_STRIDE * sizeof(double), 0));
-    AMC_TRY(hipMalloc(&h->d_partials2, (size_t)32 * (4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
-    AMC_TRY(hipMalloc(&h->d_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double)));
-    AMC_TRY(hipHostMalloc((void**)&h->h_out, (size_t)(4 + AMC_MAX_MOVES + AMC_MAX_LEARN * 4 + 2) * sizeof(double), 0));
-    AMC_TRY(hipHostMalloc((void**)&h->h_pg_out, (size_t)AMC_MAX_LEARN * 4 * sizeof(double), 0));
+    AMC_TRY(hipMalloc(&h->d_out, (size_t)PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double)));
+    AMC_TRY(hipHostMalloc((void**)&h->h_pg_out, (size_t)PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double), 0));
     AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * 5 * sizeof(double)));
     AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
@@ -955,12 +968,11 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         const size_t groups = (size_t)(h->n_slots + amc::PG_GROUP - 1) / amc::PG_GROUP + 1;
         AMC_TRY(hipMalloc(&h->d_pg_tickets, (groups + 1) * sizeof(uint32_t)));
         AMC_TRY(hipMemsetAsync(h->d_pg_tickets, 0, (groups + 1) * sizeof(uint32_t), h->stream));
-        AMC_TRY(hipMalloc(&h->d_pg_groups, groups * AMC_MAX_LEARN * 4 * sizeof(double)));
+        AMC_TRY(hipMalloc(&h->d_pg_groups, groups * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));
         AMC_TRY(hipMalloc(&h->d_pg_tail, sizeof(amc::PgTail)));
     }
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
-    AMC_TRY(hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
     AMC_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
     AMC_TRY(hipHostMalloc((void**)&h->h_params, AMC_MAX_MOVES * sizeof(double), 0));
 #undef AMC_TRY
@@ -1101,15 +1113,18 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_totals);
     (void)hipFree(h->d_acc_slots);
     (void)hipFree(h->d_partials);
-    (void)hipFree(h->d_partials2);
-    if (h->h_partials) (void)hipHostFree(h->h_partials);
-    if (h->h_ratio) (void)hipHostFree(h->h_ratio);
+    for (int i = 0; i < RED_TICKETS; ++i) {
+        RedTicket& t = h->red[i];
+        if (t.h_rows) (void)hipHostFree(t.h_rows);
+        if (t.h_ratio) (void)hipHostFree(t.h_ratio);
+        (void)hipFree(t.d_ratio_acc);
+        if (t.h_ratio_acc) (void)hipHostFree(t.h_ratio_acc);
+        if (t.ev) (void)hipEventDestroy(t.ev);
+    }
     (void)hipFree(h->d_out);
-    if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_pg_out) (void)hipHostFree(h->h_pg_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ev_red) (void)hipEventDestroy(h->ev_red);
     if (h->ev_params) (void)hipEventDestroy(h->ev_params);
     (void)hipFree(h->d_hist);
     if (h->h_params) (void)hipHostFree(h->h_params);
@@ -1353,7 +1368,7 @@ static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
     a.key0 = (uint32_t)h->seed;
     a.key1 = (uint32_t)(h->seed >> 32);
     a.beta = h->beta;
-    a.red_partials = h->h_partials;
+    a.red_partials = h->red[(h->red_head + h->red_count) % RED_TICKETS].h_rows;   // the ticket a REDUCE launch would fill
     a.red_stride = RED_HOST_STRIDE;
     a.exact_accept = h->exact_accept ? 1 : 0;
     a.n_slots = h->n_slots;
@@ -1614,159 +1629,194 @@ int amc_set_step(amc_handle* h, uint64_t t)
     return AMC_OK;
 }
 
-// Final passes of a reduction over d_partials[n_rows][n_vals] (+ the accepted slots): n_vals + 1 doubles to `out`
-// (device or pinned host memory).  Two levels above FINAL_SPLIT_ROWS rows, see reduce_final_kernel.
-static const int FINAL_BLOCKS = 32, FINAL_SPLIT_ROWS = 256;
-static int launch_final_reduce(amc_handle* h, int n_rows, int n_vals, double* out, const unsigned long long* slots,
-                               int n_slots)
+// The ticket a new reduction fills (tickets complete in the order they were begun), or nullptr when RED_TICKETS are in flight.
+static RedTicket* red_next(amc_handle* h) { return h->red_count == RED_TICKETS ? nullptr : &h->red[(h->red_head + h->red_count) % RED_TICKETS]; }
+
+static int red_commit(amc_handle* h, RedTicket* t, int rows)
 {
-    if (n_rows <= FINAL_SPLIT_ROWS) {
-        hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, n_rows, n_vals,
-                           out, slots, n_slots, n_rows, n_slots);
-        AMC_HIP(hipGetLastError());
-        return AMC_OK;
-    }
-    const int rpb = (n_rows + FINAL_BLOCKS - 1) / FINAL_BLOCKS, spb = (n_slots + FINAL_BLOCKS - 1) / FINAL_BLOCKS;
-    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(FINAL_BLOCKS), dim3(AMC_BLOCK), 0, h->stream, h->d_partials, n_rows,
-                       n_vals, h->d_partials2, slots, n_slots, rpb, spb);
-    AMC_HIP(hipGetLastError());
-    // second level: the 32 rows of n_vals + 1 columns; its own slot column (index n_vals + 1) is written as 0 and
-    // lies past what any caller reads
-    hipLaunchKernelGGL(amc::reduce_final_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, h->d_partials2, FINAL_BLOCKS,
-                       n_vals + 1, out, (const unsigned long long*)nullptr, 0, FINAL_BLOCKS, 0);
-    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipEventRecord(t->ev, h->stream));
+    t->pending = true;
+    t->rows = rows;
+    t->t_counted = h->t_counted;
+    h->red_count += 1;
     return AMC_OK;
 }
 
 int amc_reduce_begin(amc_handle* h)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_reduce_begin: NULL handle");
-    if (h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
+    RedTicket* t = red_next(h);
+    if (!t) return fail(AMC_ERR_STATE, "amc_reduce_begin: %d reductions are already in flight (call amc_reduce_end)", RED_TICKETS);
     AMC_HIP(hipSetDevice(h->device));
     int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
-    const int n_vals = 4 + h->K;
-    h->red_ratio_rows = 0;
+    t->ratio_rows = 0;
+    t->ratio_acc = false;
     if (ratio_mode != 0 && h->K <= 4) {
         // per-chain counters, few moves: the fold of the step log forms the acceptance-ratio sums while the counters
         // are in its registers (rows in h_ratio); the pass below then reads x only
-        const int rc = fold_log(h, true, &h->red_ratio_rows);
+        const int rc = fold_log(h, true, &t->ratio_rows, t->h_ratio);
         if (rc != AMC_OK) return rc;
         ratio_mode = 0;
     } else if (ratio_mode != 0) {
         const int rc = fold_log(h);
         if (rc != AMC_OK) return rc;
+        AMC_HIP(hipMemsetAsync(t->d_ratio_acc, 0, (size_t)AMC_MAX_MOVES * 3 * sizeof(unsigned long long), h->stream));
+        t->ratio_acc = true;
     }
-    // Few columns (K <= 4): the blocks store their partial rows straight into pinned, device-mapped host memory
-    // and the HOST forms the column sums in amc_reduce_end -- no final-pass launches (~5 us each even when empty)
-    // and no D2H copy in stream order (which would hold the next sweep back for a copy-engine round trip).
-    const bool host = n_vals <= RED_HOST_STRIDE;
-    double* rows = host ? h->h_partials : h->d_partials;
-    const int stride = host ? RED_HOST_STRIDE : n_vals;
-    const unsigned long long* slots = (host && ratio_mode == 0 && h->red_ratio_rows == 0) ? h->d_acc_slots : nullptr;
+    // The blocks store their rows straight into pinned, device-mapped host memory and the HOST adds them up in
+    // amc_reduce_end (integers: amc_xsum.h) -- no final-pass launches (~5 us each even when empty) and no D2H copy in
+    // stream order (which would hold the next sweep back for a copy-engine round trip).
+    amc::xs_word* rows = t->h_rows;
+    const int stride = RED_HOST_STRIDE;
+    const unsigned long long* slots = (ratio_mode == 0 && t->ratio_rows == 0) ? h->d_acc_slots : nullptr;
+    unsigned long long* racc = t->d_ratio_acc;
     if (h->use_rtc) {
         const double* d_x = h->d_x;
         const uint32_t *d_acc = h->d_acc, *d_tot = h->d_tot;
         int64_t m = h->M, m_pad = h->M_pad;
         int k = h->K, mode = ratio_mode, st = stride, n_slots = h->n_slots;
         uint64_t t_counted = h->t_counted;
-        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots};
+        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots, &racc};
         const int rc = rtc_launch(h, "amc::reduce_kernel<" + std::to_string(h->potential) + ">", h->red_blocks, params);
         if (rc != AMC_OK) return rc;
     } else if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots);
+                           h->n_slots, racc);
     else
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots);
+                           h->n_slots, racc);
     AMC_HIP(hipGetLastError());
-    if (!host) {
-        // many columns: device final passes, result (n_vals + 1 doubles) stored into the pinned result buffer
-        const int rc = launch_final_reduce(h, h->red_blocks, n_vals, h->h_out, h->d_acc_slots, h->n_slots);
-        if (rc != AMC_OK) return rc;
-    }
-    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
-    h->red_pending = true;
-    h->red_host = host;
-    h->red_rows = h->red_blocks;
-    h->red_t_counted = h->t_counted;
-    return AMC_OK;
+    if (t->ratio_acc)
+        AMC_HIP(hipMemcpyAsync(t->h_ratio_acc, t->d_ratio_acc, (size_t)h->K * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               h->stream));
+    return red_commit(h, t, h->red_blocks);
 }
 
-// Second half of a reduction whose sums over x were formed by the launch that has just been queued (rows in
-// h_partials[grid][8]): with per-chain counters the fold of the step log (pending rows incl. that launch's) forms the ratio
-// sums -- no pass re-reads x or the counters.
+// Second half of a reduction whose sums over x were formed by the launch that has just been queued (rows in the next ticket's
+// h_rows[grid][RED_HOST_STRIDE], make_sweep_args): with per-chain counters the fold of the step log (pending rows incl. that
+// launch's) forms the ratio sums -- no pass re-reads x or the counters.
 static int finish_fused_reduce(amc_handle* h, int grid)
 {
-    h->red_ratio_rows = 0;
+    RedTicket* t = red_next(h);
+    if (!t) return fail(AMC_ERR_STATE, "finish_fused_reduce: no free reduction ticket");
+    t->ratio_rows = 0;
+    t->ratio_acc = false;
     if (h->counters) {
-        const int rc2 = fold_log(h, true, &h->red_ratio_rows);
+        const int rc2 = fold_log(h, true, &t->ratio_rows, t->h_ratio);
         if (rc2 != AMC_OK) return rc2;
     }
-    AMC_HIP(hipEventRecord(h->ev_red, h->stream));
-    h->red_pending = true;
-    h->red_host = true;
-    h->red_rows = grid;
-    h->red_t_counted = h->t_counted;
-    return AMC_OK;
+    return red_commit(h, t, grid);
 }
 
 int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
-    if (h->red_pending) return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: a reduction is already in flight (call amc_reduce_end)");
-    if (h->K > 4) {                         // wide rows: sweep, then the ordinary reduction passes
+    if (!red_next(h))
+        return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: %d reductions are already in flight (call amc_reduce_end)", RED_TICKETS);
+    if (h->K > 4) {                         // the ratio sums need the counters of every move: sweep, then the reduction pass
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
     int grid = 0;
-    const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote the sums over x to h_partials[grid][8]
+    const int rc = sweep_impl(h, n_sweeps, true, &grid);     // the last launch wrote the sums over x to the ticket's rows
     if (rc != AMC_OK) return rc;
     return finish_fused_reduce(h, grid);
+}
+
+// Finishes the OLDEST reduction in flight: its columns as records (amc_xsum.h): AMC_RED_HEADER + K of them.
+static int reduce_end_records(amc_handle* h, const char* who, double* recs, uint64_t* steps_counted)
+{
+    if (h->red_count == 0) return fail(AMC_ERR_STATE, "%s: no reduction in flight (call amc_reduce_begin)", who);
+    AMC_HIP(hipSetDevice(h->device));
+    RedTicket* t = &h->red[h->red_head];
+    AMC_HIP(wait_event(t->ev));                  // waits for that reduction only, not for work queued after it
+    t->pending = false;
+    h->red_head = (h->red_head + 1) % RED_TICKETS;
+    h->red_count -= 1;
+    namespace xs = amc::xs;
+    xs::PartR col[amc::RED_COLS];
+    for (int c = 0; c < amc::RED_COLS; ++c) col[c] = xs::part_r_empty();
+    double count = 0.0, slot_total = 0.0;
+    for (int r = 0; r < t->rows; ++r) {
+        const amc::xs_word* row = t->h_rows + (size_t)r * RED_HOST_STRIDE;
+        for (int c = 0; c < amc::RED_COLS; ++c) xs::part_r_merge(col[c], amc::xs_load_r_row(row + c * amc::XS_ROW_R));
+        double v;
+        std::memcpy(&v, row + amc::RED_ROW_COUNT, sizeof(double)); count += v;          // integers: exact in any order
+        std::memcpy(&v, row + amc::RED_ROW_SLOT, sizeof(double)); slot_total += v;
+    }
+    for (int c = 0; c < amc::RED_COLS; ++c) xs::rec_from_r(recs + (size_t)c * xs::XS_WORDS, col[c]);
+    xs::rec_from_plain(recs + (size_t)AMC_RED_COUNT * xs::XS_WORDS, count);
+    for (int k = 0; k < h->K; ++k) {
+        xs::PartQ q = xs::PartQ{xs::i128{0, 0}, 0u};
+        int e = xs::XS_E_RATIO;
+        if (t->ratio_rows > 0) {
+            for (int r = 0; r < t->ratio_rows; ++r) {
+                const long long v = (long long)t->h_ratio[(size_t)r * RATIO_STRIDE + k];
+                if (v == AMC_XS_POISON_HI) q.flags |= xs::XS_F_NAN;
+                else q.k = xs::i128_add(q.k, xs::i128_of(v));
+            }
+        } else if (t->ratio_acc) {
+            const unsigned long long* a = t->h_ratio_acc + 3 * k;
+            if (a[2] != 0) q.flags |= xs::XS_F_NAN;
+            // low halves (each below 2^32) and high halves were added separately: k = hi 2^32 + lo
+            xs::i128 hi = xs::i128_of((long long)a[1]);
+            hi = xs::i128{hi.lo << 32, (int64_t)(((uint64_t)hi.hi << 32) | (hi.lo >> 32))};
+            q.k = xs::i128_add(hi, xs::i128{a[0], 0});
+        } else {
+            // K == 1 without per-chain counters: total_calls is the same on every chain, so sum_c accepted_c / total is
+            // (sum_c accepted_c) / total up to rounding: the record is the pool-wide accepted TOTAL
+            // (an integer, quantum 2^0); whoever rounds it divides by steps_counted
+            q.k = xs::i128_of((long long)slot_total);
+            e = 0;
+        }
+        xs::rec_from_q(recs + (size_t)(AMC_RED_HEADER + k) * xs::XS_WORDS, q, e);
+    }
+    if (steps_counted) *steps_counted = t->t_counted;
+    return AMC_OK;
+}
+
+int amc_reduce_end_exact(amc_handle* h, double* records, uint64_t* steps_counted)
+{
+    if (!h || !records) return fail(AMC_ERR_BAD_ARG, "amc_reduce_end_exact: NULL argument");
+    return reduce_end_records(h, "amc_reduce_end_exact", records, steps_counted);
 }
 
 int amc_reduce_end(amc_handle* h, double* out)
 {
     if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce_end: NULL argument");
-    if (!h->red_pending) return fail(AMC_ERR_STATE, "amc_reduce_end: no reduction in flight (call amc_reduce_begin)");
-    AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(wait_event(h->ev_red));              // waits for the reduction only, not for work queued after it
-    h->red_pending = false;
-    const int n_vals = 4 + h->K;
-    double slot_total;
-    if (h->red_host) {
-        // fixed order: rows 0, 1, 2, ... per column (a function of the grid only)
-        double acc[RED_HOST_STRIDE] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        const int n_cols = h->red_ratio_rows > 0 ? 4 : n_vals;       // columns 4.. come from the fold's rows
-        for (int r = 0; r < h->red_rows; ++r) {
-            const double* row = h->h_partials + (size_t)r * RED_HOST_STRIDE;
-            for (int i = 0; i < n_cols; ++i) acc[i] += row[i];
-        }
-        for (int r = 0; r < h->red_ratio_rows; ++r) {
-            const double* row = h->h_ratio + (size_t)r * RATIO_STRIDE;
-            for (int k = 0; k < h->K; ++k) acc[4 + k] += row[k];
-        }
-        for (int i = 0; i < n_vals; ++i) out[i] = acc[i];
-        slot_total = acc[4];                     // K == 1, pool-wide counter: exact (integers below 2^53)
-    } else {
-        for (int i = 0; i < n_vals; ++i) out[i] = h->h_out[i];
-        slot_total = h->h_out[n_vals];
-    }
-    if (h->K == 1 && !h->counters) {
-        // K == 1 without per-chain counters: total_calls is the same on every chain, so
-        // sum_c accepted_c/total == (sum_c accepted_c)/total up to rounding
-        out[AMC_RED_SUM_RATIO0] = slot_total / (double)h->red_t_counted;
-    }
+    double recs[(AMC_RED_HEADER + AMC_MAX_MOVES) * amc::xs::XS_WORDS];
+    uint64_t steps = 0;
+    const int rc = reduce_end_records(h, "amc_reduce_end", recs, &steps);
+    if (rc != AMC_OK) return rc;
+    for (int i = 0; i < AMC_RED_HEADER + h->K; ++i) out[i] = amc::xs::rec_round(recs + (size_t)i * amc::xs::XS_WORDS);
+    if (h->K == 1 && !h->counters) out[AMC_RED_SUM_RATIO0] = out[AMC_RED_SUM_RATIO0] / (double)steps;
     return AMC_OK;
 }
 
 int amc_reduce(amc_handle* h, double* out)
 {
     if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_reduce: NULL argument");
+    if (h->red_count != 0) return fail(AMC_ERR_STATE, "amc_reduce: a reduction is in flight (call amc_reduce_end first)");
     const int rc = amc_reduce_begin(h);
     return rc != AMC_OK ? rc : amc_reduce_end(h, out);
+}
+
+// Host-side arithmetic on records (no device involved): into[i] += from[i]; out[i] = the Float64 of records[i].
+int amc_xsum_merge(double* into, const double* from, int n_records)
+{
+    if (!into || !from || n_records < 0) return fail(AMC_ERR_BAD_ARG, "amc_xsum_merge: bad argument");
+    for (int i = 0; i < n_records; ++i) amc::xs::rec_merge(into + (size_t)i * amc::xs::XS_WORDS, from + (size_t)i * amc::xs::XS_WORDS);
+    return AMC_OK;
+}
+
+int amc_xsum_round(const double* records, int n_records, double* out)
+{
+    if (!records || !out || n_records < 0) return fail(AMC_ERR_BAD_ARG, "amc_xsum_round: bad argument");
+    for (int i = 0; i < n_records; ++i) out[i] = amc::xs::rec_round(records + (size_t)i * amc::xs::XS_WORDS);
+    return AMC_OK;
 }
 
 int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
@@ -1818,11 +1868,11 @@ int amc_parameters_end(amc_handle* h, double* sigma)
     return AMC_OK;
 }
 
-// Validates, launches K3 over this shard and leaves sum_{chains x q} (j, grad j, grad logq, g) per learnable
-// move in h->d_out[l*4 + i] (device, on the stream).  Shared by the host- and device-resident estimator paths.
-// tail: 1 = sums only, 2 = + gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
+// Validates, launches K3 over this shard.  Shared by the host- and device-resident estimator paths.
+// tail: 1 = the totals of (j, grad j, grad logq, g) per learnable move as records in h->d_out (this shard's slot), 2 = instead
+// gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
 // with_sweep: the launch first does one make_step!(::Metropolis) (caller checked pg_fusable).
-// reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in h_partials[*grid_out][8].
+// reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in the next reduction ticket's rows.
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false, bool reduce = false,
                      int* grid_out = nullptr)
@@ -1844,7 +1894,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.x = h->d_x;
     a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
     a.ptab = h->d_ptab;
-    a.partials = h->d_partials;
+    a.partials = h->d_partials;          // [grid][nl * 4][words per column] (amc::PgKind)
     a.n_chains = h->M;
     a.pair0 = (uint64_t)h->offset >> 1;
     a.t_est = h->t_est;
@@ -1866,6 +1916,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         tl.status = h->d_status;
         tl.n_samples = (double)h->M * (double)q_batch;
         tl.n_moves = h->K;
+        tl.rank = h->comm ? h->comm_rank : 0;
+        tl.n_ranks = h->comm ? h->comm_ranks : 1;
         for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
         if (!h->pg_tail_valid || std::memcmp(&tl, &h->pg_tail_host, sizeof(tl)) != 0) {
@@ -1898,23 +1950,50 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         h->t_counted += 1;
         if (h->d_log) h->log_fill += 1;
     }
-    // the launch itself left sum_{blocks} partials[grid][nl][4] in d_out[nl*4] (in-kernel final reduction)
+    // tail 1: the launch itself left the columns' totals as records in d_out[ranks][n_learn * 4][XS_WORDS] (in-kernel final reduction)
     h->t_est += 1;
     *nl_out = nl;
+    return AMC_OK;
+}
+
+// The estimator's fold over this shard as records: n_learn * 4 of them (j, grad j, grad logq, g per learnable move).
+static int pg_estimate_records(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, const double** recs)
+{
+    int nl = 0;
+    const int rc = pg_launch(h, who, n_learn, learn_ids, q_batch, &nl);
+    if (rc != AMC_OK || n_learn == 0) return rc;
+    const int slot = h->comm ? h->comm_rank : 0;
+    const size_t n = (size_t)n_learn * 4 * amc::xs::XS_WORDS;
+    AMC_HIP(hipMemcpyAsync(h->h_pg_out, h->d_out + (size_t)slot * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    AMC_HIP(wait_stream(h->stream));
+    *recs = h->h_pg_out;
     return AMC_OK;
 }
 
 int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, double* out)
 {
     if (!h || !out) return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate: NULL argument");
-    int nl = 0;
-    const int rc = pg_launch(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &nl);
+    const double* recs = nullptr;
+    const int rc = pg_estimate_records(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &recs);
     if (rc != AMC_OK || n_learn == 0) return rc;
-    AMC_HIP(hipMemcpyAsync(h->h_pg_out, h->d_out, (size_t)nl * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    AMC_HIP(wait_stream(h->stream));
     for (int l = 0; l < n_learn; ++l) {
-        for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = h->h_pg_out[l * 4 + i];
+        for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = amc::xs::rec_round(recs + (size_t)(l * 4 + i) * amc::xs::XS_WORDS);
         out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
+    }
+    return AMC_OK;
+}
+
+int amc_pg_estimate_exact(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, double* records)
+{
+    if (!h || !records) return fail(AMC_ERR_BAD_ARG, "amc_pg_estimate_exact: NULL argument");
+    const double* recs = nullptr;
+    const int rc = pg_estimate_records(h, "amc_pg_estimate_exact", n_learn, learn_ids, q_batch, &recs);
+    if (rc != AMC_OK || n_learn == 0) return rc;
+    for (int l = 0; l < n_learn; ++l) {
+        for (int i = 0; i < 4; ++i)
+            std::memcpy(records + (size_t)(l * AMC_GD_STRIDE + i) * amc::xs::XS_WORDS, recs + (size_t)(l * 4 + i) * amc::xs::XS_WORDS,
+                        amc::xs::XS_WORDS * sizeof(double));
+        amc::xs::rec_from_plain(records + (size_t)(l * AMC_GD_STRIDE + AMC_GD_N) * amc::xs::XS_WORDS, (double)h->M * (double)q_batch);
     }
     return AMC_OK;
 }
@@ -1938,19 +2017,23 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep, reduce, grid_out);
     if (rc != AMC_OK || n_learn == 0) return rc;
     if (!h->comm) return AMC_OK;
-    // shards: one in-place all-reduce of n_learn*4 doubles on the engine's stream
-    const int e = h->rccl.AllReduce(h->d_out, h->d_out, (size_t)nl * 4, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    // shards: the launch wrote this shard's records into its slot of d_out[ranks][n_learn * 4][XS_WORDS] and zeroed the other
+    // slots, so ONE in-place all-reduce(sum) on the engine's stream is a gather -- exact whatever order RCCL adds in; the
+    // kernel behind it merges the shards' integer totals and rounds once (pg_merge_slots): every shard, and a single shard
+    // holding all the chains, arrive at the same bits
+    const size_t n_words = (size_t)h->comm_ranks * (size_t)n_learn * 4 * amc::xs::XS_WORDS;
+    const int e = h->rccl.AllReduce(h->d_out, h->d_out, n_words, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
     // one communicator, two streams: a collective amc_allreduce_sum queues on comm_stream later must start after this one
     AMC_HIP(hipEventRecord(h->ev_comm_main, h->stream));
     h->comm_main_pending = true;
     const double n_samples = (double)h->M_global * (double)q_batch;
     if (opt) {      // gradients_data += gd and the learning step in ONE launch: both sit on the critical path of the next sweep
-        hipLaunchKernelGGL(amc::pg_accumulate_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->d_ptab, h->d_gd_acc, n_learn,
-                           make_ids(n_learn, learn_ids), n_samples, *opt, h->K, h->d_status);
+        hipLaunchKernelGGL(amc::pg_accumulate_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->comm_ranks, h->d_ptab,
+                           h->d_gd_acc, n_learn, make_ids(n_learn, learn_ids), n_samples, *opt, h->K, h->d_status);
     } else {
-        hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, n_learn, make_ids(n_learn, learn_ids),
-                           n_samples, h->d_gd_acc);
+        hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->comm_ranks, n_learn,
+                           make_ids(n_learn, learn_ids), n_samples, h->d_gd_acc);
     }
     AMC_HIP(hipGetLastError());
     return AMC_OK;
@@ -2003,7 +2086,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     if (n_learn > 0 && (!learn_ids || (do_update && (!optimiser || !hyper0 || !hyper1))))
         return fail(AMC_ERR_BAD_ARG, "%s: NULL argument", who);
     if (reduce && n_steps < 1) return fail(AMC_ERR_BAD_ARG, "%s: n_steps must be >= 1", who);
-    if (reduce && h->red_pending) return fail(AMC_ERR_STATE, "%s: a reduction is already in flight (call amc_reduce_end)", who);
+    if (reduce && !red_next(h)) return fail(AMC_ERR_STATE, "%s: %d reductions are already in flight (call amc_reduce_end)", who, RED_TICKETS);
     amc::PgOpts opt;
     if (do_update && n_learn > 0) {
         const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt);
@@ -2175,6 +2258,10 @@ static void comm_release(amc_handle* h)
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     h->comm = nullptr;
+    h->comm_rank = 0;
+    h->comm_ranks = 1;
+    h->comm_capacity = 0;
+    h->pg_tail_valid = false;
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     h->comm_stream = nullptr;
     if (h->ev_comm_main) (void)hipEventDestroy(h->ev_comm_main);
@@ -2196,8 +2283,22 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
     if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
     // everything the communicator's users need exists BEFORE the communicator does: a failure below leaves the handle
     // a clean single shard (amc_allreduce_sum the identity again, a later amc_comm_init welcome)
-    hipError_t he = hipMalloc(&h->d_comm, 256 * sizeof(double));
-    if (he == hipSuccess) he = hipHostMalloc(&h->h_comm, 256 * sizeof(double), hipHostMallocDefault);
+    // room for a gather of every shard's callback records (amc_allreduce_xsum) and, in d_out, of its estimator records
+    const int capacity = n_ranks * (AMC_RED_HEADER + AMC_MAX_MOVES) * amc::xs::XS_WORDS > 256
+                             ? n_ranks * (AMC_RED_HEADER + AMC_MAX_MOVES) * amc::xs::XS_WORDS : 256;
+    hipError_t he = hipMalloc(&h->d_comm, (size_t)capacity * sizeof(double));
+    if (he == hipSuccess) he = hipHostMalloc(&h->h_comm, (size_t)capacity * sizeof(double), hipHostMallocDefault);
+    if (he == hipSuccess && n_ranks > h->d_out_ranks) {
+        double* bigger = nullptr;
+        he = hipStreamSynchronize(h->stream);
+        if (he == hipSuccess) he = hipMalloc(&bigger, (size_t)n_ranks * PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double));
+        if (he == hipSuccess) {
+            (void)hipFree(h->d_out);
+            h->d_out = bigger;
+            h->d_out_ranks = n_ranks;
+            h->pg_tail_valid = false;           // the estimator's record holds the old pointer
+        }
+    }
     // (a higher stream priority changes nothing for these few bytes between device-filling sweeps: measured, round 3)
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&h->ev_comm_main, hipEventDisableTiming);
@@ -2215,6 +2316,10 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
         comm_release(h);
         return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
     }
+    h->comm_rank = rank;
+    h->comm_ranks = n_ranks;
+    h->comm_capacity = capacity;
+    h->pg_tail_valid = false;                   // rank / n_ranks are part of the estimator's record
     return AMC_OK;
 }
 
@@ -2275,8 +2380,9 @@ int amc_runtime_info(int* hip_runtime_version, char* hip_runtime_path, int path_
 int amc_allreduce_sum(amc_handle* h, double* buf, int n)
 {
     if (!h || !buf) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: NULL argument");
-    if (n < 0 || n > 256) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, 256]");
+    if (n < 0) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n < 0");
     if (!h->comm) return AMC_OK;   // single shard: the local sum is the global sum
+    if (n > h->comm_capacity) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, %d]", h->comm_capacity);
     AMC_HIP(hipSetDevice(h->device));
     // The values are the caller's (host) numbers: nothing here depends on the sweeps queued on the engine's stream, so the
     // collective runs on comm_stream and the host waits for THAT only (bench.py keeps ten sweeps in flight behind a
@@ -2296,6 +2402,39 @@ int amc_allreduce_sum(amc_handle* h, double* buf, int n)
     AMC_HIP(hipMemcpyAsync(h->h_comm, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
     AMC_HIP(hipStreamSynchronize(h->comm_stream));
     std::memcpy(buf, h->h_comm, (size_t)n * sizeof(double));
+    return AMC_OK;
+}
+
+// records[i] <- the sum over all shards of records[i], for every i < n_records: a GATHER of the shards' records (each shard
+// fills its own slot of a zeroed buffer, so the all-reduce(sum) adds one value and zeros per word: exact in any order),
+// then the integer merge of amc_xsum.h in rank order -- which, the merge being exact, is any order.  Every shard ends
+// with the same bits, and they are the bits a single shard holding all the chains would have.
+int amc_allreduce_xsum(amc_handle* h, double* records, int n_records)
+{
+    if (!h || !records) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: NULL argument");
+    if (n_records < 0) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: n_records < 0");
+    if (!h->comm || n_records == 0) return AMC_OK;
+    const size_t per = (size_t)n_records * amc::xs::XS_WORDS;
+    if (per * (size_t)h->comm_ranks > (size_t)h->comm_capacity)
+        return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: at most %d records", h->comm_capacity / (h->comm_ranks * amc::xs::XS_WORDS));
+    std::vector<double> buf(per * (size_t)h->comm_ranks, 0.0);
+    std::memcpy(buf.data() + per * (size_t)h->comm_rank, records, per * sizeof(double));
+    const int rc = amc_allreduce_sum(h, buf.data(), (int)buf.size());
+    if (rc != AMC_OK) return rc;
+    std::memcpy(records, buf.data(), per * sizeof(double));
+    for (int r = 1; r < h->comm_ranks; ++r)
+        for (int i = 0; i < n_records; ++i)
+            amc::xs::rec_merge(records + (size_t)i * amc::xs::XS_WORDS, buf.data() + per * (size_t)r + (size_t)i * amc::xs::XS_WORDS);
+    return AMC_OK;
+}
+
+// 1 when AMC_RCCL_LIBRARY replaced librccl for this process (a site's own build -- or the tests' stand-in): a result obtained
+// that way must say so.
+int amc_comm_library_forced(int* forced)
+{
+    if (!forced) return fail(AMC_ERR_BAD_ARG, "amc_comm_library_forced: NULL argument");
+    const char* f = std::getenv("AMC_RCCL_LIBRARY");
+    *forced = (f && *f) ? 1 : 0;
     return AMC_OK;
 }
 

@@ -13,6 +13,7 @@
 #pragma once
 
 #include "amc_math.h"
+#include "amc_xsum.h"
 
 #define AMC_MAX_MOVES 64
 #define AMC_MAX_LEARN 8
@@ -454,6 +455,269 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
     __syncthreads();
 }
 
+// ---- reproducible cross-chain sums (amc_xsum.h): the device side ---------------------------
+// A lane keeps one f64 accumulator per kind-Q column and two per kind-R column; a wave keeps the integer totals of what its
+// lanes have flushed in LDS ("slots", written by its lane 0 only: no atomics); at the end of the kernel thread 0 of the block
+// merges the block's four wave slots into one row of 64-bit words that the next level (the tail of the estimator kernel, or
+// the host) adds up -- integers throughout, so no order of additions enters any result.
+typedef unsigned long long xs_word;
+enum { XS_ROW_Q = 2, XS_ROW_R = 6 };      // words per column of a block row: (lo, hi) / (top | flags << 32, k1.lo, k1.hi, k2.lo, k2.hi, 0)
+#define AMC_XS_POISON_HI ((long long)0x8000000000000000ull)   // kind-Q row whose sum is NaN: hi = INT64_MIN, lo = 0
+
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;                                  // valid in lane 0
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ void xs_store_q_row(xs_word* row, const xs::PartQ& p)
+{
+    const bool bad = p.flags != 0;
+    row[0] = bad ? 0ull : (xs_word)p.k.lo;
+    row[1] = bad ? (xs_word)AMC_XS_POISON_HI : (xs_word)p.k.hi;
+}
+__device__ __forceinline__ void xs_store_r_row(xs_word* row, const xs::PartR& p)
+{
+    row[0] = (xs_word)(uint32_t)p.top | ((xs_word)p.flags << 32);
+    row[1] = (xs_word)p.k1.lo; row[2] = (xs_word)p.k1.hi;
+    row[3] = (xs_word)p.k2.lo; row[4] = (xs_word)p.k2.hi;
+    row[5] = 0ull;
+}
+__host__ __device__ inline xs::PartQ xs_load_q_row(const xs_word* row)
+{
+    xs::PartQ p;
+    p.k.lo = (uint64_t)row[0]; p.k.hi = (int64_t)row[1];
+    p.flags = 0u;
+    if ((long long)row[1] == AMC_XS_POISON_HI && row[0] == 0ull) { p.flags = xs::XS_F_NAN; p.k = xs::i128{0, 0}; }
+    return p;
+}
+__host__ __device__ inline xs::PartR xs_load_r_row(const xs_word* row)
+{
+    xs::PartR p;
+    p.top = (int32_t)(uint32_t)row[0]; p.flags = (uint32_t)(row[0] >> 32);
+    p.k1.lo = (uint64_t)row[1]; p.k1.hi = (int64_t)row[2];
+    p.k2.lo = (uint64_t)row[3]; p.k2.hi = (int64_t)row[4];
+    return p;
+}
+
+// Kind Q: NC lane accumulators s[] with wave-uniform constants cbits[] (bits of 1.5 * 2^(E + 52)).  q_flush: every lane's
+// integer (bits(s) - cbits) is added into the wave's slot with LDS atomics -- its low 32 bits and its high part into two
+// separate 64-bit words, so no carry has to travel (k = hi 2^32 + lo) --, the accumulators restart at their constants.  No
+// wave-wide operation: a flush may sit inside divergent control flow (the ragged last trip).  An accumulator that has left its
+// binade met a NaN or an infinity (or, never with the quanta of amc_xsum.h, too large a sum): the column is NaN.
+struct QSlot {
+    unsigned long long lo, hi;          // hi: two's complement
+    unsigned int flags, pad_;
+};
+__device__ __forceinline__ void q_slot_clear(QSlot& s) { s.lo = 0ull; s.hi = 0ull; s.flags = 0u; s.pad_ = 0u; }
+template <int NC>
+__device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)[NC], QSlot* slot)
+{
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const uint64_t b = (uint64_t)__double_as_longlong(s[c]);
+        const long long k = (long long)(b - cbits[c]);
+        if (((b ^ cbits[c]) >> 52) != 0ull) atomicOr(&slot[c].flags, (unsigned int)xs::XS_F_NAN);
+        else if (k != 0) {
+            atomicAdd(&slot[c].lo, (unsigned long long)(k & 0xFFFFFFFFll));
+            atomicAdd(&slot[c].hi, (unsigned long long)(k >> 32));
+        }
+        s[c] = __longlong_as_double((long long)cbits[c]);
+    }
+}
+__device__ __forceinline__ xs::PartQ q_slot_value(const QSlot& s)
+{
+    // k = hi 2^32 + lo
+    const xs::i128 h = xs::i128_of((long long)s.hi);
+    const xs::i128 hs = xs::i128{h.lo << 32, (int64_t)(((uint64_t)h.hi << 32) | (h.lo >> 32))};
+    return xs::PartQ{xs::i128_add(hs, xs::i128{(uint64_t)s.lo, 0}), s.flags};
+}
+
+// Kind R: the running-top accumulators of NC columns.  top[] and what derives from it (the two levels' constants, the bound)
+// are wave-uniform -- every assignment comes from a readfirstlane --; a1[] / a2[] are the lane's 64-bit sums of the BIT PATTERNS
+// of t = c1 + lsb1(v) and t2 = c2 + lsb1(r) (amc_xsum.h): n bits(c) + the sum of the multiples, n = summands since the last flush.
+template <int NC>
+struct RLanes {
+    unsigned long long a1[NC], a2[NC];
+    double c1[NC], c2[NC];
+    uint32_t cap_hi[NC];
+    int top[NC];
+    int n[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ void r_set_level(RLanes<NC>& L, int c, int top)
+{
+    L.top[c] = top;
+    L.c1[c] = __longlong_as_double((long long)xs::xs_level_c_bits(top));
+    L.c2[c] = __longlong_as_double((long long)xs::xs_level_c_bits(top - 1));
+    L.cap_hi[c] = xs::xs_level_cap_hi(top);
+}
+
+template <int NC>
+__device__ __forceinline__ void r_init(RLanes<NC>& L, xs::PartR* slot)
+{
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        L.n[c] = 0;
+        r_set_level(L, c, xs::XS_LMIN);
+        L.a1[c] = L.a2[c] = 0ull;
+        if ((threadIdx.x & 63) == 0) slot[c] = xs::part_r_empty();
+    }
+}
+
+// The rare arm of r_deposit2: some lane holds a value the current top cannot take, or one that is not finite (or as good as).
+template <int NC>
+__device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& a, double& b, xs::PartR* slot)
+{
+    int need = xs::XS_LMIN;
+    uint32_t fl = 0u;
+    auto look = [&](double& v) {
+        const uint64_t bits = (uint64_t)__double_as_longlong(v);
+        const bool nan = ((bits >> 52) & 0x7FFull) == 0x7FFull && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
+        const int l = xs::xs_level_of(v);                  // > LMAX for infinities, NaN and finite |v| >= 2^999
+        if (l > xs::XS_LMAX) {
+            fl |= nan ? xs::XS_F_NAN : ((bits >> 63) ? xs::XS_F_NINF : xs::XS_F_PINF);
+            v = 0.0;                                       // the flags carry it
+        } else {
+            need = l > need ? l : need;
+        }
+    };
+    look(a);
+    look(b);
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const uint32_t f_nan = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_NAN) != 0u) ? xs::XS_F_NAN : 0u;
+    const uint32_t f_pinf = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_PINF) != 0u) ? xs::XS_F_PINF : 0u;
+    const uint32_t f_ninf = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_NINF) != 0u) ? xs::XS_F_NINF : 0u;
+    if (lane0) slot[c].flags |= f_nan | f_pinf | f_ninf;
+    need = wave_max_i32(need);
+    if (need > L.top[c]) {
+        // one level up the level-1 multiples ARE the new level-2 multiples; further up nothing of what was taken so far is
+        // as large as half a quantum of the new lower level.  (n summands are on the books: n times the new constants' bits.)
+        const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
+        const unsigned long long k1 = L.a1[c] - n * (unsigned long long)__double_as_longlong(L.c1[c]);
+        const bool one_up = need - L.top[c] == 1;
+        r_set_level(L, c, need);
+        L.a1[c] = n * (unsigned long long)__double_as_longlong(L.c1[c]);
+        L.a2[c] = (one_up ? k1 : 0ull) + n * (unsigned long long)__double_as_longlong(L.c2[c]);
+        if (lane0) xs::part_r_raise(slot[c], need);
+    }
+}
+
+// Two summands per lane (the two chains of a pair; pass 0.0 for a chain that does not exist).
+template <int NC>
+__device__ __forceinline__ void r_deposit2(RLanes<NC>& L, int c, double a, double b, xs::PartR* slot)
+{
+    // |v| < 2^(50 top + 49) for both, tested on the high words of the bit patterns (NaN and infinities lie above every bound);
+    // the OR of the two words is at least their maximum: a conservative test, settled exactly in the rare arm
+    const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(a) >> 32), hb = (uint32_t)((uint64_t)__double_as_longlong(b) >> 32);
+    if (__builtin_amdgcn_ballot_w64(((ha | hb) & 0x7FFFFFFFu) >= L.cap_hi[c]) != 0ull) r_slow(L, c, a, b, slot);
+    auto put = [&](double v) {
+        const double v1 = __longlong_as_double(__double_as_longlong(v) | 1ll);
+        const double t = L.c1[c] + v1;
+        const double r = v1 - (t - L.c1[c]);
+        const double t2 = L.c2[c] + __longlong_as_double(__double_as_longlong(r) | 1ll);
+        L.a1[c] += (unsigned long long)__double_as_longlong(t);
+        L.a2[c] += (unsigned long long)__double_as_longlong(t2);
+    };
+    put(a);
+    put(b);
+    L.n[c] += 2;
+}
+
+template <int NC>
+__device__ __forceinline__ void r_flush(RLanes<NC>& L, xs::PartR* slot)
+{
+    const bool lane0 = (threadIdx.x & 63) == 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
+        // |sum of multiples| < n 2^49 < 2^63: the 64-bit arithmetic modulo 2^64 holds it
+        const long long k1 = (long long)(L.a1[c] - n * (unsigned long long)__double_as_longlong(L.c1[c]));
+        const long long k2 = (long long)(L.a2[c] - n * (unsigned long long)__double_as_longlong(L.c2[c]));
+        // a wave's 64 lanes: the sums need up to 6 more bits -- low 32 bits and high parts separately
+        const long long lo1 = wave_sum_i64(k1 & 0xFFFFFFFFll), hi1 = wave_sum_i64(k1 >> 32);
+        const long long lo2 = wave_sum_i64(k2 & 0xFFFFFFFFll), hi2 = wave_sum_i64(k2 >> 32);
+        if (lane0) {
+            const xs::i128 h1 = xs::i128_of(hi1), h2 = xs::i128_of(hi2);
+            slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_add(xs::i128_shl(h1, 32), xs::i128_of(lo1)));
+            slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_add(xs::i128_shl(h2, 32), xs::i128_of(lo2)));
+        }
+        L.a1[c] = L.a2[c] = 0ull;
+        L.n[c] = 0;
+    }
+}
+
+// The block's row of a kind-R / kind-Q column from its wave slots slots[wave][NC] (thread 0, after a barrier).
+template <int NC>
+__device__ __forceinline__ xs::PartR r_block_total(const xs::PartR (*slots)[NC], int c)
+{
+    xs::PartR t = slots[0][c];
+    for (int w = 1; w < AMC_BLOCK / 64; ++w) xs::part_r_merge(t, slots[w][c]);
+    return t;
+}
+template <int NC>
+__device__ __forceinline__ xs::PartQ q_block_total(const QSlot (*slots)[NC], int c)
+{
+    xs::PartQ t = q_slot_value(slots[0][c]);
+    for (int w = 1; w < AMC_BLOCK / 64; ++w) {
+        const xs::PartQ o = q_slot_value(slots[w][c]);
+        t.k = xs::i128_add(t.k, o.k);
+        t.flags |= o.flags;
+    }
+    return t;
+}
+
+// The callback sums a REDUCE launch forms of the state it stores (callback_energy particle_1d.jl:68-70, the moments of
+// test/distribution_test.jl:36-37): kind-R columns sum e, sum x, sum x^2 -- with U = x^2 in Float64 sum x^2 IS sum e (the same
+// products), and the row's third column is a copy of the first.  Float64 sums whatever the state type.
+enum { RED_COLS = 3, RED_ROW_COUNT = RED_COLS * XS_ROW_R, RED_ROW_SLOT = RED_ROW_COUNT + 1, RED_ROW_WORDS = RED_ROW_COUNT + 2 };
+template <int POT>
+struct RedCols {
+    static constexpr bool X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
+    static constexpr int NC = X2_IS_E ? 2 : 3;
+};
+
+template <int POT>
+__device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 xv, bool v0, bool v1, const double* s_math,
+                                             xs::PartR* slot)
+{
+    const double x0 = v0 ? (double)xv.x : 0.0, x1 = v1 ? (double)xv.y : 0.0;
+    const double e0 = v0 ? (double)potential<POT>(xv.x, s_math) : 0.0, e1 = v1 ? (double)potential<POT>(xv.y, s_math) : 0.0;
+    r_deposit2(L, 0, e0, e1, slot);
+    r_deposit2(L, 1, x0, x1, slot);
+    if (!RedCols<POT>::X2_IS_E) r_deposit2(L, 2, x0 * x0, x1 * x1, slot);
+}
+
+// End of the launch: flush, then thread 0 writes the block's row (count = chains this block summed, as a double).
+template <int POT>
+__device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::PartR (*slots)[RedCols<POT>::NC], double count,
+                                           xs_word* row)
+{
+    constexpr int NC = RedCols<POT>::NC;
+    r_flush(L, slots[threadIdx.x >> 6]);
+    double cnt[1] = {count};
+    double total[1];
+    block_sum_store<1>(cnt, total);                 // ends in a barrier: the slots are visible to thread 0
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xs_store_r_row(row + c * XS_ROW_R, r_block_total<NC>(slots, c));
+        if (RedCols<POT>::X2_IS_E) xs_store_r_row(row + 2 * XS_ROW_R, r_block_total<NC>(slots, 0));
+        row[RED_ROW_COUNT] = (xs_word)__double_as_longlong(total[0]);
+    }
+}
+
 struct SweepArgs {
     real_t* x;
     const real_t* beta_arr;       // nullptr unless per-chain beta
@@ -469,8 +733,9 @@ struct SweepArgs {
     int32_t n_moves;
     uint32_t key0, key1;
     double beta;
-    double* red_partials;         // REDUCE launches: [grid][red_stride] block partials of (sum e, sum x, sum x^2, count,
-                                  // this block's pool-wide accepted slot after the launch), pinned host memory
+    xs_word* red_partials;        // REDUCE launches: [grid][red_stride] block rows, pinned host memory: three kind-R columns
+                                  // (sum e, sum x, sum x^2: XS_ROW_R words each), then as doubles the count and this block's
+                                  // pool-wide accepted slot after the launch (RED_ROW_COUNT, RED_ROW_SLOT)
     int32_t red_stride;
     int32_t log_pos;              // row of the step log the first step of this launch writes
     int32_t exact_accept;         // != 0: skip the accept filter, every decision by accept_exact (tests; AMC_EXACT_ACCEPT)
@@ -613,11 +878,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     // REDUCE with LOG (per-chain counters): rows carry the sums over x only; the acceptance ratios of the same
     // callback come from the fold of the step log that follows (fold_log_kernel<KS, true>)
     static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
-    double red[4] = {0.0, 0.0, 0.0, 0.0};
-    // the callback sums' registers cost a wave of occupancy (69 against 59, 79 against 70, 100 against 92 VGPRs): the count of
-    // full trips lives on the scalar unit, and with U = x^2 in Float64 sum x^2 IS sum e (the same products added in the same order)
+    // the callback sums: reproducible (amc_xsum.h); the count of full trips lives on the scalar unit
+    constexpr int RNC = RedCols<POT>::NC;
+    RLanes<RNC> red;
+    __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
+    if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
     int red_pairs = 0, red_ragged = 0;
-    constexpr bool RED_X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[MULTI ? AMC_PICK_CELLS : 16];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
@@ -700,12 +966,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                                                    sigma1, den1, rden1, logc1, wave_acc, lw, &dr);
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
-        if (REDUCE) {      // the sums are Float64 whatever the state type (a Float32 sum over 1e7 chains keeps no digits)
-            const double x0 = xv.x, x1 = xv.y;
-            red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
-            red[1] += x0 + x1;
-            if (!RED_X2_IS_E) red[2] += x0 * x0 + x1 * x1;
+        if (REDUCE) {
+            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
             red_pairs += 1;
+            if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
         }
         x_done = xv;
         lw_done = lw;
@@ -729,16 +993,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, p, lw);
         }
         if (REDUCE) {
-            const double x0 = xv.x, x1 = xv.y;
-            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; if (!RED_X2_IS_E) red[2] += x0 * x0; red_ragged += 1; }
-            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; if (!RED_X2_IS_E) red[2] += x1 * x1; red_ragged += 1; }
+            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
+            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
         }
     }
-    if (REDUCE) {
-        red[3] = (double)(2 * red_pairs + red_ragged);     // full trips: two chains per lane each
-        if (RED_X2_IS_E) red[2] = red[0];
-        block_sum_store<4>(red, a.red_partials + (int64_t)blockIdx.x * a.red_stride);
-    }
+    if (REDUCE)          // full trips: two chains per lane each
+        red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), a.red_partials + (int64_t)blockIdx.x * a.red_stride);
     if (!MULTI) {
         // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
         // address at kernel end serialise at ~13 ns each; one address per block does not contend).
@@ -752,7 +1012,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
                 // value after this launch (exact in a double below 2^53); the rows are summed by the host
                 if (t != 0) __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.red_partials[(int64_t)blockIdx.x * a.red_stride + 4] = (double)(slots_before + t);
+                a.red_partials[(int64_t)blockIdx.x * a.red_stride + RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)(slots_before + t));
             } else if (t != 0) {
                 // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
                 __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -845,7 +1105,7 @@ template <int KS, bool RATIO = false, typename CT = uint32_t, bool HIGH = false,
 __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log, int n_rows, CT* acc,
                                                               CT* tot, uint16_t* acc_hi, uint16_t* tot_hi,
                                                               int64_t n_chains, int64_t m_stride,
-                                                              int group, uint64_t t_counted, double* ratio_partials,
+                                                              int group, uint64_t t_counted, xs_word* ratio_partials,
                                                               int rp_stride)
 {
     static_assert(KS >= 1 && KS <= 4, "four moves per pass");
@@ -857,9 +1117,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
     constexpr uint32_t ONES = 0x01010101u;
     constexpr bool ALL_TOT = GROUP == 1;                                         // every move of this pass has a total array
     __shared__ __attribute__((aligned(16))) uint32_t s_pk[2 * KK][4 * AMC_BLOCK];   // [k: accepted, total][quad of the tile]
+    // callback_acceptance's sums: kind-Q columns of quantum 2^XS_E_RATIO (amc_xsum.h); a lane adds at most 16 ratios per tile
     double ratio[KK];
 #pragma unroll
-    for (int k = 0; k < KK; ++k) ratio[k] = 0.0;
+    for (int k = 0; k < KK; ++k) ratio[k] = xs::xs_c(xs::XS_E_RATIO);
     // the group a step belongs to: bit 3 of a nibble (pools of 5..8), bits 3..6 of a byte (up to 64 moves)
     const uint32_t group_field = BYTES ? 0x0F0F0F0Fu : ONES;
     const uint32_t group_word = (uint32_t)group * ONES;
@@ -973,13 +1234,33 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
-                            ratio[k] += (double)a4[e] / (double)t4[e];
+                            ratio[k] += __longlong_as_double(__double_as_longlong((double)a4[e] / (double)t4[e]) | 1ll);
                 }
             }
         }
         __syncthreads();                                   // the next tile overwrites s_pk
     }
-    if (RATIO) block_sum_store<KK>(ratio, ratio_partials + (int64_t)blockIdx.x * rp_stride);
+    if (RATIO) {
+        // one 64-bit integer per move and block (a block adds fewer than 2^24 ratios of at most 2^34 quanta each); a 0/0 = NaN
+        // among them (a chain that never picked the move, metropolis.jl:320) makes the column NaN
+        __shared__ QSlot s_ratio[AMC_BLOCK / 64][KK];
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < KK; ++k) q_slot_clear(s_ratio[threadIdx.x >> 6][k]);
+        __syncthreads();
+        uint64_t cb[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) cb[k] = xs::xs_c_bits(xs::XS_E_RATIO);
+        q_flush<KK>(ratio, cb, s_ratio[threadIdx.x >> 6]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const xs::PartQ t = q_block_total<KK>(s_ratio, k);
+                ratio_partials[(int64_t)blockIdx.x * rp_stride + k] = t.flags ? (xs_word)AMC_XS_POISON_HI : (xs_word)t.k.lo;
+            }
+        }
+    }
 }
 
 
@@ -1078,13 +1359,6 @@ __device__ __forceinline__ void pg_accumulate_one(const double* red, int l, int 
     a[4] += n_samples;
 }
 
-AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* red, int n_learn, PgIds ids, double n_samples, double* acc)
-{
-    const int l = threadIdx.x;
-    if (l >= n_learn) return;
-    pg_accumulate_one(red, l, ids.v[l], n_samples, acc);
-}
-
 // make_step!(::PolicyGradientUpdate) (update.jl:50-57) for P = 1: average (gradients.jl:83-85), learning_step!
 // (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164; inv(g + eps I) is a scalar reciprocal), reset
 // the accumulators, refresh the derived parameter table.  A step that leaves sigma outside [1e-100, 1e100]
@@ -1155,53 +1429,58 @@ AMC_KERNEL_LINKAGE __global__ void pg_update_kernel(double* ptab, double* acc, i
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
 }
 
-// Both in one launch, for shards connected by a communicator: what follows the in-place all-reduce of the estimator's sums
-// when the time step also updates (estimator.jl:130, then update.jl:50-57) -- one tiny launch on the critical path instead of two.
-AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* red, double* ptab, double* acc, int n_learn, PgIds ids,
-                                                              double n_samples, PgOpts opt, int n_moves, int* status)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, red, n_samples);
-}
-
-// K2a: callback reductions, pass 1.  partials[block][4 + K]:
-//   sum e (callback_energy particle_1d.jl:68-70), sum x, sum x^2 (distribution_test.jl:36-37),
-//   count, and per move sum_c accepted/total (callback_acceptance metropolis.jl:319-321).
-// ratio_mode: 0 = none (K == 1 without per-chain counters; host uses the pool-wide total),
-//             1 = K == 1 with per-chain acc (total = t_steps for every chain), 2 = K > 1.
-// Rows are p_stride doubles apart (device buffer, or pinned host memory when the host forms the column sums).
-// slots != nullptr (ratio_mode 0): column 4 of row b = sum of the accepted slots b, b + grid, ... (exact).
+// K2a: the callback reductions as a pass of their own (when no sweep launch could carry them).  Row b of `rows` (pinned
+// host memory, p_stride words apart): the kind-R columns sum e (callback_energy particle_1d.jl:68-70), sum x, sum x^2
+// (distribution_test.jl:36-37) as in red_finish, the count, and the pool-wide accepted slots b, b + grid, ... (exact).
+// ratio_mode: 0 = no per-chain ratios here (K == 1 without per-chain counters: the host uses the pool-wide total; K <= 4: the
+//                 fold of the step log forms them);
+//             1 = K == 1 with per-chain acc (total = t_steps for every chain), 2 = K > 1: sum_c accepted/total per move
+//                 (callback_acceptance metropolis.jl:319-321) as kind-Q integers of quantum 2^XS_E_RATIO, added into
+//                 ratio_acc[k][3] = (sum of low 32-bit halves, sum of high halves, blocks that met a NaN) with one atomic per block
+//                 and word -- integer additions, so the order the blocks arrive in does not matter.
 template <int POT>
 __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, const uint32_t* acc,
                                                             const uint32_t* tot, int64_t n_chains,
                                                             int64_t m_stride, int n_moves, int ratio_mode,
-                                                            uint64_t t_steps, double* partials, int p_stride,
-                                                            const unsigned long long* slots, int n_slots)
+                                                            uint64_t t_steps, xs_word* rows, int p_stride,
+                                                            const unsigned long long* slots, int n_slots,
+                                                            unsigned long long* ratio_acc)
 {
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     __shared__ double s_math[POT == POT_CUSTOM ? TAB_DOUBLES : 1];      // a custom potential may call amc_exp
     if (POT == POT_CUSTOM) stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int RNC = RedCols<POT>::NC;
+    RLanes<RNC> red;
+    __shared__ xs::PartR s_red[AMC_BLOCK / 64][RNC];
+    r_init(red, s_red[threadIdx.x >> 6]);
+    int n_mine = 0;
     const int64_t n_pairs = (n_chains + 1) >> 1;              // 16-byte loads; x is padded, the odd slot of a lone last chain is masked
-    for (int64_t p = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; p < n_pairs; p += stride) {
-        const real2 xp = *reinterpret_cast<const real2*>(x + 2 * p);
-        const double x0 = xp.x, x1 = xp.y;
-        v[0] += (double)potential<POT>(xp.x, s_math);
-        v[1] += x0;
-        v[2] += x0 * x0;
-        v[3] += 1.0;
-        if (2 * p + 1 < n_chains) {
-            v[0] += (double)potential<POT>(xp.y, s_math);
-            v[1] += x1;
-            v[2] += x1 * x1;
-            v[3] += 1.0;
-        }
+    // every lane of a wave takes the same number of trips (the flushes inside are wave-wide): lanes past the end add zeros
+    const int64_t wave_first = (int64_t)blockIdx.x * AMC_BLOCK + (threadIdx.x & ~63);
+    for (int64_t pw = wave_first; pw < n_pairs; pw += stride) {
+        const int64_t p = pw + (threadIdx.x & 63);
+        const bool v0 = p < n_pairs, v1 = v0 && (2 * p + 1 < n_chains);
+        real2 xp = {(real_t)0.0, (real_t)0.0};
+        if (v0) xp = *reinterpret_cast<const real2*>(x + 2 * p);
+        red_add_pair<POT>(red, xp, v0, v1, s_math, s_red[threadIdx.x >> 6]);
+        n_mine += (v0 ? 1 : 0) + (v1 ? 1 : 0);
+        if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
     }
-    double* out = partials + (int64_t)blockIdx.x * p_stride;
-    block_sum_store<4>(v, out);
+    xs_word* out = rows + (int64_t)blockIdx.x * p_stride;
+    red_finish<POT>(red, s_red, (double)n_mine, out);
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        if (slots)
+            for (int s = blockIdx.x; s < n_slots; s += gridDim.x) a += slots[s];
+        out[RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)a);
+    }
     if (ratio_mode != 0) {
+        __shared__ QSlot s_ratio[AMC_BLOCK / 64][1];
         for (int k = 0; k < n_moves; ++k) {
-            double r[1] = {0.0};
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) q_slot_clear(s_ratio[threadIdx.x >> 6][0]);
+            __syncthreads();
+            double r[1] = {xs::xs_c(xs::XS_E_RATIO)};
             for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
                 const double a = (double)acc[(int64_t)k * m_stride + c];
                 double n = (double)t_steps;
@@ -1215,78 +1494,21 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                         n = (double)(t_steps - others);
                     }
                 }
-                r[0] += a / n;    // Int/Int -> Float64 division; 0/0 = NaN like the reference
+                r[0] += __longlong_as_double(__double_as_longlong(a / n) | 1ll);    // Int/Int -> Float64 division; 0/0 = NaN like the reference
             }
-            block_sum_store<1>(r, out + 4 + k);
-        }
-    } else if (threadIdx.x == 0) {
-        for (int k = 0; k < n_moves; ++k) out[4 + k] = 0.0;
-        if (slots) {
-            unsigned long long a = 0;
-            for (int s = blockIdx.x; s < n_slots; s += gridDim.x) a += slots[s];
-            out[4] = (double)a;
-        }
-    }
-}
-
-// K2b: final passes of a reduction: fixed-order column sums of the per-block partials [n_rows][n_vals].
-// Block g sums rows [g*rows_per_block, (g+1)*rows_per_block) and writes row g of `out` ([gridDim][n_vals + 1]);
-// column n_vals receives the sum of block g's slice of the per-block accepted slots (exact: integers below 2^53;
-// 0 when slots == nullptr).  Launched twice when there are many rows -- 32 blocks, then one block over their 32
-// rows with the slot column as an ordinary column -- because one CU alone streams 2048 rows from far memory in
-// ~10 us; once (gridDim = 1) otherwise.  Either way the order of additions depends on the row count only.
-AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void reduce_final_kernel(const double* partials, int n_rows, int n_vals,
-                                                                  double* out, const unsigned long long* slots,
-                                                                  int n_slots, int rows_per_block, int slots_per_block)
-{
-    const int r0 = blockIdx.x * rows_per_block;
-    const int n_blocks = (n_rows - r0 < rows_per_block) ? ((n_rows - r0 > 0) ? n_rows - r0 : 0) : rows_per_block;
-    partials += (int64_t)r0 * n_vals;
-    out += (int64_t)blockIdx.x * (n_vals + 1);
-    // All loads of a chunk of <= 8 columns (and of the slots) are issued before the first sum is formed.  Per
-    // column: thread t adds rows t, t+256, ... in turn, then the wave shuffle tree, then waves 0..3.
-    unsigned long long t = 0;
-    if (slots) {
-        const int s0 = blockIdx.x * slots_per_block;
-        const int s1 = (s0 + slots_per_block < n_slots) ? s0 + slots_per_block : n_slots;
-        for (int b = s0 + threadIdx.x; b < s1; b += AMC_BLOCK) t += slots[b];
-    }
-    for (int q0 = 0; q0 < n_vals; q0 += 8) {
-        const int nq = (n_vals - q0 < 8) ? n_vals - q0 : 8;
-        double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 4 * AMC_BLOCK) {
-            // four rows per trip; every load is unconditional (index clamped, value masked) so that all 32 are in
-            // flight together
-            double w[4][8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int b = b0 + j * AMC_BLOCK;
-                const bool row_ok = b < n_blocks;
-                const double* row = partials + (int64_t)(row_ok ? b : 0) * n_vals + q0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const double x = row[(i < nq) ? i : 0];
-                    w[j][i] = (row_ok && i < nq) ? x : 0.0;
+            const uint64_t cb[1] = {xs::xs_c_bits(xs::XS_E_RATIO)};
+            q_flush<1>(r, cb, s_ratio[threadIdx.x >> 6]);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const xs::PartQ t = q_block_total<1>(s_ratio, 0);
+                const long long kk = (long long)t.k.lo;                  // |k| < 2^58: one word
+                if (t.flags) atomicAdd(ratio_acc + 3 * k + 2, 1ull);
+                else {
+                    atomicAdd(ratio_acc + 3 * k, (unsigned long long)(kk & 0xFFFFFFFFll));
+                    atomicAdd(ratio_acc + 3 * k + 1, (unsigned long long)(kk >> 32));
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] += w[j][i];
         }
-        double r[8];
-        block_sum_store<8>(v, r);          // thread 0 holds the sums in r
-        if (threadIdx.x == 0)
-            for (int i = 0; i < nq; ++i) out[q0 + i] = r[i];
-    }
-    __shared__ unsigned long long s_u[AMC_BLOCK / 64];
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    if ((threadIdx.x & 63) == 0) s_u[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long a = 0;
-        for (int w = 0; w < AMC_BLOCK / 64; ++w) a += s_u[w];
-        out[n_vals] = (double)a;
     }
 }
 
@@ -1348,13 +1570,14 @@ __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc
 // struct used to have cost the fused sweep + estimator kernel ~70 v_readlane / v_writelane spill instructions per loop trip.
 struct PgTail {
     uint32_t* tickets;            // [1 + n_groups], zero between launches
-    double* group_sums;           // [n_groups][NL*4]
-    double* out;
+    xs_word* group_sums;          // [n_groups][NL*4][words per column]
+    double* out;                  // tail_mode 1: records [n_ranks][NL*4][XS_WORDS], this shard's slot filled, the others zeroed
     double* gd_acc;               // [AMC_MAX_MOVES][5]
     double* ptab_rw;              // == ptab (written by the update)
     int* status;
     double n_samples;
     int32_t n_moves;
+    int32_t rank, n_ranks;        // slot of this shard in `out` (0 of 1 without a communicator)
     int32_t pad_;
     int32_t learn_ids[AMC_MAX_LEARN];
     PgOpts opt;
@@ -1364,7 +1587,7 @@ struct PgArgs {
     real_t* x;
     const real_t* beta_arr;
     const double* ptab;
-    double* partials;             // [grid][NL][4]
+    xs_word* partials;            // [grid][NL*4][words per column]: block rows (pg_row_words)
     const PgTail* tail;           // device memory
     int64_t n_chains;
     uint64_t pair0;
@@ -1375,8 +1598,8 @@ struct PgArgs {
     uint32_t key0, key1;
     double beta;
     // Tail of the launch (no further launches for the fold's bookkeeping; each tiny launch costs ~5 us plus a ~6 us
-    // dependent-launch gap on this part).  tail_mode 0: block partials only; 1: + their fixed-order sum in `out`
-    // [NL*4]; 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
+    // dependent-launch gap on this part).  tail_mode 0: block rows only; 1: + their total as records in `out`;
+    // 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
@@ -1387,6 +1610,20 @@ AMC_KERNEL_LINKAGE __global__ void pg_tail_store_kernel(PgTail value, PgTail* ds
 }
 
 enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kernel final reduction
+
+// The GradientData fold (gradients.jl:68-76 over estimator.jl:113-129) is a reproducible sum (amc_xsum.h).  Its kind:
+// Q, quanta from sigma, for the Gaussian displacement policy on a built-in potential with the model's reward delta^2 -- every
+// summand is then bounded by a function of sigma (xs_gd_exponents) --; R, running top, as soon as a script-defined expression
+// takes part (potential and reward come together as POT_CUSTOM; a state-dependent width; a whole proposal).
+template <int POT>
+struct PgKind {
+#if defined(AMC_USER_SCALE) || defined(AMC_USER_LOGQ)
+    static constexpr bool Q = false;
+#else
+    static constexpr bool Q = POT != POT_CUSTOM;
+#endif
+    static constexpr int ROW = Q ? XS_ROW_Q : XS_ROW_R;       // words per column of a block row
+};
 
 // One pgmc_estimate sample (gradients.jl:93-109 via sample_gradient_data :117-121), P = 1.
 // Leaves x at (x+delta)+(-delta) like the reference (perform_action_cached! :103).
@@ -1421,6 +1658,7 @@ __device__ __forceinline__ LogQ log_proposal_density_withgrad_w(real_t delta, do
 
 // pgmc_estimate (gradients.jl:93-109) with the state-dependent width: the forward density and gradient at the old state,
 // the backward ones at the new state; grad_j takes the forward gradient when alpha == 1, else the backward one (:106).
+// g: the sample's four summands (j, grad j, grad logq, g) in the reference's operations.
 template <int POT>
 __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double sigma, double z, double (&g)[4], const double* T)
 {
@@ -1443,17 +1681,17 @@ __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double 
     double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
     alpha = (arg >= 0.0) ? 1.0 : alpha;
     const double j = r * alpha;
-    g[0] += j;
-    g[1] += j * ((alpha == 1.0) ? f.dlogq : b.dlogq);
-    g[2] += f.dlogq;
-    g[3] += f.dlogq * f.dlogq;
+    g[0] = j;
+    g[1] = j * ((alpha == 1.0) ? f.dlogq : b.dlogq);
+    g[2] = f.dlogq;
+    g[3] = f.dlogq * f.dlogq;
 }
 #endif
 
 #ifdef AMC_USER_LOGQ
 // pgmc_estimate (gradients.jl:93-109) with a script-defined proposal: value and sigma-derivative of the forward density
 // at the old state (:97), of the backward density at the new state (:102); grad_j takes the forward gradient when
-// alpha == 1, else the backward one (:106).
+// alpha == 1, else the backward one (:106).  g: the sample's four summands in the reference's operations.
 template <int POT>
 __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[4], const double* T)
 {
@@ -1473,28 +1711,30 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
     alpha = (arg >= 0.0) ? 1.0 : alpha;
     const double j = r * alpha;
-    g[0] += j;
-    g[1] += j * ((alpha == 1.0) ? dlogq_f : dlogq_b);
-    g[2] += dlogq_f;
-    g[3] += dlogq_f * dlogq_f;
+    g[0] = j;
+    g[1] = j * ((alpha == 1.0) ? dlogq_f : dlogq_b);
+    g[2] = dlogq_f;
+    g[3] = dlogq_f * dlogq_f;
 }
 #endif
 
 // One pgmc_estimate sample of the StandardGaussian policy.  What leaves this function per chain is (a) the position,
-// x = (x + delta) + (-delta) in the reference's operations (bit-exact against the oracle), and (b) four SUMMANDS of
-// GradientData (j, grad j, grad logq, g: gradients.jl:104-108), which the reference folds with `+` over 1e7 chains in
-// whatever order its reducer takes (foldxl / foldxt, estimator.jl:94,113) and which are compared with the oracle at
-// rtol 1e-10.  The summands therefore need not repeat the reference's rounding sequence operation for operation, and
-// two parts of it that cost 19 of the 46 f64 operations per sample are replaced by forms that agree to a few ulp:
+// x = (x + delta) + (-delta) in the reference's operations, and (b) four SUMMANDS of GradientData (j, grad j, grad logq, g:
+// gradients.jl:104-108), which the reference folds with `+` over all chains in whatever order its reducer takes (foldxl /
+// foldxt, estimator.jl:94,113).  The summands follow the ARITHMETIC SPEC of DESIGN.md section 3.6b, which the oracle restates
+// operation for operation (its spec-form sample) next to the reference-ordered form (a few ulp apart,
+// test_pg_sample_summands_within_ulps): two parts of the reference's rounding sequence that cost 19 of its 46 f64 operations
+// per sample are replaced --
 //   * alpha = min(1, exp((dlogp + logq_b) - logq_f)) with logq_b == logq_f bit for bit: the detour through logq moves
-//     the argument by at most 2^-53 (2|dlogp| + |logq|), i.e. alpha by a relative 1e-16 |logq| -- alpha = min(1, exp(dlogp)),
-//     and log_proposal_density itself (a division by 2 sigma^2 and log(2 pi sigma^2)/2) is not formed at all;
+//     the argument by at most 2^-53 (2|dlogp| + |logq|) -- alpha = exp(min(dlogp, 0)), and log_proposal_density itself (a
+//     division by 2 sigma^2 and log(2 pi sigma^2)/2) is not formed at all;
 //   * d logq / d sigma, which ForwardDiff forms as -((-(d^2)/den)/den) dden - dlhalf (two IEEE divisions), is the
 //     polynomial d^2 (dden/den^2) - dlhalf: one fma with the coefficient split hi + lo (prepare_params) so that no
 //     constant's rounding biases the sum, and a second fma for the lo part.
-// The CPU restatement the tests compare with keeps the reference's operation order; test_pg_sample_summands_within_ulps
-// pins the per-sample difference at a few ulp of each summand's terms, the sums at rtol 1e-10 as before.
-template <int POT>
+// ACC (kind Q): g[] are the lane's four accumulators; the summands enter them with the last bit of j and of d logq / d sigma
+// set (lsb1, amc_xsum.h) -- grad j and g as EXACT products rounded once by the accumulator's fma.  !ACC (kind R: a
+// script-defined potential or reward): g[] receives the four summands, products rounded to Float64.
+template <int POT, bool ACC>
 __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double c3hi, double c3lo, double c1,
                                           double z, double (&g)[4], const double* T)
 {
@@ -1522,30 +1762,82 @@ __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, 
         alpha = rare ? ((arg != arg) ? arg : 0.0) : alpha;
     }
     const double j = r * alpha;
-    g[0] += j;
-    g[1] = __builtin_fma(j, dlogq, g[1]);          // forward and backward gradients coincide for this policy (gradients.jl:106)
-    g[2] += dlogq;
-    g[3] = __builtin_fma(dlogq, dlogq, g[3]);
+    if (ACC) {
+        // forward and backward gradients coincide for this policy (gradients.jl:106)
+        const double j1 = __longlong_as_double(__double_as_longlong(j) | 1ll);
+        const double d1 = __longlong_as_double(__double_as_longlong(dlogq) | 1ll);
+        g[0] += j1;
+        g[1] = __builtin_fma(j1, d1, g[1]);
+        g[2] += d1;
+        g[3] = __builtin_fma(d1, d1, g[3]);
+    } else {
+        g[0] = j;
+        g[1] = j * dlogq;
+        g[2] = dlogq;
+        g[3] = dlogq * dlogq;
+    }
 }
 
-// Column sums, in row order, of rows[n_rows][NV] that OTHER blocks wrote (agent-scope loads, one per thread and
-// trip so that they are all in flight together), staged through `scratch` (capacity cap_rows rows).  Called by the
-// whole block; the sums are valid in threads < NV.
-template <int NV>
-__device__ __forceinline__ double ordered_column_sum(const double* rows, int n_rows, double* scratch, int cap_rows)
+// gradients_data[k] = gradients_data[k] + gd (estimator.jl:130) from the records the shards have exchanged: recs is
+// [n_ranks][nv][XS_WORDS], slot r filled by shard r (the in-place all-reduce(sum) over disjoint slots is a gather).  One
+// thread merges the shards' integer totals per column -- in any order: integers -- and rounds once.
+__device__ __forceinline__ void pg_merge_slots(const double* recs, int n_ranks, int nv, double* vals)
 {
-    double t = 0.0;
-    for (int base = 0; base < n_rows; base += cap_rows) {
-        const int nr = (n_rows - base < cap_rows) ? n_rows - base : cap_rows;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nr * NV; i += AMC_BLOCK)
-            scratch[i] = __hip_atomic_load(rows + (int64_t)base * NV + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (threadIdx.x < NV)
-            for (int r = 0; r < nr; ++r) t += scratch[r * NV + threadIdx.x];
+    for (int c = 0; c < nv; ++c) {
+        double rec[xs::XS_WORDS];
+        xs::rec_clear(rec);
+        for (int r = 0; r < n_ranks; ++r) xs::rec_merge(rec, recs + ((size_t)r * nv + c) * xs::XS_WORDS);
+        vals[c] = xs::rec_round(rec);
     }
-    return t;
 }
+
+AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* recs, int n_ranks, int n_learn, PgIds ids, double n_samples, double* acc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double vals[AMC_MAX_LEARN * 4];
+    pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
+    for (int l = 0; l < n_learn; ++l) pg_accumulate_one(vals, l, ids.v[l], n_samples, acc);
+}
+
+// Both in one launch, for shards connected by a communicator: what follows the in-place all-reduce of the estimator's sums
+// when the time step also updates (estimator.jl:130, then update.jl:50-57) -- one tiny launch on the critical path instead of two.
+AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* recs, int n_ranks, double* ptab, double* acc, int n_learn, PgIds ids,
+                                                              double n_samples, PgOpts opt, int n_moves, int* status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double vals[AMC_MAX_LEARN * 4];
+    pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
+    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, vals, n_samples);
+}
+
+// Sum, over rows[n_rows][NV][ROW words] that OTHER blocks wrote (agent-scope loads), of column c: integers, so the order is
+// immaterial; thread c of the calling block owns column c.
+template <bool Q>
+struct PgCol {
+    xs::PartQ q;
+    xs::PartR r;
+    __device__ __forceinline__ void clear() { q = xs::PartQ{xs::i128{0, 0}, 0u}; r = xs::part_r_empty(); }
+    __device__ __forceinline__ void add_row(const xs_word* row)
+    {
+        xs_word w[Q ? XS_ROW_Q : XS_ROW_R];
+#pragma unroll
+        for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); ++i) w[i] = __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Q) {
+            const xs::PartQ b = xs_load_q_row(w);
+            q.k = xs::i128_add(q.k, b.k);
+            q.flags |= b.flags;
+        } else {
+            xs::part_r_merge(r, xs_load_r_row(w));
+        }
+    }
+    __device__ __forceinline__ void store_row(xs_word* row) const
+    {
+        xs_word w[Q ? XS_ROW_Q : XS_ROW_R];
+        if (Q) xs_store_q_row(w, q); else xs_store_r_row(w, r);
+#pragma unroll
+        for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); ++i) __hip_atomic_store(row + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
 
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
 // SWEEP != 0: the launch first performs ONE make_step!(::Metropolis) of sweepstep = 1 on the pair it has just loaded
@@ -1562,20 +1854,25 @@ template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
-    double red[4] = {0.0, 0.0, 0.0, 0.0};
-    // the callback sums' registers cost a wave of occupancy (69 against 59, 79 against 70, 100 against 92 VGPRs): the count of
-    // full trips lives on the scalar unit, and with U = x^2 in Float64 sum x^2 IS sum e (the same products added in the same order)
+    constexpr bool QK = PgKind<POT>::Q;
+    constexpr int ROW = PgKind<POT>::ROW;
+    constexpr int NV = NL * 4;
+    // the callback sums: reproducible (amc_xsum.h); the count of full trips lives on the scalar unit
+    constexpr int RNC = RedCols<POT>::NC;
+    RLanes<RNC> red;
+    __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
+    if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
     int red_pairs = 0, red_ragged = 0;
-    constexpr bool RED_X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
     // the pool-wide accepted total this block can see before the launch (see sweep_kernel)
     unsigned long long slots_before = 0;
     if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
         for (int sl = (int)blockIdx.x; sl < sw.n_slots; sl += (int)gridDim.x) slots_before += sw.acc_total[sl];
-    // the math tables; after the sampling loop the same LDS stages the rows of the in-kernel final reduction
-    constexpr int SCRATCH = (PG_GROUP * NL * 4 > TAB_DOUBLES) ? PG_GROUP * NL * 4 : TAB_DOUBLES;
-    __shared__ double s_math[SCRATCH];
+    __shared__ double s_math[TAB_DOUBLES];
     __shared__ double s_tab[SWEEP == 2 ? 5 * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[SWEEP == 2 ? AMC_PICK_CELLS : 16];
+    // the GradientData fold: wave slots of the columns' integer totals
+    __shared__ QSlot s_gq[AMC_BLOCK / 64][QK ? NV : 1];
+    __shared__ xs::PartR s_gr[AMC_BLOCK / 64][QK ? 1 : NV];
     if (SWEEP == 2) {
         stage_pick_table(s_pick, sw.pick_tab);
         for (int i = threadIdx.x; i < sw.n_moves; i += AMC_BLOCK) {
@@ -1604,11 +1901,46 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
-    double g[NL][4];
+    // The lane's GradientData accumulators.  Kind Q: g[l][i] starts at 1.5 * 2^(E + 52), E the column's quantum exponent from
+    // the move's sigma (xs_gd_exponents: integer arithmetic on the scalar unit; the constants are formed again where a flush
+    // needs them instead of staying live across the sampling loop).  Kind R: two accumulators per column and a running top.
+    double g[QK ? NL : 1][4];
+    RLanes<QK ? 1 : NV> gr;
+    auto q_constants = [&](int l, uint64_t (&cb)[4]) {
+        const xs::GdExponents ge = xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]);
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
+        for (int i = 0; i < 4; ++i) cb[i] = xs::xs_c_bits(ge.e[i]);
+    };
+    if (QK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[l][i] = 0.0;
+        for (int l = 0; l < NL; ++l) {
+            uint64_t cb[4] = {0, 0, 0, 0};
+            if (l < a.n_learn) q_constants(l, cb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[QK ? l : 0][i] = __longlong_as_double((long long)cb[i]);
+                if ((threadIdx.x & 63) == 0) q_slot_clear(s_gq[threadIdx.x >> 6][QK ? l * 4 + i : 0]);
+            }
+        }
+    } else {
+        r_init(gr, s_gr[threadIdx.x >> 6]);
+    }
+    auto flush_gd = [&]() {
+        if (QK) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                if (l < a.n_learn) {
+                    uint64_t cb[4];
+                    q_constants(l, cb);
+                    q_flush<4>(g[QK ? l : 0], cb, s_gq[threadIdx.x >> 6] + (QK ? l * 4 : 0));
+                }
+        } else {
+            r_flush(gr, s_gr[threadIdx.x >> 6]);
+        }
+    };
+    // summands the lane has put into each GradientData accumulator since the last flush (two per sample: both chains)
+    constexpr int GD_CAP = QK ? xs::XS_GD_LANE_CAP : xs::XS_LANE_CAP;
+    int dep = 0;
 
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
@@ -1629,26 +1961,42 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         c_sg[l] = c_hi[l] = c_lo[l] = c_c1[l] = 0.0;
         if (HOIST && l < a.n_learn) move_consts(l);
     }
-    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v1) {
+    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v0, bool v1) {
+        (void)v0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (l < a.n_learn) {
                 if (!HOIST) move_consts(l);
                 for (int q = 0; q < a.q_batch; ++q) {
+                    // a lane's accumulators take GD_CAP summands between two flushes (at 1e7 chains a lane sees ~20 per launch)
+                    if (l == 0 && (dep += 2) > GD_CAP) { flush_gd(); dep = 2; }
                     double z0, z1;
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
                                                           STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1, s_math, mk);
+#if defined(AMC_USER_LOGQ) || defined(AMC_USER_SCALE)
+                    double s0[4], s1[4] = {0.0, 0.0, 0.0, 0.0};
 #if defined(AMC_USER_LOGQ)
-                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
-                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);
-#elif defined(AMC_USER_SCALE)
-                    pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, g[l], s_math);
-                    if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, g[l], s_math);
+                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
+                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
 #else
-                    pg_sample<POT>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[l], s_math);
-                    if (v1) pg_sample<POT>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[l], s_math);
+                    pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
+                    if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
+#endif
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r_deposit2(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s1[i], s_gr[threadIdx.x >> 6]);
+#else
+                    if (QK) {
+                        pg_sample<POT, true>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[QK ? l : 0], s_math);
+                        if (v1) pg_sample<POT, true>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[QK ? l : 0], s_math);
+                    } else {
+                        double s0[4], s1[4] = {0.0, 0.0, 0.0, 0.0};
+                        pg_sample<POT, false>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, s0, s_math);
+                        if (v1) pg_sample<POT, false>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, s1, s_math);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r_deposit2(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s1[i], s_gr[threadIdx.x >> 6]);
+                    }
 #endif
                 }
             }
@@ -1674,13 +2022,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         if (BETA) b_nxt = load_b(base + stride);
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
-        samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true);
-        if (REDUCE) {      // Float64 sums whatever the state type
-            const double x0 = xv.x, x1 = xv.y;
-            red[0] += (double)potential<POT>(xv.x, s_math) + (double)potential<POT>(xv.y, s_math);
-            red[1] += x0 + x1;
-            if (!RED_X2_IS_E) red[2] += x0 * x0 + x1 * x1;
+        samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true);
+        if (REDUCE) {
+            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
             red_pairs += 1;
+            if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
         }
         x_done = xv;
         base_done = base;
@@ -1692,70 +2038,70 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         real2 xv = x_nxt;
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
-        if (v0) {
-            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, v1);
-            store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
+        if (QK) {
+            if (v0) samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, true, v1);
+        } else {
+            // kind R deposits are wave-wide (a raise of the running top is a wave-uniform decision): the lanes past the end
+            // go through the motions on a pair nobody stores and deposit zeros
+            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1);
         }
+        if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
         if (REDUCE) {
-            const double x0 = xv.x, x1 = xv.y;
-            if (v0) { red[0] += (double)potential<POT>(xv.x, s_math); red[1] += x0; if (!RED_X2_IS_E) red[2] += x0 * x0; red_ragged += 1; }
-            if (v1) { red[0] += (double)potential<POT>(xv.y, s_math); red[1] += x1; if (!RED_X2_IS_E) red[2] += x1 * x1; red_ragged += 1; }
+            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
+            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
         }
     }
-    if (REDUCE) {
-        red[3] = (double)(2 * red_pairs + red_ragged);     // full trips: two chains per lane each
-        if (RED_X2_IS_E) red[2] = red[0];
-        block_sum_store<4>(red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
-    }
+    if (REDUCE)          // full trips: two chains per lane each
+        red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
     if (SWEEP == 1 || SWEEP == 3) {      // K == 1: the pool-wide accepted total (counter_totals)
         const unsigned long long t = add_block_accepts(sw.acc_total, wave_acc);
-        // column 4 of this block's row: the slot's value after this launch (exact in a double below 2^53)
+        // this block's slot after this launch (exact in a double below 2^53)
         if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
-            sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + 4] = (double)(slots_before + t);
+            sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)(slots_before + t));
     }
-    // Block partial sums -> row blockIdx.x of partials[grid][NL][4].  All cross-block traffic of the tail below goes
+    // Block totals -> row blockIdx.x of partials[grid][NV][ROW words].  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
     // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /
     // invalidate per block, which cost ~70 us per launch over 2048 blocks when it was tried.
-    constexpr int NV = NL * 4;
-    double* row = a.partials + (int64_t)blockIdx.x * NV;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        double r[4] = {0.0, 0.0, 0.0, 0.0};
-        if (l < a.n_learn) block_sum_store<4>(g[l], r);              // thread 0 holds the sums
-        if (threadIdx.x == 0)
-            for (int i = 0; i < 4; ++i) __hip_atomic_store(row + l * 4 + i, r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flush_gd();
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_learn * 4) {
+        PgCol<QK> col;
+        if (QK) col.q = q_block_total<QK ? NV : 1>(s_gq, QK ? (int)threadIdx.x : 0);
+        else col.r = r_block_total<QK ? 1 : NV>(s_gr, QK ? 0 : (int)threadIdx.x);
+        col.store_row(a.partials + ((int64_t)blockIdx.x * NV + threadIdx.x) * ROW);
     }
     if (a.tail_mode == 0) return;
     const PgTail* const tl = a.tail;       // loaded here, not at kernel entry (see PgArgs)
 
     // In-kernel final reduction, two levels of "the last one to arrive sums": the last block of each group of
-    // PG_GROUP consecutive blocks adds the group's rows in row order, the last group to finish adds the group sums in
-    // group order -- the ORDER of additions depends on the grid only, not on which block happens to be last.
-    // Ordering: thread 0 wrote the row, waits for those stores (vmcnt(0)) and only then takes its ticket; the block
-    // that draws the last ticket reads the rows after the ticket's return value has arrived.
+    // PG_GROUP consecutive blocks adds the group's rows, the last group to finish adds the group sums -- integer additions
+    // (amc_xsum.h), so neither the grid nor which block happens to be last enters the result.
+    // Ordering: the threads that wrote the row wait for those stores (vmcnt(0)), the block meets at a barrier, and only then
+    // thread 0 takes its ticket; the block that draws the last ticket reads the rows after the ticket's return value has arrived.
     __shared__ int s_role;
     __shared__ double s_tot[NV];
     const int grp = blockIdx.x / PG_GROUP;
     const int n_groups = (gridDim.x + PG_GROUP - 1) / PG_GROUP;
     const int r0 = grp * PG_GROUP;
     const int n_rows = ((int)gridDim.x - r0 < PG_GROUP) ? (int)gridDim.x - r0 : PG_GROUP;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t prev = __hip_atomic_fetch_add(tl->tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_rows - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (s_role != 1) return;
-    constexpr int CAP_ROWS = SCRATCH / NV;             // >= PG_GROUP
-    {
-        const double t = ordered_column_sum<NV>(a.partials + (int64_t)r0 * NV, n_rows, s_math, CAP_ROWS);
-        if (threadIdx.x < NV) {
-            __hip_atomic_store(tl->group_sums + grp * NV + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    const int nv = a.n_learn * 4;
+    if ((int)threadIdx.x < nv) {
+        PgCol<QK> col;
+        col.clear();
+        for (int r = 0; r < n_rows; ++r) col.add_row(a.partials + ((int64_t)(r0 + r) * NV + threadIdx.x) * ROW);
+        col.store_row(tl->group_sums + ((int64_t)grp * NV + threadIdx.x) * ROW);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();                                   // NV <= 32: the stores above all belong to wave 0, now complete
+    __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(tl->tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         const uint32_t prev = __hip_atomic_fetch_add(tl->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1763,11 +2109,22 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     __syncthreads();
     if (s_role != 2) return;
-    {
-        const double t = ordered_column_sum<NV>(tl->group_sums, n_groups, s_math, CAP_ROWS);
-        if (threadIdx.x < NV) {
-            tl->out[threadIdx.x] = t;
-            s_tot[threadIdx.x] = t;
+    if ((int)threadIdx.x < nv) {
+        PgCol<QK> col;
+        col.clear();
+        for (int gI = 0; gI < n_groups; ++gI) col.add_row(tl->group_sums + ((int64_t)gI * NV + threadIdx.x) * ROW);
+        const int l = (int)threadIdx.x >> 2, i = (int)threadIdx.x & 3;
+        const int e = QK ? xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i] : 0;
+        if (a.tail_mode == 1) {
+            // records: this shard's slot filled, the other shards' slots zeroed (the all-reduce that follows is a gather)
+            for (int r = 0; r < tl->n_ranks; ++r) {
+                double* rec = tl->out + ((size_t)r * nv + threadIdx.x) * xs::XS_WORDS;
+                if (r != tl->rank) xs::rec_clear(rec);
+                else if (QK) xs::rec_from_q(rec, col.q, e);
+                else xs::rec_from_r(rec, col.r);
+            }
+        } else {
+            s_tot[threadIdx.x] = QK ? xs::part_q_round(col.q, e) : xs::part_r_round(col.r);
         }
     }
     __syncthreads();

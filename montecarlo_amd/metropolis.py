@@ -90,7 +90,10 @@ class Metropolis(AriannaAlgorithm):
         self._epoch = 0          # bumped whenever the device state changes
         self._red_key = None
         self._red_val = None
-        self._claimed = None     # the Reduction a callback holds whose sums have not been fetched from the engine yet
+        # Reductions callbacks hold whose sums still sit in the engine, oldest first.  The engine keeps up to two reductions in
+        # flight and hands them back oldest first (amc_reduce_begin / amc_reduce_end): while the device forms the sums of one
+        # observation point the host reads those of the one before.
+        self._inflight = []
 
     # ---- plugin protocol ---------------------------------------------------------------
     def initialise(self, simulation: Simulation) -> None:
@@ -117,8 +120,8 @@ class Metropolis(AriannaAlgorithm):
         schedule), so the sums are formed inside the sweep launch instead of by a second pass over the chains."""
         self._drop_pending_reduction()
         if with_reductions and hasattr(self.engine, "sweep_reduce_begin"):
-            self._settle_claimed()              # one reduction in flight per engine: the previous callback's is fetched now,
-            self.engine.sweep_reduce_begin(1)   # a whole callback period after it was queued -- no wait
+            self._settle_claimed(keep=1)        # two reductions in flight per engine: the last callback's may still be on its
+            self.engine.sweep_reduce_begin(1)   # way, the one before it is fetched now -- two callback periods after it was queued
             self._pending_red_epoch = self._epoch + 1
         else:
             self.engine.sweep(1)
@@ -126,12 +129,14 @@ class Metropolis(AriannaAlgorithm):
 
     def _drop_pending_reduction(self) -> None:
         if getattr(self, "_pending_red_epoch", None) is not None:
-            self.engine.reduce_end()            # nobody asked for it: discard
+            self._settle_claimed()              # the engine hands reductions back oldest first: fetch what callbacks hold,
+            self.engine.reduce_end_exact()      # then discard the one nobody asked for
             self._pending_red_epoch = None
 
-    def _settle_claimed(self) -> None:
-        if self._claimed is not None:
-            self._claimed.result()
+    def _settle_claimed(self, keep: int = 0) -> None:
+        """Fetch the oldest reductions callbacks hold until at most `keep` of them are left in the engine."""
+        while len(self._inflight) > keep:
+            self._inflight[0].result()
 
     def make_steps(self, simulation: Simulation, n: int) -> None:
         """n consecutive make_step!s fused in one launch (state stays in registers)."""
@@ -204,21 +209,21 @@ class Metropolis(AriannaAlgorithm):
         ticket = Reduction(self)
         if getattr(self, "_pending_red_epoch", None) == self._epoch:
             self._pending_red_epoch = None      # formed inside the launch (make_step(with_reductions=True)): claim it
-            self._claimed = ticket
-        elif hasattr(self.engine, "reduce_begin"):
-            self._drop_pending_reduction()
-            self._settle_claimed()
-            self.engine.reduce_begin()
-            self._claimed = ticket
+            self._inflight.append(ticket)
         else:
-            ticket._finish(self.engine.reduce())
+            self._drop_pending_reduction()
+            self._settle_claimed(keep=1)
+            self.engine.reduce_begin()
+            self._inflight.append(ticket)
         self._red_key, self._red_val = key, ticket
         return ticket
 
     def _fetch(self, ticket: "Reduction") -> None:
-        assert self._claimed is ticket
-        self._claimed = None
-        ticket._finish(self.engine.reduce_end())
+        while self._inflight and self._inflight[0] is not ticket:       # oldest first
+            self._inflight[0].result()
+        assert self._inflight and self._inflight[0] is ticket
+        self._inflight.pop(0)
+        ticket._finish(*self.engine.reduce_end_exact())
 
     def invalidate_reductions(self) -> None:
         """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
@@ -232,8 +237,11 @@ class Reduction:
         self._met = metropolis
         self._val = None
 
-    def _finish(self, local: np.ndarray) -> None:
-        red = sharding.allreduce_sum(local, self._met.engine)
+    def _finish(self, records: np.ndarray, steps_counted: int) -> None:
+        # the shards' partial sums are merged as exact integer records (reproducible sums, include/amc.h) and rounded ONCE:
+        # the rows a callback writes do not depend on how many GPUs the chains are spread over
+        merged = sharding.allreduce_xsum(records, self._met.engine)
+        red = self._met.engine.reduce_records_value(merged, steps_counted)
         n = red[3]
         self._val = {
             "energy": red[0] / n,                      # mean(system.e for system in chains)

@@ -230,9 +230,13 @@ class PolicyGradientEstimator(AriannaAlgorithm):
             self.metropolis.engine.pg_accumulate(self.learn_ids, self.q_batch_size)
             self.metropolis.invalidate_reductions()
             return
-        local = self.metropolis.engine.pg_estimate(self.learn_ids, self.q_batch_size)
+        from ._capi import xsum_round
+        local = self.metropolis.engine.pg_estimate_exact(self.learn_ids, self.q_batch_size)
         self.metropolis.invalidate_reductions()      # every sample leaves x at (x+d)-d (gradients.jl:103)
-        total = sharding.allreduce_sum(local.reshape(-1), self.metropolis.engine).reshape(local.shape)
+        # the `+` fold over the shards: exact integer records merged, rounded once (reproducible sums) -- the same bits for
+        # every number of shards
+        merged = sharding.allreduce_xsum(local, self.metropolis.engine)
+        total = xsum_round(merged).reshape(local.shape[0], local.shape[1])
         for k in range(len(self.learn_ids)):
             gd = GradientData(float(total[k, 0]), np.array([total[k, 1]]), np.array([total[k, 2]]),
                               np.array([[total[k, 3]]]), int(round(total[k, 4])))
@@ -250,7 +254,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         met = self.metropolis
         met._drop_pending_reduction()
         # with_reductions: a callback observes the state these steps leave -- the sums ride in the last step's launch
-        red = bool(with_reductions) and hasattr(eng, "reduce_end")
+        red = bool(with_reductions) and hasattr(eng, "reduce_end_exact")
         if update is not None:
             codes = [optimiser_code(self.optimisers[lid]) for lid in self.learn_ids]
             opt = ([c[0] for c in codes], [c[1] for c in codes], [c[2] for c in codes])
@@ -263,7 +267,7 @@ class PolicyGradientEstimator(AriannaAlgorithm):
             # while the host reads (fetching first left the queue empty for a few microseconds every callback period).
             if n > 1:
                 eng.pgmc_steps(n - 1, self.learn_ids, self.q_batch_size, *opt)
-            met._settle_claimed()
+            met._settle_claimed(keep=1)          # two reductions in flight per engine (Metropolis._inflight)
             eng.pgmc_steps(1, self.learn_ids, self.q_batch_size, *opt, reduce_begin=True)
         else:
             eng.pgmc_steps(n, self.learn_ids, self.q_batch_size, *opt)

@@ -235,6 +235,29 @@ def allreduce_sum(values: np.ndarray, engine=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
+def allreduce_xsum(records: np.ndarray, engine=None) -> np.ndarray:
+    """The merged records of all ranks (reproducible sums, include/amc.h): every rank ends with the same bits, those a single
+    rank holding all the chains would have.  With a communicator: amc_allreduce_xsum (one RCCL all-reduce used as a gather).
+    Otherwise the same gather over the host path -- each rank fills its own slot of a zeroed buffer, so the sum adds one value
+    and zeros per word and is exact in any order -- followed by the integer merge of libamc.so (amc_xsum_merge)."""
+    from ._capi import AMC_XSUM_WORDS, xsum_merge
+    rank, size = world()
+    rec = np.ascontiguousarray(records, dtype=np.float64)
+    shape = rec.shape
+    if engine is not None and getattr(engine, "comm_connected", False):
+        return engine.allreduce_xsum(rec).reshape(shape)
+    if size == 1:
+        return rec
+    flat = rec.reshape(-1)
+    buf = np.zeros((size, flat.size))
+    buf[rank] = flat
+    tot = allreduce_sum(buf.reshape(-1), None).reshape(size, -1, AMC_XSUM_WORDS)
+    merged = tot[0]
+    for r in range(1, size):
+        merged = xsum_merge(merged, tot[r])
+    return merged.reshape(shape)
+
+
 def all_ranks(flag: bool, engine=None) -> bool:
     """True on every rank iff every rank passed a true flag -- ONE small sum over the ranks (the engine's communicator when it
     has one).  For loops whose exit depends on something local, a clock say: every rank must leave after the same number of

@@ -755,9 +755,305 @@ void amo_make_steps(amo_sim *s, int64_t n, int n_threads)
     s->t = t0 + (uint64_t)n * (uint64_t)steps;
 }
 
-/* particle_1d.jl:68-70 callback_energy: mean(system.e for system in chains),
- * a left-to-right sum divided by M. */
+/* ------------------------------------------------------------------------ */
+/* Reproducible sums.                                 */
+/* The reference folds across chains with `+` in whatever order its reducer   */
+/* takes (mean: particle_1d.jl:68-70, metropolis.jl:319-321; foldxl / foldxt: */
+/* estimator.jl:94,113), so the order is not part of its semantics.  The      */
+/* engine defines each cross-chain sum so that no order can enter: summands   */
+/* are rounded once to multiples of a power of two fixed by order-independent */
+/* facts, the multiples are added as integers, the total is rounded once.     */
+/* This is that definition restated with integer arithmetic on the operands'  */
+/* bit patterns (the kernels form the same integers with floating-point       */
+/* additions into accumulators of a fixed binade).  The plain left-to-right   */
+/* sums stay beside it (amo_*_plain) to pin the difference.                   */
+/* ------------------------------------------------------------------------ */
+typedef __int128 i128_t;
+typedef unsigned __int128 u128_t;
+enum { XS_WORDS = 12, XS_EMPTY = 0, XS_Q = 1, XS_R = 2, XS_PLAIN = 3, XS_NAN = 1, XS_PINF = 2, XS_NINF = 4,
+       XS_LEVEL_BITS = 50, XS_LMIN = -20, XS_LMAX = 19, XS_E_RATIO = -34 };
+typedef struct { int kind, e; unsigned flags; i128_t k1, k2; double plain; } xs_t;
+
+static double lsb1(double v) { return u2d(d2u(v) | 1ull); }
+
+/* round-half-even of |m| 2^e / 2^q for an unsigned integer m; *overflow set when the result needs more than 62 bits */
+static int64_t rn_u128(u128_t m, int e, int q, int *overflow)
+{
+    int s = q - e;                       /* divide by 2^s */
+    u128_t r;
+    if (m == 0) return 0;
+    if (s <= 0) {
+        int bits = 0;
+        for (u128_t t = m; t; t >>= 1) ++bits;
+        if (bits - s > 62) { *overflow = 1; return 0; }
+        r = m << (-s);
+    } else if (s >= 128) {
+        r = 0;
+    } else {
+        u128_t rem = m & ((((u128_t)1) << s) - 1), half = ((u128_t)1) << (s - 1);
+        r = m >> s;
+        if (rem > half || (rem == half && (r & 1))) r += 1;
+        if (r >> 62) { *overflow = 1; return 0; }
+    }
+    return (int64_t)r;
+}
+
+/* finite x = (-1)^neg m 2^e with m an integer below 2^53 */
+static void split_double(double x, int *neg, uint64_t *m, int *e)
+{
+    uint64_t b = d2u(x);
+    int be = (int)((b >> 52) & 0x7FF);
+    *neg = (int)(b >> 63);
+    *m = b & ((1ull << 52) - 1);
+    if (be == 0) *e = -1074;
+    else { *m |= 1ull << 52; *e = be - 1075; }
+}
+
+/* RN(x / 2^q), x finite */
+static int64_t rn_scaled(double x, int q, int *overflow)
+{
+    int neg, e;
+    uint64_t m;
+    split_double(x, &neg, &m, &e);
+    int64_t r = rn_u128((u128_t)m, e, q, overflow);
+    return neg ? -r : r;
+}
+
+/* RN(a b / 2^q): the exact product of two finite doubles, rounded once */
+static int64_t rn_scaled_product(double a, double b, int q, int *overflow)
+{
+    int na, nb, ea, eb;
+    uint64_t ma, mb;
+    split_double(a, &na, &ma, &ea);
+    split_double(b, &nb, &mb, &eb);
+    int64_t r = rn_u128((u128_t)ma * (u128_t)mb, ea + eb, q, overflow);
+    return (na != nb) ? -r : r;
+}
+
+static int is_finite(double v) { return ((d2u(v) >> 52) & 0x7FF) != 0x7FF; }
+
+static void xs_flag_nonfinite(xs_t *a, double v)
+{
+    if (v != v) a->flags |= XS_NAN;
+    else a->flags |= (v > 0) ? XS_PINF : XS_NINF;
+}
+
+/* kind Q: a->e is the quantum exponent.  Any summand that is not finite makes the sum NaN. */
+static void xs_q_add(xs_t *a, double v)
+{
+    int ov = 0;
+    if (!is_finite(v)) { a->flags |= XS_NAN; return; }
+    a->k1 += rn_scaled(lsb1(v), a->e, &ov);
+    if (ov) a->flags |= XS_NAN;
+}
+static void xs_q_add_product(xs_t *a, double x, double y)
+{
+    int ov = 0;
+    if (!is_finite(x) || !is_finite(y)) { a->flags |= XS_NAN; return; }
+    a->k1 += rn_scaled_product(lsb1(x), lsb1(y), a->e, &ov);
+    if (ov) a->flags |= XS_NAN;
+}
+
+/* kind R: the level a finite value needs, max(LMIN, floor((ilogb(v) + 1) / 50)); zero and subnormals: LMIN */
+static int xs_level_of(double v)
+{
+    int be = (int)((d2u(v) >> 52) & 0x7FF);
+    if (be == 0) return XS_LMIN;
+    int num = be - 1023 + 1;                          /* ilogb + 1 */
+    int l = (num >= 0) ? num / XS_LEVEL_BITS : -((-num + XS_LEVEL_BITS - 1) / XS_LEVEL_BITS);
+    return l < XS_LMIN ? XS_LMIN : l;
+}
+static void xs_r_raise(xs_t *a, int top)
+{
+    int d = top - a->e;
+    if (d <= 0) return;
+    a->k2 = (d == 1) ? a->k1 : 0;      /* one level up the level-1 multiples ARE the level-2 multiples; further up all round to 0 */
+    a->k1 = 0;
+    a->e = top;
+}
+static void xs_r_add(xs_t *a, double v)
+{
+    int ov = 0;
+    if (!is_finite(v)) { xs_flag_nonfinite(a, v); return; }
+    int l = xs_level_of(v);
+    if (l > XS_LMAX) { a->flags |= (v > 0) ? XS_PINF : XS_NINF; return; }    /* |v| >= 2^999: beyond the last level */
+    if (l > a->e) xs_r_raise(a, l);
+    double v1 = lsb1(v);
+    int64_t k1 = rn_scaled(v1, XS_LEVEL_BITS * a->e, &ov);
+    double r = v1 - ldexp((double)k1, XS_LEVEL_BITS * a->e);      /* exact: the low part of v1 */
+    int64_t k2 = rn_scaled(lsb1(r), XS_LEVEL_BITS * (a->e - 1), &ov);
+    a->k1 += k1;
+    a->k2 += k2;
+    if (ov) a->flags |= XS_NAN;
+}
+static xs_t xs_new(int kind, int e)
+{
+    xs_t a;
+    memset(&a, 0, sizeof(a));
+    a.kind = kind;
+    a.e = (kind == XS_R) ? XS_LMIN : e;
+    return a;
+}
+
+/* K rounded to 53 significant bits (ties to even), times 2^e */
+static double round_i128(i128_t K, int e)
+{
+    int neg = K < 0;
+    u128_t m = neg ? (u128_t)(-K) : (u128_t)K;
+    int bits = 0;
+    for (u128_t t = m; t; t >>= 1) ++bits;
+    double v;
+    if (bits <= 53) v = ldexp((double)(uint64_t)m, e);
+    else {
+        int s = bits - 53;
+        u128_t rem = m & ((((u128_t)1) << s) - 1), half = ((u128_t)1) << (s - 1);
+        uint64_t q = (uint64_t)(m >> s);
+        if (rem > half || (rem == half && (q & 1))) q += 1;
+        v = ldexp((double)q, e + s);
+    }
+    return neg ? -v : v;
+}
+static double xs_value(const xs_t *a)
+{
+    if (a->kind == XS_EMPTY) return 0.0;
+    if (a->kind == XS_PLAIN) return a->plain;
+    if (a->flags) {
+        if ((a->flags & XS_NAN) || ((a->flags & XS_PINF) && (a->flags & XS_NINF))) return 0.0 / 0.0;
+        return (a->flags & XS_PINF) ? 1.0 / 0.0 : -1.0 / 0.0;
+    }
+    if (a->kind == XS_Q) return round_i128(a->k1, a->e);
+    return round_i128(a->k1 * (((i128_t)1) << XS_LEVEL_BITS) + a->k2, XS_LEVEL_BITS * (a->e - 1));
+}
+static void xs_merge(xs_t *a, const xs_t *b_in)
+{
+    xs_t b = *b_in;
+    if (b.kind == XS_EMPTY) return;
+    if (a->kind == XS_EMPTY) { *a = b; return; }
+    if (a->kind != b.kind || (a->kind == XS_Q && a->e != b.e)) { a->flags |= XS_NAN; return; }
+    if (a->kind == XS_PLAIN) { a->plain += b.plain; return; }
+    if (a->kind == XS_R) {
+        if (b.e > a->e) xs_r_raise(a, b.e);
+        else xs_r_raise(&b, a->e);
+    }
+    a->k1 += b.k1;
+    a->k2 += b.k2;
+    a->flags |= b.flags;
+}
+/* records: the transport form of include/amc.h (AMC_XSUM_WORDS doubles, 32-bit limbs, the top one signed) */
+static void limbs_out(double *w, i128_t k)
+{
+    u128_t u = (u128_t)k;
+    w[0] = (double)(uint32_t)u;
+    w[1] = (double)(uint32_t)(u >> 32);
+    w[2] = (double)(uint32_t)(u >> 64);
+    w[3] = (double)(int32_t)(uint32_t)(u >> 96);
+}
+static i128_t limbs_in(const double *w)
+{
+    i128_t r = 0;
+    for (int i = 3; i >= 0; --i) r = r * (((i128_t)1) << 32) + (i128_t)(int64_t)w[i];
+    return r;
+}
+static void xs_to_record(const xs_t *a, double *rec)
+{
+    for (int i = 0; i < XS_WORDS; ++i) rec[i] = 0.0;
+    rec[0] = (double)a->kind;
+    if (a->kind == XS_PLAIN) { rec[11] = a->plain; return; }
+    rec[1] = (double)a->e;
+    rec[2] = (double)a->flags;
+    limbs_out(rec + 3, a->k1);
+    if (a->kind == XS_R) limbs_out(rec + 7, a->k2);
+}
+static xs_t xs_from_record(const double *rec)
+{
+    xs_t a;
+    memset(&a, 0, sizeof(a));
+    a.kind = (int)rec[0];
+    a.e = (int)rec[1];
+    a.flags = (unsigned)rec[2];
+    a.k1 = limbs_in(rec + 3);
+    a.k2 = limbs_in(rec + 7);
+    a.plain = rec[11];
+    return a;
+}
+
+/* exported: the definition applied to explicit operands (known-answer tests against an independent big-integer model) */
+void amo_xsum_q(const double *v, int64_t n, int e, double *rec)
+{
+    xs_t a = xs_new(XS_Q, e);
+    for (int64_t i = 0; i < n; ++i) xs_q_add(&a, v[i]);
+    xs_to_record(&a, rec);
+}
+void amo_xsum_q_product(const double *x, const double *y, int64_t n, int e, double *rec)
+{
+    xs_t a = xs_new(XS_Q, e);
+    for (int64_t i = 0; i < n; ++i) xs_q_add_product(&a, x[i], y[i]);
+    xs_to_record(&a, rec);
+}
+void amo_xsum_r(const double *v, int64_t n, double *rec)
+{
+    xs_t a = xs_new(XS_R, 0);
+    for (int64_t i = 0; i < n; ++i) xs_r_add(&a, v[i]);
+    xs_to_record(&a, rec);
+}
+void amo_xsum_merge(double *into, const double *from)
+{
+    xs_t a = xs_from_record(into), b = xs_from_record(from);
+    xs_merge(&a, &b);
+    xs_to_record(&a, into);
+}
+double amo_xsum_round(const double *rec)
+{
+    xs_t a = xs_from_record(rec);
+    return xs_value(&a);
+}
+/* GradientData of the Gaussian displacement policy: quantum exponents of (j, grad j, grad logq, g) from
+ * 2^(es-1) <= sigma < 2^es and z^2 <= 72.1, alpha <= 1: the bounds 2^(2es+7), 2^(es+13), 2^(8-es), 2^(15-2es) of one
+ * summand, each minus 46 (a lane of the engine adds 2^5 summands into an accumulator of 2^51 quanta). */
+void amo_gd_exponents(double sigma, int e[4])
+{
+    int es = (int)((d2u(sigma) >> 52) & 0x7FF) - 1023 + 1;
+    e[0] = 2 * es + 7 - 46;
+    e[1] = es + 13 - 46;
+    e[2] = 8 - es - 46;
+    e[3] = 15 - 2 * es - 46;
+}
+
+/* The callbacks' sums over this simulation's chains as records, in the layout of amc_reduce: sum e, sum x, sum x^2 (kind R),
+ * the count (plain), per move sum_c accepted_c / total_c (kind Q, quantum 2^-34; 0/0 = NaN like the reference). */
+void amo_callback_records(const amo_sim *s, double *recs)
+{
+    xs_t se = xs_new(XS_R, 0), sx = xs_new(XS_R, 0), sxx = xs_new(XS_R, 0), cnt = xs_new(XS_PLAIN, 0);
+    for (int64_t c = 0; c < s->M; ++c) {
+        double x = s->chains[c].x;
+        xs_r_add(&se, s->chains[c].e);
+        xs_r_add(&sx, x);
+        xs_r_add(&sxx, x * x);
+    }
+    cnt.plain = (double)s->M;
+    xs_to_record(&se, recs);
+    xs_to_record(&sx, recs + XS_WORDS);
+    xs_to_record(&sxx, recs + 2 * XS_WORDS);
+    xs_to_record(&cnt, recs + 3 * XS_WORDS);
+    for (int k = 0; k < s->K; ++k) {
+        xs_t r = xs_new(XS_Q, XS_E_RATIO);
+        for (int64_t c = 0; c < s->M; ++c) {
+            const move_t *m = &s->pools[c * s->K + k];
+            xs_q_add(&r, (double)m->accepted_calls / (double)m->total_calls);
+        }
+        xs_to_record(&r, recs + (4 + k) * XS_WORDS);
+    }
+}
+
+/* particle_1d.jl:68-70 callback_energy: mean(system.e for system in chains) -- the sum as defined above, divided by M. */
 double amo_callback_energy(const amo_sim *s)
+{
+    xs_t se = xs_new(XS_R, 0);
+    for (int64_t c = 0; c < s->M; ++c) xs_r_add(&se, s->chains[c].e);
+    return xs_value(&se) / (double)s->M;
+}
+/* ... and as a left-to-right Float64 sum, one of the orders the reference's `mean` may take */
+double amo_callback_energy_plain(const amo_sim *s)
 {
     double acc = 0.0;
     for (int64_t c = 0; c < s->M; ++c) acc += s->chains[c].e;
@@ -767,6 +1063,17 @@ double amo_callback_energy(const amo_sim *s)
 /* metropolis.jl:319-321 callback_acceptance: mean over chains of the per-chain
  * vector [accepted_calls / total_calls for move in pool]; 0/0 -> NaN. */
 void amo_callback_acceptance(const amo_sim *s, double *out)
+{
+    for (int k = 0; k < s->K; ++k) {
+        xs_t r = xs_new(XS_Q, XS_E_RATIO);
+        for (int64_t c = 0; c < s->M; ++c) {
+            const move_t *m = &s->pools[c * s->K + k];
+            xs_q_add(&r, (double)m->accepted_calls / (double)m->total_calls);
+        }
+        out[k] = xs_value(&r) / (double)s->M;
+    }
+}
+void amo_callback_acceptance_plain(const amo_sim *s, double *out)
 {
     for (int k = 0; k < s->K; ++k) {
         double acc = 0.0;
@@ -781,13 +1088,13 @@ void amo_callback_acceptance(const amo_sim *s, double *out)
 /* Statistic of test/distribution_test.jl:33-37 (mean/std of positions). */
 void amo_moments(const amo_sim *s, double out[2])
 {
-    double sx = 0.0, sxx = 0.0;
+    xs_t sx = xs_new(XS_R, 0), sxx = xs_new(XS_R, 0);
     for (int64_t c = 0; c < s->M; ++c) {
         double x = s->chains[c].x;
-        sx += x;
-        sxx += x * x;
+        xs_r_add(&sx, x);
+        xs_r_add(&sxx, x * x);
     }
-    out[0] = sx; out[1] = sxx;
+    out[0] = xs_value(&sx); out[1] = xs_value(&sxx);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -910,12 +1217,168 @@ static void pgmc_sample_f32(particle_t *p, move_t *m, double sigma, int pot, dou
     gd[3] = dlogq_f * dlogq_f;
 }
 
+/* ---- the estimator's summands by the ARITHMETIC SPEC of DESIGN.md section 3.6b --------------------------------
+ * The Gaussian policy's four GradientData summands enter nothing but `+` folds whose order the reference leaves open,
+ * and the engine forms them with two of the reference's sub-expressions replaced by forms that agree to a few ulp
+ * (amc_kernels.h pg_sample): alpha = exp(min(dlogp, 0)) without the detour through logq_b - logq_f (which cancels bit
+ * for bit), and d logq / d sigma = d^2 c3 - 1/sigma as one fma chain with c3 = dden / den^2 split hi + lo.  For the fold
+ * to be bit-reproducible against the engine the oracle restates THAT arithmetic here, operation for operation;
+ * pgmc_sample above is the reference-ordered form (gradients.jl:93-109), and the tests pin the two within a few ulp per
+ * sample (test_pg_sample_summands_within_ulps).  The position update is the reference's in both. */
+typedef struct { double sigma, c3hi, c3lo, c1; } spec_consts_t;
+static spec_consts_t spec_consts(double sigma)
+{
+    const double TWO_PI = 0x1.921fb54442d18p+2;
+    spec_consts_t k;
+    double s2 = sigma * sigma, ds2 = sigma + sigma;
+    double den = 2.0 * s2, dden = 2.0 * ds2;
+    double av = TWO_PI * s2;
+    k.sigma = sigma;
+    k.c1 = ((TWO_PI * ds2) / av) / 2.0;                 /* d/dsigma of log(2 pi sigma^2) / 2 by ForwardDiff's rules */
+    double d_hi = den * den, d_lo = fma(den, den, -d_hi);
+    k.c3hi = dden / d_hi;
+    double res = fma(-k.c3hi, d_hi, dden) - k.c3hi * d_lo;
+    k.c3lo = res / d_hi;
+    return k;
+}
+static double spec_alpha(double arg)
+{
+    /* min(1, exp(arg)) with Julia's NaN-keeping min; the spec's exp has exp(0) == 1 and exp(arg <= 0) <= 1 exactly */
+    if (arg != arg) return arg;
+    if (arg >= 0.0) return 1.0;
+    if (arg >= -708.0) return amo_exp(arg);
+    return 0.0;
+}
+/* gd = (j, d logq / d sigma): the two numbers the four summands are made of (grad j = j dlogq, g = dlogq^2) */
+static void pgmc_sample_spec(particle_t *p, move_t *m, const spec_consts_t *k, int pot, double z, double *j, double *dlogq)
+{
+    m->delta = fma(k->sigma, z, 0.0);                               /* 0.0 + sigma*z, bit for bit */
+    double e1, e2;
+    perform_action(p, m, pot, &e1, &e2);
+    double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta);
+    double d2 = m->delta * m->delta;
+    double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : d2;
+    m->delta = -m->delta;
+    perform_action(p, m, pot, &e1, &e2);                            /* always reverts: x = (x + d) + (-d) */
+    *dlogq = fma(d2, k->c3hi, fma(d2, k->c3lo, -k->c1));
+    *j = r * spec_alpha(dlogp);
+}
+static void pgmc_sample_spec_f32(particle_t *p, move_t *m, const spec_consts_t *k, int pot, double z, double *j, double *dlogq)
+{
+    float delta = (float)fma(k->sigma, z, 0.0);
+    float e1, e2, beta = (float)p->beta;
+    perform_action_f32(p, delta, pot, &e1, &e2);
+    float dlogp = delta_log_target_density_f32(e1, e2, beta);
+    float d2t = delta * delta;
+    double d2 = (double)d2t;
+    double r = g_custom_reward_f32 ? g_custom_reward_f32(delta, (float)p->x) : d2;
+    delta = -delta;
+    perform_action_f32(p, delta, pot, &e1, &e2);
+    m->delta = (double)delta;
+    *dlogq = fma(d2, k->c3hi, fma(d2, k->c3lo, -k->c1));
+    *j = r * spec_alpha((double)dlogp);
+}
+/* exported for the per-sample comparison with the reference-ordered form */
+void amo_pg_summands_spec(int pot, double beta, double sigma, double z, double *x, double out[4])
+{
+    particle_t p = { *x, beta, amo_potential(pot, *x) };
+    move_t m = { 0.0, 0, 0 };
+    spec_consts_t k = spec_consts(sigma);
+    double j, d;
+    pgmc_sample_spec(&p, &m, &k, pot, z, &j, &d);
+    out[0] = j; out[1] = j * d; out[2] = d; out[3] = d * d;
+    *x = p.x;
+}
+void amo_pg_summands_reference(int pot, double beta, double sigma, double z, double *x, double out[4])
+{
+    particle_t p = { *x, beta, amo_potential(pot, *x) };
+    move_t m = { 0.0, 0, 0 };
+    pgmc_sample(&p, &m, sigma, pot, z, out);
+    *x = p.x;
+}
+
+/* Which kind of reproducible sum the fold is (amc_kernels.h PgKind): quanta from sigma for the Gaussian displacement
+ * policy on a built-in potential with the model's reward -- every summand is then bounded by a function of sigma --,
+ * running top as soon as a script-defined expression takes part. */
+static int pg_fold_bounded(const amo_sim *s)
+{
+    return !(g_custom_logq || g_custom_scale || g_custom_scale_f32 || g_custom_reward || g_custom_reward_f32 ||
+             s->pot == AMO_POT_CUSTOM);
+}
+
 /* estimator.jl:111-134 make_step!(::PolicyGradientEstimator): for each learnable
- * move, foldxl(+) of GradientData (gradients.jl:68-76) over chains x q_batch
- * samples.  The caller owns the running accumulators (:130-131).  Draws come
+ * move, the `+` fold of GradientData (gradients.jl:68-76) over chains x q_batch
+ * samples -- as a reproducible sum (above).  The caller owns the running accumulators (:130-131).  Draws come
  * from the ESTIMATOR stream (the reference replays the sampler's seeds,
- * estimator.jl:91-92,107 -- a quirk that is deliberately not reproduced). */
+ * estimator.jl:91-92,107 -- a quirk that is deliberately not reproduced).
+ * recs: n_learn x 5 records (j, grad j, grad logq, g, n). */
+void amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *recs)
+{
+    uint64_t t = s->t_est;
+    const int bounded = pg_fold_bounded(s);
+    const int script = (g_custom_logq || g_custom_scale || g_custom_scale_f32) ? 1 : 0;
+    for (int l = 0; l < n_learn; ++l) {
+        int lid = learn_ids[l];
+        int ex[4] = { 0, 0, 0, 0 };
+        if (bounded) amo_gd_exponents(s->sigma[lid], ex);
+        xs_t col[4];
+        for (int i = 0; i < 4; ++i) col[i] = xs_new(bounded ? XS_Q : XS_R, ex[i]);
+        spec_consts_t k = spec_consts(s->sigma[lid]);
+        int64_t n = 0;
+        for (int64_t c = 0; c < s->M; ++c) {
+            uint64_t g = (uint64_t)(s->offset + c);
+            int half = (int)(g & 1u);
+            for (int q = 0; q < q_batch; ++q) {
+                uint32_t v[4];
+                double zz[2];
+                draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
+                amo_box_muller(v, zz);
+                particle_t *p = &s->chains[c];
+                move_t *m = &s->pools[c * s->K + lid];
+                if (script) {
+                    /* script-defined policies: the reference's operations (the kernels mirror them), products rounded */
+                    double gd[4];
+                    if (s->f32) pgmc_sample_f32(p, m, s->sigma[lid], s->pot, zz[half], gd);
+                    else pgmc_sample(p, m, s->sigma[lid], s->pot, zz[half], gd);
+                    for (int i = 0; i < 4; ++i) xs_r_add(&col[i], gd[i]);
+                } else {
+                    double j, d;
+                    if (s->f32) pgmc_sample_spec_f32(p, m, &k, s->pot, zz[half], &j, &d);
+                    else pgmc_sample_spec(p, m, &k, s->pot, zz[half], &j, &d);
+                    if (bounded) {
+                        xs_q_add(&col[0], j);
+                        xs_q_add_product(&col[1], j, d);
+                        xs_q_add(&col[2], d);
+                        xs_q_add_product(&col[3], d, d);
+                    } else {
+                        xs_r_add(&col[0], j);
+                        xs_r_add(&col[1], j * d);
+                        xs_r_add(&col[2], d);
+                        xs_r_add(&col[3], d * d);
+                    }
+                }
+                n += 1;
+            }
+        }
+        for (int i = 0; i < 4; ++i) xs_to_record(&col[i], recs + (size_t)(l * 5 + i) * XS_WORDS);
+        xs_t cnt = xs_new(XS_PLAIN, 0);
+        cnt.plain = (double)n;
+        xs_to_record(&cnt, recs + (size_t)(l * 5 + 4) * XS_WORDS);
+    }
+    s->t_est = t + 1;
+}
+
 void amo_pg_estimate(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *out)
+{
+    double *recs = (double *)malloc((size_t)(n_learn > 0 ? n_learn : 1) * 5 * XS_WORDS * sizeof(double));
+    amo_pg_estimate_records(s, n_learn, learn_ids, q_batch, recs);
+    for (int i = 0; i < n_learn * 5; ++i) out[i] = amo_xsum_round(recs + (size_t)i * XS_WORDS);
+    free(recs);
+}
+
+/* The same call with the reference-ordered summands (pgmc_sample) folded left to right in Float64: one of the orders the
+ * reference's reducer may take (foldxl).  Pins the reproducible fold above at rtol 1e-10 in the tests. */
+void amo_pg_estimate_plain(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *out)
 {
     uint64_t t = s->t_est;
     for (int l = 0; l < n_learn; ++l) {

@@ -110,9 +110,30 @@ double amo_callback_energy(const amo_sim *s);
 void   amo_callback_acceptance(const amo_sim *s, double *out /* K */);
 void   amo_moments(const amo_sim *s, double out[2]);      /* sum x, sum x^2 */
 
-/* make_step!(::PolicyGradientEstimator): out[n_learn][5] = (j, dj, dlogq_fwd, g, n) */
+/* make_step!(::PolicyGradientEstimator): out[n_learn][5] = (j, dj, dlogq_fwd, g, n); the fold is a reproducible sum
+ * (amc_oracle.c "Reproducible sums": the cross-chain sums are defined independently of the order of the additions). */
 void   amo_pg_estimate(amo_sim *s, int n_learn, const int *learn_ids, int q_batch,
                        double *out);
+/* ... as records (n_learn x 5 x 12 doubles: what shards exchange), and with the reference-ordered summands folded left
+ * to right in Float64 (one of the orders the reference's reducer may take) */
+void   amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *recs);
+void   amo_pg_estimate_plain(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *out);
+/* one sample's summands (j, grad j, grad logq, g) of the Gaussian policy: by the arithmetic spec the engine follows
+ *  and in the reference's operation order (gradients.jl:93-109); *x is updated like the chain's */
+void   amo_pg_summands_spec(int pot, double beta, double sigma, double z, double *x, double out[4]);
+void   amo_pg_summands_reference(int pot, double beta, double sigma, double z, double *x, double out[4]);
+
+/* ---- reproducible sums: the definition applied to explicit operands, records of 12 doubles (include/amc.h) ---- */
+void   amo_xsum_q(const double *v, int64_t n, int e, double *rec);
+void   amo_xsum_q_product(const double *x, const double *y, int64_t n, int e, double *rec);
+void   amo_xsum_r(const double *v, int64_t n, double *rec);
+void   amo_xsum_merge(double *into, const double *from);
+double amo_xsum_round(const double *rec);
+void   amo_gd_exponents(double sigma, int e[4]);
+/* the callbacks' sums as records, layout of amc_reduce: sum e, sum x, sum x^2, count, sum_c acc/tot per move */
+void   amo_callback_records(const amo_sim *s, double *recs);
+double amo_callback_energy_plain(const amo_sim *s);
+void   amo_callback_acceptance_plain(const amo_sim *s, double *out);
 /* learning_step! for P = 1: gd = averaged (j, dj, dlogq_fwd, g); returns new parameter */
 double amo_learning_step(int opt, double hyper0, double hyper1, double theta,
                          const double gd[4]);

@@ -94,6 +94,19 @@ def load() -> C.CDLL:
         "amo_callback_acceptance": (None, [S, dp]),
         "amo_moments": (None, [S, dp]),
         "amo_pg_estimate": (None, [S, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amo_pg_estimate_records": (None, [S, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amo_pg_estimate_plain": (None, [S, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amo_pg_summands_spec": (None, [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]),
+        "amo_pg_summands_reference": (None, [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]),
+        "amo_xsum_q": (None, [dp, C.c_int64, C.c_int, dp]),
+        "amo_xsum_q_product": (None, [dp, dp, C.c_int64, C.c_int, dp]),
+        "amo_xsum_r": (None, [dp, C.c_int64, dp]),
+        "amo_xsum_merge": (None, [dp, dp]),
+        "amo_xsum_round": (C.c_double, [dp]),
+        "amo_gd_exponents": (None, [C.c_double, C.POINTER(C.c_int)]),
+        "amo_callback_records": (None, [S, dp]),
+        "amo_callback_energy_plain": (C.c_double, [S]),
+        "amo_callback_acceptance_plain": (None, [S, dp]),
         "amo_learning_step": (C.c_double, [C.c_int, C.c_double, C.c_double, C.c_double, dp]),
         "amo_build_schedule_linear": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int64]),
         "amo_build_schedule_block": (C.c_int64, [C.c_int64, C.c_int64, i64p, C.c_int, i64p, C.c_int64]),
@@ -114,6 +127,60 @@ def load() -> C.CDLL:
 
 def _dptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---- reproducible sums (oracle/amc_oracle.c "Reproducible sums"): records of XS_WORDS doubles ----------------------
+XS_WORDS = 12
+
+
+def xsum_q(values, e):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    rec = np.zeros(XS_WORDS)
+    load().amo_xsum_q(_dptr(v), v.size, int(e), _dptr(rec))
+    return rec
+
+
+def xsum_q_product(x, y, e):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    rec = np.zeros(XS_WORDS)
+    load().amo_xsum_q_product(_dptr(x), _dptr(y), x.size, int(e), _dptr(rec))
+    return rec
+
+
+def xsum_r(values):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    rec = np.zeros(XS_WORDS)
+    load().amo_xsum_r(_dptr(v), v.size, _dptr(rec))
+    return rec
+
+
+def xsum_merge(into, other):
+    a = np.ascontiguousarray(into, dtype=np.float64).reshape(-1, XS_WORDS).copy()
+    b = np.ascontiguousarray(other, dtype=np.float64).reshape(-1, XS_WORDS)
+    for i in range(a.shape[0]):
+        load().amo_xsum_merge(_dptr(a[i]), _dptr(np.ascontiguousarray(b[i])))
+    return a
+
+
+def xsum_round(records):
+    a = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, XS_WORDS)
+    return np.array([load().amo_xsum_round(_dptr(np.ascontiguousarray(r))) for r in a])
+
+
+def gd_exponents(sigma):
+    e = (C.c_int * 4)()
+    load().amo_gd_exponents(float(sigma), e)
+    return list(e)
+
+
+def pg_summands(pot, beta, sigma, z, x, form="spec"):
+    """One estimator sample of the Gaussian policy: (summands[4], new x); form 'spec'  or 'reference'."""
+    xx = np.array([float(x)])
+    out = np.zeros(4)
+    fn = load().amo_pg_summands_spec if form == "spec" else load().amo_pg_summands_reference
+    fn(POTENTIALS[pot] if isinstance(pot, str) else int(pot), float(beta), float(sigma), float(z), _dptr(xx), _dptr(out))
+    return out, float(xx[0])
 
 
 # ---- primitive helpers ---------------------------------------------------------------
@@ -392,6 +459,36 @@ class OracleSim:
         self.lib.amo_pg_estimate(self.h, n, ids, int(q_batch), _dptr(out))
         return out
 
+    def pg_estimate_records(self, learn_ids, q_batch):
+        """The fold as records, shape (n_learn, 5, XS_WORDS)."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, 5, XS_WORDS))
+        self.lib.amo_pg_estimate_records(self.h, n, ids, int(q_batch), _dptr(out))
+        return out
+
+    def pg_estimate_plain(self, learn_ids, q_batch):
+        """Reference-ordered summands folded left to right in Float64 (one order the reference's reducer may take)."""
+        n = len(learn_ids)
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, 5))
+        self.lib.amo_pg_estimate_plain(self.h, n, ids, int(q_batch), _dptr(out))
+        return out
+
+    def callback_records(self):
+        """The callbacks' sums as records, shape (4 + K, XS_WORDS): sum e, sum x, sum x^2, count, sum_c acc/tot per move."""
+        out = np.zeros((4 + self.K, XS_WORDS))
+        self.lib.amo_callback_records(self.h, _dptr(out))
+        return out
+
+    def energy_plain(self):
+        return self.lib.amo_callback_energy_plain(self.h)
+
+    def acceptance_plain(self):
+        out = np.empty(self.K)
+        self.lib.amo_callback_acceptance_plain(self.h, _dptr(out))
+        return out
+
     def run_pooled_moments(self, steps, burn, dt, threads=1):
         out = np.zeros(4)
         self.lib.amo_run_pooled_moments(self.h, int(steps), int(burn), int(dt), int(threads), _dptr(out))
@@ -422,6 +519,7 @@ class OracleEngine:
                  stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
+        self.per_chain_counters = bool(per_chain_counters) or self.n_moves > 1
         self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
                              weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype,
@@ -462,14 +560,24 @@ class OracleEngine:
     def step(self, t):
         self.sim.step = t
 
-    def reduce(self):
-        out = np.empty(4 + self.n_moves)
-        m = self.sim.moments()
-        out[0] = self.sim.energy() * self.n_chains
-        out[1], out[2] = m[0], m[1]
-        out[3] = float(self.n_chains)
-        out[4:] = self.sim.acceptance() * self.n_chains
+    def reduce_exact(self):
+        """(records, steps counted): what HipEngine.reduce_end_exact returns.  A K = 1 engine without per-chain counters
+        carries the pool-wide accepted TOTAL in the ratio record (amc_reduce_end_exact)."""
+        rec = self.sim.callback_records()
+        if self.n_moves == 1 and not self.per_chain_counters:
+            acc, _ = self.sim.counters()
+            rec[4] = xsum_q([float(acc.sum())], 0)
+        return rec, int(self.sim.step)
+
+    def reduce_records_value(self, records, steps_counted):
+        out = xsum_round(records)
+        if self.n_moves == 1 and not self.per_chain_counters:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out[4] = out[4] / np.float64(steps_counted)          # 0/0 = NaN before the first step, like the reference
         return out
+
+    def reduce(self):
+        return self.reduce_records_value(*self.reduce_exact())
 
     def upload_counters(self, accepted, total=None):
         a = np.ascontiguousarray(accepted, dtype=np.int64).reshape(self.n_moves, self.n_chains)
@@ -515,15 +623,19 @@ class OracleEngine:
         self.sim.lib.amo_set_estimator_step(self.sim.h, int(t))
 
     def reduce_begin(self):
-        self._pending = self.reduce()
+        q = self.__dict__.setdefault("_pending", [])
+        assert len(q) < 2, "two reductions are already in flight"       # amc_reduce_begin: AMC_ERR_STATE
+        q.append(self.reduce_exact())
 
     def sweep_reduce_begin(self, n_sweeps=1):
         self.sweep(n_sweeps)
-        self._pending = self.reduce()
+        self.reduce_begin()
+
+    def reduce_end_exact(self):
+        return self._pending.pop(0)           # the oldest
 
     def reduce_end(self):
-        out, self._pending = self._pending, None
-        return out
+        return self.reduce_records_value(*self.reduce_end_exact())
 
     def set_parameters(self, k, p):
         self.sim.set_sigma(k, float(np.asarray(p).reshape(-1)[0]))
@@ -542,6 +654,9 @@ class OracleEngine:
 
     def pg_estimate(self, learn_ids, q_batch):
         return self.sim.pg_estimate(learn_ids, q_batch)
+
+    def pg_estimate_exact(self, learn_ids, q_batch):
+        return self.sim.pg_estimate_records(learn_ids, q_batch)
 
     # device-resident estimator / update of the HIP engine (amc_pg_accumulate / amc_pg_update / amc_pgmc_steps),
     # restated on the host: running sums per move, learning step by the oracle's amo_learning_step

@@ -371,7 +371,11 @@ def test_oracle_custom_reward_default_is_delta_squared(oracle):
     ga = a.pg_estimate([0], 3)
     b = oracle.OracleSim(3000, **kw)                      # reward_expr None restores delta^2
     b.init_uniform(-2, 2); b.make_steps(5)
-    assert np.array_equal(ga, b.pg_estimate([0], 3))
+    # the same summands; the fold is a running-top sum as soon as a script-defined reward takes part and a sigma-quantum sum
+    # without one: two definitions of the same sum, ~1e-12 apart at this size
+    gb = b.pg_estimate([0], 3)
+    assert np.allclose(ga, gb, rtol=1e-9, atol=0.0)
+    assert np.array_equal(a.state()[0], b.state()[0])
     a.close(); b.close()
 
 
