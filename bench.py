@@ -13,8 +13,9 @@ For N > 1 (configs[3]) the ensemble is N x 1e7 chains sharded by global chain id
 the energy/acceptance callbacks are all-reduced over RCCL every 10 sweeps inside the timed region -- by the engines' own
 communicator (amc_comm_init / amc_allreduce_sum, on a communication stream of the engine's own), which also carries the barriers
 around the timed region (one 8-byte all-reduce each; every rank stamps its own K steps after its own synchronize, the
-job's time is the MAX over ranks); the launcher's TCP store carries the ncclUniqueId, the set-up barriers and the max over
-ranks.  No torch process group, no torch tensors.  config.rccl_ranks is
+job's time is the MAX over ranks); a plain-socket key-value store on MASTER_PORT + 1 (sharding.SocketStore, rank 0 serves it)
+carries the ncclUniqueId, the set-up barriers and the max over ranks.  No torch in the worker at all: the launcher only starts
+it, so libamc.so binds the system's HIP runtime and RCCL in every rank exactly as in a single process.  config.rccl_ranks is
 what ncclCommCount reports for that communicator; the RCCL / HIP runtime versions and files really bound are in the line too.
 
 Rank 0 prints ONE JSON line.  Extra objects:
@@ -268,6 +269,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=M_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step block for min / median (not part of value)")
+    ap.add_argument("--min-gpu-seconds", type=float, default=8.0,
+                    help="keep repeating the K-step block (not part of value) until this much wall clock has gone by, so that a "
+                         "coarse outside sampler of GPU activity sees the device busy; 0: just --repeats blocks")
     ap.add_argument("--no-ladder", action="store_true", help="skip the 4e7 / 1.6e8-chain launches behind roofline.ladder")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 / config-5 end-to-end figures")
     args = ap.parse_args()
@@ -301,7 +305,15 @@ def main():
         grp = sharding.init_store_group(rank, world)                 # the launcher's store: before any GPU call
         grp.barrier()
 
+    # The CPU leg FIRST (rank 0, N = 1 only): the GPU phase then sits at the END of the run, where an outside sampler of GPU
+    # activity finds it (with the baseline last, ~4 s of GPU work used to precede 22 s of host-only work).  The checker is
+    # loaded and timed here and nowhere near the product path below.
+    cpu_line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline()
+
     from montecarlo_amd import _capi as A
+    assert world == 1 or force_dist or "torch" not in sys.modules, "the worker must not import torch (libamc.so binds the system's ROCm)"
 
     m_local = args.chains_per_gpu
     m_global = m_local * world
@@ -335,7 +347,8 @@ def main():
     # bundled ROCm; a bare single-process run binds /opt/rocm)
     rt = A.runtime_info()
     ci = eng.comm_info() if getattr(eng, "comm_connected", False) else None
-    stack = {"hip_runtime_version": rt["hip_runtime_version"], "hip_runtime": rt["hip_runtime"],
+    stack = {"torch_imported": "torch" in sys.modules, "rccl_library_forced": A.comm_library_forced(),
+             "hip_runtime_version": rt["hip_runtime_version"], "hip_runtime": rt["hip_runtime"],
              "rccl_ranks": None if ci is None else ci["n_ranks"], "rccl_rank": None if ci is None else ci["rank"],
              "rccl_version": None if ci is None else ci["rccl_version"], "librccl": None if ci is None else ci["librccl"]}
     if grp is not None:
@@ -345,6 +358,8 @@ def main():
         stack["rccl_ranks"] = None if any(c is None for c in counts) else min(counts)
         stack["rccl_ranks_by_rank"] = counts
         stack["hip_runtime_versions_by_rank"] = [st["hip_runtime_version"] for st in stacks]
+        stack["hip_runtimes_by_rank"] = sorted({st["hip_runtime"] for st in stacks})
+        stack["torch_imported"] = any(st["torch_imported"] for st in stacks)
     cb_every = CALLBACK_EVERY_MULTI if grp is not None else 0
     if os.environ.get("AMC_BENCH_CB_EVERY"):                 # developer knob: separate the cost of the callbacks from the process group's
         cb_every = int(os.environ["AMC_BENCH_CB_EVERY"])
@@ -352,10 +367,13 @@ def main():
     pending = [False]
 
     def finish_callback():
-        """all-reduce the callback sums enqueued one period ago (the host never drains the sweep queue)."""
+        """merge the callback sums enqueued one period ago over the shards (the host never drains the sweep queue): the shards'
+        exact integer records through ONE ncclAllReduce used as a gather (amc_allreduce_xsum) -- callback_energy and
+        callback_acceptance then have the same bits whatever N is."""
         if pending[0]:
             pending[0] = False
-            return sharding.allreduce_sum(eng.reduce_end(), eng)   # callback_energy + callback_acceptance, ONE ncclAllReduce
+            rec, steps = eng.reduce_end_exact()
+            return eng.reduce_records_value(sharding.allreduce_xsum(rec, eng), steps)
         return None
 
     def step(i):
@@ -417,8 +435,17 @@ def main():
 
     # the same K-step block, repeated (not part of `value`): a 20-step driver run is 0.7 ms of timed region, and one slow
     # launch moves it by 5 %
+    # ... and, with --min-gpu-seconds, for at least that long: the device stays busy long enough for a sampler outside this
+    # process to see it at work (every block is the timed region's own: same steps, same barriers)
     rep_ms = []
-    for _ in range(max(0, args.repeats)):
+    t_rep = time.perf_counter()
+    while True:
+        n_done = len(rep_ms)
+        more = n_done < max(0, args.repeats) or (args.repeats > 0 and time.perf_counter() - t_rep < args.min_gpu_seconds)
+        if grp is not None:
+            more = sharding.all_ranks(more, eng) if args.min_gpu_seconds > 0 else n_done < max(0, args.repeats)
+        if not more:
+            break
         barrier()
         r0 = time.perf_counter()
         for i in range(args.steps):
@@ -429,7 +456,8 @@ def main():
     if grp is not None and rep_ms:
         rep_ms = [max(col) for col in zip(*grp.allgather(rep_ms))]
 
-    red = sharding.allreduce_sum(eng.reduce(), eng)
+    rec, steps_counted = eng.reduce_exact()
+    red = eng.reduce_records_value(sharding.allreduce_xsum(rec, eng), steps_counted)
     n = red[3]
     energy, acceptance = red[0] / n, red[4] / n
 
@@ -482,8 +510,9 @@ def main():
                 "callbacks_allreduce_every": cb_every, "callbacks_allreduce_via": allreduce_via,
                 **stack,
                 "sharding": "contiguous global chain ids per rank; no data-path collective",
-                "multi_gpu_note": "N > 1: callbacks all-reduced by the engines' own RCCL communicator (amc_allreduce_sum), unique id "
-                                  "and barriers over the launcher's TCP store; rccl_ranks is ncclCommCount of that communicator "
+                "multi_gpu_note": "N > 1: callback sums merged over the shards as exact integer records by the engines' own RCCL "
+                                  "communicator (amc_allreduce_xsum: one ncclAllReduce used as a gather), unique id and barriers over a "
+                                  "plain-socket store (no torch in the worker); rccl_ranks is ncclCommCount of that communicator "
                                   "(null: no communicator); this repository's own GPU runs have one device, so N > 1 has never "
                                   "been run by the builder",
             },
@@ -506,13 +535,20 @@ def main():
             },
             "repeat": None if not rep_ms else {
                 "blocks": len(rep_ms), "steps_per_block": args.steps, "ms_per_step_min": min(rep_ms),
-                "ms_per_step_median": sorted(rep_ms)[len(rep_ms) // 2], "ms_per_step_all": rep_ms},
+                "ms_per_step_median": sorted(rep_ms)[len(rep_ms) // 2],
+                "ms_per_step_p10": sorted(rep_ms)[len(rep_ms) // 10], "ms_per_step_p90": sorted(rep_ms)[(9 * len(rep_ms)) // 10],
+                "ms_per_step_all": rep_ms[:5] if len(rep_ms) > 16 else rep_ms,        # the first five of a long series
+                "seconds": sum(rep_ms) * args.steps * 1e-3},
             "check": {"mean_energy": energy, "acceptance": acceptance},
             "fused_sweepstep16": fused,
             "other_configs": others,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+        if cpu_line is not None:
+            result["cpu_baseline"] = cpu_line
+        # a stand-in or a site build in place of librccl: the line says so, and carries no `value` unless a test asked for it
+        if stack.get("rccl_library_forced") and os.environ.get("AMC_BENCH_ALLOW_FORCED_RCCL") != "1":
+            result["value"] = None
+            result["value_withheld"] = "AMC_RCCL_LIBRARY replaced librccl in this run: not a measurement over RCCL"
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
     eng.close()

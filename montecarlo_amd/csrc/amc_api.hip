@@ -85,7 +85,7 @@ struct Rccl {
 }  // namespace
 
 static const int RED_HOST_STRIDE = amc::RED_ROW_WORDS;   // 64-bit words per row of the callback sums' block rows (red_finish)
-static const int RATIO_STRIDE = 4;      // words per row of the fold's acceptance-ratio partials (K <= 4): one integer per move
+static const int RATIO_STRIDE = 4;      // columns per row of the fold's acceptance-ratio partials (K <= 4): XS_ROW_Q words per move
 static const int PG_MAX_COLS = AMC_MAX_LEARN * 4;   // GradientData columns of one estimator call
 static const int RED_TICKETS = 2;       // reductions that may be in flight per handle (amc_reduce_begin .. amc_reduce_end)
 
@@ -953,7 +953,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     for (int i = 0; i < RED_TICKETS; ++i) {
         RedTicket& t = h->red[i];
         AMC_TRY(hipHostMalloc((void**)&t.h_rows, (size_t)h->n_slots * RED_HOST_STRIDE * sizeof(amc::xs_word), 0));
-        AMC_TRY(hipHostMalloc((void**)&t.h_ratio, (size_t)h->n_slots * RATIO_STRIDE * sizeof(amc::xs_word), 0));
+        AMC_TRY(hipHostMalloc((void**)&t.h_ratio, (size_t)h->n_slots * RATIO_STRIDE * amc::XS_ROW_Q * sizeof(amc::xs_word), 0));
         AMC_TRY(hipMalloc(&t.d_ratio_acc, (size_t)AMC_MAX_MOVES * 3 * sizeof(unsigned long long)));
         AMC_TRY(hipHostMalloc((void**)&t.h_ratio_acc, (size_t)AMC_MAX_MOVES * 3 * sizeof(unsigned long long), 0));
         AMC_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
@@ -1754,17 +1754,15 @@ static int reduce_end_records(amc_handle* h, const char* who, double* recs, uint
         int e = xs::XS_E_RATIO;
         if (t->ratio_rows > 0) {
             for (int r = 0; r < t->ratio_rows; ++r) {
-                const long long v = (long long)t->h_ratio[(size_t)r * RATIO_STRIDE + k];
-                if (v == AMC_XS_POISON_HI) q.flags |= xs::XS_F_NAN;
-                else q.k = xs::i128_add(q.k, xs::i128_of(v));
+                const xs::PartQ b = amc::xs_load_q_row(t->h_ratio + ((size_t)r * RATIO_STRIDE + k) * amc::XS_ROW_Q);
+                q.k = xs::i128_add(q.k, b.k);
+                q.flags |= b.flags;
             }
         } else if (t->ratio_acc) {
             const unsigned long long* a = t->h_ratio_acc + 3 * k;
             if (a[2] != 0) q.flags |= xs::XS_F_NAN;
-            // low halves (each below 2^32) and high halves were added separately: k = hi 2^32 + lo
-            xs::i128 hi = xs::i128_of((long long)a[1]);
-            hi = xs::i128{hi.lo << 32, (int64_t)(((uint64_t)hi.hi << 32) | (hi.lo >> 32))};
-            q.k = xs::i128_add(hi, xs::i128{a[0], 0});
+            // low 32-bit halves and high parts were added separately: k = hi 2^32 + lo
+            q.k = xs::i128_add(xs::i128_shl(xs::i128_of((long long)a[1]), 32), xs::i128{a[0], 0});
         } else {
             // K == 1 without per-chain counters: total_calls is the same on every chain, so sum_c accepted_c / total is
             // (sum_c accepted_c) / total up to rounding: the record is the pool-wide accepted TOTAL

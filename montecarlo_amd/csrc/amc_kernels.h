@@ -536,6 +536,27 @@ __device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)
         s[c] = __longlong_as_double((long long)cbits[c]);
     }
 }
+// the same for a lane that holds the integer itself
+__device__ __forceinline__ void q_flush_int(unsigned long long& acc, QSlot* slot)
+{
+    const long long k = (long long)acc;
+    if (k != 0) {
+        atomicAdd(&slot->lo, (unsigned long long)(k & 0xFFFFFFFFll));
+        atomicAdd(&slot->hi, (unsigned long long)(k >> 32));
+    }
+    acc = 0ull;
+}
+// One acceptance ratio accepted / total (callback_acceptance, metropolis.jl:319-321: Int / Int -> Float64) as a multiple of
+// 2^XS_E_RATIO, added to the lane's integer; a chain that never picked the move has 0 / 0 = NaN (`nan` is set; the
+// division is then by 1).
+__device__ __forceinline__ void ratio_add(unsigned long long& acc, bool& nan, uint32_t accepted, uint32_t total)
+{
+    const uint32_t den = total > 1u ? total : 1u;
+    nan = nan | (total == 0u);
+    const double q = (double)accepted / (double)den;
+    const double t = xs::xs_c(xs::XS_E_RATIO) + __longlong_as_double(__double_as_longlong(q) | 1ll);
+    acc += (unsigned long long)__double_as_longlong(t) - xs::xs_c_bits(xs::XS_E_RATIO);
+}
 __device__ __forceinline__ xs::PartQ q_slot_value(const QSlot& s)
 {
     // k = hi 2^32 + lo
@@ -1117,10 +1138,19 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
     constexpr uint32_t ONES = 0x01010101u;
     constexpr bool ALL_TOT = GROUP == 1;                                         // every move of this pass has a total array
     __shared__ __attribute__((aligned(16))) uint32_t s_pk[2 * KK][4 * AMC_BLOCK];   // [k: accepted, total][quad of the tile]
-    // callback_acceptance's sums: kind-Q columns of quantum 2^XS_E_RATIO (amc_xsum.h); a lane adds at most 16 ratios per tile
-    double ratio[KK];
+    // callback_acceptance's sums: kind-Q columns of quantum 2^XS_E_RATIO (amc_xsum.h), 16 ratios per lane, move and tile
+    unsigned long long ratio[KK];
+    bool ratio_nan[KK];
+    int ratio_tiles = 0;
+    __shared__ QSlot s_ratio[RATIO ? AMC_BLOCK / 64 : 1][KK];
+    if (RATIO) {
+        if ((threadIdx.x & 63) == 0)
 #pragma unroll
-    for (int k = 0; k < KK; ++k) ratio[k] = xs::xs_c(xs::XS_E_RATIO);
+            for (int k = 0; k < KK; ++k) q_slot_clear(s_ratio[threadIdx.x >> 6][k]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < KK; ++k) { ratio[k] = 0ull; ratio_nan[k] = false; }
     // the group a step belongs to: bit 3 of a nibble (pools of 5..8), bits 3..6 of a byte (up to 64 moves)
     const uint32_t group_field = BYTES ? 0x0F0F0F0Fu : ONES;
     const uint32_t group_word = (uint32_t)group * ONES;
@@ -1234,31 +1264,30 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (c0 + e < n_chains)                        // the padding behind the last chain has no ratio
-                            ratio[k] += __longlong_as_double(__double_as_longlong((double)a4[e] / (double)t4[e]) | 1ll);
+                            ratio_add(ratio[k], ratio_nan[k], a4[e], t4[e]);
                 }
             }
         }
         __syncthreads();                                   // the next tile overwrites s_pk
+        if (RATIO && ++ratio_tiles == xs::XS_RATIO_LANE_CAP / 16) {       // (ensembles beyond 2e9 chains)
+#pragma unroll
+            for (int k = 0; k < KK; ++k) q_flush_int(ratio[k], &s_ratio[threadIdx.x >> 6][k]);
+            ratio_tiles = 0;
+        }
     }
     if (RATIO) {
-        // one 64-bit integer per move and block (a block adds fewer than 2^24 ratios of at most 2^34 quanta each); a 0/0 = NaN
-        // among them (a chain that never picked the move, metropolis.jl:320) makes the column NaN
-        __shared__ QSlot s_ratio[AMC_BLOCK / 64][KK];
-        if ((threadIdx.x & 63) == 0)
+        // one row of two words per move and block; a 0/0 = NaN among the ratios (a chain that never picked the move,
+        // metropolis.jl:320) makes every column NaN that met one
 #pragma unroll
-            for (int k = 0; k < KK; ++k) q_slot_clear(s_ratio[threadIdx.x >> 6][k]);
-        __syncthreads();
-        uint64_t cb[KK];
-#pragma unroll
-        for (int k = 0; k < KK; ++k) cb[k] = xs::xs_c_bits(xs::XS_E_RATIO);
-        q_flush<KK>(ratio, cb, s_ratio[threadIdx.x >> 6]);
+        for (int k = 0; k < KK; ++k) {
+            q_flush_int(ratio[k], &s_ratio[threadIdx.x >> 6][k]);
+            if (ratio_nan[k]) atomicOr(&s_ratio[threadIdx.x >> 6][k].flags, (unsigned int)xs::XS_F_NAN);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < KK; ++k) {
-                const xs::PartQ t = q_block_total<KK>(s_ratio, k);
-                ratio_partials[(int64_t)blockIdx.x * rp_stride + k] = t.flags ? (xs_word)AMC_XS_POISON_HI : (xs_word)t.k.lo;
-            }
+            for (int k = 0; k < KK; ++k)
+                xs_store_q_row(ratio_partials + ((int64_t)blockIdx.x * rp_stride + k) * XS_ROW_Q, q_block_total<KK>(s_ratio, k));
         }
     }
 }
@@ -1480,32 +1509,35 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
             __syncthreads();
             if ((threadIdx.x & 63) == 0) q_slot_clear(s_ratio[threadIdx.x >> 6][0]);
             __syncthreads();
-            double r[1] = {xs::xs_c(xs::XS_E_RATIO)};
+            unsigned long long r = 0ull;
+            bool nan = false;
+            int n_r = 0;
             for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
-                const double a = (double)acc[(int64_t)k * m_stride + c];
-                double n = (double)t_steps;
+                const uint32_t a = acc[(int64_t)k * m_stride + c];
+                uint32_t n = (uint32_t)t_steps;
                 if (ratio_mode == 2) {
                     // total_calls of the last move has no array: the step count minus the other moves' (fold_log_kernel)
                     if (k + 1 < n_moves) {
-                        n = (double)tot[(int64_t)k * m_stride + c];
+                        n = tot[(int64_t)k * m_stride + c];
                     } else {
                         uint64_t others = 0;
                         for (int j = 0; j + 1 < n_moves; ++j) others += tot[(int64_t)j * m_stride + c];
-                        n = (double)(t_steps - others);
+                        n = (uint32_t)(t_steps - others);
                     }
                 }
-                r[0] += __longlong_as_double(__double_as_longlong(a / n) | 1ll);    // Int/Int -> Float64 division; 0/0 = NaN like the reference
+                ratio_add(r, nan, a, n);      // Int/Int -> Float64 division; 0/0 = NaN like the reference
+                if (++n_r == xs::XS_RATIO_LANE_CAP) { q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]); n_r = 0; }
             }
-            const uint64_t cb[1] = {xs::xs_c_bits(xs::XS_E_RATIO)};
-            q_flush<1>(r, cb, s_ratio[threadIdx.x >> 6]);
+            q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]);
+            if (nan) atomicOr(&s_ratio[threadIdx.x >> 6][0].flags, (unsigned int)xs::XS_F_NAN);
             __syncthreads();
             if (threadIdx.x == 0) {
+                // the block's total as low 32 bits + high part: two 64-bit atomics on the move's words (three with the NaN count)
                 const xs::PartQ t = q_block_total<1>(s_ratio, 0);
-                const long long kk = (long long)t.k.lo;                  // |k| < 2^58: one word
                 if (t.flags) atomicAdd(ratio_acc + 3 * k + 2, 1ull);
                 else {
-                    atomicAdd(ratio_acc + 3 * k, (unsigned long long)(kk & 0xFFFFFFFFll));
-                    atomicAdd(ratio_acc + 3 * k + 1, (unsigned long long)(kk >> 32));
+                    atomicAdd(ratio_acc + 3 * k, (unsigned long long)(t.k.lo & 0xFFFFFFFFull));
+                    atomicAdd(ratio_acc + 3 * k + 1, (unsigned long long)(((uint64_t)t.k.hi << 32) | (t.k.lo >> 32)));
                 }
             }
         }

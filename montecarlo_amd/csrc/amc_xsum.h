@@ -54,8 +54,8 @@ enum { XS_W = 50, XS_B = 49 };            // bits per level; a level takes |v| <
 enum { XS_LMIN = -20, XS_LMAX = 19 };     // q_(LMIN-1) = 2^-1050 keeps 1.5 * 2^(q+52) a normal number; level 19 takes |v| < 2^999
 enum { XS_LANE_CAP = 4096 };              // kind R: summands a lane adds into one pair of 64-bit integers between two flushes
 enum { XS_GD_CAP_BITS = 5, XS_GD_LANE_CAP = 1 << XS_GD_CAP_BITS };   // kind Q (GradientData): 32 summands between two flushes
-enum { XS_E_RATIO = -34 };                // accepted / total in [0, 1]: quantum 2^-34, 2^16 summands per lane without a flush
-enum { XS_RATIO_LANE_CAP = 65536 };
+enum { XS_E_RATIO = -50 };                // accepted / total in [0, 1]: quantum 2^-50.  Lanes add the bit patterns of 6.0 + lsb1(ratio)
+enum { XS_RATIO_LANE_CAP = 4096 };        // (6.0 = 1.5 * 2^2 has ulp 2^-50) minus those of 6.0 as 64-bit integers: 2^12 ratios fit
 
 // ---- 128-bit two's complement integers (no __int128 on the device side of every toolchain this is compiled by) ----
 struct i128 {
@@ -251,12 +251,14 @@ AMC_XS_HD void rec_from_q(double* rec, const PartQ& p, int e)
 {
     rec_clear(rec);
     rec[0] = (double)XS_Q; rec[1] = (double)e; rec[2] = (double)p.flags;
+    if (p.flags) return;                      // NaN: the integer means nothing, canonically zero
     limbs_store(rec + 3, p.k);
 }
 AMC_XS_HD void rec_from_r(double* rec, const PartR& p)
 {
     rec_clear(rec);
     rec[0] = (double)XS_R; rec[1] = (double)p.top; rec[2] = (double)p.flags;
+    if (p.flags) return;                      // NaN / infinite: the integers mean nothing, canonically zero
     limbs_store(rec + 3, p.k1);
     limbs_store(rec + 7, p.k2);
 }

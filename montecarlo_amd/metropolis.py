@@ -188,6 +188,19 @@ class Metropolis(AriannaAlgorithm):
             move.parameters[...] = self.engine.get_parameters(k)
         self.device_params_dirty = False
 
+    def parameters_async(self, t: int) -> "ParameterRead":
+        """The parameters of every move as of the steps queued so far, as a ticket (engine.parameters_begin: a copy in stream
+        order; ``result()`` fetches it).  The engine keeps ONE such read in flight: algorithms that ask at the same time step
+        share the ticket, and a new time step first fetches the older read -- whoever holds it gets the values all the same."""
+        tk = getattr(self, "_param_ticket", None)
+        if tk is not None and tk.t == t:
+            return tk
+        if tk is not None:
+            tk.result()
+        tk = ParameterRead(self.engine, t)
+        self._param_ticket = tk
+        return tk
+
     def download_counters(self):
         """pools[c][k].accepted_calls / total_calls of this rank's shard, shape (K, M_local)."""
         return self.engine.download_counters()
@@ -228,6 +241,19 @@ class Metropolis(AriannaAlgorithm):
     def invalidate_reductions(self) -> None:
         """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
         self._epoch += 1
+
+
+class ParameterRead:
+    """A queued read of the moves' parameters (see Metropolis.parameters_async)."""
+
+    def __init__(self, engine, t: int):
+        engine.parameters_begin()
+        self._engine, self.t, self._val = engine, t, None
+
+    def result(self) -> np.ndarray:
+        if self._val is None:
+            self._val = self._engine.parameters_end()
+        return self._val
 
 
 class Reduction:

@@ -7,8 +7,8 @@ collective.  Information crosses chains in exactly two places, both tiny sums:
   * the GradientData `+` fold of the estimator (src/PolicyGuided/estimator.jl:113-129)
 These become ONE all-reduce(sum, f64) of a few dozen bytes.  On GPUs it runs through the engine's own RCCL
 communicator (amc_comm_init / amc_allreduce_sum: RCCL over xGMI, on a stream of the engine's own, no torch tensors involved);
-the launcher's TCP store carries the 128-byte ncclUniqueId and the run's barriers (`StoreGroup`: no process group, no
-second RCCL instance in the process).  A torch.distributed process group, if the script has one, is used the same way
+a plain-socket key-value store beside the launcher's carries the 128-byte ncclUniqueId and the run's barriers (`StoreGroup`:
+no process group, no torch in the worker, one RCCL instance in the process -- the system's).  A torch.distributed process group, if the script has one, is used the same way
 ("gloo" in CPU tests; "nccl" only to ship the unique id).  The Philox counter uses the global chain id, so results do
 not depend on W (shard invariance is tested).
 """
@@ -21,21 +21,191 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 
+class SocketStore:
+    """A key-value store over plain TCP sockets: what this path needs of the launcher's rendezvous (set / get / add / wait /
+    delete), without torch.  Rank 0 serves it from a daemon thread on MASTER_ADDR : MASTER_PORT + 1 (the launcher's own store
+    sits on MASTER_PORT); every rank -- rank 0 included -- is a client.  Requests are length-prefixed pickles, one reply
+    each; `get` blocks on the server until the key exists.  A worker that uses this store never imports torch, so
+    libamc.so binds the system's HIP runtime and RCCL (/opt/rocm) in every rank, as it does in a single process."""
+
+    def __init__(self, host: str, port: int, is_master: bool, timeout_s: float = 600.0):
+        import socket
+        import threading
+        import time
+        self._timeout = float(timeout_s)
+        self._lock = threading.Lock()
+        if is_master:
+            self._data = {}
+            self._cond = threading.Condition()
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host, int(port)))
+            srv.listen(256)
+            srv.settimeout(0.2)
+            self._srv = srv
+            self._open = 0            # client connections open now / ever accepted
+            self._ever = 0
+            # NOT a daemon: the serving process (rank 0) must outlive its clients' last reads -- the thread ends once the main
+            # thread is done and every other client has hung up (or 30 s later)
+            threading.Thread(target=self._serve, daemon=False).start()
+        deadline = time.monotonic() + self._timeout
+        while True:                                   # the server may come up after its clients
+            try:
+                self._sock = socket.create_connection((host, int(port)), timeout=5.0)
+                break
+            except OSError:
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"no SocketStore at {host}:{port} after {self._timeout:.0f} s")
+                time.sleep(0.05)
+        self._sock.settimeout(self._timeout)
+        self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+
+    # ---- server side (rank 0) ----
+    def _serve(self) -> None:
+        import socket
+        import threading
+        import time
+        main_done_at = None
+        while True:
+            try:
+                conn, _ = self._srv.accept()
+                with self._cond:
+                    self._open += 1
+                    self._ever += 1
+                threading.Thread(target=self._client, args=(conn,), daemon=True).start()
+                continue
+            except socket.timeout:
+                pass
+            except OSError:
+                return
+            if not threading.main_thread().is_alive():
+                main_done_at = main_done_at or time.monotonic()
+                with self._cond:
+                    others_open = self._open - 1          # this process's own client connection stays open to the end
+                if others_open <= 0 or time.monotonic() - main_done_at > 30.0:
+                    self._srv.close()
+                    return
+
+    def _client(self, conn) -> None:
+        import socket
+        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        try:
+            while True:
+                req = _recv_msg(conn)
+                if req is None:
+                    return
+                op, key, val = req
+                with self._cond:
+                    if op == "set":
+                        self._data[key] = val
+                        self._cond.notify_all()
+                        rep = True
+                    elif op == "add":
+                        self._data[key] = int(self._data.get(key, 0)) + int(val)
+                        self._cond.notify_all()
+                        rep = self._data[key]
+                    elif op == "get":
+                        if not self._cond.wait_for(lambda: key in self._data, timeout=self._timeout):
+                            rep = _StoreTimeout(key)
+                        else:
+                            rep = self._data[key]
+                    elif op == "del":
+                        rep = self._data.pop(key, None) is not None
+                    elif op == "len":
+                        rep = len(self._data)
+                    else:
+                        rep = _StoreTimeout(f"unknown request {op!r}")
+                _send_msg(conn, rep)
+        except OSError:
+            return
+        finally:
+            conn.close()
+            with self._cond:
+                self._open -= 1
+
+    # ---- client side ----
+    def _call(self, op: str, key: str, val=None):
+        with self._lock:
+            _send_msg(self._sock, (op, key, val))
+            rep = _recv_msg(self._sock)
+        if isinstance(rep, _StoreTimeout):
+            raise TimeoutError(f"SocketStore: {rep.what}")
+        return rep
+
+    def set(self, key: str, value: bytes) -> None:
+        self._call("set", key, value)
+
+    def get(self, key: str) -> bytes:
+        return self._call("get", key)
+
+    def add(self, key: str, amount: int) -> int:
+        return int(self._call("add", key, int(amount)))
+
+    def wait(self, keys) -> None:
+        for k in keys:
+            self._call("get", k)
+
+    def delete_key(self, key: str) -> bool:
+        return bool(self._call("del", key))
+
+    def num_keys(self) -> int:
+        return int(self._call("len", ""))
+
+
+class _StoreTimeout:
+    def __init__(self, what):
+        self.what = str(what)
+
+
+def _send_msg(sock, obj) -> None:
+    import struct
+    data = pickle.dumps(obj)
+    sock.sendall(struct.pack("<Q", len(data)) + data)
+
+
+def _recv_msg(sock):
+    import struct
+
+    def exactly(n):
+        buf = b""
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                return None
+            buf += chunk
+        return buf
+    head = exactly(8)
+    if head is None:
+        return None
+    body = exactly(struct.unpack("<Q", head)[0])
+    return None if body is None else pickle.loads(body)
+
+
 class StoreGroup:
-    """The ranks of one launch, tied together by the launcher's key-value store only.
+    """The ranks of one launch, tied together by a key-value store only: barrier, all-gather of small Python objects
+    (timings, the ncclUniqueId), and a deterministic host-side sum for engines without a communicator (CPU tests).  No
+    init_process_group, hence no torch-side NCCL/RCCL communicator and no torch CUDA context.
 
-    `python -m torch.distributed.run` hands every worker RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT and hosts a
-    TCPStore on that port (TORCHELASTIC_USE_AGENT_STORE=True); started by hand, rank 0 hosts it.  That store is all
-    this path needs from torch: barrier, all-gather of small Python objects (timings, the ncclUniqueId), and a
-    deterministic host-side sum for engines without a communicator (CPU tests).  No init_process_group, hence no
-    torch-side NCCL/RCCL communicator and no torch CUDA context."""
+    `python -m torch.distributed.run` hands every worker RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  By default the
+    store is this module's own `SocketStore` on MASTER_PORT + 1 (rank 0 serves it): the worker does not import torch at
+    all, so libamc.so binds the system's HIP runtime and RCCL exactly as in a single process.  `store="torch"` (or
+    AMC_STORE=torch) uses the launcher's own TCPStore on MASTER_PORT instead (TORCHELASTIC_USE_AGENT_STORE=True; started by
+    hand, rank 0 hosts it) -- torch then has to be imported first and its bundled ROCm is what libamc.so binds."""
 
-    def __init__(self, rank: int, world_size: int, host: str, port: int, agent_store: bool, timeout_s: float = 600.0):
-        from datetime import timedelta
-        from torch.distributed import TCPStore         # torch first, then libamc.so (one HIP runtime per process)
+    def __init__(self, rank: int, world_size: int, host: str, port: int, agent_store: bool, timeout_s: float = 600.0,
+                 store: Optional[str] = None):
         self.rank, self.world_size = int(rank), int(world_size)
-        self.store = TCPStore(host, int(port), self.world_size, is_master=(self.rank == 0 and not agent_store),
-                              timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+        kind = (store or os.environ.get("AMC_STORE", "socket")).lower()
+        if kind == "torch":
+            from datetime import timedelta
+            from torch.distributed import TCPStore         # torch first, then libamc.so (one HIP runtime per process)
+            self.store = TCPStore(host, int(port), self.world_size, is_master=(self.rank == 0 and not agent_store),
+                                  timeout=timedelta(seconds=timeout_s), wait_for_workers=False)
+        elif kind == "socket":
+            self.store = SocketStore(host, int(port) + 1, is_master=(self.rank == 0), timeout_s=timeout_s)
+        else:
+            raise ValueError(f"unknown store kind {kind!r}: 'socket' or 'torch'")
+        self.kind = kind
         self._n = 0
         self._old: List[str] = []        # rank 0: keys of finished rounds, deleted once every rank is known to be past them
 
@@ -93,9 +263,10 @@ class StoreGroup:
 _group: Optional[StoreGroup] = None
 
 
-def init_store_group(rank: Optional[int] = None, world_size: Optional[int] = None) -> StoreGroup:
-    """Join the launch's ranks through the launcher's store (environment of torch.distributed.run, or RANK /
-    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set by hand).  Call before building the Simulation, in place of
+def init_store_group(rank: Optional[int] = None, world_size: Optional[int] = None, store: Optional[str] = None) -> StoreGroup:
+    """Join the launch's ranks through a key-value store (environment of torch.distributed.run, or RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set by hand): this module's socket store by default (no torch in the worker), the launcher's
+    TCPStore with store="torch" / AMC_STORE=torch.  Call before building the Simulation, in place of
     torch.distributed.init_process_group."""
     global _group
     if _group is not None:
@@ -108,7 +279,7 @@ def init_store_group(rank: Optional[int] = None, world_size: Optional[int] = Non
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29500"))
     agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
-    _group = StoreGroup(rank, world_size, host, port, agent)
+    _group = StoreGroup(rank, world_size, host, port, agent, store=store)
     return _group
 
 

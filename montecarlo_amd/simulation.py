@@ -432,7 +432,7 @@ class StoreParameters(AriannaAlgorithm):
         self.files: List[Any] = []
         self.rows: List[List[tuple]] = [[] for _ in self.ids]
         self.defer = bool(defer)
-        self._pending_t: Optional[int] = None    # time of the read queued on the engine and not fetched yet
+        self._pending = None                     # (t, ticket) of the read queued on the engine whose row is not written yet
 
     def initialise(self, simulation: Simulation) -> None:
         if self.rank == 0:
@@ -451,10 +451,10 @@ class StoreParameters(AriannaAlgorithm):
 
     def flush(self) -> None:
         """Fetch the queued read, if any, and write its row."""
-        if self._pending_t is None:
+        if self._pending is None:
             return
-        sigma = self.metropolis.engine.parameters_end()
-        t, self._pending_t = self._pending_t, None
+        (t, ticket), self._pending = self._pending, None
+        sigma = ticket.result()
         values = []
         for k, prm in zip(self.ids, self.parameters_list):
             v = prm.copy()
@@ -466,9 +466,10 @@ class StoreParameters(AriannaAlgorithm):
         met = self.metropolis
         if getattr(met, "device_params_dirty", False):
             if self.defer and hasattr(met.engine, "parameters_begin"):
-                self.flush()                        # one read in flight: the previous row first (queued a period ago)
-                met.engine.parameters_begin()       # sigma as of the steps queued so far
-                self._pending_t = simulation.t
+                self.flush()                        # the previous row first (its read was queued a period ago)
+                # sigma as of the steps queued so far; one read in flight per engine, shared by every StoreParameters of this
+                # Metropolis that is due at the same t (Metropolis.parameters_async)
+                self._pending = (simulation.t, met.parameters_async(simulation.t))
                 return
             met.pull_parameters()                   # sigma was updated by a device-resident learning step
         self.flush()

@@ -771,7 +771,7 @@ void amo_make_steps(amo_sim *s, int64_t n, int n_threads)
 typedef __int128 i128_t;
 typedef unsigned __int128 u128_t;
 enum { XS_WORDS = 12, XS_EMPTY = 0, XS_Q = 1, XS_R = 2, XS_PLAIN = 3, XS_NAN = 1, XS_PINF = 2, XS_NINF = 4,
-       XS_LEVEL_BITS = 50, XS_LMIN = -20, XS_LMAX = 19, XS_E_RATIO = -34 };
+       XS_LEVEL_BITS = 50, XS_LMIN = -20, XS_LMAX = 19, XS_E_RATIO = -50 };
 typedef struct { int kind, e; unsigned flags; i128_t k1, k2; double plain; } xs_t;
 
 static double lsb1(double v) { return u2d(d2u(v) | 1ull); }
@@ -961,6 +961,7 @@ static void xs_to_record(const xs_t *a, double *rec)
     if (a->kind == XS_PLAIN) { rec[11] = a->plain; return; }
     rec[1] = (double)a->e;
     rec[2] = (double)a->flags;
+    if (a->flags) return;                  /* NaN / infinite: the integers mean nothing, canonically zero */
     limbs_out(rec + 3, a->k1);
     if (a->kind == XS_R) limbs_out(rec + 7, a->k2);
 }
@@ -1020,7 +1021,7 @@ void amo_gd_exponents(double sigma, int e[4])
 }
 
 /* The callbacks' sums over this simulation's chains as records, in the layout of amc_reduce: sum e, sum x, sum x^2 (kind R),
- * the count (plain), per move sum_c accepted_c / total_c (kind Q, quantum 2^-34; 0/0 = NaN like the reference). */
+ * the count (plain), per move sum_c accepted_c / total_c (kind Q, quantum 2^-50; 0/0 = NaN like the reference). */
 void amo_callback_records(const amo_sim *s, double *recs)
 {
     xs_t se = xs_new(XS_R, 0), sx = xs_new(XS_R, 0), sxx = xs_new(XS_R, 0), cnt = xs_new(XS_PLAIN, 0);

@@ -64,7 +64,9 @@ int main(void)
         }
         if (amc_get_parameters(h, 1, &s2, 1)) return 1;
         if (amc_pgmc_steps_reduce_begin(h, 1, 1, ids, 1, 1, opt, eta, zero)) return 1;
-        if (amc_pgmc_steps_reduce_begin(h, 1, 1, ids, 1, 1, opt, eta, zero) != AMC_ERR_STATE) return 3;      /* one reduction in flight */
+        if (amc_pgmc_steps_reduce_begin(h, 1, 1, ids, 1, 1, opt, eta, zero)) return 1;                         /* two may be in flight */
+        if (amc_pgmc_steps_reduce_begin(h, 1, 1, ids, 1, 1, opt, eta, zero) != AMC_ERR_STATE) return 3;      /* ... a third may not */
+        if (amc_reduce_end(h, r2)) return 1;                                                                   /* the oldest first */
         if (amc_reduce_end(h, r2)) return 1;
         /* no communicator: one rank, no library; and which HIP runtime this process is bound to */
         if (amc_comm_info(h, &n_ranks, &rank, &version, path, (int)sizeof(path)) || amc_runtime_info(&hip_version, hip_path, (int)sizeof(hip_path)))

@@ -8,14 +8,16 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import torch                      # first: libamc.so then shares torch's HIP runtime and RCCL (same sonames)
-import torch.distributed as dist
+USE_STORE = os.environ.get("AMC_TEST_GROUP") == "store"        # ranks joined over the plain-socket store only: no torch here
+if not USE_STORE:
+    import torch                  # first: libamc.so then shares torch's HIP runtime and RCCL (same sonames)
+    import torch.distributed as dist
 import montecarlo_amd as ma
 
-USE_STORE = os.environ.get("AMC_TEST_GROUP") == "store"        # ranks joined over the launcher's TCP store only
 if USE_STORE:
     grp = ma.sharding.init_store_group()
     WORLD, RANK = grp.world_size, grp.rank
+    assert "torch" not in sys.modules
 else:
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
@@ -49,7 +51,8 @@ for mode in ("comm", "host"):
                      energy=[[t, float(v)] for t, v in sim.algorithms[3].rows[0]],
                      acceptance=[[t, [float(a) for a in v]] for t, v in sim.algorithms[3].rows[1]],
                      comm=(eng.comm_info() if hasattr(eng, "comm_info") else None), world=WORLD,
-                     x_head=[float(v).hex() for v in chains.x[:8]], shard=list(sim.algorithms[0].shard))
+                     x_head=[float(v).hex() for v in chains.x[:8]], shard=list(sim.algorithms[0].shard),
+                     torch_imported="torch" in sys.modules, hip_runtime=ma._capi.runtime_info()["hip_runtime"])
 if RANK == 0:
     print(json.dumps(out))
 if USE_STORE:

@@ -18,7 +18,7 @@ M = 400_000
 def run_bench(extra_env, *args):
     env = dict(os.environ, **extra_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--spinup-s", "0.05",
-           "--repeats", "3", "--chains-per-gpu", str(M), *args]
+           "--repeats", "3", "--min-gpu-seconds", "0", "--chains-per-gpu", str(M), *args]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -62,6 +62,7 @@ def test_single_process_line():
     # no communicator in a single process; the HIP runtime libamc.so is bound to is named with its file
     assert c["rccl_ranks"] is None and c["librccl"] is None
     assert c["hip_runtime_version"] > 60000000 and "libamdhip64" in c["hip_runtime"]
+    assert c["torch_imported"] is False and c["rccl_library_forced"] is False
     # BASELINE configs 3 and 5 end to end next to the headline, never instead of it
     oc = d["other_configs"]
     assert "error" not in oc and 0 < oc["config3_double_well_K2"]["us_per_time_step"] < oc["config5_pgmc"]["us_per_time_step"]
@@ -81,6 +82,22 @@ def test_distributed_path_on_one_rank():
     assert "librccl" in c["librccl"] and c["rccl_version"] > 20000
     assert c["callbacks_allreduce_via"].startswith("rccl")
     assert c["hip_runtime_versions_by_rank"] == [c["hip_runtime_version"]]
+    # the N > 1 route runs on the stack the single process runs on: no torch in the worker, the system's HIP runtime
+    assert c["torch_imported"] is False and "/opt/rocm" in c["hip_runtime"]
+
+
+def test_min_gpu_seconds_keeps_the_device_busy():
+    """--min-gpu-seconds: the K-step block is repeated (outside `value`) until that much wall clock has gone by, so that a coarse
+    sampler of GPU activity outside the process finds the device at work."""
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10", "--spinup-s", "0.05", "--repeats", "2",
+           "--min-gpu-seconds", "2.0", "--chains-per-gpu", str(M), "--no-cpu-baseline", "--no-other-configs", "--no-ladder"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    rp = d["repeat"]
+    assert rp["blocks"] > 100 and rp["seconds"] > 1.0 and len(rp["ms_per_step_all"]) == 5
+    assert rp["ms_per_step_min"] <= rp["ms_per_step_p10"] <= rp["ms_per_step_median"] <= rp["ms_per_step_p90"]
 
 
 def test_gpus_flag_without_a_launcher_is_an_error():
@@ -93,7 +110,7 @@ def test_default_size_line_carries_the_ladder():
     """At the default ensemble size the line also holds the M-ladder (4e7 and 1.6e8 chains: state far beyond the 256 MiB
     Infinity Cache) next to the headline figure and its regime."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--spinup-s", "0.2", "--repeats", "2",
-           "--no-cpu-baseline"]
+           "--min-gpu-seconds", "0", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
@@ -124,7 +141,7 @@ def test_two_ranks_on_one_device_fall_back_to_the_store():
     env = dict(os.environ, AMC_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = ["timeout", "-k", "10", "300", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40",
-           "--warmup", "10", "--spinup-s", "0.05", "--repeats", "3", "--chains-per-gpu", str(M)]
+           "--warmup", "10", "--spinup-s", "0.05", "--repeats", "3", "--min-gpu-seconds", "0", "--chains-per-gpu", str(M)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -132,6 +149,7 @@ def test_two_ranks_on_one_device_fall_back_to_the_store():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["chains_total"] == 2 * M and d["config"]["callbacks_allreduce_every"] == 10
     assert "store" in d["config"]["callbacks_allreduce_via"] or "rccl" in d["config"]["callbacks_allreduce_via"]
+    assert d["config"]["torch_imported"] is False            # the launcher only starts the workers
     if "store" in d["config"]["callbacks_allreduce_via"]:       # all or none: no rank kept a communicator the other lacks
         assert d["config"]["rccl_ranks"] is None and d["config"]["rccl_ranks_by_rank"] == [None, None]
     else:

@@ -368,15 +368,15 @@ def test_hip_matches_golden_trajectories(gpu, idx):
         acc, tot = e.download_counters()
         assert acc.tolist() == snap["accepted"] and tot.tolist() == snap["total"]
         if "energy" in snap:
-            red = e.reduce()
-            assert red[0] / sp["M"] == pytest.approx(float.fromhex(snap["energy"]), rel=1e-14)
-            np.testing.assert_allclose(red[4:] / sp["M"], fh(snap["acceptance"]), rtol=1e-14, equal_nan=True)
+            red = e.reduce()                         # reproducible sums: the oracle's bits, whatever the grid
+            assert red[0] / sp["M"] == float.fromhex(snap["energy"])
+            assert np.array_equal(red[4:] / sp["M"], fh(snap["acceptance"]), equal_nan=True)
     e.sweep(256 - done)
     if "pg_estimate_q3" not in case:
         e.close()
         return
     g = e.pg_estimate(list(range(len(sp["sigma"]))), 3)
-    np.testing.assert_allclose(g.ravel(), fh(case["pg_estimate_q3"]), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(bits(g.ravel()), bits(fh(case["pg_estimate_q3"])))
     assert np.array_equal(bits(e.download_state()[0]), bits(fh(case["x_after_pg"])))
     e.close()
 
@@ -723,9 +723,11 @@ def test_fused_sweep_and_callback_reduction(gpu, oracle, M, n, counters, K):
     np.testing.assert_allclose(red[4:] / M, o.acceptance(), rtol=RED_RTOL, equal_nan=True)
     o.make_steps(1, 4)
     assert np.array_equal(bits(e.download_state()[0]), bits(o.state()[0]))
-    with pytest.raises(gpu.AmcError):
-        e.sweep_reduce_begin(1)
-        e.sweep_reduce_begin(1)                 # only one reduction in flight
+    e.sweep_reduce_begin(1)
+    e.sweep_reduce_begin(1)                     # two reductions may be in flight ...
+    with pytest.raises(gpu.AmcError, match="already in flight"):
+        e.sweep_reduce_begin(1)                 # ... a third may not
+    e.reduce_end()
     e.reduce_end()
     e.close()
 
@@ -995,9 +997,11 @@ def test_pgmc_steps_reduce_begin_equals_steps_then_reduce(gpu, case):
         ca, cb = a.download_counters(), b.download_counters()
         assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
         assert np.all(ca[1].sum(axis=0) == 3 + 8 + 4)          # every chain took every step
+    a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)
+    a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)            # two reductions may be in flight
     with pytest.raises(gpu.AmcError, match="already in flight"):
         a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)
-        a.pgmc_steps(1, ids, 2, kinds, h0, h1, reduce_begin=True)
+    a.reduce_end()
     a.reduce_end()
     a.close(); b.close()
 

@@ -52,7 +52,7 @@ def test_callback_records_equal_the_oracles(gpu, oracle, M, potential, sigma, we
     _records_equal(rec, ref.callback_records(), "separate pass")
     out = eng.reduce_records_value(rec, steps)
     assert out[0] / M == ref.energy()
-    assert np.array_equal(bits(out[4:] / M), bits(ref.acceptance()))
+    assert np.array_equal(out[4:] / M, ref.acceptance(), equal_nan=True)      # NaN where a chain never picked the move
     assert np.array_equal(bits(out[1:3]), bits(ref.moments()))
     eng.close()
 

@@ -331,6 +331,31 @@ def test_deferred_parameter_rows_are_the_same_rows_written_one_period_later(orac
     assert out[0][3] == out[1][3]
 
 
+def test_two_store_parameters_on_one_metropolis_share_the_queued_read(oracle, tmp_path):
+    """Two StoreParameters on the same Metropolis (different ids, paths, schedules) beside device-resident learning steps: the
+    engine keeps one parameter read in flight, so instances that are due at the same t share it (Metropolis.parameters_async)
+    and one that is due at a later t fetches the older read first -- rows and files equal those of reading at once."""
+    out = []
+    for i, defer in enumerate((False, True)):
+        steps, path = 100, str(tmp_path / str(i))
+        chains = ma.ParticleChains.uniform(12, 2.0, -2.0, 2.0)
+        pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6), ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
+        al = (dict(algorithm=ma.Metropolis, pool=pool, seed=5, engine_factory=oracle.OracleEngine),
+              dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.VPG(0.02), ma.VPG(0.01)), q_batch_size=2),
+              dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
+              dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), ids=[0], scheduler=ma.build_schedule(steps, 20, 20), defer=defer,
+                   path=os.path.join(path, "a"), store_last=True),
+              dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), ids=[1], scheduler=ma.build_schedule(steps, 20, 30), defer=defer,
+                   path=os.path.join(path, "b")))
+        sim = ma.Simulation(chains, al, steps, path=path)
+        ma.run(sim)
+        rows = [[[(t, float(v[0])) for t, v in r] for r in alg.rows] for alg in sim.algorithms[-2:]]
+        out.append(rows)
+    assert out[0] == out[1]
+    assert [t for t, _ in out[1][0][0]] == [0, 20, 40, 60, 80, 100, 100] and [t for t, _ in out[1][1][0]] == [0, 20, 50, 80, 100]
+    assert out[1][0][0][1][1] != 0.2 and out[1][1][0][1][1] != 0.1                 # both moves learned
+
+
 def test_deferred_callback_rows_are_the_same_rows_written_one_period_later(oracle, tmp_path):
     """StoreCallbacks(defer=True, the default for the engine-backed callbacks): the row of time t is written when the next
     scheduled time comes (or at finalise); the reduction is claimed at t (a ticket) and fetched later.  Files and rows are

@@ -14,7 +14,7 @@ from fractions import Fraction
 LEVEL_BITS = 50
 LMIN = -20
 LMAX = 19
-E_RATIO = -34
+E_RATIO = -50
 
 
 def bits(v: float) -> int:
