@@ -1710,13 +1710,23 @@ static int finish_fused_reduce(amc_handle* h, int grid)
     return red_commit(h, t, grid);
 }
 
+// A launch that forms the callback sums adds two summands per trip into each lane's accumulators, and those hold XS_LANE_CAP of
+// them (amc_xsum.h); the launches of grid_for() make ceil(pairs / (grid 256)) trips per lane.  Beyond that (ensembles of more
+// than 2e9 chains) the sums are formed by the pass of their own, which flushes as it goes.
+static bool reduce_fits_in_launch(const amc_handle* h)
+{
+    const int64_t pairs = (h->M + 1) / 2;
+    const int64_t lanes = (int64_t)grid_for(h, pairs, h->blocks_per_cu_single < h->blocks_per_cu ? h->blocks_per_cu_single : h->blocks_per_cu) * AMC_BLOCK;
+    return 2 * ((pairs + lanes - 1) / lanes) <= amc::xs::XS_LANE_CAP - 2;
+}
+
 int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
     if (!red_next(h))
         return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: %d reductions are already in flight (call amc_reduce_end)", RED_TICKETS);
-    if (h->K > 4) {                         // the ratio sums need the counters of every move: sweep, then the reduction pass
+    if (h->K > 4 || !reduce_fits_in_launch(h)) {      // the ratio sums need the counters of every move: sweep, then the reduction pass
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
@@ -2099,7 +2109,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
-    const bool fused_reduce = reduce && fused && h->K <= 4;
+    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h);
     int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);

@@ -511,11 +511,12 @@ __host__ __device__ inline xs::PartR xs_load_r_row(const xs_word* row)
     return p;
 }
 
-// Kind Q: NC lane accumulators s[] with wave-uniform constants cbits[] (bits of 1.5 * 2^(E + 52)).  q_flush: every lane's
-// integer (bits(s) - cbits) is added into the wave's slot with LDS atomics -- its low 32 bits and its high part into two
-// separate 64-bit words, so no carry has to travel (k = hi 2^32 + lo) --, the accumulators restart at their constants.  No
-// wave-wide operation: a flush may sit inside divergent control flow (the ragged last trip).  An accumulator that has left its
-// binade met a NaN or an infinity (or, never with the quanta of amc_xsum.h, too large a sum): the column is NaN.
+// Kind Q: NC lane accumulators s[] with wave-uniform constants cbits[] (bits of 1.5 * 2^(E + 52)).  A flush adds every lane's
+// integer (bits(s) - cbits) into the wave's slot -- its low 32 bits and its high part as two separate 64-bit words, so no
+// carry has to travel (k = hi 2^32 + lo) -- and restarts the accumulators at their constants.  An accumulator that has left
+// its binade met a NaN or an infinity (or, never with the quanta of amc_xsum.h, too large a sum): the column is NaN.
+// All 64 lanes take part (wave shuffles; lane 0 updates the slot): a flush never sits inside divergent control flow.  (64 lanes
+// adding to one LDS address with atomics serialise: that form cost the fused time step 20 us per launch.)
 struct QSlot {
     unsigned long long lo, hi;          // hi: two's complement
     unsigned int flags, pad_;
@@ -524,25 +525,44 @@ __device__ __forceinline__ void q_slot_clear(QSlot& s) { s.lo = 0ull; s.hi = 0ul
 template <int NC>
 __device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)[NC], QSlot* slot)
 {
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    long long k[NC];
+    bool any_bad[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const uint64_t b = (uint64_t)__double_as_longlong(s[c]);
-        const long long k = (long long)(b - cbits[c]);
-        if (((b ^ cbits[c]) >> 52) != 0ull) atomicOr(&slot[c].flags, (unsigned int)xs::XS_F_NAN);
-        else if (k != 0) {
-            atomicAdd(&slot[c].lo, (unsigned long long)(k & 0xFFFFFFFFll));
-            atomicAdd(&slot[c].hi, (unsigned long long)(k >> 32));
-        }
+        const bool bad = ((b ^ cbits[c]) >> 52) != 0ull;
+        k[c] = bad ? 0ll : (long long)(b - cbits[c]);              // |k| < 2^51 per lane: 2^57 per wave
+        any_bad[c] = __builtin_amdgcn_ballot_w64(bad) != 0ull;
         s[c] = __longlong_as_double((long long)cbits[c]);
     }
+    // the columns share the shuffle steps: their crossbar latencies overlap
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        long long o[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = __shfl_down(k[c], off, 64);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) k[c] += o[c];
+    }
+    if (lane0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            slot[c].lo += (unsigned long long)(k[c] & 0xFFFFFFFFll);
+            slot[c].hi += (unsigned long long)(k[c] >> 32);
+            if (any_bad[c]) slot[c].flags |= (unsigned int)xs::XS_F_NAN;
+        }
+    }
 }
-// the same for a lane that holds the integer itself
+// the same for lanes that hold the integer itself (|k| < 2^62: low 32 bits and high part go through the wave separately); all
+// 64 lanes take part
 __device__ __forceinline__ void q_flush_int(unsigned long long& acc, QSlot* slot)
 {
     const long long k = (long long)acc;
-    if (k != 0) {
-        atomicAdd(&slot->lo, (unsigned long long)(k & 0xFFFFFFFFll));
-        atomicAdd(&slot->hi, (unsigned long long)(k >> 32));
+    const long long lo = wave_sum_i64(k & 0xFFFFFFFFll), hi = wave_sum_i64(k >> 32);
+    if ((threadIdx.x & 63) == 0) {
+        slot->lo += (unsigned long long)lo;
+        slot->hi += (unsigned long long)hi;
     }
     acc = 0ull;
 }
@@ -565,25 +585,29 @@ __device__ __forceinline__ xs::PartQ q_slot_value(const QSlot& s)
     return xs::PartQ{xs::i128_add(hs, xs::i128{(uint64_t)s.lo, 0}), s.flags};
 }
 
-// Kind R: the running-top accumulators of NC columns.  top[] and what derives from it (the two levels' constants, the bound)
-// are wave-uniform -- every assignment comes from a readfirstlane --; a1[] / a2[] are the lane's 64-bit sums of the BIT PATTERNS
-// of t = c1 + lsb1(v) and t2 = c2 + lsb1(r) (amc_xsum.h): n bits(c) + the sum of the multiples, n = summands since the last flush.
+// Kind R: the running-top accumulators of NC columns.  top[] is wave-uniform -- every assignment comes from a readfirstlane --;
+// a1[] / a2[] are the lane's 64-bit sums of the BIT PATTERNS of t = c1 + lsb1(v) and t2 = c2 + lsb1(r) (amc_xsum.h):
+// n bits(c) + the sum of the multiples, n[] = summands since the last flush.  The two levels' constants and the bound are
+// formed from top where they are used (a handful of scalar-unit integer operations): kept in registers across the sampling
+// loops they would be ten more SGPRs per column in kernels that have none to spare -- spilled to VGPR lanes and fetched back
+// with v_readlane, a vector-unit instruction, at every use (measured: +50 VALU instructions per trip).
 template <int NC>
 struct RLanes {
     unsigned long long a1[NC], a2[NC];
-    double c1[NC], c2[NC];
-    uint32_t cap_hi[NC];
     int top[NC];
     int n[NC];
 };
-
-template <int NC>
-__device__ __forceinline__ void r_set_level(RLanes<NC>& L, int c, int top)
+struct RLevel {
+    double c1, c2, cap;
+};
+__device__ __forceinline__ RLevel r_level(int top)
 {
-    L.top[c] = top;
-    L.c1[c] = __longlong_as_double((long long)xs::xs_level_c_bits(top));
-    L.c2[c] = __longlong_as_double((long long)xs::xs_level_c_bits(top - 1));
-    L.cap_hi[c] = xs::xs_level_cap_hi(top);
+    asm volatile("" : "+s"(top));          // not hoisted out of the caller's loop (see above)
+    RLevel v;
+    v.c1 = __longlong_as_double((long long)xs::xs_level_c_bits(top));
+    v.c2 = __longlong_as_double((long long)xs::xs_level_c_bits(top - 1));
+    v.cap = xs::xs_level_cap(top);
+    return v;
 }
 
 template <int NC>
@@ -592,31 +616,29 @@ __device__ __forceinline__ void r_init(RLanes<NC>& L, xs::PartR* slot)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         L.n[c] = 0;
-        r_set_level(L, c, xs::XS_LMIN);
+        L.top[c] = xs::XS_LMIN;
         L.a1[c] = L.a2[c] = 0ull;
         if ((threadIdx.x & 63) == 0) slot[c] = xs::part_r_empty();
     }
 }
 
-// The rare arm of r_deposit2: some lane holds a value the current top cannot take, or one that is not finite (or as good as).
+// The rare arm of r_deposit: some lane holds a value the current top cannot take, or one that is not finite (or as good as).
 template <int NC>
-__device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& a, double& b, xs::PartR* slot)
+__device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& v, xs::PartR* slot)
 {
     int need = xs::XS_LMIN;
     uint32_t fl = 0u;
-    auto look = [&](double& v) {
+    {
         const uint64_t bits = (uint64_t)__double_as_longlong(v);
         const bool nan = ((bits >> 52) & 0x7FFull) == 0x7FFull && (bits & 0xFFFFFFFFFFFFFull) != 0ull;
         const int l = xs::xs_level_of(v);                  // > LMAX for infinities, NaN and finite |v| >= 2^999
         if (l > xs::XS_LMAX) {
-            fl |= nan ? xs::XS_F_NAN : ((bits >> 63) ? xs::XS_F_NINF : xs::XS_F_PINF);
+            fl = nan ? xs::XS_F_NAN : ((bits >> 63) ? xs::XS_F_NINF : xs::XS_F_PINF);
             v = 0.0;                                       // the flags carry it
         } else {
-            need = l > need ? l : need;
+            need = l;
         }
-    };
-    look(a);
-    look(b);
+    }
     const bool lane0 = (threadIdx.x & 63) == 0;
     const uint32_t f_nan = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_NAN) != 0u) ? xs::XS_F_NAN : 0u;
     const uint32_t f_pinf = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_PINF) != 0u) ? xs::XS_F_PINF : 0u;
@@ -627,56 +649,72 @@ __device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& a, double& 
         // one level up the level-1 multiples ARE the new level-2 multiples; further up nothing of what was taken so far is
         // as large as half a quantum of the new lower level.  (n summands are on the books: n times the new constants' bits.)
         const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
-        const unsigned long long k1 = L.a1[c] - n * (unsigned long long)__double_as_longlong(L.c1[c]);
+        const unsigned long long k1 = L.a1[c] - n * xs::xs_level_c_bits(L.top[c]);
         const bool one_up = need - L.top[c] == 1;
-        r_set_level(L, c, need);
-        L.a1[c] = n * (unsigned long long)__double_as_longlong(L.c1[c]);
-        L.a2[c] = (one_up ? k1 : 0ull) + n * (unsigned long long)__double_as_longlong(L.c2[c]);
+        L.top[c] = need;
+        L.a1[c] = n * xs::xs_level_c_bits(need);
+        L.a2[c] = (one_up ? k1 : 0ull) + n * xs::xs_level_c_bits(need - 1);
         if (lane0) xs::part_r_raise(slot[c], need);
     }
 }
 
-// Two summands per lane (the two chains of a pair; pass 0.0 for a chain that does not exist).
+// One summand per lane (every lane of the wave is in the call: pass 0.0 where there is nothing to add).
 template <int NC>
-__device__ __forceinline__ void r_deposit2(RLanes<NC>& L, int c, double a, double b, xs::PartR* slot)
+__device__ __forceinline__ void r_deposit(RLanes<NC>& L, int c, double v, xs::PartR* slot)
 {
-    // |v| < 2^(50 top + 49) for both, tested on the high words of the bit patterns (NaN and infinities lie above every bound);
-    // the OR of the two words is at least their maximum: a conservative test, settled exactly in the rare arm
-    const uint32_t ha = (uint32_t)((uint64_t)__double_as_longlong(a) >> 32), hb = (uint32_t)((uint64_t)__double_as_longlong(b) >> 32);
-    if (__builtin_amdgcn_ballot_w64(((ha | hb) & 0x7FFFFFFFu) >= L.cap_hi[c]) != 0ull) r_slow(L, c, a, b, slot);
-    auto put = [&](double v) {
-        const double v1 = __longlong_as_double(__double_as_longlong(v) | 1ll);
-        const double t = L.c1[c] + v1;
-        const double r = v1 - (t - L.c1[c]);
-        const double t2 = L.c2[c] + __longlong_as_double(__double_as_longlong(r) | 1ll);
-        L.a1[c] += (unsigned long long)__double_as_longlong(t);
-        L.a2[c] += (unsigned long long)__double_as_longlong(t2);
-    };
-    put(a);
-    put(b);
-    L.n[c] += 2;
+    // |v| < 2^(50 top + 49) (NaN compares false: it takes the rare arm like infinities and finite values of 2^999 or more)
+    if (__builtin_amdgcn_ballot_w64(!(__builtin_fabs(v) < r_level(L.top[c]).cap)) != 0ull) r_slow(L, c, v, slot);
+    const RLevel lv = r_level(L.top[c]);
+    const double v1 = __longlong_as_double(__double_as_longlong(v) | 1ll);
+    const double t = lv.c1 + v1;
+    const double r = v1 - (t - lv.c1);
+    const double t2 = lv.c2 + __longlong_as_double(__double_as_longlong(r) | 1ll);
+    L.a1[c] += (unsigned long long)__double_as_longlong(t);
+    L.a2[c] += (unsigned long long)__double_as_longlong(t2);
+    L.n[c] += 1;
 }
 
 template <int NC>
 __device__ __forceinline__ void r_flush(RLanes<NC>& L, xs::PartR* slot)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
+    // per column: the two levels' multiples, |.| < n 2^49 < 2^63 (the 64-bit arithmetic modulo 2^64 holds them); a wave's 64 lanes
+    // need up to 6 more bits, so low 32 bits and high parts go through the shuffles separately -- the four of them in the same
+    // steps: their crossbar latencies overlap
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
-        // |sum of multiples| < n 2^49 < 2^63: the 64-bit arithmetic modulo 2^64 holds it
-        const long long k1 = (long long)(L.a1[c] - n * (unsigned long long)__double_as_longlong(L.c1[c]));
-        const long long k2 = (long long)(L.a2[c] - n * (unsigned long long)__double_as_longlong(L.c2[c]));
-        // a wave's 64 lanes: the sums need up to 6 more bits -- low 32 bits and high parts separately
-        const long long lo1 = wave_sum_i64(k1 & 0xFFFFFFFFll), hi1 = wave_sum_i64(k1 >> 32);
-        const long long lo2 = wave_sum_i64(k2 & 0xFFFFFFFFll), hi2 = wave_sum_i64(k2 >> 32);
-        if (lane0) {
-            const xs::i128 h1 = xs::i128_of(hi1), h2 = xs::i128_of(hi2);
-            slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_add(xs::i128_shl(h1, 32), xs::i128_of(lo1)));
-            slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_add(xs::i128_shl(h2, 32), xs::i128_of(lo2)));
-        }
+        const long long k1 = (long long)(L.a1[c] - n * xs::xs_level_c_bits(L.top[c]));
+        const long long k2 = (long long)(L.a2[c] - n * xs::xs_level_c_bits(L.top[c] - 1));
         L.a1[c] = L.a2[c] = 0ull;
         L.n[c] = 0;
+        if (n <= 128ull) {
+            // few summands (a launch over 1e7 chains gives a lane ~10): |k| < 2^56, the 64 lanes' sum fits 64 bits
+            long long v[2] = {k1, k2};
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const long long o0 = __shfl_down(v[0], off, 64), o1 = __shfl_down(v[1], off, 64);
+                v[0] += o0; v[1] += o1;
+            }
+            if (lane0) {
+                slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_of(v[0]));
+                slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_of(v[1]));
+            }
+        } else {
+            long long v[4] = {k1 & 0xFFFFFFFFll, k1 >> 32, k2 & 0xFFFFFFFFll, k2 >> 32};
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                long long o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = __shfl_down(v[i], off, 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += o[i];
+            }
+            if (lane0) {
+                slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_add(xs::i128_shl(xs::i128_of(v[1]), 32), xs::i128_of(v[0])));
+                slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_add(xs::i128_shl(xs::i128_of(v[3]), 32), xs::i128_of(v[2])));
+            }
+        }
     }
 }
 
@@ -703,6 +741,10 @@ __device__ __forceinline__ xs::PartQ q_block_total(const QSlot (*slots)[NC], int
 // The callback sums a REDUCE launch forms of the state it stores (callback_energy particle_1d.jl:68-70, the moments of
 // test/distribution_test.jl:36-37): kind-R columns sum e, sum x, sum x^2 -- with U = x^2 in Float64 sum x^2 IS sum e (the same
 // products), and the row's third column is a copy of the first.  Float64 sums whatever the state type.
+// A column's SUMMANDS are the chain PAIRS' sums (global chains 2p and 2p + 1, the pair a lane owns): fl(e_2p + e_2p+1),
+// fl(x_2p + x_2p+1), fl(fl(x_2p^2) + fl(x_2p+1^2)) -- one of the orders in which the reference's `mean` may add, fixed by the global
+// chain ids alone (shards begin at even ids), and half the work of taking the chains one by one (a lone last chain is
+// its own summand).
 enum { RED_COLS = 3, RED_ROW_COUNT = RED_COLS * XS_ROW_R, RED_ROW_SLOT = RED_ROW_COUNT + 1, RED_ROW_WORDS = RED_ROW_COUNT + 2 };
 template <int POT>
 struct RedCols {
@@ -716,9 +758,9 @@ __device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 
 {
     const double x0 = v0 ? (double)xv.x : 0.0, x1 = v1 ? (double)xv.y : 0.0;
     const double e0 = v0 ? (double)potential<POT>(xv.x, s_math) : 0.0, e1 = v1 ? (double)potential<POT>(xv.y, s_math) : 0.0;
-    r_deposit2(L, 0, e0, e1, slot);
-    r_deposit2(L, 1, x0, x1, slot);
-    if (!RedCols<POT>::X2_IS_E) r_deposit2(L, 2, x0 * x0, x1 * x1, slot);
+    r_deposit(L, 0, e0 + e1, slot);
+    r_deposit(L, 1, x0 + x1, slot);
+    if (!RedCols<POT>::X2_IS_E) r_deposit(L, 2, x0 * x0 + x1 * x1, slot);
 }
 
 // End of the launch: flush, then thread 0 writes the block's row (count = chains this block summed, as a double).
@@ -731,12 +773,16 @@ __device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::Part
     double cnt[1] = {count};
     double total[1];
     block_sum_store<1>(cnt, total);                 // ends in a barrier: the slots are visible to thread 0
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) xs_store_r_row(row + c * XS_ROW_R, r_block_total<NC>(slots, c));
-        if (RedCols<POT>::X2_IS_E) xs_store_r_row(row + 2 * XS_ROW_R, r_block_total<NC>(slots, 0));
-        row[RED_ROW_COUNT] = (xs_word)__double_as_longlong(total[0]);
+    // the row goes to pinned host memory: composed in LDS by thread 0, stored by ONE wave instruction (20 lanes, consecutive
+    // words: three 64-byte writes on the link instead of twenty 8-byte ones)
+    __shared__ xs_word s_row[RED_ROW_WORDS];
+    if (threadIdx.x < RED_COLS) {          // thread c: column c (sum x^2 = sum e where they are the same sums)
+        const int c = (RedCols<POT>::X2_IS_E && threadIdx.x == 2) ? 0 : (int)threadIdx.x;
+        xs_store_r_row(s_row + threadIdx.x * XS_ROW_R, r_block_total<NC>(slots, c));
+        if (threadIdx.x == 0) s_row[RED_ROW_COUNT] = (xs_word)__double_as_longlong(total[0]);
     }
+    __syncthreads();
+    if (threadIdx.x <= RED_ROW_COUNT) row[threadIdx.x] = s_row[threadIdx.x];
 }
 
 struct SweepArgs {
@@ -990,7 +1036,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         if (REDUCE) {
             red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
             red_pairs += 1;
-            if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
         }
         x_done = xv;
         lw_done = lw;
@@ -1281,7 +1326,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void fold_log_kernel(const uint8_t* log,
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             q_flush_int(ratio[k], &s_ratio[threadIdx.x >> 6][k]);
-            if (ratio_nan[k]) atomicOr(&s_ratio[threadIdx.x >> 6][k].flags, (unsigned int)xs::XS_F_NAN);
+            if (__builtin_amdgcn_ballot_w64(ratio_nan[k]) != 0ull && (threadIdx.x & 63) == 0)
+                s_ratio[threadIdx.x >> 6][k].flags |= (unsigned int)xs::XS_F_NAN;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1512,7 +1558,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
             unsigned long long r = 0ull;
             bool nan = false;
             int n_r = 0;
-            for (int64_t c = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; c < n_chains; c += stride) {
+            for (int64_t cw = (int64_t)blockIdx.x * AMC_BLOCK + (threadIdx.x & ~63); cw < n_chains; cw += stride) {
+                const int64_t c = cw + (threadIdx.x & 63);        // every lane of a wave takes the same trips (the flush is wave-wide)
+                if (++n_r == xs::XS_RATIO_LANE_CAP) { q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]); n_r = 0; }
+                if (c >= n_chains) continue;
                 const uint32_t a = acc[(int64_t)k * m_stride + c];
                 uint32_t n = (uint32_t)t_steps;
                 if (ratio_mode == 2) {
@@ -1526,10 +1575,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                     }
                 }
                 ratio_add(r, nan, a, n);      // Int/Int -> Float64 division; 0/0 = NaN like the reference
-                if (++n_r == xs::XS_RATIO_LANE_CAP) { q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]); n_r = 0; }
             }
             q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]);
-            if (nan) atomicOr(&s_ratio[threadIdx.x >> 6][0].flags, (unsigned int)xs::XS_F_NAN);
+            if (__builtin_amdgcn_ballot_w64(nan) != 0ull && (threadIdx.x & 63) == 0)
+                s_ratio[threadIdx.x >> 6][0].flags |= (unsigned int)xs::XS_F_NAN;
             __syncthreads();
             if (threadIdx.x == 0) {
                 // the block's total as low 32 bits + high part: two 64-bit atomics on the move's words (three with the NaN count)
@@ -1766,9 +1815,10 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
 // ACC (kind Q): g[] are the lane's four accumulators; the summands enter them with the last bit of j and of d logq / d sigma
 // set (lsb1, amc_xsum.h) -- grad j and g as EXACT products rounded once by the accumulator's fma.  !ACC (kind R: a
 // script-defined potential or reward): g[] receives the four summands, products rounded to Float64.
+// valid (ACC only; the ragged last trip): a lane without a chain goes through the motions and adds exact zeros.
 template <int POT, bool ACC>
 __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, double c3hi, double c3lo, double c1,
-                                          double z, double (&g)[4], const double* T)
+                                          double z, double (&g)[4], const double* T, bool valid = true)
 {
     const real_t delta = (real_t)__builtin_fma(sigma, z, 0.0);       // 0.0 + sigma*z, bit for bit (see propose)
     const real_t e1 = potential<POT>(x, T);
@@ -1796,8 +1846,10 @@ __device__ __forceinline__ void pg_sample(real_t& x, real_t beta, double sigma, 
     const double j = r * alpha;
     if (ACC) {
         // forward and backward gradients coincide for this policy (gradients.jl:106)
-        const double j1 = __longlong_as_double(__double_as_longlong(j) | 1ll);
-        const double d1 = __longlong_as_double(__double_as_longlong(dlogq) | 1ll);
+        double j1 = __longlong_as_double(__double_as_longlong(j) | 1ll);
+        double d1 = __longlong_as_double(__double_as_longlong(dlogq) | 1ll);
+        j1 = valid ? j1 : 0.0;                 // (folds away where valid is the literal true)
+        d1 = valid ? d1 : 0.0;
         g[0] += j1;
         g[1] = __builtin_fma(j1, d1, g[1]);
         g[2] += d1;
@@ -1849,11 +1901,8 @@ struct PgCol {
     xs::PartQ q;
     xs::PartR r;
     __device__ __forceinline__ void clear() { q = xs::PartQ{xs::i128{0, 0}, 0u}; r = xs::part_r_empty(); }
-    __device__ __forceinline__ void add_row(const xs_word* row)
+    __device__ __forceinline__ void add_row(const xs_word* w)        // a row in LDS (pg_sum_rows)
     {
-        xs_word w[Q ? XS_ROW_Q : XS_ROW_R];
-#pragma unroll
-        for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); ++i) w[i] = __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (Q) {
             const xs::PartQ b = xs_load_q_row(w);
             q.k = xs::i128_add(q.k, b.k);
@@ -1870,6 +1919,55 @@ struct PgCol {
         for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); ++i) __hip_atomic_store(row + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
+
+// Wave-wide total of the lanes' 128-bit integers (valid in lane 0).  The low word travels as two 32-bit limbs, the high word
+// whole (|v| < 2^120 here: 64 high words add without overflow); the three sums share the shuffle steps, so their LDS-crossbar
+// latencies overlap instead of queueing up behind each other (one reduction after the other: ~1.2 us per call on the tail).
+__device__ __forceinline__ xs::i128 wave_sum_i128(xs::i128 v)
+{
+    long long l0 = (long long)(v.lo & 0xFFFFFFFFull), l1 = (long long)(v.lo >> 32), l2 = (long long)v.hi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long a0 = __shfl_down(l0, off, 64), a1 = __shfl_down(l1, off, 64), a2 = __shfl_down(l2, off, 64);
+        l0 += a0; l1 += a1; l2 += a2;
+    }
+    xs::i128 r = xs::i128_add(xs::i128_of(l0), xs::i128_shl(xs::i128_of(l1), 32));
+    r.hi = (int64_t)((uint64_t)r.hi + (uint64_t)l2);
+    return r;
+}
+
+// Total of ONE column over n_rows <= 64 rows that OTHER blocks wrote (row r at rows + r stride_words): lane r of the calling
+// wave loads row r (agent-scope loads, all in flight together: one far-memory round trip) and the wave adds up -- integers: the
+// order is immaterial.  Valid in lane 0.  (A single thread walking 64 rows paid 64 dependent steps: 10 us per launch.)
+template <bool Q>
+__device__ __forceinline__ PgCol<Q> pg_col_total(const xs_word* rows, int n_rows, int64_t stride_words)
+{
+    constexpr int ROW = Q ? XS_ROW_Q : XS_ROW_R;
+    const int lane = threadIdx.x & 63;
+    const bool have = lane < n_rows;
+    xs_word w[ROW];
+#pragma unroll
+    for (int i = 0; i < ROW; ++i)
+        w[i] = have ? __hip_atomic_load(rows + (int64_t)lane * stride_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    PgCol<Q> col;
+    col.clear();
+    if (Q) {
+        const xs::PartQ p = xs_load_q_row(w);
+        col.q.k = wave_sum_i128(p.k);
+        col.q.flags = __builtin_amdgcn_ballot_w64(p.flags != 0u) != 0ull ? (uint32_t)xs::XS_F_NAN : 0u;
+    } else {
+        xs::PartR p = have ? xs_load_r_row(w) : xs::part_r_empty();
+        const int top = wave_max_i32(p.top);
+        xs::part_r_raise(p, top);                      // exact (amc_xsum.h)
+        col.r.top = top;
+        col.r.k1 = wave_sum_i128(p.k1);
+        col.r.k2 = wave_sum_i128(p.k2);
+        col.r.flags = (__builtin_amdgcn_ballot_w64((p.flags & xs::XS_F_NAN) != 0u) != 0ull ? (uint32_t)xs::XS_F_NAN : 0u) |
+                      (__builtin_amdgcn_ballot_w64((p.flags & xs::XS_F_PINF) != 0u) != 0ull ? (uint32_t)xs::XS_F_PINF : 0u) |
+                      (__builtin_amdgcn_ballot_w64((p.flags & xs::XS_F_NINF) != 0u) != 0ull ? (uint32_t)xs::XS_F_NINF : 0u);
+    }
+    return col;
+}
 
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
 // SWEEP != 0: the launch first performs ONE make_step!(::Metropolis) of sweepstep = 1 on the pair it has just loaded
@@ -1957,23 +2055,29 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     } else {
         r_init(gr, s_gr[threadIdx.x >> 6]);
     }
+    auto flush_move = [&](int l) {       // kind Q: the four accumulators of learnable move l
+        uint64_t cb[4];
+        q_constants(l, cb);
+        q_flush<4>(g[QK ? l : 0], cb, s_gq[threadIdx.x >> 6] + (QK ? l * 4 : 0));
+    };
     auto flush_gd = [&]() {
         if (QK) {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                if (l < a.n_learn) {
-                    uint64_t cb[4];
-                    q_constants(l, cb);
-                    q_flush<4>(g[QK ? l : 0], cb, s_gq[threadIdx.x >> 6] + (QK ? l * 4 : 0));
-                }
+                if (l < a.n_learn) flush_move(l);
         } else {
             r_flush(gr, s_gr[threadIdx.x >> 6]);
         }
     };
     // summands the lane has put into each GradientData accumulator since the last flush (two per sample: both chains)
     constexpr int GD_CAP = QK ? xs::XS_GD_LANE_CAP : xs::XS_LANE_CAP;
-    int dep = 0;
-
+    int dep[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) dep[l] = 0;
+    // A lane's accumulators take GD_CAP summands between two flushes.  Whether a launch needs a flush before its end at all is
+    // known at entry (trips per lane x samples per trip): the sampling loops exist in two copies, and the one the common case
+    // runs -- ~20 summands per lane at 1e7 chains -- has no flush code in it (sharing its loop with that code cost the launch
+    // 2.5 us: `mid_flush` below).
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
     // padded), the ragged last iteration peeled.
@@ -1993,7 +2097,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         c_sg[l] = c_hi[l] = c_lo[l] = c_c1[l] = 0.0;
         if (HOIST && l < a.n_learn) move_consts(l);
     }
-    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v0, bool v1) {
+    // Every lane of the wave is in every call (the flushes inside use wave-wide operations).  whole_trip: all 256 pairs of the
+    // trip exist; otherwise (the ragged last trip) v0 / v1 say which of the lane's two chains do, and the others add zeros.
+    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v0, bool v1, bool whole_trip, bool mid_flush) {
         (void)v0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -2001,7 +2107,11 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                 if (!HOIST) move_consts(l);
                 for (int q = 0; q < a.q_batch; ++q) {
                     // a lane's accumulators take GD_CAP summands between two flushes (at 1e7 chains a lane sees ~20 per launch)
-                    if (l == 0 && (dep += 2) > GD_CAP) { flush_gd(); dep = 2; }
+                    if (mid_flush && (dep[l] += 2) > GD_CAP) {
+                        if (QK) flush_move(l);
+                        else if (l == 0) r_flush(gr, s_gr[threadIdx.x >> 6]);       // all columns at once
+                        dep[l] = 2;
+                    }
                     double z0, z1;
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
                                                           STREAM_ESTIMATOR),
@@ -2017,17 +2127,28 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
 #endif
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r_deposit2(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s1[i], s_gr[threadIdx.x >> 6]);
+                    for (int i = 0; i < 4; ++i) {
+                        r_deposit(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
+                        r_deposit(gr, QK ? 0 : l * 4 + i, s1[i], s_gr[threadIdx.x >> 6]);
+                    }
 #else
                     if (QK) {
-                        pg_sample<POT, true>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[QK ? l : 0], s_math);
-                        if (v1) pg_sample<POT, true>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[QK ? l : 0], s_math);
+                        if (whole_trip) {
+                            pg_sample<POT, true>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[QK ? l : 0], s_math);
+                            pg_sample<POT, true>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[QK ? l : 0], s_math);
+                        } else {
+                            pg_sample<POT, true>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, g[QK ? l : 0], s_math, v0);
+                            pg_sample<POT, true>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, g[QK ? l : 0], s_math, v1);
+                        }
                     } else {
                         double s0[4], s1[4] = {0.0, 0.0, 0.0, 0.0};
                         pg_sample<POT, false>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, s0, s_math);
                         if (v1) pg_sample<POT, false>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, s1, s_math);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) r_deposit2(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s1[i], s_gr[threadIdx.x >> 6]);
+                        for (int i = 0; i < 4; ++i) {
+                        r_deposit(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
+                        r_deposit(gr, QK ? 0 : l * 4 + i, s1[i], s_gr[threadIdx.x >> 6]);
+                    }
                     }
 #endif
                 }
@@ -2044,44 +2165,47 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
-    real2 x_done = {(real_t)0.0, (real_t)0.0};
-    int64_t base_done = -1;
-    int64_t base = first;
-    for (; base + stride < n_pairs; base += stride) {        // full iterations
-        real2 xv = x_nxt;
-        const real_t b0 = b_nxt.x, b1 = b_nxt.y;
-        x_nxt = load_x(base + stride);
-        if (BETA) b_nxt = load_b(base + stride);
-        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-        if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
-        samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true);
-        if (REDUCE) {
-            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
-            red_pairs += 1;
-            if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
+    auto trips = [&](const bool mid_flush) {
+        real2 x_done = {(real_t)0.0, (real_t)0.0};
+        int64_t base_done = -1;
+        int64_t base = first;
+        for (; base + stride < n_pairs; base += stride) {        // full iterations
+            real2 xv = x_nxt;
+            const real_t b0 = b_nxt.x, b1 = b_nxt.y;
+            x_nxt = load_x(base + stride);
+            if (BETA) b_nxt = load_b(base + stride);
+            if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
+            if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
+            samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true, true, mid_flush);
+            if (REDUCE) {
+                red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
+                red_pairs += 1;
+            }
+            x_done = xv;
+            base_done = base;
         }
-        x_done = xv;
-        base_done = base;
-    }
-    if (base < n_pairs) {                                    // last, possibly ragged, iteration
-        const int64_t p = base + threadIdx.x;
-        const bool v0 = p < n_pairs;
-        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-        real2 xv = x_nxt;
-        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-        if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
-        if (QK) {
-            if (v0) samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)p, true, v1);
-        } else {
-            // kind R deposits are wave-wide (a raise of the running top is a wave-uniform decision): the lanes past the end
-            // go through the motions on a pair nobody stores and deposit zeros
-            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1);
+        if (base < n_pairs) {                                    // last, possibly ragged, iteration
+            const int64_t p = base + threadIdx.x;
+            const bool v0 = p < n_pairs;
+            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+            real2 xv = x_nxt;
+            if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
+            if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
+            // flushes and kind-R deposits are wave-wide (a raise of the running top is a wave-uniform decision): the lanes past the
+            // end go through the motions on a pair nobody stores and add zeros
+            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1, false, mid_flush);
+            if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
+            if (REDUCE) {
+                red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
+                red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
+            }
         }
-        if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
-        if (REDUCE) {
-            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
-            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
-        }
+    };
+    {
+        // summands one accumulator takes in this launch: trips of this lane x two chains x q_batch samples (block-uniform)
+        const int64_t my_trips = first < n_pairs ? (n_pairs - first + stride - 1) / stride : 0;
+        if (my_trips * 2 * (int64_t)a.q_batch <= (int64_t)GD_CAP) trips(false);
+        else trips(true);
     }
     if (REDUCE)          // full trips: two chains per lane each
         red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
@@ -2105,6 +2229,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     if (a.tail_mode == 0) return;
     const PgTail* const tl = a.tail;       // loaded here, not at kernel entry (see PgArgs)
+    // the pointers the tail works through, fetched together NOW (one far-memory round trip, under the wait for the row's stores)
+    // instead of one dependent load at each first use between the tickets
+    uint32_t* const tickets = tl->tickets;
+    xs_word* const group_sums = tl->group_sums;
+    double* const tail_out = tl->out;
+    const int tail_rank = tl->rank, tail_ranks = tl->n_ranks;
+    asm volatile("" ::"v"(tickets), "v"(group_sums), "v"(tail_out), "v"(tail_rank), "v"(tail_ranks));
 
     // In-kernel final reduction, two levels of "the last one to arrive sums": the last block of each group of
     // PG_GROUP consecutive blocks adds the group's rows, the last group to finish adds the group sums -- integer additions
@@ -2117,51 +2248,50 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const int n_groups = (gridDim.x + PG_GROUP - 1) / PG_GROUP;
     const int r0 = grp * PG_GROUP;
     const int n_rows = ((int)gridDim.x - r0 < PG_GROUP) ? (int)gridDim.x - r0 : PG_GROUP;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row's stores belong to wave 0 (NV <= 32)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(tl->tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t prev = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_rows - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (s_role != 1) return;
     const int nv = a.n_learn * 4;
-    if ((int)threadIdx.x < nv) {
-        PgCol<QK> col;
-        col.clear();
-        for (int r = 0; r < n_rows; ++r) col.add_row(a.partials + ((int64_t)(r0 + r) * NV + threadIdx.x) * ROW);
-        col.store_row(tl->group_sums + ((int64_t)grp * NV + threadIdx.x) * ROW);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int wave = threadIdx.x >> 6;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    // wave w adds up columns w, w + 4, ...: lanes = the group's rows (PG_GROUP = 64 of them at most)
+    for (int c = wave; c < nv; c += AMC_BLOCK / 64) {
+        const PgCol<QK> col = pg_col_total<QK>(a.partials + ((int64_t)r0 * NV + c) * ROW, n_rows, (int64_t)NV * ROW);
+        if (lane0) col.store_row(group_sums + ((int64_t)grp * NV + c) * ROW);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(tl->tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        const uint32_t prev = __hip_atomic_fetch_add(tl->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const uint32_t prev = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_groups - 1u) ? 2 : 0;
     }
     __syncthreads();
     if (s_role != 2) return;
-    if ((int)threadIdx.x < nv) {
-        PgCol<QK> col;
-        col.clear();
-        for (int gI = 0; gI < n_groups; ++gI) col.add_row(tl->group_sums + ((int64_t)gI * NV + threadIdx.x) * ROW);
-        const int l = (int)threadIdx.x >> 2, i = (int)threadIdx.x & 3;
-        const int e = QK ? xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i] : 0;
-        if (a.tail_mode == 1) {
+    for (int c = wave; c < nv; c += AMC_BLOCK / 64) {          // lanes = the groups (at most 64: the host caps the grid)
+        const int l = c >> 2, i = c & 3;
+        const int e = QK ? xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i] : 0;   // (its load ahead of the rows')
+        const PgCol<QK> col = pg_col_total<QK>(group_sums + (int64_t)c * ROW, n_groups, (int64_t)NV * ROW);
+        if (lane0 && a.tail_mode == 1) {
             // records: this shard's slot filled, the other shards' slots zeroed (the all-reduce that follows is a gather)
-            for (int r = 0; r < tl->n_ranks; ++r) {
-                double* rec = tl->out + ((size_t)r * nv + threadIdx.x) * xs::XS_WORDS;
-                if (r != tl->rank) xs::rec_clear(rec);
+            for (int r = 0; r < tail_ranks; ++r) {
+                double* rec = tail_out + ((size_t)r * nv + c) * xs::XS_WORDS;
+                if (r != tail_rank) xs::rec_clear(rec);
                 else if (QK) xs::rec_from_q(rec, col.q, e);
                 else xs::rec_from_r(rec, col.r);
             }
-        } else {
-            s_tot[threadIdx.x] = QK ? xs::part_q_round(col.q, e) : xs::part_r_round(col.r);
+        } else if (lane0) {
+            s_tot[c] = QK ? xs::part_q_round(col.q, e) : xs::part_r_round(col.r);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(tl->tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (loading what the update reads BEFORE the last ticket, in every block that might draw it, was measured: slower,
         // 62.4 against 61.4 us per fused time step -- the loads sit on the path from the group sums to the ticket)
         if (a.tail_mode >= 3)

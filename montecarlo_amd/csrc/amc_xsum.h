@@ -98,13 +98,7 @@ AMC_XS_HD double i128_round_scaled(i128 K, int e)
         return negative ? -v : v;
     }
     // position of the leading bit
-    int p = 0;
-    {
-        uint64_t t = hi ? hi : lo;
-        int b = 0;
-        while (t >>= 1) ++b;
-        p = hi ? 64 + b : b;
-    }
+    const int p = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
     const int s = p - 52;                                    // bits to drop, >= 1
     // mant = |K| >> s (53 bits), rem = dropped bits compared with half
     uint64_t mant, half_bit, below;
@@ -141,11 +135,10 @@ AMC_XS_HD uint64_t xs_double_bits(double d)
 // 1.5 * 2^(e + 52): the accumulator whose ulp is 2^e
 AMC_XS_HD uint64_t xs_c_bits(int e) { return ((uint64_t)(e + 52 + 1023) << 52) | (1ull << 51); }
 AMC_XS_HD double xs_c(int e) { return xs_bits_double(xs_c_bits(e)); }
-// level l of a running-top column: the accumulator constant, and the high 32 bits of the bound 2^(50 l + 49) its summands stay
-// below (a power of two: |v| is below it exactly when the high word of |v|'s bit pattern is below this one -- NaN, infinities
-// and finite values of 2^999 or more lie at or above the last level's)
+// level l of a running-top column: the accumulator constant, and the bound 2^(50 l + 49) its summands stay below (2^999 for the
+// last level: infinities, NaN -- which compares false -- and finite values of 2^999 or more lie beyond every level)
 AMC_XS_HD uint64_t xs_level_c_bits(int l) { return xs_c_bits(XS_W * l); }
-AMC_XS_HD uint32_t xs_level_cap_hi(int l) { return (uint32_t)(XS_W * l + XS_B + 1023) << 20; }
+AMC_XS_HD double xs_level_cap(int l) { return xs_bits_double((uint64_t)(XS_W * l + XS_B + 1023) << 52); }
 // the level a finite value needs: max(LMIN, floor((ilogb(v) + 1) / 50)), which exceeds LMAX for |v| >= 2^999; zero and subnormals: LMIN
 AMC_XS_HD int xs_level_of(double v)
 {

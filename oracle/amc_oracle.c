@@ -1020,17 +1020,27 @@ void amo_gd_exponents(double sigma, int e[4])
     e[3] = 15 - 2 * es - 46;
 }
 
+/* The summands of the three sums over the state: the chain PAIRS' sums -- global chains 2p and 2p + 1 (shards begin at even
+ * ids, so a pair never straddles two of them), a lone last chain by itself: fl(e_2p + e_2p+1), fl(x_2p + x_2p+1),
+ * fl(fl(x_2p^2) + fl(x_2p+1^2)).  One of the orders in which the reference's `mean` may add, fixed by the chain ids alone. */
+static void state_sums(const amo_sim *s, xs_t *se, xs_t *sx, xs_t *sxx)
+{
+    for (int64_t c = 0; c < s->M; c += 2) {
+        const int two = c + 1 < s->M;
+        const double x0 = s->chains[c].x, x1 = two ? s->chains[c + 1].x : 0.0;
+        const double e0 = s->chains[c].e, e1 = two ? s->chains[c + 1].e : 0.0;
+        if (se) xs_r_add(se, e0 + e1);
+        if (sx) xs_r_add(sx, x0 + x1);
+        if (sxx) xs_r_add(sxx, x0 * x0 + x1 * x1);
+    }
+}
+
 /* The callbacks' sums over this simulation's chains as records, in the layout of amc_reduce: sum e, sum x, sum x^2 (kind R),
  * the count (plain), per move sum_c accepted_c / total_c (kind Q, quantum 2^-50; 0/0 = NaN like the reference). */
 void amo_callback_records(const amo_sim *s, double *recs)
 {
     xs_t se = xs_new(XS_R, 0), sx = xs_new(XS_R, 0), sxx = xs_new(XS_R, 0), cnt = xs_new(XS_PLAIN, 0);
-    for (int64_t c = 0; c < s->M; ++c) {
-        double x = s->chains[c].x;
-        xs_r_add(&se, s->chains[c].e);
-        xs_r_add(&sx, x);
-        xs_r_add(&sxx, x * x);
-    }
+    state_sums(s, &se, &sx, &sxx);
     cnt.plain = (double)s->M;
     xs_to_record(&se, recs);
     xs_to_record(&sx, recs + XS_WORDS);
@@ -1050,7 +1060,7 @@ void amo_callback_records(const amo_sim *s, double *recs)
 double amo_callback_energy(const amo_sim *s)
 {
     xs_t se = xs_new(XS_R, 0);
-    for (int64_t c = 0; c < s->M; ++c) xs_r_add(&se, s->chains[c].e);
+    state_sums(s, &se, 0, 0);
     return xs_value(&se) / (double)s->M;
 }
 /* ... and as a left-to-right Float64 sum, one of the orders the reference's `mean` may take */
@@ -1090,11 +1100,7 @@ void amo_callback_acceptance_plain(const amo_sim *s, double *out)
 void amo_moments(const amo_sim *s, double out[2])
 {
     xs_t sx = xs_new(XS_R, 0), sxx = xs_new(XS_R, 0);
-    for (int64_t c = 0; c < s->M; ++c) {
-        double x = s->chains[c].x;
-        xs_r_add(&sx, x);
-        xs_r_add(&sxx, x * x);
-    }
+    state_sums(s, 0, &sx, &sxx);
     out[0] = xs_value(&sx); out[1] = xs_value(&sxx);
 }
 
