@@ -137,7 +137,7 @@ struct amc_handle {
     unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
     unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
     int n_slots = 0;
-    amc::xs_word* d_partials = nullptr;   // [red_blocks][PG_MAX_COLS][XS_ROW_R]: block rows of the estimator's fold
+    amc::xs_word* d_partials = nullptr;   // [groups][nl * 4][PG_GROUP][words per column]: block rows of the estimator's fold
     RedTicket red[RED_TICKETS];      // reductions in flight, oldest first from red_head
     int red_head = 0, red_count = 0;
     double* d_out = nullptr;    // records of the estimator's fold: [comm ranks][PG_MAX_COLS][XS_WORDS]
@@ -166,7 +166,7 @@ struct amc_handle {
     double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
-    amc::xs_word* d_pg_groups = nullptr;   // [groups][PG_MAX_COLS][XS_ROW_R]
+    amc::xs_word* d_pg_groups = nullptr;   // [nl * 4][PG_GROUP][words per column]: group rows
     amc::PgTail* d_pg_tail = nullptr;   // the estimator kernel's per-configuration record (see amc::PgTail)
     amc::PgTail pg_tail_host;           // ... and what it holds now (rewritten only when it changes)
     bool pg_tail_valid = false;
@@ -400,23 +400,33 @@ int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
     return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
 }
 
-template <int POT, int NL, int SWEEP, bool REDUCE = false>
+template <int POT, int NL, int SWEEP, bool REDUCE = false, bool MID = false>
 int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid)
 {
     if (h->beta_arr)
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP, REDUCE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP, REDUCE, MID>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     else
-        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false, SWEEP, REDUCE>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
+        hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, false, SWEEP, REDUCE, MID>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     AMC_HIP(hipGetLastError());
     return AMC_OK;
 }
 
 // sweep: 0 = estimator only; 1 / 2 / 3 = preceded by one make_step!(::Metropolis) in the same launch (K == 1 with the step
-// log / K > 1 / K == 1 with the pool-wide counter; offered for up to 2 learnable moves, see pg_fusable)
+// log / K > 1 / K == 1 with the pool-wide counter; offered for up to 2 learnable moves, see `fused` in pgmc_steps_impl)
 // reduce (sweep != 0): the launch also leaves the callback sums of the state it stores (pg_estimate_kernel<.., REDUCE>)
+// mid (sweep == 0): a lane's GradientData accumulators do not take the whole launch -- the kernel form that flushes as it goes
 template <int POT>
-int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce)
+int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
+    if (mid && sweep != 0) return fail(AMC_ERR_STATE, "launch_pg: a fused time step that needs a flush mid-launch (see pg_fits_without_flush)");
+    if (mid) {
+        switch (nl_cap) {
+        case 1: return launch_pg_nls<POT, 1, 0, false, true>(h, a, sw, grid);
+        case 2: return launch_pg_nls<POT, 2, 0, false, true>(h, a, sw, grid);
+        case 4: return launch_pg_nls<POT, 4, 0, false, true>(h, a, sw, grid);
+        default: return launch_pg_nls<POT, 8, 0, false, true>(h, a, sw, grid);
+        }
+    }
     if (reduce) {
         if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, true>(h, a, sw, grid);
         if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, true>(h, a, sw, grid);
@@ -707,10 +717,11 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
     return rtc_launch(h, inst, grid, params);
 }
 
-int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce)
+int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
+    if (mid && sweep != 0) return fail(AMC_ERR_STATE, "launch_pg_custom: a fused time step that needs a flush mid-launch");
     const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
-                             std::to_string(sweep) + "," + tf(reduce) + ">";
+                             std::to_string(sweep) + "," + tf(reduce) + "," + tf(mid) + ">";
     void* params[] = {&a, &sw};
     return rtc_launch(h, inst, grid, params);
 }
@@ -949,7 +960,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMalloc(&h->d_acc_slots, (size_t)h->n_slots * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
     h->red_blocks = grid_for(h, h->M);
-    AMC_TRY(hipMalloc(&h->d_partials, (size_t)h->red_blocks * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));
+    AMC_TRY(hipMalloc(&h->d_partials, (size_t)(h->red_blocks + amc::PG_GROUP) * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));   // whole groups
     for (int i = 0; i < RED_TICKETS; ++i) {
         RedTicket& t = h->red[i];
         AMC_TRY(hipHostMalloc((void**)&t.h_rows, (size_t)h->n_slots * RED_HOST_STRIDE * sizeof(amc::xs_word), 0));
@@ -968,7 +979,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         const size_t groups = (size_t)(h->n_slots + amc::PG_GROUP - 1) / amc::PG_GROUP + 1;
         AMC_TRY(hipMalloc(&h->d_pg_tickets, (groups + 1) * sizeof(uint32_t)));
         AMC_TRY(hipMemsetAsync(h->d_pg_tickets, 0, (groups + 1) * sizeof(uint32_t), h->stream));
-        AMC_TRY(hipMalloc(&h->d_pg_groups, groups * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));
+        AMC_TRY(hipMalloc(&h->d_pg_groups, (size_t)amc::PG_GROUP * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));   // at most PG_GROUP groups
         AMC_TRY(hipMalloc(&h->d_pg_tail, sizeof(amc::PgTail)));
     }
     AMC_TRY(hipEventCreate(&h->ev0));
@@ -1876,10 +1887,30 @@ int amc_parameters_end(amc_handle* h, double* sigma)
     return AMC_OK;
 }
 
+// The estimator's grid over this shard.
+static int pg_grid(const amc_handle* h)
+{
+    int grid = grid_for(h, (h->M + 1) / 2);
+    if (grid > h->red_blocks) grid = h->red_blocks;
+    return grid > amc::PG_GROUP * amc::PG_GROUP ? amc::PG_GROUP * amc::PG_GROUP : grid;      // two levels of PG_GROUP in the kernel's tail
+}
+
+// An estimator launch puts 2 q_batch summands per trip into each of a lane's GradientData accumulators, which hold XS_GD_LANE_CAP
+// (kind Q: the built-in potentials) or XS_LANE_CAP (kind R: hiprtc forms) of them between two flushes (amc_xsum.h).  Launches
+// whose lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH);
+// the fused time step exists in that form only.
+static bool pg_fits_without_flush(const amc_handle* h, int q_batch)
+{
+    const int64_t pairs = (h->M + 1) / 2;
+    const int64_t lanes = (int64_t)pg_grid(h) * AMC_BLOCK;
+    const int64_t cap = h->use_rtc ? amc::xs::XS_LANE_CAP : amc::xs::XS_GD_LANE_CAP;
+    return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap;
+}
+
 // Validates, launches K3 over this shard.  Shared by the host- and device-resident estimator paths.
 // tail: 1 = the totals of (j, grad j, grad logq, g) per learnable move as records in h->d_out (this shard's slot), 2 = instead
 // gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
-// with_sweep: the launch first does one make_step!(::Metropolis) (caller checked pg_fusable).
+// with_sweep: the launch first does one make_step!(::Metropolis) (caller decided: `fused` in pgmc_steps_impl).
 // reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in the next reduction ticket's rows.
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false, bool reduce = false,
@@ -1902,7 +1933,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.x = h->d_x;
     a.beta_arr = h->beta_arr ? h->d_beta : nullptr;
     a.ptab = h->d_ptab;
-    a.partials = h->d_partials;          // [grid][nl * 4][words per column] (amc::PgKind)
+    a.partials = h->d_partials;          // [groups][nl * 4][PG_GROUP][words per column] (amc::PgKind)
     a.n_chains = h->M;
     a.pair0 = (uint64_t)h->offset >> 1;
     a.t_est = h->t_est;
@@ -1938,8 +1969,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         a.tail = h->d_pg_tail;
     }
     const int nl = nl_capacity(n_learn);
-    int grid = grid_for(h, (h->M + 1) / 2);
-    if (grid > h->red_blocks) grid = h->red_blocks;
+    const int grid = pg_grid(h);
+    const bool mid = !pg_fits_without_flush(h, q_batch);
     int sweep = 0;
     if (with_sweep) {
         { const int rcc = counter_room(h, who, 1); if (rcc != AMC_OK) return rcc; }
@@ -1949,9 +1980,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     if (grid_out) *grid_out = grid;
     amc::SweepArgs sw = make_sweep_args(h, 1);
     const bool red = reduce && with_sweep;
-    const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep, red)
-                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep, red)
-                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep, red);
+    const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep, red, mid)
+                   : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep, red, mid)
+                                                                 : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep, red, mid);
     if (rc != AMC_OK) return rc;
     if (with_sweep) {
         h->t += 1;
@@ -2107,7 +2138,8 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
     const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
-                       log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+                       log_form(h) != AMC_LOG_BYTES && pg_fits_without_flush(h, q_batch) &&
+                       std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
     const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h);
     int grid = 0;

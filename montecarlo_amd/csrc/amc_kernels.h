@@ -464,11 +464,49 @@ typedef unsigned long long xs_word;
 enum { XS_ROW_Q = 2, XS_ROW_R = 6 };      // words per column of a block row: (lo, hi) / (top | flags << 32, k1.lo, k1.hi, k2.lo, k2.hi, 0)
 #define AMC_XS_POISON_HI ((long long)0x8000000000000000ull)   // kind-Q row whose sum is NaN: hi = INT64_MIN, lo = 0
 
+// Wave-wide totals of N 64-bit integers per lane, valid in EVERY lane afterwards.  Data-parallel-primitive moves instead of
+// __shfl_down: a shuffle of a 64-bit value is two ds_bpermute_b32 through the LDS crossbar (~100 cycles each way, six rounds),
+// a DPP move is a vector-unit instruction.  Rounds: row_shr 1, 2, 4, 8 inside the rows of 16 lanes (lanes without a source
+// add 0), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15), then lane 31 into rows 2 and 3 (row_bcast31): lane 63
+// holds the total, read back through the scalar unit.  The N values share the rounds (independent instructions back to back).
+// (On the estimator kernel's tail and flushes: 1.1 us per launch of the 8 us the tail took with shuffles.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_move_i64(long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)v, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+template <int N, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_round_i64(long long (&v)[N])
+{
+    long long o[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = dpp_move_i64<CTRL, ROW_MASK>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += o[i];
+}
+template <int N>
+__device__ __forceinline__ void wave_total_i64(long long (&v)[N])
+{
+    dpp_round_i64<N, 0x111, 0xF>(v);      // row_shr:1
+    dpp_round_i64<N, 0x112, 0xF>(v);      // row_shr:2
+    dpp_round_i64<N, 0x114, 0xF>(v);      // row_shr:4
+    dpp_round_i64<N, 0x118, 0xF>(v);      // row_shr:8
+    dpp_round_i64<N, 0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    dpp_round_i64<N, 0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v[i], 63);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v[i] >> 32), 63);
+        v[i] = (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+    }
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;                                  // valid in lane 0
+    long long a[1] = {v};
+    wave_total_i64<1>(a);
+    return a[0];                               // valid in every lane
 }
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -536,15 +574,7 @@ __device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)
         any_bad[c] = __builtin_amdgcn_ballot_w64(bad) != 0ull;
         s[c] = __longlong_as_double((long long)cbits[c]);
     }
-    // the columns share the shuffle steps: their crossbar latencies overlap
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        long long o[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) o[c] = __shfl_down(k[c], off, 64);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) k[c] += o[c];
-    }
+    wave_total_i64<NC>(k);                 // the columns share the rounds
     if (lane0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -691,25 +721,14 @@ __device__ __forceinline__ void r_flush(RLanes<NC>& L, xs::PartR* slot)
         if (n <= 128ull) {
             // few summands (a launch over 1e7 chains gives a lane ~10): |k| < 2^56, the 64 lanes' sum fits 64 bits
             long long v[2] = {k1, k2};
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const long long o0 = __shfl_down(v[0], off, 64), o1 = __shfl_down(v[1], off, 64);
-                v[0] += o0; v[1] += o1;
-            }
+            wave_total_i64<2>(v);
             if (lane0) {
                 slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_of(v[0]));
                 slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_of(v[1]));
             }
         } else {
             long long v[4] = {k1 & 0xFFFFFFFFll, k1 >> 32, k2 & 0xFFFFFFFFll, k2 >> 32};
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                long long o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = __shfl_down(v[i], off, 64);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += o[i];
-            }
+            wave_total_i64<4>(v);
             if (lane0) {
                 slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_add(xs::i128_shl(xs::i128_of(v[1]), 32), xs::i128_of(v[0])));
                 slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_add(xs::i128_shl(xs::i128_of(v[3]), 32), xs::i128_of(v[2])));
@@ -1651,7 +1670,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void counter_totals_kernel(const CT* acc
 // struct used to have cost the fused sweep + estimator kernel ~70 v_readlane / v_writelane spill instructions per loop trip.
 struct PgTail {
     uint32_t* tickets;            // [1 + n_groups], zero between launches
-    xs_word* group_sums;          // [n_groups][NL*4][words per column]
+    xs_word* group_sums;          // [NL*4][PG_GROUP][words per column]
     double* out;                  // tail_mode 1: records [n_ranks][NL*4][XS_WORDS], this shard's slot filled, the others zeroed
     double* gd_acc;               // [AMC_MAX_MOVES][5]
     double* ptab_rw;              // == ptab (written by the update)
@@ -1668,7 +1687,7 @@ struct PgArgs {
     real_t* x;
     const real_t* beta_arr;
     const double* ptab;
-    xs_word* partials;            // [grid][NL*4][words per column]: block rows (pg_row_words)
+    xs_word* partials;            // [groups of PG_GROUP blocks][NL*4][PG_GROUP][words per column]: block rows
     const PgTail* tail;           // device memory
     int64_t n_chains;
     uint64_t pair0;
@@ -1915,24 +1934,24 @@ struct PgCol {
     {
         xs_word w[Q ? XS_ROW_Q : XS_ROW_R];
         if (Q) xs_store_q_row(w, q); else xs_store_r_row(w, r);
+        // agent scope (sc1: aux 16), 16 bytes per instruction -- rows are 16-byte aligned
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); ++i) __hip_atomic_store(row + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < (Q ? XS_ROW_Q : XS_ROW_R); i += 2) {
+            const u32v4_t v = {(uint32_t)w[i], (uint32_t)(w[i] >> 32), (uint32_t)w[i + 1], (uint32_t)(w[i + 1] >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, i * 8, 0, 16);
+        }
     }
 };
 
-// Wave-wide total of the lanes' 128-bit integers (valid in lane 0).  The low word travels as two 32-bit limbs, the high word
-// whole (|v| < 2^120 here: 64 high words add without overflow); the three sums share the shuffle steps, so their LDS-crossbar
-// latencies overlap instead of queueing up behind each other (one reduction after the other: ~1.2 us per call on the tail).
+// Wave-wide total of the lanes' 128-bit integers (valid in every lane).  The low word travels as two 32-bit limbs, the high
+// word whole (|v| < 2^120 here: 64 high words add without overflow); the three sums share the rounds of wave_total_i64.
 __device__ __forceinline__ xs::i128 wave_sum_i128(xs::i128 v)
 {
-    long long l0 = (long long)(v.lo & 0xFFFFFFFFull), l1 = (long long)(v.lo >> 32), l2 = (long long)v.hi;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long a0 = __shfl_down(l0, off, 64), a1 = __shfl_down(l1, off, 64), a2 = __shfl_down(l2, off, 64);
-        l0 += a0; l1 += a1; l2 += a2;
-    }
-    xs::i128 r = xs::i128_add(xs::i128_of(l0), xs::i128_shl(xs::i128_of(l1), 32));
-    r.hi = (int64_t)((uint64_t)r.hi + (uint64_t)l2);
+    long long l[3] = {(long long)(v.lo & 0xFFFFFFFFull), (long long)(v.lo >> 32), (long long)v.hi};
+    wave_total_i64<3>(l);
+    xs::i128 r = xs::i128_add(xs::i128_of(l[0]), xs::i128_shl(xs::i128_of(l[1]), 32));
+    r.hi = (int64_t)((uint64_t)r.hi + (uint64_t)l[2]);
     return r;
 }
 
@@ -1946,9 +1965,17 @@ __device__ __forceinline__ PgCol<Q> pg_col_total(const xs_word* rows, int n_rows
     const int lane = threadIdx.x & 63;
     const bool have = lane < n_rows;
     xs_word w[ROW];
+    {
+        // agent scope (sc1: aux 16), 16 bytes per instruction, no branch around the loads: the lanes past the last row read row 0
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, 0x7fffffff, 0x00020000);
+        const int off = (have ? lane : 0) * (int)stride_words * 8;
 #pragma unroll
-    for (int i = 0; i < ROW; ++i)
-        w[i] = have ? __hip_atomic_load(rows + (int64_t)lane * stride_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int i = 0; i < ROW; i += 2) {
+            const u32v4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + i * 8, 0, 16);
+            w[i] = have ? (((xs_word)v.y << 32) | v.x) : 0ull;
+            w[i + 1] = have ? (((xs_word)v.w << 32) | v.z) : 0ull;
+        }
+    }
     PgCol<Q> col;
     col.clear();
     if (Q) {
@@ -1980,10 +2007,11 @@ __device__ __forceinline__ PgCol<Q> pg_col_total(const xs_word* rows, int n_rows
 // accepted total) of the state it stores -- AFTER the estimator's samples, which is what a callback scheduled at the same t
 // observes (run! calls Metropolis, estimator, update, then the callbacks: src/simulation.jl:185-190) -- as one row per block in
 // sw.red_partials, like sweep_kernel<.., REDUCE>: a callback after a fused time step needs no pass over x.
-template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false>
+template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false, bool MIDFLUSH = false>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
+    static_assert(!MIDFLUSH || SWEEP == 0, "a fused time step is launched only when its lanes stay within one accumulator capacity");
     constexpr bool QK = PgKind<POT>::Q;
     constexpr int ROW = PgKind<POT>::ROW;
     constexpr int NV = NL * 4;
@@ -2075,9 +2103,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 #pragma unroll
     for (int l = 0; l < NL; ++l) dep[l] = 0;
     // A lane's accumulators take GD_CAP summands between two flushes.  Whether a launch needs a flush before its end at all is
-    // known at entry (trips per lane x samples per trip): the sampling loops exist in two copies, and the one the common case
-    // runs -- ~20 summands per lane at 1e7 chains -- has no flush code in it (sharing its loop with that code cost the launch
-    // 2.5 us: `mid_flush` below).
+    // known to the host (trips per lane x samples per trip: pg_fits_without_flush, amc_api.hip), and the launches that do are
+    // a different instantiation (MIDFLUSH): flush code inside the sampling loop costs the loop ~20 VGPRs -- a wave per SIMD --
+    // even where it never runs (107 against 86 VGPRs; 2.5 us per launch at 1e7 chains, where a lane sees ~20 summands).
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
     // padded), the ragged last iteration peeled.
@@ -2099,7 +2127,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     // Every lane of the wave is in every call (the flushes inside use wave-wide operations).  whole_trip: all 256 pairs of the
     // trip exist; otherwise (the ragged last trip) v0 / v1 say which of the lane's two chains do, and the others add zeros.
-    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v0, bool v1, bool whole_trip, bool mid_flush) {
+    auto samples = [&](real2& xv, real_t b0, real_t b1, uint64_t pair, bool v0, bool v1, bool whole_trip) {
         (void)v0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -2107,7 +2135,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                 if (!HOIST) move_consts(l);
                 for (int q = 0; q < a.q_batch; ++q) {
                     // a lane's accumulators take GD_CAP summands between two flushes (at 1e7 chains a lane sees ~20 per launch)
-                    if (mid_flush && (dep[l] += 2) > GD_CAP) {
+                    if (MIDFLUSH && (dep[l] += 2) > GD_CAP) {
                         if (QK) flush_move(l);
                         else if (l == 0) r_flush(gr, s_gr[threadIdx.x >> 6]);       // all columns at once
                         dep[l] = 2;
@@ -2165,47 +2193,39 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
-    auto trips = [&](const bool mid_flush) {
-        real2 x_done = {(real_t)0.0, (real_t)0.0};
-        int64_t base_done = -1;
-        int64_t base = first;
-        for (; base + stride < n_pairs; base += stride) {        // full iterations
-            real2 xv = x_nxt;
-            const real_t b0 = b_nxt.x, b1 = b_nxt.y;
-            x_nxt = load_x(base + stride);
-            if (BETA) b_nxt = load_b(base + stride);
-            if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-            if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
-            samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true, true, mid_flush);
-            if (REDUCE) {
-                red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
-                red_pairs += 1;
-            }
-            x_done = xv;
-            base_done = base;
+    real2 x_done = {(real_t)0.0, (real_t)0.0};
+    int64_t base_done = -1;
+    int64_t base = first;
+    for (; base + stride < n_pairs; base += stride) {        // full iterations
+        real2 xv = x_nxt;
+        const real_t b0 = b_nxt.x, b1 = b_nxt.y;
+        x_nxt = load_x(base + stride);
+        if (BETA) b_nxt = load_b(base + stride);
+        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
+        if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
+        samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true, true);
+        if (REDUCE) {
+            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
+            red_pairs += 1;
         }
-        if (base < n_pairs) {                                    // last, possibly ragged, iteration
-            const int64_t p = base + threadIdx.x;
-            const bool v0 = p < n_pairs;
-            const bool v1 = v0 && (2 * p + 1 < a.n_chains);
-            real2 xv = x_nxt;
-            if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
-            if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
-            // flushes and kind-R deposits are wave-wide (a raise of the running top is a wave-uniform decision): the lanes past the
-            // end go through the motions on a pair nobody stores and add zeros
-            samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1, false, mid_flush);
-            if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
-            if (REDUCE) {
-                red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
-                red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
-            }
+        x_done = xv;
+        base_done = base;
+    }
+    if (base < n_pairs) {                                    // last, possibly ragged, iteration
+        const int64_t p = base + threadIdx.x;
+        const bool v0 = p < n_pairs;
+        const bool v1 = v0 && (2 * p + 1 < a.n_chains);
+        real2 xv = x_nxt;
+        if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
+        if (SWEEP) mh(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1);
+        // flushes and kind-R deposits are wave-wide (a raise of the running top is a wave-uniform decision): the lanes past the
+        // end go through the motions on a pair nobody stores and add zeros
+        samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1, false);
+        if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
+        if (REDUCE) {
+            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
+            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
         }
-    };
-    {
-        // summands one accumulator takes in this launch: trips of this lane x two chains x q_batch samples (block-uniform)
-        const int64_t my_trips = first < n_pairs ? (n_pairs - first + stride - 1) / stride : 0;
-        if (my_trips * 2 * (int64_t)a.q_batch <= (int64_t)GD_CAP) trips(false);
-        else trips(true);
     }
     if (REDUCE)          // full trips: two chains per lane each
         red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
@@ -2215,17 +2235,20 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
             sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)(slots_before + t));
     }
-    // Block totals -> row blockIdx.x of partials[grid][NV][ROW words].  All cross-block traffic of the tail below goes
+    // Block totals -> this block's row of partials.  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
     // the 8 XCDs have private L2s) instead of release/acquire fences: an agent-scope fence is an L2 write-back /
     // invalidate per block, which cost ~70 us per launch over 2048 blocks when it was tried.
+    // (Integer atomic ADDS of the block totals straight into the group rows -- no block rows, one level of reading less -- were
+    // tried for the kind-Q columns: 12 far atomics per block onto 32-64 addresses each cost the launch 15 us, 67 -> 82 us.)
     flush_gd();
     __syncthreads();
     if ((int)threadIdx.x < a.n_learn * 4) {
         PgCol<QK> col;
         if (QK) col.q = q_block_total<QK ? NV : 1>(s_gq, QK ? (int)threadIdx.x : 0);
         else col.r = r_block_total<QK ? 1 : NV>(s_gr, QK ? 0 : (int)threadIdx.x);
-        col.store_row(a.partials + ((int64_t)blockIdx.x * NV + threadIdx.x) * ROW);
+        // layout [group][column][block of the group][ROW words]: the wave that adds a column up reads consecutive rows
+        col.store_row(a.partials + (((int64_t)(blockIdx.x / PG_GROUP) * NV + threadIdx.x) * PG_GROUP + blockIdx.x % PG_GROUP) * ROW);
     }
     if (a.tail_mode == 0) return;
     const PgTail* const tl = a.tail;       // loaded here, not at kernel entry (see PgArgs)
@@ -2248,9 +2271,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const int n_groups = (gridDim.x + PG_GROUP - 1) / PG_GROUP;
     const int r0 = grp * PG_GROUP;
     const int n_rows = ((int)gridDim.x - r0 < PG_GROUP) ? (int)gridDim.x - r0 : PG_GROUP;
-    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row's stores belong to wave 0 (NV <= 32)
-    __syncthreads();
     if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row's stores belong to this thread's wave (NV <= 32)
         const uint32_t prev = __hip_atomic_fetch_add(tickets + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_role = (prev == (uint32_t)n_rows - 1u) ? 1 : 0;
     }
@@ -2261,9 +2283,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     const bool lane0 = (threadIdx.x & 63) == 0;
     // wave w adds up columns w, w + 4, ...: lanes = the group's rows (PG_GROUP = 64 of them at most)
     for (int c = wave; c < nv; c += AMC_BLOCK / 64) {
-        const PgCol<QK> col = pg_col_total<QK>(a.partials + ((int64_t)r0 * NV + c) * ROW, n_rows, (int64_t)NV * ROW);
-        if (lane0) col.store_row(group_sums + ((int64_t)grp * NV + c) * ROW);
+        const PgCol<QK> col = pg_col_total<QK>(a.partials + ((int64_t)grp * NV + c) * PG_GROUP * ROW, n_rows, ROW);
+        if (lane0) col.store_row(group_sums + ((int64_t)c * PG_GROUP + grp) * ROW);          // [column][group][ROW words]
     }
+    // the quantum exponent of this wave's first column: the last block rounds with it -- formed here, under the ticket's latency,
+    // not between the ticket and the group rows' loads (two dependent loads: 0.4 us on the launch's critical path)
+    int e_first = 0;
+    if (QK && wave < nv) e_first = xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[wave >> 2]]).e[wave & 3];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2275,8 +2301,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     if (s_role != 2) return;
     for (int c = wave; c < nv; c += AMC_BLOCK / 64) {          // lanes = the groups (at most 64: the host caps the grid)
         const int l = c >> 2, i = c & 3;
-        const int e = QK ? xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i] : 0;   // (its load ahead of the rows')
-        const PgCol<QK> col = pg_col_total<QK>(group_sums + (int64_t)c * ROW, n_groups, (int64_t)NV * ROW);
+        const int e = !QK ? 0 : c == wave ? e_first : xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i];
+        const PgCol<QK> col = pg_col_total<QK>(group_sums + (int64_t)c * PG_GROUP * ROW, n_groups, ROW);
         if (lane0 && a.tail_mode == 1) {
             // records: this shard's slot filled, the other shards' slots zeroed (the all-reduce that follows is a gather)
             for (int r = 0; r < tail_ranks; ++r) {

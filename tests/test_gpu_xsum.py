@@ -186,10 +186,13 @@ def test_gradient_data_with_nan_state_is_nan(gpu, oracle):
     eng.close()
 
 
-def test_free_running_pgmc_is_bit_exact_against_the_oracle(gpu, oracle):
+@pytest.mark.parametrize("q_batch,stretches", [(1, (1, 3, 50, 146)), (24, (1, 2, 7))])
+def test_free_running_pgmc_is_bit_exact_against_the_oracle(gpu, oracle, q_batch, stretches):
     """BASELINE config 5 in small: [Metropolis, estimator, update] time steps on the device against the oracle running
     on its own -- nothing fed back: the learned sigma, the positions and the per-chain counters are EQUAL after every
-    stretch, because the GradientData fold is the same integer sum on both sides."""
+    stretch, because the GradientData fold is the same integer sum on both sides.
+    q_batch 24: more summands per trip (48) than a lane's accumulators take between two flushes -- such a time step is two
+    launches, the estimator's in its flushing form (pg_fits_without_flush, amc_api.hip)."""
     M = 100003
     kw = dict(potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
     eng = gpu.HipEngine(n_chains=M, device=0, **kw)
@@ -197,9 +200,9 @@ def test_free_running_pgmc_is_bit_exact_against_the_oracle(gpu, oracle):
     eng.init_uniform(-2.0, 2.0)
     ref.init_uniform(-2.0, 2.0)
     ids, kinds, h0, h1 = [1], [1], [0.05], [0.0]          # VPG(0.05) on move 2, Static on move 1
-    for stretch in (1, 3, 50, 146):
-        eng.pgmc_steps(stretch, ids, 1, kinds, h0, h1, reduce_begin=True)
-        ref.pgmc_steps(stretch, ids, 1, kinds, h0, h1, reduce_begin=True)
+    for stretch in stretches:
+        eng.pgmc_steps(stretch, ids, q_batch, kinds, h0, h1, reduce_begin=True)
+        ref.pgmc_steps(stretch, ids, q_batch, kinds, h0, h1, reduce_begin=True)
         a, sa = eng.reduce_end_exact()
         b, sb = ref.reduce_end_exact()
         assert eng.get_parameters(1)[0] == ref.get_parameters(1)[0], f"sigma after {stretch} more steps"
@@ -210,7 +213,7 @@ def test_free_running_pgmc_is_bit_exact_against_the_oracle(gpu, oracle):
     ac, tc = eng.download_counters()
     ao, to = ref.download_counters()
     assert np.array_equal(ac, ao) and np.array_equal(tc, to)
-    assert 0.2 < eng.get_parameters(1)[0] < 2.0
+    assert 0.1 < eng.get_parameters(1)[0] < 2.0 and eng.get_parameters(1)[0] != 0.1          # it learns
     eng.close()
 
 
