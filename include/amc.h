@@ -174,6 +174,32 @@ int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, 
  * Float64 state only.  Every accept decision takes the reference-ordered arithmetic (no accept filter). */
 int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
                                const char *sample_expr, const char *logq_expr, const char *dlogq_expr, amc_handle **out);
+/* The same for a policy with SEVERAL parameters: Move.parameters is an array in the reference (src/metropolis.jl:140-147),
+ * GradientData keeps grad j and grad logq_forward as arrays of its shape and g as their P x P outer product
+ * (src/PolicyGuided/gradients.jl:41-61,104-108), and the natural-gradient optimisers invert g + eps I
+ * (learning.jl:103-104,130-133,159-163).  n_params = P in [1, AMC_MAX_PARAMS]; the expressions see the move's parameters as
+ * theta0 .. theta{P-1} (`sigma` stays a name of theta0), dlogq_exprs[p] = d logq / d theta_p (all P of them, or NULL: no
+ * estimator), perform_expr / invert_expr as in amc_create_action_model (both NULL: the displacement).  E.g. a Gaussian
+ * with a learnable drift, delta = theta0 + theta1 z:
+ *     sample "theta0 + theta1*z"     logq "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)"
+ *     dlogq  { "(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1" }
+ * Parameter 0 of every move starts at cfg->sigma[k] (which must pass its range check), the others at 0: set the vector
+ * with amc_set_parameters(h, k, theta, P) -- any finite values.  With P > 1:
+ *   - every output that holds GradientData has AMC_GD_STRIDE_P(P) = 2 + 2P + P^2 doubles (records) per learnable move:
+ *     j, grad j [P], grad logq_forward [P], g [P][P] row by row, n  (P = 1: the five of AMC_GD_*);
+ *   - the estimator takes one launch per learnable move (1 + 2P + P(P+1)/2 reproducible column sums: g is symmetric), the
+ *     accumulate and update steps one tiny launch each; there is no fused time step;
+ *   - a learning step that leaves a parameter non-finite, or meets a singular g + eps I, is not applied (as for P = 1:
+ *     reported by amc_pg_get_accumulated);
+ *   - inv(g + eps I) is Gauss-Jordan elimination with partial pivoting (amc::pg_inv_small) where Julia calls LAPACK's
+ *     getrf / getri: equal up to rounding (a few ulp times the condition number), exactly 1 / a for P = 1. */
+#define AMC_MAX_PARAMS 4
+#define AMC_GD_STRIDE_P(P) (2 + 2 * (P) + (P) * (P))
+int  amc_create_vector_policy_model(const amc_config *cfg, int n_params, const char *potential_expr, const char *reward_expr,
+                                    const char *sample_expr, const char *logq_expr, const char *const *dlogq_exprs,
+                                    const char *perform_expr, const char *invert_expr, amc_handle **out);
+/* P and AMC_GD_STRIDE_P(P) of a handle (either pointer may be NULL). */
+int  amc_n_params(amc_handle *h, int *n_params, int *gd_stride);
 /* The same with a script-defined ACTION -- the reference's Action interface (src/metropolis.jl:15-119; the displacement's
  * methods are example/particle_1d/particle_1d.jl:30-40) for a one-parameter action on the position:
  *     perform_expr   the position after perform_action!(system, action), from `x` and `delta`      (displacement: x + delta)

@@ -84,6 +84,9 @@ def load() -> C.CDLL:
                                                 C.POINTER(H)]),
         "amc_create_action_model": (C.c_int, [C.POINTER(AmcConfig), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                               C.c_char_p, C.c_char_p, C.POINTER(H)]),
+        "amc_create_vector_policy_model": (C.c_int, [C.POINTER(AmcConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                                     C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.POINTER(H)]),
+        "amc_n_params": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -228,7 +231,10 @@ class HipEngine:
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
                  reward_expr: Optional[str] = None, dtype: str = "f64", scale_expr: Optional[str] = None,
-                 proposal: Optional[Sequence[Optional[str]]] = None):
+                 proposal: Optional[Sequence[Optional[str]]] = None, n_params: int = 1):
+        """``n_params`` > 1 (with ``proposal``): a policy with several parameters (amc_create_vector_policy_model) -- the
+        expressions see theta0 .. theta{P-1}, ``proposal[2]`` is the list of the P partials of logq (or None), and ``sigma``
+        holds one parameter VECTOR per move."""
         lib = load()
         if str(dtype) not in STATE_DTYPES:
             raise AmcError(f"unknown state dtype {dtype!r}; one of {sorted(STATE_DTYPES)}")
@@ -239,6 +245,16 @@ class HipEngine:
                            "and CustomPotential(expr)")
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
+        self.n_params = int(n_params)
+        self.gd_stride = 2 + 2 * self.n_params + self.n_params ** 2          # AMC_GD_STRIDE_P
+        if self.n_params != 1 and proposal is None:
+            raise AmcError("n_params > 1 needs a script-defined proposal (sample, logq, [dlogq ...])")
+        theta = None
+        if self.n_params > 1:
+            theta = [np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in sigma]
+            if any(v.size != self.n_params for v in theta):
+                raise AmcError(f"sigma must hold one vector of {self.n_params} parameters per move")
+            sigma = [1.0] * self.n_moves          # parameter 0 at creation; the vectors follow through amc_set_parameters
         self.per_chain_counters = bool(per_chain_counters) or self.n_moves > 1
         self._sigma = (C.c_double * self.n_moves)(*[float(s) for s in sigma])
         self._weight = (C.c_double * self.n_moves)(*[float(w) for w in weight])
@@ -269,8 +285,19 @@ class HipEngine:
             sample, logq, dlogq, perform, invert = (list(proposal) + [None] * 4)[:5]
             if expr is None:
                 cfg.potential = POTENTIALS[potential]
-            _check(lib.amc_create_action_model(C.byref(cfg), enc(expr), enc(reward_expr), enc(sample), enc(logq), enc(dlogq),
-                                               enc(perform), enc(invert), C.byref(self._h)))
+            if self.n_params > 1:
+                partials = None
+                if dlogq is not None:
+                    if isinstance(dlogq, (str, bytes)) or len(dlogq) != self.n_params:
+                        raise AmcError(f"proposal[2] must list the {self.n_params} partial derivatives of logq (or be None)")
+                    partials = (C.c_char_p * self.n_params)(*[enc(d) for d in dlogq])
+                _check(lib.amc_create_vector_policy_model(C.byref(cfg), self.n_params, enc(expr), enc(reward_expr), enc(sample),
+                                                          enc(logq), partials, enc(perform), enc(invert), C.byref(self._h)))
+                for k, v in enumerate(theta):
+                    self.set_parameters(k, v)
+            else:
+                _check(lib.amc_create_action_model(C.byref(cfg), enc(expr), enc(reward_expr), enc(sample), enc(logq), enc(dlogq),
+                                                   enc(perform), enc(invert), C.byref(self._h)))
         elif scale_expr is not None:
             # script-defined policy of the Gaussian-displacement family: proposal width sigma * scale(x)
             if expr is None:
@@ -434,8 +461,8 @@ class HipEngine:
         _check(self._lib.amc_set_parameters(self._h, int(k), _dptr(a), int(a.size)))
 
     def get_parameters(self, k: int) -> np.ndarray:
-        a = np.empty(1, dtype=np.float64)
-        _check(self._lib.amc_get_parameters(self._h, int(k), _dptr(a), 1))
+        a = np.empty(self.n_params, dtype=np.float64)
+        _check(self._lib.amc_get_parameters(self._h, int(k), _dptr(a), self.n_params))
         return a
 
     def parameters_begin(self) -> None:
@@ -450,7 +477,7 @@ class HipEngine:
     def pg_estimate(self, learn_ids: Sequence[int], q_batch: int) -> np.ndarray:
         n = len(learn_ids)
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
-        out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
+        out = np.zeros((n, self.gd_stride), dtype=np.float64)
         _check(self._lib.amc_pg_estimate(self._h, n, ids, int(q_batch), _dptr(out)))
         return out
 
@@ -458,7 +485,7 @@ class HipEngine:
         """The same fold as records, shape (n_learn, AMC_GD_STRIDE, AMC_XSUM_WORDS): what shards exchange."""
         n = len(learn_ids)
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
-        out = np.zeros((n, AMC_GD_STRIDE, AMC_XSUM_WORDS), dtype=np.float64)
+        out = np.zeros((n, self.gd_stride, AMC_XSUM_WORDS), dtype=np.float64)
         _check(self._lib.amc_pg_estimate_exact(self._h, n, ids, int(q_batch), _dptr(out)))
         return out
 
@@ -495,7 +522,7 @@ class HipEngine:
     def pg_get_accumulated(self, learn_ids: Sequence[int]) -> np.ndarray:
         n = len(learn_ids)
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
-        out = np.zeros((n, AMC_GD_STRIDE), dtype=np.float64)
+        out = np.zeros((n, self.gd_stride), dtype=np.float64)
         _check(self._lib.amc_pg_get_accumulated(self._h, n, ids, _dptr(out)))
         return out
 
@@ -503,7 +530,7 @@ class HipEngine:
         """Resume: replace the device-resident gradients_data of the moves learn_ids by rows[n][5] (j, grad_j, grad_logq, g, n)."""
         n = len(learn_ids)
         ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
-        a = np.ascontiguousarray(rows, dtype=np.float64).reshape(n, AMC_GD_STRIDE)
+        a = np.ascontiguousarray(rows, dtype=np.float64).reshape(n, self.gd_stride)
         _check(self._lib.amc_pg_set_accumulated(self._h, n, ids, _dptr(a)))
 
     def sync(self) -> None:
@@ -708,7 +735,7 @@ class SplitEngine:
 
     def pg_estimate(self, learn_ids, q_batch) -> np.ndarray:
         rec = self.pg_estimate_exact(learn_ids, q_batch)
-        return xsum_round(rec).reshape(rec.shape[0], AMC_GD_STRIDE)
+        return xsum_round(rec).reshape(rec.shape[0], rec.shape[1])
 
     def sync(self) -> None:
         for p in self.parts:

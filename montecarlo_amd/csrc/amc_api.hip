@@ -86,7 +86,8 @@ struct Rccl {
 
 static const int RED_HOST_STRIDE = amc::RED_ROW_WORDS;   // 64-bit words per row of the callback sums' block rows (red_finish)
 static const int RATIO_STRIDE = 4;      // columns per row of the fold's acceptance-ratio partials (K <= 4): XS_ROW_Q words per move
-static const int PG_MAX_COLS = AMC_MAX_LEARN * 4;   // GradientData columns of one estimator call
+static const int PG_MAX_COLS = AMC_MAX_LEARN * 4;   // GradientData columns of one estimator launch
+static const int PG_NP_MAX_COLS = 1 + 2 * AMC_MAX_NP + AMC_MAX_NP * (AMC_MAX_NP + 1) / 2;   // ... of one move with AMC_MAX_NP parameters (< PG_MAX_COLS)
 static const int RED_TICKETS = 2;       // reductions that may be in flight per handle (amc_reduce_begin .. amc_reduce_end)
 
 // One reduction in flight: where its block rows land and what amc_reduce_end needs to finish it.
@@ -163,7 +164,8 @@ struct amc_handle {
     hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
     hipEvent_t ev_comm_main = nullptr;   // behind the last collective queued on the engine's stream (the estimator's all-reduce)
     bool comm_main_pending = false;      // ... which comm_stream has not been ordered behind yet
-    double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator)
+    double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator); n_params > 1:
+                                  // [AMC_MAX_MOVES][AMC_GD_STRIDE_MAX], fields as in amc::pg_np_unpack
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
     amc::xs_word* d_pg_groups = nullptr;   // [nl * 4][PG_GROUP][words per column]: group rows
@@ -178,6 +180,7 @@ struct amc_handle {
     bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model)
     bool script_policy = false;   // sample_action! / log_proposal_density are script-defined expressions (amc_create_proposal_model)
     bool script_dlogq = false;    // ... and so is d logq / d sigma: the estimator is available
+    int n_params = 1;             // parameters of the moves' policy (amc_create_policy_model; 1: sigma)
     bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
     double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
@@ -527,7 +530,7 @@ int validate_potential_expr(const char* expr, const char* what = "custom potenti
             !(i + vl < n && (std::isalnum((unsigned char)expr[i + vl]) || expr[i + vl] == '_')))
             has_x = true;
     }
-    if (!has_x) return fail(AMC_ERR_BAD_ARG, "%s: the expression does not mention %s", what, var);
+    if (!has_x && var[0] != 0) return fail(AMC_ERR_BAD_ARG, "%s: the expression does not mention %s", what, var);
     return AMC_OK;
 }
 
@@ -626,13 +629,25 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         expr.erase(at);
         return tail;
     };
+    const std::string e_np = cut_tail('\x0e');           // [ '\x0e' P ]: parameters of the policy, when more than one; the dlogq section then holds P
+                                                         // expressions, '\x0b' between them
     const std::string e_invert = cut_tail('\x08'), e_perform = cut_tail('\x07');
     const std::string e_dlogq = cut_tail('\x06'), e_logq = cut_tail('\x05'), e_sample = cut_tail('\x04'), e_scale = cut_tail('\x03');
     if (!e_perform.empty()) src += "#define AMC_USER_PERFORM(x, delta) (" + e_perform + ")\n";
     if (!e_invert.empty()) src += "#define AMC_USER_INVERT(delta, x) (" + e_invert + ")\n";
     if (!e_sample.empty()) src += "#define AMC_USER_SAMPLE(z, x, sigma) (" + e_sample + ")\n";
     if (!e_logq.empty()) src += "#define AMC_USER_LOGQ(delta, x, sigma) (" + e_logq + ")\n";
-    if (!e_dlogq.empty()) src += "#define AMC_USER_DLOGQ(delta, x, sigma) (" + e_dlogq + ")\n";
+    if (!e_np.empty()) src += "#define AMC_NP " + e_np + "\n";
+    if (!e_dlogq.empty()) {
+        size_t from = 0;
+        for (int pidx = 0; from <= e_dlogq.size(); ++pidx) {
+            const size_t to = e_dlogq.find('\x0b', from);
+            const std::string one = e_dlogq.substr(from, to == std::string::npos ? std::string::npos : to - from);
+            src += "#define AMC_USER_DLOGQ" + (pidx == 0 ? std::string() : std::to_string(pidx)) + "(delta, x, sigma) (" + one + ")\n";
+            if (to == std::string::npos) break;
+            from = to + 1;
+        }
+    }
     if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
     const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
@@ -781,7 +796,7 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; };
+struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; int n_params; const char* const* dlogq_more; };   // dlogq_more: partials 1 .. n_params - 1
 
 static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
                        const char* scale_expr = nullptr, const ProposalExprs* proposal = nullptr)
@@ -819,7 +834,14 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         if (proposal) {
             int rc_p = validate_potential_expr(proposal->sample, "sample_action expression", "z");
             if (rc_p == AMC_OK) rc_p = validate_potential_expr(proposal->logq, "log_proposal_density expression", "delta");
-            if (rc_p == AMC_OK && proposal->dlogq) rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "sigma");
+            if (rc_p == AMC_OK && proposal->dlogq) {
+                rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", proposal->n_params > 1 ? "" : "sigma");
+                if (rc_p != AMC_OK && proposal->n_params == 1 &&         // theta0 is another name of sigma
+                    validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "theta0") == AMC_OK)
+                    rc_p = AMC_OK;
+            }
+            for (int pidx = 1; rc_p == AMC_OK && proposal->dlogq && pidx < proposal->n_params; ++pidx)
+                rc_p = validate_potential_expr(proposal->dlogq_more[pidx - 1], "d log_proposal_density / d theta expression", "");
             if (rc_p == AMC_OK && (proposal->perform != nullptr) != (proposal->invert != nullptr))
                 rc_p = fail(AMC_ERR_BAD_ARG, "amc_create_action_model: perform_expr and invert_expr come together (No invert_action! is defined)");
             if (rc_p == AMC_OK && proposal->perform) rc_p = validate_potential_expr(proposal->perform, "perform_action expression", "delta");
@@ -901,10 +923,15 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (potential_expr && scale_expr) { h->pot_expr += std::string("\x03") + scale_expr; h->scaled_policy = true; }
     if (potential_expr && proposal) {
         h->pot_expr += std::string("\x04") + proposal->sample + std::string("\x05") + proposal->logq;
-        if (proposal->dlogq) h->pot_expr += std::string("\x06") + proposal->dlogq;
+        if (proposal->dlogq) {
+            h->pot_expr += std::string("\x06") + proposal->dlogq;
+            for (int pidx = 1; pidx < proposal->n_params; ++pidx) h->pot_expr += std::string("\x0b") + proposal->dlogq_more[pidx - 1];
+        }
         if (proposal->perform) h->pot_expr += std::string("\x07") + proposal->perform + std::string("\x08") + proposal->invert;
+        if (proposal->n_params > 1) h->pot_expr += std::string("\x0e") + std::to_string(proposal->n_params);
         h->script_policy = true;
         h->script_dlogq = proposal->dlogq != nullptr;
+        h->n_params = proposal->n_params;
     }
     h->K = cfg->n_moves;
     h->sweepstep = cfg->sweepstep;
@@ -970,9 +997,9 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         AMC_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
     }
     AMC_TRY(hipMalloc(&h->d_out, (size_t)PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double)));
-    AMC_TRY(hipHostMalloc((void**)&h->h_pg_out, (size_t)PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double), 0));
-    AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * 5 * sizeof(double)));
-    AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * 5 * sizeof(double), h->stream));
+    AMC_TRY(hipHostMalloc((void**)&h->h_pg_out, (size_t)AMC_MAX_LEARN * PG_NP_MAX_COLS * amc::xs::XS_WORDS * sizeof(double), 0));
+    AMC_TRY(hipMalloc(&h->d_gd_acc, (size_t)AMC_MAX_MOVES * AMC_GD_STRIDE_MAX * sizeof(double)));
+    AMC_TRY(hipMemsetAsync(h->d_gd_acc, 0, (size_t)AMC_MAX_MOVES * AMC_GD_STRIDE_MAX * sizeof(double), h->stream));
     AMC_TRY(hipMalloc(&h->d_status, sizeof(int)));
     AMC_TRY(hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream));
     {
@@ -1060,6 +1087,33 @@ int amc_create_proposal_model(const amc_config* cfg, const char* potential_expr,
     return amc_create_action_model(cfg, potential_expr, reward_expr, sample_expr, logq_expr, dlogq_expr, nullptr, nullptr, out);
 }
 
+int amc_create_vector_policy_model(const amc_config* cfg, int n_params, const char* potential_expr, const char* reward_expr,
+                            const char* sample_expr, const char* logq_expr, const char* const* dlogq_exprs, const char* perform_expr,
+                            const char* invert_expr, amc_handle** out)
+{
+    if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: NULL argument");
+    if (n_params < 1 || n_params > AMC_MAX_NP)
+        return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: n_params must be in [1, %d]", AMC_MAX_NP);
+    if (!sample_expr || !logq_expr)
+        return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: sample_expr and logq_expr are both required (No sample_action! / log_proposal_density is defined)");
+    if (dlogq_exprs)
+        for (int p = 0; p < n_params; ++p)
+            if (!dlogq_exprs[p]) return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: dlogq_exprs[%d] is NULL (one expression per parameter, or none at all)", p);
+    const char* pot = potential_expr;
+    if (!pot) {
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: potential_expr is NULL and cfg->potential names no built-in");
+    }
+    amc_config c2;
+    std::memset(&c2, 0, sizeof(c2));
+    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
+    c2.potential = AMC_POTENTIAL_CUSTOM;
+    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_exprs ? dlogq_exprs[0] : nullptr, perform_expr, invert_expr, n_params,
+                                dlogq_exprs ? dlogq_exprs + 1 : nullptr};
+    return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
+}
+
 int amc_create_action_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, const char* sample_expr,
                             const char* logq_expr, const char* dlogq_expr, const char* perform_expr, const char* invert_expr,
                             amc_handle** out)
@@ -1077,7 +1131,7 @@ int amc_create_action_model(const amc_config* cfg, const char* potential_expr, c
     std::memset(&c2, 0, sizeof(c2));
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
     c2.potential = AMC_POTENTIAL_CUSTOM;
-    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr};
+    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr, 1, nullptr};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 
@@ -1838,18 +1892,31 @@ int amc_xsum_round(const double* records, int n_records, double* out)
     return AMC_OK;
 }
 
+// row of the parameter table that holds parameter p of every move
+static int theta_row(int p) { return p == 0 ? (int)amc::PT_SIGMA : (int)amc::PT_THETA1 + p - 1; }
+
 int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
 {
     if (!h || !p) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: NULL argument");
     if (k < 0 || k >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: move index %d out of range", k);
-    if (n != 1) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: StandardGaussian has exactly 1 parameter (sigma)");
-    if (!(p[0] >= 1e-100) || !(p[0] <= 1e100))
-        return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: sigma must lie in [1e-100, 1e100] (got %.17g)", p[0]);
+    if (n != h->n_params)
+        return fail(AMC_ERR_BAD_ARG, h->n_params == 1 ? "amc_set_parameters: StandardGaussian has exactly 1 parameter (sigma)"
+                                                     : "amc_set_parameters: this handle's policy has %d parameters", h->n_params);
+    if (h->n_params == 1) {
+        if (!(p[0] >= 1e-100) || !(p[0] <= 1e100))
+            return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: sigma must lie in [1e-100, 1e100] (got %.17g)", p[0]);
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (!(p[i] - p[i] == 0.0)) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: parameter %d is not finite", i);
+    }
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipMemcpyAsync(h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, p, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int i = 0; i < n; ++i)
+        AMC_HIP(hipMemcpyAsync(h->d_ptab + theta_row(i) * AMC_MAX_MOVES + k, p + i, sizeof(double), hipMemcpyHostToDevice, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
-    hipLaunchKernelGGL(amc::prepare_params_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->K);
-    AMC_HIP(hipGetLastError());
+    if (h->n_params == 1) {            // what derives from sigma (the script kernels of a policy with several parameters read none of it)
+        hipLaunchKernelGGL(amc::prepare_params_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->K);
+        AMC_HIP(hipGetLastError());
+    }
     return AMC_OK;
 }
 
@@ -1857,10 +1924,21 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
 {
     if (!h || !p) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: NULL argument");
     if (k < 0 || k >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: move index %d out of range", k);
-    if (n != 1) return fail(AMC_ERR_BAD_ARG, "amc_get_parameters: StandardGaussian has exactly 1 parameter (sigma)");
+    if (n != h->n_params)
+        return fail(AMC_ERR_BAD_ARG, h->n_params == 1 ? "amc_get_parameters: StandardGaussian has exactly 1 parameter (sigma)"
+                                                     : "amc_get_parameters: this handle's policy has %d parameters", h->n_params);
     AMC_HIP(hipSetDevice(h->device));
-    AMC_HIP(hipMemcpyAsync(p, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + k, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    for (int i = 0; i < n; ++i)
+        AMC_HIP(hipMemcpyAsync(p + i, h->d_ptab + theta_row(i) * AMC_MAX_MOVES + k, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+int amc_n_params(amc_handle* h, int* n_params, int* gd_stride)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_n_params: NULL handle");
+    if (n_params) *n_params = h->n_params;
+    if (gd_stride) *gd_stride = amc::pg_gd_stride(h->n_params);
     return AMC_OK;
 }
 
@@ -1912,9 +1990,11 @@ static bool pg_fits_without_flush(const amc_handle* h, int q_batch)
 // gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
 // with_sweep: the launch first does one make_step!(::Metropolis) (caller decided: `fused` in pgmc_steps_impl).
 // reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in the next reduction ticket's rows.
+// l_base, advance (policies with several parameters: one launch per learnable move): the move's index in the estimator call,
+// and whether this launch is the call's last (the estimator's step counter then advances).
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false, bool reduce = false,
-                     int* grid_out = nullptr)
+                     int* grid_out = nullptr, int l_base = 0, bool advance = true)
 {
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
@@ -1928,6 +2008,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         return fail(AMC_ERR_STATE, "%s: this handle's script-defined proposal came without d logq / d sigma (dlogq_expr): "
                                    "No withgrad_log_proposal_density! is defined", who);
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
+    if (h->n_params > 1 && (n_learn != 1 || tail != 1 || with_sweep))
+        return fail(AMC_ERR_STATE, "%s: a policy with several parameters takes one learnable move per launch", who);
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;
     a.x = h->d_x;
@@ -1944,6 +2026,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.key1 = (uint32_t)(h->seed >> 32);
     a.beta = h->beta;
     a.tail_mode = tail;
+    a.l_base = l_base;
     {
         amc::PgTail tl;
         std::memset(&tl, 0, sizeof(tl));          // padding included: the record is compared bytewise below
@@ -1990,7 +2073,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         if (h->d_log) h->log_fill += 1;
     }
     // tail 1: the launch itself left the columns' totals as records in d_out[ranks][n_learn * 4][XS_WORDS] (in-kernel final reduction)
-    h->t_est += 1;
+    if (advance) h->t_est += 1;
     *nl_out = nl;
     return AMC_OK;
 }
@@ -1999,6 +2082,22 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
 static int pg_estimate_records(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, const double** recs)
 {
     int nl = 0;
+    if (h->n_params > 1) {
+        // one launch per learnable move, its 1 + 2P + P(P+1)/2 records behind those of the moves before it
+        if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
+        if (n_learn == 0) return pg_launch(h, who, 0, learn_ids, q_batch, &nl);
+        const int nc = amc::pg_n_columns(h->n_params);
+        const int slot = h->comm ? h->comm_rank : 0;
+        const size_t n = (size_t)nc * amc::xs::XS_WORDS;
+        for (int l = 0; l < n_learn; ++l) {
+            const int rc = pg_launch(h, who, 1, learn_ids + l, q_batch, &nl, 1, nullptr, false, false, nullptr, l, l + 1 == n_learn);
+            if (rc != AMC_OK) return rc;
+            AMC_HIP(hipMemcpyAsync(h->h_pg_out + (size_t)l * n, h->d_out + (size_t)slot * n, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        AMC_HIP(wait_stream(h->stream));
+        *recs = h->h_pg_out;
+        return AMC_OK;
+    }
     const int rc = pg_launch(h, who, n_learn, learn_ids, q_batch, &nl);
     if (rc != AMC_OK || n_learn == 0) return rc;
     const int slot = h->comm ? h->comm_rank : 0;
@@ -2015,6 +2114,16 @@ int amc_pg_estimate(amc_handle* h, int n_learn, const int* learn_ids, int q_batc
     const double* recs = nullptr;
     const int rc = pg_estimate_records(h, "amc_pg_estimate", n_learn, learn_ids, q_batch, &recs);
     if (rc != AMC_OK || n_learn == 0) return rc;
+    if (h->n_params > 1) {             // [j, grad j [P], grad logq [P], g [P][P], n] per move
+        const int np = h->n_params, nc = amc::pg_n_columns(np), stride = amc::pg_gd_stride(np);
+        for (int l = 0; l < n_learn; ++l) {
+            double vals[PG_NP_MAX_COLS];
+            for (int c = 0; c < nc; ++c) vals[c] = amc::xs::rec_round(recs + (size_t)(l * nc + c) * amc::xs::XS_WORDS);
+            amc::pg_np_unpack(vals, np, out + (size_t)l * stride);
+            out[(size_t)l * stride + stride - 1] = (double)h->M * (double)q_batch;
+        }
+        return AMC_OK;
+    }
     for (int l = 0; l < n_learn; ++l) {
         for (int i = 0; i < 4; ++i) out[l * AMC_GD_STRIDE + i] = amc::xs::rec_round(recs + (size_t)(l * 4 + i) * amc::xs::XS_WORDS);
         out[l * AMC_GD_STRIDE + AMC_GD_N] = (double)h->M * (double)q_batch;
@@ -2028,6 +2137,24 @@ int amc_pg_estimate_exact(amc_handle* h, int n_learn, const int* learn_ids, int 
     const double* recs = nullptr;
     const int rc = pg_estimate_records(h, "amc_pg_estimate_exact", n_learn, learn_ids, q_batch, &recs);
     if (rc != AMC_OK || n_learn == 0) return rc;
+    if (h->n_params > 1) {
+        const int np = h->n_params, nc = amc::pg_n_columns(np), stride = amc::pg_gd_stride(np);
+        const size_t W = amc::xs::XS_WORDS;
+        for (int l = 0; l < n_learn; ++l) {
+            double* dst = records + (size_t)l * stride * W;
+            const double* src = recs + (size_t)l * nc * W;
+            std::memcpy(dst, src, (size_t)(1 + 2 * np) * W * sizeof(double));
+            int at = 1 + 2 * np;
+            for (int a = 0; a < np; ++a)
+                for (int b = a; b < np; ++b) {
+                    std::memcpy(dst + (size_t)(1 + 2 * np + a * np + b) * W, src + (size_t)at * W, W * sizeof(double));
+                    std::memcpy(dst + (size_t)(1 + 2 * np + b * np + a) * W, src + (size_t)at * W, W * sizeof(double));
+                    ++at;
+                }
+            amc::xs::rec_from_plain(dst + (size_t)(stride - 1) * W, (double)h->M * (double)q_batch);
+        }
+        return AMC_OK;
+    }
     for (int l = 0; l < n_learn; ++l) {
         for (int i = 0; i < 4; ++i)
             std::memcpy(records + (size_t)(l * AMC_GD_STRIDE + i) * amc::xs::XS_WORDS, recs + (size_t)(l * 4 + i) * amc::xs::XS_WORDS,
@@ -2044,6 +2171,30 @@ static amc::PgIds make_ids(int n_learn, const int* learn_ids)
     return ids;
 }
 
+// The gather of the shards' records d_out[ranks][n_cols][XS_WORDS] (each shard filled its slot, zeroed the others): one in-place
+// all-reduce(sum) on the engine's stream.
+static int pg_allreduce_records(amc_handle* h, int n_cols)
+{
+    const size_t n_words = (size_t)h->comm_ranks * (size_t)n_cols * amc::xs::XS_WORDS;
+    const int e = h->rccl.AllReduce(h->d_out, h->d_out, n_words, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
+    // one communicator, two streams: a collective amc_allreduce_sum queues on comm_stream later must start after this one
+    AMC_HIP(hipEventRecord(h->ev_comm_main, h->stream));
+    h->comm_main_pending = true;
+    return AMC_OK;
+}
+
+// make_step!(::PolicyGradientUpdate) for a policy with several parameters: one tiny launch per learnable move
+static int pg_update_np(amc_handle* h, int n_learn, const int* learn_ids, const amc::PgOpts& opt)
+{
+    for (int l = 0; l < n_learn; ++l) {
+        hipLaunchKernelGGL(amc::pg_update_np_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, h->n_params, learn_ids[l],
+                           opt.kind[l], opt.h0[l], opt.h1[l], h->d_status);
+        AMC_HIP(hipGetLastError());
+    }
+    return AMC_OK;
+}
+
 // make_step!(::PolicyGradientEstimator) on the device, optionally followed by make_step!(::PolicyGradientUpdate)
 // (opt != nullptr).  Single shard: ONE launch (the estimator kernel's last block folds, accumulates and, if asked,
 // takes the learning step).  Shards connected by amc_comm_init: estimator launch, in-place all-reduce, then the
@@ -2052,6 +2203,24 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
                               bool with_sweep = false, bool reduce = false, int* grid_out = nullptr)
 {
     int nl = 0;
+    if (h->n_params > 1) {
+        // per learnable move: estimator launch (records in d_out), the gather across shards, gradients_data[k] += gd
+        if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters");
+        if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+        if (n_learn == 0) return pg_launch(h, "amc_pg_accumulate", 0, learn_ids, q_batch, &nl);
+        const int nc = amc::pg_n_columns(h->n_params);
+        const int ranks = h->comm ? h->comm_ranks : 1;
+        for (int l = 0; l < n_learn; ++l) {
+            int rc = pg_launch(h, "amc_pg_accumulate", 1, learn_ids + l, q_batch, &nl, 1, nullptr, false, false, nullptr, l, l + 1 == n_learn);
+            if (rc == AMC_OK && h->comm) rc = pg_allreduce_records(h, nc);
+            if (rc != AMC_OK) return rc;
+            hipLaunchKernelGGL(amc::pg_accumulate_np_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, ranks, h->n_params, learn_ids[l],
+                               (double)h->M_global * (double)q_batch, h->d_gd_acc);
+            AMC_HIP(hipGetLastError());
+        }
+        if (opt) return pg_update_np(h, n_learn, learn_ids, *opt);
+        return AMC_OK;
+    }
     const int tail = h->comm ? 1 : (opt ? 3 : 2);
     const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep, reduce, grid_out);
     if (rc != AMC_OK || n_learn == 0) return rc;
@@ -2060,12 +2229,7 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     // slots, so ONE in-place all-reduce(sum) on the engine's stream is a gather -- exact whatever order RCCL adds in; the
     // kernel behind it merges the shards' integer totals and rounds once (pg_merge_slots): every shard, and a single shard
     // holding all the chains, arrive at the same bits
-    const size_t n_words = (size_t)h->comm_ranks * (size_t)n_learn * 4 * amc::xs::XS_WORDS;
-    const int e = h->rccl.AllReduce(h->d_out, h->d_out, n_words, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    // one communicator, two streams: a collective amc_allreduce_sum queues on comm_stream later must start after this one
-    AMC_HIP(hipEventRecord(h->ev_comm_main, h->stream));
-    h->comm_main_pending = true;
+    { const int rca = pg_allreduce_records(h, n_learn * 4); if (rca != AMC_OK) return rca; }
     const double n_samples = (double)h->M_global * (double)q_batch;
     if (opt) {      // gradients_data += gd and the learning step in ONE launch: both sit on the critical path of the next sweep
         hipLaunchKernelGGL(amc::pg_accumulate_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->comm_ranks, h->d_ptab,
@@ -2109,6 +2273,7 @@ int amc_pg_update(amc_handle* h, int n_learn, const int* learn_ids, const int* o
     amc::PgOpts opt;
     { const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt); if (rc != AMC_OK) return rc; }
     AMC_HIP(hipSetDevice(h->device));
+    if (h->n_params > 1) return pg_update_np(h, n_learn, learn_ids, opt);
     hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
                        make_ids(n_learn, learn_ids), opt, h->K, h->d_status);
     AMC_HIP(hipGetLastError());
@@ -2137,7 +2302,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
-    const bool fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
+    const bool fused = h->n_params == 1 && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && pg_fits_without_flush(h, q_batch) &&
                        std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
@@ -2171,17 +2336,20 @@ int amc_pg_get_accumulated(amc_handle* h, int n_learn, const int* learn_ids, dou
 {
     if (!h || !out || (n_learn > 0 && !learn_ids)) return fail(AMC_ERR_BAD_ARG, "amc_pg_get_accumulated: NULL argument");
     AMC_HIP(hipSetDevice(h->device));
-    std::vector<double> acc((size_t)AMC_MAX_MOVES * 5);
+    const int np = h->n_params;
+    const size_t dev_stride = np > 1 ? (size_t)AMC_GD_STRIDE_MAX : 5, out_stride = (size_t)amc::pg_gd_stride(np);
+    std::vector<double> acc((size_t)AMC_MAX_MOVES * dev_stride);
     int status = 0;
     AMC_HIP(hipMemcpyAsync(acc.data(), h->d_gd_acc, acc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipMemcpyAsync(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
     for (int l = 0; l < n_learn; ++l) {
         if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_get_accumulated: learn_ids[%d] out of range", l);
-        for (int i = 0; i < 5; ++i) out[l * AMC_GD_STRIDE + i] = acc[(size_t)learn_ids[l] * 5 + i];
+        for (size_t i = 0; i < out_stride; ++i) out[(size_t)l * out_stride + i] = acc[(size_t)learn_ids[l] * dev_stride + i];
     }
     if (status != 0)
-        return fail(AMC_ERR_STATE, "a learning step produced a sigma outside [1e-100, 1e100] (or NaN) and was not applied");
+        return fail(AMC_ERR_STATE, np > 1 ? "a learning step produced a parameter that is not finite (or met a singular metric) and was not applied"
+                                          : "a learning step produced a sigma outside [1e-100, 1e100] (or NaN) and was not applied");
     return AMC_OK;
 }
 
@@ -2191,13 +2359,16 @@ int amc_pg_set_accumulated(amc_handle* h, int n_learn, const int* learn_ids, con
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: n_learn must be in [0, %d]", AMC_MAX_LEARN);
     for (int l = 0; l < n_learn; ++l) {
         if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: learn_ids[%d] out of range", l);
-        const double n = in[l * AMC_GD_STRIDE + AMC_GD_N];
+        const double n = in[(size_t)l * amc::pg_gd_stride(h->n_params) + amc::pg_gd_stride(h->n_params) - 1];
         if (!(n >= 0.0) || n != std::floor(n)) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: n of move %d is not a sample count", learn_ids[l]);
     }
     AMC_HIP(hipSetDevice(h->device));
-    for (int l = 0; l < n_learn; ++l)
-        AMC_HIP(hipMemcpyAsync(h->d_gd_acc + (size_t)learn_ids[l] * 5, in + (size_t)l * AMC_GD_STRIDE, 5 * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream));
+    {
+        const size_t dev_stride = h->n_params > 1 ? (size_t)AMC_GD_STRIDE_MAX : 5, in_stride = (size_t)amc::pg_gd_stride(h->n_params);
+        for (int l = 0; l < n_learn; ++l)
+            AMC_HIP(hipMemcpyAsync(h->d_gd_acc + (size_t)learn_ids[l] * dev_stride, in + (size_t)l * in_stride, in_stride * sizeof(double),
+                                   hipMemcpyHostToDevice, h->stream));
+    }
     AMC_HIP(hipStreamSynchronize(h->stream));      // the caller's buffer is only valid during the call
     return AMC_OK;
 }

@@ -50,7 +50,22 @@ typedef double2 real2;
 
 // Rows of the per-move parameter table.
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
-       PT_RDEN = 7, PT_C3HI = 8, PT_C3LO = 9, PT_ROWS = 10 };
+       PT_RDEN = 7, PT_C3HI = 8, PT_C3LO = 9,
+       PT_THETA1 = 10, PT_THETA2 = 11, PT_THETA3 = 12,      // parameters 1..3 of a script-defined policy with several (AMC_NP)
+       PT_ROWS = 13 };
+
+// Parameters of a move's policy (Move.parameters, src/metropolis.jl:140-147: an array; GradientData keeps grad j and
+// grad logq as arrays of that shape and g as their outer product, PolicyGuided/gradients.jl:41-61).  The built-in Gaussian
+// displacement has one (sigma); a script-defined policy (amc_create_vector_policy_model) may have up to four, theta0 (= PT_SIGMA's
+// row, `sigma` in the expressions) .. theta3: the translation unit hiprtc compiles for it defines AMC_NP.  Everything that
+// serves AMC_NP > 1 is behind `#if AMC_NP > 1` or a constant that is 4 for AMC_NP == 1: the one-parameter kernels are the
+// code they were.
+#ifndef AMC_NP
+#define AMC_NP 1
+#endif
+#define AMC_MAX_NP 4
+// GradientData columns of one learnable move: j, grad j [NP], grad logq [NP], g [upper triangle, row by row]
+#define AMC_PG_NC (1 + 2 * AMC_NP + AMC_NP * (AMC_NP + 1) / 2)
 
 // a / b, correctly rounded, for a divisor b whose reciprocal y = RN(1/b) is precomputed
 // (b = 2 sigma^2 is one value per move).  Two Markstein corrections: q1 is a faithful rounding of
@@ -140,20 +155,53 @@ __device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const doub
 {
     return (real_t)(AMC_USER_INVERT(delta, x));
 }
-__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_)
+// The move's further parameters (AMC_NP > 1) live in an LDS copy of their table rows, staged by the kernels that propose
+// (stage_user_theta); the expressions see them as theta1 .. theta3, and theta0 is another name of sigma.  k: the move.
+#if AMC_NP > 1
+__shared__ double s_user_theta[AMC_MAX_NP - 1][AMC_MAX_MOVES];
+#define AMC_USER_THETAS(k)                                                                                             \
+    const double theta0 = sigma, theta1 = s_user_theta[0][k], theta2 = AMC_NP > 2 ? s_user_theta[1][k] : 0.0,          \
+                 theta3 = AMC_NP > 3 ? s_user_theta[2][k] : 0.0;                                                       \
+    (void)theta0; (void)theta1; (void)theta2; (void)theta3
+#else
+#define AMC_USER_THETAS(k) const double theta0 = sigma; (void)theta0; (void)k
+#endif
+__device__ __forceinline__ void stage_user_theta(const double* ptab)       // before a barrier the caller already has
 {
+#if AMC_NP > 1
+    for (int i = threadIdx.x; i < (AMC_NP - 1) * AMC_MAX_MOVES; i += AMC_BLOCK)
+        s_user_theta[i / AMC_MAX_MOVES][i % AMC_MAX_MOVES] = ptab[(PT_THETA1 + i / AMC_MAX_MOVES) * AMC_MAX_MOVES + i % AMC_MAX_MOVES];
+#else
+    (void)ptab;
+#endif
+}
+__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_, int k)
+{
+    AMC_USER_THETAS(k);
     return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
 }
-__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_)
+__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k)
 {
+    AMC_USER_THETAS(k);
     return (double)(AMC_USER_LOGQ(delta, x, sigma));
 }
-__device__ __forceinline__ double user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_)
+// grad log_proposal_density with respect to the parameters, d[p] = d logq / d theta_p
+__device__ __forceinline__ void user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, double (&d)[AMC_NP])
 {
+    AMC_USER_THETAS(k);
 #ifdef AMC_USER_DLOGQ
-    return (double)(AMC_USER_DLOGQ(delta, x, sigma));
+    d[0] = (double)(AMC_USER_DLOGQ(delta, x, sigma));
+#if AMC_NP > 1
+    d[1] = (double)(AMC_USER_DLOGQ1(delta, x, sigma));
+#endif
+#if AMC_NP > 2
+    d[2] = (double)(AMC_USER_DLOGQ2(delta, x, sigma));
+#endif
+#if AMC_NP > 3
+    d[3] = (double)(AMC_USER_DLOGQ3(delta, x, sigma));
+#endif
 #else
-    return __builtin_nan("");                         // the host refuses the estimator for such a handle
+    for (int p = 0; p < AMC_NP; ++p) d[p] = __builtin_nan("");     // the host refuses the estimator for such a handle
 #endif
 }
 #endif
@@ -294,16 +342,16 @@ __device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, 
 // One mc_step! with a script-defined proposal (see user_sample / user_logq), in the reference's operation order
 // (metropolis.jl:176-190).
 template <int POT>
-__device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, double z, double u, const double* T)
+__device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, double z, double u, const double* T, int k)
 {
-    const real_t delta = user_sample(z, x, sigma, T);                    // :177 sample_action!
-    const double logq_f = user_logq(delta, x, sigma, T);                 // :178
+    const real_t delta = user_sample(z, x, sigma, T, k);                 // :177 sample_action!
+    const double logq_f = user_logq(delta, x, sigma, T, k);              // :178
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T);                         // :179 perform_action!
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
     const real_t nd = user_invert(delta, xn, T);                         // :181 invert_action!
-    const double logq_b = user_logq(nd, xn, sigma, T);                   // :182
+    const double logq_b = user_logq(nd, xn, sigma, T, k);                // :182
     const double arg = ((double)dlogp + logq_b) - logq_f;                // :183
     const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
     const bool acc = c_pos | (c_rng & c_exp);
@@ -337,8 +385,8 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
     {
         if (!have_pu) pu = philox4x32_10(accept_ctr, key0, key1);
 #ifdef AMC_USER_LOGQ
-        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
-        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
+        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T, MULTI ? k0 : 0);
+        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T, MULTI ? k1 : 0);
 #else
         const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
         const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
@@ -1027,6 +1075,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     constexpr bool AHEAD = SINGLE;
     StepDraws dr_nxt = {};
     if (AHEAD && first < n_pairs) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
+#ifdef AMC_USER_LOGQ
+    stage_user_theta(a.ptab);
+#endif
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load; ends in a barrier
     // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
     // and puts a counted wait before the first use of x in every iteration -- which in steady state waits for
@@ -1701,6 +1752,9 @@ struct PgArgs {
     // dependent-launch gap on this part).  tail_mode 0: block rows only; 1: + their total as records in `out`;
     // 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
+    // AMC_NP > 1: a launch takes ONE learnable move (its columns fill a row), the l_base-th of the estimator call -- the index
+    // that, with q, names the sample's draw
+    int32_t l_base;
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
 // to outlive the call and launches already queued keep reading the old record until they are done.
@@ -1793,17 +1847,20 @@ __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double 
 // at the old state (:97), of the backward density at the new state (:102); grad_j takes the forward gradient when
 // alpha == 1, else the backward one (:106).  g: the sample's four summands in the reference's operations.
 template <int POT>
-__device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[4], const double* T)
+__device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[AMC_PG_NC], const double* T, int k)
 {
-    const real_t delta = user_sample(z, x, sigma, T);
-    const double logq_f = user_logq(delta, x, sigma, T), dlogq_f = user_dlogq(delta, x, sigma, T);
+    const real_t delta = user_sample(z, x, sigma, T, k);
+    double d_f[AMC_NP], d_b[AMC_NP];
+    const double logq_f = user_logq(delta, x, sigma, T, k);
+    user_dlogq(delta, x, sigma, T, k, d_f);
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T);
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
     const real_t nd = user_invert(delta, xn, T);
-    const double logq_b = user_logq(nd, xn, sigma, T), dlogq_b = user_dlogq(nd, xn, sigma, T);
+    const double logq_b = user_logq(nd, xn, sigma, T, k);
+    user_dlogq(nd, xn, sigma, T, k, d_b);
     x = user_perform(xn, nd, T);
     const double arg = ((double)dlogp + logq_b) - logq_f;
     double ex = exp_core_f64(arg, T);
@@ -1811,10 +1868,17 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     double alpha = (arg >= -708.0) ? ex : ((arg != arg) ? arg : 0.0);
     alpha = (arg >= 0.0) ? 1.0 : alpha;
     const double j = r * alpha;
+    // GradientData(j, grad j, grad logq_forward, g = grad logq_forward * grad logq_forward', 1): gradients.jl:104-108.  g is
+    // symmetric (a product commutes): its upper triangle, row by row
     g[0] = j;
-    g[1] = j * ((alpha == 1.0) ? dlogq_f : dlogq_b);
-    g[2] = dlogq_f;
-    g[3] = dlogq_f * dlogq_f;
+    int at = 1 + 2 * AMC_NP;
+#pragma unroll
+    for (int p = 0; p < AMC_NP; ++p) {
+        g[1 + p] = j * ((alpha == 1.0) ? d_f[p] : d_b[p]);
+        g[1 + AMC_NP + p] = d_f[p];
+#pragma unroll
+        for (int q = p; q < AMC_NP; ++q) g[at++] = d_f[p] * d_f[q];
+    }
 }
 #endif
 
@@ -1911,6 +1975,141 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* rec
     double vals[AMC_MAX_LEARN * 4];
     pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, vals, n_samples);
+}
+
+// ---- policies with several parameters (handles of amc_create_vector_policy_model with n_params > 1) ----
+// gradients_data of a move: [j, grad j [P], grad logq_forward [P], g [P][P] row by row, n] -- GradientData, gradients.jl:41-61 --
+// AMC_GD_STRIDE_MAX doubles apart.  The estimator's launch takes one learnable move and leaves 1 + 2P + P(P+1)/2 records (g's
+// upper triangle: the outer product of a vector with itself is symmetric bit for bit).  Compiled offline, P at run time.
+#define AMC_GD_STRIDE_MAX (2 + 2 * AMC_MAX_NP + AMC_MAX_NP * AMC_MAX_NP)
+__host__ __device__ inline int pg_gd_stride(int np) { return 2 + 2 * np + np * np; }
+__host__ __device__ inline int pg_n_columns(int np) { return 1 + 2 * np + np * (np + 1) / 2; }
+
+// the 1 + 2P + P(P+1)/2 column totals `vals` of one move, spread out as GradientData's fields (g: both triangles)
+__host__ __device__ inline void pg_np_unpack(const double* vals, int np, double* gd)
+{
+    for (int i = 0; i < 1 + 2 * np; ++i) gd[i] = vals[i];
+    int at = 1 + 2 * np;
+    for (int p = 0; p < np; ++p)
+        for (int q = p; q < np; ++q) {
+            gd[1 + 2 * np + p * np + q] = vals[at];
+            gd[1 + 2 * np + q * np + p] = vals[at];
+            ++at;
+        }
+}
+
+// gradients_data[k] = gradients_data[k] + gd (estimator.jl:130) for the move lid: recs[n_ranks][columns][XS_WORDS]
+AMC_KERNEL_LINKAGE __global__ void pg_accumulate_np_kernel(const double* recs, int n_ranks, int np, int lid, double n_samples, double* acc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double vals[1 + 2 * AMC_MAX_NP + AMC_MAX_NP * (AMC_MAX_NP + 1) / 2], gd[AMC_GD_STRIDE_MAX];
+    pg_merge_slots(recs, n_ranks, pg_n_columns(np), vals);
+    pg_np_unpack(vals, np, gd);
+    double* a = acc + (size_t)lid * AMC_GD_STRIDE_MAX;
+    for (int i = 0; i < 1 + 2 * np + np * np; ++i) a[i] += gd[i];
+    a[1 + 2 * np + np * np] += n_samples;
+}
+
+// inv(A) of a P x P matrix, P <= 4, by Gauss-Jordan elimination with partial pivoting (rows swapped for the largest |pivot| of
+// the column, the first of equals), in this exact order of operations -- the oracle's amo_inv_small is the same sequence.
+// (Julia's inv(::Matrix) is LAPACK's getrf + getri: the same pivoting rule, another order of the same eliminations, so the
+// two differ by rounding, a few ulp times the condition number; for P = 1 both are 1 / a.)  false: a pivot was 0 or not finite.
+__host__ __device__ inline bool pg_inv_small(const double* A, int np, double* inv)
+{
+    double m[AMC_MAX_NP][2 * AMC_MAX_NP];
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) { m[i][j] = A[i * np + j]; m[i][np + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < np; ++c) {
+        int piv = c;
+        double best = m[c][c] < 0.0 ? -m[c][c] : m[c][c];
+        for (int r = c + 1; r < np; ++r) {
+            const double v = m[r][c] < 0.0 ? -m[r][c] : m[r][c];
+            if (v > best) { best = v; piv = r; }
+        }
+        if (!(best > 0.0) || !(best <= 1.7976931348623157e308)) return false;
+        if (piv != c)
+            for (int j = 0; j < 2 * np; ++j) { const double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
+        const double d = m[c][c];
+        for (int j = 0; j < 2 * np; ++j) m[c][j] = m[c][j] / d;
+        for (int r = 0; r < np; ++r) {
+            if (r == c) continue;
+            const double f = m[r][c];
+            for (int j = 0; j < 2 * np; ++j) m[r][j] = m[r][j] - f * m[c][j];
+        }
+    }
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) inv[i * np + j] = m[i][np + j];
+    return true;
+}
+
+// learning_step! (learning.jl:32-34, 50-52, 77-79, 103-105, 130-134, 160-164) on the averaged GradientData gd of a move with
+// np parameters theta: the array expressions of the reference written out left to right -- `eta * inv(F) * v` is
+// (eta * inv(F)) * v, a matrix-vector product adds its terms in index order, dot(a, b) likewise.  false: F is singular.
+__host__ __device__ inline bool pg_learning_step_np(int kind, double h0, double h1, int np, const double* gd, double* theta)
+{
+    const double j = gd[0];
+    const double* dj = gd + 1;
+    const double* dl = gd + 1 + np;
+    const double* g = gd + 1 + 2 * np;
+    double v[AMC_MAX_NP], step[AMC_MAX_NP];
+    double eta = h0;
+    const bool baseline = kind == OPT_BLPG || kind == OPT_BLAPG || kind == OPT_BLANPG;
+    for (int p = 0; p < np; ++p) v[p] = baseline ? dj[p] - j * dl[p] : dj[p];
+    if (kind == OPT_VPG || kind == OPT_BLPG || kind == OPT_BLAPG) {
+        if (kind == OPT_BLAPG) {
+            double dot = 0.0;
+            for (int p = 0; p < np; ++p) dot = p == 0 ? dj[0] * dj[0] : dot + dj[p] * dj[p];
+            eta = __builtin_sqrt(2.0 * h0 / (dot + h1));
+        }
+        for (int p = 0; p < np; ++p) step[p] = eta * v[p];
+    } else if (kind == OPT_NPG || kind == OPT_ANPG || kind == OPT_BLANPG) {
+        double F[AMC_MAX_NP * AMC_MAX_NP], Fi[AMC_MAX_NP * AMC_MAX_NP];
+        for (int a = 0; a < np; ++a)
+            for (int b = 0; b < np; ++b) F[a * np + b] = a == b ? g[a * np + b] + h1 * 1.0 : g[a * np + b];     // g + eps I
+        if (!pg_inv_small(F, np, Fi)) return false;
+        if (kind != OPT_NPG) {
+            double w[AMC_MAX_NP];
+            for (int a = 0; a < np; ++a) {
+                double t = Fi[a * np] * v[0];
+                for (int b = 1; b < np; ++b) t = t + Fi[a * np + b] * v[b];
+                w[a] = t;
+            }
+            double dot = v[0] * w[0];
+            for (int p = 1; p < np; ++p) dot = dot + v[p] * w[p];
+            eta = __builtin_sqrt(2.0 * h0 / dot);
+        }
+        for (int a = 0; a < np; ++a) {
+            double t = (eta * Fi[a * np]) * v[0];
+            for (int b = 1; b < np; ++b) t = t + (eta * Fi[a * np + b]) * v[b];
+            step[a] = t;
+        }
+    } else {
+        return true;                       // Static
+    }
+    for (int p = 0; p < np; ++p) theta[p] = theta[p] + step[p];
+    return true;
+}
+
+// make_step!(::PolicyGradientUpdate) (update.jl:50-57) for the move lid of a pool whose policy has np parameters: average
+// (gradients.jl:83-85), learning_step!, initialise_gradient_data.  A step that leaves a parameter non-finite (or meets a
+// singular metric) is not applied; status[0] is set instead.
+AMC_KERNEL_LINKAGE __global__ void pg_update_np_kernel(double* ptab, double* acc, int np, int lid, int kind, double h0, double h1, int* status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double* a = acc + (size_t)lid * AMC_GD_STRIDE_MAX;
+    const int nf = 1 + 2 * np + np * np;
+    const double n = a[nf];
+    double gd[AMC_GD_STRIDE_MAX];
+    for (int i = 0; i < nf; ++i) gd[i] = a[i] / n;
+    double theta[AMC_MAX_NP];
+    for (int p = 0; p < np; ++p) theta[p] = ptab[(p == 0 ? PT_SIGMA : PT_THETA1 + p - 1) * AMC_MAX_MOVES + lid];
+    bool ok = pg_learning_step_np(kind, h0, h1, np, gd, theta);
+    for (int p = 0; p < np; ++p) ok = ok && theta[p] - theta[p] == 0.0;          // finite
+    for (int i = 0; i <= nf; ++i) a[i] = 0.0;
+    if (ok)
+        for (int p = 0; p < np; ++p) ptab[(p == 0 ? PT_SIGMA : PT_THETA1 + p - 1) * AMC_MAX_MOVES + lid] = theta[p];
+    else
+        status[0] = 1;
 }
 
 // Sum, over rows[n_rows][NV][ROW words] that OTHER blocks wrote (agent-scope loads), of column c: integers, so the order is
@@ -2014,7 +2213,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     static_assert(!MIDFLUSH || SWEEP == 0, "a fused time step is launched only when its lanes stay within one accumulator capacity");
     constexpr bool QK = PgKind<POT>::Q;
     constexpr int ROW = PgKind<POT>::ROW;
-    constexpr int NV = NL * 4;
+    constexpr int NC = AMC_PG_NC;               // GradientData columns per learnable move (4 for one parameter)
+    static_assert(!QK || NC == 4, "the quanta of xs_gd_exponents are those of the one-parameter Gaussian policy");
+    constexpr int NV = NL * NC;
+    static_assert(NV <= 32, "the tail's wave 0 owns a row's columns");
     // the callback sums: reproducible (amc_xsum.h); the count of full trips lives on the scalar unit
     constexpr int RNC = RedCols<POT>::NC;
     RLanes<RNC> red;
@@ -2141,23 +2343,29 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                         dep[l] = 2;
                     }
                     double z0, z1;
-                    box_muller(philox4x32_10(draw_counter(pair, a.t_est, (uint32_t)(l * a.q_batch + q),
-                                                          STREAM_ESTIMATOR),
+#if AMC_NP > 1
+                    const uint32_t sample_id = (uint32_t)((a.l_base + l) * a.q_batch + q);
+#else
+                    const uint32_t sample_id = (uint32_t)(l * a.q_batch + q);
+#endif
+                    box_muller(philox4x32_10(draw_counter(pair, a.t_est, sample_id, STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1, s_math, mk);
 #if defined(AMC_USER_LOGQ) || defined(AMC_USER_SCALE)
-                    double s0[4], s1[4] = {0.0, 0.0, 0.0, 0.0};
+                    double s0[NC], s1[NC];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) s1[i] = 0.0;
 #if defined(AMC_USER_LOGQ)
-                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
-                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
+                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math, a.learn_ids[l]);
+                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math, a.learn_ids[l]);
 #else
                     pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
 #endif
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        r_deposit(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
-                        r_deposit(gr, QK ? 0 : l * 4 + i, s1[i], s_gr[threadIdx.x >> 6]);
+                    for (int i = 0; i < NC; ++i) {
+                        r_deposit(gr, QK ? 0 : l * NC + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
+                        r_deposit(gr, QK ? 0 : l * NC + i, s1[i], s_gr[threadIdx.x >> 6]);
                     }
 #else
                     if (QK) {
@@ -2191,6 +2399,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         x_nxt = load_x(first);
         if (BETA) b_nxt = load_b(first);
     }
+#ifdef AMC_USER_LOGQ
+    stage_user_theta(a.ptab);
+#endif
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
     real2 x_done = {(real_t)0.0, (real_t)0.0};
@@ -2243,7 +2454,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     // tried for the kind-Q columns: 12 far atomics per block onto 32-64 addresses each cost the launch 15 us, 67 -> 82 us.)
     flush_gd();
     __syncthreads();
-    if ((int)threadIdx.x < a.n_learn * 4) {
+    if ((int)threadIdx.x < a.n_learn * NC) {
         PgCol<QK> col;
         if (QK) col.q = q_block_total<QK ? NV : 1>(s_gq, QK ? (int)threadIdx.x : 0);
         else col.r = r_block_total<QK ? 1 : NV>(s_gr, QK ? 0 : (int)threadIdx.x);
@@ -2278,7 +2489,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     }
     __syncthreads();
     if (s_role != 1) return;
-    const int nv = a.n_learn * 4;
+    const int nv = a.n_learn * NC;
     const int wave = threadIdx.x >> 6;
     const bool lane0 = (threadIdx.x & 63) == 0;
     // wave w adds up columns w, w + 4, ...: lanes = the group's rows (PG_GROUP = 64 of them at most)

@@ -305,6 +305,21 @@ void amo_set_custom_proposal(double (*sample)(double, double, double), double (*
     g_custom_sample = sample; g_custom_logq = logq; g_custom_dlogq = dlogq;
 }
 
+/* A script-defined policy with SEVERAL parameters (Move.parameters is an array, src/metropolis.jl:140-147; GradientData keeps
+ * grad j / grad logq_forward as arrays of its shape and g as their outer product, PolicyGuided/gradients.jl:41-61,104-108):
+ * sample(z, x, theta), logq(delta, x, theta), dlogq(delta, x, theta, out[P]) compiled from the script's expressions.
+ * 0: none (the one-parameter forms above). */
+#define AMO_MAX_NP 4
+static int g_np = 1;
+static double (*g_vec_sample)(double, double, const double *) = 0;
+static double (*g_vec_logq)(double, double, const double *) = 0;
+static void (*g_vec_dlogq)(double, double, const double *, double *) = 0;
+void amo_set_vector_policy(int np, double (*sample)(double, double, const double *), double (*logq)(double, double, const double *),
+                           void (*dlogq)(double, double, const double *, double *))
+{
+    g_np = sample ? np : 1; g_vec_sample = sample; g_vec_logq = logq; g_vec_dlogq = dlogq;
+}
+
 /* A script-defined ACTION (the reference's Action interface, src/metropolis.jl:15-119; particle_1d.jl:30-40 are the
  * displacement's methods): perform(x, delta) = the position after perform_action!, invert(delta, x_new) = the parameter of
  * the inverted action.  0: the displacement (x + delta, -delta).  Used together with a script-defined proposal. */
@@ -338,6 +353,7 @@ struct amo_sim {
     int pot, K, sweepstep;
     int f32;                  /* Particle{Float32} / Displacement{Float32}: see the Float32 section below */
     double *sigma, *weight;   /* shared parameters / weights, length K */
+    double *theta_more;       /* parameters 1 .. 3 of every move (a policy with several): [K][AMO_MAX_NP - 1] */
     particle_t *chains;       /* Vector{Particle} */
     move_t *pools;            /* pools[c*K + k] */
     uint64_t seed;
@@ -419,6 +435,31 @@ static inline double julia_min(double a, double b)
     if (a != a) return a;
     if (b != b) return b;
     return b < a ? b : a;
+}
+
+/* the move's parameter array: theta[0] is what the one-parameter forms call sigma */
+static inline void move_theta(const struct amo_sim *s, int k, double th[AMO_MAX_NP])
+{
+    th[0] = s->sigma[k];
+    for (int p = 1; p < AMO_MAX_NP; ++p) th[p] = s->theta_more[k * (AMO_MAX_NP - 1) + p - 1];
+}
+
+static inline void script_perform_action(particle_t *p, const move_t *m, int pot, double *e1, double *e2);
+
+/* metropolis.jl:176-190 mc_step! for a policy with several parameters */
+static inline int mc_step_vec(particle_t *p, move_t *m, const double *theta, int pot, double z, double u)
+{
+    m->delta = g_vec_sample(z, p->x, theta);                           /* :177 sample_action! */
+    double logq_f = g_vec_logq(m->delta, p->x, theta);                 /* :178 at the old state */
+    double e1c, e2c;
+    script_perform_action(p, m, pot, &e1c, &e2c);                      /* :179 */
+    double dlogp_c = delta_log_target_density(e1c, p->beta, e2c, p->beta); /* :180 */
+    m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;  /* :181 */
+    double logq_b = g_vec_logq(m->delta, p->x, theta);                 /* :182 at the new state */
+    double alpha_c = julia_min(1.0, amo_exp(dlogp_c + logq_b - logq_f)); /* :183 */
+    if (alpha_c > u) return 1;                                         /* :184 */
+    script_perform_action(p, m, pot, &e1c, &e2c);                      /* :187 perform_action_cached! */
+    return 0;
 }
 
 /* metropolis.jl:176-190 mc_step!, with sample_action! (particle_1d.jl:56-59)
@@ -615,6 +656,11 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         amo_box_muller(v, zz);
         double u = amo_uniform_accept(amo_spare_accept12(v, half), va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
+        if (g_vec_logq) {
+            double th[AMO_MAX_NP];
+            move_theta(s, id, th);
+            move->accepted_calls += mc_step_vec(p, move, th, s->pot, zz[half], u);
+        } else
         move->accepted_calls += s->f32 ? mc_step_f32(p, move, s->sigma[id], s->pot, zz[half], u)
                                        : mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
         move->total_calls += 1;                                    /* :209 */
@@ -631,6 +677,7 @@ amo_sim *amo_create(int64_t n_chains, int64_t chain_offset, int potential, doubl
     s->sweepstep = sweepstep; s->seed = seed;
     s->sigma = (double *)malloc(sizeof(double) * (size_t)n_moves);
     s->weight = (double *)malloc(sizeof(double) * (size_t)n_moves);
+    s->theta_more = (double *)calloc((size_t)n_moves * (AMO_MAX_NP - 1), sizeof(double));
     memcpy(s->sigma, sigma, sizeof(double) * (size_t)n_moves);
     memcpy(s->weight, weight, sizeof(double) * (size_t)n_moves);
     s->chains = (particle_t *)calloc((size_t)(n_chains > 0 ? n_chains : 1), sizeof(particle_t));
@@ -646,7 +693,7 @@ amo_sim *amo_create(int64_t n_chains, int64_t chain_offset, int potential, doubl
 void amo_destroy(amo_sim *s)
 {
     if (!s) return;
-    free(s->sigma); free(s->weight); free(s->chains); free(s->pools); free(s);
+    free(s->sigma); free(s->theta_more); free(s->weight); free(s->chains); free(s->pools); free(s);
 }
 
 /* particle_1d.jl:13-15: Particle(x, beta) sets e = potential(x). */
@@ -707,6 +754,8 @@ void amo_get_counters(const amo_sim *s, int64_t *accepted, int64_t *total)
 }
 
 void amo_set_sigma(amo_sim *s, int k, double sigma) { s->sigma[k] = sigma; }
+void amo_set_theta(amo_sim *s, int k, int p, double v) { if (p == 0) s->sigma[k] = v; else s->theta_more[k * (AMO_MAX_NP - 1) + p - 1] = v; }
+double amo_get_theta(const amo_sim *s, int k, int p) { return p == 0 ? s->sigma[k] : s->theta_more[k * (AMO_MAX_NP - 1) + p - 1]; }
 double amo_get_sigma(const amo_sim *s, int k) { return s->sigma[k]; }
 uint64_t amo_get_step(const amo_sim *s) { return s->t; }
 void amo_set_step(amo_sim *s, uint64_t t) { s->t = t; }
@@ -1412,6 +1461,140 @@ void amo_pg_estimate_plain(amo_sim *s, int n_learn, const int *learn_ids, int q_
         out[l * 5 + 4] = (double)n;
     }
     s->t_est = t + 1;
+}
+
+/* ---- a policy with several parameters ----------------------------------------------------------------------------- */
+/* gradients.jl:93-109 pgmc_estimate: gd = [j, grad j [P], grad logq_forward [P], g [P][P] row by row] */
+static void pgmc_sample_vec(particle_t *p, move_t *m, const double *theta, int pot, double z, double *gd)
+{
+    const int P = g_np;
+    double d_f[AMO_MAX_NP], d_b[AMO_MAX_NP];
+    m->delta = g_vec_sample(z, p->x, theta);
+    double logq_f = g_vec_logq(m->delta, p->x, theta);                 /* :97 forward, at the old state */
+    g_vec_dlogq(m->delta, p->x, theta, d_f);
+    double e1, e2;
+    script_perform_action(p, m, pot, &e1, &e2);                        /* :98 */
+    double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :99 */
+    double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;   /* :100 */
+    m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;              /* :101 */
+    double logq_b = g_vec_logq(m->delta, p->x, theta);                 /* :102 backward, at the new state */
+    g_vec_dlogq(m->delta, p->x, theta, d_b);
+    script_perform_action(p, m, pot, &e1, &e2);                        /* :103 perform_action_cached! */
+    double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f));   /* :104 */
+    double j = r * alpha;                                              /* :105 */
+    gd[0] = j;
+    for (int a = 0; a < P; ++a) {
+        gd[1 + a] = j * (alpha == 1.0 ? d_f[a] : d_b[a]);              /* :106 */
+        gd[1 + P + a] = d_f[a];
+        for (int b = 0; b < P; ++b) gd[1 + 2 * P + a * P + b] = d_f[a] * d_f[b];   /* :107 */
+    }
+}
+
+/* estimator.jl:111-134 for such a policy: recs = n_learn x (2 + 2P + P^2) records, fields as above and n last; every field a
+ * running-top reproducible sum (the two triangles of g are the same sums: a product commutes). */
+void amo_pg_estimate_records_vec(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *recs)
+{
+    const int P = g_np, nf = 1 + 2 * P + P * P, stride = nf + 1;
+    uint64_t t = s->t_est;
+    for (int l = 0; l < n_learn; ++l) {
+        int lid = learn_ids[l];
+        double th[AMO_MAX_NP];
+        move_theta(s, lid, th);
+        xs_t col[1 + 2 * AMO_MAX_NP + AMO_MAX_NP * AMO_MAX_NP];
+        for (int i = 0; i < nf; ++i) col[i] = xs_new(XS_R, 0);
+        int64_t n = 0;
+        for (int64_t c = 0; c < s->M; ++c) {
+            uint64_t g = (uint64_t)(s->offset + c);
+            int half = (int)(g & 1u);
+            for (int q = 0; q < q_batch; ++q) {
+                uint32_t v[4];
+                double zz[2], gd[1 + 2 * AMO_MAX_NP + AMO_MAX_NP * AMO_MAX_NP];
+                draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
+                amo_box_muller(v, zz);
+                pgmc_sample_vec(&s->chains[c], &s->pools[c * s->K + lid], th, s->pot, zz[half], gd);
+                for (int i = 0; i < nf; ++i) xs_r_add(&col[i], gd[i]);
+                n += 1;
+            }
+        }
+        for (int i = 0; i < nf; ++i) xs_to_record(&col[i], recs + (size_t)(l * stride + i) * XS_WORDS);
+        xs_t cnt = xs_new(XS_PLAIN, 0);
+        cnt.plain = (double)n;
+        xs_to_record(&cnt, recs + (size_t)(l * stride + nf) * XS_WORDS);
+    }
+    s->t_est = t + 1;
+}
+
+/* inv(A), P x P, P <= 4: Gauss-Jordan elimination with partial pivoting -- the sequence of amc::pg_inv_small (amc_kernels.h),
+ * operation for operation.  (Julia's inv is LAPACK getrf / getri: the same pivots, another order of the eliminations.) */
+int amo_inv_small(const double *A, int np, double *inv)
+{
+    double m[AMO_MAX_NP][2 * AMO_MAX_NP];
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) { m[i][j] = A[i * np + j]; m[i][np + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < np; ++c) {
+        int piv = c;
+        double best = fabs(m[c][c]);
+        for (int r = c + 1; r < np; ++r)
+            if (fabs(m[r][c]) > best) { best = fabs(m[r][c]); piv = r; }
+        if (!(best > 0.0) || !(best <= 1.7976931348623157e308)) return 0;
+        if (piv != c)
+            for (int j = 0; j < 2 * np; ++j) { double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
+        double d = m[c][c];
+        for (int j = 0; j < 2 * np; ++j) m[c][j] = m[c][j] / d;
+        for (int r = 0; r < np; ++r) {
+            if (r == c) continue;
+            double f = m[r][c];
+            for (int j = 0; j < 2 * np; ++j) m[r][j] = m[r][j] - f * m[c][j];
+        }
+    }
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) inv[i * np + j] = m[i][np + j];
+    return 1;
+}
+
+/* learning.jl:32-34,50-52,77-79,103-105,130-134,160-164 learning_step! on arrays: gd = the AVERAGED GradientData
+ * [j, grad j, grad logq_forward, g]; theta is updated in place.  `eta * inv(F) * v` is (eta * inv(F)) * v; matrix-vector products
+ * and dot add their terms in index order.  0: F = g + eps I is singular (nothing applied). */
+int amo_learning_step_vec(int opt, double h0, double h1, int np, const double *gd, double *theta)
+{
+    double j = gd[0];
+    const double *dj = gd + 1, *dl = gd + 1 + np, *g = gd + 1 + 2 * np;
+    double v[AMO_MAX_NP], step[AMO_MAX_NP], eta = h0;
+    int baseline = opt == AMO_OPT_BLPG || opt == AMO_OPT_BLAPG || opt == AMO_OPT_BLANPG;
+    for (int p = 0; p < np; ++p) v[p] = baseline ? dj[p] - j * dl[p] : dj[p];
+    if (opt == AMO_OPT_VPG || opt == AMO_OPT_BLPG || opt == AMO_OPT_BLAPG) {
+        if (opt == AMO_OPT_BLAPG) {
+            double dot = dj[0] * dj[0];
+            for (int p = 1; p < np; ++p) dot = dot + dj[p] * dj[p];
+            eta = sqrt(2.0 * h0 / (dot + h1));
+        }
+        for (int p = 0; p < np; ++p) step[p] = eta * v[p];
+    } else if (opt == AMO_OPT_NPG || opt == AMO_OPT_ANPG || opt == AMO_OPT_BLANPG) {
+        double F[AMO_MAX_NP * AMO_MAX_NP], Fi[AMO_MAX_NP * AMO_MAX_NP];
+        for (int a = 0; a < np; ++a)
+            for (int b = 0; b < np; ++b) F[a * np + b] = a == b ? g[a * np + b] + h1 * 1.0 : g[a * np + b];
+        if (!amo_inv_small(F, np, Fi)) return 0;
+        if (opt != AMO_OPT_NPG) {
+            double w[AMO_MAX_NP] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int a = 0; a < np; ++a) {
+                double t = Fi[a * np] * v[0];
+                for (int b = 1; b < np; ++b) t = t + Fi[a * np + b] * v[b];
+                w[a] = t;
+            }
+            double dot = v[0] * w[0];
+            for (int p = 1; p < np; ++p) dot = dot + v[p] * w[p];
+            eta = sqrt(2.0 * h0 / dot);
+        }
+        for (int a = 0; a < np; ++a) {
+            double t = (eta * Fi[a * np]) * v[0];
+            for (int b = 1; b < np; ++b) t = t + (eta * Fi[a * np + b]) * v[b];
+            step[a] = t;
+        }
+    } else {
+        return 1;
+    }
+    for (int p = 0; p < np; ++p) theta[p] = theta[p] + step[p];
+    return 1;
 }
 
 /* learning.jl:32-34,50-52,77-79,103-105,130-134,160-164 learning_step! for P = 1;

@@ -99,6 +99,14 @@ void   amo_init_uniform(amo_sim *s, double lo, double hi);
 void   amo_get_state(const amo_sim *s, double *x, double *e);
 void   amo_get_counters(const amo_sim *s, int64_t *accepted, int64_t *total); /* [k*M + c] */
 void   amo_set_sigma(amo_sim *s, int k, double sigma);
+/* a policy with several parameters (Move.parameters as an array; amc_create_vector_policy_model is the engine's entry) */
+void   amo_set_vector_policy(int np, double (*sample)(double, double, const double *), double (*logq)(double, double, const double *),
+                             void (*dlogq)(double, double, const double *, double *));
+void   amo_set_theta(amo_sim *s, int k, int p, double v);
+double amo_get_theta(const amo_sim *s, int k, int p);
+void   amo_pg_estimate_records_vec(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *recs);
+int    amo_inv_small(const double *A, int np, double *inv);
+int    amo_learning_step_vec(int opt, double h0, double h1, int np, const double *gd, double *theta);
 double amo_get_sigma(const amo_sim *s, int k);
 uint64_t amo_get_step(const amo_sim *s);
 void   amo_set_step(amo_sim *s, uint64_t t);

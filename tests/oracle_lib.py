@@ -368,6 +368,59 @@ def install_custom_proposal(proposal) -> None:
         lib.amo_set_custom_action(None, None)
 
 
+def install_vector_policy(n_params, proposal) -> None:
+    """The oracle's global policy with SEVERAL parameters (amo_set_vector_policy): proposal = (sample, logq, [dlogq_0 .. dlogq_{P-1}]
+    or None[, perform, invert]) as C expressions in z / delta, x and theta0 .. theta{P-1} (`sigma` names theta0), compiled by
+    gcc.  None restores the one-parameter forms."""
+    import hashlib
+    import tempfile
+    lib = load()
+    lib.amo_set_vector_policy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.amo_set_vector_policy.restype = None
+    lib.amo_set_custom_action.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amo_set_custom_action.restype = None
+    if proposal is None:
+        lib.amo_set_vector_policy(1, None, None, None)
+        return
+    P = int(n_params)
+    sample, logq, dlogq, perform, invert = (list(proposal) + [None] * 4)[:5]
+    key = "v" + hashlib.sha1(repr((P, sample, logq, dlogq, perform, invert)).encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_vec_")
+        src, so = os.path.join(d, "vec.cpp"), os.path.join(d, f"vec_{key}.so")
+        names = "".join(f"const double theta{i} = {'theta[%d]' % i if i < P else '0.0'}; (void)theta{i}; " for i in range(4))
+        names += "const double sigma = theta0; (void)sigma; "
+        with open(src, "w") as f:
+            f.write(_CUSTOM_PROLOGUE +
+                    f"double amo_vec_sample(double z, double x, const double* theta) {{ {names} return ({sample}); }}\n"
+                    f"double amo_vec_logq(double delta, double x, const double* theta) {{ {names} return ({logq}); }}\n" +
+                    ("void amo_vec_dlogq(double delta, double x, const double* theta, double* out) { " + names +
+                     " ".join(f"out[{i}] = ({e});" for i, e in enumerate(dlogq)) + " }\n" if dlogq else "") +
+                    (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
+                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    L = _custom_libs[key]
+    lib.amo_set_vector_policy(P, C.cast(L.amo_vec_sample, C.c_void_p), C.cast(L.amo_vec_logq, C.c_void_p),
+                              C.cast(L.amo_vec_dlogq, C.c_void_p) if dlogq else None)
+    if perform:
+        lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
+    else:
+        lib.amo_set_custom_action(None, None)
+
+
+def learning_step_vec(opt: str, h0: float, h1: float, theta, gd) -> "np.ndarray | None":
+    """amo_learning_step_vec on the averaged GradientData [j, grad j, grad logq, g]; None: singular metric."""
+    lib = load()
+    lib.amo_learning_step_vec.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.amo_learning_step_vec.restype = C.c_int
+    th = np.ascontiguousarray(theta, dtype=np.float64).copy()
+    g = np.ascontiguousarray(gd, dtype=np.float64)
+    ok = lib.amo_learning_step_vec(OPTIMISERS[opt], float(h0), float(h1), int(th.size), _dptr(g), _dptr(th))
+    return th if ok else None
+
+
 def _potential_id(potential) -> int:
     expr = getattr(potential, "expr", None)
     if expr is not None:
@@ -380,11 +433,17 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None, proposal=None):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1):
         self.lib = load()
         self.dtype = dtype
+        self.n_params = int(n_params)
+        theta = None
+        if self.n_params > 1:
+            theta = [np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in sigma]
+            sigma = [float(v[0]) for v in theta]
         install_custom_scale(scale_expr)            # process-global like the potential: one simulation at a time
-        install_custom_proposal(proposal)
+        install_custom_proposal(None if self.n_params > 1 else proposal)
+        install_vector_policy(self.n_params, proposal if self.n_params > 1 else None)
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
@@ -398,6 +457,13 @@ class OracleSim:
             self.lib.amo_set_state_f32(self.h, 1)
         elif dtype != "f64":
             raise ValueError(f"dtype {dtype!r}")
+        self.lib.amo_set_theta.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+        self.lib.amo_set_theta.restype = None
+        self.lib.amo_get_theta.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.lib.amo_get_theta.restype = C.c_double
+        if theta is not None:
+            for k, v in enumerate(theta):
+                self.set_theta(k, v)
 
     def close(self):
         if self.h:
@@ -497,6 +563,24 @@ class OracleSim:
     def set_sigma(self, k, s):
         self.lib.amo_set_sigma(self.h, int(k), float(s))
 
+    def set_theta(self, k, v):
+        for p, t in enumerate(np.asarray(v, dtype=np.float64).reshape(-1)):
+            self.lib.amo_set_theta(self.h, int(k), p, float(t))
+
+    def get_theta(self, k):
+        return np.array([self.lib.amo_get_theta(self.h, int(k), p) for p in range(self.n_params)])
+
+    def pg_estimate_records_vec(self, learn_ids, q_batch):
+        """A policy with several parameters: records (n_learn, 2 + 2P + P^2, XS_WORDS) -- j, grad j, grad logq, g, n."""
+        n = len(learn_ids)
+        P = self.n_params
+        ids = (C.c_int * max(n, 1))(*[int(i) for i in learn_ids])
+        out = np.zeros((n, 2 + 2 * P + P * P, XS_WORDS))
+        self.lib.amo_pg_estimate_records_vec.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double)]
+        self.lib.amo_pg_estimate_records_vec.restype = None
+        self.lib.amo_pg_estimate_records_vec(self.h, n, ids, int(q_batch), _dptr(out))
+        return out
+
     def get_sigma(self, k):
         return self.lib.amo_get_sigma(self.h, int(k))
 
@@ -516,14 +600,16 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None):
+                 stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
+        self.n_params = int(n_params)
+        self.gd_stride = 2 + 2 * self.n_params + self.n_params ** 2
         self.per_chain_counters = bool(per_chain_counters) or self.n_moves > 1
         self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
                              weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype,
-                             scale_expr=scale_expr, proposal=proposal)
+                             scale_expr=scale_expr, proposal=proposal, n_params=n_params)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 
@@ -638,10 +724,13 @@ class OracleEngine:
         return self.reduce_records_value(*self.reduce_end_exact())
 
     def set_parameters(self, k, p):
-        self.sim.set_sigma(k, float(np.asarray(p).reshape(-1)[0]))
+        if self.n_params > 1:
+            self.sim.set_theta(k, p)
+        else:
+            self.sim.set_sigma(k, float(np.asarray(p).reshape(-1)[0]))
 
     def get_parameters(self, k):
-        return np.array([self.sim.get_sigma(k)])
+        return self.sim.get_theta(k) if self.n_params > 1 else np.array([self.sim.get_sigma(k)])
 
     def parameters_begin(self):           # amc_parameters_begin: sigma as of now, fetched later
         assert getattr(self, "_params_pending", None) is None, "a parameter read was begun while another was in flight"
@@ -653,36 +742,49 @@ class OracleEngine:
         return out
 
     def pg_estimate(self, learn_ids, q_batch):
+        if self.n_params > 1:
+            rec = self.sim.pg_estimate_records_vec(learn_ids, q_batch)
+            return xsum_round(rec).reshape(rec.shape[0], rec.shape[1])
         return self.sim.pg_estimate(learn_ids, q_batch)
 
     def pg_estimate_exact(self, learn_ids, q_batch):
+        if self.n_params > 1:
+            return self.sim.pg_estimate_records_vec(learn_ids, q_batch)
         return self.sim.pg_estimate_records(learn_ids, q_batch)
 
     # device-resident estimator / update of the HIP engine (amc_pg_accumulate / amc_pg_update / amc_pgmc_steps),
     # restated on the host: running sums per move, learning step by the oracle's amo_learning_step
     def pg_accumulate(self, learn_ids, q_batch):
-        gd = self.sim.pg_estimate(learn_ids, q_batch)
+        gd = self.pg_estimate(learn_ids, q_batch)
         acc = self.__dict__.setdefault("_gd_acc", {})
         for row, k in zip(gd, learn_ids):
-            acc[k] = acc.get(k, np.zeros(5)) + row
+            acc[k] = acc.get(k, np.zeros(self.gd_stride)) + row
         self.pgmc_calls = getattr(self, "pgmc_calls", 0)
 
     def pg_update(self, learn_ids, kinds, hyper0, hyper1):
         acc = self.__dict__.setdefault("_gd_acc", {})
         names = {v: k for k, v in OPTIMISERS.items()}
         for k, kind, h0, h1 in zip(learn_ids, kinds, hyper0, hyper1):
-            a = acc.get(k, np.zeros(5))
+            a = acc.get(k, np.zeros(self.gd_stride))
+            if self.n_params > 1:
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    gd = a[:-1] / a[-1]                                   # average (gradients.jl:83-85)
+                nxt = learning_step_vec(names[int(kind)], float(h0), float(h1), self.sim.get_theta(k), gd)
+                if nxt is not None and np.all(np.isfinite(nxt)):         # as the engine: a step that cannot be taken is not applied
+                    self.sim.set_theta(k, nxt)
+                acc[k] = np.zeros(self.gd_stride)
+                continue
             gd4 = [a[i] / a[4] for i in range(4)]
             self.sim.set_sigma(k, learning_step(names[int(kind)], float(h0), float(h1), self.sim.get_sigma(k), gd4))
             acc[k] = np.zeros(5)
 
     def pg_get_accumulated(self, learn_ids):
         acc = self.__dict__.setdefault("_gd_acc", {})
-        return np.array([acc.get(k, np.zeros(5)) for k in learn_ids]).reshape(len(learn_ids), 5)
+        return np.array([acc.get(k, np.zeros(self.gd_stride)) for k in learn_ids]).reshape(len(learn_ids), self.gd_stride)
 
     def pg_set_accumulated(self, learn_ids, rows):
         acc = self.__dict__.setdefault("_gd_acc", {})
-        for k, row in zip(learn_ids, np.asarray(rows, dtype=np.float64).reshape(len(learn_ids), 5)):
+        for k, row in zip(learn_ids, np.asarray(rows, dtype=np.float64).reshape(len(learn_ids), self.gd_stride)):
             acc[k] = row.copy()
 
     def pgmc_steps(self, n_steps, learn_ids, q_batch, kinds=None, hyper0=(), hyper1=(), reduce_begin=False):
