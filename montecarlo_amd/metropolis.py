@@ -75,13 +75,21 @@ class Metropolis(AriannaAlgorithm):
         scripts = {((m.policy.sample, m.policy.logq, m.policy.dlogq) +
                     ((m.action.perform, m.action.invert) if hasattr(m.action, "perform") else (None, None)))
                    if hasattr(m.policy, "logq") else None for m in self.pool}
+        n_params = 1
         if scripts != {None}:
             if len(scripts) != 1:
                 raise ValueError("all moves of a pool must share one policy (and one action): one ScriptPolicy, or none")
             extra["proposal"] = scripts.pop()
+            # a policy with several parameters (ScriptPolicy(n_params=P)): the engine takes one parameter vector per move
+            n_params = int(getattr(self.pool[0].policy, "n_params", 1))
+            if n_params > 1:
+                pr = extra["proposal"]
+                extra["n_params"] = n_params
+                extra["proposal"] = pr[:2] + (None if pr[2] is None else list(pr[2]),) + pr[3:]
+        self.n_params = n_params
         self.engine = factory(n_chains=stop - start, chain_offset=start, n_chains_global=len(chains), **extra,
                               potential=chains.potential, beta=chains.beta,
-                              sigma=[m.sigma for m in self.pool], weight=[m.weight for m in self.pool],
+                              sigma=[(m.parameters.copy() if n_params > 1 else m.sigma) for m in self.pool], weight=[m.weight for m in self.pool],
                               seed=self.seed, sweepstep=self.sweepstep,
                               per_chain_counters=bool(per_chain_counters) or len(self.pool) > 1, device=device)
         # sharded on GPUs: the engine gets an RCCL communicator of its own (callback sums and the estimator's fold are then

@@ -130,6 +130,13 @@ def initialise_gradient_data(parameters: np.ndarray) -> GradientData:           
     return GradientData(0.0, z.copy(), z.copy(), np.outer(z, z), 0)
 
 
+def gradient_data_from_row(row: np.ndarray, n_params: int) -> GradientData:
+    """One move's row of the engine's estimator output, [j, grad j [P], grad logq [P], g [P][P], n] (AMC_GD_STRIDE_P)."""
+    P = int(n_params)
+    return GradientData(float(row[0]), np.array(row[1:1 + P]), np.array(row[1 + P:1 + 2 * P]),
+                        np.array(row[1 + 2 * P:1 + 2 * P + P * P]).reshape(P, P), int(round(row[1 + 2 * P + P * P])))
+
+
 def average(gd: GradientData) -> GradientData:                                   # gradients.jl:83-85
     with np.errstate(divide="ignore", invalid="ignore"):
         return GradientData(gd.j / gd.n if gd.n else float("nan"), gd.grad_j / gd.n, gd.grad_logq_forward / gd.n,
@@ -217,10 +224,9 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         """Device-resident mode: pull the running gradients_data / objectives to the host (synchronises)."""
         if self.device_resident and self.learn_ids:
             acc = self.metropolis.engine.pg_get_accumulated(self.learn_ids)
-            for k in range(len(self.learn_ids)):
-                self.gradients_data[k] = GradientData(float(acc[k, 0]), np.array([acc[k, 1]]), np.array([acc[k, 2]]),
-                                                      np.array([[acc[k, 3]]]), int(round(acc[k, 4])))
-                self.objectives[k] = acc[k, 0] / acc[k, 4] if acc[k, 4] else 0.0
+            for k, lid in enumerate(self.learn_ids):
+                self.gradients_data[k] = gradient_data_from_row(acc[k], self.parameters_list[lid].shape[0])
+                self.objectives[k] = acc[k, 0] / acc[k, -1] if acc[k, -1] else 0.0
 
     def make_step(self, simulation: Simulation) -> None:
         """estimator.jl:111-134: fold GradientData over chains x q_batch samples per learnable move."""
@@ -237,9 +243,8 @@ class PolicyGradientEstimator(AriannaAlgorithm):
         # every number of shards
         merged = sharding.allreduce_xsum(local, self.metropolis.engine)
         total = xsum_round(merged).reshape(local.shape[0], local.shape[1])
-        for k in range(len(self.learn_ids)):
-            gd = GradientData(float(total[k, 0]), np.array([total[k, 1]]), np.array([total[k, 2]]),
-                              np.array([[total[k, 3]]]), int(round(total[k, 4])))
+        for k, lid in enumerate(self.learn_ids):
+            gd = gradient_data_from_row(total[k], self.parameters_list[lid].shape[0])
             self.gradients_data[k] = self.gradients_data[k] + gd                   # :130
             self.objectives[k] = self.gradients_data[k].j / self.gradients_data[k].n   # :131
 

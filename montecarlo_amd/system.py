@@ -157,10 +157,30 @@ class ScriptPolicy(Policy):
       ``dlogq``   d logq / d sigma (the reference's AD backends, gradients.jl:28-33) -- needed by the estimator only
     e.g. a drifted Gaussian (Langevin) proposal for U = x^2, beta = 2:
       ScriptPolicy("-2.0*sigma*sigma*x + sigma*z", "-(delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x)/(2.0*sigma*sigma) - amc_log(sigma)", ...)
-    All moves of a pool share the policy."""
+    All moves of a pool share the policy.
+
+    SEVERAL parameters (Move.parameters is an array in the reference, src/metropolis.jl:140-147; grad j, grad logq and the
+    P x P metric g of GradientData follow its shape, PolicyGuided/gradients.jl:41-61): ``n_params`` = P <= 4, the expressions
+    say theta0 .. theta{P-1} (``sigma`` stays a name of theta0) and ``dlogq`` lists the P partial derivatives -- e.g. a
+    Gaussian displacement with a learnable drift,
+      ScriptPolicy("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
+                   ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"], n_params=2)"""
     sample: str = "sigma*z"
     logq: str = "-(delta*delta)/(2.0*sigma*sigma) - amc_log(sigma)"
-    dlogq: Optional[str] = None
+    dlogq: Optional[object] = None          # one expression, or the list of the n_params partials
+    n_params: int = 1
+
+    def __post_init__(self):
+        if isinstance(self.dlogq, (list, tuple)):
+            object.__setattr__(self, "dlogq", tuple(self.dlogq))        # hashable: Metropolis compares the moves' policies
+            if len(self.dlogq) != self.n_params:
+                raise ValueError(f"dlogq must list the {self.n_params} partial derivatives of logq")
+            if self.n_params == 1:
+                object.__setattr__(self, "dlogq", self.dlogq[0])
+        elif self.dlogq is not None and self.n_params != 1:
+            raise ValueError(f"dlogq must list the {self.n_params} partial derivatives of logq")
+        if not 1 <= int(self.n_params) <= 4:
+            raise ValueError("n_params must be in [1, 4]")
 
     @staticmethod
     def setup_parameters() -> Dict[str, float]:
@@ -187,8 +207,10 @@ class Move:
         if isinstance(p, dict):
             p = [p["sigma"]]
         self.parameters = np.atleast_1d(np.asarray(p, dtype=np.float64)).copy()
-        if self.parameters.shape != (1,):
-            raise ValueError("StandardGaussian has exactly one parameter (sigma)")
+        n_params = int(getattr(self.policy, "n_params", 1))
+        if self.parameters.shape != (n_params,):
+            raise ValueError("StandardGaussian has exactly one parameter (sigma)" if n_params == 1
+                             else f"this policy has {n_params} parameters")
         if not isinstance(self.action, (Displacement, ScriptAction)) or not isinstance(self.policy, (StandardGaussian, ScaledGaussian, ScriptPolicy)):
             raise TypeError("the HIP engine supports Displacement / ScriptAction actions with a StandardGaussian, ScaledGaussian or ScriptPolicy policy only")
         if isinstance(self.action, ScriptAction) and not isinstance(self.policy, ScriptPolicy):

@@ -602,3 +602,50 @@ def test_policy_gradient_sums_against_quadrature_at_full_size(gpu, sigma):
     assert moved == pytest.approx((acc1[0] - acc0[0]) / (tot1[0] - tot0[0]), abs=6 * 0.5 / np.sqrt(m))
     assert 0.05 < float(np.mean((after != before) & (np.abs(after - before) <= 1e-9))) < 0.5      # the quirk is there
     e.close()
+
+
+def test_two_parameter_gradient_sums_against_quadrature_at_full_size(gpu):
+    """The same for a policy with TWO parameters, delta = mu + sigma z (amc_create_vector_policy_model): the proposal is not
+    symmetric, log q_b - log q_f = -2 delta mu / sigma^2 enters the acceptance, and with the chains at stationarity
+        j / n           -> J(mu, sigma) = E[delta^2 min(1, exp(dlogp + logq_b - logq_f))]
+        grad_j / n      -> (dJ/dmu, dJ/dsigma)                 (score-function identity, gradients.jl:106)
+        grad_logq / n   -> (0, 0),   g / n -> diag(1, 2) / sigma^2   (Fisher information of a Gaussian's mean and scale)
+    J by a 2-D quadrature on the host, its gradient by central differences; tolerances are 6 standard errors of 1e7 samples."""
+    beta, mu, sigma = 2.0, 0.15, 0.9
+    sample = "theta0 + theta1*z"
+    logq = "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)"
+    dlogq = ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"]
+    e = gpu.HipEngine(n_chains=M_FULL, potential="harmonic", beta=beta, sigma=[[mu, sigma]], weight=[1.0], seed=78,
+                      per_chain_counters=False, proposal=(sample, logq, dlogq), n_params=2)
+    e.init_uniform(-2, 2)
+    e.sweep(300)
+    x = e.download_strided(0, 10, 1_000_000)
+    assert np.mean(x) == pytest.approx(0.0, abs=6 * 0.5 / 1e3) and np.mean(x * x) == pytest.approx(1 / (2 * beta), abs=3e-3)   # still the target
+    g = e.pg_estimate([0], 1)[0]
+    n = g[-1]
+    assert g.shape == (10,) and n == M_FULL
+
+    def J(m, s):
+        xx = np.linspace(-3.5, 3.5, 2801)[:, None]
+        d = np.linspace(m - 8.0 * s, m + 8.0 * s, 6401)[None, :]
+        px = np.exp(-beta * xx * xx)
+        px = px / np.trapezoid(px[:, 0], xx[:, 0])
+        qd = np.exp(-(d - m) ** 2 / (2 * s * s)) / np.sqrt(2 * np.pi * s * s)
+        alpha = np.minimum(1.0, np.exp(-beta * ((xx + d) ** 2 - xx * xx) - 2.0 * d * m / (s * s)))
+        inner = np.trapezoid(qd * d * d * alpha, d[0], axis=1)
+        return float(np.trapezoid(px[:, 0] * inner, xx[:, 0]))
+
+    j_true = J(mu, sigma)
+    dj_mu = (J(mu + 1e-3, sigma) - J(mu - 1e-3, sigma)) / 2e-3
+    dj_sg = (J(mu, sigma + 1e-3) - J(mu, sigma - 1e-3)) / 2e-3
+    se = 1.0 / np.sqrt(n)
+    assert g[0] / n == pytest.approx(j_true, abs=6 * 1.5 * (sigma ** 2 + mu ** 2) * se + 2e-5)
+    assert g[1] / n == pytest.approx(dj_mu, abs=6 * 3.0 * se + 1e-4)         # sd(j dlogq/dmu) ~ sigma |z|^3 / sigma: a few units
+    assert g[2] / n == pytest.approx(dj_sg, abs=6 * 4.0 * sigma * se + 1e-4)
+    assert abs(dj_mu) > 5 * 6 * 3.0 * se                                      # the gradient along the drift is many tolerances from zero: a real check
+    assert g[3] / n == pytest.approx(0.0, abs=6 / sigma * se) and g[4] / n == pytest.approx(0.0, abs=6 * np.sqrt(2.0) / sigma * se)
+    G = g[5:9].reshape(2, 2) / n
+    assert G[0, 0] == pytest.approx(1 / sigma ** 2, rel=6 * np.sqrt(2.0) * se)            # var(z^2) = 2
+    assert G[1, 1] == pytest.approx(2 / sigma ** 2, rel=6 * np.sqrt(28.0) / 2.0 * se)
+    assert G[0, 1] == G[1, 0] and G[0, 1] == pytest.approx(0.0, abs=6 * np.sqrt(10.0) / sigma ** 2 * se)   # E[z (z^2-1)] = 0, var = 10
+    e.close()

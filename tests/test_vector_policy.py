@@ -242,3 +242,52 @@ def test_theta0_is_another_name_of_sigma(gpu):
     assert np.array_equal(bits(a.download_state()[0]), bits(b.download_state()[0]))
     a.close()
     b.close()
+
+
+# ---- the host mirror ------------------------------------------------------------------------------------------------------
+
+def _pgmc_simulation(ma, engine_factory, path, device_resident, steps=24):
+    chains = ma.ParticleChains.uniform(3001, BETA, -2.0, 2.0)
+    pol = ma.ScriptPolicy(DRIFT[0], DRIFT[1], DRIFT[2], n_params=2)
+    pool = [ma.Move(ma.Displacement(0.0), pol, [0.1, 0.3], 0.5), ma.Move(ma.Displacement(0.0), pol, [0.0, 0.8], 0.5)]
+    opts = [ma.Static(), ma.BLANPG(1e-5, 1e-6)]
+    algos = [dict(algorithm=ma.Metropolis, pool=pool, seed=3, engine_factory=engine_factory),
+             dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=opts, q_batch_size=2,
+                  device_resident=device_resident),
+             dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=list(range(0, steps + 1, 3))),
+             dict(algorithm=ma.StoreParameters, dependencies=(ma.Metropolis,), scheduler=list(range(0, steps + 1, 6)))]
+    sim = ma.Simulation(chains, algos, steps, path=str(path))
+    ma.run(sim)
+    return chains, pool
+
+
+def test_host_mirror_runs_a_two_parameter_policy(oracle, tmp_path):
+    """The reference's own arrangement -- [Metropolis, PolicyGradientEstimator, PolicyGradientUpdate] with a ScriptPolicy of
+    two parameters -- through the host mirror on the CPU test double: the host path (GradientData folded and learning_step!
+    taken on the host, numpy) and the engine-resident path agree to rounding (numpy's inv against the engine's elimination)."""
+    import montecarlo_amd as ma
+    with pytest.raises(ValueError, match="this policy has 2 parameters"):
+        ma.Move(ma.Displacement(0.0), ma.ScriptPolicy(DRIFT[0], DRIFT[1], DRIFT[2], n_params=2), [0.3], 1.0)
+    with pytest.raises(ValueError, match="must list the 2 partial"):
+        ma.ScriptPolicy(DRIFT[0], DRIFT[1], DRIFT[2][0], n_params=2)
+    ch_h, pool_h = _pgmc_simulation(ma, oracle.OracleEngine, tmp_path / "host", False)
+    ch_d, pool_d = _pgmc_simulation(ma, oracle.OracleEngine, tmp_path / "dev", True)
+    assert pool_h[0].parameters.tolist() == [0.1, 0.3]                      # Static
+    assert not np.array_equal(pool_h[1].parameters, [0.0, 0.8])
+    assert np.allclose(pool_h[1].parameters, pool_d[1].parameters, rtol=1e-9, atol=1e-12)
+    # StoreParameters writes "$(t) $(collect(parameters))" (src/metropolis.jl:438-443): "24 [a, b]"
+    lines = (tmp_path / "dev" / "parameters" / "2" / "parameters.dat").read_text().splitlines()
+    assert len(lines) == 5 and lines[0] == "0 [0.0, 0.8]" and lines[-1].startswith("24 [")
+    last = [float(v) for v in lines[-1].split(" ", 1)[1].strip("[]").split(",")]
+    assert last == pool_d[1].parameters.tolist()
+    oracle.install_vector_policy(1, None)
+
+
+@pytest.mark.gpu
+def test_host_mirror_on_the_engine_equals_the_test_double(gpu, oracle, tmp_path):
+    import montecarlo_amd as ma
+    ch_g, pool_g = _pgmc_simulation(ma, None, tmp_path / "gpu", True)
+    ch_o, pool_o = _pgmc_simulation(ma, oracle.OracleEngine, tmp_path / "cpu", True)
+    assert np.array_equal(bits(pool_g[1].parameters), bits(pool_o[1].parameters))
+    assert np.array_equal(bits(ch_g.x), bits(ch_o.x))
+    oracle.install_vector_policy(1, None)
