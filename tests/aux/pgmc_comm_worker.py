@@ -27,10 +27,19 @@ for mode in ("comm", "host"):
     chains = ma.ParticleChains.uniform(60_000, 2.0, -2.0, 2.0)
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.2}, 0.6),
             ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.1}, 0.4))
+    optimisers = (ma.Static(), ma.VPG(0.3))
+    if os.environ.get("AMC_TEST_POLICY") == "drift2":
+        # a policy with TWO parameters (delta = theta0 + theta1 z) and a natural-gradient optimiser: P x P metric, records of
+        # 1 + 2P + P(P+1)/2 columns per learnable move through the communicator
+        pol = ma.ScriptPolicy("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
+                              ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"],
+                              n_params=2)
+        pool = (ma.Move(ma.Displacement(0.0), pol, [0.0, 0.2], 0.6), ma.Move(ma.Displacement(0.0), pol, [0.05, 0.1], 0.4))
+        optimisers = (ma.Static(), ma.BLANPG(1e-4, 1e-6))
     # AMC_TEST_DEVICE: every rank on that device (the shared-memory RCCL stand-in of tests/aux/fake_rccl.c lets ranks share a GPU)
     dev = {} if "AMC_TEST_DEVICE" not in os.environ else {"device": int(os.environ["AMC_TEST_DEVICE"])}
     al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, **dev),
-          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), ma.VPG(0.3)),
+          dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=optimisers,
                q_batch_size=2, device_resident=(None if mode == "comm" else False)),
           dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,)),
           # callbacks between the grouped time steps: their sums are all-reduced on the engine's communication stream
@@ -46,7 +55,8 @@ for mode in ("comm", "host"):
             est.device_resident = True
         ma.run(sim)
     eng = sim.algorithms[0].engine
-    out[mode] = dict(sigma=[m.sigma for m in pool], device_resident=est.device_resident,
+    out[mode] = dict(sigma=[m.sigma for m in pool], parameters=[[float(v).hex() for v in m.parameters] for m in pool],
+                     device_resident=est.device_resident,
                      connected=bool(getattr(sim.algorithms[0], "_comm_connected", False)), x0=float(chains.x[0]),
                      energy=[[t, float(v)] for t, v in sim.algorithms[3].rows[0]],
                      acceptance=[[t, [float(a) for a in v]] for t, v in sim.algorithms[3].rows[1]],

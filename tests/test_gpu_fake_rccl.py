@@ -77,6 +77,26 @@ def test_two_ranks_share_one_gpu_pgmc_with_callbacks(fake_rccl):
     assert two["comm"]["x_head"] == one["comm"]["x_head"]
 
 
+def test_two_ranks_two_parameter_policy(fake_rccl):
+    """The same with a policy of TWO parameters and BLANPG (amc_create_vector_policy_model): one estimator launch, one gather of
+    8 records and one accumulate launch per learnable move, the 2 x 2 metric inverted on the device -- two shards against one:
+    the parameter vectors, the callback rows and the chains are equal bit for bit; the host path (numpy's inv) agrees to
+    rounding."""
+    env = dict(AMC_TEST_GROUP="store", AMC_RCCL_LIBRARY=fake_rccl, AMC_TEST_DEVICE="0", AMC_TEST_POLICY="drift2")
+    worker = [os.path.join(AUX, "pgmc_comm_worker.py")]
+    two = json.loads([ln for ln in launch(worker, 2, env).stdout.splitlines() if ln.startswith("{")][-1])
+    one = json.loads([ln for ln in launch(worker, 1, env).stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["comm"]["connected"] and two["comm"]["device_resident"] and two["comm"]["comm"]["n_ranks"] == 2
+    assert two["comm"]["parameters"] == one["comm"]["parameters"]
+    assert two["comm"]["parameters"][0] == [float(0.0).hex(), float(0.2).hex()]                       # Static
+    learned = [float.fromhex(v) for v in two["comm"]["parameters"][1]]
+    assert learned != [0.05, 0.1] and 0.1 < learned[1] < 2.0
+    assert two["comm"]["energy"] == one["comm"]["energy"] and two["comm"]["x_head"] == one["comm"]["x_head"]
+    host = [float.fromhex(v) for v in two["host"]["parameters"][1]]
+    assert np.allclose(host, learned, rtol=1e-7)          # 120 learning steps with numpy's inv against the engine's elimination
+    assert two["host"]["parameters"] == one["host"]["parameters"]                                     # the host path is shard-invariant too
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_gpus_n_over_the_stand_in(fake_rccl, world):
     """bench.py under the driver's launch line with N ranks on device 0: the RCCL route (not the store fallback), callbacks
