@@ -2011,7 +2011,7 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_np_kernel(const double* recs, i
 }
 
 // inv(A) of a P x P matrix, P <= 4, by Gauss-Jordan elimination with partial pivoting (rows swapped for the largest |pivot| of
-// the column, the first of equals), in this exact order of operations -- the oracle's amo_inv_small is the same sequence.
+// the column, the first of equals), in this exact order of operations -- the tests' CPU restatement is the same sequence.
 // (Julia's inv(::Matrix) is LAPACK's getrf + getri: the same pivoting rule, another order of the same eliminations, so the
 // two differ by rounding, a few ulp times the condition number; for P = 1 both are 1 / a.)  false: a pivot was 0 or not finite.
 __host__ __device__ inline bool pg_inv_small(const double* A, int np, double* inv)
