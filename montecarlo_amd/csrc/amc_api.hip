@@ -28,7 +28,8 @@
 namespace amc {
 #define AMC_PG_FUSED(POT, NL, BETA)                                                                             \
     extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false>(const PgArgs, const SweepArgs); \
-    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, true>(const PgArgs, const SweepArgs)
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, true>(const PgArgs, const SweepArgs);  \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false, true>(const PgArgs, const SweepArgs)
 AMC_PG_FUSED(POT_HARMONIC, 1, false);
 AMC_PG_FUSED(POT_HARMONIC, 1, true);
 AMC_PG_FUSED(POT_HARMONIC, 2, false);
@@ -421,8 +422,11 @@ int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw,
 template <int POT>
 int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
-    if (mid && sweep != 0) return fail(AMC_ERR_STATE, "launch_pg: a fused time step that needs a flush mid-launch (see pg_fits_without_flush)");
+    if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on launches that need no flush mid-launch (see pg_fits_without_flush)");
     if (mid) {
+        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, false, true>(h, a, sw, grid);
+        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, false, true>(h, a, sw, grid);
+        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, false, true>(h, a, sw, grid);
         switch (nl_cap) {
         case 1: return launch_pg_nls<POT, 1, 0, false, true>(h, a, sw, grid);
         case 2: return launch_pg_nls<POT, 2, 0, false, true>(h, a, sw, grid);
@@ -604,7 +608,7 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
     // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
     const bool licm_off = inst.rfind("amc::pg_estimate_kernel<", 0) == 0 &&
-                          (inst.find(",2,false>") != std::string::npos || inst.find(",2,true>") != std::string::npos);
+                          (inst.find(",2,false,") != std::string::npos || inst.find(",2,true,") != std::string::npos);      // <.., SWEEP = 2, REDUCE, MIDFLUSH>
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : ""));
     {
@@ -734,7 +738,7 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
 
 int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
-    if (mid && sweep != 0) return fail(AMC_ERR_STATE, "launch_pg_custom: a fused time step that needs a flush mid-launch");
+    if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg_custom: the callback sums ride on launches that need no flush mid-launch");
     const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
                              std::to_string(sweep) + "," + tf(reduce) + "," + tf(mid) + ">";
     void* params[] = {&a, &sw};
@@ -1975,8 +1979,8 @@ static int pg_grid(const amc_handle* h)
 
 // An estimator launch puts 2 q_batch summands per trip into each of a lane's GradientData accumulators, which hold XS_GD_LANE_CAP
 // (kind Q: the built-in potentials) or XS_LANE_CAP (kind R: hiprtc forms) of them between two flushes (amc_xsum.h).  Launches
-// whose lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH);
-// the fused time step exists in that form only.
+// whose lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH); the
+// others empty full accumulators into integers of the lane on the way.
 static bool pg_fits_without_flush(const amc_handle* h, int q_batch)
 {
     const int64_t pairs = (h->M + 1) / 2;
@@ -2303,10 +2307,9 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
     const bool fused = h->n_params == 1 && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
-                       log_form(h) != AMC_LOG_BYTES && pg_fits_without_flush(h, q_batch) &&
-                       std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
-    // the callback sums ride in the last fused launch (rows the host sums: K <= 4)
-    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h);
+                       log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
+    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h) && pg_fits_without_flush(h, q_batch);
     int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);

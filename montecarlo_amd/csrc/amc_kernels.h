@@ -2210,7 +2210,6 @@ template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false, bool M
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
-    static_assert(!MIDFLUSH || SWEEP == 0, "a fused time step is launched only when its lanes stay within one accumulator capacity");
     constexpr bool QK = PgKind<POT>::Q;
     constexpr int ROW = PgKind<POT>::ROW;
     constexpr int NC = AMC_PG_NC;               // GradientData columns per learnable move (4 for one parameter)
@@ -2285,10 +2284,58 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     } else {
         r_init(gr, s_gr[threadIdx.x >> 6]);
     }
-    auto flush_move = [&](int l) {       // kind Q: the four accumulators of learnable move l
+    // MIDFLUSH, kind Q: a full f64 accumulator is emptied into an INTEGER of the lane (bits(S) - bits(C), S back to C: eight
+    // vector instructions per column, nothing crosses lanes), and the lanes' integers go through the wave once, at the end --
+    // a wave-wide flush every 16 samples cost launches with q_batch 4 a sixth of their time.  |k| < 2^51 per emptying: the
+    // 64-bit integer takes LANE_FLUSHES of them before it is itself flushed (wave-wide, in halves of 32 bits).
+    constexpr bool LANE_INT = QK && MIDFLUSH;
+    constexpr int LANE_FLUSHES = 1024;
+    // (the integers live in LDS, one word per thread and column -- conflict-free --: eight more registers per move cost the
+    // kernel a wave per SIMD)
+    __shared__ long long s_kl[LANE_INT ? NL * 4 : 1][LANE_INT ? AMC_BLOCK : 1];
+    uint32_t kl_bad = 0u;                 // bit l * 4 + i: column i of move l met a value that is no multiple of its quantum (NaN, Inf)
+    int kl_n[LANE_INT ? NL : 1];
+#pragma unroll
+    for (int l = 0; l < (LANE_INT ? NL : 1); ++l) {
+        kl_n[l] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_kl[LANE_INT ? l * 4 + i : 0][LANE_INT ? threadIdx.x : 0] = 0ll;
+    }
+    auto flush_move = [&](int l) {       // kind Q: the four accumulators of learnable move l, and what the lane's integers hold, into the wave's slots
         uint64_t cb[4];
         q_constants(l, cb);
         q_flush<4>(g[QK ? l : 0], cb, s_gq[threadIdx.x >> 6] + (QK ? l * 4 : 0));
+        if (LANE_INT) {
+            // one column after the other: this sits inside the sampling loop (rarely run), where registers are dear
+            for (int i = 0; i < 4; ++i) {
+                const long long k = s_kl[LANE_INT ? l * 4 + i : 0][LANE_INT ? threadIdx.x : 0];
+                s_kl[LANE_INT ? l * 4 + i : 0][LANE_INT ? threadIdx.x : 0] = 0ll;
+                long long h[2] = {k & 0xFFFFFFFFll, k >> 32};
+                wave_total_i64<2>(h);
+                const bool any = __builtin_amdgcn_ballot_w64(((kl_bad >> (l * 4 + i)) & 1u) != 0u) != 0ull;
+                if ((threadIdx.x & 63) == 0) {
+                    QSlot* slot = s_gq[threadIdx.x >> 6] + (QK ? l * 4 + i : 0);
+                    slot->lo += (unsigned long long)h[0];
+                    slot->hi += (unsigned long long)h[1];
+                    if (any) slot->flags |= (unsigned int)xs::XS_F_NAN;
+                }
+            }
+            kl_bad &= ~(0xFu << (l * 4));
+            kl_n[LANE_INT ? l : 0] = 0;
+        }
+    };
+    auto lane_flush = [&](int l) {       // MIDFLUSH, kind Q: the four accumulators of move l into the lane's integers
+        uint64_t cb[4];
+        q_constants(l, cb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t b = (uint64_t)__double_as_longlong(g[QK ? l : 0][i]);
+            const bool bad = ((b ^ cb[i]) >> 52) != 0ull;
+            s_kl[LANE_INT ? l * 4 + i : 0][LANE_INT ? threadIdx.x : 0] += bad ? 0ll : (long long)(b - cb[i]);
+            kl_bad |= (bad ? 1u : 0u) << (l * 4 + i);
+            g[QK ? l : 0][i] = __longlong_as_double((long long)cb[i]);
+        }
+        if ((kl_n[LANE_INT ? l : 0] += 1) >= LANE_FLUSHES) flush_move(l);
     };
     auto flush_gd = [&]() {
         if (QK) {
@@ -2306,8 +2353,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     for (int l = 0; l < NL; ++l) dep[l] = 0;
     // A lane's accumulators take GD_CAP summands between two flushes.  Whether a launch needs a flush before its end at all is
     // known to the host (trips per lane x samples per trip: pg_fits_without_flush, amc_api.hip), and the launches that do are
-    // a different instantiation (MIDFLUSH): flush code inside the sampling loop costs the loop ~20 VGPRs -- a wave per SIMD --
-    // even where it never runs (107 against 86 VGPRs; 2.5 us per launch at 1e7 chains, where a lane sees ~20 summands).
+    // a different instantiation (MIDFLUSH): flush code inside the sampling loop costs the common launch -- ~20 summands per lane
+    // at 1e7 chains -- 1 to 2.6 us where it never runs (same-box A/B of both forms, profiles/r04_NOTES.md).
     // Same memory schedule as the sweep kernel: prefetch of the next iteration and the write-through store of
     // the previous one at the START of an iteration; full iterations without per-lane predicates (arrays are
     // padded), the ragged last iteration peeled.
@@ -2335,13 +2382,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         for (int l = 0; l < NL; ++l) {
             if (l < a.n_learn) {
                 if (!HOIST) move_consts(l);
-                for (int q = 0; q < a.q_batch; ++q) {
-                    // a lane's accumulators take GD_CAP summands between two flushes (at 1e7 chains a lane sees ~20 per launch)
-                    if (MIDFLUSH && (dep[l] += 2) > GD_CAP) {
-                        if (QK) flush_move(l);
-                        else if (l == 0) r_flush(gr, s_gr[threadIdx.x >> 6]);       // all columns at once
-                        dep[l] = 2;
-                    }
+                // MIDFLUSH: the samples go in blocks of at most GD_CAP / 2 (two summands each), the check for room in the lane's
+                // accumulators BETWEEN the blocks: inside the loop over samples the branch alone cost 4-10 % per sample
+                constexpr int QBLOCK = GD_CAP / 2;
+                for (int q0 = 0; q0 < a.q_batch; q0 += MIDFLUSH ? QBLOCK : (1 << 30)) {
+                const int q1 = MIDFLUSH ? (a.q_batch - q0 < QBLOCK ? a.q_batch : q0 + QBLOCK) : a.q_batch;
+                if (MIDFLUSH && (dep[l] += 2 * (q1 - q0)) > GD_CAP) {
+                    if (QK) lane_flush(l);
+                    else if (l == 0) r_flush(gr, s_gr[threadIdx.x >> 6]);       // all columns at once
+                    dep[l] = 2 * (q1 - q0);
+                }
+                for (int q = q0; q < q1; ++q) {
                     double z0, z1;
 #if AMC_NP > 1
                     const uint32_t sample_id = (uint32_t)((a.l_base + l) * a.q_batch + q);
@@ -2388,6 +2439,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                     }
 #endif
                 }
+                }       // blocks of samples
             }
         }
     };

@@ -1006,11 +1006,13 @@ def test_pgmc_steps_reduce_begin_equals_steps_then_reduce(gpu, case):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("lag", [1, 2])
 @pytest.mark.parametrize("depth", [2, 5, 16])
 @pytest.mark.parametrize("K", [1, 2, 3])
-def test_callback_folds_interleaved_with_queued_sweeps(gpu, oracle, monkeypatch, depth, K):
+def test_callback_folds_interleaved_with_queued_sweeps(gpu, oracle, monkeypatch, depth, K, lag):
     """A callback's fold of the step log (amc_sweep_reduce_begin) with sweeps queued behind it before its sums are read:
-    callbacks read one period late (the pipelined form StoreCallbacks uses) and at once, small log depths so that full
+    callbacks read `lag` periods late -- one (the pipelined form) or two (TWO reductions pending in the engine, handed back
+    oldest first: what StoreCallbacks does with a callback at every step) -- and at once, small log depths so that full
     logs are folded in between; counters and sums against the oracle throughout."""
     monkeypatch.setenv("AMC_LOG_DEPTH", str(depth))
     M = 9001
@@ -1021,25 +1023,28 @@ def test_callback_folds_interleaved_with_queued_sweeps(gpu, oracle, monkeypatch,
     e.init_uniform(-2, 2)
     o.init_uniform(-2, 2)
     expect, got = [], []
-    pending = False
+    pending = 0
     for i, n in enumerate([1, 3, 1, 4, 2, 7, 1, 1, 5, 3, 2, 6]):
         e.sweep(n)
         o.make_steps(n, 4)
-        if pending:
-            got.append(e.reduce_end())                    # the previous callback's sums, a period late
+        if pending == lag:
+            got.append(e.reduce_end())                    # the oldest pending callback's sums, `lag` periods late
+            pending -= 1
         e.sweep_reduce_begin(1 + i % 2)
         o.make_steps(1 + i % 2, 4)
         expect.append((o.energy(), o.moments(), o.acceptance()))
-        pending = True
+        pending += 1
         if i % 4 == 3:
-            got.append(e.reduce_end())                    # ... or at once
-            pending = False
+            while pending:
+                got.append(e.reduce_end())                # ... or at once
+                pending -= 1
             if i == 7:
                 a2, t2 = e.download_counters()            # a reader of the counters between two callbacks
                 ao, to = o.counters()
                 assert np.array_equal(a2, ao) and np.array_equal(t2, to)
-    if pending:
+    while pending:
         got.append(e.reduce_end())
+        pending -= 1
     assert len(got) == len(expect)
     for red, (en, mom, acc) in zip(got, expect):
         assert red[3] == M
