@@ -1521,10 +1521,8 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
         acc_max = std::max(acc_max, accepted[i]);
     }
     AMC_HIP(hipSetDevice(h->device));
-    h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
-    // u16 planes: the high halves take part from now on unless no counter can have reached 2^16 (see counter_room); both
-    // planes are always written, so that halves which do not take part yet are zero when they do
-    if (h->narrow) h->use_high = steps > 0xFFFFull || (uint64_t)acc_max > steps;
+    // (the handle's own bookkeeping -- log_fill, use_high, t_counted -- changes only once every plane has been copied: a copy
+    // that fails leaves the handle counting as before)
     std::vector<uint32_t> buf((size_t)h->M);
     unsigned long long acc_sum = 0;
     for (int k = 0; k < h->K; ++k) {
@@ -1551,12 +1549,16 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
             AMC_HIP(hipStreamSynchronize(h->stream));
         }
     }
-    h->t_counted = steps;
     if (h->K == 1) {
         AMC_HIP(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
         AMC_HIP(hipMemcpyAsync(h->d_acc_slots, &acc_sum, sizeof(acc_sum), hipMemcpyHostToDevice, h->stream));
         AMC_HIP(hipStreamSynchronize(h->stream));
     }
+    h->log_fill = 0;            // every counter is replaced: steps still waiting in the log are dropped with the old values
+    // u16 planes: the high halves take part from now on unless no counter can have reached 2^16 (see counter_room); both
+    // planes are always written, so that halves which do not take part yet are zero when they do
+    if (h->narrow) h->use_high = steps > 0xFFFFull || (uint64_t)acc_max > steps;
+    h->t_counted = steps;
     return AMC_OK;
 }
 

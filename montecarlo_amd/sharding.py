@@ -317,15 +317,27 @@ def connect_engine(engine) -> bool:
             out = [None] * size
             dist.all_gather_object(out, obj)
             return out
-    # round 1: the unique id, or the reason rank 0 has none -- rank 0 ALWAYS broadcasts, so no rank waits for a key that
-    # never comes
-    record = None
-    if rank == 0:
+    # round 0: is every rank ready to enter ncclCommInitRank?  That call is itself a collective -- a rank whose engine cannot
+    # do it, or whose librccl does not load, would leave the others blocked inside it --, so readiness is gathered first:
+    # making a unique id loads the library and calls into it without touching any other rank (ids of ranks > 0 are dropped)
+    uid, why_not = None, None
+    if capable:
         try:
-            record = ("uid", engine.comm_unique_id()) if capable else ("error", "engine has no comm_init")
+            uid = engine.comm_unique_id()
         except Exception as err:                       # librccl not loadable, ncclGetUniqueId failed
-            record = ("error", str(err))
-    record = bcast(record)
+            why_not = str(err)
+    else:
+        why_not = "engine has no comm_init"
+    ready = gather((uid is not None, why_not))
+    if not all(f[0] for f in ready):
+        engine.comm_connected = False
+        if rank == 0:
+            import sys
+            reasons = "; ".join(f"rank {r}: {f[1]}" for r, f in enumerate(ready) if not f[0])
+            print(f"[montecarlo_amd] no RCCL communicator over the shards ({reasons}): sums go over the host", file=sys.stderr)
+        return False
+    # round 1: rank 0's unique id
+    record = bcast(("uid", uid) if rank == 0 else None)
     ok, why = False, None
     if record[0] == "uid" and capable:
         try:

@@ -51,17 +51,16 @@ class StoreHistogram(AriannaAlgorithm):
     def make_step(self, simulation: Simulation) -> None:
         eng = self.metropolis.engine
         self._settle()
-        on_device = hasattr(eng, "histogram_accumulate") and getattr(self, "_on_device", True)
+        # The engine keeps ONE running histogram.  The first StoreHistogram of a Metropolis to sample owns it (its counts stay
+        # on the device until finalise and its moments are read one sample late: nothing makes the host wait for the queued
+        # sweeps); any other instance -- same bins or not -- fetches its counts at each sample time.
+        owner = getattr(self.metropolis, "_histogram_owner", None)
+        if owner is None and hasattr(eng, "histogram_accumulate"):
+            owner = self.metropolis._histogram_owner = self
+        on_device = owner is self
         if on_device:
-            # the counts stay on the device until finalise and the moments are read one sample late: nothing here makes the
-            # host wait for the queued sweeps (a histogram fetched at every sample time did, twice)
-            try:
-                eng.histogram_accumulate(self.lo, self.hi, self.bins)
-            except Exception:               # the engine's running histogram has other bins (a second StoreHistogram): fetch each time
-                if getattr(self, "_on_device", None):
-                    raise
-                on_device = False
-            self._on_device = on_device
+            eng.histogram_accumulate(self.lo, self.hi, self.bins)
+            self._on_device = True
         if on_device:
             self._ticket = self.metropolis.reductions_async()
         else:
@@ -74,6 +73,7 @@ class StoreHistogram(AriannaAlgorithm):
         if getattr(self, "_on_device", False):
             self.counts += self.metropolis.engine.histogram_fetch(self.bins, reset=True)
             self._on_device = False
+            self.metropolis._histogram_owner = None
         total = sharding.allreduce_sum(self.counts.astype(np.float64))
         self.global_counts = np.rint(total).astype(np.uint64)
         n, sx, sxx = self.moments

@@ -212,6 +212,24 @@ def test_histogram_snapshots_and_exact_resume(oracle, tmp_path):
         ma.restore(other.algorithms[0], str(tmp_path / "ckpt"))
 
 
+def test_two_histograms_on_one_metropolis(oracle, tmp_path):
+    """The engine keeps one running histogram: the first StoreHistogram to sample owns it, a second one -- here with the SAME
+    bins, which used to add into the same accumulator and double the first one's counts -- fetches its counts each time."""
+    chains = ma.ParticleChains.uniform(500, 2.0)
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.3], 1.0),)
+    sched = list(range(5, 41, 5))
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=5, engine_factory=oracle.OracleEngine),
+          dict(algorithm=ma.StoreHistogram, dependencies=(ma.Metropolis,), lo=-1.5, hi=1.5, bins=20, scheduler=sched, path=str(tmp_path / "h1")),
+          dict(algorithm=ma.StoreHistogram, dependencies=(ma.Metropolis,), lo=-1.5, hi=1.5, bins=20, scheduler=sched, path=str(tmp_path / "h2")),
+          dict(algorithm=ma.StoreHistogram, dependencies=(ma.Metropolis,), lo=-1.0, hi=1.0, bins=8, scheduler=sched[1::2], path=str(tmp_path / "h3")))
+    sim = ma.Simulation(chains, al, 40, path=str(tmp_path))
+    ma.run(sim)
+    h1, h2, h3 = sim.algorithms[1:4]
+    assert int(h1.global_counts.sum()) == int(h2.global_counts.sum()) == 500 * len(sched)
+    assert np.array_equal(h1.global_counts, h2.global_counts) and h1.mean == h2.mean
+    assert int(h3.global_counts.sum()) == 500 * len(sched[1::2])
+
+
 def test_resume_keeps_gradient_accumulators_when_updates_are_sparser_than_the_estimator(oracle, tmp_path):
     """PolicyGradientUpdate every 7 steps, estimator every step (update.jl:50-57 averages everything accumulated since the
     last update): a checkpoint that falls between two updates must carry the device-resident gradients_data, or the
