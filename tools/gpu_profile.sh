@@ -1,9 +1,9 @@
 #!/bin/bash
 # Developer tool, run on the GPU box (gpurun -- 'bash tools/gpu_profile.sh'): rocprofv3 kernel-trace summaries and
 # PMC passes (own runs, counters only) of bench.py and of the workloads of tools/gpu_workload.py; tools/summarize_profiles.py
-# turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r03).
+# turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r04).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${AMC_ROUND_TAG:-r03}
+TAG=${AMC_ROUND_TAG:-r04}
 export AMC_ROUND_TAG=$TAG
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O

@@ -3,7 +3,7 @@
 register and spill counts of the kernels the profiles name, and their per-block instruction mixes (tools/isa_blocks.py)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("AMC_ROUND_TAG", "r03")
+TAG = os.environ.get("AMC_ROUND_TAG", "r04")
 S = open(os.path.join(ROOT, "montecarlo_amd/csrc/amc_api.gfx950.s")).read()
 NAMED = ["sweep_kernel<0, false, 0, false, true, false>", "sweep_kernel<1, true, 1, false, true, false>",
          "sweep_kernel<1, true, 1, false, true, true>", "pg_estimate_kernel<0, 1, false, 2, false>", "pg_estimate_kernel<0, 1, false, 2, true>",
@@ -31,6 +31,24 @@ for want in NAMED:
         if want in d:
             rows.append((d, meta(n)))
 sw = [meta(n)["sspill"] for n, d in dem.items() if "sweep_kernel<" in d]
+# what the register / spill columns mean for these kernels (history of the findings, rounds 1-3)
+NOTES = """
+Where the spills came from and went: the compiler hoisted the 20 Philox round keys (k + r W, r = 0..9, two words) out of the sampling loop as
+loop invariants; with ~35 f64 polynomial constants (two SGPRs each) that exceeds the 102 SGPRs of a wave, and what did not fit was parked in VGPR
+lanes (v_writelane) and fetched back inside the loop (v_readlane: a VALU-slot instruction).  Round 2 keeps the key schedule on the scalar unit per
+call (18 s_add_i32, amc_math.h philox4x32_10): the headline kernel's loop has no v_readlane left, the fused sweep + estimator kernel went from
+~70 to ~10 per trip.  The remaining spills are kernel arguments and loop-invariant addresses saved in the prologue and restored in the epilogue
+(outside the loop).
+The estimator kernels (pg_estimate_kernel) hold the eight Box-Muller polynomial coefficients that enter an fma as its addend as opaque 64-bit VGPR
+values (amc_math.h MathK): hipcc keeps a 64-bit literal as two separately hoisted 32-bit halves and reassembles the pair at every use, which for an
+fma addend means v_mov_b64 + v_fmac_f64; 18 such copies per pair-iteration of the fused kernel (10 in its estimator loop, 8 in its sweep block) are
+gone, and alpha = exp(min(arg, 0)) with the rare cases behind a wave-uniform branch replaced 3 compares + 6 selects per sample by one v_min_f64 and one
+compare.  PMC: 399 -> 366 VALU instructions per wave-iteration (fused), 219 -> 197 (estimator alone).  The pinned values raise the fused kernel from 93
+to 103 VGPRs (4 instead of 5 waves per SIMD); measured on one box the launch is 2-3 % faster with them than without at every grid from 4 to 8 blocks per CU.
+The K > 1 fused sweep + estimator kernels (pg_estimate_kernel<.., 2>) are built in an object of their own (amc_pg_fused.hip) with LLVM's Machine LICM
+off: hoisting every loop-invariant out of their sampling loop cost 103 VGPRs and 25 SGPR-lane spills; without it 90 VGPRs (5 waves per SIMD), none.
+"""
+
 out = []
 out.append("ISA summary of the kernels the profiles name (hipcc ROCm 7.2, -O3 --offload-arch=gfx950 -ffp-contract=off; `make -C montecarlo_amd/csrc asm`")
 out.append("writes the full listing, which is not tracked; this file: tools/isa_summary.py).  Loop instruction mixes: tools/isa_blocks.py; counters: " + TAG + "_pmc_summary.json.")
@@ -40,7 +58,7 @@ for d, m in rows:
     out.append("%-70s %4d %4d %10d %12d %9d" % (d[:70], m["vgpr"], m["sgpr"], m["sspill"], m["vspill"], m["lds"]))
 out.append("")
 out.append("sweep_kernel, all %d instantiations: SGPR spills min %d / max %d (round 1: 8..45)." % (len(sw), min(sw), max(sw)))
-out.append(open(os.path.join(ROOT, "tools", "isa_summary_notes.txt")).read().rstrip())
+out.append(NOTES.strip())
 out.append("")
 out.append("Instruction mix per basic block (>= 15 instructions; tools/isa_blocks.py): f64 = f64-class VALU, mad64 = v_mad_u64_u32 (Philox), v32 = other VALU,")
 out.append("lane = v_readlane / v_writelane (SGPR spill traffic), salu / lds / vmem.  The sampling loops are the blocks with mad64 / f64 counts.")

@@ -1,6 +1,6 @@
 """Probe: config 5's pool through Simulation / run under different schedules -- a scan for cliffs in the host mirror's grouping."""
 import os, sys, time, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.environ.get("AMC_PACKAGE_ROOT", ROOT))      # another build of the package (tools/gpu_ab.py snapshot), for before / after
 import montecarlo_amd as ma
 M, steps = 10_000_000, 3000

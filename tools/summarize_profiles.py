@@ -13,7 +13,7 @@
 """
 import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("AMC_ROUND_TAG", "r03")
+TAG = os.environ.get("AMC_ROUND_TAG", "r04")
 G = os.path.join(ROOT, "gpurun_out", TAG)
 OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
 os.makedirs(OUT, exist_ok=True)
@@ -30,7 +30,7 @@ def one(pattern):
 
 def kernel_hash():
     h = hashlib.sha256()
-    for fn in ("amc_kernels.h", "amc_math.h", "amc_tables.h"):
+    for fn in ("amc_kernels.h", "amc_math.h", "amc_tables.h", "amc_xsum.h"):
         h.update(open(os.path.join(ROOT, "montecarlo_amd", "csrc", fn), "rb").read())
     return h.hexdigest()[:16]
 

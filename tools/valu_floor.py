@@ -15,7 +15,7 @@ frequency; everything else counts once per trip.  The resulting VALU count is ch
 import collections, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("AMC_ROUND_TAG", "r03")
+TAG = os.environ.get("AMC_ROUND_TAG", "r04")
 ASM = os.path.join(ROOT, "montecarlo_amd", "csrc", "amc_api.gfx950.s")
 COSTS = os.path.join(ROOT, "profiles", "r03_ubench_issue_costs.txt")
 if not os.path.exists(COSTS):
