@@ -105,17 +105,25 @@ mutable struct HIPMetropolis{P} <: Arianna.AriannaAlgorithm
     n_chains::Int
     K::Int
     n_ranks::Int
+    per_chain_counters::Bool
+    n_params::Int           # parameters of the moves' policy (1: sigma; amc_create_vector_policy_model otherwise)
     red_t::Int              # simulation.t the cached reduction belongs to (-1: none)
     red::Vector{Float64}
 end
 
+# proposal = (sample, logq, dlogq): a script-defined policy as C expressions (amc_create_proposal_model); with a policy of
+# SEVERAL parameters (Move.parameters of length P > 1) dlogq is the vector of the P partial derivatives and the expressions
+# say theta0 .. theta{P-1} (amc_create_vector_policy_model).
 function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing, scale=nothing,
-                       chain_offset=0, n_chains_global=length(chains), per_chain_counters=true,
+                       proposal=nothing, chain_offset=0, n_chains_global=length(chains), per_chain_counters=true,
                        rank=0, n_ranks=1, unique_id=nothing, extras...)
     template = deepcopy(pool)                                      # ONE copy (metropolis.jl:289 makes M), see LazyPools
     K = length(template)
     pools = LazyPools(template, length(chains), Matrix{Int64}(undef, 0, K), Matrix{Int64}(undef, 0, K))
-    sigma = Float64[move.parameters.σ for move in template]
+    n_params = length(template[1].parameters)
+    thetas = [Float64.(collect(move.parameters)) for move in template]
+    # parameter 0 at creation must pass sigma's range check; the full vectors follow through amc_set_parameters
+    sigma = n_params == 1 ? Float64[th[1] for th in thetas] : ones(Float64, K)
     weight = Float64[move.weight for move in template]
     # the asserts of metropolis.jl:249-251 (identical parameters / weights across chains) hold by construction
     handle = Ref{Ptr{Cvoid}}(C_NULL)
@@ -127,7 +135,25 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
                         Int32(K), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL,
                         Int32(eltype_of_state(chains) === Float32 ? 1 : 0), Int32(0))
-        if scale isa AbstractString
+        if proposal !== nothing
+            pot = potential isa AbstractString ? potential : C_NULL
+            rew = reward isa AbstractString ? reward : C_NULL
+            sample, logq, dlogq = proposal
+            if n_params == 1
+                check(ccall((:amc_create_proposal_model, libamc), Cint,
+                            (Ref{AmcConfig}, Cstring, Cstring, Cstring, Cstring, Cstring, Ref{Ptr{Cvoid}}),
+                            cfg, pot, rew, sample, logq, dlogq === nothing ? C_NULL : dlogq, handle))
+            else
+                partials = dlogq === nothing ? C_NULL : Base.cconvert(Ptr{Cstring}, collect(String, dlogq))
+                GC.@preserve partials check(ccall((:amc_create_vector_policy_model, libamc), Cint,
+                            (Ref{AmcConfig}, Cint, Cstring, Cstring, Cstring, Cstring, Ptr{Cstring}, Cstring, Cstring, Ref{Ptr{Cvoid}}),
+                            cfg, n_params, pot, rew, sample, logq, partials === C_NULL ? C_NULL : Base.unsafe_convert(Ptr{Cstring}, partials),
+                            C_NULL, C_NULL, handle))
+                for k in 1:K
+                    check(ccall((:amc_set_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), handle[], k - 1, thetas[k], n_params))
+                end
+            end
+        elseif scale isa AbstractString
             # a policy whose width depends on the state: delta ~ Normal(0, sigma * scale(system.x)); the expression is the
             # C restatement of what the script's sample_action! / log_proposal_density do with `system`
             pot = potential isa AbstractString ? potential : C_NULL
@@ -147,7 +173,10 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
             check(ccall((:amc_create, libamc), Cint, (Ref{AmcConfig}, Ref{Ptr{Cvoid}}), cfg, handle))
         end
     end
-    alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), K, n_ranks, -1, Float64[])
+    np_ref = Ref{Cint}(0); stride_ref = Ref{Cint}(0)
+    check(ccall((:amc_n_params, libamc), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), handle[], np_ref, stride_ref))
+    @assert np_ref[] == n_params && stride_ref[] == 2 + 2n_params + n_params^2          # AMC_GD_STRIDE_P
+    alg = HIPMetropolis(handle[], pools, sweepstep, seed, length(chains), K, n_ranks, per_chain_counters || K > 1, n_params, -1, Float64[])
     finalizer(a -> ccall((:amc_destroy, libamc), Cint, (Ptr{Cvoid},), a.handle), alg)
     n_ranks > 1 && comm_init!(alg, rank, n_ranks, unique_id)
     return alg
@@ -224,11 +253,26 @@ hip_algorithm(simulation) = only(filter(a -> isa(a, HIPMetropolis), simulation.a
 
 # out = [Σe, Σx, Σx², count, Σ_c acc_ck/tot_ck ...]   (AMC_RED_* in amc.h), summed over the shards; ONE reduction and
 # ONE all-reduce per simulation.t however many callbacks read it (StoreCallbacks calls them back to back, algorithms.jl:97-102)
+# The sums cross the shards as RECORDS (AMC_XSUM_WORDS doubles per sum: integer limbs, amc.h "reproducible sums"): merged
+# exactly and rounded once, so every rank -- and a single GPU holding all the chains -- gets the same bits.
+const XSUM_WORDS = 12
+function finish_records!(alg::HIPMetropolis, records::Matrix{Float64}, steps_counted::UInt64)
+    n = size(records, 2)
+    check(ccall((:amc_allreduce_xsum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.handle, records, n))
+    out = Vector{Float64}(undef, n)
+    check(ccall((:amc_xsum_round, libamc), Cint, (Ptr{Float64}, Cint, Ptr{Float64}), records, n, out))
+    # K = 1 without per-chain counters: the ratio record holds the pool-wide accepted TOTAL (amc_reduce_end_exact)
+    alg.K == 1 && !alg.per_chain_counters && (out[5] = out[5] / steps_counted)
+    return out
+end
+
 function reduce(alg::HIPMetropolis, t::Int)
     alg.red_t == t && return alg.red
-    out = Vector{Float64}(undef, 4 + alg.K)
-    check(ccall((:amc_reduce, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), alg.handle, out))
-    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.handle, out, length(out)))
+    records = Matrix{Float64}(undef, XSUM_WORDS, 4 + alg.K)
+    steps = Ref{UInt64}(0)
+    check(ccall((:amc_reduce_begin, libamc), Cint, (Ptr{Cvoid},), alg.handle))
+    check(ccall((:amc_reduce_end_exact, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{UInt64}), alg.handle, records, steps))
+    out = finish_records!(alg, records, steps[])
     alg.red_t = t; alg.red = out
     return out
 end
@@ -259,13 +303,19 @@ end
 function make_step!(::Simulation, alg::HIPPolicyGradientEstimator)
     n = length(alg.learn_ids)
     ids = Cint[k - 1 for k in alg.learn_ids]                                  # C side is 0-based
-    out = Matrix{Float64}(undef, 5, n)                                        # (j, ∇j, ∇logq, g, n) per move
-    check(ccall((:amc_pg_estimate, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Ptr{Float64}),
-                alg.metropolis.handle, n, ids, alg.q_batch_size, out))
-    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.metropolis.handle, out, length(out)))
+    P = alg.metropolis.n_params
+    stride = 2 + 2P + P^2                                                     # (j, ∇j[P], ∇logq[P], g[P,P], n) per move: AMC_GD_STRIDE_P
+    records = Array{Float64}(undef, XSUM_WORDS, stride, n)                    # exact records: merged across shards, rounded once
+    check(ccall((:amc_pg_estimate_exact, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Ptr{Float64}),
+                alg.metropolis.handle, n, ids, alg.q_batch_size, records))
+    check(ccall((:amc_allreduce_xsum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), alg.metropolis.handle, records, stride * n))
+    out = Matrix{Float64}(undef, stride, n)
+    check(ccall((:amc_xsum_round, libamc), Cint, (Ptr{Float64}, Cint, Ptr{Float64}), records, stride * n, out))
     alg.metropolis.red_t = -1                                                 # every sample moves x to (x + δ) - δ
     for k in 1:n
-        gd = PolicyGuided.GradientData(out[1, k], [out[2, k]], [out[3, k]], fill(out[4, k], 1, 1), Int(out[5, k]))
+        # g arrives row by row and is symmetric bit for bit, so Julia's column-major reshape is the same matrix
+        gd = PolicyGuided.GradientData(out[1, k], out[2:1+P, k], out[2+P:1+2P, k], reshape(out[2+2P:1+2P+P^2, k], P, P),
+                                       Int(out[stride, k]))
         alg.gradients_data[k] = alg.gradients_data[k] + gd                    # estimator.jl:130
         alg.objectives[k] = alg.gradients_data[k].j / alg.gradients_data[k].n # estimator.jl:131
     end
@@ -273,8 +323,8 @@ function make_step!(::Simulation, alg::HIPPolicyGradientEstimator)
 end
 
 function set_parameters!(alg::HIPMetropolis, k::Int, parameters)
-    p = Float64[parameters.σ]
-    check(ccall((:amc_set_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), alg.handle, k - 1, p, 1))
+    p = Float64.(collect(parameters))                    # ComponentArray(σ = ...) or a longer parameter array: P doubles
+    check(ccall((:amc_set_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), alg.handle, k - 1, p, length(p)))
 end
 
 # kw-constructor in the shape Simulation builds algorithms with (src/simulation.jl:76-83; estimator.jl:103-109):
@@ -342,10 +392,10 @@ function pgmc_steps_observed!(metropolis::HIPMetropolis, n::Integer, learn_ids::
     check(ccall((:amc_pgmc_steps_reduce_begin, libamc), Cint,
                 (Ptr{Cvoid}, Int64, Cint, Ptr{Cint}, Cint, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
                 metropolis.handle, n, length(ids), ids, q_batch, 1, optimiser, hyper0, hyper1))
-    out = Vector{Float64}(undef, 4 + metropolis.K)
-    check(ccall((:amc_reduce_end, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), metropolis.handle, out))
-    check(ccall((:amc_allreduce_sum, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), metropolis.handle, out, length(out)))
-    metropolis.red_t = t; metropolis.red = out
+    records = Matrix{Float64}(undef, XSUM_WORDS, 4 + metropolis.K)
+    steps = Ref{UInt64}(0)
+    check(ccall((:amc_reduce_end_exact, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{UInt64}), metropolis.handle, records, steps))
+    metropolis.red_t = t; metropolis.red = finish_records!(metropolis, records, steps[])
     return nothing
 end
 
@@ -366,12 +416,12 @@ function runtime_info()
     return (hip_runtime_version=Int(v[]), hip_runtime=unsafe_string(pointer(path)))
 end
 
-# sigma_k of the device copy back into the shared Move.parameters objects (after pgmc_steps!)
+# the device copy of every move's parameters back into the shared Move.parameters objects (after pgmc_steps!)
 function pull_parameters!(metropolis::HIPMetropolis)
-    p = Vector{Float64}(undef, 1)
+    p = Vector{Float64}(undef, metropolis.n_params)
     for (k, move) in enumerate(metropolis.pools.template)
-        check(ccall((:amc_get_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), metropolis.handle, k - 1, p, 1))
-        move.parameters.σ = p[1]
+        check(ccall((:amc_get_parameters, libamc), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), metropolis.handle, k - 1, p, length(p)))
+        move.parameters .= p
     end
     return nothing
 end

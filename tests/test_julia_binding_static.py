@@ -18,6 +18,7 @@ C_TO_JULIA = {
     "amc_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "amc_config*": {"Ref{AmcConfig}", "Ptr{AmcConfig}"},
     "char*": {"Cstring", "Ptr{UInt8}", "Ptr{Cchar}"},
+    "char**": {"Ptr{Cstring}", "Ptr{Ptr{UInt8}}"},
     "double*": {"Ptr{Float64}", "Ref{Float64}"},
     "double": {"Float64", "Cdouble"},
     "float": {"Float32", "Cfloat"},
@@ -157,8 +158,11 @@ def test_every_ccall_matches_its_prototype():
 def test_binding_covers_the_entry_points_a_run_needs():
     used = {c["name"] for c in julia_ccalls()}
     need = {"amc_create", "amc_create_custom", "amc_create_model", "amc_create_policy_model", "amc_destroy",
-            "amc_upload_state", "amc_sweep", "amc_download_state", "amc_download_counters", "amc_reduce",
-            "amc_allreduce_sum", "amc_comm_unique_id", "amc_comm_init", "amc_pg_estimate", "amc_set_parameters",
+            "amc_upload_state", "amc_sweep", "amc_download_state", "amc_download_counters", "amc_reduce_begin",
+            # sums cross the shards as exact records, merged and rounded once (reproducible sums): never as rounded doubles
+            "amc_reduce_end_exact", "amc_allreduce_xsum", "amc_xsum_round", "amc_pg_estimate_exact",
+            "amc_create_proposal_model", "amc_create_vector_policy_model", "amc_n_params",
+            "amc_comm_unique_id", "amc_comm_init", "amc_set_parameters",
             "amc_get_parameters", "amc_pgmc_steps", "amc_pg_get_accumulated", "amc_pg_set_accumulated", "amc_last_error"}
     assert need <= used, sorted(need - used)
 

@@ -6,8 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = os.environ.get("AMC_ROUND_TAG", "r04")
 S = open(os.path.join(ROOT, "montecarlo_amd/csrc/amc_api.gfx950.s")).read()
 NAMED = ["sweep_kernel<0, false, 0, false, true, false>", "sweep_kernel<1, true, 1, false, true, false>",
-         "sweep_kernel<1, true, 1, false, true, true>", "pg_estimate_kernel<0, 1, false, 2, false>", "pg_estimate_kernel<0, 1, false, 2, true>",
-         "pg_estimate_kernel<0, 1, false, 0, false>",
+         "sweep_kernel<1, true, 1, false, true, true>", "pg_estimate_kernel<0, 1, false, 2, false, false>", "pg_estimate_kernel<0, 1, false, 2, true, false>",
+         "pg_estimate_kernel<0, 1, false, 0, false, false>",
          "fold_log_kernel<2, true>", "fold_log_kernel<2, false>", "reduce_kernel<0>"]
 
 

@@ -20,7 +20,7 @@ os.makedirs(OUT, exist_ok=True)
 ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
               "k2": 165_000_000, "pgmc": 165_000_000, "est": 16 * 10_000_000}     # 16 B of state + half a step-log byte per update
 MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, false>", "k2": "sweep_kernel<1, true, 1, false, true",
-        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false>"}
+        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false, false>"}
 
 
 def one(pattern):
