@@ -550,6 +550,28 @@ __device__ __forceinline__ void wave_total_i64(long long (&v)[N])
         v[i] = (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
     }
 }
+// The same for N 32-bit limbs whose wave totals fit 32 bits: ONE instruction per limb and round (the compiler folds the DPP
+// move into the add: v_add_u32_dpp), where a 64-bit value costs two moves and a two-instruction add.  These kernels are bound
+// by vector-instruction issue and every wave runs its flush once per launch: 27 instructions per wave-trip over round 3
+// (PMC SQ_INSTS_VALU, 368 -> 395) came from the 64-bit rounds.
+template <int N, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_round_u32(uint32_t (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[i], CTRL, ROW_MASK, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ void wave_total_u32(uint32_t (&v)[N])      // valid in every lane
+{
+    dpp_round_u32<N, 0x111, 0xF>(v);
+    dpp_round_u32<N, 0x112, 0xF>(v);
+    dpp_round_u32<N, 0x114, 0xF>(v);
+    dpp_round_u32<N, 0x118, 0xF>(v);
+    dpp_round_u32<N, 0x142, 0xA>(v);
+    dpp_round_u32<N, 0x143, 0xC>(v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (uint32_t)__builtin_amdgcn_readlane((int)v[i], 63);
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
     long long a[1] = {v};
@@ -622,7 +644,17 @@ __device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)
         any_bad[c] = __builtin_amdgcn_ballot_w64(bad) != 0ull;
         s[c] = __longlong_as_double((long long)cbits[c]);
     }
-    wave_total_i64<NC>(k);                 // the columns share the rounds
+    // |k| < 2^51: k + 2^51 is an unsigned integer of 52 bits, two limbs of 26 whose totals over 64 lanes fit 32 bits
+    uint32_t limb[2 * NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const unsigned long long u = (unsigned long long)(k[c] + (1ll << 51));
+        limb[2 * c] = (uint32_t)(u & 0x3FFFFFFull);
+        limb[2 * c + 1] = (uint32_t)(u >> 26);
+    }
+    wave_total_u32<2 * NC>(limb);          // the columns share the rounds
+#pragma unroll
+    for (int c = 0; c < NC; ++c) k[c] = (long long)limb[2 * c] + ((long long)limb[2 * c + 1] << 26) - (64ll << 51);
     if (lane0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
