@@ -200,6 +200,19 @@ int  amc_create_vector_policy_model(const amc_config *cfg, int n_params, const c
                                     const char *perform_expr, const char *invert_expr, amc_handle **out);
 /* P and AMC_GD_STRIDE_P(P) of a handle (either pointer may be NULL). */
 int  amc_n_params(amc_handle *h, int *n_params, int *gd_stride);
+/* Pools that MIX policy and action types.  In the reference every Move carries its own `action` and `policy`
+ * (src/metropolis.jl:140-162; the pool's moves need only agree across CHAINS, :249-260), and sample_action! /
+ * log_proposal_density / perform_action! / invert_action! dispatch on their types.  Here: up to AMC_MAX_CLASSES expression sets
+ * ("classes"), class_of_move[k] in [0, n_classes) names the one move k uses; sample_exprs / logq_exprs have one entry per class,
+ * dlogq_exprs one per class or NULL (no estimator), perform_exprs / invert_exprs one per class with NULL entries (or NULL
+ * arrays) for the displacement.  One parameter (sigma) per move.  E.g. a plain Gaussian displacement beside a Langevin
+ * (drifted) proposal and a scaling action in one pool.  Everything else -- counters, step log, callbacks, estimator, learning
+ * steps, sharding -- is that of amc_create_action_model. */
+#define AMC_MAX_CLASSES 4
+int  amc_create_mixed_model(const amc_config *cfg, int n_classes, const int *class_of_move, const char *potential_expr,
+                            const char *reward_expr, const char *const *sample_exprs, const char *const *logq_exprs,
+                            const char *const *dlogq_exprs, const char *const *perform_exprs, const char *const *invert_exprs,
+                            amc_handle **out);
 /* The same with a script-defined ACTION -- the reference's Action interface (src/metropolis.jl:15-119; the displacement's
  * methods are example/particle_1d/particle_1d.jl:30-40) for a one-parameter action on the position:
  *     perform_expr   the position after perform_action!(system, action), from `x` and `delta`      (displacement: x + delta)

@@ -87,6 +87,9 @@ def load() -> C.CDLL:
         "amc_create_vector_policy_model": (C.c_int, [C.POINTER(AmcConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                                      C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.POINTER(H)]),
         "amc_n_params": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "amc_create_mixed_model": (C.c_int, [C.POINTER(AmcConfig), C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                             C.POINTER(H)]),
         "amc_potential_check": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "amc_destroy": (C.c_int, [H]),
         "amc_upload_state": (C.c_int, [H, dp, dp]),
@@ -231,10 +234,13 @@ class HipEngine:
                  weight: Sequence[float] = (1.0,), seed: int = 1, sweepstep: int = 1,
                  per_chain_counters: bool = True, device: int = 0, stream: Optional[int] = None,
                  reward_expr: Optional[str] = None, dtype: str = "f64", scale_expr: Optional[str] = None,
-                 proposal: Optional[Sequence[Optional[str]]] = None, n_params: int = 1):
+                 proposal: Optional[Sequence[Optional[str]]] = None, n_params: int = 1,
+                 classes: Optional[Sequence[Sequence[Optional[str]]]] = None, class_of_move: Optional[Sequence[int]] = None):
         """``n_params`` > 1 (with ``proposal``): a policy with several parameters (amc_create_vector_policy_model) -- the
         expressions see theta0 .. theta{P-1}, ``proposal[2]`` is the list of the P partials of logq (or None), and ``sigma``
-        holds one parameter VECTOR per move."""
+        holds one parameter VECTOR per move.
+        ``classes`` (with ``class_of_move``): a pool that MIXES policy / action types (amc_create_mixed_model) -- one
+        (sample, logq, dlogq or None[, perform, invert]) per class, ``class_of_move[k]`` the class move k uses."""
         lib = load()
         if str(dtype) not in STATE_DTYPES:
             raise AmcError(f"unknown state dtype {dtype!r}; one of {sorted(STATE_DTYPES)}")
@@ -277,7 +283,24 @@ class HipEngine:
         self._lib = lib
         self._h = C.c_void_p()
         enc = lambda t: None if t is None else str(t).encode()
-        if proposal is not None:
+        if classes is not None:
+            if proposal is not None or scale_expr is not None or self.n_params != 1:
+                raise AmcError("classes cannot be combined with proposal / scale_expr / n_params > 1")
+            if class_of_move is None or len(class_of_move) != self.n_moves:
+                raise AmcError("class_of_move must name one class per move")
+            cl = [tuple((list(c) + [None] * 4)[:5]) for c in classes]
+            n = len(cl)
+            arr = lambda i, need: ((C.c_char_p * n)(*[enc(c[i]) for c in cl]) if need else None)
+            have_d = all(c[2] is not None for c in cl)
+            if not have_d and any(c[2] is not None for c in cl):
+                raise AmcError("dlogq: one expression per class, or none at all")
+            com = (C.c_int * self.n_moves)(*[int(v) for v in class_of_move])
+            if expr is None:
+                cfg.potential = POTENTIALS[potential]
+            _check(lib.amc_create_mixed_model(C.byref(cfg), n, com, enc(expr), enc(reward_expr), arr(0, True), arr(1, True), arr(2, have_d),
+                                              arr(3, any(c[3] is not None for c in cl)), arr(4, any(c[4] is not None for c in cl)),
+                                              C.byref(self._h)))
+        elif proposal is not None:
             # script-defined sample_action! / log_proposal_density (/ its sigma-derivative) and, optionally, the action's
             # perform_action! / invert_action!: (sample, logq, dlogq or None[, perform, invert])
             if scale_expr is not None:

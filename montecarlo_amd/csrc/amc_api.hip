@@ -182,6 +182,8 @@ struct amc_handle {
     bool script_policy = false;   // sample_action! / log_proposal_density are script-defined expressions (amc_create_proposal_model)
     bool script_dlogq = false;    // ... and so is d logq / d sigma: the estimator is available
     int n_params = 1;             // parameters of the moves' policy (amc_create_policy_model; 1: sigma)
+    int n_classes = 1;            // policy / action classes of the pool (amc_create_mixed_model)
+    int class_of_move[AMC_MAX_MOVES] = {0};
     bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
     double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
     std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
@@ -633,6 +635,7 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         expr.erase(at);
         return tail;
     };
+    const std::string e_classes = cut_tail('\x0f');      // [ '\x0f' n_classes { sections of the classes 1 .. } ]: pools that mix policies / actions
     const std::string e_np = cut_tail('\x0e');           // [ '\x0e' P ]: parameters of the policy, when more than one; the dlogq section then holds P
                                                          // expressions, '\x0b' between them
     const std::string e_invert = cut_tail('\x08'), e_perform = cut_tail('\x07');
@@ -653,6 +656,25 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         }
     }
     if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
+    if (!e_classes.empty()) {
+        const size_t first = e_classes.find('\x10');
+        src += "#define AMC_NCLASS " + e_classes.substr(0, first) + "\n";
+        size_t at = first;
+        for (int c = 1; at != std::string::npos; ++c) {
+            const size_t nxt = e_classes.find('\x10', at + 1);
+            const std::string blob = e_classes.substr(at + 1, nxt == std::string::npos ? std::string::npos : nxt - at - 1);
+            const size_t m1 = blob.find('\x11'), m2 = blob.find('\x12'), m3 = blob.find('\x13'), m4 = blob.find('\x14');
+            const std::string sfx = "_" + std::to_string(c);
+            const std::string c_sample = blob.substr(0, m1), c_logq = blob.substr(m1 + 1, m2 - m1 - 1), c_dlogq = blob.substr(m2 + 1, m3 - m2 - 1),
+                              c_perform = blob.substr(m3 + 1, m4 - m3 - 1), c_invert = blob.substr(m4 + 1);
+            src += "#define AMC_USER_SAMPLE" + sfx + "(z, x, sigma) (" + c_sample + ")\n";
+            src += "#define AMC_USER_LOGQ" + sfx + "(delta, x, sigma) (" + c_logq + ")\n";
+            if (!c_dlogq.empty()) src += "#define AMC_USER_DLOGQ" + sfx + "(delta, x, sigma) (" + c_dlogq + ")\n";
+            src += "#define AMC_USER_PERFORM" + sfx + "(x, delta) (" + (c_perform.empty() ? std::string("(x) + (delta)") : c_perform) + ")\n";
+            src += "#define AMC_USER_INVERT" + sfx + "(delta, x) (" + (c_invert.empty() ? std::string("-(delta)") : c_invert) + ")\n";
+            at = nxt;
+        }
+    }
     const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
@@ -800,7 +822,9 @@ int amc_device_count(int* count)
     return AMC_OK;
 }
 
-struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; int n_params; const char* const* dlogq_more; };   // dlogq_more: partials 1 .. n_params - 1
+struct ClassExprs { const char *sample, *logq, *dlogq, *perform, *invert; };
+struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; int n_params; const char* const* dlogq_more;   // dlogq_more: partials 1 .. n_params - 1
+                       int n_classes; const ClassExprs* more_classes; const int* class_of_move; };   // pools that mix policies / actions: classes 1 .. n_classes - 1
 
 static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
                        const char* scale_expr = nullptr, const ProposalExprs* proposal = nullptr)
@@ -850,6 +874,14 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
                 rc_p = fail(AMC_ERR_BAD_ARG, "amc_create_action_model: perform_expr and invert_expr come together (No invert_action! is defined)");
             if (rc_p == AMC_OK && proposal->perform) rc_p = validate_potential_expr(proposal->perform, "perform_action expression", "delta");
             if (rc_p == AMC_OK && proposal->invert) rc_p = validate_potential_expr(proposal->invert, "invert_action expression", "delta");
+            for (int c = 1; rc_p == AMC_OK && c < proposal->n_classes; ++c) {
+                const ClassExprs& ce = proposal->more_classes[c - 1];
+                rc_p = validate_potential_expr(ce.sample, "sample_action expression", "z");
+                if (rc_p == AMC_OK) rc_p = validate_potential_expr(ce.logq, "log_proposal_density expression", "delta");
+                if (rc_p == AMC_OK && ce.dlogq) rc_p = validate_potential_expr(ce.dlogq, "d log_proposal_density / d sigma expression", "");
+                if (rc_p == AMC_OK && ce.perform) rc_p = validate_potential_expr(ce.perform, "perform_action expression", "delta");
+                if (rc_p == AMC_OK && ce.invert) rc_p = validate_potential_expr(ce.invert, "invert_action expression", "delta");
+            }
             if (rc_p != AMC_OK) return rc_p;
             if (state_dtype != AMC_DTYPE_F64)
                 return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: script-defined proposals are offered for Float64 state");
@@ -933,6 +965,17 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         }
         if (proposal->perform) h->pot_expr += std::string("\x07") + proposal->perform + std::string("\x08") + proposal->invert;
         if (proposal->n_params > 1) h->pot_expr += std::string("\x0e") + std::to_string(proposal->n_params);
+        if (proposal->n_classes > 1) {
+            // [ '\x0f' n_classes { '\x10' sample '\x11' logq '\x12' dlogq '\x13' perform '\x14' invert } per class 1 .. ]: empty = not given
+            h->pot_expr += std::string("\x0f") + std::to_string(proposal->n_classes);
+            for (int c = 1; c < proposal->n_classes; ++c) {
+                const ClassExprs& ce = proposal->more_classes[c - 1];
+                h->pot_expr += std::string("\x10") + ce.sample + std::string("\x11") + ce.logq + std::string("\x12") + (ce.dlogq ? ce.dlogq : "") +
+                               std::string("\x13") + (ce.perform ? ce.perform : "") + std::string("\x14") + (ce.invert ? ce.invert : "");
+            }
+            h->n_classes = proposal->n_classes;
+            for (int k = 0; k < cfg->n_moves; ++k) h->class_of_move[k] = proposal->class_of_move[k];
+        }
         h->script_policy = true;
         h->script_dlogq = proposal->dlogq != nullptr;
         h->n_params = proposal->n_params;
@@ -1020,6 +1063,12 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
+    if (h->n_classes > 1) {            // the moves' classes: a row of the parameter table (amc_kernels.h PT_CLASS)
+        double cls[AMC_MAX_MOVES];
+        for (int k = 0; k < AMC_MAX_MOVES; ++k) cls[k] = (double)h->class_of_move[k];
+        if (hipMemcpy(h->d_ptab + amc::PT_CLASS * AMC_MAX_MOVES, cls, sizeof(cls), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(AMC_ERR_HIP, "amc_create_mixed_model: copying the class table failed"));
+    }
     if (h->use_rtc) {
         // compile the smallest kernel now so that a malformed expression fails HERE, with the compiler's message
         hipFunction_t fn = nullptr;
@@ -1114,7 +1163,7 @@ int amc_create_vector_policy_model(const amc_config* cfg, int n_params, const ch
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
     c2.potential = AMC_POTENTIAL_CUSTOM;
     const ProposalExprs prop = {sample_expr, logq_expr, dlogq_exprs ? dlogq_exprs[0] : nullptr, perform_expr, invert_expr, n_params,
-                                dlogq_exprs ? dlogq_exprs + 1 : nullptr};
+                                dlogq_exprs ? dlogq_exprs + 1 : nullptr, 1, nullptr, nullptr};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 
@@ -1135,7 +1184,46 @@ int amc_create_action_model(const amc_config* cfg, const char* potential_expr, c
     std::memset(&c2, 0, sizeof(c2));
     std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
     c2.potential = AMC_POTENTIAL_CUSTOM;
-    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr, 1, nullptr};
+    const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr, 1, nullptr, 1, nullptr, nullptr};
+    return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
+}
+
+int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* class_of_move, const char* potential_expr,
+                           const char* reward_expr, const char* const* sample_exprs, const char* const* logq_exprs,
+                           const char* const* dlogq_exprs, const char* const* perform_exprs, const char* const* invert_exprs,
+                           amc_handle** out)
+{
+    if (!cfg || !class_of_move || !sample_exprs || !logq_exprs) return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: NULL argument");
+    if (n_classes < 1 || n_classes > AMC_MAX_CLASSES)
+        return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: n_classes must be in [1, %d]", AMC_MAX_CLASSES);
+    if (cfg->n_moves < 1 || cfg->n_moves > AMC_MAX_MOVES) return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: n_moves must be in [1, %d]", AMC_MAX_MOVES);
+    for (int k = 0; k < cfg->n_moves; ++k)
+        if (class_of_move[k] < 0 || class_of_move[k] >= n_classes)
+            return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class_of_move[%d] = %d is no class", k, class_of_move[k]);
+    for (int c = 0; c < n_classes; ++c) {
+        if (!sample_exprs[c] || !logq_exprs[c])
+            return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class %d has no sample / logq expression (No sample_action! / log_proposal_density is defined)", c);
+        if (dlogq_exprs && !dlogq_exprs[c])
+            return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: dlogq_exprs[%d] is NULL (one expression per class, or none at all)", c);
+        const bool p = perform_exprs && perform_exprs[c], i = invert_exprs && invert_exprs[c];
+        if (p != i) return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class %d: perform_expr and invert_expr come together (No invert_action! is defined)", c);
+    }
+    const char* pot = potential_expr;
+    if (!pot) {
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: potential_expr is NULL and cfg->potential names no built-in");
+    }
+    amc_config c2;
+    std::memset(&c2, 0, sizeof(c2));
+    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
+    c2.potential = AMC_POTENTIAL_CUSTOM;
+    ClassExprs more[AMC_MAX_CLASSES];
+    for (int c = 1; c < n_classes; ++c)
+        more[c - 1] = ClassExprs{sample_exprs[c], logq_exprs[c], dlogq_exprs ? dlogq_exprs[c] : nullptr, perform_exprs ? perform_exprs[c] : nullptr,
+                                 invert_exprs ? invert_exprs[c] : nullptr};
+    const ProposalExprs prop = {sample_exprs[0], logq_exprs[0], dlogq_exprs ? dlogq_exprs[0] : nullptr, perform_exprs ? perform_exprs[0] : nullptr,
+                                invert_exprs ? invert_exprs[0] : nullptr, 1, nullptr, n_classes, more, class_of_move};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 
@@ -1991,6 +2079,10 @@ static bool pg_fits_without_flush(const amc_handle* h, int q_batch)
     return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap;
 }
 
+// Handles whose estimator takes one launch per learnable move: policies with several parameters (the move's columns fill a row
+// of the kernel's tail) and pools of several policy / action classes (see PgArgs.l_base).
+static bool per_move_launches(const amc_handle* h) { return h->n_params > 1 || h->n_classes > 1; }
+
 // Validates, launches K3 over this shard.  Shared by the host- and device-resident estimator paths.
 // tail: 1 = the totals of (j, grad j, grad logq, g) per learnable move as records in h->d_out (this shard's slot), 2 = instead
 // gradients_data += gd, 3 = + learning step (opt must be given); see PgArgs.
@@ -2014,8 +2106,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         return fail(AMC_ERR_STATE, "%s: this handle's script-defined proposal came without d logq / d sigma (dlogq_expr): "
                                    "No withgrad_log_proposal_density! is defined", who);
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
-    if (h->n_params > 1 && (n_learn != 1 || tail != 1 || with_sweep))
-        return fail(AMC_ERR_STATE, "%s: a policy with several parameters takes one learnable move per launch", who);
+    if (per_move_launches(h) && (n_learn != 1 || tail != 1 || with_sweep))
+        return fail(AMC_ERR_STATE, "%s: a policy with several parameters (a pool of several classes) takes one learnable move per launch", who);
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;
     a.x = h->d_x;
@@ -2088,7 +2180,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
 static int pg_estimate_records(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, const double** recs)
 {
     int nl = 0;
-    if (h->n_params > 1) {
+    if (per_move_launches(h)) {
         // one launch per learnable move, its 1 + 2P + P(P+1)/2 records behind those of the moves before it
         if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
         if (n_learn == 0) return pg_launch(h, who, 0, learn_ids, q_batch, &nl);
@@ -2209,9 +2301,9 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
                               bool with_sweep = false, bool reduce = false, int* grid_out = nullptr)
 {
     int nl = 0;
-    if (h->n_params > 1) {
+    if (per_move_launches(h)) {
         // per learnable move: estimator launch (records in d_out), the gather across shards, gradients_data[k] += gd
-        if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters");
+        if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters (a pool of several classes)");
         if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
         if (n_learn == 0) return pg_launch(h, "amc_pg_accumulate", 0, learn_ids, q_batch, &nl);
         const int nc = amc::pg_n_columns(h->n_params);
@@ -2220,11 +2312,20 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
             int rc = pg_launch(h, "amc_pg_accumulate", 1, learn_ids + l, q_batch, &nl, 1, nullptr, false, false, nullptr, l, l + 1 == n_learn);
             if (rc == AMC_OK && h->comm) rc = pg_allreduce_records(h, nc);
             if (rc != AMC_OK) return rc;
-            hipLaunchKernelGGL(amc::pg_accumulate_np_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, ranks, h->n_params, learn_ids[l],
-                               (double)h->M_global * (double)q_batch, h->d_gd_acc);
+            if (h->n_params > 1)
+                hipLaunchKernelGGL(amc::pg_accumulate_np_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, ranks, h->n_params, learn_ids[l],
+                                   (double)h->M_global * (double)q_batch, h->d_gd_acc);
+            else          // one parameter (a pool of several classes): the one-parameter accumulators, one move at a time
+                hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, ranks, 1, make_ids(1, learn_ids + l),
+                                   (double)h->M_global * (double)q_batch, h->d_gd_acc);
             AMC_HIP(hipGetLastError());
         }
-        if (opt) return pg_update_np(h, n_learn, learn_ids, *opt);
+        if (opt && h->n_params > 1) return pg_update_np(h, n_learn, learn_ids, *opt);
+        if (opt) {
+            hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
+                               make_ids(n_learn, learn_ids), *opt, h->K, h->d_status);
+            AMC_HIP(hipGetLastError());
+        }
         return AMC_OK;
     }
     const int tail = h->comm ? 1 : (opt ? 3 : 2);
@@ -2308,7 +2409,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
-    const bool fused = h->n_params == 1 && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
+    const bool fused = !per_move_launches(h) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
     const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h) && pg_fits_without_flush(h, q_batch);

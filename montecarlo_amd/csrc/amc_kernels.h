@@ -52,7 +52,8 @@ typedef double2 real2;
 enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF = 5, PT_WEIGHT = 6,
        PT_RDEN = 7, PT_C3HI = 8, PT_C3LO = 9,
        PT_THETA1 = 10, PT_THETA2 = 11, PT_THETA3 = 12,      // parameters 1..3 of a script-defined policy with several (AMC_NP)
-       PT_ROWS = 13 };
+       PT_CLASS = 13,                                       // the move's policy / action class (pools that mix them: AMC_NCLASS)
+       PT_ROWS = 14 };
 
 // Parameters of a move's policy (Move.parameters, src/metropolis.jl:140-147: an array; GradientData keeps grad j and
 // grad logq as arrays of that shape and g as their outer product, PolicyGuided/gradients.jl:41-61).  The built-in Gaussian
@@ -63,6 +64,14 @@ enum { PT_SIGMA = 0, PT_DEN = 1, PT_LOGC = 2, PT_CUM = 3, PT_DDEN = 4, PT_DLHALF
 #ifndef AMC_NP
 #define AMC_NP 1
 #endif
+// Pools that MIX policy / action types: every Move carries its own `action` and `policy` (metropolis.jl:140-162), and the
+// generic functions dispatch on their types.  A handle of amc_create_mixed_model has up to AMC_MAX_CLASSES expression sets
+// ("classes": sample, logq, dlogq, perform, invert), one class per move (PT_CLASS); the translation unit defines AMC_NCLASS and,
+// for the classes 1 .. 3, the macros suffixed _1 .. _3 (class 0: the unsuffixed ones).  One parameter per move.
+#ifndef AMC_NCLASS
+#define AMC_NCLASS 1
+#endif
+#define AMC_MAX_CLASSES 4
 #define AMC_MAX_NP 4
 // GradientData columns of one learnable move: j, grad j [NP], grad logq [NP], g [upper triangle, row by row]
 #define AMC_PG_NC (1 + 2 * AMC_NP + AMC_NP * (AMC_NP + 1) / 2)
@@ -147,27 +156,81 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
 #ifndef AMC_USER_INVERT
 #define AMC_USER_INVERT(delta, x) (-(delta))
 #endif
-__device__ __forceinline__ real_t user_perform(real_t x, real_t delta, const double* amc_tables_)
+#if AMC_NCLASS > 1
+__shared__ int s_user_class[AMC_MAX_MOVES];
+// the expression of move k's class: class 0 the unsuffixed macro, classes 1 .. 3 (where the pool has them) the suffixed ones
+// (k carries the class in its bits 8 and up -- user_move_key: per lane in the sweep, where the lanes of a wave hold different
+// moves; read through the scalar unit in the estimator, whose move is the launch's)
+#define AMC_BY_CLASS(k, T_, E0, E1, E2, E3)                                                                            \
+    do {                                                                                                               \
+        const int cls_ = (k) >> 8;                                                                                     \
+        if (cls_ == 1) return (T_)(E1);                                                                                \
+        if (AMC_NCLASS > 2 && cls_ == 2) return (T_)(E2);                                                              \
+        if (AMC_NCLASS > 3 && cls_ == 3) return (T_)(E3);                                                              \
+        return (T_)(E0);                                                                                               \
+    } while (0)
+#if AMC_NCLASS < 3
+#define AMC_USER_SAMPLE_2 AMC_USER_SAMPLE
+#define AMC_USER_LOGQ_2 AMC_USER_LOGQ
+#define AMC_USER_PERFORM_2 AMC_USER_PERFORM
+#define AMC_USER_INVERT_2 AMC_USER_INVERT
+#endif
+#if AMC_NCLASS < 4
+#define AMC_USER_SAMPLE_3 AMC_USER_SAMPLE
+#define AMC_USER_LOGQ_3 AMC_USER_LOGQ
+#define AMC_USER_PERFORM_3 AMC_USER_PERFORM
+#define AMC_USER_INVERT_3 AMC_USER_INVERT
+#endif
+// d logq / d sigma: given for every class or for none (the host refuses the estimator then)
+#ifdef AMC_USER_DLOGQ
+#define AMC_USER_DLOGQ_0 AMC_USER_DLOGQ
+#if AMC_NCLASS < 3
+#define AMC_USER_DLOGQ_2 AMC_USER_DLOGQ
+#endif
+#if AMC_NCLASS < 4
+#define AMC_USER_DLOGQ_3 AMC_USER_DLOGQ
+#endif
+#else
+#define AMC_USER_DLOGQ_0(delta, x, sigma) __builtin_nan("")
+#define AMC_USER_DLOGQ_1(delta, x, sigma) __builtin_nan("")
+#define AMC_USER_DLOGQ_2(delta, x, sigma) __builtin_nan("")
+#define AMC_USER_DLOGQ_3(delta, x, sigma) __builtin_nan("")
+#endif
+#endif
+__device__ __forceinline__ real_t user_perform(real_t x, real_t delta, const double* amc_tables_, int k)
 {
+#if AMC_NCLASS > 1
+    AMC_BY_CLASS(k, real_t, AMC_USER_PERFORM(x, delta), AMC_USER_PERFORM_1(x, delta), AMC_USER_PERFORM_2(x, delta), AMC_USER_PERFORM_3(x, delta));
+#else
+    (void)k;
     return (real_t)(AMC_USER_PERFORM(x, delta));
+#endif
 }
-__device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const double* amc_tables_)
+__device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const double* amc_tables_, int k)
 {
+#if AMC_NCLASS > 1
+    AMC_BY_CLASS(k, real_t, AMC_USER_INVERT(delta, x), AMC_USER_INVERT_1(delta, x), AMC_USER_INVERT_2(delta, x), AMC_USER_INVERT_3(delta, x));
+#else
+    (void)k;
     return (real_t)(AMC_USER_INVERT(delta, x));
+#endif
 }
 // The move's further parameters (AMC_NP > 1) live in an LDS copy of their table rows, staged by the kernels that propose
 // (stage_user_theta); the expressions see them as theta1 .. theta3, and theta0 is another name of sigma.  k: the move.
 #if AMC_NP > 1
 __shared__ double s_user_theta[AMC_MAX_NP - 1][AMC_MAX_MOVES];
 #define AMC_USER_THETAS(k)                                                                                             \
-    const double theta0 = sigma, theta1 = s_user_theta[0][k], theta2 = AMC_NP > 2 ? s_user_theta[1][k] : 0.0,          \
-                 theta3 = AMC_NP > 3 ? s_user_theta[2][k] : 0.0;                                                       \
+    const double theta0 = sigma, theta1 = s_user_theta[0][(k) & 0xFF], theta2 = AMC_NP > 2 ? s_user_theta[1][(k) & 0xFF] : 0.0, \
+                 theta3 = AMC_NP > 3 ? s_user_theta[2][(k) & 0xFF] : 0.0;                                              \
     (void)theta0; (void)theta1; (void)theta2; (void)theta3
 #else
 #define AMC_USER_THETAS(k) const double theta0 = sigma; (void)theta0; (void)k
 #endif
 __device__ __forceinline__ void stage_user_theta(const double* ptab)       // before a barrier the caller already has
 {
+#if AMC_NCLASS > 1
+    for (int i = threadIdx.x; i < AMC_MAX_MOVES; i += AMC_BLOCK) s_user_class[i] = (int)ptab[PT_CLASS * AMC_MAX_MOVES + i];
+#endif
 #if AMC_NP > 1
     for (int i = threadIdx.x; i < (AMC_NP - 1) * AMC_MAX_MOVES; i += AMC_BLOCK)
         s_user_theta[i / AMC_MAX_MOVES][i % AMC_MAX_MOVES] = ptab[(PT_THETA1 + i / AMC_MAX_MOVES) * AMC_MAX_MOVES + i % AMC_MAX_MOVES];
@@ -175,21 +238,52 @@ __device__ __forceinline__ void stage_user_theta(const double* ptab)       // be
     (void)ptab;
 #endif
 }
+// what the user_* functions take as `k`: the move, with its class above bit 8 in pools that mix classes
+__device__ __forceinline__ int user_move_key(int k)                    // the sweep: the lane's move, class from the LDS copy
+{
+#if AMC_NCLASS > 1
+    return k | (s_user_class[k] << 8);
+#else
+    return k;
+#endif
+}
+__device__ __forceinline__ int user_move_key_uniform(int k, const double* ptab)      // the estimator: the launch's move
+{
+#if AMC_NCLASS > 1
+    return k | ((int)ptab[PT_CLASS * AMC_MAX_MOVES + k] << 8);
+#else
+    (void)ptab;
+    return k;
+#endif
+}
 __device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_, int k)
 {
     AMC_USER_THETAS(k);
+#if AMC_NCLASS > 1
+    AMC_BY_CLASS(k, real_t, AMC_USER_SAMPLE(z, x, sigma), AMC_USER_SAMPLE_1(z, x, sigma), AMC_USER_SAMPLE_2(z, x, sigma), AMC_USER_SAMPLE_3(z, x, sigma));
+#else
     return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
+#endif
 }
 __device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k)
 {
     AMC_USER_THETAS(k);
+#if AMC_NCLASS > 1
+    AMC_BY_CLASS(k, double, AMC_USER_LOGQ(delta, x, sigma), AMC_USER_LOGQ_1(delta, x, sigma), AMC_USER_LOGQ_2(delta, x, sigma), AMC_USER_LOGQ_3(delta, x, sigma));
+#else
     return (double)(AMC_USER_LOGQ(delta, x, sigma));
+#endif
 }
 // grad log_proposal_density with respect to the parameters, d[p] = d logq / d theta_p
 __device__ __forceinline__ void user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, double (&d)[AMC_NP])
 {
     AMC_USER_THETAS(k);
-#ifdef AMC_USER_DLOGQ
+#if AMC_NCLASS > 1
+    d[0] = [&]() -> double {
+        AMC_BY_CLASS(k, double, AMC_USER_DLOGQ_0(delta, x, sigma), AMC_USER_DLOGQ_1(delta, x, sigma), AMC_USER_DLOGQ_2(delta, x, sigma),
+                     AMC_USER_DLOGQ_3(delta, x, sigma));
+    }();
+#elif defined(AMC_USER_DLOGQ)
     d[0] = (double)(AMC_USER_DLOGQ(delta, x, sigma));
 #if AMC_NP > 1
     d[1] = (double)(AMC_USER_DLOGQ1(delta, x, sigma));
@@ -347,15 +441,15 @@ __device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, 
     const real_t delta = user_sample(z, x, sigma, T, k);                 // :177 sample_action!
     const double logq_f = user_logq(delta, x, sigma, T, k);              // :178
     const real_t e1 = potential<POT>(x, T);
-    const real_t xn = user_perform(x, delta, T);                         // :179 perform_action!
+    const real_t xn = user_perform(x, delta, T, k);                      // :179 perform_action!
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
-    const real_t nd = user_invert(delta, xn, T);                         // :181 invert_action!
+    const real_t nd = user_invert(delta, xn, T, k);                      // :181 invert_action!
     const double logq_b = user_logq(nd, xn, sigma, T, k);                // :182
     const double arg = ((double)dlogp + logq_b) - logq_f;                // :183
     const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
     const bool acc = c_pos | (c_rng & c_exp);
-    x = acc ? xn : user_perform(xn, nd, T);                              // :187 perform_action_cached!
+    x = acc ? xn : user_perform(xn, nd, T, k);                           // :187 perform_action_cached!
     return acc;
 }
 #endif
@@ -385,8 +479,8 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
     {
         if (!have_pu) pu = philox4x32_10(accept_ctr, key0, key1);
 #ifdef AMC_USER_LOGQ
-        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T, MULTI ? k0 : 0);
-        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T, MULTI ? k1 : 0);
+        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T, user_move_key(MULTI ? k0 : 0));
+        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T, user_move_key(MULTI ? k1 : 0));
 #else
         const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
         const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
@@ -1784,8 +1878,9 @@ struct PgArgs {
     // dependent-launch gap on this part).  tail_mode 0: block rows only; 1: + their total as records in `out`;
     // 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
-    // AMC_NP > 1: a launch takes ONE learnable move (its columns fill a row), the l_base-th of the estimator call -- the index
-    // that, with q, names the sample's draw
+    // AMC_NP > 1, AMC_NCLASS > 1: a launch takes ONE learnable move (several parameters: its columns fill a row; classes: hipcc
+    // 7.2 fails on the unrolled loop over moves with a class switch in it, "illegal VGPR to SGPR copy"), the l_base-th of the
+    // estimator call -- the index that, with q, names the sample's draw
     int32_t l_base;
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
@@ -1886,14 +1981,14 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     const double logq_f = user_logq(delta, x, sigma, T, k);
     user_dlogq(delta, x, sigma, T, k, d_f);
     const real_t e1 = potential<POT>(x, T);
-    const real_t xn = user_perform(x, delta, T);
+    const real_t xn = user_perform(x, delta, T, k);
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
-    const real_t nd = user_invert(delta, xn, T);
+    const real_t nd = user_invert(delta, xn, T, k);
     const double logq_b = user_logq(nd, xn, sigma, T, k);
     user_dlogq(nd, xn, sigma, T, k, d_b);
-    x = user_perform(xn, nd, T);
+    x = user_perform(xn, nd, T, k);
     const double arg = ((double)dlogp + logq_b) - logq_f;
     double ex = exp_core_f64(arg, T);
     asm volatile("" : "+v"(ex));
@@ -2426,7 +2521,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                 }
                 for (int q = q0; q < q1; ++q) {
                     double z0, z1;
-#if AMC_NP > 1
+#if AMC_NP > 1 || AMC_NCLASS > 1
                     const uint32_t sample_id = (uint32_t)((a.l_base + l) * a.q_batch + q);
 #else
                     const uint32_t sample_id = (uint32_t)(l * a.q_batch + q);
@@ -2439,8 +2534,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 #pragma unroll
                     for (int i = 0; i < NC; ++i) s1[i] = 0.0;
 #if defined(AMC_USER_LOGQ)
-                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math, a.learn_ids[l]);
-                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math, a.learn_ids[l]);
+                    const int move_key = user_move_key_uniform(a.learn_ids[l], a.ptab);
+                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math, move_key);
+                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math, move_key);
 #else
                     pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);

@@ -18,6 +18,33 @@ from .simulation import AriannaAlgorithm, Simulation, _calls, julia_repr
 from .system import Move, ParticleChains
 
 
+GAUSS_SAMPLE = "sigma*z"
+GAUSS_LOGQ = "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0"      # particle_1d.jl:52-54
+GAUSS_DLOGQ = "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma"
+
+
+def _move_signature(m):
+    """What the kernels must be compiled for to serve this move: its (policy, action) type with their expressions."""
+    act = (m.action.perform, m.action.invert) if hasattr(m.action, "perform") else (None, None)
+    if hasattr(m.policy, "logq"):
+        return ("script", m.policy.sample, m.policy.logq, m.policy.dlogq) + act
+    scale = getattr(m.policy, "scale", None)
+    if scale is not None:
+        return ("scaled", scale) + act
+    return ("gauss",) + act
+
+
+def _class_expressions(sig):
+    """(sample, logq, dlogq, perform, invert) of one class of a mixed pool; the Gaussian policies written out as expressions."""
+    if sig[0] == "script":
+        return tuple(sig[1:6])
+    if sig[0] == "scaled":
+        w = f"(sigma*({sig[1]}))"
+        return (f"{w}*z", f"-(delta*delta)/(2.0*({w}*{w})) - amc_log(6.283185307179586*({w}*{w}))/2.0",
+                f"((delta*delta)/({w}*{w}*{w}))*({sig[1]}) - ({sig[1]})/{w}", sig[2], sig[3])
+    return (GAUSS_SAMPLE, GAUSS_LOGQ, GAUSS_DLOGQ, sig[1], sig[2])
+
+
 class Metropolis(AriannaAlgorithm):
     """Metropolis(chains; pool, sweepstep=1, seed=1, ...) -- src/metropolis.jl:288-291.
 
@@ -66,20 +93,26 @@ class Metropolis(AriannaAlgorithm):
         extra = {} if getattr(chains, "reward", None) is None else {"reward_expr": chains.reward}
         if getattr(chains, "dtype", "f64") != "f64":
             extra["dtype"] = chains.dtype
-        scales = {getattr(m.policy, "scale", None) for m in self.pool}
-        if scales != {None}:
-            # one policy expression per handle: the kernels are compiled for it
-            if len(scales) != 1:
-                raise ValueError("all moves of a pool must share one policy: either StandardGaussian or one ScaledGaussian(scale)")
-            extra["scale_expr"] = scales.pop()
-        scripts = {((m.policy.sample, m.policy.logq, m.policy.dlogq) +
-                    ((m.action.perform, m.action.invert) if hasattr(m.action, "perform") else (None, None)))
-                   if hasattr(m.policy, "logq") else None for m in self.pool}
         n_params = 1
-        if scripts != {None}:
-            if len(scripts) != 1:
-                raise ValueError("all moves of a pool must share one policy (and one action): one ScriptPolicy, or none")
-            extra["proposal"] = scripts.pop()
+        kinds = [_move_signature(m) for m in self.pool]
+        if len(set(kinds)) > 1:
+            # A pool that MIXES policy / action types -- every Move carries its own (src/metropolis.jl:140-162): one expression set
+            # ("class") per distinct (policy, action) pair, the built-in Gaussian displacement written out as expressions too
+            # (amc_create_mixed_model).  One parameter per move.
+            if any(int(getattr(m.policy, "n_params", 1)) != 1 for m in self.pool):
+                raise ValueError("a pool that mixes policy types takes policies of one parameter")
+            order = list(dict.fromkeys(kinds))
+            if len(order) > 4:
+                raise ValueError("a pool may mix at most 4 different (policy, action) types")
+            classes = [_class_expressions(k) for k in order]
+            if any(c[2] is None for c in classes):            # d logq / d sigma for every class or for none (no estimator then)
+                classes = [(c[0], c[1], None, c[3], c[4]) for c in classes]
+            extra["classes"] = classes
+            extra["class_of_move"] = [order.index(k) for k in kinds]
+        elif kinds[0][0] == "scaled":
+            extra["scale_expr"] = kinds[0][1]                  # one policy expression per handle: the kernels are compiled for it
+        elif kinds[0][0] == "script":
+            extra["proposal"] = kinds[0][1:]
             # a policy with several parameters (ScriptPolicy(n_params=P)): the engine takes one parameter vector per move
             n_params = int(getattr(self.pool[0].policy, "n_params", 1))
             if n_params > 1:

@@ -325,6 +325,41 @@ void amo_set_vector_policy(int np, double (*sample)(double, double, const double
  * the inverted action.  0: the displacement (x + delta, -delta).  Used together with a script-defined proposal. */
 static double (*g_custom_perform)(double, double) = 0;
 static double (*g_custom_invert)(double, double) = 0;
+
+/* Pools that mix policy / action types (every Move carries its own action and policy, src/metropolis.jl:140-162; the generic
+ * functions dispatch on their types): up to AMO_MAX_CLASSES sets of functions, one class per move.  The class of the move at hand
+ * is a thread-local the sweep / estimator loops set before they call mc_step / pgmc_sample (the chains run on OpenMP threads). */
+#define AMO_MAX_CLASSES 4
+static int g_n_classes = 1;
+static int g_class_of_move[64];
+static double (*g_cls_sample[AMO_MAX_CLASSES])(double, double, double);
+static double (*g_cls_logq[AMO_MAX_CLASSES])(double, double, double);
+static double (*g_cls_dlogq[AMO_MAX_CLASSES])(double, double, double);
+static double (*g_cls_perform[AMO_MAX_CLASSES])(double, double);
+static double (*g_cls_invert[AMO_MAX_CLASSES])(double, double);
+static _Thread_local int tl_cls = 0;
+#define CUR_SAMPLE  (g_n_classes > 1 ? g_cls_sample[tl_cls] : g_custom_sample)
+#define CUR_LOGQ    (g_n_classes > 1 ? g_cls_logq[tl_cls] : g_custom_logq)
+#define CUR_DLOGQ   (g_n_classes > 1 ? g_cls_dlogq[tl_cls] : g_custom_dlogq)
+#define CUR_PERFORM (g_n_classes > 1 ? g_cls_perform[tl_cls] : g_custom_perform)
+#define CUR_INVERT  (g_n_classes > 1 ? g_cls_invert[tl_cls] : g_custom_invert)
+static inline void set_class_of(int k) { tl_cls = g_n_classes > 1 ? g_class_of_move[k] : 0; }
+void amo_set_policy_classes(int n_classes, const int *class_of_move, int n_moves, void *const *sample, void *const *logq,
+                            void *const *dlogq, void *const *perform, void *const *invert)
+{
+    g_n_classes = n_classes > 1 ? n_classes : 1;
+    if (g_n_classes == 1) return;
+    for (int k = 0; k < 64; ++k) g_class_of_move[k] = k < n_moves ? class_of_move[k] : 0;
+    for (int c = 0; c < n_classes; ++c) {
+        g_cls_sample[c] = (double (*)(double, double, double))sample[c];
+        g_cls_logq[c] = (double (*)(double, double, double))logq[c];
+        g_cls_dlogq[c] = dlogq ? (double (*)(double, double, double))dlogq[c] : 0;
+        g_cls_perform[c] = perform ? (double (*)(double, double))perform[c] : 0;
+        g_cls_invert[c] = invert ? (double (*)(double, double))invert[c] : 0;
+    }
+    /* the one-policy switches stay meaningful: a script-defined proposal is active, with or without its sigma-derivative */
+    g_custom_sample = g_cls_sample[0]; g_custom_logq = g_cls_logq[0]; g_custom_dlogq = g_cls_dlogq[0];
+}
 void amo_set_custom_action(double (*perform)(double, double), double (*invert)(double, double))
 {
     g_custom_perform = perform; g_custom_invert = invert;
@@ -424,7 +459,7 @@ static inline void perform_action(particle_t *p, const move_t *m, int pot, doubl
 static inline void script_perform_action(particle_t *p, const move_t *m, int pot, double *e1, double *e2)
 {
     *e1 = p->e;
-    p->x = g_custom_perform ? g_custom_perform(p->x, m->delta) : p->x + m->delta;
+    p->x = CUR_PERFORM ? CUR_PERFORM(p->x, m->delta) : p->x + m->delta;
     p->e = amo_potential(pot, p->x);
     *e2 = p->e;
 }
@@ -454,7 +489,7 @@ static inline int mc_step_vec(particle_t *p, move_t *m, const double *theta, int
     double e1c, e2c;
     script_perform_action(p, m, pot, &e1c, &e2c);                      /* :179 */
     double dlogp_c = delta_log_target_density(e1c, p->beta, e2c, p->beta); /* :180 */
-    m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;  /* :181 */
+    m->delta = CUR_INVERT ? CUR_INVERT(m->delta, p->x) : -m->delta;  /* :181 */
     double logq_b = g_vec_logq(m->delta, p->x, theta);                 /* :182 at the new state */
     double alpha_c = julia_min(1.0, amo_exp(dlogp_c + logq_b - logq_f)); /* :183 */
     if (alpha_c > u) return 1;                                         /* :184 */
@@ -467,13 +502,13 @@ static inline int mc_step_vec(particle_t *p, move_t *m, const double *theta, int
 static inline int mc_step(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
 {
     if (g_custom_logq) {                                           /* script-defined proposal */
-        m->delta = g_custom_sample(z, p->x, sigma);                    /* :177 sample_action! */
-        double logq_f = g_custom_logq(m->delta, p->x, sigma);          /* :178 at the old state */
+        m->delta = CUR_SAMPLE(z, p->x, sigma);                    /* :177 sample_action! */
+        double logq_f = CUR_LOGQ(m->delta, p->x, sigma);          /* :178 at the old state */
         double e1c, e2c;
         script_perform_action(p, m, pot, &e1c, &e2c);                  /* :179 */
         double dlogp_c = delta_log_target_density(e1c, p->beta, e2c, p->beta); /* :180 */
-        m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;  /* :181 invert_action!(action, system) */
-        double logq_b = g_custom_logq(m->delta, p->x, sigma);          /* :182 at the new state */
+        m->delta = CUR_INVERT ? CUR_INVERT(m->delta, p->x) : -m->delta;  /* :181 invert_action!(action, system) */
+        double logq_b = CUR_LOGQ(m->delta, p->x, sigma);          /* :182 at the new state */
         double alpha_c = julia_min(1.0, amo_exp(dlogp_c + logq_b - logq_f)); /* :183 */
         if (alpha_c > u) return 1;                                     /* :184 */
         script_perform_action(p, m, pot, &e1c, &e2c);                  /* :187 perform_action_cached! */
@@ -656,6 +691,7 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         amo_box_muller(v, zz);
         double u = amo_uniform_accept(amo_spare_accept12(v, half), va[2 * half], va[2 * half + 1]);
         move_t *move = &pool[id];                                  /* :207 */
+        set_class_of(id);
         if (g_vec_logq) {
             double th[AMO_MAX_NP];
             move_theta(s, id, th);
@@ -1164,16 +1200,16 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
     if (g_custom_logq) {
         /* script-defined proposal: value and sigma-derivative of the forward density at the old state (:97), of the
          * backward density at the new state (:102) */
-        m->delta = g_custom_sample(z, p->x, sigma);
-        double logq_f = g_custom_logq(m->delta, p->x, sigma);
-        double dlogq_f = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
+        m->delta = CUR_SAMPLE(z, p->x, sigma);
+        double logq_f = CUR_LOGQ(m->delta, p->x, sigma);
+        double dlogq_f = g_custom_dlogq ? CUR_DLOGQ(m->delta, p->x, sigma) : (0.0 / 0.0);
         double e1, e2;
         script_perform_action(p, m, pot, &e1, &e2);
         double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta);
         double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;
-        m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;
-        double logq_b = g_custom_logq(m->delta, p->x, sigma);
-        double dlogq_b = g_custom_dlogq ? g_custom_dlogq(m->delta, p->x, sigma) : (0.0 / 0.0);
+        m->delta = CUR_INVERT ? CUR_INVERT(m->delta, p->x) : -m->delta;
+        double logq_b = CUR_LOGQ(m->delta, p->x, sigma);
+        double dlogq_b = g_custom_dlogq ? CUR_DLOGQ(m->delta, p->x, sigma) : (0.0 / 0.0);
         script_perform_action(p, m, pot, &e1, &e2);
         double alpha = julia_min(1.0, amo_exp(dlogp + logq_b - logq_f));
         double j = r * alpha;
@@ -1391,6 +1427,7 @@ void amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int 
                 amo_box_muller(v, zz);
                 particle_t *p = &s->chains[c];
                 move_t *m = &s->pools[c * s->K + lid];
+                set_class_of(lid);
                 if (script) {
                     /* script-defined policies: the reference's operations (the kernels mirror them), products rounded */
                     double gd[4];
@@ -1449,6 +1486,7 @@ void amo_pg_estimate_plain(amo_sim *s, int n_learn, const int *learn_ids, int q_
                 double zz[2], gd[4];
                 draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
                 amo_box_muller(v, zz);
+                set_class_of(lid);
                 if (s->f32)
                     pgmc_sample_f32(&s->chains[c], &s->pools[c * s->K + lid], s->sigma[lid], s->pot, zz[half], gd);
                 else
@@ -1476,7 +1514,7 @@ static void pgmc_sample_vec(particle_t *p, move_t *m, const double *theta, int p
     script_perform_action(p, m, pot, &e1, &e2);                        /* :98 */
     double dlogp = delta_log_target_density(e1, p->beta, e2, p->beta); /* :99 */
     double r = g_custom_reward ? g_custom_reward(m->delta, p->x) : m->delta * m->delta;   /* :100 */
-    m->delta = g_custom_invert ? g_custom_invert(m->delta, p->x) : -m->delta;              /* :101 */
+    m->delta = CUR_INVERT ? CUR_INVERT(m->delta, p->x) : -m->delta;              /* :101 */
     double logq_b = g_vec_logq(m->delta, p->x, theta);                 /* :102 backward, at the new state */
     g_vec_dlogq(m->delta, p->x, theta, d_b);
     script_perform_action(p, m, pot, &e1, &e2);                        /* :103 perform_action_cached! */

@@ -102,6 +102,10 @@ void   amo_set_sigma(amo_sim *s, int k, double sigma);
 /* a policy with several parameters (Move.parameters as an array; amc_create_vector_policy_model is the engine's entry) */
 void   amo_set_vector_policy(int np, double (*sample)(double, double, const double *), double (*logq)(double, double, const double *),
                              void (*dlogq)(double, double, const double *, double *));
+/* pools that mix policy / action types: one class of functions per move (sample / logq / dlogq (z|delta, x, sigma), perform(x, delta),
+ * invert(delta, x); dlogq, perform, invert arrays or entries may be 0); n_classes <= 1 restores the one-policy forms */
+void   amo_set_policy_classes(int n_classes, const int *class_of_move, int n_moves, void *const *sample, void *const *logq,
+                              void *const *dlogq, void *const *perform, void *const *invert);
 void   amo_set_theta(amo_sim *s, int k, int p, double v);
 double amo_get_theta(const amo_sim *s, int k, int p);
 void   amo_pg_estimate_records_vec(amo_sim *s, int n_learn, const int *learn_ids, int q_batch, double *recs);

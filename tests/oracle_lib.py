@@ -410,6 +410,51 @@ def install_vector_policy(n_params, proposal) -> None:
         lib.amo_set_custom_action(None, None)
 
 
+def install_policy_classes(classes, class_of_move) -> None:
+    """The oracle's global policy CLASSES of a pool that mixes policy / action types (amo_set_policy_classes): classes = list of
+    (sample, logq, dlogq or None, perform or None, invert or None) as C expressions; class_of_move[k] = the class of move k.
+    None restores the one-policy forms."""
+    import hashlib
+    import tempfile
+    lib = load()
+    VP = C.POINTER(C.c_void_p)
+    lib.amo_set_policy_classes.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, VP, VP, VP, VP, VP]
+    lib.amo_set_policy_classes.restype = None
+    if classes is None:
+        lib.amo_set_policy_classes(1, None, 0, None, None, None, None, None)
+        return
+    cl = [tuple((list(c) + [None] * 4)[:5]) for c in classes]
+    key = "m" + hashlib.sha1(repr(cl).encode()).hexdigest()[:16]
+    if key not in _custom_libs:
+        d = tempfile.mkdtemp(prefix="amo_cls_")
+        src, so = os.path.join(d, "cls.cpp"), os.path.join(d, f"cls_{key}.so")
+        body = ""
+        for i, (sample, logq, dlogq, perform, invert) in enumerate(cl):
+            th = "const double theta0 = sigma; (void)theta0; "
+            body += f"double amo_cls_sample_{i}(double z, double x, double sigma) {{ {th}return ({sample}); }}\n"
+            body += f"double amo_cls_logq_{i}(double delta, double x, double sigma) {{ {th}return ({logq}); }}\n"
+            if dlogq:
+                body += f"double amo_cls_dlogq_{i}(double delta, double x, double sigma) {{ {th}return ({dlogq}); }}\n"
+            if perform:
+                body += f"double amo_cls_perform_{i}(double x, double delta) {{ return ({perform}); }}\n"
+                body += f"double amo_cls_invert_{i}(double delta, double x) {{ return ({invert}); }}\n"
+        with open(src, "w") as f:
+            f.write(_CUSTOM_PROLOGUE + body + "}\n")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
+                        src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
+        _custom_libs[key] = C.CDLL(so)
+    L = _custom_libs[key]
+    n = len(cl)
+
+    def ptrs(name, present):
+        return (C.c_void_p * n)(*[C.cast(getattr(L, f"amo_cls_{name}_{i}"), C.c_void_p) if present(cl[i]) else None for i in range(n)])
+    have_d = all(c[2] for c in cl)
+    com = (C.c_int * len(class_of_move))(*[int(v) for v in class_of_move])
+    lib.amo_set_policy_classes(n, com, len(class_of_move), ptrs("sample", lambda c: True), ptrs("logq", lambda c: True),
+                               ptrs("dlogq", lambda c: True) if have_d else None, ptrs("perform", lambda c: c[3]),
+                               ptrs("invert", lambda c: c[3]))
+
+
 def learning_step_vec(opt: str, h0: float, h1: float, theta, gd) -> "np.ndarray | None":
     """amo_learning_step_vec on the averaged GradientData [j, grad j, grad logq, g]; None: singular metric."""
     lib = load()
@@ -433,7 +478,8 @@ class OracleSim:
     """amo_sim: reference-shaped (AoS) ensemble + Metropolis on the CPU."""
 
     def __init__(self, n_chains, *, chain_offset=0, potential="harmonic", beta=1.0, sigma=(1.0,),
-                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1):
+                 weight=(1.0,), seed=1, sweepstep=1, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1,
+                 classes=None, class_of_move=None):
         self.lib = load()
         self.dtype = dtype
         self.n_params = int(n_params)
@@ -444,6 +490,7 @@ class OracleSim:
         install_custom_scale(scale_expr)            # process-global like the potential: one simulation at a time
         install_custom_proposal(None if self.n_params > 1 else proposal)
         install_vector_policy(self.n_params, proposal if self.n_params > 1 else None)
+        install_policy_classes(classes, class_of_move)       # after the one-policy installer: it sets the script switches
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)
@@ -600,7 +647,8 @@ class OracleEngine:
 
     def __init__(self, *, n_chains, chain_offset=0, n_chains_global=None, potential="harmonic", beta=1.0,
                  sigma=(1.0,), weight=(1.0,), seed=1, sweepstep=1, per_chain_counters=True, device=0,
-                 stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1):
+                 stream=None, reward_expr=None, dtype="f64", scale_expr=None, proposal=None, n_params=1, classes=None,
+                 class_of_move=None):
         self.n_chains = int(n_chains)
         self.n_moves = len(sigma)
         self.n_params = int(n_params)
@@ -609,7 +657,7 @@ class OracleEngine:
         self.dtype = dtype
         self.sim = OracleSim(n_chains, chain_offset=chain_offset, potential=potential, beta=beta, sigma=sigma,
                              weight=weight, seed=seed, sweepstep=sweepstep, reward_expr=reward_expr, dtype=dtype,
-                             scale_expr=scale_expr, proposal=proposal, n_params=n_params)
+                             scale_expr=scale_expr, proposal=proposal, n_params=n_params, classes=classes, class_of_move=class_of_move)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
 

@@ -47,8 +47,11 @@ def test_host_mirror_passes_the_policy_to_the_engine(oracle, tmp_path):
     assert not np.array_equal(bits(chains.x), bits(plain.state()[0]))
     mixed = [ma.Move(ma.Displacement(0.0), ma.ScaledGaussian(SCALE), [0.3], 0.5),
              ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), [0.9], 0.5)]
-    with pytest.raises(ValueError, match="share one policy"):
-        ma.Metropolis(ma.ParticleChains.uniform(8, 2.0), pool=mixed, engine_factory=oracle.OracleEngine)
+    # a ScaledGaussian beside a StandardGaussian: a pool of two classes (tests/test_mixed_pool.py), the Gaussians written out as
+    # expressions -- the same chain as the scaled policy's own engine gives when BOTH moves are scaled with scale 1 for the second
+    met = ma.Metropolis(ma.ParticleChains.uniform(8, 2.0), pool=mixed, engine_factory=oracle.OracleEngine)
+    assert met.engine.sim.lib is not None and met.n_params == 1
+    oracle.install_policy_classes(None, None)
 
 
 @pytest.mark.gpu

@@ -54,9 +54,11 @@ def test_host_mirror_passes_the_script_policy_to_the_engine(oracle, tmp_path):
     o.init_uniform(-2, 2)
     o.make_steps(20)
     assert np.array_equal(bits(chains.x), bits(o.state()[0]))
+    # a pool that mixes policy types is a pool of classes (tests/test_mixed_pool.py)
     mixed = [ma.Move(ma.Displacement(0.0), pol, [0.3], 0.5), ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), [0.9], 0.5)]
-    with pytest.raises(ValueError, match="share one policy"):
-        ma.Metropolis(ma.ParticleChains.uniform(8, BETA), pool=mixed, engine_factory=oracle.OracleEngine)
+    met = ma.Metropolis(ma.ParticleChains.uniform(8, BETA), pool=mixed, engine_factory=oracle.OracleEngine)
+    assert met.n_params == 1
+    oracle.install_policy_classes(None, None)
     oracle.install_custom_proposal(None)
 
 
