@@ -264,7 +264,7 @@ def main():
     note = os.path.join(ROOT, "profiles", "r03_valu_floor_verdict.md")
     if os.path.exists(note):
         text += "\n" + open(note).read()
-    open(os.path.join(ROOT, "profiles", "r03_valu_floor.md"), "w").write(text)
+    open(os.path.join(ROOT, "profiles", TAG + "_valu_floor.md"), "w").write(text)
     print(text)
 
 
