@@ -41,6 +41,13 @@ chains = ma.ParticleChains.uniform(M, 2.0, -2.0, 2.0)
 pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.2], 0.6),
         ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 0.4))
 learn = ma.VPG(0.01) if os.environ.get("AMC_TEST_LEARN", "1") == "1" else ma.Static()
+if os.environ.get("AMC_TEST_POLICY") == "drift2":
+    # a policy with TWO parameters (delta = theta0 + theta1 z): GradientData rows of 2 + 2P + P^2 records cross the shards, the
+    # natural-gradient step inverts the 2 x 2 metric on every rank from the same merged sums
+    pol = ma.ScriptPolicy("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
+                          ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"], n_params=2)
+    pool = (ma.Move(ma.Displacement(), pol, [0.0, 0.2], 0.6), ma.Move(ma.Displacement(), pol, [0.05, 0.1], 0.4))
+    learn = ma.NPG(0.002, 1e-6)
 al = (dict(algorithm=ma.Metropolis, pool=pool, seed=42, engine_factory=O.OracleEngine),
       dict(algorithm=ma.PolicyGradientEstimator, dependencies=(ma.Metropolis,), optimisers=(ma.Static(), learn), q_batch_size=2),
       dict(algorithm=ma.PolicyGradientUpdate, dependencies=(ma.PolicyGradientEstimator,), scheduler=ma.build_schedule(steps, 10, 2)),
@@ -51,7 +58,7 @@ ma.run(sim)
 cb = sim.algorithms[-1]
 res = dict(rank=rank, shard=list(sim.algorithms[0].shard), x=[v.hex() for v in chains.x],
            energy=[(t, float(v)) for t, v in cb.rows[0]], acceptance=[(t, [float(a) for a in v]) for t, v in cb.rows[1]],
-           sigma=[float(m.sigma) for m in pool], accepted=[m.accepted_calls for m in pool], total=[m.total_calls for m in pool])
+           sigma=[float(m.sigma) for m in pool], parameters=[[float(v).hex() for v in m.parameters] for m in pool], accepted=[m.accepted_calls for m in pool], total=[m.total_calls for m in pool])
 json.dump(res, open(os.path.join(out, f"rank{{rank}}.json"), "w"))
 if world > 1 and use_store:
     sharding.barrier()
@@ -66,12 +73,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(tmp_path, world, learn=True, group="gloo"):
-    out = tmp_path / f"w{world}{'L' if learn else 'S'}{group}"
+def run_world(tmp_path, world, learn=True, group="gloo", policy=""):
+    out = tmp_path / f"w{world}{'L' if learn else 'S'}{group}{policy}"
     out.mkdir()
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, OMP_NUM_THREADS="1", AMC_TEST_LEARN="1" if learn else "0", AMC_TEST_GROUP=group)
+    env = dict(os.environ, OMP_NUM_THREADS="1", AMC_TEST_LEARN="1" if learn else "0", AMC_TEST_GROUP=group, AMC_TEST_POLICY=policy)
     if world == 1:
         cmd = [sys.executable, str(script), str(out)]
     else:
@@ -100,6 +107,18 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
         assert r["sigma"][0] == 0.2 and r["sigma"][1] != 0.1
         assert r["accepted"] == one["accepted"] and r["total"] == one["total"]
     assert two[0]["energy"] == two[1]["energy"]
+
+
+@pytest.mark.slow
+def test_two_ranks_reproduce_one_rank_with_a_two_parameter_policy(tmp_path):
+    """The same with a policy of two parameters and NPG: rows of ten records per learnable move cross the shards, both ranks
+    invert the same 2 x 2 metric -- parameter vectors, callback rows and chains equal to the one-rank run, bit for bit."""
+    one = run_world(tmp_path, 1, policy="drift2")[0]
+    two = run_world(tmp_path, 2, group="store", policy="drift2")
+    assert two[0]["x"] + two[1]["x"] == one["x"]
+    for r in two:
+        assert r["parameters"] == one["parameters"] and r["energy"] == one["energy"]
+        assert r["parameters"][0] == [float(0.0).hex(), float(0.2).hex()] and r["parameters"][1] != [float(0.05).hex(), float(0.1).hex()]
 
 
 @pytest.mark.slow
