@@ -28,18 +28,35 @@ class SocketStore:
     each; `get` blocks on the server until the key exists.  A worker that uses this store never imports torch, so
     libamc.so binds the system's HIP runtime and RCCL (/opt/rocm) in every rank, as it does in a single process."""
 
+    # Where the store may sit, relative to the port asked for: the first of these that rank 0 can bind.  Clients walk the same
+    # list and know their server by its greeting (the magic word and the port asked for), so a foreign service that happens to
+    # own MASTER_PORT + 1 neither stops the run nor gets mistaken for the store.
+    PORT_OFFSETS = (0, 100, 202, 1008, 2006)
+    MAGIC = "amc-socket-store-1"
+
     def __init__(self, host: str, port: int, is_master: bool, timeout_s: float = 600.0):
         import socket
         import threading
         import time
         self._timeout = float(timeout_s)
         self._lock = threading.Lock()
+        self._hello = f"{self.MAGIC} {int(port)}\n".encode()       # raw bytes: nothing a stranger sends is ever unpickled
         if is_master:
             self._data = {}
             self._cond = threading.Condition()
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((host, int(port)))
+            srv, last = None, None
+            for off in self.PORT_OFFSETS:
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    cand.bind((host, int(port) + off))
+                    srv = cand
+                    break
+                except OSError as err:                # the port is taken: the next candidate
+                    last = err
+                    cand.close()
+            if srv is None:
+                raise OSError(f"SocketStore: none of the ports {[int(port) + o for o in self.PORT_OFFSETS]} on {host} can be bound ({last})")
             srv.listen(256)
             srv.settimeout(0.2)
             self._srv = srv
@@ -49,13 +66,30 @@ class SocketStore:
             # thread is done and every other client has hung up (or 30 s later)
             threading.Thread(target=self._serve, daemon=False).start()
         deadline = time.monotonic() + self._timeout
-        while True:                                   # the server may come up after its clients
-            try:
-                self._sock = socket.create_connection((host, int(port)), timeout=5.0)
-                break
-            except OSError:
+        self._sock = None
+        while self._sock is None:                     # the server may come up after its clients
+            for off in self.PORT_OFFSETS:
+                try:
+                    sk = socket.create_connection((host, int(port) + off), timeout=5.0)
+                except OSError:
+                    continue
+                try:
+                    sk.settimeout(3.0)
+                    got = b""
+                    while len(got) < len(self._hello):
+                        chunk = sk.recv(len(self._hello) - len(got))
+                        if not chunk:
+                            break
+                        got += chunk
+                    if got == self._hello:            # our store, not whoever else listens there
+                        self._sock = sk
+                        break
+                except Exception:
+                    pass
+                sk.close()
+            if self._sock is None:
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"no SocketStore at {host}:{port} after {self._timeout:.0f} s")
+                    raise TimeoutError(f"no SocketStore at {host}:{port} (+{list(self.PORT_OFFSETS)}) after {self._timeout:.0f} s")
                 time.sleep(0.05)
         self._sock.settimeout(self._timeout)
         self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
@@ -90,6 +124,7 @@ class SocketStore:
         import socket
         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         try:
+            conn.sendall(self._hello)                 # the greeting clients know their store by
             while True:
                 req = _recv_msg(conn)
                 if req is None:

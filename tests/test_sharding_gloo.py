@@ -121,6 +121,25 @@ def test_two_ranks_reproduce_one_rank_with_a_two_parameter_policy(tmp_path):
         assert r["parameters"][0] == [float(0.0).hex(), float(0.2).hex()] and r["parameters"][1] != [float(0.05).hex(), float(0.1).hex()]
 
 
+def test_socket_store_steps_aside_for_a_stranger_on_its_port():
+    """MASTER_PORT + 1 owned by something else: rank 0 binds the next candidate port, the clients pass the stranger by (it does
+    not greet them as the store does) and find the store."""
+    import threading
+    from montecarlo_amd.sharding import SocketStore
+    stranger = socket.socket()
+    stranger.bind(("127.0.0.1", 0))
+    stranger.listen(8)
+    port = stranger.getsockname()[1]
+    threading.Thread(target=lambda: [stranger.accept()[0].sendall(b"HTTP/1.0 400 go away\r\n\r\n") for _ in range(4)], daemon=True).start()
+    master = SocketStore("127.0.0.1", port, is_master=True, timeout_s=20.0)
+    client = SocketStore("127.0.0.1", port, is_master=False, timeout_s=20.0)
+    master.set("k", b"v")
+    assert client.get("k") == b"v" and client.add("n", 2) == 2 and master.add("n", 3) == 5
+    assert master._srv.getsockname()[1] == port + SocketStore.PORT_OFFSETS[1]
+    master._srv.close()
+    stranger.close()
+
+
 @pytest.mark.slow
 def test_two_ranks_bit_exact_without_learning(tmp_path):
     """With every optimiser Static nothing the chains see depends on a cross-shard sum: the concatenated shards equal
