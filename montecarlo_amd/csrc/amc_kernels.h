@@ -2397,20 +2397,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) cb[i] = xs::xs_c_bits(ge.e[i]);
     };
-    if (QK) {
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            uint64_t cb[4] = {0, 0, 0, 0};
-            if (l < a.n_learn) q_constants(l, cb);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                g[QK ? l : 0][i] = __longlong_as_double((long long)cb[i]);
-                if ((threadIdx.x & 63) == 0) q_slot_clear(s_gq[threadIdx.x >> 6][QK ? l * 4 + i : 0]);
-            }
-        }
-    } else {
-        r_init(gr, s_gr[threadIdx.x >> 6]);
-    }
     // MIDFLUSH, kind Q: a full f64 accumulator is emptied into an INTEGER of the lane (bits(S) - bits(C), S back to C: eight
     // vector instructions per column, nothing crosses lanes), and the lanes' integers go through the wave once, at the end --
     // a wave-wide flush every 16 samples cost launches with q_batch 4 a sixth of their time.  |k| < 2^51 per emptying: the
@@ -2582,6 +2568,22 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 #ifdef AMC_USER_LOGQ
     stage_user_theta(a.ptab);
 #endif
+    // the accumulators' constants, formed with the first load in flight: they need sigma's value at once -- a scalar load of a table the
+    // previous launch's learning step has just rewritten, and a wait
+    if (QK) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            uint64_t cb[4] = {0, 0, 0, 0};
+            if (l < a.n_learn) q_constants(l, cb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[QK ? l : 0][i] = __longlong_as_double((long long)cb[i]);
+                if ((threadIdx.x & 63) == 0) q_slot_clear(s_gq[threadIdx.x >> 6][QK ? l * 4 + i : 0]);
+            }
+        }
+    } else {
+        r_init(gr, s_gr[threadIdx.x >> 6]);
+    }
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
     real2 x_done = {(real_t)0.0, (real_t)0.0};
