@@ -2392,8 +2392,14 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     // needs them instead of staying live across the sampling loop).  Kind R: two accumulators per column and a running top.
     double g[QK ? NL : 1][4];
     RLanes<QK ? 1 : NV> gr;
+    // (of sigma only its binade is kept across the sampling loop, one scalar per move: a flush that went back to the table for sigma
+    // paid a scalar load and its wait on every block's way out)
+    int gd_es[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+        gd_es[l] = (QK && l < a.n_learn) ? __builtin_amdgcn_readfirstlane(xs::xs_gd_es(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]])) : 0;
     auto q_constants = [&](int l, uint64_t (&cb)[4]) {
-        const xs::GdExponents ge = xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]);
+        const xs::GdExponents ge = xs::xs_gd_exponents_es(gd_es[l]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) cb[i] = xs::xs_c_bits(ge.e[i]);
     };

@@ -160,9 +160,20 @@ AMC_XS_HD double xs_lsb1(double v) { return xs_bits_double(xs_double_bits(v) | 1
 // E = bound exponent + 5 - 51.  (Each summand is thus rounded to 2^-46 of its bound -- for a typical summand, 2^-29 .. 2^-39
 // of itself; over the 1e7+ chains of a fold the rounding errors average out to far below the Float64 rounding of the total.)
 struct GdExponents { int e[4]; };
+AMC_XS_HD int xs_gd_es(double sigma) { return (int)((xs_double_bits(sigma) >> 52) & 0x7FFu) - 1023 + 1; }
+AMC_XS_HD GdExponents xs_gd_exponents_es(int es)
+{
+    const int drop = 51 - XS_GD_CAP_BITS;
+    GdExponents g;
+    g.e[0] = 2 * es + 7 - drop;
+    g.e[1] = es + 13 - drop;
+    g.e[2] = 8 - es - drop;
+    g.e[3] = 15 - 2 * es - drop;
+    return g;
+}
 AMC_XS_HD GdExponents xs_gd_exponents(double sigma)
 {
-    const int es = (int)((xs_double_bits(sigma) >> 52) & 0x7FFu) - 1023 + 1;
+    const int es = xs_gd_es(sigma);
     const int drop = 51 - XS_GD_CAP_BITS;
     GdExponents g;
     g.e[0] = 2 * es + 7 - drop;
