@@ -115,7 +115,7 @@ end
 # SEVERAL parameters (Move.parameters of length P > 1) dlogq is the vector of the P partial derivatives and the expressions
 # say theta0 .. theta{P-1} (amc_create_vector_policy_model).
 function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing, scale=nothing,
-                       proposal=nothing, chain_offset=0, n_chains_global=length(chains), per_chain_counters=true,
+                       proposal=nothing, classes=nothing, class_of_move=nothing, chain_offset=0, n_chains_global=length(chains), per_chain_counters=true,
                        rank=0, n_ranks=1, unique_id=nothing, extras...)
     template = deepcopy(pool)                                      # ONE copy (metropolis.jl:289 makes M), see LazyPools
     K = length(template)
@@ -135,7 +135,19 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
                         Int32(K), chains[1].β, pointer(sigma), pointer(weight), UInt64(seed),
                         Int32(sweepstep), Int32(per_chain_counters), C_NULL,
                         Int32(eltype_of_state(chains) === Float32 ? 1 : 0), Int32(0))
-        if proposal !== nothing
+        if classes !== nothing
+            # a pool that mixes policy / action types: one (sample, logq, dlogq, perform, invert) per class (nothing: not given),
+            # class_of_move[k] (1-based here) the class of move k -- amc_create_mixed_model
+            pot = potential isa AbstractString ? potential : C_NULL
+            rew = reward isa AbstractString ? reward : C_NULL
+            col(i) = Cstring[(c[i] === nothing ? Cstring(C_NULL) : Base.unsafe_convert(Cstring, Base.cconvert(Cstring, c[i]))) for c in classes]
+            texts = [String(t) for c in classes for t in c if t !== nothing]          # keeps the strings alive across the call
+            have_d = all(c -> c[3] !== nothing, classes)
+            com = Cint[k - 1 for k in class_of_move]
+            GC.@preserve texts classes check(ccall((:amc_create_mixed_model, libamc), Cint,
+                        (Ref{AmcConfig}, Cint, Ptr{Cint}, Cstring, Cstring, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ref{Ptr{Cvoid}}),
+                        cfg, length(classes), com, pot, rew, col(1), col(2), have_d ? col(3) : C_NULL, col(4), col(5), handle))
+        elseif proposal !== nothing
             pot = potential isa AbstractString ? potential : C_NULL
             rew = reward isa AbstractString ? reward : C_NULL
             sample, logq, dlogq = proposal
