@@ -25,7 +25,7 @@
 #include <unistd.h>
 
 #define FAKE_MAX_RANKS 8
-#define FAKE_MAX_COUNT 256
+#define FAKE_MAX_COUNT 4096      /* 8 ranks x 32 sums x 12-word records */
 #define FAKE_TIMEOUT_S 60.0
 
 /* AMC_FAKE_RCCL_TIMEOUT_S: how long a rank waits for the others; AMC_FAKE_RCCL_FAIL_RANK: that rank's ncclCommInitRank fails

@@ -51,7 +51,7 @@ def launch(script_args, world, env):
 
 def test_two_ranks_share_one_gpu_pgmc_with_callbacks(fake_rccl):
     """PGMC (device-resident estimator / update over the communicator) with callbacks every 10 time steps, two ranks of 30 000
-    chains each on device 0, against the same worker on ONE rank (its own one-rank communicator): NOTHING depends on the
+    chains each (then four of 15 000) on device 0, against the same worker on ONE rank (its own one-rank communicator): NOTHING depends on the
     sharding -- the cross-shard sums are reproducible sums (integer records merged, rounded once), so the
     learned sigma, every callback row and every chain are equal bit for bit; the communicator reports two ranks, and the
     host path (records over the same communicator, learning step on the host) gives the same bits too."""
@@ -75,6 +75,13 @@ def test_two_ranks_share_one_gpu_pgmc_with_callbacks(fake_rccl):
                           equal_nan=True)
     # positions of the first chains (rank 0's shard starts at global chain 0 in both runs): the same bits
     assert two["comm"]["x_head"] == one["comm"]["x_head"]
+    # ... and FOUR ranks of 15 000 chains each: the same sigma, the same callback rows, the same chains
+    four = json.loads([ln for ln in launch(worker, 4, env).stdout.splitlines() if ln.startswith("{")][-1])
+    assert four["comm"]["comm"]["n_ranks"] == 4 and four["comm"]["shard"] == [0, 15_000] and four["comm"]["connected"]
+    assert four["comm"]["sigma"] == one["comm"]["sigma"] == four["host"]["sigma"]
+    assert four["comm"]["energy"] == one["comm"]["energy"] and four["comm"]["x_head"] == one["comm"]["x_head"]
+    assert np.array_equal(np.array([v for _, v in four["comm"]["acceptance"]]), np.array([v for _, v in one["comm"]["acceptance"]]),
+                          equal_nan=True)
 
 
 def test_two_ranks_two_parameter_policy(fake_rccl):
