@@ -149,6 +149,7 @@ struct amc_handle {
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
+    int blocks_per_cu_pg = 5;       // ... of the estimator kernels: what a CU holds of them (86-96 VGPRs: 5 waves per SIMD), ONE round of blocks
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]
     int hist_bins = 0;
@@ -941,7 +942,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     h->blocks_per_cu_single = (cfg->n_moves == 1 && !cfg->per_chain_counters) ? 6 : 8;
     if (const char* env = std::getenv("AMC_BLOCKS_PER_CU")) {   // tuning knob, 1..64
         const int v = std::atoi(env);
-        if (v >= 1 && v <= 64) h->blocks_per_cu = h->blocks_per_cu_single = v;
+        if (v >= 1 && v <= 64) h->blocks_per_cu = h->blocks_per_cu_single = h->blocks_per_cu_pg = v;
     }
     if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
     h->M = cfg->n_chains;
@@ -2060,9 +2061,12 @@ int amc_parameters_end(amc_handle* h, double* sigma)
 }
 
 // The estimator's grid over this shard.
+// One round of resident blocks: every block's prologue and way out (table staging, the row's stores, the ticket's round trip) are
+// latency the CU cannot hide behind other blocks' arithmetic at the end of a round, so 1.6 rounds (8 blocks per CU on 5 slots) paid
+// them 1.6 times -- 43.1 -> 40.6 us for the estimator launch, 66.0 -> 65.5 for the fused time step at 1e7 chains (NOTES_r04.md).
 static int pg_grid(const amc_handle* h)
 {
-    int grid = grid_for(h, (h->M + 1) / 2);
+    int grid = grid_for(h, (h->M + 1) / 2, h->blocks_per_cu_pg);
     if (grid > h->red_blocks) grid = h->red_blocks;
     return grid > amc::PG_GROUP * amc::PG_GROUP ? amc::PG_GROUP * amc::PG_GROUP : grid;      // two levels of PG_GROUP in the kernel's tail
 }
