@@ -2064,9 +2064,10 @@ int amc_parameters_end(amc_handle* h, double* sigma)
 // One round of resident blocks: every block's prologue and way out (table staging, the row's stores, the ticket's round trip) are
 // latency the CU cannot hide behind other blocks' arithmetic at the end of a round, so 1.6 rounds (8 blocks per CU on 5 slots) paid
 // them 1.6 times -- 43.1 -> 40.6 us for the estimator launch, 66.0 -> 65.5 for the fused time step at 1e7 chains (NOTES_r04.md).
-static int pg_grid(const amc_handle* h)
+// (The form that also leaves the callback sums needs 106 VGPRs -- 4 resident blocks per CU --: two rounds of those, 8 per CU.)
+static int pg_grid(const amc_handle* h, bool reduce = false)
 {
-    int grid = grid_for(h, (h->M + 1) / 2, h->blocks_per_cu_pg);
+    int grid = grid_for(h, (h->M + 1) / 2, reduce ? (h->blocks_per_cu_pg == 5 ? 8 : h->blocks_per_cu_pg) : h->blocks_per_cu_pg);
     if (grid > h->red_blocks) grid = h->red_blocks;
     return grid > amc::PG_GROUP * amc::PG_GROUP ? amc::PG_GROUP * amc::PG_GROUP : grid;      // two levels of PG_GROUP in the kernel's tail
 }
@@ -2075,10 +2076,10 @@ static int pg_grid(const amc_handle* h)
 // (kind Q: the built-in potentials) or XS_LANE_CAP (kind R: hiprtc forms) of them between two flushes (amc_xsum.h).  Launches
 // whose lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH); the
 // others empty full accumulators into integers of the lane on the way.
-static bool pg_fits_without_flush(const amc_handle* h, int q_batch)
+static bool pg_fits_without_flush(const amc_handle* h, int q_batch, bool reduce = false)
 {
     const int64_t pairs = (h->M + 1) / 2;
-    const int64_t lanes = (int64_t)pg_grid(h) * AMC_BLOCK;
+    const int64_t lanes = (int64_t)pg_grid(h, reduce) * AMC_BLOCK;
     const int64_t cap = h->use_rtc ? amc::xs::XS_LANE_CAP : amc::xs::XS_GD_LANE_CAP;
     return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap;
 }
@@ -2154,8 +2155,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         a.tail = h->d_pg_tail;
     }
     const int nl = nl_capacity(n_learn);
-    const int grid = pg_grid(h);
-    const bool mid = !pg_fits_without_flush(h, q_batch);
+    const int grid = pg_grid(h, reduce && with_sweep);
+    const bool mid = !pg_fits_without_flush(h, q_batch, reduce && with_sweep);
     int sweep = 0;
     if (with_sweep) {
         { const int rcc = counter_room(h, who, 1); if (rcc != AMC_OK) return rcc; }
@@ -2416,7 +2417,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     const bool fused = !per_move_launches(h) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
-    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h) && pg_fits_without_flush(h, q_batch);
+    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h) && pg_fits_without_flush(h, q_batch, true);
     int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);
