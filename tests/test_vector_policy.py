@@ -291,3 +291,35 @@ def test_host_mirror_on_the_engine_equals_the_test_double(gpu, oracle, tmp_path)
     assert np.array_equal(bits(pool_g[1].parameters), bits(pool_o[1].parameters))
     assert np.array_equal(bits(ch_g.x), bits(ch_o.x))
     oracle.install_vector_policy(1, None)
+
+
+# ---- three and four parameters: the 3 x 3 and 4 x 4 metric inverted on the device ------------------------------------------
+_R4 = "(delta-theta0-theta2*x-theta3*x*x)"
+BEND = ("theta0 + theta2*x + theta3*x*x + theta1*z",
+        f"-({_R4}*{_R4})/(2.0*theta1*theta1) - amc_log(theta1)",
+        [f"{_R4}/(theta1*theta1)", f"({_R4}*{_R4})/(theta1*theta1*theta1) - 1.0/theta1", f"{_R4}*x/(theta1*theta1)",
+         f"{_R4}*x*x/(theta1*theta1)"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lean3", "bend4"])
+@pytest.mark.parametrize("opt", [OPTS[3], OPTS[5]], ids=["NPG", "BLANPG"])
+def test_free_running_pgmc_with_three_and_four_parameters(gpu, oracle, case, opt):
+    """The natural-gradient steps with a 3 x 3 and a 4 x 4 metric (Gauss-Jordan with partial pivoting on the device, the same
+    sequence in the oracle): parameter vectors equal after every update, nothing fed back."""
+    name, kind, h0, h1 = opt
+    policy, P, thetas = (LEAN, 3, [[0.05, 0.4, -0.3], [0.0, 0.9, 0.1]]) if case == "lean3" else \
+                        (BEND, 4, [[0.05, 0.4, -0.3, 0.02], [0.0, 0.9, 0.1, -0.05]])
+    eng, ref = _pair(gpu, oracle, 20011, policy, P, thetas, [0.5, 0.5])
+    ids = [0, 1]
+    for stretch in (1, 2, 9):
+        eng.pgmc_steps(stretch, ids, 2, [kind, kind], [h0, h0], [h1, h1])
+        ref.pgmc_steps(stretch, ids, 2, [kind, kind], [h0, h0], [h1, h1])
+        for k in ids:
+            assert np.array_equal(bits(eng.get_parameters(k)), bits(ref.get_parameters(k))), (name, case, stretch, k)
+    assert np.array_equal(bits(eng.download_state()[0]), bits(ref.download_state()[0]))
+    assert not np.array_equal(eng.get_parameters(0), thetas[0]) and np.all(np.isfinite(eng.get_parameters(0)))
+    acc = eng.pg_get_accumulated(ids)
+    assert acc.shape == (2, 2 + 2 * P + P * P) and np.all(acc == 0.0)
+    eng.close()
+    oracle.install_vector_policy(1, None)
