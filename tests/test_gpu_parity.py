@@ -351,13 +351,14 @@ def test_first_row_acceptance_is_nan(gpu):
 
 
 # ---- golden vectors -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("idx", range(6))
+@pytest.mark.parametrize("idx", range(8))
 def test_hip_matches_golden_trajectories(gpu, idx):
     case = json.load(open(os.path.join(GOLDEN, "oracle_trajectories.json")))["cases"][idx]
     sp = case["spec"]
+    extra = {k: sp[k] for k in ("proposal", "n_params", "classes", "class_of_move") if k in sp}     # cases 6, 7 (round 4)
     e = gpu.HipEngine(n_chains=sp["M"], chain_offset=sp["offset"], n_chains_global=sp["offset"] + sp["M"],
                       potential=sp["potential"], beta=sp["beta"], sigma=sp["sigma"], weight=sp["weight"],
-                      seed=sp["seed"], sweepstep=sp["sweepstep"], dtype=sp.get("dtype", "f64"), scale_expr=sp.get("scale"))
+                      seed=sp["seed"], sweepstep=sp["sweepstep"], dtype=sp.get("dtype", "f64"), scale_expr=sp.get("scale"), **extra)
     e.init_uniform(-2.0, 2.0)
     done = 0
     for snap in case["snapshots"]:

@@ -243,6 +243,36 @@ def test_mc_step_semantics(oracle):
 
 
 # ---- golden trajectories (self-generated; pins the oracle against drift) ---------------------------
+@pytest.mark.parametrize("idx", [6, 7])
+def test_golden_trajectories_of_vector_policies_and_mixed_pools(oracle, idx):
+    """Round 4's two golden cases (a two-parameter policy; a pool of three policy / action classes), through the engine-shaped
+    wrapper of the oracle: states, counters, callback values and the estimator's rows."""
+    case = load_json("oracle_trajectories.json")["cases"][idx]
+    sp = case["spec"]
+    extra = {k: sp[k] for k in ("proposal", "n_params", "classes", "class_of_move") if k in sp}
+    o = oracle.OracleEngine(n_chains=sp["M"], chain_offset=sp["offset"], potential=sp["potential"], beta=sp["beta"], sigma=sp["sigma"],
+                            weight=sp["weight"], seed=sp["seed"], sweepstep=sp["sweepstep"], **extra)
+    o.init_uniform(-2.0, 2.0)
+    done = 0
+    for snap in case["snapshots"]:
+        o.sweep(snap["sweep"] - done)
+        done = snap["sweep"]
+        x, e = o.download_state()
+        assert np.array_equal(x, fh(snap["x"])) and np.array_equal(e, fh(snap["e"]))
+        acc, tot = o.download_counters()
+        assert acc.tolist() == snap["accepted"] and tot.tolist() == snap["total"]
+        if "energy" in snap:
+            red = o.reduce()
+            assert red[0] / sp["M"] == float.fromhex(snap["energy"])
+            assert np.array_equal(red[4:] / sp["M"], fh(snap["acceptance"]), equal_nan=True)
+    o.sweep(256 - done)
+    g = o.pg_estimate(list(range(len(sp["sigma"]))), 3)
+    assert np.array_equal(g.ravel(), fh(case["pg_estimate_q3"]))
+    assert np.array_equal(o.download_state()[0], fh(case["x_after_pg"]))
+    oracle.install_vector_policy(1, None)
+    oracle.install_policy_classes(None, None)
+
+
 @pytest.mark.parametrize("idx", range(6))
 def test_golden_trajectories(oracle, idx):
     case = load_json("oracle_trajectories.json")["cases"][idx]
