@@ -149,7 +149,10 @@ struct amc_handle {
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
-    int blocks_per_cu_pg = 5;       // ... of the estimator kernels: what a CU holds of them (86-96 VGPRs: 5 waves per SIMD), ONE round of blocks
+    int blocks_per_cu_pg = 0;       // ... of the estimator kernels when AMC_BLOCKS_PER_CU is given; 0: what a CU HOLDS of the kernel form at hand
+                                    // (hipOccupancyMaxActiveBlocksPerMultiprocessor: 5 for the built-in forms, 4 for most hiprtc ones), see pg_plan
+    int occ_query = 0;              // out-slot of a launch_pg call made with grid < 0 (a query, nothing is launched)
+    std::map<int, int> pg_resident; // resident blocks per CU of the estimator kernel forms, by (nl, sweep, reduce)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]
     int hist_bins = 0;
@@ -410,6 +413,13 @@ int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
 template <int POT, int NL, int SWEEP, bool REDUCE = false, bool MID = false>
 int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid)
 {
+    if (grid < 0) {            // a query: how many blocks of this form a CU holds
+        int nb = 0;
+        if (h->beta_arr) AMC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, amc::pg_estimate_kernel<POT, NL, true, SWEEP, REDUCE, MID>, AMC_BLOCK, 0));
+        else AMC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, amc::pg_estimate_kernel<POT, NL, false, SWEEP, REDUCE, MID>, AMC_BLOCK, 0));
+        h->occ_query = nb;
+        return AMC_OK;
+    }
     if (h->beta_arr)
         hipLaunchKernelGGL((amc::pg_estimate_kernel<POT, NL, true, SWEEP, REDUCE, MID>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a, sw);
     else
@@ -425,7 +435,7 @@ int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw,
 template <int POT>
 int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
-    if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on launches that need no flush mid-launch (see pg_fits_without_flush)");
+    if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on launches that need no flush mid-launch (see pg_plan)");
     if (mid) {
         if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, false, true>(h, a, sw, grid);
         if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, false, true>(h, a, sw, grid);
@@ -764,6 +774,14 @@ int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid
     if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg_custom: the callback sums ride on launches that need no flush mid-launch");
     const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
                              std::to_string(sweep) + "," + tf(reduce) + "," + tf(mid) + ">";
+    if (grid < 0) {            // a query: how many blocks of this form a CU holds
+        hipFunction_t fn = nullptr;
+        { const int rc = rtc_function(h, inst, &fn); if (rc != AMC_OK) return rc; }
+        int nb = 0;
+        AMC_HIP(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, AMC_BLOCK, 0));
+        h->occ_query = nb;
+        return AMC_OK;
+    }
     void* params[] = {&a, &sw};
     return rtc_launch(h, inst, grid, params);
 }
@@ -2063,27 +2081,53 @@ int amc_parameters_end(amc_handle* h, double* sigma)
 }
 
 // The estimator's grid over this shard.
-// One round of resident blocks: every block's prologue and way out (table staging, the row's stores, the ticket's round trip) are
+// The estimator's grid over this shard and the kernel form it needs.
+// ONE round of resident blocks: every block's prologue and way out (table staging, the row's stores, the ticket's round trip) are
 // latency the CU cannot hide behind other blocks' arithmetic at the end of a round, so 1.6 rounds (8 blocks per CU on 5 slots) paid
-// them 1.6 times -- 43.1 -> 40.6 us for the estimator launch, 66.0 -> 65.5 for the fused time step at 1e7 chains (NOTES_r04.md).
-// (The form that also leaves the callback sums needs 106 VGPRs -- 4 resident blocks per CU --: two rounds of those, 8 per CU.)
-static int pg_grid(const amc_handle* h, bool reduce = false)
-{
-    int grid = grid_for(h, (h->M + 1) / 2, reduce ? (h->blocks_per_cu_pg == 5 ? 8 : h->blocks_per_cu_pg) : h->blocks_per_cu_pg);
-    if (grid > h->red_blocks) grid = h->red_blocks;
-    return grid > amc::PG_GROUP * amc::PG_GROUP ? amc::PG_GROUP * amc::PG_GROUP : grid;      // two levels of PG_GROUP in the kernel's tail
-}
-
+// them 1.6 times -- 43.1 -> 40.6 us for the estimator launch, 66.0 -> 65.5 for the fused time step at 1e7 chains; whole rounds are
+// good, fractions bad (NOTES_r04.md).  What a CU holds of the kernel form at hand is asked of the runtime (5 blocks for the built-in
+// forms, 4 for the form that also leaves the callback sums and for most hiprtc forms).
 // An estimator launch puts 2 q_batch summands per trip into each of a lane's GradientData accumulators, which hold XS_GD_LANE_CAP
-// (kind Q: the built-in potentials) or XS_LANE_CAP (kind R: hiprtc forms) of them between two flushes (amc_xsum.h).  Launches
-// whose lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH); the
-// others empty full accumulators into integers of the lane on the way.
-static bool pg_fits_without_flush(const amc_handle* h, int q_batch, bool reduce = false)
+// (kind Q: the built-in potentials) or XS_LANE_CAP (kind R: hiprtc forms) of them between two flushes (amc_xsum.h).  Launches whose
+// lanes stay within that run the kernel form without flush code in its sampling loop (pg_estimate_kernel, MIDFLUSH) -- with two
+// rounds of blocks if one does not fit and two do --; the others empty full accumulators into integers of the lane on the way.
+struct PgPlan { int grid; bool mid; };
+static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, PgPlan* plan)
 {
     const int64_t pairs = (h->M + 1) / 2;
-    const int64_t lanes = (int64_t)pg_grid(h, reduce) * AMC_BLOCK;
+    int limit = h->red_blocks;
+    if (limit > amc::PG_GROUP * amc::PG_GROUP) limit = amc::PG_GROUP * amc::PG_GROUP;      // two levels of PG_GROUP in the kernel's tail
     const int64_t cap = h->use_rtc ? amc::xs::XS_LANE_CAP : amc::xs::XS_GD_LANE_CAP;
-    return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap;
+    auto fits = [&](int grid) { const int64_t lanes = (int64_t)grid * AMC_BLOCK; return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap; };
+    int per_cu = h->blocks_per_cu_pg;                    // AMC_BLOCKS_PER_CU given: that many
+    if (per_cu == 0) {
+        const int key = (nl << 8) | (sweep << 4) | (reduce ? 1 : 0);
+        auto it = h->pg_resident.find(key);
+        if (it == h->pg_resident.end()) {
+            amc::PgArgs a0;
+            std::memset(&a0, 0, sizeof(a0));
+            amc::SweepArgs s0;
+            std::memset(&s0, 0, sizeof(s0));
+            h->occ_query = 0;
+            const int rc = h->use_rtc                                    ? launch_pg_custom(h, a0, s0, -1, nl, sweep, reduce, false)
+                           : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a0, s0, -1, nl, sweep, reduce, false)
+                                                                         : launch_pg<amc::POT_HARMONIC>(h, a0, s0, -1, nl, sweep, reduce, false);
+            if (rc != AMC_OK) return rc;
+            if (std::getenv("AMC_DEBUG_PLAN")) std::fprintf(stderr, "[amc] estimator form nl=%d sweep=%d reduce=%d: %d resident blocks per CU\n", nl, sweep, (int)reduce, h->occ_query);
+            it = h->pg_resident.emplace(key, h->occ_query > 0 ? h->occ_query : 5).first;
+        }
+        per_cu = it->second;
+    }
+    int one = grid_for(h, pairs, per_cu);
+    if (one > limit) one = limit;
+    plan->grid = one;
+    plan->mid = !fits(one);
+    if (plan->mid && h->blocks_per_cu_pg == 0) {
+        int two = grid_for(h, pairs, 2 * per_cu);
+        if (two > limit) two = limit;
+        if (fits(two)) { plan->grid = two; plan->mid = false; }
+    }
+    return AMC_OK;
 }
 
 // Handles whose estimator takes one launch per learnable move: policies with several parameters (the move's columns fill a row
@@ -2157,17 +2201,19 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         a.tail = h->d_pg_tail;
     }
     const int nl = nl_capacity(n_learn);
-    const int grid = pg_grid(h, reduce && with_sweep);
-    const bool mid = !pg_fits_without_flush(h, q_batch, reduce && with_sweep);
     int sweep = 0;
     if (with_sweep) {
         { const int rcc = counter_room(h, who, 1); if (rcc != AMC_OK) return rcc; }
         if (h->d_log) { int room = 0; const int rcf = log_room(h, &room); if (rcf != AMC_OK) return rcf; }
         sweep = h->K > 1 ? 2 : (h->d_log ? 1 : 3);
     }
+    const bool red = reduce && with_sweep;
+    PgPlan plan;
+    { const int rcp = pg_plan(h, nl, sweep, red, q_batch, &plan); if (rcp != AMC_OK) return rcp; }
+    const int grid = plan.grid;
+    const bool mid = plan.mid;
     if (grid_out) *grid_out = grid;
     amc::SweepArgs sw = make_sweep_args(h, 1);
-    const bool red = reduce && with_sweep;
     const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep, red, mid)
                    : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep, red, mid)
                                                                  : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep, red, mid);
@@ -2419,7 +2465,13 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     const bool fused = !per_move_launches(h) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
-    const bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h) && pg_fits_without_flush(h, q_batch, true);
+    bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h);
+    if (fused_reduce) {            // ... and launches that need no flush on the way
+        PgPlan plan;
+        const int rcp = pg_plan(h, nl_capacity(n_learn), h->K > 1 ? 2 : (h->d_log ? 1 : 3), true, q_batch, &plan);
+        if (rcp != AMC_OK) return rcp;
+        fused_reduce = !plan.mid;
+    }
     int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);
