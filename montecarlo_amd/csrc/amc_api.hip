@@ -1561,7 +1561,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
     // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
     // (a call whose last launch also forms the callback sums: that form holds 5 blocks per CU -- 89 VGPRs -- and runs one round of
     // them, 49 -> 45 us per callback at K = 2 and 1e7 chains; plain sweeps are indifferent between 5 and 8)
-    const int grid = grid_for(h, (h->M + 1) / 2, fuse_reduce ? h->blocks_per_cu_pg : (remaining == 1 ? h->blocks_per_cu_single : 0));
+    const int grid = grid_for(h, (h->M + 1) / 2, fuse_reduce ? (h->blocks_per_cu_pg ? h->blocks_per_cu_pg : 5) : (remaining == 1 ? h->blocks_per_cu_single : 0));
     if (grid_out) *grid_out = grid;
     while (remaining > 0) {
         int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
