@@ -140,6 +140,73 @@ def test_socket_store_steps_aside_for_a_stranger_on_its_port():
     stranger.close()
 
 
+def test_socket_store_serves_its_own_launch_only(tmp_path):
+    """Both ends prove the launch token before anything is served: a client of another launch does not take the server for its
+    store (it keeps looking and times out), and one that skips the handshake is dropped unserved; the rightful client works
+    before and after."""
+    import struct
+    from montecarlo_amd import sharding as S
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    master = S.SocketStore("127.0.0.1", port, is_master=True, timeout_s=20.0, token=b"launch-A")
+    master.set("k", b"v")
+    with pytest.raises(TimeoutError):
+        S.SocketStore("127.0.0.1", port, is_master=False, timeout_s=0.5, token=b"launch-B")
+    # a peer that reads the greeting and then talks without answering it: a would-be pickle bomb in the old framing
+    marker = tmp_path / "executed"
+    import pickle
+
+    class Bomb:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+    payload = pickle.dumps(("set", "x", Bomb()))
+    raw = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+    raw.recv(4096)
+    raw.sendall(struct.pack("<Q", len(payload)) + payload)
+    raw.settimeout(5.0)
+    try:
+        assert raw.recv(16) == b""                      # dropped: nothing parsed, nothing answered
+    except ConnectionResetError:                        # (closed with our bytes still unread)
+        pass
+    raw.close()
+    assert not marker.exists()
+    friend = S.SocketStore("127.0.0.1", port, is_master=False, timeout_s=20.0, token=b"launch-A")
+    assert friend.get("k") == b"v" and friend.num_keys() == 1
+    # after the handshake: frames are plain fields; garbage and oversized frames end the connection, the store lives on
+    friend._sock.sendall(struct.pack("<I", S.SocketStore.MAX_FRAME + 1))
+    with pytest.raises((ConnectionError, OSError)):
+        friend.get("k")
+    again = S.SocketStore("127.0.0.1", port, is_master=False, timeout_s=20.0, token=b"launch-A")
+    assert again.get("k") == b"v"
+    with pytest.raises(TypeError):
+        again.set("obj", {"not": "bytes"})
+    master._srv.close()
+
+
+def test_store_values_are_plain_data():
+    """What the ranks exchange through the store is a closed set of plain types in a tagged binary form -- round trip, and no
+    way in for objects."""
+    from montecarlo_amd.sharding import _dumps, _loads
+    vals = [None, True, False, 7, -2**62, 0.1, float("inf"), "reason: \u00e9", bytes(range(128)), [1, 2.5, "x"], (True, None),
+            {"rank": 1, "v": [1, 1, 1], "nested": {"a": (1, b"z")}}, np.arange(12, dtype=np.float64).reshape(3, 4),
+            np.array([], dtype=np.int32), np.float64(2.5), np.int64(-3), np.bool_(True)]
+    for v in vals:
+        got = _loads(_dumps(v))
+        if isinstance(v, np.ndarray):
+            assert got.dtype == v.dtype and got.shape == v.shape and np.array_equal(got, v)
+        else:
+            assert got == v and type(got) is (type(v) if not isinstance(v, np.generic) else type(v.item()))
+    nan = _loads(_dumps(float("nan")))
+    assert nan != nan
+    for bad in (object(), {1, 2}, np.array([object()]), lambda: 0):
+        with pytest.raises(TypeError):
+            _dumps(bad)
+    for junk in (b"", b"?", b"i\x00", b"a\x03\x01|O8" + b"\x00" * 8, _dumps(1) + b"x"):
+        with pytest.raises((ValueError, TypeError, Exception)):
+            _loads(junk)
+
+
 @pytest.mark.slow
 def test_two_ranks_bit_exact_without_learning(tmp_path):
     """With every optimiser Static nothing the chains see depends on a cross-shard sum: the concatenated shards equal
