@@ -194,6 +194,7 @@ def other_configs(A, m, device, periods=40):
 
     def run(e, period):
         e.init_uniform(-2.0, 2.0)
+        e.set_reduce_columns(A.HipEngine.REDUCE_E)       # callback_energy + callback_acceptance: of the sums over x, sum e alone
         early = measure(e, period)
         # counts past the 16-bit mark: the high counter planes take part from here on (amc_upload_counters)
         tot = np.zeros((2, m), dtype=np.int64)
@@ -266,6 +267,8 @@ def main():
     ap.add_argument("--spinup-s", type=float, default=0.6,
                     help="seconds of untimed single-sweep launches before the W warm-up steps: the GPU needs "
                          "~0.1-0.5 s of load to reach its sustained clock (65 -> 56 us/sweep measured)")
+    ap.add_argument("--spinup-cap-s", type=float, default=3.0,
+                    help="... and the ramp's upper bound: it ends earlier once three consecutive 200-launch blocks agree within 1 %%")
     ap.add_argument("--chains-per-gpu", type=int, default=M_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step block for min / median (not part of value)")
@@ -313,7 +316,8 @@ def main():
         cpu_line = cpu_baseline()
 
     from montecarlo_amd import _capi as A
-    assert world == 1 or force_dist or "torch" not in sys.modules, "the worker must not import torch (libamc.so binds the system's ROCm)"
+    assert world == 1 or force_dist or grp.kind == "torch" or "torch" not in sys.modules, \
+        "the worker must not import torch (libamc.so binds the system's ROCm)"
 
     m_local = args.chains_per_gpu
     m_global = m_local * world
@@ -322,6 +326,7 @@ def main():
                       beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1, per_chain_counters=False,
                       device=int(os.environ.get("AMC_BENCH_DEVICE", local_rank)))
     eng.init_uniform(-2.0, 2.0)
+    eng.set_reduce_columns(A.HipEngine.REDUCE_E)     # the callbacks of configs 2 - 5 are callback_energy and callback_acceptance: sum e alone
     allreduce_via = "none (single process)"
     if grp is not None:
         # the shards' RCCL communicator (ncclUniqueId over the store), built HERE and used once: the first collective
@@ -398,8 +403,11 @@ def main():
             else:
                 grp.barrier()
 
+    rccl_failed = False
     t_spin = time.perf_counter()                 # clock ramp (untimed), then the W warm-up steps
+    spin_blocks = []                             # ms per 200-launch block of the ramp
     while True:
+        b0 = time.perf_counter()
         # with callbacks: the very steps of the timed loop, callbacks included -- whatever W is (the driver's W = 5 never
         # reaches a callback step), the first launch of the sum-forming kernel form and the first real all-reduces happen here;
         # so does a one-off of the stack: some 0.1-0.2 s into a process's first callback-bearing steps the queue stands still
@@ -408,7 +416,14 @@ def main():
             step(i) if cb_every else eng.sweep(1)
         finish_callback()
         eng.sync()
-        time_up = time.perf_counter() - t_spin >= args.spinup_s
+        spin_blocks.append((time.perf_counter() - b0) * 1e3)
+        # steady state, not a fixed time: the clock keeps coming up for as long as the host leg before it kept the GPU idle
+        # (BENCH_r04: 20 timed steps at 32.7 us behind a fixed 0.6 s, the same run's later blocks at 29.5), so the ramp ends
+        # when the last three blocks agree within 1 % -- not before --spinup-s, not after --spinup-cap-s
+        spun = time.perf_counter() - t_spin
+        last = spin_blocks[-3:]
+        steady = len(last) == 3 and max(last) <= 1.01 * min(last)
+        time_up = (spun >= args.spinup_s and steady) or spun >= args.spinup_cap_s
         if grp is None:
             if time_up:
                 break
@@ -549,11 +564,22 @@ def main():
         if stack.get("rccl_library_forced") and os.environ.get("AMC_BENCH_ALLOW_FORCED_RCCL") != "1":
             result["value"] = None
             result["value_withheld"] = "AMC_RCCL_LIBRARY replaced librccl in this run: not a measurement over RCCL"
+        # N > 1: the line is a measurement over RCCL or it is no measurement -- a run in which some rank fell back to the
+        # launcher's store for the sums, or whose communicator does not span all N ranks, keeps its diagnostics and loses `value`
+        # (a fresh process is the retry, never a re-exec)
+        if grp is not None and world > 1 and not (getattr(eng, "comm_connected", False) and stack.get("rccl_ranks") == world):
+            result["value"] = None
+            result["value_withheld"] = (f"RCCL did not carry this run (communicator over {stack.get('rccl_ranks')} of {world} ranks; "
+                                        f"callback sums via: {allreduce_via}): not a measurement of the N-GPU path")
+            rccl_failed = True
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
     eng.close()
     if grp is not None:
         grp.barrier()
+        # every rank leaves with the same code: rank 0 decided, the others learn it over the store
+        if bool(grp.broadcast(bool(rccl_failed) if rank == 0 else None)):
+            raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -310,6 +310,13 @@ int  amc_reduce_begin(amc_handle *h);
  * step log that follows it. */
 int  amc_sweep_reduce_begin(amc_handle *h, int64_t n_sweeps);
 int  amc_reduce_end(amc_handle *h, double *out);
+/* Which of the sums over x the reductions begun from now on form: callback_energy (particle_1d.jl:68-70) needs sum e alone,
+ * the moments of test/distribution_test.jl:36-37 sum x and sum x^2; callback_acceptance (metropolis.jl:319-321) none of the
+ * three.  Every sum costs the launch that forms it nine vector instructions per chain pair, so a caller that knows its
+ * callbacks names them (default: all).  A sum that was not formed reads NaN (amc_reduce_end) / is an all-zero record
+ * (amc_reduce_end_exact). */
+enum { AMC_REDUCE_E = 1, AMC_REDUCE_X = 2, AMC_REDUCE_XX = 4, AMC_REDUCE_ALL = 7 };
+int  amc_set_reduce_columns(amc_handle *h, int columns);
 /* The same as records: (AMC_RED_HEADER + K) * AMC_XSUM_WORDS doubles, column order as above (the count is a record too).
  * steps_counted (may be NULL) receives the MH steps counted per chain at _begin.  On a K = 1 handle without per-chain
  * counters record AMC_RED_SUM_RATIO0 holds the pool-wide accepted TOTAL (an integer); sum_c accepted_c / total_c is its
@@ -434,6 +441,12 @@ int  amc_selftest_accept_filter(int device, float t_from, float t_to, double *ma
 /* out4[i] = Philox4x32-10(key = seed, counter of draw (pair[i], t[i], draw, stream)). */
 int  amc_selftest_philox(int device, uint64_t seed, const uint64_t *pair, const uint64_t *t,
                          uint32_t draw, uint32_t stream, uint32_t *out4, int64_t n);
+
+/* The kernels' wave-wide integer totals (every reproducible sum ends in one): values is [6][64] -- six 64-bit integers per lane
+ * of one wavefront --, totals[0..5] their sums through the six-value form, [6..7] values 4, 1 through the two-value form,
+ * [8..10] values 5, 0, 2 through the three-value form, [11] value 3 alone, [12] the largest low 32-bit word of row 0;
+ * totals_plain[0..5]: the six sums by plain DPP rounds.  Sums are modulo 2^64. */
+int  amc_selftest_wave_totals(int device, const int64_t *values, int64_t *totals, int64_t *totals_plain);
 
 #ifdef __cplusplus
 }

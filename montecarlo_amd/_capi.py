@@ -146,6 +146,8 @@ def load() -> C.CDLL:
         "amc_selftest_accept_filter": (C.c_int, [C.c_int, C.c_float, C.c_float, dp]),
         "amc_selftest_philox": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]),
+        "amc_set_reduce_columns": (C.c_int, [H, C.c_int]),
+        "amc_selftest_wave_totals": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -444,6 +446,13 @@ class HipEngine:
         _check(self._lib.amc_reduce(self._h, _dptr(out)))
         return out
 
+    REDUCE_E, REDUCE_X, REDUCE_XX, REDUCE_ALL = 1, 2, 4, 7
+
+    def set_reduce_columns(self, columns: int) -> None:
+        """Which of sum e / sum x / sum x^2 the reductions begun from now on form (amc_set_reduce_columns; REDUCE_* bits).  A
+        sum that is not formed reads NaN."""
+        _check(self._lib.amc_set_reduce_columns(self._h, int(columns)))
+
     def reduce_begin(self) -> None:
         """Enqueue the reduction; sweeps queued afterwards keep running while the host does other work."""
         _check(self._lib.amc_reduce_begin(self._h))
@@ -474,6 +483,7 @@ class HipEngine:
         """Merged records -> the sums (layout of amc_reduce).  A K = 1 engine without per-chain counters carries the pool-wide
         accepted TOTAL in the ratio record: every chain has the same total_calls, the ratio sum is that total / steps."""
         out = xsum_round(records)
+        out[np.asarray(records).reshape(-1, AMC_XSUM_WORDS)[:, 0] == 0.0] = np.nan      # an empty record: a sum nobody asked for
         if self.n_moves == 1 and not self.per_chain_counters:
             with np.errstate(invalid="ignore", divide="ignore"):
                 out[AMC_RED_HEADER] = out[AMC_RED_HEADER] / np.float64(steps_counted)   # 0/0 = NaN before the first step
@@ -809,3 +819,16 @@ def selftest_philox(seed: int, pair: np.ndarray, t: np.ndarray, draw: int, strea
                                       t.ctypes.data_as(u64p), int(draw), int(stream),
                                       out.ctypes.data_as(C.POINTER(C.c_uint32)), pair.size))
     return out
+
+
+def selftest_wave_totals(values: np.ndarray, device: int = 0):
+    """The kernels' wave-wide integer totals of values[6][64] (int64) on the GPU: (totals[13], totals_plain[6]), see
+    include/amc.h (parity tests only)."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    assert values.shape == (6, 64)
+    out = np.zeros(13, dtype=np.int64)
+    ref = np.zeros(6, dtype=np.int64)
+    i64p = C.POINTER(C.c_int64)
+    _check(load().amc_selftest_wave_totals(int(device), values.ctypes.data_as(i64p), out.ctypes.data_as(i64p),
+                                           ref.ctypes.data_as(i64p)))
+    return out, ref

@@ -12,6 +12,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -98,6 +99,8 @@ struct RedTicket {
     int ratio_rows = 0;              // rows of h_ratio that belong to it (0: none)
     bool ratio_acc = false;          // the per-move ratio totals come from h_ratio_acc (K > 4)
     uint64_t t_counted = 0;
+    int row_stride = RED_HOST_STRIDE;    // words per row of h_rows: the wide form, or amc::RED_COMPACT_WORDS (red_finish)
+    int cols = amc::RED_WANT_ALL;        // the sums that were formed (amc_set_reduce_columns at the time)
     hipEvent_t ev = nullptr;
     amc::xs_word* h_rows = nullptr;      // pinned [n_slots][RED_HOST_STRIDE]
     amc::xs_word* h_ratio = nullptr;     // pinned [n_slots][RATIO_STRIDE]
@@ -146,9 +149,12 @@ struct amc_handle {
     int d_out_ranks = 1;
     double* h_pg_out = nullptr; // pinned: records of amc_pg_estimate
     int red_blocks = 0;
+    int red_cols = amc::RED_WANT_ALL;   // the callback sums a reduction forms (amc_set_reduce_columns)
+    bool wide_red_rows = false;         // env AMC_WIDE_RED_ROWS=1 (read at amc_create; tests): the wide row form whatever the launch
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
+    int blocks_per_cu_red = 5;      // ... of the sweep launch that also forms the callback sums (env AMC_BLOCKS_PER_CU_REDUCE)
     int blocks_per_cu_pg = 0;       // ... of the estimator kernels when AMC_BLOCKS_PER_CU is given; 0: what a CU HOLDS of the kernel form at hand
                                     // (hipOccupancyMaxActiveBlocksPerMultiprocessor: 5 for the built-in forms, 4 for most hiprtc ones), see pg_plan
     int occ_query = 0;              // out-slot of a launch_pg call made with grid < 0 (a query, nothing is launched)
@@ -620,8 +626,20 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     int rtc_major = 0, rtc_minor = 0;
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
     // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
-    const bool licm_off = inst.rfind("amc::pg_estimate_kernel<", 0) == 0 &&
-                          (inst.find(",2,false,") != std::string::npos || inst.find(",2,true,") != std::string::npos);      // <.., SWEEP = 2, REDUCE, MIDFLUSH>
+    // (decided from the instantiation's FOURTH template argument, SWEEP == 2 -- `<POT, NL, BETA, SWEEP, REDUCE, MIDFLUSH>`: a
+    // substring test would also catch NL = 2 followed by BETA)
+    const bool licm_off = [&] {
+        const std::string head = "amc::pg_estimate_kernel<";
+        if (inst.rfind(head, 0) != 0) return false;
+        size_t at = head.size();
+        for (int arg = 0; arg < 3; ++arg) {
+            at = inst.find(',', at);
+            if (at == std::string::npos) return false;
+            ++at;
+        }
+        const size_t end = inst.find_first_of(",>", at);
+        return end != std::string::npos && inst.substr(at, end - at) == "2";
+    }();
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : ""));
     {
@@ -956,13 +974,24 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     }
     // 8 resident blocks per CU; the single-step launch of the K = 1 pool-wide-counter sweep (no step log) measures 5 %
     // faster with 6 (29.4 vs 31.2 us at 1e7 chains; its fused launches and all other forms are fastest at 8)
+    // (round 5: the K > 1 single-step launch holds 7 blocks per CU -- 70 VGPRs -- and ONE round of them is 4 % faster than 8 on
+    // 7 slots, 31.1 against 32.4 us; env AMC_BLOCKS_PER_CU_SINGLE)
     h->blocks_per_cu = 8;
-    h->blocks_per_cu_single = (cfg->n_moves == 1 && !cfg->per_chain_counters) ? 6 : 8;
+    h->blocks_per_cu_single = (cfg->n_moves == 1 && !cfg->per_chain_counters) ? 6 : (cfg->n_moves > 1 ? 7 : 8);
     if (const char* env = std::getenv("AMC_BLOCKS_PER_CU")) {   // tuning knob, 1..64
         const int v = std::atoi(env);
         if (v >= 1 && v <= 64) h->blocks_per_cu = h->blocks_per_cu_single = h->blocks_per_cu_pg = v;
     }
+    if (const char* env = std::getenv("AMC_BLOCKS_PER_CU_SINGLE")) {   // tuning knob, 1..64
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 64) h->blocks_per_cu_single = v;
+    }
+    if (const char* env = std::getenv("AMC_BLOCKS_PER_CU_REDUCE")) {   // tuning knob, 1..64
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 64) h->blocks_per_cu_red = v;
+    }
     if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
+    if (const char* env = std::getenv("AMC_WIDE_RED_ROWS")) h->wide_red_rows = std::atoi(env) != 0;
     h->M = cfg->n_chains;
     // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
     // (M_pad is a multiple of 256): a wave's 128-byte step-log store then covers exactly one aligned line
@@ -1050,7 +1079,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipMalloc(&h->d_totals, 2 * AMC_MAX_MOVES * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
     // room for two rounds of the estimator kernels' resident blocks (pg_plan: up to 2 x 5 per CU) beside the sweeps' 8 per CU
-    const int slots_per_cu = h->blocks_per_cu > 10 ? h->blocks_per_cu : 10;
+    const int slots_per_cu = std::max(std::max(std::max(h->blocks_per_cu, h->blocks_per_cu_single), h->blocks_per_cu_red), 10);
     h->n_slots = h->n_cu * slots_per_cu;
     AMC_TRY(hipMalloc(&h->d_acc_slots, (size_t)h->n_slots * sizeof(unsigned long long)));
     AMC_TRY(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
@@ -1527,6 +1556,14 @@ static int counter_room(amc_handle* h, const char* who, uint64_t steps)
                 who, (unsigned long long)h->t_counted, (unsigned long long)steps);
 }
 
+// The form of the rows a launch of `grid` blocks leaves its callback sums in (amc::red_finish): the compact 64-byte row while a
+// lane adds at most RED_COMPACT_TRIPS summands per column -- one per trip --, the wide one beyond.
+static int red_row_stride(const amc_handle* h, int grid)
+{
+    const int64_t pairs = (h->M + 1) / 2, lanes = (int64_t)grid * AMC_BLOCK;
+    return (!h->wide_red_rows && (pairs + lanes - 1) / lanes <= amc::RED_COMPACT_TRIPS) ? (int)amc::RED_COMPACT_WORDS : RED_HOST_STRIDE;
+}
+
 static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
 {
     amc::SweepArgs a;
@@ -1548,9 +1585,16 @@ static amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps)
     a.beta = h->beta;
     a.red_partials = h->red[(h->red_head + h->red_count) % RED_TICKETS].h_rows;   // the ticket a REDUCE launch would fill
     a.red_stride = RED_HOST_STRIDE;
+    a.red_cols = h->red_cols;
     a.exact_accept = h->exact_accept ? 1 : 0;
     a.n_slots = h->n_slots;
     return a;
+}
+
+// the grid of the sweep launch that also forms the callback sums (sweep_impl)
+static int reduce_sweep_grid(const amc_handle* h)
+{
+    return grid_for(h, (h->M + 1) / 2, h->blocks_per_cu_pg ? h->blocks_per_cu_pg : h->blocks_per_cu_red);
 }
 
 // n_sweeps x sweepstep MH steps in launches of at most 2^20 steps; when fuse_reduce is set (streamed form
@@ -1563,7 +1607,8 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
     // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
     // (a call whose last launch also forms the callback sums: that form holds 5 blocks per CU -- 89 VGPRs -- and runs one round of
     // them, 49 -> 45 us per callback at K = 2 and 1e7 chains; plain sweeps are indifferent between 5 and 8)
-    const int grid = grid_for(h, (h->M + 1) / 2, fuse_reduce ? (h->blocks_per_cu_pg ? h->blocks_per_cu_pg : 5) : (remaining == 1 ? h->blocks_per_cu_single : 0));
+    const int grid = fuse_reduce ? reduce_sweep_grid(h) : grid_for(h, (h->M + 1) / 2, remaining == 1 ? h->blocks_per_cu_single : 0);
+    if (fuse_reduce && grid > h->n_slots) return fail(AMC_ERR_STATE, "sweep_impl: a grid of %d blocks has no rows to leave its callback sums in (%d)", grid, h->n_slots);
     if (grid_out) *grid_out = grid;
     while (remaining > 0) {
         int32_t chunk = remaining > (1 << 20) ? (1 << 20) : (int32_t)remaining;
@@ -1574,6 +1619,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
             if (chunk > room) chunk = room;
         }
         amc::SweepArgs a = make_sweep_args(h, chunk);
+        a.red_stride = red_row_stride(h, grid);
         const bool last = remaining == chunk;
         int rc;
         if (h->use_rtc)
@@ -1819,6 +1865,8 @@ static int red_commit(amc_handle* h, RedTicket* t, int rows)
     AMC_HIP(hipEventRecord(t->ev, h->stream));
     t->pending = true;
     t->rows = rows;
+    t->row_stride = red_row_stride(h, rows);       // (rows = the grid of the launch that wrote them)
+    t->cols = h->red_cols;
     t->t_counted = h->t_counted;
     h->red_count += 1;
     return AMC_OK;
@@ -1849,7 +1897,8 @@ int amc_reduce_begin(amc_handle* h)
     // amc_reduce_end (integers: amc_xsum.h) -- no final-pass launches (~5 us each even when empty) and no D2H copy in
     // stream order (which would hold the next sweep back for a copy-engine round trip).
     amc::xs_word* rows = t->h_rows;
-    const int stride = RED_HOST_STRIDE;
+    const int stride = red_row_stride(h, h->red_blocks);
+    int cols = h->red_cols;
     const unsigned long long* slots = (ratio_mode == 0 && t->ratio_rows == 0) ? h->d_acc_slots : nullptr;
     unsigned long long* racc = t->d_ratio_acc;
     if (h->use_rtc) {
@@ -1858,17 +1907,17 @@ int amc_reduce_begin(amc_handle* h)
         int64_t m = h->M, m_pad = h->M_pad;
         int k = h->K, mode = ratio_mode, st = stride, n_slots = h->n_slots;
         uint64_t t_counted = h->t_counted;
-        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots, &racc};
+        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots, &racc, &cols};
         const int rc = rtc_launch(h, "amc::reduce_kernel<" + std::to_string(h->potential) + ">", h->red_blocks, params);
         if (rc != AMC_OK) return rc;
     } else if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots, racc);
+                           h->n_slots, racc, cols);
     else
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots, racc);
+                           h->n_slots, racc, cols);
     AMC_HIP(hipGetLastError());
     if (t->ratio_acc)
         AMC_HIP(hipMemcpyAsync(t->h_ratio_acc, t->d_ratio_acc, (size_t)h->K * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -1892,23 +1941,21 @@ static int finish_fused_reduce(amc_handle* h, int grid)
     return red_commit(h, t, grid);
 }
 
-// A launch that forms the callback sums adds two summands per trip into each lane's accumulators, and those hold XS_LANE_CAP of
-// them (amc_xsum.h); the launches of grid_for() make ceil(pairs / (grid 256)) trips per lane.  Beyond that (ensembles of more
-// than 2e9 chains) the sums are formed by the pass of their own, which flushes as it goes.
-static bool reduce_fits_in_launch(const amc_handle* h)
+// A launch that forms the callback sums adds ONE summand per trip and column (a chain pair's sum) into each lane's accumulators,
+// and those hold XS_LANE_CAP of them (amc_xsum.h); a launch of `grid` blocks makes ceil(pairs / (grid 256)) trips per lane.
+// Beyond that (ensembles of more than 2e9 chains) the sums are formed by the pass of their own, which flushes as it goes.
+static bool reduce_fits_in_grid(const amc_handle* h, int grid)
 {
-    const int64_t pairs = (h->M + 1) / 2;
-    const int64_t lanes = (int64_t)grid_for(h, pairs, h->blocks_per_cu_single < h->blocks_per_cu ? h->blocks_per_cu_single : h->blocks_per_cu) * AMC_BLOCK;
-    return 2 * ((pairs + lanes - 1) / lanes) <= amc::xs::XS_LANE_CAP - 2;
+    const int64_t pairs = (h->M + 1) / 2, lanes = (int64_t)grid * AMC_BLOCK;
+    return (pairs + lanes - 1) / lanes <= amc::xs::XS_LANE_CAP - 2;
 }
-
 int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: NULL handle");
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
     if (!red_next(h))
         return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: %d reductions are already in flight (call amc_reduce_end)", RED_TICKETS);
-    if (h->K > 4 || !reduce_fits_in_launch(h)) {      // the ratio sums need the counters of every move: sweep, then the reduction pass
+    if (h->K > 4 || !reduce_fits_in_grid(h, reduce_sweep_grid(h))) {      // the ratio sums need the counters of every move: sweep, then the reduction pass
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
@@ -1931,16 +1978,27 @@ static int reduce_end_records(amc_handle* h, const char* who, double* recs, uint
     namespace xs = amc::xs;
     xs::PartR col[amc::RED_COLS];
     for (int c = 0; c < amc::RED_COLS; ++c) col[c] = xs::part_r_empty();
-    double count = 0.0, slot_total = 0.0;
+    double slot_total = 0.0;
+    const bool compact = t->row_stride == amc::RED_COMPACT_WORDS;
+    const bool with_slot = h->K == 1 && !h->counters;       // the row's last word is written by those launches only
     for (int r = 0; r < t->rows; ++r) {
-        const amc::xs_word* row = t->h_rows + (size_t)r * RED_HOST_STRIDE;
-        for (int c = 0; c < amc::RED_COLS; ++c) xs::part_r_merge(col[c], amc::xs_load_r_row(row + c * amc::XS_ROW_R));
-        double v;
-        std::memcpy(&v, row + amc::RED_ROW_COUNT, sizeof(double)); count += v;          // integers: exact in any order
-        std::memcpy(&v, row + amc::RED_ROW_SLOT, sizeof(double)); slot_total += v;
+        const amc::xs_word* row = t->h_rows + (size_t)r * t->row_stride;
+        for (int c = 0; c < amc::RED_COLS; ++c)
+            xs::part_r_merge(col[c], compact ? amc::xs_load_compact_row(row, c) : amc::xs_load_r_row(row + c * amc::XS_ROW_R));
+        if (with_slot) {
+            double v;
+            std::memcpy(&v, row + (compact ? (int)amc::RED_COMPACT_SLOT : (int)amc::RED_ROW_SLOT), sizeof(double));
+            slot_total += v;                                // integers: exact in any order
+        }
     }
-    for (int c = 0; c < amc::RED_COLS; ++c) xs::rec_from_r(recs + (size_t)c * xs::XS_WORDS, col[c]);
-    xs::rec_from_plain(recs + (size_t)AMC_RED_COUNT * xs::XS_WORDS, count);
+    // a sum nobody asked for (amc_set_reduce_columns) was not formed: its record stays empty
+    static const int want[amc::RED_COLS] = {amc::RED_WANT_E, amc::RED_WANT_X, amc::RED_WANT_XX};
+    for (int c = 0; c < amc::RED_COLS; ++c) {
+        if (t->cols & want[c]) xs::rec_from_r(recs + (size_t)c * xs::XS_WORDS, col[c]);
+        else xs::rec_clear(recs + (size_t)c * xs::XS_WORDS);
+    }
+    // the rows of a reduction cover the handle's chains
+    xs::rec_from_plain(recs + (size_t)AMC_RED_COUNT * xs::XS_WORDS, (double)h->M);
     for (int k = 0; k < h->K; ++k) {
         xs::PartQ q = xs::PartQ{xs::i128{0, 0}, 0u};
         int e = xs::XS_E_RATIO;
@@ -1981,7 +2039,8 @@ int amc_reduce_end(amc_handle* h, double* out)
     uint64_t steps = 0;
     const int rc = reduce_end_records(h, "amc_reduce_end", recs, &steps);
     if (rc != AMC_OK) return rc;
-    for (int i = 0; i < AMC_RED_HEADER + h->K; ++i) out[i] = amc::xs::rec_round(recs + (size_t)i * amc::xs::XS_WORDS);
+    for (int i = 0; i < AMC_RED_HEADER + h->K; ++i)
+        out[i] = recs[(size_t)i * amc::xs::XS_WORDS] == (double)amc::xs::XS_EMPTY ? std::nan("") : amc::xs::rec_round(recs + (size_t)i * amc::xs::XS_WORDS);
     if (h->K == 1 && !h->counters) out[AMC_RED_SUM_RATIO0] = out[AMC_RED_SUM_RATIO0] / (double)steps;
     return AMC_OK;
 }
@@ -1992,6 +2051,14 @@ int amc_reduce(amc_handle* h, double* out)
     if (h->red_count != 0) return fail(AMC_ERR_STATE, "amc_reduce: a reduction is in flight (call amc_reduce_end first)");
     const int rc = amc_reduce_begin(h);
     return rc != AMC_OK ? rc : amc_reduce_end(h, out);
+}
+
+int amc_set_reduce_columns(amc_handle* h, int columns)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_set_reduce_columns: NULL handle");
+    if (columns < 0 || columns > AMC_REDUCE_ALL) return fail(AMC_ERR_BAD_ARG, "amc_set_reduce_columns: columns must be a combination of AMC_REDUCE_E / _X / _XX");
+    h->red_cols = columns;
+    return AMC_OK;
 }
 
 // Host-side arithmetic on records (no device involved): into[i] += from[i]; out[i] = the Float64 of records[i].
@@ -2101,9 +2168,12 @@ static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, P
     if (limit > amc::PG_GROUP * amc::PG_GROUP) limit = amc::PG_GROUP * amc::PG_GROUP;      // two levels of PG_GROUP in the kernel's tail
     const int64_t cap = h->use_rtc ? amc::xs::XS_LANE_CAP : amc::xs::XS_GD_LANE_CAP;
     auto fits = [&](int grid) { const int64_t lanes = (int64_t)grid * AMC_BLOCK; return 2 * (int64_t)q_batch * ((pairs + lanes - 1) / lanes) <= cap; };
-    int per_cu = h->blocks_per_cu_pg;                    // AMC_BLOCKS_PER_CU given: that many
-    if (per_cu == 0) {
-        const int key = (nl << 8) | (sweep << 4) | (reduce ? 1 : 0);
+    // what a CU holds of the kernel form at hand (AMC_BLOCKS_PER_CU given: that many), asked once per form -- the flushing
+    // form (mid) is an instantiation of its own, with its own register count
+    auto resident = [&](bool mid, int* per_cu) -> int {
+        if (h->blocks_per_cu_pg) { *per_cu = h->blocks_per_cu_pg; return AMC_OK; }
+        const bool red = reduce && !mid;             // (the callback sums ride on launches that need no flush: launch_pg)
+        const int key = (nl << 8) | (sweep << 4) | (red ? 1 : 0) | (mid ? 2 : 0);
         auto it = h->pg_resident.find(key);
         if (it == h->pg_resident.end()) {
             amc::PgArgs a0;
@@ -2111,24 +2181,27 @@ static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, P
             amc::SweepArgs s0;
             std::memset(&s0, 0, sizeof(s0));
             h->occ_query = 0;
-            const int rc = h->use_rtc                                    ? launch_pg_custom(h, a0, s0, -1, nl, sweep, reduce, false)
-                           : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a0, s0, -1, nl, sweep, reduce, false)
-                                                                         : launch_pg<amc::POT_HARMONIC>(h, a0, s0, -1, nl, sweep, reduce, false);
+            const int rc = h->use_rtc                                    ? launch_pg_custom(h, a0, s0, -1, nl, sweep, red, mid)
+                           : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a0, s0, -1, nl, sweep, red, mid)
+                                                                         : launch_pg<amc::POT_HARMONIC>(h, a0, s0, -1, nl, sweep, red, mid);
             if (rc != AMC_OK) return rc;
-            if (std::getenv("AMC_DEBUG_PLAN")) std::fprintf(stderr, "[amc] estimator form nl=%d sweep=%d reduce=%d: %d resident blocks per CU\n", nl, sweep, (int)reduce, h->occ_query);
+            if (std::getenv("AMC_DEBUG_PLAN")) std::fprintf(stderr, "[amc] estimator form nl=%d sweep=%d reduce=%d mid=%d: %d resident blocks per CU\n", nl, sweep, (int)red, (int)mid, h->occ_query);
             it = h->pg_resident.emplace(key, h->occ_query > 0 ? h->occ_query : 5).first;
         }
-        per_cu = it->second;
-    }
-    int one = grid_for(h, pairs, per_cu);
-    if (one > limit) one = limit;
-    plan->grid = one;
-    plan->mid = !fits(one);
+        *per_cu = it->second;
+        return AMC_OK;
+    };
+    auto grid_of = [&](int per_cu) { const int g = grid_for(h, pairs, per_cu); return g > limit ? limit : g; };
+    int per_cu = 0;
+    { const int rc = resident(false, &per_cu); if (rc != AMC_OK) return rc; }
+    plan->grid = grid_of(per_cu);
+    plan->mid = !fits(plan->grid);
     if (plan->mid && h->blocks_per_cu_pg == 0) {
-        int two = grid_for(h, pairs, 2 * per_cu);
-        if (two > limit) two = limit;
-        plan->grid = two;                // (the flushing form, too, is 3 % faster on two rounds than on one: q_batch 4, 143.6 -> 138.8 us)
-        if (fits(two)) plan->mid = false;
+        const int two = grid_of(2 * per_cu);
+        if (fits(two)) { plan->grid = two; plan->mid = false; return AMC_OK; }
+        // the flushing form, on two rounds of ITS resident blocks (3 % faster than on one: q_batch 4, 143.6 -> 138.8 us)
+        { const int rc = resident(true, &per_cu); if (rc != AMC_OK) return rc; }
+        plan->grid = grid_of(2 * per_cu);
     }
     return AMC_OK;
 }
@@ -2217,6 +2290,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     const bool mid = plan.mid;
     if (grid_out) *grid_out = grid;
     amc::SweepArgs sw = make_sweep_args(h, 1);
+    sw.red_stride = red_row_stride(h, grid);
     const int rc = h->use_rtc                                    ? launch_pg_custom(h, a, sw, grid, nl, sweep, red, mid)
                    : (h->potential == AMC_POTENTIAL_DOUBLE_WELL) ? launch_pg<amc::POT_DOUBLE_WELL>(h, a, sw, grid, nl, sweep, red, mid)
                                                                  : launch_pg<amc::POT_HARMONIC>(h, a, sw, grid, nl, sweep, red, mid);
@@ -2468,12 +2542,12 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     const bool fused = !per_move_launches(h) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
-    bool fused_reduce = reduce && fused && h->K <= 4 && reduce_fits_in_launch(h);
+    bool fused_reduce = reduce && fused && h->K <= 4;
     if (fused_reduce) {            // ... and launches that need no flush on the way
         PgPlan plan;
         const int rcp = pg_plan(h, nl_capacity(n_learn), h->K > 1 ? 2 : (h->d_log ? 1 : 3), true, q_batch, &plan);
         if (rcp != AMC_OK) return rcp;
-        fused_reduce = !plan.mid;
+        fused_reduce = !plan.mid && reduce_fits_in_grid(h, plan.grid);
     }
     int grid = 0;
     for (int64_t i = 0; i < n_steps; ++i) {
@@ -2878,6 +2952,23 @@ int amc_selftest_philox(int device, uint64_t seed, const uint64_t* pair, const u
     AMC_HIP(hipGetLastError());
     AMC_HIP(hipMemcpy(out4, dout, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     (void)hipFree(dp); (void)hipFree(dt); (void)hipFree(dout);
+    return AMC_OK;
+}
+
+int amc_selftest_wave_totals(int device, const int64_t* values, int64_t* totals, int64_t* totals_plain)
+{
+    if (!values || !totals || !totals_plain) return fail(AMC_ERR_BAD_ARG, "amc_selftest_wave_totals: NULL argument");
+    AMC_HIP(hipSetDevice(device));
+    long long *din = nullptr, *dout = nullptr, *dref = nullptr;
+    AMC_HIP(hipMalloc(&din, 6 * 64 * sizeof(long long)));
+    AMC_HIP(hipMalloc(&dout, 13 * sizeof(long long)));
+    AMC_HIP(hipMalloc(&dref, 6 * sizeof(long long)));
+    AMC_HIP(hipMemcpy(din, values, 6 * 64 * sizeof(long long), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(amc::selftest_wave_totals_kernel, dim3(1), dim3(64), 0, 0, din, dout, dref);
+    AMC_HIP(hipGetLastError());
+    AMC_HIP(hipMemcpy(totals, dout, 13 * sizeof(long long), hipMemcpyDeviceToHost));
+    AMC_HIP(hipMemcpy(totals_plain, dref, 6 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dref);
     return AMC_OK;
 }
 

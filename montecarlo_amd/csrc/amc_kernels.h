@@ -566,37 +566,6 @@ __device__ __forceinline__ void store_pair_block_writethrough(real_t* block_base
 #endif
 }
 
-// ---- deterministic block reduction helpers -------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Sums NV per-thread values over the block; thread 0 writes them to out[0..NV).
-template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double* out)
-{
-    __shared__ double s_part[NV][AMC_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double w = wave_sum(v[i]);
-        if (lane == 0) s_part[i][wave] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double t = s_part[i][0];
-            for (int w = 1; w < AMC_BLOCK / 64; ++w) t += s_part[i][w];
-            out[i] = t;
-        }
-    }
-    __syncthreads();
-}
-
 // ---- reproducible cross-chain sums (amc_xsum.h): the device side ---------------------------
 // A lane keeps one f64 accumulator per kind-Q column and two per kind-R column; a wave keeps the integer totals of what its
 // lanes have flushed in LDS ("slots", written by its lane 0 only: no atomics); at the end of the kernel thread 0 of the block
@@ -629,7 +598,7 @@ __device__ __forceinline__ void dpp_round_i64(long long (&v)[N])
     for (int i = 0; i < N; ++i) v[i] += o[i];
 }
 template <int N>
-__device__ __forceinline__ void wave_total_i64(long long (&v)[N])
+__device__ __forceinline__ void wave_total_i64_dpp(long long (&v)[N])      // the plain form (round 4): kept as the selftest's reference
 {
     dpp_round_i64<N, 0x111, 0xF>(v);      // row_shr:1
     dpp_round_i64<N, 0x112, 0xF>(v);      // row_shr:2
@@ -643,6 +612,100 @@ __device__ __forceinline__ void wave_total_i64(long long (&v)[N])
         const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v[i] >> 32), 63);
         v[i] = (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
     }
+}
+
+// Wave totals by FOLDING (round 5).  The form above costs seven vector instructions per value and round (hipcc keeps a 64-bit
+// DPP move as two v_mov_b32_dpp into zeroed registers plus the add: 93 instructions for two values), and every wave of a launch
+// that forms callback sums pays it once per column.  gfx950 can swap half-waves and rows of two registers in ONE instruction
+// (v_permlane32_swap: lanes 32..63 of the first operand with lanes 0..31 of the second; v_permlane16_swap: the odd rows of the
+// first with the even rows of the second), so two values fold into one register whose halves (rows) hold one value each, with
+// half the lanes left to add up -- a transposing reduction: 3 instructions per PAIR of values and step instead of 14.
+//   fold32(a, b)   lanes 0..31: a[l] + a[l + 32]      lanes 32..63: b[l - 32] + b[l]
+//   fold16(a, b)   row 0: a.row0 + a.row1   row 1: b.row0 + b.row1   row 2: a.row2 + a.row3   row 3: b.row2 + b.row3
+// The last four steps, inside a row of 16 lanes, are an in-place scan (lane 15 of the row ends with the row's total): a 64-bit
+// add whose first operand comes through DPP is v_add_co_u32_dpp + v_addc_co_u32_dpp, which hipcc does not form from C++
+// (inline assembly; lanes without a source keep their value: bound_ctrl is off and the destination is the second operand).
+// s_nop 1: a DPP operand must not be read within two wait states of the vector instruction that wrote it, and the compiler's
+// hazard pass does not look inside an asm statement.
+__device__ __forceinline__ long long fold32_i64(long long a, long long b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned int)(unsigned long long)a, (unsigned int)(unsigned long long)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned int)((unsigned long long)a >> 32), (unsigned int)((unsigned long long)b >> 32), false, false);
+    return (long long)(((unsigned long long)hi[0] << 32) | lo[0]) + (long long)(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ long long fold16_i64(long long a, long long b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)(unsigned long long)a, (unsigned int)(unsigned long long)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)((unsigned long long)a >> 32), (unsigned int)((unsigned long long)b >> 32), false, false);
+    return (long long)(((unsigned long long)hi[0] << 32) | lo[0]) + (long long)(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+#define AMC_ROW_STEP_I64(LO, HI, CTRL)                                                         \
+    "s_nop 1\n\t"                                                                               \
+    "v_add_co_u32_dpp " LO ", vcc, " LO ", " LO " " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
+    "v_addc_co_u32_dpp " HI ", vcc, " HI ", " HI ", vcc " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+// lane 15 of every row: the total of the row's 16 lanes
+__device__ __forceinline__ long long row_total_i64(long long v)
+{
+    unsigned int lo = (unsigned int)(unsigned long long)v, hi = (unsigned int)((unsigned long long)v >> 32);
+    asm volatile(AMC_ROW_STEP_I64("%0", "%1", "row_shr:1") AMC_ROW_STEP_I64("%0", "%1", "row_shr:2")
+                 AMC_ROW_STEP_I64("%0", "%1", "row_shr:4") AMC_ROW_STEP_I64("%0", "%1", "row_shr:8")
+                 : "+v"(lo), "+v"(hi) : : "vcc");
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+// ... and lane 31 / lane 63: the totals of rows 0 + 1 / rows 2 + 3 (one more step: row_bcast:15 into rows 1 and 3)
+__device__ __forceinline__ long long half_total_i64(long long v)
+{
+    unsigned int lo = (unsigned int)(unsigned long long)v, hi = (unsigned int)((unsigned long long)v >> 32);
+    asm volatile(AMC_ROW_STEP_I64("%0", "%1", "row_shr:1") AMC_ROW_STEP_I64("%0", "%1", "row_shr:2")
+                 AMC_ROW_STEP_I64("%0", "%1", "row_shr:4") AMC_ROW_STEP_I64("%0", "%1", "row_shr:8")
+                 "s_nop 1\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 : "+v"(lo), "+v"(hi) : : "vcc");
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+#undef AMC_ROW_STEP_I64
+__device__ __forceinline__ long long read_lane_i64(long long v, int lane)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+// Wave-wide totals of N 64-bit integers per lane, valid in EVERY lane afterwards (read back through the scalar unit): four values
+// per register (fold32 twice, fold16, the row scan: rows hold v0, v2, v1, v3), a remaining pair in the halves of one, a single
+// value folded onto itself.
+template <int N>
+__device__ __forceinline__ void wave_total_i64(long long (&v)[N])
+{
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= N; i += 4) {
+        const long long u = row_total_i64(fold16_i64(fold32_i64(v[i], v[i + 1]), fold32_i64(v[i + 2], v[i + 3])));
+        v[i] = read_lane_i64(u, 15); v[i + 2] = read_lane_i64(u, 31); v[i + 1] = read_lane_i64(u, 47); v[i + 3] = read_lane_i64(u, 63);
+    }
+    if (N - i == 3) {
+        const long long u = row_total_i64(fold16_i64(fold32_i64(v[i], v[i + 1]), fold32_i64(v[i + 2], 0ll)));
+        v[i] = read_lane_i64(u, 15); v[i + 2] = read_lane_i64(u, 31); v[i + 1] = read_lane_i64(u, 47);
+    } else if (N - i == 2) {
+        const long long u = half_total_i64(fold32_i64(v[i], v[i + 1]));
+        v[i] = read_lane_i64(u, 31); v[i + 1] = read_lane_i64(u, 63);
+    } else if (N - i == 1) {
+        const long long u = half_total_i64(fold32_i64(v[i], 0ll));
+        v[i] = read_lane_i64(u, 31);
+    }
+}
+// the wave's largest value, valid in every lane (v_max_u32 through DPP: lanes without a source see 0)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#define AMC_MAX_STEP(CTRL, MASK)                                                                                       \
+    {                                                                                                                  \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, MASK, 0xF, false);                   \
+        v = o > v ? o : v;                                                                                             \
+    }
+    AMC_MAX_STEP(0x111, 0xF) AMC_MAX_STEP(0x112, 0xF) AMC_MAX_STEP(0x114, 0xF) AMC_MAX_STEP(0x118, 0xF)
+    AMC_MAX_STEP(0x142, 0xA) AMC_MAX_STEP(0x143, 0xC)
+#undef AMC_MAX_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // The same for N 32-bit limbs whose wave totals fit 32 bits: ONE instruction per limb and round (the compiler folds the DPP
 // move into the add: v_add_u32_dpp), where a 64-bit value costs two moves and a two-instruction add.  These kernels are bound
@@ -666,13 +729,6 @@ __device__ __forceinline__ void wave_total_u32(uint32_t (&v)[N])      // valid i
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = (uint32_t)__builtin_amdgcn_readlane((int)v[i], 63);
 }
-__device__ __forceinline__ long long wave_sum_i64(long long v)
-{
-    long long a[1] = {v};
-    wave_total_i64<1>(a);
-    return a[0];                               // valid in every lane
-}
-
 __device__ __forceinline__ int wave_max_i32(int v)
 {
 #pragma unroll
@@ -763,10 +819,11 @@ __device__ __forceinline__ void q_flush(double (&s)[NC], const uint64_t (&cbits)
 __device__ __forceinline__ void q_flush_int(unsigned long long& acc, QSlot* slot)
 {
     const long long k = (long long)acc;
-    const long long lo = wave_sum_i64(k & 0xFFFFFFFFll), hi = wave_sum_i64(k >> 32);
+    long long h[2] = {k & 0xFFFFFFFFll, k >> 32};
+    wave_total_i64<2>(h);
     if ((threadIdx.x & 63) == 0) {
-        slot->lo += (unsigned long long)lo;
-        slot->hi += (unsigned long long)hi;
+        slot->lo += (unsigned long long)h[0];
+        slot->hi += (unsigned long long)h[1];
     }
     acc = 0ull;
 }
@@ -827,8 +884,14 @@ __device__ __forceinline__ void r_init(RLanes<NC>& L, xs::PartR* slot)
 }
 
 // The rare arm of r_deposit: some lane holds a value the current top cannot take, or one that is not finite (or as good as).
+// Every wave of a launch comes through here once per column -- its first deposit finds the column's level --, so the common
+// case is kept short (round 5; the general form below cost ~135 instructions per column, a wave-wide maximum through six LDS
+// permutes among them): the level a wave needs is a function of its largest |v|, and for everything finite |v| is monotone in
+// the high word of its bit pattern -- one v_and, six v_max_u32 through DPP, and the level is formed on the scalar unit.  Only a
+// wave that holds a NaN, an infinity or a finite value of 2^999 or more (high words that sort above every level's) classifies
+// its lanes one by one.
 template <int NC>
-__device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& v, xs::PartR* slot)
+__device__ __forceinline__ int r_slow_classify(int c, double& v, xs::PartR* slot)
 {
     int need = xs::XS_LMIN;
     uint32_t fl = 0u;
@@ -848,7 +911,14 @@ __device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& v, xs::Part
     const uint32_t f_pinf = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_PINF) != 0u) ? xs::XS_F_PINF : 0u;
     const uint32_t f_ninf = __builtin_amdgcn_ballot_w64((fl & xs::XS_F_NINF) != 0u) ? xs::XS_F_NINF : 0u;
     if (lane0) slot[c].flags |= f_nan | f_pinf | f_ninf;
-    need = wave_max_i32(need);
+    return wave_max_i32(need);
+}
+template <int NC>
+__device__ __forceinline__ void r_slow(RLanes<NC>& L, int c, double& v, xs::PartR* slot)
+{
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const int be_max = (int)(wave_max_u32((uint32_t)((uint64_t)__double_as_longlong(v) >> 32) & 0x7FFFFFFFu) >> 20);
+    const int need = be_max >= (int)xs::XS_BE_BEYOND ? r_slow_classify<NC>(c, v, slot) : xs::xs_level_of_exponent(be_max);
     if (need > L.top[c]) {
         // one level up the level-1 multiples ARE the new level-2 multiples; further up nothing of what was taken so far is
         // as large as half a quantum of the new lower level.  (n summands are on the books: n times the new constants' bits.)
@@ -883,24 +953,47 @@ __device__ __forceinline__ void r_flush(RLanes<NC>& L, xs::PartR* slot)
 {
     const bool lane0 = (threadIdx.x & 63) == 0;
     // per column: the two levels' multiples, |.| < n 2^49 < 2^63 (the 64-bit arithmetic modulo 2^64 holds them); a wave's 64 lanes
-    // need up to 6 more bits, so low 32 bits and high parts go through the shuffles separately -- the four of them in the same
-    // steps: their crossbar latencies overlap
+    // need up to 6 more bits.  Few summands (a launch over 1e7 chains gives a lane 10 to 16): |k| < 2^56, the 64 lanes' sum fits
+    // 64 bits, and ALL columns' multiples go through the wave together (wave_total_i64: four values per folded register).
+    // Otherwise low 32 bits and high parts travel separately, a column at a time.
+    int n_max = 0;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < NC; ++c) n_max = L.n[c] > n_max ? L.n[c] : n_max;
+    auto multiples = [&](int c, long long& k1, long long& k2) {
         const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
-        const long long k1 = (long long)(L.a1[c] - n * xs::xs_level_c_bits(L.top[c]));
-        const long long k2 = (long long)(L.a2[c] - n * xs::xs_level_c_bits(L.top[c] - 1));
+        k1 = (long long)(L.a1[c] - n * xs::xs_level_c_bits(L.top[c]));
+        k2 = (long long)(L.a2[c] - n * xs::xs_level_c_bits(L.top[c] - 1));
         L.a1[c] = L.a2[c] = 0ull;
         L.n[c] = 0;
-        if (n <= 128ull) {
-            // few summands (a launch over 1e7 chains gives a lane ~10): |k| < 2^56, the 64 lanes' sum fits 64 bits
-            long long v[2] = {k1, k2};
-            wave_total_i64<2>(v);
+    };
+    if (n_max <= 128) {
+#pragma unroll
+        for (int c = 0; c + 2 <= NC; c += 2) {            // two columns per folded register
+            long long v[4];
+            multiples(c, v[0], v[1]);
+            multiples(c + 1, v[2], v[3]);
+            wave_total_i64<4>(v);
             if (lane0) {
                 slot[c].k1 = xs::i128_add(slot[c].k1, xs::i128_of(v[0]));
                 slot[c].k2 = xs::i128_add(slot[c].k2, xs::i128_of(v[1]));
+                slot[c + 1].k1 = xs::i128_add(slot[c + 1].k1, xs::i128_of(v[2]));
+                slot[c + 1].k2 = xs::i128_add(slot[c + 1].k2, xs::i128_of(v[3]));
             }
-        } else {
+        }
+        if (NC & 1) {
+            long long v[2];
+            multiples(NC - 1, v[0], v[1]);
+            wave_total_i64<2>(v);
+            if (lane0) {
+                slot[NC - 1].k1 = xs::i128_add(slot[NC - 1].k1, xs::i128_of(v[0]));
+                slot[NC - 1].k2 = xs::i128_add(slot[NC - 1].k2, xs::i128_of(v[1]));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            long long k1, k2;
+            multiples(c, k1, k2);
             long long v[4] = {k1 & 0xFFFFFFFFll, k1 >> 32, k2 & 0xFFFFFFFFll, k2 >> 32};
             wave_total_i64<4>(v);
             if (lane0) {
@@ -939,40 +1032,130 @@ __device__ __forceinline__ xs::PartQ q_block_total(const QSlot (*slots)[NC], int
 // chain ids alone (shards begin at even ids), and half the work of taking the chains one by one (a lone last chain is
 // its own summand).
 enum { RED_COLS = 3, RED_ROW_COUNT = RED_COLS * XS_ROW_R, RED_ROW_SLOT = RED_ROW_COUNT + 1, RED_ROW_WORDS = RED_ROW_COUNT + 2 };
+// The block's row in its COMPACT form (round 5): ONE 64-byte line per block on the link to the host instead of three.  A launch
+// whose lanes see at most RED_COMPACT_TRIPS summands per column (the host knows: trips per lane) has block totals below 2^62 --
+// 256 lanes x 32 x 2^49 -- so a column is two 64-bit words, and the three columns' tops and flags share a word:
+//   word 0       16 bits per column: (top + 128) | flags << 8
+//   word 1 + 2c  k1 of column c        word 2 + 2c  k2 of column c
+//   word 7       the pool-wide accepted slot (as in the wide row), else 0
+// The count needs no word: the rows of a launch cover the handle's chains, the host knows their number.
+enum { RED_COMPACT_WORDS = 8, RED_COMPACT_SLOT = 7, RED_COMPACT_TRIPS = 32 };
+// Which sums a launch forms (SweepArgs.red_cols; amc_set_reduce_columns): callback_energy needs sum e alone, the moments of
+// test/distribution_test.jl sum x and sum x^2 -- a deposit costs nine vector instructions per trip and column, so what nobody
+// asked for is not formed (its record stays empty).
+enum { RED_WANT_E = 1, RED_WANT_X = 2, RED_WANT_XX = 4, RED_WANT_ALL = 7 };
 template <int POT>
 struct RedCols {
     static constexpr bool X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
     static constexpr int NC = X2_IS_E ? 2 : 3;
 };
-
-template <int POT>
-__device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 xv, bool v0, bool v1, const double* s_math,
-                                             xs::PartR* slot)
+__host__ __device__ inline xs::PartR xs_load_compact_row(const xs_word* row, int c)
 {
-    const double x0 = v0 ? (double)xv.x : 0.0, x1 = v1 ? (double)xv.y : 0.0;
-    const double e0 = v0 ? (double)potential<POT>(xv.x, s_math) : 0.0, e1 = v1 ? (double)potential<POT>(xv.y, s_math) : 0.0;
-    r_deposit(L, 0, e0 + e1, slot);
-    r_deposit(L, 1, x0 + x1, slot);
-    if (!RedCols<POT>::X2_IS_E) r_deposit(L, 2, x0 * x0 + x1 * x1, slot);
+    xs::PartR p;
+    const unsigned int f = (unsigned int)(row[0] >> (16 * c)) & 0xFFFFu;
+    p.top = (int32_t)(f & 0xFFu) - 128;
+    p.flags = f >> 8;
+    p.k1 = xs::i128_of((long long)row[1 + 2 * c]);
+    p.k2 = xs::i128_of((long long)row[2 + 2 * c]);
+    return p;
 }
 
-// End of the launch: flush, then thread 0 writes the block's row (count = chains this block summed, as a double).
+// cols: RED_WANT_* bits (wave-uniform: a kernel argument)
 template <int POT>
-__device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::PartR (*slots)[RedCols<POT>::NC], double count,
-                                           xs_word* row)
+__device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 xv, bool v0, bool v1, const double* s_math,
+                                             xs::PartR* slot, int cols)
+{
+    const double x0 = v0 ? (double)xv.x : 0.0, x1 = v1 ? (double)xv.y : 0.0;
+    if (cols & (RedCols<POT>::X2_IS_E ? (RED_WANT_E | RED_WANT_XX) : RED_WANT_E)) {
+        const double e0 = v0 ? (double)potential<POT>(xv.x, s_math) : 0.0, e1 = v1 ? (double)potential<POT>(xv.y, s_math) : 0.0;
+        r_deposit(L, 0, e0 + e1, slot);
+    }
+    if (cols & RED_WANT_X) r_deposit(L, 1, x0 + x1, slot);
+    if (!RedCols<POT>::X2_IS_E && (cols & RED_WANT_XX)) r_deposit(L, 2, x0 * x0 + x1 * x1, slot);
+}
+
+// End of the launch: the block's row.
+// compact (block-uniform; see RED_COMPACT_WORDS): the lanes' integers go through the wave (wave_total_i64), lane 0 leaves the
+// wave's totals and tops in LDS, one barrier, and threads 0 .. 6 of the block form one word of the row each -- the tops' maximum,
+// the waves' totals brought to it (amc_xsum.h: one level up a k1 total is the k2 total, further up nothing is left) -- and store
+// it: seven lanes of one instruction, one 64-byte write.  No wave slot is read-modified-written and nothing is 128 bits wide;
+// the slots only carry the flags of the rare arm.  (Round 4's form, kept as the wide form below, cost the K = 2 launch 4.2 us
+// at 1e7 chains, its three-line row 1.4 us of them.)
+// wide: flush into the wave slots, thread c merges the block's slots of column c (any number of summands, mid-launch flushes).
+template <int POT>
+__device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::PartR (*slots)[RedCols<POT>::NC], xs_word* row, bool compact,
+                                           int cols)
 {
     constexpr int NC = RedCols<POT>::NC;
+    if (compact) {
+        __shared__ long long s_fin_k[AMC_BLOCK / 64][2 * NC];
+        __shared__ int s_fin_top[AMC_BLOCK / 64][NC];
+        long long k[2 * NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long n = (unsigned long long)(unsigned)L.n[c];
+            k[2 * c] = (long long)(L.a1[c] - n * xs::xs_level_c_bits(L.top[c]));
+            k[2 * c + 1] = (long long)(L.a2[c] - n * xs::xs_level_c_bits(L.top[c] - 1));
+        }
+        // (the common request is sum e alone -- callback_energy --: its two integers travel by themselves, the columns nobody
+        // deposited into are zero without a sum)
+        if ((cols & ~(RedCols<POT>::X2_IS_E ? (RED_WANT_E | RED_WANT_XX) : RED_WANT_E)) == 0) {
+            long long k0[2] = {k[0], k[1]};
+            wave_total_i64<2>(k0);
+            k[0] = k0[0]; k[1] = k0[1];
+        } else {
+            wave_total_i64<2 * NC>(k);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                s_fin_k[threadIdx.x >> 6][2 * c] = k[2 * c];
+                s_fin_k[threadIdx.x >> 6][2 * c + 1] = k[2 * c + 1];
+                s_fin_top[threadIdx.x >> 6][c] = L.top[c];
+            }
+        }
+        __syncthreads();
+        const int t = (int)threadIdx.x;
+        if (t < 1 + 2 * RED_COLS) {
+            xs_word w = 0ull;
+            // the lane column behind row column rc (sum x^2 = sum e where they are the same sums)
+            auto lane_col = [](int rc) { return (RedCols<POT>::X2_IS_E && rc == 2) ? 0 : rc; };
+            auto top_of = [&](int c) {
+                int T = s_fin_top[0][c];
+                for (int wv = 1; wv < AMC_BLOCK / 64; ++wv) T = s_fin_top[wv][c] > T ? s_fin_top[wv][c] : T;
+                return T;
+            };
+            if (t == 0) {
+                for (int rc = 0; rc < RED_COLS; ++rc) {
+                    const int c = lane_col(rc);
+                    uint32_t fl = 0u;
+                    for (int wv = 0; wv < AMC_BLOCK / 64; ++wv) fl |= slots[wv][c].flags;
+                    w |= (xs_word)((uint32_t)(top_of(c) + 128) | (fl << 8)) << (16 * rc);
+                }
+            } else {
+                const int c = lane_col((t - 1) >> 1), second = (t - 1) & 1;
+                const int T = top_of(c);
+                long long sum = 0;
+                for (int wv = 0; wv < AMC_BLOCK / 64; ++wv) {
+                    const int d = T - s_fin_top[wv][c];
+                    if (d == 0) sum += s_fin_k[wv][2 * c + second];
+                    else if (d == 1 && second) sum += s_fin_k[wv][2 * c];
+                }
+                w = (xs_word)sum;
+            }
+            row[t] = w;
+        }
+        return;
+    }
     r_flush(L, slots[threadIdx.x >> 6]);
-    double cnt[1] = {count};
-    double total[1];
-    block_sum_store<1>(cnt, total);                 // ends in a barrier: the slots are visible to thread 0
-    // the row goes to pinned host memory: composed in LDS by thread 0, stored by ONE wave instruction (20 lanes, consecutive
-    // words: three 64-byte writes on the link instead of twenty 8-byte ones)
+    __syncthreads();                                // the slots are visible to the threads that compose the row
+    // the row goes to pinned host memory: composed in LDS, stored by ONE wave instruction (consecutive words: three 64-byte
+    // writes on the link instead of twenty 8-byte ones)
     __shared__ xs_word s_row[RED_ROW_WORDS];
     if (threadIdx.x < RED_COLS) {          // thread c: column c (sum x^2 = sum e where they are the same sums)
         const int c = (RedCols<POT>::X2_IS_E && threadIdx.x == 2) ? 0 : (int)threadIdx.x;
         xs_store_r_row(s_row + threadIdx.x * XS_ROW_R, r_block_total<NC>(slots, c));
-        if (threadIdx.x == 0) s_row[RED_ROW_COUNT] = (xs_word)__double_as_longlong(total[0]);
+        if (threadIdx.x == 0) s_row[RED_ROW_COUNT] = 0ull;          // (unused: the host knows the chains a launch covers)
     }
     __syncthreads();
     if (threadIdx.x <= RED_ROW_COUNT) row[threadIdx.x] = s_row[threadIdx.x];
@@ -996,7 +1179,8 @@ struct SweepArgs {
     xs_word* red_partials;        // REDUCE launches: [grid][red_stride] block rows, pinned host memory: three kind-R columns
                                   // (sum e, sum x, sum x^2: XS_ROW_R words each), then as doubles the count and this block's
                                   // pool-wide accepted slot after the launch (RED_ROW_COUNT, RED_ROW_SLOT)
-    int32_t red_stride;
+    int32_t red_stride;           // words per row: RED_ROW_WORDS, or RED_COMPACT_WORDS for the compact form (red_finish)
+    int32_t red_cols;             // RED_WANT_* bits: the sums this launch forms
     int32_t log_pos;              // row of the step log the first step of this launch writes
     int32_t exact_accept;         // != 0: skip the accept filter, every decision by accept_exact (tests; AMC_EXACT_ACCEPT)
     int32_t n_slots;              // length of acc_total (launches of different grids share it)
@@ -1143,7 +1327,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
     if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
-    int red_pairs = 0, red_ragged = 0;
     __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[MULTI ? AMC_PICK_CELLS : 16];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
@@ -1230,8 +1413,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
         if (REDUCE) {
-            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
-            red_pairs += 1;
+            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], a.red_cols);
         }
         x_done = xv;
         lw_done = lw;
@@ -1254,13 +1436,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             store_pair_block_writethrough(a.x + 2 * base, xv);
             if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, p, lw);
         }
-        if (REDUCE) {
-            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
-            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
-        }
+        if (REDUCE) red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], a.red_cols);
     }
-    if (REDUCE)          // full trips: two chains per lane each
-        red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), a.red_partials + (int64_t)blockIdx.x * a.red_stride);
+    if (REDUCE)
+        red_finish<POT>(red, s_red, a.red_partials + (int64_t)blockIdx.x * a.red_stride, a.red_stride == RED_COMPACT_WORDS, a.red_cols);
     if (!MULTI) {
         // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
         // address at kernel end serialise at ~13 ns each; one address per block does not contend).
@@ -1274,7 +1453,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
                 // the callback wants the pool-wide accepted total: column 4 of this block's row carries the slot's
                 // value after this launch (exact in a double below 2^53); the rows are summed by the host
                 if (t != 0) __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.red_partials[(int64_t)blockIdx.x * a.red_stride + RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)(slots_before + t));
+                a.red_partials[(int64_t)blockIdx.x * a.red_stride + (a.red_stride == RED_COMPACT_WORDS ? (int)RED_COMPACT_SLOT : (int)RED_ROW_SLOT)] =
+                    (xs_word)__double_as_longlong((double)(slots_before + t));
             } else if (t != 0) {
                 // no-return atomic: fire and forget (a read-modify-write would hold the block for a memory round trip)
                 __hip_atomic_fetch_add(a.acc_total + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1715,8 +1895,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                                                             int64_t m_stride, int n_moves, int ratio_mode,
                                                             uint64_t t_steps, xs_word* rows, int p_stride,
                                                             const unsigned long long* slots, int n_slots,
-                                                            unsigned long long* ratio_acc)
+                                                            unsigned long long* ratio_acc, int red_cols)
 {
+    // p_stride names the row's form (red_finish): the compact one for passes of at most RED_COMPACT_TRIPS trips per lane
+    const bool compact = p_stride == RED_COMPACT_WORDS;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
     __shared__ double s_math[POT == POT_CUSTOM ? TAB_DOUBLES : 1];      // a custom potential may call amc_exp
     if (POT == POT_CUSTOM) stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);
@@ -1724,7 +1906,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[AMC_BLOCK / 64][RNC];
     r_init(red, s_red[threadIdx.x >> 6]);
-    int n_mine = 0;
+    int n_trips = 0;                                          // summands per column since the last flush (scalar unit)
     const int64_t n_pairs = (n_chains + 1) >> 1;              // 16-byte loads; x is padded, the odd slot of a lone last chain is masked
     // every lane of a wave takes the same number of trips (the flushes inside are wave-wide): lanes past the end add zeros
     const int64_t wave_first = (int64_t)blockIdx.x * AMC_BLOCK + (threadIdx.x & ~63);
@@ -1733,17 +1915,16 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
         const bool v0 = p < n_pairs, v1 = v0 && (2 * p + 1 < n_chains);
         real2 xp = {(real_t)0.0, (real_t)0.0};
         if (v0) xp = *reinterpret_cast<const real2*>(x + 2 * p);
-        red_add_pair<POT>(red, xp, v0, v1, s_math, s_red[threadIdx.x >> 6]);
-        n_mine += (v0 ? 1 : 0) + (v1 ? 1 : 0);
-        if (red.n[0] > xs::XS_LANE_CAP - 2) r_flush(red, s_red[threadIdx.x >> 6]);
+        red_add_pair<POT>(red, xp, v0, v1, s_math, s_red[threadIdx.x >> 6], red_cols);
+        if (++n_trips > xs::XS_LANE_CAP - 2) { r_flush(red, s_red[threadIdx.x >> 6]); n_trips = 0; }      // (never in a compact pass)
     }
     xs_word* out = rows + (int64_t)blockIdx.x * p_stride;
-    red_finish<POT>(red, s_red, (double)n_mine, out);
+    red_finish<POT>(red, s_red, out, compact, red_cols);
     if (threadIdx.x == 0) {
         unsigned long long a = 0;
         if (slots)
             for (int s = blockIdx.x; s < n_slots; s += gridDim.x) a += slots[s];
-        out[RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)a);
+        out[compact ? (int)RED_COMPACT_SLOT : (int)RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)a);
     }
     if (ratio_mode != 0) {
         __shared__ QSlot s_ratio[AMC_BLOCK / 64][1];
@@ -2348,7 +2529,6 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
     if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
-    int red_pairs = 0, red_ragged = 0;
     // the pool-wide accepted total this block can see before the launch (see sweep_kernel)
     unsigned long long slots_before = 0;
     if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
@@ -2603,10 +2783,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
         samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true, true);
-        if (REDUCE) {
-            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6]);
-            red_pairs += 1;
-        }
+        if (REDUCE) red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
         x_done = xv;
         base_done = base;
     }
@@ -2621,18 +2798,16 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         // end go through the motions on a pair nobody stores and add zeros
         samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1, false);
         if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
-        if (REDUCE) {
-            red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6]);
-            red_ragged += (v0 ? 1 : 0) + (v1 ? 1 : 0);
-        }
+        if (REDUCE) red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
     }
-    if (REDUCE)          // full trips: two chains per lane each
-        red_finish<POT>(red, s_red, (double)(2 * red_pairs + red_ragged), sw.red_partials + (int64_t)blockIdx.x * sw.red_stride);
+    if (REDUCE)
+        red_finish<POT>(red, s_red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride, sw.red_stride == RED_COMPACT_WORDS, sw.red_cols);
     if (SWEEP == 1 || SWEEP == 3) {      // K == 1: the pool-wide accepted total (counter_totals)
         const unsigned long long t = add_block_accepts(sw.acc_total, wave_acc);
         // this block's slot after this launch (exact in a double below 2^53)
         if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
-            sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + RED_ROW_SLOT] = (xs_word)__double_as_longlong((double)(slots_before + t));
+            sw.red_partials[(int64_t)blockIdx.x * sw.red_stride + (sw.red_stride == RED_COMPACT_WORDS ? (int)RED_COMPACT_SLOT : (int)RED_ROW_SLOT)] =
+                (xs_word)__double_as_longlong((double)(slots_before + t));
     }
     // Block totals -> this block's row of partials.  All cross-block traffic of the tail below goes
     // through AGENT-scope relaxed atomic stores / loads (sc1: written through to, and read from, the memory side --
@@ -2861,6 +3036,33 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(256) void selftest_filter_kernel
         worst = (o > worst) ? o : worst;
     }
     if ((threadIdx.x & 63) == 0) atomicMax(out_max_bits, (unsigned long long)__double_as_longlong(worst));
+}
+
+// The wave-total primitives (wave_total_i64 by folding, wave_max_u32) on one wave's worth of arbitrary lane values: in is
+// [6][64] 64-bit integers; out[0..5] the six totals through wave_total_i64<6>, out[6..7] two of them through <2>, out[8..10]
+// three through <3>, out[11] one through <1>, out[12] wave_max_u32 of the low words of row 0; ref[0..5] the totals by the plain
+// DPP form of round 4.  The host compares both with its own sums.
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(64) void selftest_wave_totals_kernel(const long long* in, long long* out, long long* ref)
+{
+    const int lane = threadIdx.x & 63;
+    long long v[6], r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = r[i] = in[i * 64 + lane];
+    long long two[2] = {v[4], v[1]}, three[3] = {v[5], v[0], v[2]}, one[1] = {v[3]};
+    const uint32_t m = wave_max_u32((uint32_t)(unsigned long long)v[0]);
+    wave_total_i64<6>(v);
+    wave_total_i64<2>(two);
+    wave_total_i64<3>(three);
+    wave_total_i64<1>(one);
+    wave_total_i64_dpp<6>(r);
+    if (lane == 17) {        // any lane: the totals are wave-uniform
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { out[i] = v[i]; ref[i] = r[i]; }
+        out[6] = two[0]; out[7] = two[1];
+        out[8] = three[0]; out[9] = three[1]; out[10] = three[2];
+        out[11] = one[0];
+        out[12] = (long long)m;
+    }
 }
 
 AMC_KERNEL_LINKAGE __global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,

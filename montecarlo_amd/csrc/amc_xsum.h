@@ -140,13 +140,15 @@ AMC_XS_HD double xs_c(int e) { return xs_bits_double(xs_c_bits(e)); }
 AMC_XS_HD uint64_t xs_level_c_bits(int l) { return xs_c_bits(XS_W * l); }
 AMC_XS_HD double xs_level_cap(int l) { return xs_bits_double((uint64_t)(XS_W * l + XS_B + 1023) << 52); }
 // the level a finite value needs: max(LMIN, floor((ilogb(v) + 1) / 50)), which exceeds LMAX for |v| >= 2^999; zero and subnormals: LMIN
-AMC_XS_HD int xs_level_of(double v)
+AMC_XS_HD int xs_level_of_exponent(int be)                    // be: the biased exponent field, 0 .. 0x7FF
 {
-    const int be = (int)((xs_double_bits(v) >> 52) & 0x7FFu);
     if (be == 0) return XS_LMIN;
     const int l = (be - 1023 + 1 + 1050) / XS_W - 21;        // numerator >= 29: plain integer division is the floor
     return l < XS_LMIN ? XS_LMIN : l;
 }
+AMC_XS_HD int xs_level_of(double v) { return xs_level_of_exponent((int)((xs_double_bits(v) >> 52) & 0x7FFu)); }
+// the smallest biased exponent that lies beyond the last level (|v| >= 2^999; infinities and NaN have 0x7FF)
+enum { XS_BE_BEYOND = 999 + 1023 };
 AMC_XS_HD double xs_lsb1(double v) { return xs_bits_double(xs_double_bits(v) | 1ull); }
 
 // GradientData of the Gaussian displacement policy (gradients.jl:104-108 with particle_1d.jl:42-59): the quantum exponents

@@ -188,6 +188,7 @@ class Metropolis(AriannaAlgorithm):
     def finalise(self, simulation: Simulation) -> None:
         self._drop_pending_reduction()
         self._settle_claimed()
+        self.set_reduction_needs(None)          # the run's narrowing ends with the run: a caller of reductions() gets every entry
         if getattr(self, "device_params_dirty", False):
             self.pull_parameters()
         if self.download_on_finalise:
@@ -279,6 +280,17 @@ class Metropolis(AriannaAlgorithm):
         self._inflight.pop(0)
         ticket._finish(*self.engine.reduce_end_exact())
 
+    def set_reduction_needs(self, needs) -> None:
+        """What the callbacks of this run read of a reduction (run() collects it from the StoreCallbacks' callbacks: names among
+        "energy", "mean_x", "mean_x2", "acceptance"; None: everything).  The engine then forms only those sums over x --
+        callback_energy (particle_1d.jl:68-70) and callback_acceptance (metropolis.jl:319-321), the reference's own two,
+        need sum e alone; what nobody asked for reads NaN."""
+        if not hasattr(self.engine, "set_reduce_columns"):
+            return
+        cols = 7 if needs is None else ((1 if "energy" in needs else 0) | (2 if "mean_x" in needs else 0) | (4 if "mean_x2" in needs else 0))
+        self._drop_pending_reduction()
+        self.engine.set_reduce_columns(cols)
+
     def invalidate_reductions(self) -> None:
         """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
         self._epoch += 1
@@ -336,32 +348,34 @@ def _find_metropolis(simulation: Simulation):
     return found[0]
 
 
-def _deferrable(pick):
+def _deferrable(pick, needs):
     """A callback f(simulation) over the engine's reduction, plus ``f.deferred(simulation)``: the same value as a thunk over
-    the reduction ticket of the current state, for StoreCallbacks to evaluate when it writes the row."""
+    the reduction ticket of the current state, for StoreCallbacks to evaluate when it writes the row; ``f.needs``: the entries
+    of the reduction it reads (Metropolis.set_reduction_needs)."""
     def wrap(fn):
         def deferred(simulation: Simulation):
             ticket = _find_metropolis(simulation).reductions_async()
             return lambda: pick(ticket.result())
         fn.deferred = deferred
+        fn.needs = tuple(needs)
         return fn
     return wrap
 
 
-@_deferrable(lambda r: float(r["energy"]))
+@_deferrable(lambda r: float(r["energy"]), needs=("energy",))
 def callback_energy(simulation: Simulation) -> float:
     """callback_energy, example/particle_1d/particle_1d.jl:68-70: mean energy over all chains."""
     return float(_find_metropolis(simulation).reductions()["energy"])
 
 
-@_deferrable(lambda r: np.array(r["acceptance"], dtype=np.float64))
+@_deferrable(lambda r: np.array(r["acceptance"], dtype=np.float64), needs=("acceptance",))
 def callback_acceptance(simulation: Simulation) -> np.ndarray:
     """callback_acceptance, src/metropolis.jl:319-321: per move, mean over chains of
     accepted_calls/total_calls (NaN before the first step, like the reference's 0/0)."""
     return np.array(_find_metropolis(simulation).reductions()["acceptance"], dtype=np.float64)
 
 
-@_deferrable(lambda r: np.array([r["mean_x"], r["mean_x2"]]))
+@_deferrable(lambda r: np.array([r["mean_x"], r["mean_x2"]]), needs=("mean_x", "mean_x2"))
 def callback_moments(simulation: Simulation) -> np.ndarray:
     """[mean(x), mean(x^2)] over all chains: the statistic test/distribution_test.jl:36-37 checks."""
     r = _find_metropolis(simulation).reductions()

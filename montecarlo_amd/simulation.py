@@ -213,6 +213,27 @@ def _due(simulation: Simulation, k: int) -> Optional[int]:
     return s[c]
 
 
+def _declare_reduction_needs(sim: Simulation) -> None:
+    """Tell the sampler which entries of a reduction this run's consumers read, so that the launches which form the sums form
+    those and no others.  Consumers are the algorithms marked ``wants_reductions`` (StoreCallbacks -- callbacks are plain
+    functions f(simulation) in the reference, src/algorithms.jl:97-102; the engine-backed ones carry ``needs`` --,
+    StoreHistogram); one that does not say what it reads (``reduction_needs()`` missing or None: any user function among the
+    callbacks) keeps everything, and so does a run without consumers (a caller of Metropolis.reductions())."""
+    needs, known, any_consumer = set(), True, False
+    for alg in sim.algorithms:
+        if not getattr(alg, "wants_reductions", False):
+            continue
+        any_consumer = True
+        n = alg.reduction_needs() if hasattr(alg, "reduction_needs") else None
+        if n is None:
+            known = False
+        else:
+            needs.update(n)
+    for alg in sim.algorithms:
+        if hasattr(alg, "set_reduction_needs"):
+            alg.set_reduction_needs(needs if (any_consumer and known) else None)
+
+
 def run(simulation: Simulation, fuse: bool = True) -> None:
     """run!(simulation), src/simulation.jl:175-204.
 
@@ -222,6 +243,7 @@ def run(simulation: Simulation, fuse: bool = True) -> None:
     """
     sim = simulation
     try:
+        _declare_reduction_needs(sim)
         for alg in sim.algorithms:                                                  # :179-181
             alg.initialise(sim)
         sim._write_summary()                                                        # :182
@@ -367,6 +389,16 @@ class StoreCallbacks(AriannaAlgorithm):
             self.files = [open(p, "w") for p in self.paths]
         if self.store_first:                                                        # :93
             self.make_step(simulation)
+
+    def reduction_needs(self):
+        """The entries of a reduction the callbacks read (their ``needs``), or None when one of them does not say."""
+        out = set()
+        for cb in self.callbacks:
+            n = getattr(cb, "needs", None)
+            if n is None:
+                return None
+            out.update(n)
+        return out
 
     def _write(self, t: int, values) -> None:
         for i, value in enumerate(values):

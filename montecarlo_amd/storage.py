@@ -40,6 +40,9 @@ class StoreHistogram(AriannaAlgorithm):
         self.path = os.path.join(path, "histogram.dat")
         self.rank, _ = sharding.world()
 
+    def reduction_needs(self):
+        return ("mean_x", "mean_x2")          # the bin-free moments (run() tells the sampler: simulation._declare_reduction_needs)
+
     def _settle(self) -> None:
         """The moments of the previous sample (a reduction ticket claimed then) are fetched when the next one is due."""
         ticket, self._ticket = getattr(self, "_ticket", None), None

@@ -660,9 +660,16 @@ class OracleEngine:
                              scale_expr=scale_expr, proposal=proposal, n_params=n_params, classes=classes, class_of_move=class_of_move)
         self.sim.set_x(np.zeros(self.n_chains))
         self.threads = 1
+        self.reduce_columns = 7
 
     def close(self):
         self.sim.close()
+
+    def set_reduce_columns(self, columns):
+        """HipEngine.set_reduce_columns: the sums over x that reductions form (1 sum e, 2 sum x, 4 sum x^2); the others' records
+        stay empty."""
+        assert 0 <= int(columns) <= 7
+        self.reduce_columns = int(columns)
 
     def upload_state(self, x, beta=None):
         self.sim.set_x(x)
@@ -698,6 +705,9 @@ class OracleEngine:
         """(records, steps counted): what HipEngine.reduce_end_exact returns.  A K = 1 engine without per-chain counters
         carries the pool-wide accepted TOTAL in the ratio record (amc_reduce_end_exact)."""
         rec = self.sim.callback_records()
+        for c in range(3):
+            if not self.reduce_columns & (1 << c):
+                rec[c] = 0.0
         if self.n_moves == 1 and not self.per_chain_counters:
             acc, _ = self.sim.counters()
             rec[4] = xsum_q([float(acc.sum())], 0)
@@ -705,6 +715,7 @@ class OracleEngine:
 
     def reduce_records_value(self, records, steps_counted):
         out = xsum_round(records)
+        out[np.asarray(records).reshape(-1, XS_WORDS)[:, 0] == 0.0] = np.nan           # a sum nobody asked for
         if self.n_moves == 1 and not self.per_chain_counters:
             with np.errstate(invalid="ignore", divide="ignore"):
                 out[4] = out[4] / np.float64(steps_counted)          # 0/0 = NaN before the first step, like the reference

@@ -41,11 +41,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(script_args, world, env):
+def launch(script_args, world, env, expect_ok=True):
     cmd = ["timeout", "-k", "10", "400", sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + script_args
     r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert (r.returncode == 0) == expect_ok, r.stdout[-2000:] + r.stderr[-4000:]
     return r
 
 
@@ -150,3 +150,20 @@ def test_one_rank_cannot_join_everybody_falls_back_together(fake_rccl):
                       if ln.startswith("{")][-1])
     assert two["comm"]["sigma"][1] == one["comm"]["sigma"][1]            # over the host path too: records, merged exactly
     assert two["comm"]["energy"] == one["comm"]["energy"]
+
+
+def test_bench_withholds_its_value_when_rccl_did_not_carry_the_run(fake_rccl):
+    """bench.py --gpus 2 with a rank whose ncclCommInitRank fails: every rank takes the store route together (the run completes,
+    the diagnostics are all there), but the line is no measurement of the N-GPU path -- `value` is null, `value_withheld` says why,
+    and the launch ends non-zero so that a driver cannot mistake it for one."""
+    M = 400_000
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "10", "--spinup-s", "0.05", "--repeats", "2",
+            "--min-gpu-seconds", "0", "--chains-per-gpu", str(M)]
+    r = launch(args, 2, dict(AMC_RCCL_LIBRARY=fake_rccl, AMC_BENCH_DEVICE="0", AMC_BENCH_ALLOW_FORCED_RCCL="1", AMC_FAKE_RCCL_FAIL_RANK="1",
+                             AMC_FAKE_RCCL_TIMEOUT_S="3"), expect_ok=False)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and "RCCL did not carry this run" in d["value_withheld"]
+    assert d["config"]["rccl_ranks"] is None and "store" in d["config"]["callbacks_allreduce_via"]
+    assert d["n_gpus"] == 2 and d["ms_per_step"] > 0 and 0.90 < d["check"]["acceptance"] < 0.97       # the run itself is whole

@@ -246,10 +246,12 @@ def test_config4_eight_shards_of_1e7_on_one_device(gpu, oracle):
     """BASELINE config 4 (particle_1d harmonic, 8 x 1e7 chains sharded over 8 GPUs, energy / acceptance callbacks
     all-reduced every 10 sweeps; the reference maps mc_sweep! over eachindex(chains), src/metropolis.jl:302-309) with the
     eight shards as eight handles on ONE device: chain_offset = r 1e7, n_chains_global = 8e7, the callback sums formed in
-    the sweep launches and added in rank order (what sharding.allreduce_sum does across processes).  Checks: slices of
-    every shard equal the oracle's run of the same GLOBAL chain ids bit for bit; the sharded ensemble equals ONE handle
-    holding all 8e7 chains -- positions bit for bit, accepted totals exactly, callback sums to the reduction tolerance --;
-    and the callbacks themselves sit on the analytic values."""
+    the sweep launches and MERGED as exact integer records (amc_reduce_end_exact + amc_xsum_merge: what
+    sharding.allreduce_xsum does across processes).  Checks: slices of every shard equal the oracle's
+    run of the same GLOBAL chain ids bit for bit; the sharded ensemble equals ONE handle holding all 8e7 chains -- positions
+    bit for bit, accepted totals exactly, and every callback sum `==`: the records word for word, hence the values --; and the
+    callbacks themselves sit on the analytic values.  (The shards' launches leave compact block rows, the 8e7-chain handle's
+    lanes see 122 summands and leave wide ones: both row forms meet here.)"""
     from montecarlo_amd import sharding
     W, M_SHARD, sweeps, cb_every = 8, M_FULL, 30, 10
     M_GLOBAL = W * M_SHARD
@@ -268,24 +270,27 @@ def test_config4_eight_shards_of_1e7_on_one_device(gpu, oracle):
         if t % cb_every == 0:
             for e in shards:
                 e.sweep_reduce_begin(1)                   # sums formed inside the sweep launch, as in bench.py
-            parts = [e.reduce_end() for e in shards]
-            total = parts[0].copy()
-            for p_ in parts[1:]:
-                total = total + p_                        # rank order: sharding.StoreGroup.allreduce_sum
-            rows_sharded.append(total)
+            parts = [e.reduce_end_exact() for e in shards]
+            merged = parts[0][0].copy()
+            for rec, steps in parts[1:]:
+                assert steps == parts[0][1]
+                merged = gpu.xsum_merge(merged, rec)      # integers: any order gives the same words
+            rows_sharded.append((merged, shards[0].reduce_records_value(merged, parts[0][1])))
             big.sweep_reduce_begin(1)
-            rows_big.append(big.reduce_end())
+            rec, steps = big.reduce_end_exact()
+            assert steps == parts[0][1] == t
+            rows_big.append((rec, big.reduce_records_value(rec, steps)))
         else:
             for e in shards:
                 e.sweep(1)
             big.sweep(1)
-    for got, want in zip(rows_sharded, rows_big):
+    for (got_rec, got), (want_rec, want) in zip(rows_sharded, rows_big):
         assert got[3] == want[3] == M_GLOBAL
-        np.testing.assert_allclose(got, want, rtol=1e-11)
-        assert got[4] == pytest.approx(want[4], rel=1e-15)       # accepted totals / steps counted: integers, one rounding
+        assert np.array_equal(got_rec, want_rec), [i for i in range(got_rec.shape[0]) if not np.array_equal(got_rec[i], want_rec[i])]
+        assert np.array_equal(bits(got), bits(want))          # what DESIGN section 3.8 promises: the same bits for 8 shards and for one
     # the callbacks' values 30 sweeps after U(-2,2): <e> on its way down from 4/3 to 1/(2 beta), the acceptance of the
     # outlying chains (0.7 at |x| = 2) still pulls the cumulative ratio below its equilibrium 0.9365
-    assert 0.85 < rows_sharded[-1][4] / M_GLOBAL < 0.94 and 0.25 < rows_sharded[-1][0] / M_GLOBAL < 4.0 / 3.0
+    assert 0.85 < rows_sharded[-1][1][4] / M_GLOBAL < 0.94 and 0.25 < rows_sharded[-1][1][0] / M_GLOBAL < 4.0 / 3.0
     acc_total = sum(int(e.counter_totals()[0][0]) for e in shards)
     assert acc_total == int(big.counter_totals()[0][0])
     for r, e in enumerate(shards):

@@ -270,3 +270,100 @@ def test_two_reductions_in_flight(gpu, oracle):
     with pytest.raises(gpu.AmcError, match="no reduction in flight"):
         eng.reduce_end()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_wave_totals_by_folding_equal_plain_sums():
+    """wave_total_i64 (half-wave / row swaps, then an in-row scan in inline assembly) against numpy's sums modulo 2^64 and
+    against the plain DPP form, on random, extreme and carry-provoking lane values."""
+    from montecarlo_amd import _capi as A
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(-2**62, 2**62, size=(6, 64), dtype=np.int64),
+             rng.integers(-2**31, 2**31, size=(6, 64), dtype=np.int64),
+             np.full((6, 64), 0xFFFFFFFF, dtype=np.int64),                       # every add carries out of the low word
+             np.full((6, 64), -1, dtype=np.int64),
+             (np.arange(6 * 64, dtype=np.int64).reshape(6, 64) + 1) * 0x100000001,
+             np.where(np.arange(64)[None, :] % 2 == 0, np.int64(2**62), np.int64(-2**62)) * np.ones((6, 1), dtype=np.int64)]
+    one_hot = np.zeros((6, 64), dtype=np.int64)
+    for lane in (0, 15, 16, 31, 32, 47, 48, 63):                               # where each lane ends up: a single non-zero lane per value
+        one_hot[:] = 0
+        for i in range(6):
+            one_hot[i, (lane + 7 * i) % 64] = (i + 1) * (1 << 40) + lane
+        cases.append(one_hot.copy())
+    for v in cases:
+        out, plain = A.selftest_wave_totals(v)
+        want = v.astype(np.uint64).sum(axis=1, dtype=np.uint64).astype(np.int64)     # modulo 2^64
+        assert np.array_equal(plain, want)
+        assert np.array_equal(out[:6], want)
+        assert np.array_equal(out[6:8], want[[4, 1]])
+        assert np.array_equal(out[8:11], want[[5, 0, 2]])
+        assert out[11] == want[3]
+        assert out[12] == int((v[0].astype(np.uint64) & np.uint64(0xFFFFFFFF)).max())
+
+
+@pytest.mark.parametrize("cols", [0, 1, 2, 4, 3, 5, 6, 7])
+@pytest.mark.parametrize("potential,sigma,weight", [("harmonic", [0.1], [1.0]), ("double_well", [0.1, 1.0], [0.5, 0.5])])
+def test_only_the_sums_asked_for_are_formed(gpu, oracle, cols, potential, sigma, weight):
+    """amc_set_reduce_columns: callback_energy needs sum e alone (particle_1d.jl:68-70), the moments sum x and sum x^2.  The
+    records of the sums that were asked for are the oracle's, the others stay empty (NaN as values) -- in the sweep launch
+    that forms them, in a fused stretch and in the pass of its own."""
+    M = 30011
+    kw = dict(potential=potential, beta=2.0, sigma=sigma, weight=weight, seed=21, per_chain_counters=True)
+    eng, ref = _pair(gpu, oracle, M, **kw)
+    eng.init_uniform(-2.0, 2.0)
+    ref.init_uniform(-2.0, 2.0)
+    eng.set_reduce_columns(cols)
+
+    def check(rec, steps, what):
+        want = np.asarray(ref.callback_records()).reshape(-1, 12).copy()
+        for c in range(3):
+            if not cols & (1 << c):
+                want[c] = 0.0
+        _records_equal(rec, want, what)
+        out = eng.reduce_records_value(rec, steps)
+        for c in range(3):
+            assert np.isnan(out[c]) == (not cols & (1 << c))
+        assert out[3] == M
+    for n in (1, 5):
+        eng.sweep_reduce_begin(n)
+        ref.make_steps(n)
+        check(*eng.reduce_end_exact(), f"fused {n}")
+    eng.sweep(2)
+    ref.make_steps(2)
+    check(*eng.reduce_exact(), "separate pass")
+    eng.set_reduce_columns(7)
+    _records_equal(eng.reduce_exact()[0], ref.callback_records(), "all again")
+    with pytest.raises(gpu.AmcError):
+        eng.set_reduce_columns(8)
+    eng.close()
+
+
+def test_compact_and_wide_block_rows_carry_the_same_sums(gpu, oracle, monkeypatch):
+    """A launch whose lanes add at most 32 summands per column leaves ONE 64-byte row per block (tops and flags packed, 64-bit
+    totals); beyond that, and with AMC_WIDE_RED_ROWS=1, the wide row.  Same records either way -- plain values, wild ones
+    (tops that differ between the waves of a block, NaN and infinities) and a pool-wide counter."""
+    rng = np.random.default_rng(8)
+    M = 70001
+    wild = rng.standard_normal(M) * np.exp2(rng.integers(-120, 120, M).astype(np.float64))
+    wild[::977] = np.inf
+    wild[5::1999] = np.nan
+    for x0, counters in ((None, True), (wild, True), (None, False)):
+        recs = []
+        for wide in ("0", "1"):
+            monkeypatch.setenv("AMC_WIDE_RED_ROWS", wide)
+            eng = gpu.HipEngine(n_chains=M, device=0, potential="double_well" if counters else "harmonic", beta=2.0,
+                                sigma=[0.1, 1.0] if counters else [0.1], weight=[0.5, 0.5] if counters else [1.0], seed=4,
+                                per_chain_counters=counters)
+            if x0 is None:
+                eng.init_uniform(-2, 2)
+            else:
+                eng.upload_state(x0)
+            eng.sweep_reduce_begin(1)
+            a = eng.reduce_end_exact()
+            b = eng.reduce_exact()
+            recs.append((a, b))
+            eng.close()
+        for (ra, sa), (rb, sb) in zip(recs[0], recs[1]):
+            _records_equal(ra, rb)
+            assert sa == sb
+    monkeypatch.delenv("AMC_WIDE_RED_ROWS")

@@ -82,6 +82,39 @@ def test_fusion_issues_few_launches(oracle, tmp_path):
     assert calls == [99, 1, 99, 1, 99, 1] and sum(calls) == 300
 
 
+def test_run_asks_the_engine_for_the_sums_its_callbacks_read(oracle, tmp_path):
+    """run() collects what the StoreCallbacks' callbacks read of a reduction (`needs`) and the sampler forms those sums only:
+    the reference's own two callbacks need sum e alone; a callback that does not say what it reads keeps everything."""
+    seen = []
+
+    class Watching(oracle.OracleEngine):
+        def set_reduce_columns(self, columns):
+            seen.append(columns)
+            super().set_reduce_columns(columns)
+
+    def user_callback(simulation):
+        return float(ma.callback_moments(simulation)[1])
+
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 1.0),)
+    cases = [((ma.callback_energy, ma.callback_acceptance), 1), ((ma.callback_acceptance,), 0), ((ma.callback_moments,), 6),
+             ((ma.callback_energy, ma.callback_moments), 7), ((ma.callback_energy, user_callback), 7)]
+    for i, (cbs, want) in enumerate(cases):
+        seen.clear()
+        al = (dict(algorithm=ma.Metropolis, pool=pool, seed=3, engine_factory=Watching),
+              dict(algorithm=ma.StoreCallbacks, callbacks=cbs, scheduler=[0, 10]))
+        sim = ma.Simulation(ma.ParticleChains.uniform(6, 2.0), al, 30, path=str(tmp_path / str(i)))
+        ma.run(sim)
+        assert seen == [want, 7]                      # ... and everything again once the run is over
+        rows = sim.algorithms[1].rows
+        assert all(np.all(np.isfinite(np.atleast_1d(v))) for r in rows for t, v in r if t > 0)     # what was asked for is there
+    # without StoreCallbacks nothing is narrowed: a caller of Metropolis.reductions() gets every entry
+    seen.clear()
+    sim = ma.Simulation(ma.ParticleChains.uniform(6, 2.0), (dict(algorithm=ma.Metropolis, pool=pool, engine_factory=Watching),), 3,
+                        path=str(tmp_path / "bare"))
+    ma.run(sim)
+    assert seen == [7, 7]
+
+
 def test_sweepstep_is_mc_steps_per_sweep(oracle, tmp_path):
     """metropolis.jl:205: one make_step! = sweepstep mc_step!s; sweepstep=3 x 100 sweeps == 300 single steps."""
     a, _ = make_sim(oracle, tmp_path / "a", steps=100, burn=10, sweepstep=3)

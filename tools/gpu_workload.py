@@ -17,6 +17,14 @@ PRECOUNT = int(os.environ.get("PRECOUNT", "0"))       # MH steps already counted
 PIPELINED = os.environ.get("PIPELINED", "0") == "1"     # read a callback's sums while the next period's launches are queued
 
 
+COLS = int(os.environ.get("COLS", "1"))       # the sums over x the callbacks need: 1 = sum e (callback_energy; configs 3 - 5), 7 = + the moments
+
+
+def want_columns(e):
+    if hasattr(e, "set_reduce_columns"):          # (A/B against libraries older than round 5: they form all three)
+        e.set_reduce_columns(COLS)
+
+
 def precount(e, m):
     """Start the count beyond the 16-bit mark (PRECOUNT=70000): the regime of a long run, high counter planes in use."""
     if PRECOUNT:
@@ -51,6 +59,7 @@ elif mode == "k2":
     M = 10_000_000
     e = A.HipEngine(n_chains=M, potential="double_well", beta=2.0, sigma=[0.1, 1.0], weight=[0.5, 0.5], seed=1)
     e.init_uniform(-2, 2)
+    want_columns(e)
     precount(e, M)
     spin(e)
     for rep in range(2):
@@ -74,6 +83,7 @@ elif mode in ("pgmc", "est"):
     M = 10_000_000
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.2, 0.1], weight=[0.6, 0.4], seed=42)
     e.init_uniform(-2, 2)
+    want_columns(e)
     precount(e, M)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.5:
