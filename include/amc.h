@@ -333,6 +333,9 @@ int  amc_get_parameters(amc_handle *h, int k, double *p, int n);
  * it long is.  One such read in flight per handle (AMC_ERR_STATE otherwise). */
 int  amc_parameters_begin(amc_handle *h);
 int  amc_parameters_end(amc_handle *h, double *sigma);
+/* ... for a policy with several parameters (amc_create_vector_policy_model): all of them, parameters[k * P + p] of move k;
+ * n = K * P.  (amc_parameters_end returns parameter 0 of every move.) */
+int  amc_parameters_end_all(amc_handle *h, double *parameters, int n);
 
 /* make_step!(simulation, ::PolicyGradientEstimator) (estimator.jl:111-134) for the
  * moves learn_ids[0..n_learn) (0-based), q_batch samples per chain per move, in the

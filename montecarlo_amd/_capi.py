@@ -147,6 +147,7 @@ def load() -> C.CDLL:
         "amc_selftest_philox": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]),
         "amc_set_reduce_columns": (C.c_int, [H, C.c_int]),
+        "amc_parameters_end_all": (C.c_int, [H, dp, C.c_int]),
         "amc_selftest_wave_totals": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     }
     for name, (res, args) in sig.items():
@@ -503,6 +504,11 @@ class HipEngine:
         _check(self._lib.amc_parameters_begin(self._h))
 
     def parameters_end(self) -> np.ndarray:
+        """sigma[K] -- for a policy with several parameters all of them, shape (K, P)."""
+        if self.n_params > 1:
+            a = np.empty((self.n_moves, self.n_params), dtype=np.float64)
+            _check(self._lib.amc_parameters_end_all(self._h, _dptr(a), a.size))
+            return a
         a = np.empty(self.n_moves, dtype=np.float64)
         _check(self._lib.amc_parameters_end(self._h, _dptr(a)))
         return a

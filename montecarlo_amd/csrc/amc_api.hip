@@ -164,7 +164,7 @@ struct amc_handle {
     int hist_bins = 0;
     double hist_lo = 0.0, hist_hi = 0.0;
     hipEvent_t ev_params = nullptr;   // behind the copy queued by amc_parameters_begin
-    double* h_params = nullptr;       // pinned [AMC_MAX_MOVES]: its destination
+    double* h_params = nullptr;       // pinned [AMC_MAX_NP][AMC_MAX_MOVES]: its destination (row p: parameter p of every move)
     bool params_pending = false;
     bool ev1_marked = false;    // amc_timing_mark recorded the end event already
     void* comm = nullptr;
@@ -1109,7 +1109,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     AMC_TRY(hipEventCreate(&h->ev0));
     AMC_TRY(hipEventCreate(&h->ev1));
     AMC_TRY(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
-    AMC_TRY(hipHostMalloc((void**)&h->h_params, AMC_MAX_MOVES * sizeof(double), 0));
+    AMC_TRY(hipHostMalloc((void**)&h->h_params, (size_t)AMC_MAX_NP * AMC_MAX_MOVES * sizeof(double), 0));
 #undef AMC_TRY
     rc = push_params(h, cfg->sigma, cfg->weight);
     if (rc != AMC_OK) return bail(rc);
@@ -2133,20 +2133,33 @@ int amc_parameters_begin(amc_handle* h)
     AMC_HIP(hipSetDevice(h->device));
     AMC_HIP(hipMemcpyAsync(h->h_params, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES, (size_t)h->K * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
+    if (h->n_params > 1)         // parameters 1 .. P - 1: consecutive rows of the table
+        AMC_HIP(hipMemcpyAsync(h->h_params + AMC_MAX_MOVES, h->d_ptab + amc::PT_THETA1 * AMC_MAX_MOVES,
+                               (size_t)(h->n_params - 1) * AMC_MAX_MOVES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipEventRecord(h->ev_params, h->stream));
     h->params_pending = true;
     return AMC_OK;
 }
 
-int amc_parameters_end(amc_handle* h, double* sigma)
+static int parameters_end_impl(amc_handle* h, const char* who, double* out, int per_move)
 {
-    if (!h || !sigma) return fail(AMC_ERR_BAD_ARG, "amc_parameters_end: NULL argument");
-    if (!h->params_pending) return fail(AMC_ERR_STATE, "amc_parameters_end: no read in flight (call amc_parameters_begin)");
+    if (!h || !out) return fail(AMC_ERR_BAD_ARG, "%s: NULL argument", who);
+    if (!h->params_pending) return fail(AMC_ERR_STATE, "%s: no read in flight (call amc_parameters_begin)", who);
     AMC_HIP(hipSetDevice(h->device));
     AMC_HIP(wait_event(h->ev_params));           // waits for that copy only, not for work queued after it
     h->params_pending = false;
-    for (int k = 0; k < h->K; ++k) sigma[k] = h->h_params[k];
+    for (int k = 0; k < h->K; ++k)
+        for (int p = 0; p < per_move; ++p) out[(size_t)k * per_move + p] = h->h_params[(size_t)p * AMC_MAX_MOVES + k];
     return AMC_OK;
+}
+
+int amc_parameters_end(amc_handle* h, double* sigma) { return parameters_end_impl(h, "amc_parameters_end", sigma, 1); }
+
+int amc_parameters_end_all(amc_handle* h, double* parameters, int n)
+{
+    if (h && n != h->K * h->n_params)
+        return fail(AMC_ERR_BAD_ARG, "amc_parameters_end_all: this handle has %d moves of %d parameters", h->K, h->n_params);
+    return parameters_end_impl(h, "amc_parameters_end_all", parameters, h ? h->n_params : 1);
 }
 
 // The estimator's grid over this shard.
@@ -2209,6 +2222,9 @@ static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, P
 // Handles whose estimator takes one launch per learnable move: policies with several parameters (the move's columns fill a row
 // of the kernel's tail) and pools of several policy / action classes (see PgArgs.l_base).
 static bool per_move_launches(const amc_handle* h) { return h->n_params > 1 || h->n_classes > 1; }
+// ... of which a policy with several parameters (one class) has the single-launch forms too when ONE move learns: the launch's
+// tail is generic in P (pg_tail_np), so sweep + estimator + gradients_data += + learning step are one launch as for P = 1
+static bool np_single_launch(const amc_handle* h, int n_learn) { return h->n_params > 1 && h->n_classes == 1 && n_learn == 1; }
 
 // Validates, launches K3 over this shard.  Shared by the host- and device-resident estimator paths.
 // tail: 1 = the totals of (j, grad j, grad logq, g) per learnable move as records in h->d_out (this shard's slot), 2 = instead
@@ -2233,7 +2249,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         return fail(AMC_ERR_STATE, "%s: this handle's script-defined proposal came without d logq / d sigma (dlogq_expr): "
                                    "No withgrad_log_proposal_density! is defined", who);
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
-    if (per_move_launches(h) && (n_learn != 1 || tail != 1 || with_sweep))
+    if (per_move_launches(h) && (n_learn != 1 || ((tail != 1 || with_sweep) && !np_single_launch(h, n_learn))))
         return fail(AMC_ERR_STATE, "%s: a policy with several parameters (a pool of several classes) takes one learnable move per launch", who);
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;
@@ -2431,7 +2447,7 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
                               bool with_sweep = false, bool reduce = false, int* grid_out = nullptr)
 {
     int nl = 0;
-    if (per_move_launches(h)) {
+    if (per_move_launches(h) && !(np_single_launch(h, n_learn) && !h->comm)) {
         // per learnable move: estimator launch (records in d_out), the gather across shards, gradients_data[k] += gd
         if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters (a pool of several classes)");
         if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
@@ -2539,7 +2555,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
-    const bool fused = !per_move_launches(h) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
+    const bool fused = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
     bool fused_reduce = reduce && fused && h->K <= 4;

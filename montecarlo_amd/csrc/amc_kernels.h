@@ -2420,6 +2420,35 @@ AMC_KERNEL_LINKAGE __global__ void pg_update_np_kernel(double* ptab, double* acc
         status[0] = 1;
 }
 
+// The same two steps at the end of the estimator launch of such a policy (one learnable move per launch: pg_estimate_kernel's
+// tail, one thread): gradients_data[lid] += gd from the launch's column totals `vals` (estimator.jl:130) and, with `update`,
+// make_step!(::PolicyGradientUpdate) right behind it -- the operations of pg_accumulate_np_kernel and pg_update_np_kernel in their
+// order, so a fused time step and the three launches it replaces leave the same bits.
+__device__ __forceinline__ void pg_tail_np(const double* vals, int np, int lid, double n_samples, bool update, int kind, double h0, double h1,
+                                           double* ptab, double* acc, int* status)
+{
+    double gd[AMC_GD_STRIDE_MAX];
+    pg_np_unpack(vals, np, gd);
+    double* a = acc + (size_t)lid * AMC_GD_STRIDE_MAX;
+    const int nf = 1 + 2 * np + np * np;
+    if (!update) {
+        for (int i = 0; i < nf; ++i) a[i] += gd[i];
+        a[nf] += n_samples;
+        return;
+    }
+    const double n = a[nf] + n_samples;
+    for (int i = 0; i < nf; ++i) gd[i] = (a[i] + gd[i]) / n;
+    double theta[AMC_MAX_NP];
+    for (int p = 0; p < np; ++p) theta[p] = ptab[(p == 0 ? PT_SIGMA : PT_THETA1 + p - 1) * AMC_MAX_MOVES + lid];
+    bool ok = pg_learning_step_np(kind, h0, h1, np, gd, theta);
+    for (int p = 0; p < np; ++p) ok = ok && theta[p] - theta[p] == 0.0;          // finite
+    for (int i = 0; i <= nf; ++i) a[i] = 0.0;
+    if (ok)
+        for (int p = 0; p < np; ++p) ptab[(p == 0 ? PT_SIGMA : PT_THETA1 + p - 1) * AMC_MAX_MOVES + lid] = theta[p];
+    else
+        status[0] = 1;
+}
+
 // Sum, over rows[n_rows][NV][ROW words] that OTHER blocks wrote (agent-scope loads), of column c: integers, so the order is
 // immaterial; thread c of the calling block owns column c.
 template <bool Q>
@@ -2894,10 +2923,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (loading what the update reads BEFORE the last ticket, in every block that might draw it, was measured: slower,
         // 62.4 against 61.4 us per fused time step -- the loads sit on the path from the group sums to the ticket)
+#if AMC_NP > 1
+        // a policy with several parameters: the launch's one learnable move (the host sees to it), its 1 + 2P + P(P+1)/2 totals
+        if (a.tail_mode >= 2)
+            pg_tail_np(s_tot, AMC_NP, tl->learn_ids[0], tl->n_samples, a.tail_mode >= 3, tl->opt.kind[0], tl->opt.h0[0], tl->opt.h1[0],
+                       tl->ptab_rw, tl->gd_acc, tl->status);
+#else
         if (a.tail_mode >= 3)
             pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status, s_tot, tl->n_samples);
         else if (a.tail_mode >= 2)
             for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, tl->learn_ids[l], tl->n_samples, tl->gd_acc);
+#endif
     }
 }
 

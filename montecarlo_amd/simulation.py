@@ -497,8 +497,7 @@ class StoreParameters(AriannaAlgorithm):
     def make_step(self, simulation: Simulation) -> None:
         met = self.metropolis
         if getattr(met, "device_params_dirty", False):
-            # (the queued read carries parameter 0 of every move: a policy with several takes the synchronous read)
-            if self.defer and hasattr(met.engine, "parameters_begin") and getattr(met, "n_params", 1) == 1:
+            if self.defer and hasattr(met.engine, "parameters_begin"):
                 self.flush()                        # the previous row first (its read was queued a period ago)
                 # sigma as of the steps queued so far; one read in flight per engine, shared by every StoreParameters of this
                 # Metropolis that is due at the same t (Metropolis.parameters_async)

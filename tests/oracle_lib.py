@@ -793,7 +793,8 @@ class OracleEngine:
 
     def parameters_begin(self):           # amc_parameters_begin: sigma as of now, fetched later
         assert getattr(self, "_params_pending", None) is None, "a parameter read was begun while another was in flight"
-        self._params_pending = np.array([self.sim.get_sigma(k) for k in range(self.n_moves)])
+        self._params_pending = (np.array([self.sim.get_theta(k) for k in range(self.n_moves)]) if self.n_params > 1 else
+                                np.array([self.sim.get_sigma(k) for k in range(self.n_moves)]))
 
     def parameters_end(self):
         out, self._params_pending = self._params_pending, None

@@ -323,3 +323,72 @@ def test_free_running_pgmc_with_three_and_four_parameters(gpu, oracle, case, opt
     assert acc.shape == (2, 2 + 2 * P + P * P) and np.all(acc == 0.0)
     eng.close()
     oracle.install_vector_policy(1, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", OPTS, ids=[o[0] for o in OPTS])
+@pytest.mark.parametrize("shape", ["K1", "K2"])
+def test_one_learnable_move_takes_the_single_launch_time_step(gpu, oracle, opt, shape):
+    """ONE move of a several-parameter policy learns: sweep + estimator + gradients_data += + learning step are ONE launch per
+    time step (round 5; the tail is generic in P), where two learnable moves take a launch each plus two small ones.  Same
+    bits as the free-running oracle after every stretch -- parameter vectors, positions, counters, the callback sums that ride
+    in the last launch, and the accumulators when no update follows."""
+    name, kind, h0, h1 = opt
+    if shape == "K1":
+        eng, ref = _pair(gpu, oracle, 20011, DRIFT, 2, [[0.05, 0.5]], [1.0])
+        ids = [0]
+    else:
+        eng, ref = _pair(gpu, oracle, 20011, DRIFT, 2, [[0.1, 0.3], [0.0, 0.8]], [0.5, 0.5])
+        ids = [1]
+    for stretch in (1, 3, 9):
+        eng.pgmc_steps(stretch, ids, 2, [kind], [h0], [h1])
+        ref.pgmc_steps(stretch, ids, 2, [kind], [h0], [h1])
+        for k in range(eng.n_moves):
+            assert np.array_equal(bits(eng.get_parameters(k)), bits(ref.get_parameters(k))), (name, stretch, k)
+    assert np.array_equal(bits(eng.download_state()[0]), bits(ref.download_state()[0]))
+    a, t = eng.download_counters()
+    ao, to = ref.download_counters()
+    assert np.array_equal(a, ao) and np.array_equal(t, to)
+    assert np.all(eng.pg_get_accumulated(ids) == 0.0)
+    # the callback sums of the state the last step leaves, formed in its launch
+    eng.pgmc_steps(2, ids, 1, [kind], [h0], [h1], reduce_begin=True)
+    ref.pgmc_steps(2, ids, 1, [kind], [h0], [h1], reduce_begin=True)
+    ra, sa = eng.reduce_end_exact()
+    rb, sb = ref.reduce_end_exact()
+    assert np.array_equal(ra, rb) and sa == sb
+    # estimator steps without an update: the accumulators
+    eng.pgmc_steps(3, ids, 2)
+    ref.pgmc_steps(3, ids, 2)
+    assert np.array_equal(bits(eng.pg_get_accumulated(ids)), bits(ref.pg_get_accumulated(ids)))
+    assert np.array_equal(bits(eng.get_parameters(ids[0])), bits(ref.get_parameters(ids[0])))
+    eng.close()
+    oracle.install_vector_policy(1, None)
+
+
+@pytest.mark.gpu
+def test_single_launch_time_step_of_a_three_parameter_policy(gpu, oracle):
+    eng, ref = _pair(gpu, oracle, 9001, LEAN, 3, [[0.0, 0.6, -0.1]], [1.0])
+    for stretch in (1, 7):
+        eng.pgmc_steps(stretch, [0], 1, [4], [5e-3], [1e-6])          # NPG: the 3 x 3 metric inverted in the launch's tail
+        ref.pgmc_steps(stretch, [0], 1, [4], [5e-3], [1e-6])
+        assert np.array_equal(bits(eng.get_parameters(0)), bits(ref.get_parameters(0)))
+    assert np.array_equal(bits(eng.download_state()[0]), bits(ref.download_state()[0]))
+    eng.close()
+    oracle.install_vector_policy(1, None)
+
+
+@pytest.mark.gpu
+def test_queued_parameter_read_returns_every_parameter(gpu):
+    """amc_parameters_begin / amc_parameters_end_all: the read queued in stream order carries all P parameters of every move."""
+    eng = gpu.HipEngine(n_chains=1000, device=0, potential="harmonic", beta=BETA, sigma=[[0.1, 0.3], [0.0, 0.8]], weight=[0.5, 0.5],
+                        seed=2, proposal=DRIFT, n_params=2)
+    eng.init_uniform(-1, 1)
+    eng.parameters_begin()
+    eng.pgmc_steps(5, [1], 1, [1], [1e-2], [0.0])            # learning steps queued BEHIND the read
+    before = eng.parameters_end()
+    assert before.shape == (2, 2) and np.array_equal(before, [[0.1, 0.3], [0.0, 0.8]])
+    eng.parameters_begin()
+    after = eng.parameters_end()
+    assert np.array_equal(after[0], [0.1, 0.3]) and not np.array_equal(after[1], [0.0, 0.8])
+    assert np.array_equal(after[1], eng.get_parameters(1))
+    eng.close()

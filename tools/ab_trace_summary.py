@@ -4,13 +4,13 @@ import collections, csv, glob, os, re, sys
 d = sys.argv[1]
 tab = collections.defaultdict(lambda: collections.defaultdict(list))      # (workload, kernel) -> variant -> [avg us per round]
 for f in sorted(glob.glob(os.path.join(d, "*_kernel_stats.csv"))):
-    m = re.match(r"(.+)_(k2|pgmc|est|ladder_\d+|vec|mixed)_(\d+)_kernel_stats\.csv", os.path.basename(f))
+    m = re.match(r"(.+)_(k2|pgmc|est|ladder_\d+|vec1|vec|mixed)_(\d+)_kernel_stats\.csv", os.path.basename(f))
     if not m:
         continue
     variant, wl = m.group(1), m.group(2)
     for r in csv.DictReader(open(f)):
         name = r["Name"]
-        if not re.search(r"sweep_kernel|pg_estimate|fold_log|reduce_kernel|pg_accumulate|pg_update", name):
+        if not re.search(r"sweep_kernel|pg_estimate|fold_log|reduce_kernel|pg_accumulate|pg_update|pg_tail", name):
             continue
         short = re.sub(r"^void amc::", "", name)
         short = re.sub(r"\(.*$", "", short)

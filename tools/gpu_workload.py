@@ -110,4 +110,38 @@ elif mode in ("pgmc", "est"):
                 e.pg_accumulate([1], 1)
         us = e.timing_end() * 1e3 / (n // 10 * 10 if mode == "pgmc" else n)
     print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}{' (callback read one period later)' if PIPELINED and mode == 'pgmc' else ''}; sigma = {e.get_parameters(1)[0]:.4f}")
+elif mode in ("vec", "mixed", "vec1"):
+    # the PGMC time step of a policy with SEVERAL parameters (vec: the drift + width proposal delta = theta0 + theta1 z, one
+    # learnable move, VPG), of its one-parameter twin written as a script (vec1: what the several-parameter forms are compared
+    # with), and of a pool that mixes two policy classes (mixed: Gaussian + Langevin, one learnable move each)
+    M = 10_000_000
+    DRIFT = ("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
+             ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"])
+    GAUSS = ("sigma*z", "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0",
+             "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma")
+    MALA = ("-2.0*sigma*sigma*x + sigma*z",
+            "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)",
+            "((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(sigma*sigma*sigma) - 4.0*x*(delta + 2.0*sigma*sigma*x)/sigma - 1.0/sigma")
+    if mode == "vec":
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5]], weight=[1.0], seed=42, proposal=DRIFT, n_params=2)
+        learn, kinds, h0 = [0], [1], [1e-3]
+    elif mode == "vec1":
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.5], weight=[1.0], seed=42, proposal=GAUSS)
+        learn, kinds, h0 = [0], [1], [1e-3]
+    else:
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.3, 0.4], weight=[0.5, 0.5], seed=42,
+                        classes=[GAUSS, MALA], class_of_move=[0, 1])
+        learn, kinds, h0 = [0, 1], [1, 1], [1e-3, 1e-3]
+    e.init_uniform(-2, 2)
+    want_columns(e)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        e.pgmc_steps(10, learn, 1, kinds, h0, [0.0] * len(learn))
+        e.sync()
+    n = min(n, 400)
+    for rep in range(2):
+        e.timing_begin()
+        e.pgmc_steps(n, learn, 1, kinds, h0, [0.0] * len(learn))
+        us = e.timing_end() * 1e3 / n
+    print(f"{mode}: {us:.2f} us per PGMC time step (sweep + estimator + update), parameters now {[list(e.get_parameters(k)) for k in range(e.n_moves)]}")
 e.close()
