@@ -237,9 +237,11 @@ int  amc_init_uniform(amc_handle *h, double lo, double hi);
 /* finalise(): chains[c].x / chains[c].e back to the host (either may be NULL). */
 int  amc_download_state(amc_handle *h, double *x, double *e);
 /* pools[c][k].accepted_calls / total_calls, move-major [k*n_chains + c].  Int (Int64) in the reference
- * (src/metropolis.jl:145-146); the device keeps them as u32 per chain, so a handle with per-chain counters counts at most
- * 2^32 - 1 MH steps: the call that would go beyond returns AMC_ERR_STATE before launching anything (download the
- * counters, amc_upload_counters zeros, continue).  The pool-wide count of a K = 1 handle without them is 64-bit.
+ * (src/metropolis.jl:145-146).  The device counts in 32-bit arrays and CARRIES: before the launch that would count step 2^32
+ * every counter is added into a 64-bit base of its own and the arrays restart at zero (once per 2^32 counted steps; what the
+ * calls below return is base + array), so a run counts on -- up to 2^52 steps, the range in which callback_acceptance's
+ * Int / Int is exact.  After the first carry the acceptance ratios are formed by a pass over arrays and bases instead of
+ * inside the fold of the step log.  The pool-wide count of a K = 1 handle without per-chain counters is 64-bit.
  * (Storage detail, invisible here: with K <= 4 a counter is two u16 halves in separate arrays, and the high halves take
  * part in the folds only from the call that would count step 65 536 on; environment AMC_WIDE_COUNTERS=1 keeps plain u32.) */
 int  amc_download_counters(amc_handle *h, int64_t *accepted, int64_t *total);

@@ -134,6 +134,12 @@ struct amc_handle {
     uint16_t* d_tot_hi = nullptr;
     bool narrow = false;
     bool use_high = false;
+    // Counts beyond 32 bits (counter_rebase): what the arrays above have been carried into, nullptr until the first carry --
+    // [K][M_pad] / [K - 1][M_pad] 64-bit integers --, the steps counted with them, and their pool totals (host side)
+    unsigned long long* d_acc_base = nullptr;
+    unsigned long long* d_tot_base = nullptr;
+    uint64_t t_base = 0;
+    unsigned long long base_acc_total[AMC_MAX_MOVES] = {0}, base_tot_total[AMC_MAX_MOVES] = {0};
     uint8_t* d_log = nullptr;   // [log_depth][M_pad / 2 or M_pad] step log: (move << 1) | accepted per chain and MH step (log_form)
     int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
     int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
@@ -1314,6 +1320,8 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_tot16);
     (void)hipFree(h->d_acc_hi);
     (void)hipFree(h->d_tot_hi);
+    (void)hipFree(h->d_acc_base);
+    (void)hipFree(h->d_tot_base);
     (void)hipFree(h->d_log);
     (void)hipFree(h->d_ptab);
     (void)hipFree(h->d_pick);
@@ -1481,21 +1489,32 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
         }
         return AMC_OK;
     };
+    // what the arrays have been carried into (counter_rebase): 64-bit bases, added in
+    std::vector<unsigned long long> bbuf(h->d_acc_base ? (size_t)h->M : 0);
+    auto add_base = [&](const unsigned long long* base, int k, int64_t* out) -> int {
+        if (!base) return AMC_OK;
+        AMC_HIP(hipMemcpyAsync(bbuf.data(), base + (size_t)k * h->M_pad, (size_t)h->M * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        AMC_HIP(hipStreamSynchronize(h->stream));
+        for (int64_t c = 0; c < h->M; ++c) out[c] += (int64_t)bbuf[(size_t)c];
+        return AMC_OK;
+    };
     for (int k = 0; k < h->K; ++k) {
         if (accepted) {
-            const int rc = fetch_row(h->d_acc, h->d_acc16, h->d_acc_hi, k, accepted + (int64_t)k * h->M);
+            int rc = fetch_row(h->d_acc, h->d_acc16, h->d_acc_hi, k, accepted + (int64_t)k * h->M);
+            if (rc == AMC_OK) rc = add_base(h->d_acc_base, k, accepted + (int64_t)k * h->M);
             if (rc != AMC_OK) return rc;
         }
         if (total) {
             if (k + 1 < h->K) {
-                const int rc = fetch_row(h->d_tot, h->d_tot16, h->d_tot_hi, k, total + (int64_t)k * h->M);
+                int rc = fetch_row(h->d_tot, h->d_tot16, h->d_tot_hi, k, total + (int64_t)k * h->M);
+                if (rc == AMC_OK) rc = add_base(h->d_tot_base, k, total + (int64_t)k * h->M);
                 if (rc != AMC_OK) return rc;
             } else {
-                // the last move: every chain has taken t_counted steps, its total_calls is what the other moves left
+                // the last move: every chain has taken the same number of steps, its total_calls is what the other moves left
                 for (int64_t c = 0; c < h->M; ++c) {
                     int64_t others = 0;
                     for (int j = 0; j + 1 < h->K; ++j) others += total[(int64_t)j * h->M + c];
-                    total[(int64_t)k * h->M + c] = (int64_t)h->t_counted - others;
+                    total[(int64_t)k * h->M + c] = (int64_t)(h->t_base + h->t_counted) - others;
                 }
             }
         }
@@ -1503,11 +1522,9 @@ int amc_download_counters(amc_handle* h, int64_t* accepted, int64_t* total)
     return AMC_OK;
 }
 
-int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
+// pool totals of the counter ARRAYS (K > 1; without their 64-bit bases): host[k] accepted, host[AMC_MAX_MOVES + k] total of move k < K - 1
+static int array_totals(amc_handle* h, unsigned long long (&host)[2 * AMC_MAX_MOVES])
 {
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_counter_totals: NULL handle");
-    AMC_HIP(hipSetDevice(h->device));
-    unsigned long long host[2 * AMC_MAX_MOVES];
     { const int rc = fold_log(h); if (rc != AMC_OK) return rc; }
     if (h->K > 1) {
         AMC_HIP(hipMemsetAsync(h->d_totals, 0, 2 * AMC_MAX_MOVES * sizeof(unsigned long long), h->stream));
@@ -1523,37 +1540,98 @@ int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
     }
     AMC_HIP(hipMemcpyAsync(host, h->d_totals, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
+    return AMC_OK;
+}
+
+int amc_counter_totals(amc_handle* h, int64_t* accepted, int64_t* total)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_counter_totals: NULL handle");
+    AMC_HIP(hipSetDevice(h->device));
+    unsigned long long host[2 * AMC_MAX_MOVES];
+    { const int rc = array_totals(h, host); if (rc != AMC_OK) return rc; }
     if (h->K == 1) {
         unsigned long long acc = 0;
-        const int rc = sum_acc_slots(h, &acc);
+        const int rc = sum_acc_slots(h, &acc);         // (the pool-wide slots are 64-bit and never carried)
         if (rc != AMC_OK) return rc;
         host[0] = acc;
     }
     unsigned long long others = 0;
     for (int k = 0; k < h->K; ++k) {
-        if (accepted) accepted[k] = (int64_t)host[k];
+        if (accepted) accepted[k] = (int64_t)(host[k] + (h->K > 1 ? h->base_acc_total[k] : 0ull));
         // the last move's total: all counted steps of all chains minus the other moves' (its per-chain array does not exist)
-        const unsigned long long tk = (k + 1 < h->K) ? host[AMC_MAX_MOVES + k] : h->t_counted * (uint64_t)h->M - others;
+        const unsigned long long tk = (k + 1 < h->K) ? host[AMC_MAX_MOVES + k] + h->base_tot_total[k]
+                                                     : (h->t_base + h->t_counted) * (uint64_t)h->M - others;
         others += tk;
         if (total) total[k] = (int64_t)tk;
     }
     return AMC_OK;
 }
 
-// Move.accepted_calls / total_calls are Int (Int64) in the reference (src/metropolis.jl:145-146); the per-chain copies on
-// the device are u32.  No chain's counter can exceed the number of counted steps, so the call that would take that number
-// past 2^32 - 1 is refused as a whole (nothing is launched) instead of letting a counter wrap silently.  The pool-wide
-// counter of a K = 1 handle without per-chain counters is 64-bit and has no such limit.
+// Carries the 32-bit counter arrays into their 64-bit bases and restarts them at zero (see counter_rebase_kernel): pending log
+// rows are folded first, the pool totals of what is carried are kept on the host (amc_counter_totals), and a handle with u16
+// planes goes on with u32 arrays -- the same bytes per counter, and the pass that forms the acceptance ratios from arrays plus
+// bases (reduce_kernel) reads those.
+static int counter_rebase(amc_handle* h)
+{
+    unsigned long long host[2 * AMC_MAX_MOVES];
+    { const int rc = array_totals(h, host); if (rc != AMC_OK) return rc; }         // folds the log
+    const size_t n = (size_t)h->K * (size_t)h->M_pad, nt = (size_t)(h->K - 1) * (size_t)h->M_pad;
+    if (!h->d_acc_base) {
+        AMC_HIP(hipMalloc(&h->d_acc_base, n * sizeof(unsigned long long)));
+        AMC_HIP(hipMemsetAsync(h->d_acc_base, 0, n * sizeof(unsigned long long), h->stream));
+        if (nt) {
+            AMC_HIP(hipMalloc(&h->d_tot_base, nt * sizeof(unsigned long long)));
+            AMC_HIP(hipMemsetAsync(h->d_tot_base, 0, nt * sizeof(unsigned long long), h->stream));
+        }
+    }
+    const int grid = grid_for(h, (int64_t)n);
+    if (h->narrow) {
+        hipLaunchKernelGGL(amc::counter_rebase_kernel<uint16_t>, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_acc16,
+                           h->use_high ? h->d_acc_hi : nullptr, (int64_t)n, h->d_acc_base);
+        if (nt) hipLaunchKernelGGL(amc::counter_rebase_kernel<uint16_t>, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_tot16,
+                                   h->use_high ? h->d_tot_hi : nullptr, (int64_t)nt, h->d_tot_base);
+    } else {
+        hipLaunchKernelGGL(amc::counter_rebase_kernel<uint32_t>, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_acc, (uint16_t*)nullptr,
+                           (int64_t)n, h->d_acc_base);
+        if (nt) hipLaunchKernelGGL(amc::counter_rebase_kernel<uint32_t>, dim3(grid), dim3(AMC_BLOCK), 0, h->stream, h->d_tot,
+                                   (uint16_t*)nullptr, (int64_t)nt, h->d_tot_base);
+    }
+    AMC_HIP(hipGetLastError());
+    if (h->narrow) {                 // u32 arrays from here on
+        AMC_HIP(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_acc16); (void)hipFree(h->d_tot16); (void)hipFree(h->d_acc_hi); (void)hipFree(h->d_tot_hi);
+        h->d_acc16 = h->d_tot16 = h->d_acc_hi = h->d_tot_hi = nullptr;
+        const hipError_t e = alloc_counters(h, false);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "counter_rebase: %s", hipGetErrorString(e));
+    }
+    if (h->K > 1)
+        for (int k = 0; k < h->K; ++k) {
+            h->base_acc_total[k] += host[k];
+            if (k + 1 < h->K) h->base_tot_total[k] += host[AMC_MAX_MOVES + k];
+        }
+    h->t_base += h->t_counted;
+    h->t_counted = 0;
+    h->use_high = false;
+    return AMC_OK;
+}
+
+// Move.accepted_calls / total_calls are Int (Int64) in the reference (src/metropolis.jl:145-146); the per-chain arrays on
+// the device count in 32 bits.  No chain's counter can exceed the number of counted steps, so before the launch that would take
+// that number past 2^32 - 1 the arrays are carried into 64-bit bases (counter_rebase) and the count goes on -- round 5; until
+// round 4 that call was refused.  `steps`: what the next LAUNCH counts (at most 2^20).  The pool-wide counter of a K = 1 handle
+// without per-chain counters is 64-bit anyway.
 // Handles with u16 planes bring the high planes into play here, before the call that would count past 65 535 steps (rows
 // still waiting in the log are then folded by the carrying form as well: it starts from high halves that are zero).
 static int counter_room(amc_handle* h, const char* who, uint64_t steps)
 {
+    (void)who;
     if (!h->counters) return AMC_OK;
+    if (h->t_counted + steps > 0xFFFFFFFFull) {
+        const int rc = counter_rebase(h);
+        if (rc != AMC_OK) return rc;
+    }
     if (h->narrow && h->t_counted + steps > 0xFFFFull) h->use_high = true;
-    if (h->t_counted + steps <= 0xFFFFFFFFull) return AMC_OK;
-    return fail(AMC_ERR_STATE, "%s: the per-chain counters are 32-bit and hold %llu counted steps, %llu more would wrap them: download "
-                               "the counters and restart the count (amc_upload_counters with zeros) first",
-                who, (unsigned long long)h->t_counted, (unsigned long long)steps);
+    return AMC_OK;
 }
 
 // The form of the rows a launch of `grid` blocks leaves its callback sums in (amc::red_finish): the compact 64-byte row while a
@@ -1603,7 +1681,6 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
 {
     AMC_HIP(hipSetDevice(h->device));
     int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
-    { const int rc = counter_room(h, "amc_sweep", (uint64_t)remaining); if (rc != AMC_OK) return rc; }
     // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
     // (a call whose last launch also forms the callback sums: that form holds 5 blocks per CU -- 89 VGPRs -- and runs one round of
     // them, 49 -> 45 us per callback at K = 2 and 1e7 chains; plain sweeps are indifferent between 5 and 8)
@@ -1618,6 +1695,7 @@ static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* gr
             if (rc != AMC_OK) return rc;
             if (chunk > room) chunk = room;
         }
+        { const int rc = counter_room(h, "amc_sweep", (uint64_t)chunk); if (rc != AMC_OK) return rc; }      // (may carry the counters: arrays restart at zero)
         amc::SweepArgs a = make_sweep_args(h, chunk);
         a.red_stride = red_row_stride(h, grid);
         const bool last = remaining == chunk;
@@ -1656,13 +1734,14 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
     if (h->K > 1 && !total) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: total is required when K > 1");
     // Every chain takes the same number of MH steps (mc_sweep!, metropolis.jl:205-210), so sum_k total_calls_ck is ONE number
     // for all chains: the count of steps taken.  The device keeps that number and K - 1 of the K total arrays.
-    uint64_t steps = h->t_counted;
+    const int64_t LIMIT = (int64_t)1 << 52;          // counts are divided as Float64s (callback_acceptance): exact below 2^53
+    uint64_t steps = h->t_base + h->t_counted;
     if (total) {
         for (int64_t c = 0; c < h->M; ++c) {
             int64_t sum = 0;
             for (int k = 0; k < h->K; ++k) {
                 const int64_t v = total[(int64_t)k * h->M + c];
-                if (v < 0 || v > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
+                if (v < 0 || v > LIMIT) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of range [0, 2^52]");
                 sum += v;
             }
             if (c == 0) steps = (uint64_t)sum;
@@ -1670,14 +1749,43 @@ int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* t
                 return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: the total_calls of a chain must add up to the same step count on "
                                              "every chain (chain 0: %llu, chain %lld: %lld)", (unsigned long long)steps, (long long)c, (long long)sum);
         }
-        if (steps > 0xFFFFFFFFull) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: step count out of u32 range");
+        if (steps > (uint64_t)LIMIT) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: step count out of range [0, 2^52]");
     }
     int64_t acc_max = 0;
     for (int64_t i = 0; i < (int64_t)h->K * h->M; ++i) {
-        if (accepted[i] < 0 || accepted[i] > 0xFFFFFFFFll) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of u32 range");
+        if (accepted[i] < 0 || accepted[i] > LIMIT) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: counter out of range [0, 2^52]");
         acc_max = std::max(acc_max, accepted[i]);
     }
     AMC_HIP(hipSetDevice(h->device));
+    if (steps > 0xFFFFFFFFull || (uint64_t)acc_max > 0xFFFFFFFFull || h->d_acc_base) {
+        // counts beyond 32 bits (or a handle that has carried before): everything goes into the 64-bit bases, the arrays restart
+        // at zero (counter_rebase does the allocating and the switch to u32 arrays; what it carries is overwritten next)
+        h->log_fill = 0;
+        { const int rc = counter_rebase(h); if (rc != AMC_OK) return rc; }
+        std::vector<unsigned long long> b((size_t)h->M);
+        for (int k = 0; k < h->K; ++k) {
+            h->base_acc_total[k] = h->base_tot_total[k] = 0ull;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int64_t* src = pass == 0 ? accepted : total;
+                if (!src || (pass == 1 && k + 1 == h->K)) continue;
+                unsigned long long sum = 0;
+                for (int64_t c = 0; c < h->M; ++c) { b[(size_t)c] = (unsigned long long)src[(int64_t)k * h->M + c]; sum += b[(size_t)c]; }
+                (pass == 0 ? h->base_acc_total[k] : h->base_tot_total[k]) = sum;
+                unsigned long long* dst = (pass == 0 ? h->d_acc_base : h->d_tot_base) + (size_t)k * h->M_pad;
+                AMC_HIP(hipMemcpyAsync(dst, b.data(), (size_t)h->M * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+                AMC_HIP(hipStreamSynchronize(h->stream));
+            }
+        }
+        if (h->K == 1) {
+            const unsigned long long acc_sum = h->base_acc_total[0];
+            AMC_HIP(hipMemsetAsync(h->d_acc_slots, 0, (size_t)h->n_slots * sizeof(unsigned long long), h->stream));
+            AMC_HIP(hipMemcpyAsync(h->d_acc_slots, &acc_sum, sizeof(acc_sum), hipMemcpyHostToDevice, h->stream));
+            AMC_HIP(hipStreamSynchronize(h->stream));
+        }
+        h->t_base = steps;
+        h->t_counted = 0;
+        return AMC_OK;
+    }
     // (the handle's own bookkeeping -- log_fill, use_high, t_counted -- changes only once every plane has been copied: a copy
     // that fails leaves the handle counting as before)
     std::vector<uint32_t> buf((size_t)h->M);
@@ -1867,7 +1975,7 @@ static int red_commit(amc_handle* h, RedTicket* t, int rows)
     t->rows = rows;
     t->row_stride = red_row_stride(h, rows);       // (rows = the grid of the launch that wrote them)
     t->cols = h->red_cols;
-    t->t_counted = h->t_counted;
+    t->t_counted = h->t_base + h->t_counted;
     h->red_count += 1;
     return AMC_OK;
 }
@@ -1881,7 +1989,7 @@ int amc_reduce_begin(amc_handle* h)
     int ratio_mode = (h->K > 1) ? 2 : (h->counters ? 1 : 0);
     t->ratio_rows = 0;
     t->ratio_acc = false;
-    if (ratio_mode != 0 && h->K <= 4) {
+    if (ratio_mode != 0 && h->K <= 4 && !h->d_acc_base) {
         // per-chain counters, few moves: the fold of the step log forms the acceptance-ratio sums while the counters
         // are in its registers (rows in h_ratio); the pass below then reads x only
         const int rc = fold_log(h, true, &t->ratio_rows, t->h_ratio);
@@ -1907,17 +2015,19 @@ int amc_reduce_begin(amc_handle* h)
         int64_t m = h->M, m_pad = h->M_pad;
         int k = h->K, mode = ratio_mode, st = stride, n_slots = h->n_slots;
         uint64_t t_counted = h->t_counted;
-        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots, &racc, &cols};
+        const unsigned long long *acc_base = h->d_acc_base, *tot_base = h->d_tot_base;
+        uint64_t t_base = h->t_base;
+        void* params[] = {&d_x, &d_acc, &d_tot, &m, &m_pad, &k, &mode, &t_counted, &rows, &st, &slots, &n_slots, &racc, &cols, &acc_base, &tot_base, &t_base};
         const int rc = rtc_launch(h, "amc::reduce_kernel<" + std::to_string(h->potential) + ">", h->red_blocks, params);
         if (rc != AMC_OK) return rc;
     } else if (h->potential == AMC_POTENTIAL_DOUBLE_WELL)
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_DOUBLE_WELL>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots, racc, cols);
+                           h->n_slots, racc, cols, h->d_acc_base, h->d_tot_base, h->t_base);
     else
         hipLaunchKernelGGL(amc::reduce_kernel<amc::POT_HARMONIC>, dim3(h->red_blocks), dim3(AMC_BLOCK), 0, h->stream,
                            h->d_x, h->d_acc, h->d_tot, h->M, h->M_pad, h->K, ratio_mode, h->t_counted, rows, stride, slots,
-                           h->n_slots, racc, cols);
+                           h->n_slots, racc, cols, h->d_acc_base, h->d_tot_base, h->t_base);
     AMC_HIP(hipGetLastError());
     if (t->ratio_acc)
         AMC_HIP(hipMemcpyAsync(t->h_ratio_acc, t->d_ratio_acc, (size_t)h->K * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -1955,7 +2065,9 @@ int amc_sweep_reduce_begin(amc_handle* h, int64_t n_sweeps)
     if (n_sweeps < 1) return fail(AMC_ERR_BAD_ARG, "amc_sweep_reduce_begin: n_sweeps must be >= 1");
     if (!red_next(h))
         return fail(AMC_ERR_STATE, "amc_sweep_reduce_begin: %d reductions are already in flight (call amc_reduce_end)", RED_TICKETS);
-    if (h->K > 4 || !reduce_fits_in_grid(h, reduce_sweep_grid(h))) {      // the ratio sums need the counters of every move: sweep, then the reduction pass
+    // the ratio sums need the counters of every move (K > 4), or arrays plus their 64-bit bases (a handle that has counted past
+    // 2^32 steps): sweep, then the reduction pass
+    if (h->K > 4 || h->d_acc_base || !reduce_fits_in_grid(h, reduce_sweep_grid(h))) {
         const int rc = sweep_impl(h, n_sweeps, false, nullptr);
         return rc != AMC_OK ? rc : amc_reduce_begin(h);
     }
@@ -2549,7 +2661,6 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
         const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt);
         if (rc != AMC_OK) return rc;
     }
-    { const int rc = counter_room(h, who, (uint64_t)n_steps * (uint64_t)h->sweepstep); if (rc != AMC_OK) return rc; }
     // the three make_step!s of one time step (src/simulation.jl:185-190), n_steps times, from one host call: two
     // launches per step on a single shard (sweep; estimator whose last block accumulates and takes the learning step)
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
@@ -2558,7 +2669,7 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     const bool fused = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                        log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
-    bool fused_reduce = reduce && fused && h->K <= 4;
+    bool fused_reduce = reduce && fused && h->K <= 4 && !h->d_acc_base;
     if (fused_reduce) {            // ... and launches that need no flush on the way
         PgPlan plan;
         const int rcp = pg_plan(h, nl_capacity(n_learn), h->K > 1 ? 2 : (h->d_log ? 1 : 3), true, q_batch, &plan);

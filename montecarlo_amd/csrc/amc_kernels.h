@@ -838,6 +838,16 @@ __device__ __forceinline__ void ratio_add(unsigned long long& acc, bool& nan, ui
     const double t = xs::xs_c(xs::XS_E_RATIO) + __longlong_as_double(__double_as_longlong(q) | 1ll);
     acc += (unsigned long long)__double_as_longlong(t) - xs::xs_c_bits(xs::XS_E_RATIO);
 }
+// ... for counts beyond 32 bits (a handle whose counters have been carried into their 64-bit bases, counter_rebase_kernel): Int / Int
+// of the reference, both below 2^53
+__device__ __forceinline__ void ratio_add(unsigned long long& acc, bool& nan, unsigned long long accepted, unsigned long long total)
+{
+    const unsigned long long den = total > 1ull ? total : 1ull;
+    nan = nan | (total == 0ull);
+    const double q = (double)accepted / (double)den;
+    const double t = xs::xs_c(xs::XS_E_RATIO) + __longlong_as_double(__double_as_longlong(q) | 1ll);
+    acc += (unsigned long long)__double_as_longlong(t) - xs::xs_c_bits(xs::XS_E_RATIO);
+}
 __device__ __forceinline__ xs::PartQ q_slot_value(const QSlot& s)
 {
     // k = hi 2^32 + lo
@@ -1895,8 +1905,12 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                                                             int64_t m_stride, int n_moves, int ratio_mode,
                                                             uint64_t t_steps, xs_word* rows, int p_stride,
                                                             const unsigned long long* slots, int n_slots,
-                                                            unsigned long long* ratio_acc, int red_cols)
+                                                            unsigned long long* ratio_acc, int red_cols,
+                                                            const unsigned long long* acc_base, const unsigned long long* tot_base,
+                                                            uint64_t t_base)
 {
+    // acc_base / tot_base (nullptr on most handles): what the 32-bit counters have been carried into so far, t_base the steps
+    // counted with it (counter_rebase_kernel); a counter's value is base + array, the steps counted t_base + t_steps
     // p_stride names the row's form (red_finish): the compact one for passes of at most RED_COMPACT_TRIPS trips per lane
     const bool compact = p_stride == RED_COMPACT_WORDS;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
@@ -1939,19 +1953,25 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                 const int64_t c = cw + (threadIdx.x & 63);        // every lane of a wave takes the same trips (the flush is wave-wide)
                 if (++n_r == xs::XS_RATIO_LANE_CAP) { q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]); n_r = 0; }
                 if (c >= n_chains) continue;
-                const uint32_t a = acc[(int64_t)k * m_stride + c];
-                uint32_t n = (uint32_t)t_steps;
+                unsigned long long a = acc[(int64_t)k * m_stride + c];
+                if (acc_base) a += acc_base[(int64_t)k * m_stride + c];
+                unsigned long long n = t_base + t_steps;
                 if (ratio_mode == 2) {
                     // total_calls of the last move has no array: the step count minus the other moves' (fold_log_kernel)
                     if (k + 1 < n_moves) {
                         n = tot[(int64_t)k * m_stride + c];
+                        if (tot_base) n += tot_base[(int64_t)k * m_stride + c];
                     } else {
-                        uint64_t others = 0;
-                        for (int j = 0; j + 1 < n_moves; ++j) others += tot[(int64_t)j * m_stride + c];
-                        n = (uint32_t)(t_steps - others);
+                        unsigned long long others = 0;
+                        for (int j = 0; j + 1 < n_moves; ++j) {
+                            others += tot[(int64_t)j * m_stride + c];
+                            if (tot_base) others += tot_base[(int64_t)j * m_stride + c];
+                        }
+                        n = t_base + t_steps - others;
                     }
                 }
-                ratio_add(r, nan, a, n);      // Int/Int -> Float64 division; 0/0 = NaN like the reference
+                if (acc_base) ratio_add(r, nan, a, n);      // Int/Int -> Float64 division; 0/0 = NaN like the reference
+                else ratio_add(r, nan, (uint32_t)a, (uint32_t)n);
             }
             q_flush_int(r, &s_ratio[threadIdx.x >> 6][0]);
             if (__builtin_amdgcn_ballot_w64(nan) != 0ull && (threadIdx.x & 63) == 0)
@@ -1967,6 +1987,21 @@ __global__ __launch_bounds__(AMC_BLOCK) void reduce_kernel(const real_t* x, cons
                 }
             }
         }
+    }
+}
+
+// Move.accepted_calls / total_calls are Int in the reference (src/metropolis.jl:145-146); the device counts in 32 bits (two u16
+// planes or a u32 array) and CARRIES: before the call that would count step 2^32 the host adds every counter into a 64-bit base
+// of its own and restarts the arrays at zero -- once per 2^32 counted steps, days into a run.  n: counters of the array.
+template <typename CT>
+__global__ __launch_bounds__(AMC_BLOCK) void counter_rebase_kernel(CT* lo, uint16_t* hi, int64_t n, unsigned long long* base)
+{
+    const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        unsigned long long v = lo[i];
+        lo[i] = 0;
+        if (hi) { v |= (unsigned long long)hi[i] << 16; hi[i] = 0; }
+        base[i] += v;
     }
 }
 

@@ -708,10 +708,11 @@ class OracleEngine:
         for c in range(3):
             if not self.reduce_columns & (1 << c):
                 rec[c] = 0.0
+        acc, tot = self.sim.counters()
         if self.n_moves == 1 and not self.per_chain_counters:
-            acc, _ = self.sim.counters()
             rec[4] = xsum_q([float(acc.sum())], 0)
-        return rec, int(self.sim.step)
+        # the MH steps counted per chain (every chain has taken the same number: the total_calls of any one add up to it)
+        return rec, int(tot[:, 0].sum()) if tot.size else 0
 
     def reduce_records_value(self, records, steps_counted):
         out = xsum_round(records)

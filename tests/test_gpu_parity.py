@@ -1070,34 +1070,75 @@ def test_callback_folds_interleaved_with_queued_sweeps(gpu, oracle, monkeypatch,
     e.close()
 
 
-@pytest.mark.parametrize("K", [1, 2])
-def test_per_chain_counters_refuse_to_wrap(gpu, K):
-    """Move.accepted_calls / total_calls are Int64 in the reference (src/metropolis.jl:145-146), u32 per chain on the
-    device: the call that would count step 2^32 returns AMC_ERR_STATE before anything is launched."""
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_per_chain_counters_count_past_2_to_the_32(gpu, oracle, K):
+    """Move.accepted_calls / total_calls are Int64 in the reference (src/metropolis.jl:145-146).  The device counts in 32-bit
+    arrays and carries them into 64-bit bases before the launch that would count step 2^32 (round 5; until round 4 that call was
+    refused): a run whose count starts five steps short of 2^32 keeps counting -- counters, pool totals, callback_acceptance's
+    ratio sums (formed from arrays plus bases after the carry) and a fused PGMC stretch equal the oracle's, whose counters are
+    64-bit all along; a checkpoint taken beyond 2^32 goes back in."""
     M = 1001
-    sigma, weight = POOLS[K]
-    e = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5, per_chain_counters=True)
-    e.init_uniform(-2, 2)
-    limit = 2 ** 32 - 1
-    acc = np.zeros((K, M), dtype=np.int64)
+    sigma, weight = {1: ([0.1], [1.0]), 2: ([0.2, 0.1], [0.6, 0.4]), 3: ([0.3, 0.2, 0.1], [0.5, 0.3, 0.2])}[K]
+    kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5, per_chain_counters=True)
+    e, o = gpu.HipEngine(device=0, **kw), oracle.OracleEngine(**kw)
+    rng = np.random.default_rng(K)
+    start = 2 ** 32 - 6
     tot = np.zeros((K, M), dtype=np.int64)
-    tot[0] = limit - 5                                      # 5 steps of room
-    acc[0] = limit - 7
-    e.upload_counters(acc, tot)
-    e.sweep(3)
-    with pytest.raises(gpu.AmcError, match="32-bit"):
-        e.sweep(3)
-    assert e.step == 3                                      # nothing was launched by the refused call
-    with pytest.raises(gpu.AmcError, match="32-bit"):
-        e.pgmc_steps(3, [0], 1)
-    e.sweep(2)
-    a2, t2 = e.download_counters()
-    assert np.all(t2.sum(axis=0) == limit) and np.all(a2[0] >= limit - 7) and np.all(a2 <= t2)
-    with pytest.raises(gpu.AmcError, match="32-bit"):
-        e.sweep(1)
-    e.upload_counters(acc * 0, tot * 0)                     # restart the count
-    e.sweep(4)
-    assert np.all(e.download_counters()[1].sum(axis=0) == 4)
+    cuts = np.sort(rng.integers(0, start + 1, size=(K - 1, M)), axis=0) if K > 1 else np.zeros((0, M), dtype=np.int64)
+    edges = np.vstack([np.zeros((1, M), dtype=np.int64), cuts, np.full((1, M), start, dtype=np.int64)])
+    tot[:] = np.diff(edges, axis=0)                         # every chain's totals add up to `start`
+    acc = (tot * rng.uniform(0.3, 1.0, size=tot.shape)).astype(np.int64)
+    for eng in (e, o):
+        eng.init_uniform(-2, 2)
+        eng.upload_counters(acc, tot)
+
+    def same(what):
+        a, t = e.download_counters()
+        ao, to = o.download_counters()
+        assert np.array_equal(a, ao) and np.array_equal(t, to), what
+        assert np.array_equal(e.counter_totals()[0], ao.sum(axis=1)) and np.array_equal(e.counter_totals()[1], to.sum(axis=1)), what
+        ra, sa = e.reduce_exact()
+        rb, sb = o.reduce_exact()
+        assert sa == sb == int(t[:, 0].sum()) and np.array_equal(ra, rb), what
+    same("before the carry")
+    for n in (3, 4, 2, 70):                                 # 3: still below; 4: the launch that crosses 2^32 carries first
+        e.sweep(n)
+        o.sweep(n)
+        same(f"after {n} more")
+    assert e.download_counters()[1].sum(axis=0).min() == start + 79 > 2 ** 32
+    # the callback sums formed with a sweep, and a fused PGMC stretch, on a handle that has carried
+    e.sweep_reduce_begin(3)
+    o.sweep_reduce_begin(3)
+    ra, sa = e.reduce_end_exact()
+    rb, sb = o.reduce_end_exact()
+    assert sa == sb and np.array_equal(ra, rb)
+    lid = K - 1
+    e.pgmc_steps(5, [lid], 1, [1], [1e-3], [0.0], reduce_begin=True)
+    o.pgmc_steps(5, [lid], 1, [1], [1e-3], [0.0], reduce_begin=True)
+    ra, sa = e.reduce_end_exact()
+    rb, sb = o.reduce_end_exact()
+    assert sa == sb and np.array_equal(ra, rb) and np.array_equal(bits(e.get_parameters(lid)), bits(o.get_parameters(lid)))
+    same("after the fused stretch")
+    # resume: counters beyond 2^32 go back in, on a fresh handle too
+    a, t = e.download_counters()
+    x = e.download_state()[0]
+    e2 = gpu.HipEngine(device=0, **kw)
+    e2.upload_state(x)
+    e2.upload_counters(a, t)
+    e2.step = e.step
+    e2.set_parameters(lid, e.get_parameters(lid))
+    for eng in (e, e2, o):
+        eng.sweep(11)
+    a2, t2 = e2.download_counters()
+    ao, to = o.download_counters()
+    assert np.array_equal(a2, ao) and np.array_equal(t2, to)
+    same("after the resume")
+    # ... and counts that fit 32 bits again restart plain arrays
+    e2.upload_counters(acc * 0, tot * 0)
+    e2.sweep(4)
+    assert np.all(e2.download_counters()[1].sum(axis=0) == 4)
+    with pytest.raises(gpu.AmcError, match="out of range"):
+        e2.upload_counters(acc * 0 + 2 ** 53, None if K == 1 else tot)
     # the pool-wide counter of a K = 1 handle without per-chain counters is 64-bit
     if K == 1:
         p = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=sigma, weight=weight, seed=5, per_chain_counters=False)
@@ -1108,6 +1149,7 @@ def test_per_chain_counters_refuse_to_wrap(gpu, K):
         assert t[0] == (2 ** 41 + 5) * M and 7 * 2 ** 40 <= a[0] <= 7 * 2 ** 40 + 5 * M
         p.close()
     e.close()
+    e2.close()
 
 
 @pytest.mark.parametrize("K", [1, 2, 3])
