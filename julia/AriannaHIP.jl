@@ -280,6 +280,7 @@ end
 
 function reduce(alg::HIPMetropolis, t::Int)
     alg.red_t == t && return alg.red
+    drop_pending!(alg); settle!(alg)             # reductions queued by run_fused! come back first (AriannaHIPRun.jl): oldest first
     records = Matrix{Float64}(undef, XSUM_WORDS, 4 + alg.K)
     steps = Ref{UInt64}(0)
     check(ccall((:amc_reduce_begin, libamc), Cint, (Ptr{Cvoid},), alg.handle))
@@ -401,6 +402,7 @@ end
 function pgmc_steps_observed!(metropolis::HIPMetropolis, n::Integer, learn_ids::Vector{Int}, q_batch::Integer,
                               optimiser::Vector{Cint}, hyper0::Vector{Float64}, hyper1::Vector{Float64}, t::Int)
     ids = Cint[k - 1 for k in learn_ids]
+    drop_pending!(metropolis); settle!(metropolis)
     check(ccall((:amc_pgmc_steps_reduce_begin, libamc), Cint,
                 (Ptr{Cvoid}, Int64, Cint, Ptr{Cint}, Cint, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
                 metropolis.handle, n, length(ids), ids, q_batch, 1, optimiser, hyper0, hyper1))
@@ -461,6 +463,11 @@ function parameters_begin!(metropolis::HIPMetropolis)
 end
 
 function parameters_end!(metropolis::HIPMetropolis)
+    if metropolis.n_params > 1                   # all P parameters of every move: column k holds move k's vector
+        θ = Matrix{Float64}(undef, metropolis.n_params, metropolis.K)
+        check(ccall((:amc_parameters_end_all, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint), metropolis.handle, θ, length(θ)))
+        return θ
+    end
     σ = Vector{Float64}(undef, metropolis.K)
     check(ccall((:amc_parameters_end, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}), metropolis.handle, σ))
     return σ
@@ -482,5 +489,9 @@ function pg_set_accumulated!(metropolis::HIPMetropolis, learn_ids::Vector{Int}, 
                 metropolis.handle, length(ids), ids, rows))
     return nothing
 end
+
+# Arianna's run! loop with look-ahead over the schedulers, deferred StoreCallbacks / StoreParameters, the device-resident
+# estimator and update as algorithms of the list (what `north_star` asks of the Julia host: the gains of the fused forms)
+include("AriannaHIPRun.jl")
 
 end # module

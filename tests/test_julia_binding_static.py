@@ -10,6 +10,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = os.path.join(ROOT, "julia", "AriannaHIP.jl")
+JL_RUN = os.path.join(ROOT, "julia", "AriannaHIPRun.jl")          # include()d by the module: run_fused!, deferred stores
 HDR = os.path.join(ROOT, "include", "amc.h")
 
 # C type (normalised: no `const`, single spaces, `*` attached) -> Julia types with the same calling-convention class
@@ -95,7 +96,8 @@ def _split_top(s):
 
 
 def julia_ccalls():
-    text = re.sub(r"#[^\n]*", "", open(JL).read())           # Julia line comments (no '#' inside the strings used there)
+    # Julia line comments (no '#' inside the strings used there); docstrings name no ccall
+    text = re.sub(r"#[^\n]*", "", open(JL).read()) + "\n" + re.sub(r"#[^\n]*", "", open(JL_RUN).read())
     calls = []
     for m in re.finditer(r"ccall\(", text):
         i = m.end()
@@ -193,3 +195,29 @@ def test_philox_rng_stub_follows_the_current_arithmetic_spec():
         assert jl in text, jl
         assert c in src, c
     assert "angle_oc2" not in text and "sincospi_tab(angle28(v[4]))" in text
+
+
+def test_julia_host_has_the_fused_run_loop():
+    """`north_star` names Julia as the host: the look-ahead over the schedulers, the callback sums formed in the observed launch,
+    whole [Metropolis, estimator, update] stretches in one engine call and the deferred rows exist on the Julia side too
+    (julia/AriannaHIPRun.jl restates montecarlo_amd/simulation.py run(fuse=True)), and the module includes them."""
+    main = open(JL).read()
+    run = re.sub(r"#[^\n]*", "", open(JL_RUN).read())
+    assert 'include("AriannaHIPRun.jl")' in main
+    for name in ("function run_fused!(simulation::Simulation)", "function fuse_sweeps!", "function fuse_pgmc!", "function make_step_observed!",
+                 "mutable struct HIPStoreCallbacks", "mutable struct HIPStoreParameters", "struct HIPDeviceEstimator", "struct HIPDeviceUpdate",
+                 "function declare_reduction_needs!", "function consecutive(", "function observed_next("):
+        assert name in run, name
+    used = {c["name"] for c in julia_ccalls()}
+    need = {"amc_sweep_reduce_begin", "amc_pgmc_steps_reduce_begin", "amc_pgmc_steps", "amc_parameters_begin", "amc_parameters_end_all",
+            "amc_set_reduce_columns", "amc_pg_accumulate", "amc_pg_update", "amc_sync", "amc_reduce_end_exact"}
+    assert need <= used, sorted(need - used)
+    # a stretch nobody observes is ONE amc_sweep of n sweeps, not n calls of one
+    assert re.search(r"ccall\(\(:amc_sweep, libamc\), Cint, \(Ptr\{Cvoid\}, Int64\), alg\.handle, n\)", run)
+    # the loop keeps the reference's order: initialise all, steps, finalise all in a `finally` (src/simulation.jl:175-204)
+    body = run[run.index("function run_fused!"):]
+    assert body.index("initialise(algorithm, simulation)") < body.index("while t <= simulation.steps") < body.index("finally") < body.index("finalise(algorithm, simulation)")
+    # every `function` / `struct` / control block of the file is closed (a cheap stand-in for a parser)
+    opens = len(re.findall(r"^\s*(?:mutable struct|struct|function|if|for|while|try|begin|let)\b|\bdo\b\s*(?:\([^)]*\)|\w+)?\s*$|=\s*begin\s*$|@elapsed begin", run, flags=re.M))
+    closes = len(re.findall(r"^\s*end\b", run, flags=re.M))
+    assert opens == closes, (opens, closes)
