@@ -157,6 +157,7 @@ struct amc_handle {
     int red_blocks = 0;
     int red_cols = amc::RED_WANT_ALL;   // the callback sums a reduction forms (amc_set_reduce_columns)
     bool wide_red_rows = false;         // env AMC_WIDE_RED_ROWS=1 (read at amc_create; tests): the wide row form whatever the launch
+    bool no_deferred_update = false;    // env AMC_NO_DEFERRED_UPDATE=1 (read at amc_create; tests, A/B): every fused time step takes its own learning step
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
     int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
@@ -186,6 +187,18 @@ struct amc_handle {
     int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
     uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
     amc::xs_word* d_pg_groups = nullptr;   // [nl * 4][PG_GROUP][words per column]: group rows
+    double* d_theta_ring = nullptr;     // [2][AMC_MAX_LEARN]: sigma of the learnable moves as the fused launches of even / odd estimator steps used it
+    // A learning step a fused time step left to the next launch's prologue (amc::pg_apply_pending): what it needs to be taken --
+    // by that launch, or by pg_resolve_kernel when anything else wants the parameter table first
+    struct {
+        bool active = false;
+        int source = 0;                 // amc::PG_PENDING_GROUPS / _RECORDS
+        int groups = 0;                 // groups of PG_GROUP blocks the launch wrote
+        int n_learn = 0;
+        uint64_t t_est = 0;             // the estimator step of that launch (its parity names the ring slot and the group rows)
+    } pend;
+    bool pend_consumed = false;         // the last estimator launch took the pending step in its prologue (pg_launch)
+    uint64_t gd_nonzero = 0;            // moves whose gradients_data on the device may be non-zero (estimator steps since their last update)
     amc::PgTail* d_pg_tail = nullptr;   // the estimator kernel's per-configuration record (see amc::PgTail)
     amc::PgTail pg_tail_host;           // ... and what it holds now (rewritten only when it changes)
     bool pg_tail_valid = false;
@@ -206,6 +219,8 @@ struct amc_handle {
     std::vector<hipModule_t> rtc_mods;
 };
 
+static int pg_resolve(amc_handle* h);      // takes a pending learning step now (defined with the estimator's host code)
+
 namespace {
 
 int grid_for(const amc_handle* h, int64_t n_items, int blocks_per_cu = 0)
@@ -220,6 +235,7 @@ int grid_for(const amc_handle* h, int64_t n_items, int blocks_per_cu = 0)
 
 int push_params(amc_handle* h, const double* sigma, const double* weight)
 {
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
     std::vector<double> tab((size_t)amc::PT_ROWS * AMC_MAX_MOVES, 0.0);
     AMC_HIP(hipMemcpyAsync(tab.data(), h->d_ptab, tab.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
@@ -998,6 +1014,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     }
     if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
     if (const char* env = std::getenv("AMC_WIDE_RED_ROWS")) h->wide_red_rows = std::atoi(env) != 0;
+    if (const char* env = std::getenv("AMC_NO_DEFERRED_UPDATE")) h->no_deferred_update = std::atoi(env) != 0;
     h->M = cfg->n_chains;
     // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
     // (M_pad is a multiple of 256): a wave's 128-byte step-log store then covers exactly one aligned line
@@ -1109,7 +1126,9 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         const size_t groups = (size_t)(h->n_slots + amc::PG_GROUP - 1) / amc::PG_GROUP + 1;
         AMC_TRY(hipMalloc(&h->d_pg_tickets, (groups + 1) * sizeof(uint32_t)));
         AMC_TRY(hipMemsetAsync(h->d_pg_tickets, 0, (groups + 1) * sizeof(uint32_t), h->stream));
-        AMC_TRY(hipMalloc(&h->d_pg_groups, (size_t)amc::PG_GROUP * PG_MAX_COLS * amc::XS_ROW_R * sizeof(amc::xs_word)));   // at most PG_GROUP groups
+        AMC_TRY(hipMalloc(&h->d_pg_groups, (size_t)2 * amc::PG_PARITY_WORDS * sizeof(amc::xs_word)));   // group rows, by the parity of the estimator step
+        AMC_TRY(hipMalloc(&h->d_theta_ring, (size_t)2 * AMC_MAX_LEARN * sizeof(double)));
+        AMC_TRY(hipMemsetAsync(h->d_theta_ring, 0, (size_t)2 * AMC_MAX_LEARN * sizeof(double), h->stream));
         AMC_TRY(hipMalloc(&h->d_pg_tail, sizeof(amc::PgTail)));
     }
     AMC_TRY(hipEventCreate(&h->ev0));
@@ -1310,6 +1329,7 @@ int amc_destroy(amc_handle* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_pg_tickets);
     (void)hipFree(h->d_pg_groups);
+    (void)hipFree(h->d_theta_ring);
     (void)hipFree(h->d_pg_tail);
     (void)hipFree(h->d_x);
     (void)hipFree(h->d_x64);
@@ -1680,6 +1700,7 @@ static int reduce_sweep_grid(const amc_handle* h)
 static int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* grid_out)
 {
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }      // the sweep kernels read sigma from the parameter table
     int64_t remaining = n_sweeps * (int64_t)h->sweepstep;
     // one grid for the whole call (the caller of a fused reduction sums `grid` rows)
     // (a call whose last launch also forms the callback sums: that form holds 5 blocks per CU -- 89 VGPRs -- and runs one round of
@@ -2206,6 +2227,7 @@ int amc_set_parameters(amc_handle* h, int k, const double* p, int n)
             if (!(p[i] - p[i] == 0.0)) return fail(AMC_ERR_BAD_ARG, "amc_set_parameters: parameter %d is not finite", i);
     }
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
     for (int i = 0; i < n; ++i)
         AMC_HIP(hipMemcpyAsync(h->d_ptab + theta_row(i) * AMC_MAX_MOVES + k, p + i, sizeof(double), hipMemcpyHostToDevice, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
@@ -2224,6 +2246,7 @@ int amc_get_parameters(amc_handle* h, int k, double* p, int n)
         return fail(AMC_ERR_BAD_ARG, h->n_params == 1 ? "amc_get_parameters: StandardGaussian has exactly 1 parameter (sigma)"
                                                      : "amc_get_parameters: this handle's policy has %d parameters", h->n_params);
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
     for (int i = 0; i < n; ++i)
         AMC_HIP(hipMemcpyAsync(p + i, h->d_ptab + theta_row(i) * AMC_MAX_MOVES + k, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     AMC_HIP(hipStreamSynchronize(h->stream));
@@ -2243,6 +2266,7 @@ int amc_parameters_begin(amc_handle* h)
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_parameters_begin: NULL handle");
     if (h->params_pending) return fail(AMC_ERR_STATE, "amc_parameters_begin: a read is already in flight (call amc_parameters_end)");
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
     AMC_HIP(hipMemcpyAsync(h->h_params, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES, (size_t)h->K * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
     if (h->n_params > 1)         // parameters 1 .. P - 1: consecutive rows of the table
@@ -2272,6 +2296,27 @@ int amc_parameters_end_all(amc_handle* h, double* parameters, int n)
     if (h && n != h->K * h->n_params)
         return fail(AMC_ERR_BAD_ARG, "amc_parameters_end_all: this handle has %d moves of %d parameters", h->K, h->n_params);
     return parameters_end_impl(h, "amc_parameters_end_all", parameters, h ? h->n_params : 1);
+}
+
+// Takes a learning step that a fused time step left pending (amc::pg_apply_pending) NOW: one small launch that brings the
+// parameter table up to date.  Everything that reads or writes the moves' parameters, gradients_data or the status flag -- other
+// than the next fused launch, which takes the step in its prologue -- calls this first.  (The device's tail record still describes
+// the pending step's configuration: a launch that changes it resolves before it rewrites.)
+static int pg_resolve(amc_handle* h)
+{
+    if (!h->pend.active) return AMC_OK;
+    AMC_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(amc::pg_resolve_kernel, dim3(1), dim3(AMC_BLOCK), 0, h->stream, (const amc::PgTail*)h->d_pg_tail, h->pend.source,
+                       (int)(h->pend.t_est & 1ull), h->pend.groups, h->pend.n_learn);
+    AMC_HIP(hipGetLastError());
+    h->pend.active = false;
+    return AMC_OK;
+}
+// the kernel forms that can take a pending step in their prologue, and leave one (amc_kernels.h CAN_DEFER): the built-in
+// potentials' Gaussian policy (kind-Q sums), at most two learnable moves
+static bool pg_form_defers(const amc_handle* h, int n_learn)
+{
+    return !h->no_deferred_update && !h->use_rtc && h->n_params == 1 && h->n_classes == 1 && n_learn >= 1 && n_learn <= 2;
 }
 
 // The estimator's grid over this shard.
@@ -2390,11 +2435,28 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         tl.ptab_rw = h->d_ptab;
         tl.status = h->d_status;
         tl.n_samples = (double)h->M * (double)q_batch;
+        tl.n_samples_global = (double)h->M_global * (double)q_batch;
+        tl.theta_ring = h->d_theta_ring;
         tl.n_moves = h->K;
         tl.rank = h->comm ? h->comm_rank : 0;
         tl.n_ranks = h->comm ? h->comm_ranks : 1;
         for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
+        // a learning step the previous fused launch left pending: this launch takes it in its prologue if it is the very next
+        // estimator step, of a kernel form that can, under the same record (learnable moves, optimisers, sample count) --
+        // anything else takes it now (pg_resolve: before the record is rewritten)
+        h->pend_consumed = false;
+        if (h->pend.active) {
+            const bool same = h->pg_tail_valid && std::memcmp(&tl, &h->pg_tail_host, sizeof(tl)) == 0;
+            if (same && pg_form_defers(h, n_learn) && h->t_est == h->pend.t_est + 1 && n_learn == h->pend.n_learn) {
+                a.tail_mode |= (h->pend.source << 8) | (h->pend.groups << 16);
+                h->pend.active = false;
+                h->pend_consumed = true;
+            } else {
+                const int rcr = pg_resolve(h);
+                if (rcr != AMC_OK) return rcr;
+            }
+        }
         if (!h->pg_tail_valid || std::memcmp(&tl, &h->pg_tail_host, sizeof(tl)) != 0) {
             // stream-ordered, the record travels as a kernel argument: launches already queued read the old one
             hipLaunchKernelGGL(amc::pg_tail_store_kernel, dim3(1), dim3(64), 0, h->stream, tl, h->d_pg_tail);
@@ -2555,8 +2617,10 @@ static int pg_update_np(amc_handle* h, int n_learn, const int* learn_ids, const 
 // (opt != nullptr).  Single shard: ONE launch (the estimator kernel's last block folds, accumulates and, if asked,
 // takes the learning step).  Shards connected by amc_comm_init: estimator launch, in-place all-reduce, then the
 // small accumulate (and update) kernels.
+// may_defer: the caller's next launch is a fused time step of the same configuration that does NOT also form the callback sums
+// (amc_pgmc_steps knows its own loop), so the learning step may be left to that launch's prologue -- see below
 static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, int q_batch, const amc::PgOpts* opt,
-                              bool with_sweep = false, bool reduce = false, int* grid_out = nullptr)
+                              bool with_sweep = false, bool reduce = false, int* grid_out = nullptr, bool may_defer = false)
 {
     int nl = 0;
     if (per_move_launches(h) && !(np_single_launch(h, n_learn) && !h->comm)) {
@@ -2586,10 +2650,45 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
         }
         return AMC_OK;
     }
-    const int tail = h->comm ? 1 : (opt ? 3 : 2);
-    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep, reduce, grid_out);
+    // (a communicator of ONE rank: its all-reduce is the identity -- the single-shard forms, no collective)
+    const bool shards = h->comm && h->comm_ranks > 1;
+    // A fused time step that also updates may leave the learning step to the next launch's prologue (amc::pg_apply_pending,
+    // round 5): the tail then ends at the group sums -- between shards: at this shard's records and the all-reduce behind them --
+    // instead of going on through the second level of sums, a ticket and the update (single shard: 63.3 -> 62.5 us per
+    // time step at 1e7 chains; shards: fused launch -> all-reduce -> next fused launch, no small launch in between).  Only behind
+    // an update: gradients_data is then zero and stays untouched.  And only where the successor is known to be a plain fused step
+    // (may_defer): the launch that also forms the callback sums holds four blocks per CU, and the prologue's extra microsecond
+    // shows there (+2 us measured) where it pays on the plain steps (-0.75 us each) -- so a pending step never outlives the
+    // amc_pgmc_steps call that left it.
+    uint64_t ids_mask = 0;
+    for (int l = 0; l < n_learn; ++l) ids_mask |= 1ull << (learn_ids[l] & 63);
+    const bool defer = may_defer && opt && with_sweep && n_learn > 0 && pg_form_defers(h, n_learn) && (h->gd_nonzero & ids_mask) == 0;
+    const int tail = shards ? 1 : (defer ? (int)amc::PG_TAIL_GROUPS : (opt ? 3 : 2));
+    const uint64_t t_est = h->t_est;
+    int grid = 0;
+    const int rc = pg_launch(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch, &nl, tail, opt, with_sweep, reduce, &grid);
+    if (grid_out) *grid_out = grid;
     if (rc != AMC_OK || n_learn == 0) return rc;
-    if (!h->comm) return AMC_OK;
+    if (defer) {
+        if (!h->pend_consumed) {
+            // the first step of a stretch (or one whose predecessor's step was taken by pg_resolve): the ring slot of this step's
+            // parity is the sigma the launch has just used -- the table's.  (Otherwise block 0 of the launch wrote sigma' there.)
+            // Queued behind the launch: it reads the table, this copies from it, nothing writes it in between.
+            for (int l = 0; l < n_learn; ++l)
+                AMC_HIP(hipMemcpyAsync(h->d_theta_ring + (size_t)(t_est & 1ull) * AMC_MAX_LEARN + l, h->d_ptab + amc::PT_SIGMA * AMC_MAX_MOVES + learn_ids[l],
+                                       sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+        if (shards) { const int rca = pg_allreduce_records(h, n_learn * 4); if (rca != AMC_OK) return rca; }
+        h->pend.active = true;
+        h->pend.source = shards ? (int)amc::PG_PENDING_RECORDS : (int)amc::PG_PENDING_GROUPS;
+        h->pend.groups = (grid + amc::PG_GROUP - 1) / amc::PG_GROUP;
+        h->pend.n_learn = n_learn;
+        h->pend.t_est = t_est;
+        return AMC_OK;
+    }
+    if (opt) h->gd_nonzero &= ~ids_mask;      // an update leaves gradients_data of its moves zero, an estimator step alone does not
+    else h->gd_nonzero |= ids_mask;
+    if (!shards) return AMC_OK;
     // shards: the launch wrote this shard's records into its slot of d_out[ranks][n_learn * 4][XS_WORDS] and zeroed the other
     // slots, so ONE in-place all-reduce(sum) on the engine's stream is a gather -- exact whatever order RCCL adds in; the
     // kernel behind it merges the shards' integer totals and rounds once (pg_merge_slots): every shard, and a single shard
@@ -2597,8 +2696,10 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     { const int rca = pg_allreduce_records(h, n_learn * 4); if (rca != AMC_OK) return rca; }
     const double n_samples = (double)h->M_global * (double)q_batch;
     if (opt) {      // gradients_data += gd and the learning step in ONE launch: both sit on the critical path of the next sweep
+        // (a launch that took a pending step in its prologue proposed with sigma', which block 0 left in this step's ring slot)
+        const double* theta_used = h->pend_consumed ? h->d_theta_ring + (size_t)(t_est & 1ull) * AMC_MAX_LEARN : nullptr;
         hipLaunchKernelGGL(amc::pg_accumulate_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->comm_ranks, h->d_ptab,
-                           h->d_gd_acc, n_learn, make_ids(n_learn, learn_ids), n_samples, *opt, h->K, h->d_status);
+                           h->d_gd_acc, n_learn, make_ids(n_learn, learn_ids), n_samples, *opt, h->K, h->d_status, theta_used);
     } else {
         hipLaunchKernelGGL(amc::pg_accumulate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_out, h->comm_ranks, n_learn,
                            make_ids(n_learn, learn_ids), n_samples, h->d_gd_acc);
@@ -2638,6 +2739,8 @@ int amc_pg_update(amc_handle* h, int n_learn, const int* learn_ids, const int* o
     amc::PgOpts opt;
     { const int rc = make_opts(h, n_learn, learn_ids, optimiser, hyper0, hyper1, &opt); if (rc != AMC_OK) return rc; }
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
+    for (int l = 0; l < n_learn; ++l) h->gd_nonzero &= ~(1ull << (learn_ids[l] & 63));
     if (h->n_params > 1) return pg_update_np(h, n_learn, learn_ids, opt);
     hipLaunchKernelGGL(amc::pg_update_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ptab, h->d_gd_acc, n_learn,
                        make_ids(n_learn, learn_ids), opt, h->K, h->d_status);
@@ -2681,7 +2784,8 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
         int rc = fused ? AMC_OK : sweep_impl(h, 1, false, nullptr);
         if (rc == AMC_OK)
             rc = pg_accumulate_impl(h, n_learn, learn_ids, q_batch, (do_update && n_learn > 0) ? &opt : nullptr, fused,
-                                    fused_reduce && i + 1 == n_steps, &grid);
+                                    fused_reduce && i + 1 == n_steps, &grid,
+                                    /* may_defer: */ fused && i + 1 < n_steps && !(fused_reduce && i + 2 == n_steps));
         if (rc != AMC_OK) return rc;
     }
     if (!reduce) return AMC_OK;
@@ -2705,6 +2809,7 @@ int amc_pg_get_accumulated(amc_handle* h, int n_learn, const int* learn_ids, dou
 {
     if (!h || !out || (n_learn > 0 && !learn_ids)) return fail(AMC_ERR_BAD_ARG, "amc_pg_get_accumulated: NULL argument");
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }      // (a pending step may set the status flag)
     const int np = h->n_params;
     const size_t dev_stride = np > 1 ? (size_t)AMC_GD_STRIDE_MAX : 5, out_stride = (size_t)amc::pg_gd_stride(np);
     std::vector<double> acc((size_t)AMC_MAX_MOVES * dev_stride);
@@ -2732,6 +2837,8 @@ int amc_pg_set_accumulated(amc_handle* h, int n_learn, const int* learn_ids, con
         if (!(n >= 0.0) || n != std::floor(n)) return fail(AMC_ERR_BAD_ARG, "amc_pg_set_accumulated: n of move %d is not a sample count", learn_ids[l]);
     }
     AMC_HIP(hipSetDevice(h->device));
+    { const int rc = pg_resolve(h); if (rc != AMC_OK) return rc; }
+    for (int l = 0; l < n_learn; ++l) h->gd_nonzero |= 1ull << (learn_ids[l] & 63);
     {
         const size_t dev_stride = h->n_params > 1 ? (size_t)AMC_GD_STRIDE_MAX : 5, in_stride = (size_t)amc::pg_gd_stride(h->n_params);
         for (int l = 0; l < n_learn; ++l)
@@ -2858,6 +2965,7 @@ int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
     if (!h || !id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: NULL argument");
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: bad rank/n_ranks");
     AMC_HIP(hipSetDevice(h->device));
+    { const int rcr = pg_resolve(h); if (rcr != AMC_OK) return rcr; }
     const int rc = load_rccl(h->rccl);
     if (rc != AMC_OK) return rc;
     if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
@@ -2907,6 +3015,7 @@ int amc_comm_destroy(amc_handle* h)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_comm_destroy: NULL handle");
     AMC_HIP(hipSetDevice(h->device));
+    { const int rcr = pg_resolve(h); if (rcr != AMC_OK) return rcr; }
     if (h->stream) AMC_HIP(hipStreamSynchronize(h->stream));      // the estimator's collectives run there
     comm_release(h);
     return AMC_OK;

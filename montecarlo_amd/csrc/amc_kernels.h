@@ -1746,29 +1746,40 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_ker
 // weights in the order Distributions.jl accumulates them; dden, dlhalf: d/dsigma
 // pieces of gradients.jl:28-33 (ForwardDiff's dual rules written out).
 // (the entries of move k that depend on its sigma alone)
-__device__ __forceinline__ void prepare_move_params(double* ptab, int k, double sigma)
+// What a move's sigma determines (the loop invariants of particle_1d.jl:53 and of its sigma-derivative), in registers.
+enum { DEF_SIGMA = 0, DEF_DEN, DEF_RDEN, DEF_LOGC, DEF_C3HI, DEF_C3LO, DEF_DLHALF, DEF_DDEN, DEF_N };
+__device__ __forceinline__ void derive_move_params(double sigma, double (&d)[DEF_N])
 {
     const double TWO_PI = 0x1.921fb54442d18p+2;
-    {
-        const double s2 = sigma * sigma;
-        const double ds2 = sigma + sigma;
-        ptab[PT_DEN * AMC_MAX_MOVES + k] = 2.0 * s2;
-        ptab[PT_RDEN * AMC_MAX_MOVES + k] = 1.0 / (2.0 * s2);        // RN(1/den) for div_by_const
-        ptab[PT_DDEN * AMC_MAX_MOVES + k] = 2.0 * ds2;
-        const double av = TWO_PI * s2;
-        ptab[PT_LOGC * AMC_MAX_MOVES + k] = log_f64(av) / 2.0;
-        ptab[PT_DLHALF * AMC_MAX_MOVES + k] = ((TWO_PI * ds2) / av) / 2.0;
-        {
-            // dden / den^2 (= 1/sigma^3) as an unevaluated sum hi + lo: the coefficient of delta^2 in the estimator's
-            // d logq / d sigma (pg_sample), good to ~2^-100 so that no rounding of a CONSTANT biases a sum over 1e7+ samples
-            const double den = 2.0 * s2, dden = 2.0 * ds2;
-            const double d_hi = den * den, d_lo = __builtin_fma(den, den, -d_hi);
-            const double c_hi = dden / d_hi;
-            const double res = __builtin_fma(-c_hi, d_hi, dden) - c_hi * d_lo;
-            ptab[PT_C3HI * AMC_MAX_MOVES + k] = c_hi;
-            ptab[PT_C3LO * AMC_MAX_MOVES + k] = res / d_hi;
-        }
-    }
+    const double s2 = sigma * sigma;
+    const double ds2 = sigma + sigma;
+    d[DEF_SIGMA] = sigma;
+    d[DEF_DEN] = 2.0 * s2;
+    d[DEF_RDEN] = 1.0 / (2.0 * s2);                                  // RN(1/den) for div_by_const
+    d[DEF_DDEN] = 2.0 * ds2;
+    const double av = TWO_PI * s2;
+    d[DEF_LOGC] = log_f64(av) / 2.0;
+    d[DEF_DLHALF] = ((TWO_PI * ds2) / av) / 2.0;
+    // dden / den^2 (= 1/sigma^3) as an unevaluated sum hi + lo: the coefficient of delta^2 in the estimator's
+    // d logq / d sigma (pg_sample), good to ~2^-100 so that no rounding of a CONSTANT biases a sum over 1e7+ samples
+    const double den = 2.0 * s2, dden = 2.0 * ds2;
+    const double d_hi = den * den, d_lo = __builtin_fma(den, den, -d_hi);
+    const double c_hi = dden / d_hi;
+    const double res = __builtin_fma(-c_hi, d_hi, dden) - c_hi * d_lo;
+    d[DEF_C3HI] = c_hi;
+    d[DEF_C3LO] = res / d_hi;
+}
+__device__ __forceinline__ void prepare_move_params(double* ptab, int k, double sigma)
+{
+    double d[DEF_N];
+    derive_move_params(sigma, d);
+    ptab[PT_DEN * AMC_MAX_MOVES + k] = d[DEF_DEN];
+    ptab[PT_RDEN * AMC_MAX_MOVES + k] = d[DEF_RDEN];
+    ptab[PT_DDEN * AMC_MAX_MOVES + k] = d[DEF_DDEN];
+    ptab[PT_LOGC * AMC_MAX_MOVES + k] = d[DEF_LOGC];
+    ptab[PT_DLHALF * AMC_MAX_MOVES + k] = d[DEF_DLHALF];
+    ptab[PT_C3HI * AMC_MAX_MOVES + k] = d[DEF_C3HI];
+    ptab[PT_C3LO * AMC_MAX_MOVES + k] = d[DEF_C3LO];
 }
 
 __device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
@@ -1858,16 +1869,18 @@ __device__ __forceinline__ double pg_learning_step(int kind, double h0, double h
 // accumulators are read once, the new sigma and what derives from it are written from registers, and only the moves that
 // learned get their derived parameters refreshed (the cumulative weights do not depend on sigma): the few dependent round
 // trips to memory this thread makes are the tail of every PGMC time step (62.4 -> 61.4 us per fused step, same box).
+// theta_used (optional): the sigma the launch proposed with, per learnable move -- the table's, except in a launch that took a
+// pending step in its prologue (pg_apply_pending: the table is then one step behind, sigma' lives in the ring)
 __device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_learn, const int32_t* ids,
                                               const PgOpts& opt, int n_moves, int* status, const double* red = nullptr,
-                                              double n_samples = 0.0)
+                                              double n_samples = 0.0, const double* theta_used = nullptr)
 {
     (void)n_moves;
     for (int l = 0; l < n_learn; ++l) {
         const int k = ids[l];
         double* a = acc + k * 5;
         double v[5] = {a[0], a[1], a[2], a[3], a[4]};
-        const double theta = ptab[PT_SIGMA * AMC_MAX_MOVES + k];
+        const double theta = theta_used ? theta_used[l] : ptab[PT_SIGMA * AMC_MAX_MOVES + k];
         if (red) {
             for (int i = 0; i < 4; ++i) v[i] += red[l * 4 + i];
             v[4] += n_samples;
@@ -2069,6 +2082,8 @@ struct PgTail {
     double* ptab_rw;              // == ptab (written by the update)
     int* status;
     double n_samples;
+    double n_samples_global;      // ... of all shards (the learning step a launch leaves pending divides by it: pg_apply_pending)
+    double* theta_ring;           // [2][AMC_MAX_LEARN]: sigma of the learnable moves as the launches of even / odd estimator steps used it
     int32_t n_moves;
     int32_t rank, n_ranks;        // slot of this shard in `out` (0 of 1 without a communicator)
     int32_t pad_;
@@ -2311,13 +2326,14 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* recs, int 
 
 // Both in one launch, for shards connected by a communicator: what follows the in-place all-reduce of the estimator's sums
 // when the time step also updates (estimator.jl:130, then update.jl:50-57) -- one tiny launch on the critical path instead of two.
+// theta_used: see pg_update_all (the ring slot of the launch before, or nullptr)
 AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* recs, int n_ranks, double* ptab, double* acc, int n_learn, PgIds ids,
-                                                              double n_samples, PgOpts opt, int n_moves, int* status)
+                                                              double n_samples, PgOpts opt, int n_moves, int* status, const double* theta_used)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double vals[AMC_MAX_LEARN * 4];
     pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
-    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, vals, n_samples);
+    pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, vals, n_samples, theta_used);
 }
 
 // ---- policies with several parameters (handles of amc_create_vector_policy_model with n_params > 1) ----
@@ -2567,6 +2583,86 @@ __device__ __forceinline__ PgCol<Q> pg_col_total(const xs_word* rows, int n_rows
     return col;
 }
 
+// ---- the learning step a launch leaves PENDING (round 5) -------------------------------------------------------------------
+// make_step!(::PolicyGradientUpdate) (update.jl:50-57) needs the sums over ALL chains, so in a launch that also takes the step it
+// sits at the very end, behind the second level of the in-kernel reduction, a ticket and a few dependent trips to memory -- on
+// the critical path of the next time step, which proposes with the new sigma.  A fused time step that updates every step
+// (amc_pgmc_steps) may instead STOP at the group sums (tail_mode PG_TAIL_GROUPS) -- or, between shards, at this shard's records and
+// the all-reduce behind them -- and leave the rest to the NEXT launch's prologue: every block adds up the (at most 64) group rows,
+// or the shards' records, rounds once and takes learning_step! itself -- the same integers and the same operations in every
+// block, so every block proposes with the same sigma' -- while its first load of positions is in flight.  Nothing a block reads
+// here is written during the launch: the sigma the previous launch used lives in a ring of two slots (by estimator step parity;
+// block 0 leaves sigma' in the other slot), the group rows likewise, gradients_data is zero throughout (the host defers only
+// behind an update).  The parameter table itself catches up when something else wants it (pg_resolve_kernel).
+// tail_mode: low byte = what the tail does; bits 8-9 = a pending step to take first (PG_PENDING_*); bits 16-23 = the groups the
+// launch that left it wrote.
+enum { PG_TAIL_GROUPS = 4 };
+enum { PG_PENDING_NONE = 0, PG_PENDING_GROUPS = 1, PG_PENDING_RECORDS = 2 };
+enum { PG_PARITY_WORDS = PG_GROUP * 32 * XS_ROW_R };      // words of group rows per parity (NV <= 32 columns)
+__host__ __device__ inline int pg_tail_of(int tail_mode) { return tail_mode & 0xFF; }
+__host__ __device__ inline int pg_pending_of(int tail_mode) { return (tail_mode >> 8) & 3; }
+__host__ __device__ inline int pg_pending_groups_of(int tail_mode) { return (tail_mode >> 16) & 0xFF; }
+
+// All threads of the block call (one barrier inside).  s_val[n_learn * 4], s_def[n_learn][DEF_N]: LDS; valid after the caller's
+// next barrier.  prev: the parity of the launch that left the step pending; writer: this block records sigma' and the status.
+__device__ __forceinline__ void pg_apply_pending(const PgTail* tl, int pending, int prev, int prev_groups, int n_learn, double* s_val,
+                                                 double (*s_def)[DEF_N], bool writer)
+{
+    const int nv = n_learn * 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double* ring = tl->theta_ring + prev * AMC_MAX_LEARN;
+    for (int c = wave; c < nv; c += AMC_BLOCK / 64) {
+        const int e = xs::xs_gd_exponent_of(ring[c >> 2], c & 3);      // the quanta the sums were formed with: from the sigma that launch used
+        double val = 0.0;
+        if (pending == PG_PENDING_GROUPS) {
+            const PgCol<true> col = pg_col_total<true>(tl->group_sums + (int64_t)prev * PG_PARITY_WORDS + (int64_t)c * PG_GROUP * XS_ROW_Q, prev_groups, XS_ROW_Q);
+            val = xs::part_q_round(col.q, e);
+        } else {
+            // the shards' records behind the all-reduce (slot r: shard r's, the all-reduce was a gather): limbs and flags add word by
+            // word -- integers below 2^53, exact in any order --, kind and exponent are the same on every shard
+            __shared__ double s_rec[AMC_BLOCK / 64][xs::XS_WORDS];
+            if (lane < xs::XS_WORDS) {
+                double w = 0.0;
+                for (int r = 0; r < tl->n_ranks; ++r) w += tl->out[((size_t)r * nv + c) * xs::XS_WORDS + lane];
+                s_rec[wave][lane] = lane == 0 ? (double)xs::XS_Q : lane == 1 ? (double)e : lane == 2 ? (w != 0.0 ? (double)xs::XS_F_NAN : 0.0) : w;
+            }
+            if (lane == 0) val = xs::rec_round(s_rec[wave]);           // (the wave's own LDS writes: in order)
+        }
+        if (lane == 0) s_val[c] = val;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = pending == PG_PENDING_GROUPS ? tl->n_samples : tl->n_samples_global;
+        for (int l = 0; l < n_learn; ++l) {
+            const double theta = ring[l];
+            // average (gradients.jl:83-85) of gradients_data = 0 + the sums, then learning_step! -- the operations of pg_update_all
+            const double j = s_val[4 * l] / n, dj = s_val[4 * l + 1] / n, dlogq = s_val[4 * l + 2] / n, g = s_val[4 * l + 3] / n;
+            double next = pg_learning_step(tl->opt.kind[l], tl->opt.h0[l], tl->opt.h1[l], theta, j, dj, dlogq, g);
+            if (!(next >= 1e-100 && next <= 1e100)) {       // a step that leaves sigma outside its range (or NaN) is not applied
+                next = theta;
+                if (writer) tl->status[0] = 1;
+            }
+            derive_move_params(next, s_def[l]);
+            if (writer) tl->theta_ring[(prev ^ 1) * AMC_MAX_LEARN + l] = next;
+        }
+    }
+}
+
+// Brings the parameter table up to date with a pending step (one block; the host launches it before anything but the next fused
+// time step reads sigma).
+AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void pg_resolve_kernel(const PgTail* tl, int pending, int prev, int prev_groups, int n_learn)
+{
+    __shared__ double s_val[AMC_MAX_LEARN * 4];
+    __shared__ double s_def[AMC_MAX_LEARN][DEF_N];
+    pg_apply_pending(tl, pending, prev, prev_groups, n_learn, s_val, s_def, true);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int l = 0; l < n_learn; ++l) {
+            const int k = tl->learn_ids[l];
+            tl->ptab_rw[PT_SIGMA * AMC_MAX_MOVES + k] = s_def[l][DEF_SIGMA];
+            prepare_move_params(tl->ptab_rw, k, s_def[l][DEF_SIGMA]);
+        }
+}
+
 // K3: make_step!(::PolicyGradientEstimator) estimator.jl:111-134, all learnable moves fused.
 // SWEEP != 0: the launch first performs ONE make_step!(::Metropolis) of sweepstep = 1 on the pair it has just loaded
 // (1: K == 1, 2: K > 1, per-chain counters through the step log in both; 3: K == 1 with the pool-wide counter only) -- run! calls the two algorithms back to
@@ -2613,10 +2709,38 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
             s_tab[4 * AMC_MAX_MOVES + i] = sw.ptab[PT_RDEN * AMC_MAX_MOVES + i];
         }
     }
-    const double sw_sigma1 = SWEEP ? sw.ptab[PT_SIGMA * AMC_MAX_MOVES] : 0.0;
-    const double sw_den1 = SWEEP ? sw.ptab[PT_DEN * AMC_MAX_MOVES] : 0.0;
-    const double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
-    const double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
+    double sw_sigma1 = SWEEP ? sw.ptab[PT_SIGMA * AMC_MAX_MOVES] : 0.0;
+    double sw_den1 = SWEEP ? sw.ptab[PT_DEN * AMC_MAX_MOVES] : 0.0;
+    double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
+    double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
+    // a learning step the previous launch left pending (pg_apply_pending): wave-uniform
+    constexpr bool CAN_DEFER = QK && NL <= 2 && AMC_NP == 1;
+    const int pending = CAN_DEFER ? pg_pending_of(a.tail_mode) : 0;
+    __shared__ double s_pend_val[CAN_DEFER ? NL * 4 : 1];
+    __shared__ double s_def[CAN_DEFER ? NL : 1][DEF_N];
+    // ... taken HERE, before the loop's state is set up (few registers are live), with this block's first loads already under way
+    real2 x_early = {(real_t)0.0, (real_t)0.0}, b_early = {(real_t)a.beta, (real_t)a.beta};
+    if (CAN_DEFER && pending) {
+        const int64_t first_pair = (int64_t)blockIdx.x * AMC_BLOCK;
+        if (first_pair < ((a.n_chains + 1) >> 1)) {
+            x_early = load_pair_block(a.x + 2 * first_pair);
+            if (BETA) b_early = load_pair_block(a.beta_arr + 2 * first_pair);
+        }
+        // sums, rounding, learning_step!: sigma' and what derives from it land in s_def (visible after the barrier that ends
+        // stage_math_tables below)
+        pg_apply_pending(a.tail, pending, (int)((a.t_est ^ 1ull) & 1ull), pg_pending_groups_of(a.tail_mode), a.n_learn, s_pend_val, s_def, blockIdx.x == 0);
+        if (SWEEP == 2 && threadIdx.x == 0) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)                  // the pool's table in LDS: the learnable moves' rows from sigma'
+                if (l < a.n_learn) {                      // (constant indices into the kernel argument: no private copy of it)
+                    const int k = a.learn_ids[l];
+                    s_tab[0 * AMC_MAX_MOVES + k] = s_def[CAN_DEFER ? l : 0][DEF_SIGMA];
+                    s_tab[1 * AMC_MAX_MOVES + k] = s_def[CAN_DEFER ? l : 0][DEF_DEN];
+                    s_tab[2 * AMC_MAX_MOVES + k] = s_def[CAN_DEFER ? l : 0][DEF_LOGC];
+                    s_tab[4 * AMC_MAX_MOVES + k] = s_def[CAN_DEFER ? l : 0][DEF_RDEN];
+                }
+        }
+    }
     unsigned long long wave_acc = 0;
     // the Box-Muller polynomials' addend coefficients as live 64-bit VGPR values (amc_math.h, MathK): this kernel has no scalar
     // registers to spare, and a literal addend costs a v_mov_b64 per fma here (18 per pair-iteration before)
@@ -2810,8 +2934,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     auto load_x = [&](int64_t b) -> real2 { return load_pair_block(a.x + 2 * b); };
     auto load_b = [&](int64_t b) -> real2 { return load_pair_block(a.beta_arr + 2 * b); };
     const int64_t first = (int64_t)blockIdx.x * AMC_BLOCK;
-    real2 x_nxt = {(real_t)0.0, (real_t)0.0}, b_nxt = {(real_t)a.beta, (real_t)a.beta};
-    if (first < n_pairs) {
+    real2 x_nxt = x_early, b_nxt = b_early;
+    if (!pending && first < n_pairs) {
         x_nxt = load_x(first);
         if (BETA) b_nxt = load_b(first);
     }
@@ -2820,7 +2944,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
 #endif
     // the accumulators' constants, formed with the first load in flight: they need sigma's value at once -- a scalar load of a table the
     // previous launch's learning step has just rewritten, and a wait
-    if (QK) {
+    auto start_accumulators = [&]() {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             uint64_t cb[4] = {0, 0, 0, 0};
@@ -2831,10 +2955,31 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                 if ((threadIdx.x & 63) == 0) q_slot_clear(s_gq[threadIdx.x >> 6][QK ? l * 4 + i : 0]);
             }
         }
+    };
+    if (QK) {
+        if (!pending) start_accumulators();
     } else {
         r_init(gr, s_gr[threadIdx.x >> 6]);
     }
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);      // overlaps the latency of the first load
+    if (CAN_DEFER && pending) {
+        auto uni = [](double v) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)b), hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(b >> 32));
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        if (SWEEP == 1 || SWEEP == 3) {                      // K == 1: the pool's only move is the one that learns
+            sw_sigma1 = uni(s_def[0][DEF_SIGMA]); sw_den1 = uni(s_def[0][DEF_DEN]); sw_logc1 = uni(s_def[0][DEF_LOGC]); sw_rden1 = uni(s_def[0][DEF_RDEN]);
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (l < a.n_learn) {
+                c_sg[l] = uni(s_def[CAN_DEFER ? l : 0][DEF_SIGMA]); c_hi[l] = uni(s_def[CAN_DEFER ? l : 0][DEF_C3HI]);
+                c_lo[l] = uni(s_def[CAN_DEFER ? l : 0][DEF_C3LO]); c_c1[l] = uni(s_def[CAN_DEFER ? l : 0][DEF_DLHALF]);
+                gd_es[l] = __builtin_amdgcn_readfirstlane(xs::xs_gd_es(c_sg[l]));
+            }
+        start_accumulators();
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): first load drained once (see sweep_kernel)
     real2 x_done = {(real_t)0.0, (real_t)0.0};
     int64_t base_done = -1;
@@ -2888,12 +3033,13 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         // layout [group][column][block of the group][ROW words]: the wave that adds a column up reads consecutive rows
         col.store_row(a.partials + (((int64_t)(blockIdx.x / PG_GROUP) * NV + threadIdx.x) * PG_GROUP + blockIdx.x % PG_GROUP) * ROW);
     }
-    if (a.tail_mode == 0) return;
+    const int tail_mode = pg_tail_of(a.tail_mode);
+    if (tail_mode == 0) return;
     const PgTail* const tl = a.tail;       // loaded here, not at kernel entry (see PgArgs)
     // the pointers the tail works through, fetched together NOW (one far-memory round trip, under the wait for the row's stores)
     // instead of one dependent load at each first use between the tickets
     uint32_t* const tickets = tl->tickets;
-    xs_word* const group_sums = tl->group_sums;
+    xs_word* const group_sums = tl->group_sums + (int64_t)(a.t_est & 1ull) * PG_PARITY_WORDS;      // group rows by the parity of the estimator step
     double* const tail_out = tl->out;
     const int tail_rank = tl->rank, tail_ranks = tl->n_ranks;
     asm volatile("" ::"v"(tickets), "v"(group_sums), "v"(tail_out), "v"(tail_rank), "v"(tail_ranks));
@@ -2924,10 +3070,23 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         const PgCol<QK> col = pg_col_total<QK>(a.partials + ((int64_t)grp * NV + c) * PG_GROUP * ROW, n_rows, ROW);
         if (lane0) col.store_row(group_sums + ((int64_t)c * PG_GROUP + grp) * ROW);          // [column][group][ROW words]
     }
+    if (tail_mode == PG_TAIL_GROUPS) {
+        // the rest -- adding up the group rows, rounding, the learning step -- is the next launch's (pg_apply_pending)
+        if (threadIdx.x == 0) __hip_atomic_store(tickets + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     // the quantum exponent of this wave's first column: the last block rounds with it -- formed here, under the ticket's latency,
     // not between the ticket and the group rows' loads (two dependent loads: 0.4 us on the launch's critical path)
+    // (from the sigma this launch USED: the table's, or -- a launch that took a pending step in its prologue -- sigma')
+    auto sigma_used = [&](int l) -> double {
+        if (!HOIST) return a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]];
+        double v = c_sg[0];
+#pragma unroll
+        for (int k = 1; k < NL; ++k) v = l == k ? c_sg[k] : v;
+        return v;
+    };
     int e_first = 0;
-    if (QK && wave < nv) e_first = xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[wave >> 2]]).e[wave & 3];
+    if (QK && wave < nv) e_first = xs::xs_gd_exponent_of(sigma_used(wave >> 2), wave & 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2939,9 +3098,9 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     if (s_role != 2) return;
     for (int c = wave; c < nv; c += AMC_BLOCK / 64) {          // lanes = the groups (at most 64: the host caps the grid)
         const int l = c >> 2, i = c & 3;
-        const int e = !QK ? 0 : c == wave ? e_first : xs::xs_gd_exponents(a.ptab[PT_SIGMA * AMC_MAX_MOVES + a.learn_ids[l]]).e[i];
+        const int e = !QK ? 0 : c == wave ? e_first : xs::xs_gd_exponent_of(sigma_used(l), i);
         const PgCol<QK> col = pg_col_total<QK>(group_sums + (int64_t)c * PG_GROUP * ROW, n_groups, ROW);
-        if (lane0 && a.tail_mode == 1) {
+        if (lane0 && tail_mode == 1) {
             // records: this shard's slot filled, the other shards' slots zeroed (the all-reduce that follows is a gather)
             for (int r = 0; r < tail_ranks; ++r) {
                 double* rec = tail_out + ((size_t)r * nv + c) * xs::XS_WORDS;
@@ -2960,13 +3119,19 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         // 62.4 against 61.4 us per fused time step -- the loads sit on the path from the group sums to the ticket)
 #if AMC_NP > 1
         // a policy with several parameters: the launch's one learnable move (the host sees to it), its 1 + 2P + P(P+1)/2 totals
-        if (a.tail_mode >= 2)
-            pg_tail_np(s_tot, AMC_NP, tl->learn_ids[0], tl->n_samples, a.tail_mode >= 3, tl->opt.kind[0], tl->opt.h0[0], tl->opt.h1[0],
+        if (tail_mode >= 2)
+            pg_tail_np(s_tot, AMC_NP, tl->learn_ids[0], tl->n_samples, tail_mode >= 3, tl->opt.kind[0], tl->opt.h0[0], tl->opt.h1[0],
                        tl->ptab_rw, tl->gd_acc, tl->status);
 #else
-        if (a.tail_mode >= 3)
-            pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status, s_tot, tl->n_samples);
-        else if (a.tail_mode >= 2)
+        if (tail_mode >= 3) {
+            // (theta: the sigma this launch proposed with -- in registers; the table's, or sigma' of a pending step)
+            double th[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) th[l] = HOIST ? c_sg[l] : 0.0;
+            pg_update_all(tl->ptab_rw, tl->gd_acc, a.n_learn, tl->learn_ids, tl->opt, tl->n_moves, tl->status, s_tot, tl->n_samples,
+                          (HOIST && pending) ? th : nullptr);
+        }
+        else if (tail_mode >= 2)
             for (int l = 0; l < a.n_learn; ++l) pg_accumulate_one(s_tot, l, tl->learn_ids[l], tl->n_samples, tl->gd_acc);
 #endif
     }

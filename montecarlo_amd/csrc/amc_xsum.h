@@ -173,6 +173,12 @@ AMC_XS_HD GdExponents xs_gd_exponents_es(int es)
     g.e[3] = 15 - 2 * es - drop;
     return g;
 }
+// column i's exponent by itself (an index that is not a constant would put the four of them in private memory)
+AMC_XS_HD int xs_gd_exponent_of(double sigma, int i)
+{
+    const int es = xs_gd_es(sigma), drop = 51 - XS_GD_CAP_BITS;
+    return i == 0 ? 2 * es + 7 - drop : i == 1 ? es + 13 - drop : i == 2 ? 8 - es - drop : 15 - 2 * es - drop;
+}
 AMC_XS_HD GdExponents xs_gd_exponents(double sigma)
 {
     const int es = xs_gd_es(sigma);

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Developer tool, run on the GPU box (gpurun -- 'bash tools/gpu_profile.sh'): rocprofv3 kernel-trace summaries and
 # PMC passes (own runs, counters only) of bench.py and of the workloads of tools/gpu_workload.py; tools/summarize_profiles.py
-# turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r04).
+# turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r05).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${AMC_ROUND_TAG:-r04}
+TAG=${AMC_ROUND_TAG:-r05}
 export AMC_ROUND_TAG=$TAG
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
@@ -16,7 +16,9 @@ rocprofv3 --kernel-trace --stats -d $O/bench_trace --output-format csv -- python
 echo "bench trace done"
 W="python3 $R/tools/gpu_workload.py"
 export PIPELINED=1      # callbacks read one period late, as the host mirror's StoreCallbacks does; the at-once figure is logged next to it
-for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "est"; do
+# k2 / pgmc: BASELINE configs 3 / 5 (callbacks every 10 ask for sum e: COLS=1, the callbacks of those configs); vec1 / vec / mixed: the PGMC
+# time step of a script-defined one-parameter policy, of the two-parameter drift + width policy, of a two-class pool (round 5)
+for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "est" "vec1" "vec" "mixed"; do
   tag=$(echo $wl | tr ' ' '_')
   rocprofv3 --kernel-trace --stats -d $O/$tag/trace --output-format csv -- $W $wl > $O/$tag.log 2>&1
   case $wl in k2|pgmc) PIPELINED=0 $W $wl 2>&1 | tail -1 | sed 's/^/unprofiled, callback read at once: /' >> $O/$tag.log

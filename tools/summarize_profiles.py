@@ -13,14 +13,19 @@
 """
 import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("AMC_ROUND_TAG", "r04")
+TAG = os.environ.get("AMC_ROUND_TAG", "r05")
 G = os.path.join(ROOT, "gpurun_out", TAG)
 OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
 os.makedirs(OUT, exist_ok=True)
 ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
-              "k2": 165_000_000, "pgmc": 165_000_000, "est": 16 * 10_000_000}     # 16 B of state + half a step-log byte per update
+              "k2": 165_000_000, "pgmc": 165_000_000, "est": 16 * 10_000_000,     # 16 B of state + half a step-log byte per update
+              "vec1": 165_000_000, "vec": 165_000_000, "mixed": 165_000_000}
 MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, false>", "k2": "sweep_kernel<1, true, 1, false, true",
-        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false, false>"}
+        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false, false>",
+        # hiprtc forms (POT_CUSTOM = 2 names the script-defined family): the fused time step of the one- / two-parameter script
+        # policy, the per-move estimator launch of the two-class pool
+        "vec1": "pg_estimate_kernel<2, 1, false, 1, false, false>", "vec": "pg_estimate_kernel<2, 1, false, 1, false, false>",
+        "mixed": "pg_estimate_kernel<2, 1, false, 0, false, false>"}
 
 
 def one(pattern):
@@ -51,6 +56,11 @@ for wl in ALGO_BYTES:
         shutil.copy(late, os.path.join(OUT, f"{TAG}_{wl}_late_kernel_stats.csv"))
     main = MAIN[wl.split("_")[0]]
     entry = collections.OrderedDict()
+    # every kernel of the path the workload launched at least five times: name -> calls, average / minimum us (the forms that
+    # also leave the callback sums, the folds of the step log, the small single-thread launches)
+    entry["kernels"] = collections.OrderedDict(
+        (r["Name"].replace("void amc::", "").split("(")[0], dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3))
+        for r in csv.DictReader(open(f)) if "amc::" in r["Name"] and int(r["Calls"]) >= 5)
     rows = [r for r in csv.DictReader(open(f)) if main in r["Name"]]
     if rows:
         # (the K = 2 workload launches two forms of the sweep kernel: plain, and with the callback sums every 10th step)
@@ -89,7 +99,7 @@ for wl in ALGO_BYTES:
         d["wait_inst_any_over_wave_cycles"] = counters.get("SQ_WAIT_INST_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
         d["wait_any_over_wave_cycles"] = counters.get("SQ_WAIT_ANY", 0) / max(counters.get("SQ_WAVE_CYCLES", 1), 1)
     if "SQ_INSTS_VALU" in counters and meta:
-        m_pairs = (10_000_000 if wl in ("k2", "pgmc") else ALGO_BYTES[wl] // 16) // 2
+        m_pairs = (10_000_000 if wl in ("k2", "pgmc", "vec1", "vec", "mixed") else ALGO_BYTES[wl] // 16) // 2
         d["valu_insts_per_pair_step"] = counters["SQ_INSTS_VALU"] * 64.0 / m_pairs / 64.0 * 64.0 / 64.0 * 1.0
         d["valu_insts_per_wave_iteration"] = counters["SQ_INSTS_VALU"] / (m_pairs / 64.0)
         for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
@@ -104,7 +114,7 @@ for wl in ALGO_BYTES:
     entry["derived"] = d
     log = os.path.join(G, wl + ".log")
     if os.path.exists(log):
-        entry["workload_line"] = [ln.strip() for ln in open(log) if ln.startswith(("ladder", "k2", "pgmc", "est"))][-1:]
+        entry["workload_line"] = [ln.strip() for ln in open(log) if ln.startswith(("ladder", "k2", "pgmc", "est", "vec", "mixed"))][-1:]
     summary[wl] = entry
 commit = os.environ.get("AMC_COMMIT") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 summary["_meta"] = dict(commit=commit, kernel_source_hash=kernel_hash(),
