@@ -157,6 +157,7 @@ struct amc_handle {
     int red_blocks = 0;
     int red_cols = amc::RED_WANT_ALL;   // the callback sums a reduction forms (amc_set_reduce_columns)
     bool wide_red_rows = false;         // env AMC_WIDE_RED_ROWS=1 (read at amc_create; tests): the wide row form whatever the launch
+    bool shard_route_one_rank = false;  // env AMC_SHARD_ROUTE_ON_ONE_RANK=1 (measurement, tests): a communicator of one rank takes the route of several
     bool no_deferred_update = false;    // env AMC_NO_DEFERRED_UPDATE=1 (read at amc_create; tests, A/B): every fused time step takes its own learning step
     int n_cu = 256;
     int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
@@ -1014,6 +1015,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     }
     if (const char* env = std::getenv("AMC_EXACT_ACCEPT")) h->exact_accept = std::atoi(env) != 0;
     if (const char* env = std::getenv("AMC_WIDE_RED_ROWS")) h->wide_red_rows = std::atoi(env) != 0;
+    if (const char* env = std::getenv("AMC_SHARD_ROUTE_ON_ONE_RANK")) h->shard_route_one_rank = std::atoi(env) != 0;
     if (const char* env = std::getenv("AMC_NO_DEFERRED_UPDATE")) h->no_deferred_update = std::atoi(env) != 0;
     h->M = cfg->n_chains;
     // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
@@ -2440,7 +2442,10 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         tl.n_moves = h->K;
         tl.rank = h->comm ? h->comm_rank : 0;
         tl.n_ranks = h->comm ? h->comm_ranks : 1;
-        for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
+        // (a launch that only leaves records -- one per learnable move of a several-parameter policy or a pool of classes -- reads
+        // neither the ids nor the optimisers from the record: kept out, or every such launch would rewrite it, 4.7 us each)
+        if (tail != 1 || !per_move_launches(h))
+            for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
         // a learning step the previous fused launch left pending: this launch takes it in its prologue if it is the very next
         // estimator step, of a kernel form that can, under the same record (learnable moves, optimisers, sample count) --
@@ -2650,8 +2655,9 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
         }
         return AMC_OK;
     }
-    // (a communicator of ONE rank: its all-reduce is the identity -- the single-shard forms, no collective)
-    const bool shards = h->comm && h->comm_ranks > 1;
+    // (a communicator of ONE rank: its all-reduce is the identity -- the single-shard forms, no collective; AMC_SHARD_ROUTE_ON_ONE_RANK=1
+    // sends it down the shards' route all the same: the only way to time that route's launches and collective on a one-GPU box)
+    const bool shards = h->comm && (h->comm_ranks > 1 || h->shard_route_one_rank);
     // A fused time step that also updates may leave the learning step to the next launch's prologue (amc::pg_apply_pending,
     // round 5): the tail then ends at the group sums -- between shards: at this shard's records and the all-reduce behind them --
     // instead of going on through the second level of sums, a ticket and the update (single shard: 63.3 -> 62.5 us per

@@ -5,6 +5,8 @@
   k2           BASELINE config 3 shape: double well, K = 2 (sigma 0.1 / 1.0), one launch per sweep, callbacks every 10
   pgmc         BASELINE config 5: amc_pgmc_steps at 1e7 chains (fused sweep + estimator + update per step), callbacks every 10
   est          the estimator launch alone (amc_pg_accumulate) on the config-5 pool
+  vec / vec1 / mixed   PGMC time steps of a two-parameter policy, its one-parameter script twin, a pool of two policy classes
+Environment: LAUNCHES, PIPELINED, PRECOUNT, COLS (which sums the callbacks ask for), COMM=1 (pgmc: connect a one-rank communicator).
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,6 +87,8 @@ elif mode in ("pgmc", "est"):
     e.init_uniform(-2, 2)
     want_columns(e)
     precount(e, M)
+    if os.environ.get("COMM", "0") == "1":                # a communicator of one rank (AMC_SHARD_ROUTE_ON_ONE_RANK=1: on the shards' route)
+        e.comm_init(0, 1, A.HipEngine.comm_unique_id())
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.5:
         (e.pgmc_steps(20, [1], 1, [1], [0.0], [0.0]) if mode == "pgmc" else [e.pg_accumulate([1], 1) for _ in range(20)])
