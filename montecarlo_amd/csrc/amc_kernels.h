@@ -149,6 +149,9 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
 //   AMC_USER_PERFORM(x, delta)    the position after perform_action!(system, action)        (displacement: x + delta)
 //   AMC_USER_INVERT(delta, x)     the parameter of the inverted action, given the NEW state (displacement: -delta)
 // perform_action_cached! (the revert) re-applies the inverted action, as the reference does (metropolis.jl:119,187).
+struct UserTheta {          // a script-defined policy's parameters theta1 .. theta3 of one move (see AMC_USER_THETAS)
+    double t1, t2, t3;
+};
 #ifdef AMC_USER_LOGQ
 #ifndef AMC_USER_PERFORM
 #define AMC_USER_PERFORM(x, delta) ((x) + (delta))
@@ -215,17 +218,47 @@ __device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const doub
     return (real_t)(AMC_USER_INVERT(delta, x));
 #endif
 }
-// The move's further parameters (AMC_NP > 1) live in an LDS copy of their table rows, staged by the kernels that propose
-// (stage_user_theta); the expressions see them as theta1 .. theta3, and theta0 is another name of sigma.  k: the move.
+// The move's further parameters (AMC_NP > 1): the expressions see them as theta1 .. theta3, and theta0 is another name of sigma.
+// They reach the user_* functions as a UserTheta VALUE.  Where the move is the same for the whole wave -- the K == 1 sweep, the
+// estimator (its launch's learnable move) -- the kernel reads them once, at its start, through the scalar unit
+// (user_theta_uniform): every subexpression of the script that depends on the parameters alone (log(theta1), 1/theta1,
+// theta1*theta1*theta1, the reciprocal refinements of a division by them) is then a loop invariant the compiler forms ONCE per
+// wave.  (Round 5: read from the LDS copy at every use, as the K > 1 sweep must -- its lanes hold different moves --, none of it
+// could leave the loop, and the two-parameter drift + width policy paid ~1070 vector instructions per wave-trip.)
 #if AMC_NP > 1
 __shared__ double s_user_theta[AMC_MAX_NP - 1][AMC_MAX_MOVES];
-#define AMC_USER_THETAS(k)                                                                                             \
-    const double theta0 = sigma, theta1 = s_user_theta[0][(k) & 0xFF], theta2 = AMC_NP > 2 ? s_user_theta[1][(k) & 0xFF] : 0.0, \
-                 theta3 = AMC_NP > 3 ? s_user_theta[2][(k) & 0xFF] : 0.0;                                              \
+#define AMC_USER_THETAS(th)                                                                                            \
+    const double theta0 = sigma, theta1 = (th).t1, theta2 = (th).t2, theta3 = (th).t3;                                  \
     (void)theta0; (void)theta1; (void)theta2; (void)theta3
 #else
-#define AMC_USER_THETAS(k) const double theta0 = sigma; (void)theta0; (void)k
+#define AMC_USER_THETAS(th) const double theta0 = sigma; (void)theta0; (void)th
 #endif
+// k: the move key (user_move_key).  Per lane, from the LDS copy staged by stage_user_theta:
+__device__ __forceinline__ UserTheta user_theta_lds(int k)
+{
+    UserTheta th = {0.0, 0.0, 0.0};
+#if AMC_NP > 1
+    th.t1 = s_user_theta[0][k & 0xFF];
+    if (AMC_NP > 2) th.t2 = s_user_theta[1][k & 0xFF];
+    if (AMC_NP > 3) th.t3 = s_user_theta[2][k & 0xFF];
+#else
+    (void)k;
+#endif
+    return th;
+}
+// ... and of a move the whole wave shares (k wave-uniform), from the parameter table itself: scalar loads
+__device__ __forceinline__ UserTheta user_theta_uniform(const double* ptab, int k)
+{
+    UserTheta th = {0.0, 0.0, 0.0};
+#if AMC_NP > 1
+    th.t1 = ptab[PT_THETA1 * AMC_MAX_MOVES + (k & 0xFF)];
+    if (AMC_NP > 2) th.t2 = ptab[(PT_THETA1 + 1) * AMC_MAX_MOVES + (k & 0xFF)];
+    if (AMC_NP > 3) th.t3 = ptab[(PT_THETA1 + 2) * AMC_MAX_MOVES + (k & 0xFF)];
+#else
+    (void)ptab; (void)k;
+#endif
+    return th;
+}
 __device__ __forceinline__ void stage_user_theta(const double* ptab)       // before a barrier the caller already has
 {
 #if AMC_NCLASS > 1
@@ -256,18 +289,18 @@ __device__ __forceinline__ int user_move_key_uniform(int k, const double* ptab) 
     return k;
 #endif
 }
-__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_, int k)
+__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th)
 {
-    AMC_USER_THETAS(k);
+    AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
     AMC_BY_CLASS(k, real_t, AMC_USER_SAMPLE(z, x, sigma), AMC_USER_SAMPLE_1(z, x, sigma), AMC_USER_SAMPLE_2(z, x, sigma), AMC_USER_SAMPLE_3(z, x, sigma));
 #else
     return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
 #endif
 }
-__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k)
+__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th)
 {
-    AMC_USER_THETAS(k);
+    AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
     AMC_BY_CLASS(k, double, AMC_USER_LOGQ(delta, x, sigma), AMC_USER_LOGQ_1(delta, x, sigma), AMC_USER_LOGQ_2(delta, x, sigma), AMC_USER_LOGQ_3(delta, x, sigma));
 #else
@@ -275,9 +308,10 @@ __device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma
 #endif
 }
 // grad log_proposal_density with respect to the parameters, d[p] = d logq / d theta_p
-__device__ __forceinline__ void user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, double (&d)[AMC_NP])
+__device__ __forceinline__ void user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th,
+                                           double (&d)[AMC_NP])
 {
-    AMC_USER_THETAS(k);
+    AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
     d[0] = [&]() -> double {
         AMC_BY_CLASS(k, double, AMC_USER_DLOGQ_0(delta, x, sigma), AMC_USER_DLOGQ_1(delta, x, sigma), AMC_USER_DLOGQ_2(delta, x, sigma),
@@ -405,11 +439,44 @@ __device__ __forceinline__ FilterCmp accept_filter(real_t dlogp, uint32_t k)
     return c;
 }
 
+// The same filter for a decision whose ARGUMENT is known in full -- the script-defined proposals below form arg = (dlogp + logq_b) -
+// logq_f in the reference's operations, nothing cancels -- : what the filter saves there is exp(arg) in Float64 and the accept draw
+// (a second Philox call per pair and step), for all but the ~1.5 % of wave-steps it leaves open.  pos is the exact comparison;
+// t = RN_f32(arg) moves the estimate's argument by at most 17 * 2^-24 = 1.0e-6, inside AMC_FILTER_EPS with the 3.1e-6 of the estimate
+// itself.  arg = NaN or -Inf: fmaxf returns -17, the filter rejects for k >= 1 -- as the exact form does (no comparison with a NaN
+// holds, and below -708 the exact form rejects) -- and leaves k = 0 open.
+__device__ __forceinline__ FilterCmp accept_filter_arg(double arg, uint32_t k)
+{
+    const float t = (float)arg;
+    const float ex = __builtin_amdgcn_exp2f(__builtin_fmaxf(t, -17.0f) * 0x1.715476p+0f);
+    const float kf = (float)k;
+    constexpr float SCALE = 4096.0f;
+    const float lo1 = __builtin_fmaf(ex, (1.0f - AMC_FILTER_EPS) * SCALE, -1.0f);
+    const float hi = ex * ((1.0f + AMC_FILTER_EPS) * SCALE);
+    FilterCmp c;
+    c.pos = arg >= 0.0;
+    c.lo = lo1 > kf;
+    c.hi = hi < kf;
+    return c;
+}
+// the reference-ordered decision from arg and the full uniform: alpha = min(1, exp(arg)) > u (metropolis.jl:183-185)
+__device__ __forceinline__ bool accept_exact_arg(double arg, double u, const double* T)
+{
+    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
+    return c_pos | (c_rng & c_exp);
+}
+// What one mc_step! of a script-defined proposal leaves for the decision: the proposed state, the state after perform_action_cached!
+// (the revert: the inverted action applied to the proposed state) and the argument of the acceptance probability.
+struct ScriptStep {
+    real_t xn, xr;
+    double arg;
+};
+
 #ifdef AMC_USER_SCALE
-// One mc_step! with the state-dependent proposal width above, in the reference's operation order.  No filter: the
-// proposal ratio does not cancel, so arg has no cheap estimate; every decision takes the exact arithmetic.
+// One mc_step! with the state-dependent proposal width above, in the reference's operation order, up to the decision (mh_pair:
+// the proposal ratio does not cancel, arg is formed in full and the filter takes it as it is, accept_filter_arg).
 template <int POT>
-__device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, double z, double u, const double* T)
+__device__ __forceinline__ ScriptStep mh_scaled(real_t x, real_t beta, double sigma, double z, const double* T)
 {
     const double TWO_PI = 0x1.921fb54442d18p+2;
     const double sc = sigma * user_scale(x, T);
@@ -424,33 +491,33 @@ __device__ __forceinline__ bool mh_scaled(real_t& x, real_t beta, double sigma, 
     const double scn = sigma * user_scale(xn, T);
     const double scn2 = scn * scn;
     const double logq_b = ((double)(-(nd * nd))) / (2.0 * scn2) - log_f64(TWO_PI * scn2) / 2.0;
-    const double arg = ((double)dlogp + logq_b) - logq_f;
-    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
-    const bool acc = c_pos | (c_rng & c_exp);
-    x = acc ? xn : (real_t)(xn + nd);
-    return acc;
+    ScriptStep st;
+    st.arg = ((double)dlogp + logq_b) - logq_f;
+    st.xn = xn;
+    st.xr = (real_t)(xn + nd);
+    return st;
 }
 #endif
 
 #ifdef AMC_USER_LOGQ
 // One mc_step! with a script-defined proposal (see user_sample / user_logq), in the reference's operation order
-// (metropolis.jl:176-190).
+// (metropolis.jl:176-190), up to the decision (mh_pair).
 template <int POT>
-__device__ __forceinline__ bool mh_script(real_t& x, real_t beta, double sigma, double z, double u, const double* T, int k)
+__device__ __forceinline__ ScriptStep mh_script(real_t x, real_t beta, double sigma, double z, const double* T, int k, const UserTheta& th)
 {
-    const real_t delta = user_sample(z, x, sigma, T, k);                 // :177 sample_action!
-    const double logq_f = user_logq(delta, x, sigma, T, k);              // :178
+    const real_t delta = user_sample(z, x, sigma, T, k, th);             // :177 sample_action!
+    const double logq_f = user_logq(delta, x, sigma, T, k, th);          // :178
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T, k);                      // :179 perform_action!
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
     const real_t nd = user_invert(delta, xn, T, k);                      // :181 invert_action!
-    const double logq_b = user_logq(nd, xn, sigma, T, k);                // :182
-    const double arg = ((double)dlogp + logq_b) - logq_f;                // :183
-    const bool c_pos = arg >= 0.0, c_rng = arg >= -708.0, c_exp = exp_core_f64(arg, T) > u;
-    const bool acc = c_pos | (c_rng & c_exp);
-    x = acc ? xn : user_perform(xn, nd, T, k);                           // :187 perform_action_cached!
-    return acc;
+    const double logq_b = user_logq(nd, xn, sigma, T, k, th);            // :182
+    ScriptStep st;
+    st.arg = ((double)dlogp + logq_b) - logq_f;                          // :183
+    st.xn = xn;
+    st.xr = user_perform(xn, nd, T, k);                                  // :187 perform_action_cached!
+    return st;
 }
 #endif
 
@@ -472,19 +539,36 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
                                         const double* s_tab, MoveExact m1, double z0, double z1, u32x4 pn, u32x4 pu,
                                         bool have_pu, u32x4 accept_ctr, uint32_t key0, uint32_t key1, const double* T,
                                         unsigned long long force_mask, uint32_t& acc_bits, unsigned long long& m0,
-                                        unsigned long long& m1_out)
+                                        unsigned long long& m1_out, const UserTheta& th1)
 {
     const uint32_t a0_12 = spare_accept12(pn, 0), a1_12 = spare_accept12(pn, 1);
 #if defined(AMC_USER_SCALE) || defined(AMC_USER_LOGQ)
     {
-        if (!have_pu) pu = philox4x32_10(accept_ctr, key0, key1);
 #ifdef AMC_USER_LOGQ
-        const bool a0 = mh_script<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T, user_move_key(MULTI ? k0 : 0));
-        const bool a1 = mh_script<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T, user_move_key(MULTI ? k1 : 0));
+        // K == 1: the pool's only move, its parameters wave-uniform values read at the kernel's start; K > 1: the lane's move
+        const int mk0 = user_move_key(MULTI ? k0 : 0), mk1 = user_move_key(MULTI ? k1 : 0);
+        const ScriptStep s0 = mh_script<POT>(xv.x, b0, sg0, z0, T, mk0, MULTI ? user_theta_lds(mk0) : th1);
+        const ScriptStep s1 = mh_script<POT>(xv.y, b1, sg1, z1, T, mk1, MULTI ? user_theta_lds(mk1) : th1);
 #else
-        const bool a0 = mh_scaled<POT>(xv.x, b0, sg0, z0, uniform_accept(a0_12, pu.x, pu.y), T);
-        const bool a1 = mh_scaled<POT>(xv.y, b1, sg1, z1, uniform_accept(a1_12, pu.z, pu.w), T);
+        const ScriptStep s0 = mh_scaled<POT>(xv.x, b0, sg0, z0, T), s1 = mh_scaled<POT>(xv.y, b1, sg1, z1, T);
 #endif
+        // round 5: the 12-bit bracket of u settles these decisions too (accept_filter_arg); exp(arg) in Float64 and the accept draw
+        // are formed by the waves in which some lane's bracket leaves its decision open, for all their lanes
+        const FilterCmp c0 = accept_filter_arg(s0.arg, a0_12), c1 = accept_filter_arg(s1.arg, a1_12);
+        const unsigned long long acc0 = __builtin_amdgcn_ballot_w64(c0.pos | c0.lo), rej0 = __builtin_amdgcn_ballot_w64(c0.hi);
+        const unsigned long long acc1 = __builtin_amdgcn_ballot_w64(c1.pos | c1.lo), rej1 = __builtin_amdgcn_ballot_w64(c1.hi);
+        const unsigned long long undecided = __builtin_amdgcn_ballot_w64(true) & ~((acc0 | rej0) & (acc1 | rej1));
+        bool a0 = c0.pos | c0.lo, a1 = c1.pos | c1.lo;
+        if ((undecided | force_mask) != 0ull) {
+            if (!have_pu) {
+                asm volatile("" : "+v"(accept_ctr.z));       // pins the second Philox call inside this arm (no speculation)
+                pu = philox4x32_10(accept_ctr, key0, key1);
+            }
+            a0 = accept_exact_arg(s0.arg, uniform_accept(a0_12, pu.x, pu.y), T);
+            a1 = accept_exact_arg(s1.arg, uniform_accept(a1_12, pu.z, pu.w), T);
+        }
+        xv.x = a0 ? s0.xn : s0.xr;
+        xv.y = a1 ? s1.xn : s1.xr;
         m0 = __builtin_amdgcn_ballot_w64(a0);
         m1_out = __builtin_amdgcn_ballot_w64(a1);
         acc_bits = (a0 ? 1u : 0u) | (a1 ? 0x100u : 0u);
@@ -1270,7 +1354,8 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
                                            int64_t p, bool v0, bool v1, const double* s_tab, const uint8_t* s_pick,
                                            const double* s_math, double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& log_word,
-                                           const StepDraws* pre = nullptr, const MathK& mk = math_k_literal())
+                                           const StepDraws* pre = nullptr, const MathK& mk = math_k_literal(),
+                                           const UserTheta& th1 = UserTheta{0.0, 0.0, 0.0})
 {
     static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
     const int K = a.n_moves;
@@ -1307,7 +1392,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
         unsigned long long m0, m1m;
         uint32_t acc_bits;
         mh_pair<POT, MULTI>(xv, b0, b1, sg0, sg1, k0, k1, s_tab, m1, z0, z1, dr.normal, pu, have_pu, accept_ctr, a.key0,
-                            a.key1, s_math, force_mask, acc_bits, m0, m1m);
+                            a.key1, s_math, force_mask, acc_bits, m0, m1m, th1);
         // K == 1: wavefront-ballot accept mask -> one scalar popcount per chain slot (pool-wide total)
         if (!MULTI) wave_acc += __popcll(m0 & __builtin_amdgcn_ballot_w64(v0)) + __popcll(m1m & __builtin_amdgcn_ballot_w64(v1));
         if (LOG) {
@@ -1357,6 +1442,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const double den1 = a.ptab[PT_DEN * AMC_MAX_MOVES];
     const double logc1 = a.ptab[PT_LOGC * AMC_MAX_MOVES];
     const double rden1 = a.ptab[PT_RDEN * AMC_MAX_MOVES];
+    UserTheta th1 = {0.0, 0.0, 0.0};
+#ifdef AMC_USER_LOGQ
+    if (!MULTI) th1 = user_theta_uniform(a.ptab, 0);
+#endif
 
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
     const int64_t stride = (int64_t)gridDim.x * AMC_BLOCK;
@@ -1419,7 +1508,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         const StepDraws dr = dr_nxt;
         uint32_t lw = 0;
         pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b0, b1, a.pair0 + (uint64_t)p, p, true, true, s_tab, s_pick, s_math,
-                                                   sigma1, den1, rden1, logc1, wave_acc, lw, &dr);
+                                                   sigma1, den1, rden1, logc1, wave_acc, lw, &dr, math_k_literal(), th1);
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
         if (REDUCE) {
@@ -1440,7 +1529,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         }
         uint32_t lw = 0;
         pair_steps<POT, MULTI, LOG, SINGLE, AHEAD>(a, xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), p, v0, v1,
-                                                   s_tab, s_pick, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt);
+                                                   s_tab, s_pick, s_math, sigma1, den1, rden1, logc1, wave_acc, lw, &dr_nxt, math_k_literal(), th1);
         // a lone last chain (odd n_chains) writes its whole pair (x and log): the odd slot is padding
         if (v0) {
             store_pair_block_writethrough(a.x + 2 * base, xv);
@@ -2205,20 +2294,21 @@ __device__ __forceinline__ void pg_sample_scaled(real_t& x, real_t beta, double 
 // at the old state (:97), of the backward density at the new state (:102); grad_j takes the forward gradient when
 // alpha == 1, else the backward one (:106).  g: the sample's four summands in the reference's operations.
 template <int POT>
-__device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[AMC_PG_NC], const double* T, int k)
+__device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double sigma, double z, double (&g)[AMC_PG_NC], const double* T, int k,
+                                                 const UserTheta& th)
 {
-    const real_t delta = user_sample(z, x, sigma, T, k);
+    const real_t delta = user_sample(z, x, sigma, T, k, th);
     double d_f[AMC_NP], d_b[AMC_NP];
-    const double logq_f = user_logq(delta, x, sigma, T, k);
-    user_dlogq(delta, x, sigma, T, k, d_f);
+    const double logq_f = user_logq(delta, x, sigma, T, k, th);
+    user_dlogq(delta, x, sigma, T, k, th, d_f);
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T, k);
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
     const real_t nd = user_invert(delta, xn, T, k);
-    const double logq_b = user_logq(nd, xn, sigma, T, k);
-    user_dlogq(nd, xn, sigma, T, k, d_b);
+    const double logq_b = user_logq(nd, xn, sigma, T, k, th);
+    user_dlogq(nd, xn, sigma, T, k, th, d_b);
     x = user_perform(xn, nd, T, k);
     const double arg = ((double)dlogp + logq_b) - logq_f;
     double ex = exp_core_f64(arg, T);
@@ -2713,6 +2803,17 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     double sw_den1 = SWEEP ? sw.ptab[PT_DEN * AMC_MAX_MOVES] : 0.0;
     double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
     double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
+    // script-defined policies: the further parameters of the sweep's only move (K == 1) and of the learnable moves, wave-uniform
+    UserTheta sw_th1 = {0.0, 0.0, 0.0};
+    UserTheta c_th[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) c_th[l] = UserTheta{0.0, 0.0, 0.0};
+#ifdef AMC_USER_LOGQ
+    if (SWEEP == 1 || SWEEP == 3) sw_th1 = user_theta_uniform(sw.ptab, 0);
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+        if (l < a.n_learn) c_th[l] = user_theta_uniform(a.ptab, a.learn_ids[l]);
+#endif
     // a learning step the previous launch left pending (pg_apply_pending): wave-uniform
     constexpr bool CAN_DEFER = QK && NL <= 2 && AMC_NP == 1;
     const int pending = CAN_DEFER ? pg_pending_of(a.tail_mode) : 0;
@@ -2750,7 +2851,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         uint32_t lw = 0;
         // SWEEP == 3: K == 1 with the pool-wide counter only -- no step log
         pair_steps<POT, SWEEP == 2, (SWEEP != 3 ? AMC_LOG_PACKED : AMC_LOG_NONE), true>(sw, xv, b0, b1, pair, p, v0, v1, s_tab, s_pick, s_math, sw_sigma1, sw_den1,
-                                                      sw_rden1, sw_logc1, wave_acc, lw, nullptr, mk);
+                                                      sw_rden1, sw_logc1, wave_acc, lw, nullptr, mk, sw_th1);
         if (SWEEP != 3 && v0) store_log_pair<AMC_LOG_PACKED>(sw, sw.log_pos, p, lw);
     };
     const int64_t n_pairs = (a.n_chains + 1) >> 1;
@@ -2895,8 +2996,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
                     for (int i = 0; i < NC; ++i) s1[i] = 0.0;
 #if defined(AMC_USER_LOGQ)
                     const int move_key = user_move_key_uniform(a.learn_ids[l], a.ptab);
-                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math, move_key);
-                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math, move_key);
+                    pg_sample_script<POT>(xv.x, b0, c_sg[l], z0, s0, s_math, move_key, c_th[l]);
+                    if (v1) pg_sample_script<POT>(xv.y, b1, c_sg[l], z1, s1, s_math, move_key, c_th[l]);
 #else
                     pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);

@@ -241,3 +241,44 @@ def test_scaling_action_bit_exact_and_half_gaussian_on_the_device(gpu, oracle):
         s += big.reduce()[:4]
     assert s[2] / s[3] == pytest.approx(0.25, abs=2e-3) and s[1] / s[3] == pytest.approx(1 / np.sqrt(np.pi * BETA), abs=2e-3)
     big.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["proposal_k1", "proposal_k2", "scaled", "classes", "two_parameters"])
+def test_accept_filter_equals_the_exact_decision_for_script_proposals(gpu, monkeypatch, case):
+    """Round 5: the decisions of script-defined proposals go through the 12-bit accept filter too (accept_filter_arg: arg is
+    formed in full, the filter saves exp(arg) and the accept draw).  2e6 chains x 300 steps = 6e8 decisions per case, once
+    filtered and once with every wave sent through the reference-ordered decision (AMC_EXACT_ACCEPT=1): positions and
+    counters must be identical -- single-step launches, the multi-step form and the fused sweep + estimator launch."""
+    M = 2_000_000
+    gauss = ("sigma*z", "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0",
+             "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma")
+    drift = ("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
+             ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"])
+    kw = dict(n_chains=M, potential="harmonic", beta=BETA, seed=23)
+    learn = [0]
+    if case == "proposal_k1":
+        kw.update(sigma=[0.4], weight=[1.0], proposal=MALA, per_chain_counters=False)
+    elif case == "proposal_k2":
+        kw.update(potential="double_well", sigma=[0.2, 0.6], weight=[0.3, 0.7], proposal=MALA)
+    elif case == "scaled":
+        kw.update(sigma=[0.4], weight=[1.0], scale_expr="0.5 + fabs(x)")
+    elif case == "classes":
+        kw.update(sigma=[0.3, 0.4], weight=[0.5, 0.5], classes=[gauss, MALA], class_of_move=[0, 1])
+    else:
+        kw.update(sigma=[[0.05, 0.5]], weight=[1.0], proposal=drift, n_params=2)
+    runs = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("AMC_EXACT_ACCEPT", exact)
+        e = gpu.HipEngine(**kw)
+        e.init_uniform(-2, 2)
+        for _ in range(20):
+            e.sweep(1)
+        e.sweep(270)
+        e.pgmc_steps(10, learn, 1, [1], [0.0], [0.0])            # fused sweep + estimator launches (eta = 0: nothing learns)
+        acc, tot = e.counter_totals()
+        runs.append((e.download_state(want_e=False)[0], np.asarray(acc), np.asarray(tot)))
+        e.close()
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert int(runs[0][2].sum()) == 300 * M and 0.2 < runs[0][1].sum() / runs[0][2].sum() < 0.99
