@@ -126,8 +126,9 @@ def kernel_source_hash():
     """Hash of the kernel sources: tells whether a committed PMC figure was taken on the kernels being timed now."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("amc_kernels.h", "amc_math.h", "amc_tables.h", "amc_xsum.h"):
-        h.update(open(os.path.join(ROOT, "montecarlo_amd", "csrc", fn), "rb").read())
+    csrc = os.path.join(ROOT, "montecarlo_amd", "csrc")
+    for fn in sorted(f for f in os.listdir(csrc) if f.startswith("amc_") and f.endswith(".h") and not f.endswith(".gen.h")):      # every kernel source
+        h.update(open(os.path.join(csrc, fn), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -4,27 +4,7 @@
 // validates arguments the way the reference's constructors assert them
 // (src/metropolis.jl:248-251, Distributions.Categorical's probability-vector check).
 // No CPU fallback: every entry point either runs on the GPU or returns an error.
-#include "../../include/amc.h"
-
-#include <hip/hip_runtime.h>
-
-#include <dlfcn.h>
-#include <time.h>
-#include <unistd.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "amc_kernels.h"
+#include "amc_internal.h"
 // defined in amc_pg_fused.hip (compiled with other code-generation options, see there): not instantiated here
 namespace amc {
 #define AMC_PG_FUSED(POT, NL, BETA)                                                                             \
@@ -41,15 +21,8 @@ AMC_PG_FUSED(POT_DOUBLE_WELL, 2, false);
 AMC_PG_FUSED(POT_DOUBLE_WELL, 2, true);
 #undef AMC_PG_FUSED
 }  // namespace amc
-#include "amc_rtc_sources.gen.h"   // the three kernel headers as string literals (Makefile), for hiprtc
 
-#ifndef AMC_BUILD_ARCH
-#define AMC_BUILD_ARCH "gfx950"      // the Makefile passes the arch the offline kernels were compiled for
-#endif
-
-namespace {
-
-thread_local std::string g_last_error;
+static thread_local std::string g_last_error;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -61,166 +34,6 @@ int fail(int code, const char* fmt, ...)
     g_last_error = buf;
     return code;
 }
-
-#define AMC_HIP(call)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(e_ == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "%s failed: %s",    \
-                        #call, hipGetErrorString(e_));                                             \
-    } while (0)
-
-// Minimal RCCL surface, resolved with dlopen so the library has no link-time RCCL
-// dependency and shares the instance a host process may already have loaded.
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // id passed by pointer (see shim)
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    int (*CommCount)(void*, int*) = nullptr;       // optional: what the communicator says about itself (amc_comm_info)
-    int (*CommUserRank)(void*, int*) = nullptr;
-    int (*GetVersion)(int*) = nullptr;
-};
-
-}  // namespace
-
-static const int RED_HOST_STRIDE = amc::RED_ROW_WORDS;   // 64-bit words per row of the callback sums' block rows (red_finish)
-static const int RATIO_STRIDE = 4;      // columns per row of the fold's acceptance-ratio partials (K <= 4): XS_ROW_Q words per move
-static const int PG_MAX_COLS = AMC_MAX_LEARN * 4;   // GradientData columns of one estimator launch
-static const int PG_NP_MAX_COLS = 1 + 2 * AMC_MAX_NP + AMC_MAX_NP * (AMC_MAX_NP + 1) / 2;   // ... of one move with AMC_MAX_NP parameters (< PG_MAX_COLS)
-static const int RED_TICKETS = 2;       // reductions that may be in flight per handle (amc_reduce_begin .. amc_reduce_end)
-
-// One reduction in flight: where its block rows land and what amc_reduce_end needs to finish it.
-struct RedTicket {
-    bool pending = false;
-    int rows = 0;                    // block rows of the sums over x in h_rows
-    int ratio_rows = 0;              // rows of h_ratio that belong to it (0: none)
-    bool ratio_acc = false;          // the per-move ratio totals come from h_ratio_acc (K > 4)
-    uint64_t t_counted = 0;
-    int row_stride = RED_HOST_STRIDE;    // words per row of h_rows: the wide form, or amc::RED_COMPACT_WORDS (red_finish)
-    int cols = amc::RED_WANT_ALL;        // the sums that were formed (amc_set_reduce_columns at the time)
-    hipEvent_t ev = nullptr;
-    amc::xs_word* h_rows = nullptr;      // pinned [n_slots][RED_HOST_STRIDE]
-    amc::xs_word* h_ratio = nullptr;     // pinned [n_slots][RATIO_STRIDE]
-    unsigned long long* d_ratio_acc = nullptr;   // [AMC_MAX_MOVES][3] (reduce_kernel, K > 4)
-    unsigned long long* h_ratio_acc = nullptr;   // pinned copy
-};
-
-struct amc_handle {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t M = 0, M_pad = 0, offset = 0, M_global = 0;
-    int potential = 0, K = 1, sweepstep = 1;
-    bool counters = false;      // per-chain counters kept
-    bool beta_arr = false;
-    double beta = 1.0;
-    uint64_t seed = 0;
-    uint64_t t = 0;             // MH steps done (Philox step index)
-    uint64_t t_counted = 0;     // MH steps counted in acc/tot since creation
-    uint64_t t_est = 0;         // estimator calls done
-    double* d_x = nullptr;
-    double* d_beta = nullptr;
-    uint32_t* d_acc = nullptr;
-    uint32_t* d_tot = nullptr;
-    // K <= 4 handles (narrow == true) keep the counters as two u16 planes instead: low halves here, high halves in *_hi;
-    // the high planes stay all zero, and untouched by the folds, until counter_room() sets use_high before the call that
-    // would count step 65 536 (fold_log_kernel<.., HIGH>).  Exactly one of the two forms is allocated.
-    uint16_t* d_acc16 = nullptr;
-    uint16_t* d_tot16 = nullptr;
-    uint16_t* d_acc_hi = nullptr;
-    uint16_t* d_tot_hi = nullptr;
-    bool narrow = false;
-    bool use_high = false;
-    // Counts beyond 32 bits (counter_rebase): what the arrays above have been carried into, nullptr until the first carry --
-    // [K][M_pad] / [K - 1][M_pad] 64-bit integers --, the steps counted with them, and their pool totals (host side)
-    unsigned long long* d_acc_base = nullptr;
-    unsigned long long* d_tot_base = nullptr;
-    uint64_t t_base = 0;
-    unsigned long long base_acc_total[AMC_MAX_MOVES] = {0}, base_tot_total[AMC_MAX_MOVES] = {0};
-    uint8_t* d_log = nullptr;   // [log_depth][M_pad / 2 or M_pad] step log: (move << 1) | accepted per chain and MH step (log_form)
-    int log_depth = 32;         // rows of the step log: 2 GiB worth, between 16 and 128 (env AMC_LOG_DEPTH, 1..255: the fold counts rows in bytes)
-    int log_fill = 0;           // rows written since the last fold into d_acc / d_tot
-    double* d_ptab = nullptr;
-    uint8_t* d_pick = nullptr;  // [AMC_PICK_CELLS] move pick by the 12 leading bits of the pick uniform (K > 1)
-    unsigned long long* d_totals = nullptr;   // [2*K]: accepted, total (K > 1, filled on demand)
-    unsigned long long* d_acc_slots = nullptr; // [max grid]: per-block accepted counts (K == 1)
-    int n_slots = 0;
-    amc::xs_word* d_partials = nullptr;   // [groups][nl * 4][PG_GROUP][words per column]: block rows of the estimator's fold
-    RedTicket red[RED_TICKETS];      // reductions in flight, oldest first from red_head
-    int red_head = 0, red_count = 0;
-    double* d_out = nullptr;    // records of the estimator's fold: [comm ranks][PG_MAX_COLS][XS_WORDS]
-    int d_out_ranks = 1;
-    double* h_pg_out = nullptr; // pinned: records of amc_pg_estimate
-    int red_blocks = 0;
-    int red_cols = amc::RED_WANT_ALL;   // the callback sums a reduction forms (amc_set_reduce_columns)
-    bool wide_red_rows = false;         // env AMC_WIDE_RED_ROWS=1 (read at amc_create; tests): the wide row form whatever the launch
-    bool shard_route_one_rank = false;  // env AMC_SHARD_ROUTE_ON_ONE_RANK=1 (measurement, tests): a communicator of one rank takes the route of several
-    bool no_deferred_update = false;    // env AMC_NO_DEFERRED_UPDATE=1 (read at amc_create; tests, A/B): every fused time step takes its own learning step
-    int n_cu = 256;
-    int blocks_per_cu = 8;      // grid cap = n_cu * blocks_per_cu blocks of 256, grid-stride beyond
-    int blocks_per_cu_single = 8;   // ... of single-step sweep launches (6 for the K = 1 pool-wide-counter form)
-    int blocks_per_cu_red = 5;      // ... of the sweep launch that also forms the callback sums (env AMC_BLOCKS_PER_CU_REDUCE)
-    int blocks_per_cu_pg = 0;       // ... of the estimator kernels when AMC_BLOCKS_PER_CU is given; 0: what a CU HOLDS of the kernel form at hand
-                                    // (hipOccupancyMaxActiveBlocksPerMultiprocessor: 5 for the built-in forms, 4 for most hiprtc ones), see pg_plan
-    int occ_query = 0;              // out-slot of a launch_pg call made with grid < 0 (a query, nothing is launched)
-    std::map<int, int> pg_resident; // resident blocks per CU of the estimator kernel forms, by (nl, sweep, reduce)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]
-    int hist_bins = 0;
-    double hist_lo = 0.0, hist_hi = 0.0;
-    hipEvent_t ev_params = nullptr;   // behind the copy queued by amc_parameters_begin
-    double* h_params = nullptr;       // pinned [AMC_MAX_NP][AMC_MAX_MOVES]: its destination (row p: parameter p of every move)
-    bool params_pending = false;
-    bool ev1_marked = false;    // amc_timing_mark recorded the end event already
-    void* comm = nullptr;
-    int comm_rank = 0, comm_ranks = 1;   // this shard's slot in record gathers (amc_comm_init's arguments)
-    int comm_capacity = 0;               // doubles d_comm / h_comm hold
-    double* d_comm = nullptr;
-    double* h_comm = nullptr;            // pinned staging of amc_allreduce_sum's values (the caller's buffer is pageable)
-    hipStream_t comm_stream = nullptr;   // amc_allreduce_sum's own stream: host-side sums must not wait for the queued sweeps
-    hipEvent_t ev_comm_main = nullptr;   // behind the last collective queued on the engine's stream (the estimator's all-reduce)
-    bool comm_main_pending = false;      // ... which comm_stream has not been ordered behind yet
-    double* d_gd_acc = nullptr;   // [AMC_MAX_MOVES][5] running GradientData per move (device-resident estimator); n_params > 1:
-                                  // [AMC_MAX_MOVES][AMC_GD_STRIDE_MAX], fields as in amc::pg_np_unpack
-    int* d_status = nullptr;      // [1] sticky flag: a learning step was rejected
-    uint32_t* d_pg_tickets = nullptr;   // [1 + groups] arrival counters of the estimator kernel's in-kernel final reduce
-    amc::xs_word* d_pg_groups = nullptr;   // [nl * 4][PG_GROUP][words per column]: group rows
-    double* d_theta_ring = nullptr;     // [2][AMC_MAX_LEARN]: sigma of the learnable moves as the fused launches of even / odd estimator steps used it
-    // A learning step a fused time step left to the next launch's prologue (amc::pg_apply_pending): what it needs to be taken --
-    // by that launch, or by pg_resolve_kernel when anything else wants the parameter table first
-    struct {
-        bool active = false;
-        int source = 0;                 // amc::PG_PENDING_GROUPS / _RECORDS
-        int groups = 0;                 // groups of PG_GROUP blocks the launch wrote
-        int n_learn = 0;
-        uint64_t t_est = 0;             // the estimator step of that launch (its parity names the ring slot and the group rows)
-    } pend;
-    bool pend_consumed = false;         // the last estimator launch took the pending step in its prologue (pg_launch)
-    uint64_t gd_nonzero = 0;            // moves whose gradients_data on the device may be non-zero (estimator steps since their last update)
-    amc::PgTail* d_pg_tail = nullptr;   // the estimator kernel's per-configuration record (see amc::PgTail)
-    amc::PgTail pg_tail_host;           // ... and what it holds now (rewritten only when it changes)
-    bool pg_tail_valid = false;
-    Rccl rccl;
-    bool exact_accept = false;    // env AMC_EXACT_ACCEPT=1: no accept filter (every decision in the reference's arithmetic)
-    std::string arch = AMC_BUILD_ARCH;   // the device's ISA name (gcnArchName up to its first ':'): what hiprtc compiles for
-    std::string pot_expr;         // AMC_POTENTIAL_CUSTOM: the C expression of potential(x); '\x02' in front: Float32 state
-    bool f32 = false;             // state_dtype == AMC_DTYPE_F32: d_x / d_beta hold floats
-    bool scaled_policy = false;   // the proposal width is sigma * scale(x) (amc_create_policy_model)
-    bool script_policy = false;   // sample_action! / log_proposal_density are script-defined expressions (amc_create_proposal_model)
-    bool script_dlogq = false;    // ... and so is d logq / d sigma: the estimator is available
-    int n_params = 1;             // parameters of the moves' policy (amc_create_policy_model; 1: sigma)
-    int n_classes = 1;            // policy / action classes of the pool (amc_create_mixed_model)
-    int class_of_move[AMC_MAX_MOVES] = {0};
-    bool use_rtc = false;         // custom potential or Float32 state: every kernel that touches x is compiled at run time
-    double* d_x64 = nullptr;      // f32 only: [M_pad] doubles, staging for uploads / downloads / host-side readers
-    std::map<std::string, hipFunction_t> rtc_fn;   // kernel instantiation -> function of a module loaded on `device`
-    std::vector<hipModule_t> rtc_mods;
-};
-
-static int pg_resolve(amc_handle* h);      // takes a pending learning step now (defined with the estimator's host code)
 
 namespace {
 
@@ -508,295 +321,6 @@ int sum_acc_slots(amc_handle* h, unsigned long long* out)
 
 int nl_capacity(int n_learn) { return n_learn <= 1 ? 1 : n_learn <= 2 ? 2 : n_learn <= 4 ? 4 : 8; }
 
-// ---- kernels compiled at run time for a user-defined potential (AMC_POTENTIAL_CUSTOM) ---------------------------
-// `potential` is a free function of the driver script in the reference (MC_harmonic_oscillator.jl:4); here it is a
-// C expression in `x`, and the templates of amc_kernels.h are instantiated for it by hiprtc (resolved with dlopen,
-// like RCCL: no link-time dependency).  One hiprtc program per kernel instantiation, compiled on first use
-// (~1 s each) and cached per process by (expression, instantiation); modules are loaded per handle (= per device).
-struct Hiprtc {
-    void* lib = nullptr;
-    int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
-    int (*AddNameExpression)(void*, const char*) = nullptr;
-    int (*CompileProgram)(void*, int, const char**) = nullptr;
-    int (*GetProgramLogSize)(void*, size_t*) = nullptr;
-    int (*GetProgramLog)(void*, char*) = nullptr;
-    int (*GetCodeSize)(void*, size_t*) = nullptr;
-    int (*GetCode)(void*, char*) = nullptr;
-    int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
-    int (*DestroyProgram)(void**) = nullptr;
-    int (*Version)(int*, int*) = nullptr;
-};
-
-std::mutex g_rtc_mu;
-Hiprtc g_hiprtc;
-struct RtcCode { std::vector<char> code; std::string lowered; };
-std::map<std::string, RtcCode> g_rtc_code;        // key: expression '\n' instantiation
-
-int load_hiprtc(Hiprtc& r)
-{
-    if (r.lib) return AMC_OK;
-    const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
-    for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
-    }
-    if (!r.lib) return fail(AMC_ERR_HIP, "custom potential: cannot dlopen libhiprtc: %s", dlerror());
-#define AMC_RTC_SYM(field, name)                                                        \
-    r.field = (decltype(r.field))dlsym(r.lib, name);                                    \
-    if (!r.field) { r.lib = nullptr; return fail(AMC_ERR_HIP, "libhiprtc is missing %s", name); }
-    AMC_RTC_SYM(CreateProgram, "hiprtcCreateProgram");
-    AMC_RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
-    AMC_RTC_SYM(CompileProgram, "hiprtcCompileProgram");
-    AMC_RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
-    AMC_RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
-    AMC_RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
-    AMC_RTC_SYM(GetCode, "hiprtcGetCode");
-    AMC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
-    AMC_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
-    AMC_RTC_SYM(Version, "hiprtcVersion");
-#undef AMC_RTC_SYM
-    return AMC_OK;
-}
-
-// The expression becomes the body of a function-like macro: keep it to one line of ordinary expression text.
-int validate_potential_expr(const char* expr, const char* what = "custom potential", const char* var = "x")
-{
-    if (!expr) return fail(AMC_ERR_BAD_ARG, "%s: expression is NULL", what);
-    const size_t n = std::strlen(expr);
-    if (n == 0 || n > 4000) return fail(AMC_ERR_BAD_ARG, "%s: expression must have 1..4000 characters", what);
-    bool has_x = false;
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char c = (unsigned char)expr[i];
-        if (c < 0x20 || c > 0x7e || c == '#' || c == '\\' || c == ';' || c == '{' || c == '}' || c == '"' || c == '\'' ||
-            c == '`' || c == '$' || c == '@')
-            return fail(AMC_ERR_BAD_ARG, "%s: character 0x%02x at offset %zu is not allowed in the expression", what, c, i);
-        const bool ident_before = i > 0 && (std::isalnum((unsigned char)expr[i - 1]) || expr[i - 1] == '_');
-        const size_t vl = std::strlen(var);
-        if (!ident_before && std::strncmp(expr + i, var, vl) == 0 &&
-            !(i + vl < n && (std::isalnum((unsigned char)expr[i + vl]) || expr[i + vl] == '_')))
-            has_x = true;
-    }
-    if (!has_x && var[0] != 0) return fail(AMC_ERR_BAD_ARG, "%s: the expression does not mention %s", what, var);
-    return AMC_OK;
-}
-
-// Optional on-disk cache of compiled code objects (AMC_RTC_CACHE_DIR; unset = in-process cache only): one file per
-// (expression, instantiation, kernel sources), named by a 64-bit FNV-1a hash of all three, holding the lowered name
-// and the code object.  A corrupt or truncated file is ignored and recompiled.
-uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
-{
-    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
-    return h;
-}
-
-std::string rtc_cache_path(const std::string& expr, const std::string& inst, const std::string& arch, const std::string& toolchain)
-{
-    const char* dir = std::getenv("AMC_RTC_CACHE_DIR");
-    if (!dir || !*dir) return std::string();
-    uint64_t h = fnv1a(expr);
-    h = fnv1a(inst, h ^ 0x9E3779B97F4A7C15ull);
-    h = fnv1a(arch, h ^ 0xC2B2AE3D27D4EB4Full);          // a code object is good for one ISA ...
-    h = fnv1a(toolchain, h);                              // ... and one compiler release
-    h = fnv1a(AMC_RTC_SRC_KERNELS, h);
-    h = fnv1a(AMC_RTC_SRC_MATH, h);
-    h = fnv1a(AMC_RTC_SRC_TABLES, h);
-    h = fnv1a(AMC_RTC_SRC_XSUM, h);
-    char name[64];
-    std::snprintf(name, sizeof(name), "/amc_rtc_%016llx.bin", (unsigned long long)h);
-    return std::string(dir) + name;
-}
-
-bool rtc_cache_load(const std::string& path, RtcCode* out)
-{
-    if (path.empty()) return false;
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    uint64_t hdr[3] = {0, 0, 0};                       // magic, name length, code length
-    bool ok = std::fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == 0x31435452434d41ull && hdr[1] > 0 && hdr[1] < 4096 &&
-              hdr[2] > 0 && hdr[2] < (1ull << 30);
-    if (ok) {
-        out->lowered.resize((size_t)hdr[1]);
-        out->code.resize((size_t)hdr[2]);
-        ok = std::fread(&out->lowered[0], 1, (size_t)hdr[1], f) == hdr[1] &&
-             std::fread(out->code.data(), 1, (size_t)hdr[2], f) == hdr[2] && std::fgetc(f) == EOF;
-    }
-    std::fclose(f);
-    return ok;
-}
-
-void rtc_cache_store(const std::string& path, const RtcCode& rc)
-{
-    if (path.empty()) return;
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return;                                    // an unwritable cache directory is not an error
-    const uint64_t hdr[3] = {0x31435452434d41ull, rc.lowered.size(), rc.code.size()};
-    const bool ok = std::fwrite(hdr, sizeof(hdr), 1, f) == 1 && std::fwrite(rc.lowered.data(), 1, rc.lowered.size(), f) == rc.lowered.size() &&
-                    std::fwrite(rc.code.data(), 1, rc.code.size(), f) == rc.code.size();
-    std::fclose(f);
-    if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());   // atomic publish
-}
-
-// Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
-// Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
-int rtc_compile(const std::string& expr_in, const std::string& inst, const std::string& arch, const RtcCode** out, std::string* log_out)
-{
-    std::lock_guard<std::mutex> lock(g_rtc_mu);
-    const std::string key = arch + "\n" + expr_in + "\n" + inst;
-    auto it = g_rtc_code.find(key);
-    if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
-    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
-    int rtc_major = 0, rtc_minor = 0;
-    (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
-    // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
-    // (decided from the instantiation's FOURTH template argument, SWEEP == 2 -- `<POT, NL, BETA, SWEEP, REDUCE, MIDFLUSH>`: a
-    // substring test would also catch NL = 2 followed by BETA)
-    const bool licm_off = [&] {
-        const std::string head = "amc::pg_estimate_kernel<";
-        if (inst.rfind(head, 0) != 0) return false;
-        size_t at = head.size();
-        for (int arg = 0; arg < 3; ++arg) {
-            at = inst.find(',', at);
-            if (at == std::string::npos) return false;
-            ++at;
-        }
-        const size_t end = inst.find_first_of(",>", at);
-        return end != std::string::npos && inst.substr(at, end - at) == "2";
-    }();
-    const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
-                                                                           (licm_off ? " licm-off" : ""));
-    {
-        RtcCode cached;
-        if (rtc_cache_load(cache_file, &cached)) {
-            if (log_out) log_out->clear();
-            *out = &g_rtc_code.emplace(key, std::move(cached)).first->second;
-            return AMC_OK;
-        }
-    }
-    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ]
-    //             [ '\x07' perform ] [ '\x08' invert ] ] ]
-    const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
-    const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
-    std::string expr = expr_full;
-    std::string src;
-    if (f32) src += "#define AMC_STATE_F32 1\n";
-    auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
-        const size_t at = expr.find(mark);
-        if (at == std::string::npos) return std::string();
-        const std::string tail = expr.substr(at + 1);
-        expr.erase(at);
-        return tail;
-    };
-    const std::string e_classes = cut_tail('\x0f');      // [ '\x0f' n_classes { sections of the classes 1 .. } ]: pools that mix policies / actions
-    const std::string e_np = cut_tail('\x0e');           // [ '\x0e' P ]: parameters of the policy, when more than one; the dlogq section then holds P
-                                                         // expressions, '\x0b' between them
-    const std::string e_invert = cut_tail('\x08'), e_perform = cut_tail('\x07');
-    const std::string e_dlogq = cut_tail('\x06'), e_logq = cut_tail('\x05'), e_sample = cut_tail('\x04'), e_scale = cut_tail('\x03');
-    if (!e_perform.empty()) src += "#define AMC_USER_PERFORM(x, delta) (" + e_perform + ")\n";
-    if (!e_invert.empty()) src += "#define AMC_USER_INVERT(delta, x) (" + e_invert + ")\n";
-    if (!e_sample.empty()) src += "#define AMC_USER_SAMPLE(z, x, sigma) (" + e_sample + ")\n";
-    if (!e_logq.empty()) src += "#define AMC_USER_LOGQ(delta, x, sigma) (" + e_logq + ")\n";
-    if (!e_np.empty()) src += "#define AMC_NP " + e_np + "\n";
-    if (!e_dlogq.empty()) {
-        size_t from = 0;
-        for (int pidx = 0; from <= e_dlogq.size(); ++pidx) {
-            const size_t to = e_dlogq.find('\x0b', from);
-            const std::string one = e_dlogq.substr(from, to == std::string::npos ? std::string::npos : to - from);
-            src += "#define AMC_USER_DLOGQ" + (pidx == 0 ? std::string() : std::to_string(pidx)) + "(delta, x, sigma) (" + one + ")\n";
-            if (to == std::string::npos) break;
-            from = to + 1;
-        }
-    }
-    if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
-    if (!e_classes.empty()) {
-        const size_t first = e_classes.find('\x10');
-        src += "#define AMC_NCLASS " + e_classes.substr(0, first) + "\n";
-        size_t at = first;
-        for (int c = 1; at != std::string::npos; ++c) {
-            const size_t nxt = e_classes.find('\x10', at + 1);
-            const std::string blob = e_classes.substr(at + 1, nxt == std::string::npos ? std::string::npos : nxt - at - 1);
-            const size_t m1 = blob.find('\x11'), m2 = blob.find('\x12'), m3 = blob.find('\x13'), m4 = blob.find('\x14');
-            const std::string sfx = "_" + std::to_string(c);
-            const std::string c_sample = blob.substr(0, m1), c_logq = blob.substr(m1 + 1, m2 - m1 - 1), c_dlogq = blob.substr(m2 + 1, m3 - m2 - 1),
-                              c_perform = blob.substr(m3 + 1, m4 - m3 - 1), c_invert = blob.substr(m4 + 1);
-            src += "#define AMC_USER_SAMPLE" + sfx + "(z, x, sigma) (" + c_sample + ")\n";
-            src += "#define AMC_USER_LOGQ" + sfx + "(delta, x, sigma) (" + c_logq + ")\n";
-            if (!c_dlogq.empty()) src += "#define AMC_USER_DLOGQ" + sfx + "(delta, x, sigma) (" + c_dlogq + ")\n";
-            src += "#define AMC_USER_PERFORM" + sfx + "(x, delta) (" + (c_perform.empty() ? std::string("(x) + (delta)") : c_perform) + ")\n";
-            src += "#define AMC_USER_INVERT" + sfx + "(delta, x) (" + (c_invert.empty() ? std::string("-(delta)") : c_invert) + ")\n";
-            at = nxt;
-        }
-    }
-    const size_t cut = expr.find('\x01');
-    if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
-    if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
-    src += "#include \"amc_kernels.h\"\n";
-    const char* headers[] = {AMC_RTC_SRC_KERNELS, AMC_RTC_SRC_MATH, AMC_RTC_SRC_TABLES, AMC_RTC_SRC_XSUM};
-    const char* names[] = {"amc_kernels.h", "amc_math.h", "amc_tables.h", "amc_xsum.h"};
-    void* prog = nullptr;
-    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", 4, headers, names);
-    if (e != 0) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", e);
-    e = g_hiprtc.AddNameExpression(prog, inst.c_str());
-    if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
-    // the flags of the offline build (Makefile): only the explicit fma()s may fuse
-    const std::string arch_opt = "--offload-arch=" + arch;
-    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm"};
-    e = g_hiprtc.CompileProgram(prog, licm_off ? 7 : 5, opts);
-    // (-disable-machine-licm is one of LLVM's generic code-generation options; a back end without it would not return an error
-    // here but end the process in its option parser, so there is nothing to fall back from)
-    std::string log;
-    size_t ls = 0;
-    if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
-        log.resize(ls);
-        g_hiprtc.GetProgramLog(prog, &log[0]);
-    }
-    if (log_out) *log_out = log;
-    if (e != 0) {
-        g_hiprtc.DestroyProgram(&prog);
-        // the first diagnostic is what the user needs; keep the message bounded
-        return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr_full.empty() ? "run-time kernel build failed" : "custom potential does not compile",
-                    log.empty() ? "(no log)" : log.c_str());
-    }
-    RtcCode rc;
-    size_t cs = 0;
-    const char* lowered = nullptr;
-    if (g_hiprtc.GetCodeSize(prog, &cs) != 0 || cs == 0 || g_hiprtc.GetLoweredName(prog, inst.c_str(), &lowered) != 0 || !lowered) {
-        g_hiprtc.DestroyProgram(&prog);
-        return fail(AMC_ERR_HIP, "hiprtc produced no code for %s", inst.c_str());
-    }
-    rc.code.resize(cs);
-    g_hiprtc.GetCode(prog, rc.code.data());
-    rc.lowered = lowered;
-    g_hiprtc.DestroyProgram(&prog);
-    rtc_cache_store(cache_file, rc);
-    *out = &g_rtc_code.emplace(key, std::move(rc)).first->second;
-    return AMC_OK;
-}
-
-// The function of instantiation `inst` for this handle's expression, loaded on this handle's device.
-int rtc_function(amc_handle* h, const std::string& inst, hipFunction_t* fn)
-{
-    auto it = h->rtc_fn.find(inst);
-    if (it != h->rtc_fn.end()) { *fn = it->second; return AMC_OK; }
-    const RtcCode* code = nullptr;
-    { const int rc = rtc_compile(h->pot_expr, inst, h->arch, &code, nullptr); if (rc != AMC_OK) return rc; }
-    hipModule_t mod = nullptr;
-    AMC_HIP(hipModuleLoadData(&mod, code->code.data()));
-    h->rtc_mods.push_back(mod);
-    hipFunction_t f = nullptr;
-    AMC_HIP(hipModuleGetFunction(&f, mod, code->lowered.c_str()));
-    h->rtc_fn[inst] = f;
-    *fn = f;
-    return AMC_OK;
-}
-
-int rtc_launch(amc_handle* h, const std::string& inst, int grid, void** params)
-{
-    hipFunction_t fn = nullptr;
-    { const int rc = rtc_function(h, inst, &fn); if (rc != AMC_OK) return rc; }
-    AMC_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, AMC_BLOCK, 1, 1, 0, h->stream, params, nullptr));
-    return AMC_OK;
-}
 
 const char* tf(bool b) { return b ? "true" : "false"; }
 
@@ -1304,21 +828,8 @@ int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* clas
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
 
-int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
-{
-    if (log && log_capacity > 0) log[0] = 0;
-    { const int rc = validate_potential_expr(potential_expr); if (rc != AMC_OK) return rc; }
-    const RtcCode* code = nullptr;
-    std::string text;
-    const int rc = rtc_compile(potential_expr, "amc::energy_kernel<2>", AMC_BUILD_ARCH, &code, &text);
-    if (log && log_capacity > 0) {
-        std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
-        log[log_capacity - 1] = 0;
-    }
-    return rc;
-}
 
-static void comm_release(amc_handle* h);
+
 
 int amc_destroy(amc_handle* h)
 {
@@ -2304,7 +1815,7 @@ int amc_parameters_end_all(amc_handle* h, double* parameters, int n)
 // parameter table up to date.  Everything that reads or writes the moves' parameters, gradients_data or the status flag -- other
 // than the next fused launch, which takes the step in its prologue -- calls this first.  (The device's tail record still describes
 // the pending step's configuration: a launch that changes it resolves before it rewrites.)
-static int pg_resolve(amc_handle* h)
+extern "C++" int pg_resolve(amc_handle* h)      // (declared in amc_internal.h: amc_comm.hip calls it too)
 {
     if (!h->pend.active) return AMC_OK;
     AMC_HIP(hipSetDevice(h->device));
@@ -2901,317 +2412,6 @@ int amc_timing_end(amc_handle* h, double* elapsed_ms)
     return AMC_OK;
 }
 
-// ---- RCCL over xGMI, for hosts that have no torch.distributed (the Julia binding) ----
-static int load_rccl(Rccl& r)
-{
-    if (r.lib) return AMC_OK;
-    // AMC_RCCL_LIBRARY=<file>: that library and no other (a site's own RCCL build; the tests' shared-memory stand-in that
-    // lets several ranks share the one GPU of a test box, tests/aux/fake_rccl.c)
-    if (const char* forced = std::getenv("AMC_RCCL_LIBRARY")) {
-        r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-        if (!r.lib) return fail(AMC_ERR_COMM, "cannot dlopen AMC_RCCL_LIBRARY=%s: %s", forced, dlerror());
-    } else {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
-        }
-    }
-    if (!r.lib) return fail(AMC_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
-    r.GetUniqueId = (int (*)(void*))dlsym(r.lib, "ncclGetUniqueId");
-    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
-    r.CommDestroy = (int (*)(void*))dlsym(r.lib, "ncclCommDestroy");
-    r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
-    r.CommCount = (int (*)(void*, int*))dlsym(r.lib, "ncclCommCount");
-    r.CommUserRank = (int (*)(void*, int*))dlsym(r.lib, "ncclCommUserRank");
-    r.GetVersion = (int (*)(int*))dlsym(r.lib, "ncclGetVersion");
-    void* init = dlsym(r.lib, "ncclCommInitRank");
-    r.CommInitRank = (int (*)(void**, int, const void*, int))init;
-    if (!r.GetUniqueId || !r.AllReduce || !r.CommDestroy || !init) {
-        r.lib = nullptr;
-        return fail(AMC_ERR_COMM, "librccl is missing a required symbol");
-    }
-    return AMC_OK;
-}
 
-int amc_comm_unique_id(void* id128)
-{
-    if (!id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_unique_id: NULL argument");
-    static Rccl r;
-    const int rc = load_rccl(r);
-    if (rc != AMC_OK) return rc;
-    const int e = r.GetUniqueId(id128);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclGetUniqueId failed: %s", r.GetErrorString ? r.GetErrorString(e) : "?");
-    return AMC_OK;
-}
-
-// Back to a single shard: the communicator and what was allocated for it.
-static void comm_release(amc_handle* h)
-{
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
-    h->comm = nullptr;
-    h->comm_rank = 0;
-    h->comm_ranks = 1;
-    h->comm_capacity = 0;
-    h->pg_tail_valid = false;
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    h->comm_stream = nullptr;
-    if (h->ev_comm_main) (void)hipEventDestroy(h->ev_comm_main);
-    h->ev_comm_main = nullptr;
-    h->comm_main_pending = false;
-    (void)hipFree(h->d_comm);
-    h->d_comm = nullptr;
-    (void)hipHostFree(h->h_comm);
-    h->h_comm = nullptr;
-}
-
-int amc_comm_init(amc_handle* h, int rank, int n_ranks, const void* id128)
-{
-    if (!h || !id128) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: NULL argument");
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(AMC_ERR_BAD_ARG, "amc_comm_init: bad rank/n_ranks");
-    AMC_HIP(hipSetDevice(h->device));
-    { const int rcr = pg_resolve(h); if (rcr != AMC_OK) return rcr; }
-    const int rc = load_rccl(h->rccl);
-    if (rc != AMC_OK) return rc;
-    if (h->comm) return fail(AMC_ERR_STATE, "amc_comm_init: this handle already has a communicator");
-    // everything the communicator's users need exists BEFORE the communicator does: a failure below leaves the handle
-    // a clean single shard (amc_allreduce_sum the identity again, a later amc_comm_init welcome)
-    // room for a gather of every shard's callback records (amc_allreduce_xsum) and, in d_out, of its estimator records
-    const int capacity = n_ranks * (AMC_RED_HEADER + AMC_MAX_MOVES) * amc::xs::XS_WORDS > 256
-                             ? n_ranks * (AMC_RED_HEADER + AMC_MAX_MOVES) * amc::xs::XS_WORDS : 256;
-    hipError_t he = hipMalloc(&h->d_comm, (size_t)capacity * sizeof(double));
-    if (he == hipSuccess) he = hipHostMalloc(&h->h_comm, (size_t)capacity * sizeof(double), hipHostMallocDefault);
-    if (he == hipSuccess && n_ranks > h->d_out_ranks) {
-        double* bigger = nullptr;
-        he = hipStreamSynchronize(h->stream);
-        if (he == hipSuccess) he = hipMalloc(&bigger, (size_t)n_ranks * PG_MAX_COLS * amc::xs::XS_WORDS * sizeof(double));
-        if (he == hipSuccess) {
-            (void)hipFree(h->d_out);
-            h->d_out = bigger;
-            h->d_out_ranks = n_ranks;
-            h->pg_tail_valid = false;           // the estimator's record holds the old pointer
-        }
-    }
-    // (a higher stream priority changes nothing for these few bytes between device-filling sweeps: measured, round 3)
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&h->ev_comm_main, hipEventDisableTiming);
-    if (he != hipSuccess) {
-        comm_release(h);
-        return fail(he == hipErrorOutOfMemory ? AMC_ERR_OOM : AMC_ERR_HIP, "amc_comm_init: %s", hipGetErrorString(he));
-    }
-    // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId /* 128-byte struct BY VALUE */, int rank)
-    struct Id { char b[128]; } id;
-    std::memcpy(&id, id128, sizeof(id));
-    typedef int (*init_fn)(void**, int, Id, int);
-    const int e = ((init_fn)(void*)h->rccl.CommInitRank)(&h->comm, n_ranks, id, rank);
-    if (e != 0) {
-        h->comm = nullptr;
-        comm_release(h);
-        return fail(AMC_ERR_COMM, "ncclCommInitRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    }
-    h->comm_rank = rank;
-    h->comm_ranks = n_ranks;
-    h->comm_capacity = capacity;
-    h->pg_tail_valid = false;                   // rank / n_ranks are part of the estimator's record
-    return AMC_OK;
-}
-
-int amc_comm_destroy(amc_handle* h)
-{
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_comm_destroy: NULL handle");
-    AMC_HIP(hipSetDevice(h->device));
-    { const int rcr = pg_resolve(h); if (rcr != AMC_OK) return rcr; }
-    if (h->stream) AMC_HIP(hipStreamSynchronize(h->stream));      // the estimator's collectives run there
-    comm_release(h);
-    return AMC_OK;
-}
-
-static void copy_path_of(const void* symbol, char* out, int capacity)
-{
-    if (!out || capacity < 1) return;
-    out[0] = 0;
-    Dl_info info;
-    if (symbol && dladdr(symbol, &info) && info.dli_fname) {
-        std::strncpy(out, info.dli_fname, (size_t)capacity - 1);
-        out[capacity - 1] = 0;
-    }
-}
-
-int amc_comm_info(amc_handle* h, int* n_ranks, int* rank, int* rccl_version, char* librccl_path, int path_capacity)
-{
-    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_comm_info: NULL handle");
-    if (n_ranks) *n_ranks = 1;
-    if (rank) *rank = 0;
-    if (rccl_version) *rccl_version = 0;
-    if (librccl_path && path_capacity > 0) librccl_path[0] = 0;
-    if (!h->comm) return AMC_OK;
-    // asked of RCCL itself, not remembered from amc_comm_init's arguments: the point is what the communicator spans
-    if (!h->rccl.CommCount || !h->rccl.CommUserRank)
-        return fail(AMC_ERR_COMM, "amc_comm_info: this librccl exports no ncclCommCount / ncclCommUserRank");
-    int v = 0;
-    int e = h->rccl.CommCount(h->comm, &v);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommCount failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    if (n_ranks) *n_ranks = v;
-    e = h->rccl.CommUserRank(h->comm, &v);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclCommUserRank failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    if (rank) *rank = v;
-    if (rccl_version && h->rccl.GetVersion && h->rccl.GetVersion(&v) == 0) *rccl_version = v;
-    copy_path_of((const void*)h->rccl.AllReduce, librccl_path, path_capacity);
-    return AMC_OK;
-}
-
-int amc_runtime_info(int* hip_runtime_version, char* hip_runtime_path, int path_capacity)
-{
-    if (hip_runtime_version) {
-        int v = 0;
-        AMC_HIP(hipRuntimeGetVersion(&v));
-        *hip_runtime_version = v;
-    }
-    copy_path_of((const void*)&hipRuntimeGetVersion, hip_runtime_path, path_capacity);
-    return AMC_OK;
-}
-
-int amc_allreduce_sum(amc_handle* h, double* buf, int n)
-{
-    if (!h || !buf) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: NULL argument");
-    if (n < 0) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n < 0");
-    if (!h->comm) return AMC_OK;   // single shard: the local sum is the global sum
-    if (n > h->comm_capacity) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_sum: n must be in [0, %d]", h->comm_capacity);
-    AMC_HIP(hipSetDevice(h->device));
-    // The values are the caller's (host) numbers: nothing here depends on the sweeps queued on the engine's stream, so the
-    // collective runs on comm_stream and the host waits for THAT only (bench.py keeps ten sweeps in flight behind a
-    // callback).  One communicator serves both streams, and RCCL wants its collectives issued and run in one order on
-    // every rank: a collective queued on the engine's stream earlier (the estimator's in-place all-reduce) is waited for
-    // here first -- which drains the engine's stream up to that point, the price of sharing the communicator; with no
-    // estimator in the run nothing is pending and nothing waits.  The other direction needs no event: this call returns
-    // only when its collective is complete.  Every rank calls in the same order (same host program).
-    if (h->comm_main_pending) {
-        AMC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_comm_main, 0));
-        h->comm_main_pending = false;
-    }
-    std::memcpy(h->h_comm, buf, (size_t)n * sizeof(double));
-    AMC_HIP(hipMemcpyAsync(h->d_comm, h->h_comm, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
-    const int e = h->rccl.AllReduce(h->d_comm, h->d_comm, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, h->comm, h->comm_stream);
-    if (e != 0) return fail(AMC_ERR_COMM, "ncclAllReduce failed: %s", h->rccl.GetErrorString ? h->rccl.GetErrorString(e) : "?");
-    AMC_HIP(hipMemcpyAsync(h->h_comm, h->d_comm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
-    AMC_HIP(hipStreamSynchronize(h->comm_stream));
-    std::memcpy(buf, h->h_comm, (size_t)n * sizeof(double));
-    return AMC_OK;
-}
-
-// records[i] <- the sum over all shards of records[i], for every i < n_records: a GATHER of the shards' records (each shard
-// fills its own slot of a zeroed buffer, so the all-reduce(sum) adds one value and zeros per word: exact in any order),
-// then the integer merge of amc_xsum.h in rank order -- which, the merge being exact, is any order.  Every shard ends
-// with the same bits, and they are the bits a single shard holding all the chains would have.
-int amc_allreduce_xsum(amc_handle* h, double* records, int n_records)
-{
-    if (!h || !records) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: NULL argument");
-    if (n_records < 0) return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: n_records < 0");
-    if (!h->comm || n_records == 0) return AMC_OK;
-    const size_t per = (size_t)n_records * amc::xs::XS_WORDS;
-    if (per * (size_t)h->comm_ranks > (size_t)h->comm_capacity)
-        return fail(AMC_ERR_BAD_ARG, "amc_allreduce_xsum: at most %d records", h->comm_capacity / (h->comm_ranks * amc::xs::XS_WORDS));
-    std::vector<double> buf(per * (size_t)h->comm_ranks, 0.0);
-    std::memcpy(buf.data() + per * (size_t)h->comm_rank, records, per * sizeof(double));
-    const int rc = amc_allreduce_sum(h, buf.data(), (int)buf.size());
-    if (rc != AMC_OK) return rc;
-    std::memcpy(records, buf.data(), per * sizeof(double));
-    for (int r = 1; r < h->comm_ranks; ++r)
-        for (int i = 0; i < n_records; ++i)
-            amc::xs::rec_merge(records + (size_t)i * amc::xs::XS_WORDS, buf.data() + per * (size_t)r + (size_t)i * amc::xs::XS_WORDS);
-    return AMC_OK;
-}
-
-// 1 when AMC_RCCL_LIBRARY replaced librccl for this process (a site's own build -- or the tests' stand-in): a result obtained
-// that way must say so.
-int amc_comm_library_forced(int* forced)
-{
-    if (!forced) return fail(AMC_ERR_BAD_ARG, "amc_comm_library_forced: NULL argument");
-    const char* f = std::getenv("AMC_RCCL_LIBRARY");
-    *forced = (f && *f) ? 1 : 0;
-    return AMC_OK;
-}
-
-// ---- parity-test hooks ----------------------------------------------------------------
-int amc_selftest_math(int device, int fn, const double* a, const double* b_or_null, double* out, int64_t n)
-{
-    if (!a || !out || n < 0 || fn < 0 || fn > 11 || ((fn == 5 || fn == 6 || fn == 9 || fn == 10 || fn == 11) && !b_or_null))
-        return fail(AMC_ERR_BAD_ARG, "amc_selftest_math: bad argument");
-    if (n == 0) return AMC_OK;
-    AMC_HIP(hipSetDevice(device));
-    double *da = nullptr, *db = nullptr, *dout = nullptr;
-    AMC_HIP(hipMalloc(&da, (size_t)n * sizeof(double)));
-    AMC_HIP(hipMalloc(&db, (size_t)n * sizeof(double)));
-    AMC_HIP(hipMalloc(&dout, (size_t)n * sizeof(double)));
-    AMC_HIP(hipMemcpy(da, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    AMC_HIP(hipMemcpy(db, b_or_null ? b_or_null : a, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(amc::selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, da, db, dout, n);
-    AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
-    return AMC_OK;
-}
-
-int amc_selftest_accept_filter(int device, float t_from, float t_to, double* max_rel_err)
-{
-    if (!max_rel_err || !(t_from <= 0.0f) || !(t_to <= t_from) || !(t_to >= -1e30f))
-        return fail(AMC_ERR_BAD_ARG, "amc_selftest_accept_filter: need 0 >= t_from >= t_to (negative floats, from the one nearer zero)");
-    AMC_HIP(hipSetDevice(device));
-    // negative floats order like their bit patterns: -0.0 = 0x80000000 < ... ; walk from t_from down to t_to
-    uint32_t b0, b1;
-    float f0 = t_from == 0.0f ? -0.0f : t_from;
-    std::memcpy(&b0, &f0, 4);
-    std::memcpy(&b1, &t_to, 4);
-    const uint64_t count = (uint64_t)b1 - (uint64_t)b0 + 1;
-    unsigned long long* d_max = nullptr;
-    AMC_HIP(hipMalloc(&d_max, sizeof(unsigned long long)));
-    AMC_HIP(hipMemset(d_max, 0, sizeof(unsigned long long)));
-    hipLaunchKernelGGL(amc::selftest_filter_kernel, dim3(4096), dim3(256), 0, 0, b0, count, d_max);
-    AMC_HIP(hipGetLastError());
-    unsigned long long bits = 0;
-    AMC_HIP(hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost));
-    (void)hipFree(d_max);
-    std::memcpy(max_rel_err, &bits, sizeof(double));
-    return AMC_OK;
-}
-
-int amc_selftest_philox(int device, uint64_t seed, const uint64_t* pair, const uint64_t* t, uint32_t draw,
-                        uint32_t stream, uint32_t* out4, int64_t n)
-{
-    if (!pair || !t || !out4 || n < 0) return fail(AMC_ERR_BAD_ARG, "amc_selftest_philox: bad argument");
-    if (n == 0) return AMC_OK;
-    AMC_HIP(hipSetDevice(device));
-    uint64_t *dp = nullptr, *dt = nullptr;
-    uint32_t* dout = nullptr;
-    AMC_HIP(hipMalloc(&dp, (size_t)n * sizeof(uint64_t)));
-    AMC_HIP(hipMalloc(&dt, (size_t)n * sizeof(uint64_t)));
-    AMC_HIP(hipMalloc(&dout, (size_t)n * 4 * sizeof(uint32_t)));
-    AMC_HIP(hipMemcpy(dp, pair, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
-    AMC_HIP(hipMemcpy(dt, t, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(amc::selftest_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), dp, dt, draw, stream, dout, n);
-    AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpy(out4, dout, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    (void)hipFree(dp); (void)hipFree(dt); (void)hipFree(dout);
-    return AMC_OK;
-}
-
-int amc_selftest_wave_totals(int device, const int64_t* values, int64_t* totals, int64_t* totals_plain)
-{
-    if (!values || !totals || !totals_plain) return fail(AMC_ERR_BAD_ARG, "amc_selftest_wave_totals: NULL argument");
-    AMC_HIP(hipSetDevice(device));
-    long long *din = nullptr, *dout = nullptr, *dref = nullptr;
-    AMC_HIP(hipMalloc(&din, 6 * 64 * sizeof(long long)));
-    AMC_HIP(hipMalloc(&dout, 13 * sizeof(long long)));
-    AMC_HIP(hipMalloc(&dref, 6 * sizeof(long long)));
-    AMC_HIP(hipMemcpy(din, values, 6 * 64 * sizeof(long long), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(amc::selftest_wave_totals_kernel, dim3(1), dim3(64), 0, 0, din, dout, dref);
-    AMC_HIP(hipGetLastError());
-    AMC_HIP(hipMemcpy(totals, dout, 13 * sizeof(long long), hipMemcpyDeviceToHost));
-    AMC_HIP(hipMemcpy(totals_plain, dref, 6 * sizeof(long long), hipMemcpyDeviceToHost));
-    (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dref);
-    return AMC_OK;
-}
 
 }  // extern "C"

@@ -1,0 +1,320 @@
+// amc_rtc.hip -- kernels compiled at run time: script-defined potentials, rewards, policies, actions and the Float32 state
+// (amc_create_custom / _model / _policy_model / _action_model / _vector_policy_model / _mixed_model).  hiprtc is resolved with
+// dlopen; the kernel sources travel in the library as string literals (amc_rtc_sources.gen.h, made by embed_sources.py).
+#define AMC_KERNEL_LINKAGE static      // the kernel headers are included for their types only: no kernel of theirs in this object
+#include "amc_internal.h"
+#include "amc_rtc_sources.gen.h"
+
+namespace {
+
+// ---- kernels compiled at run time for a user-defined potential (AMC_POTENTIAL_CUSTOM) ---------------------------
+// `potential` is a free function of the driver script in the reference (MC_harmonic_oscillator.jl:4); here it is a
+// C expression in `x`, and the templates of amc_kernels.h are instantiated for it by hiprtc (resolved with dlopen,
+// like RCCL: no link-time dependency).  One hiprtc program per kernel instantiation, compiled on first use
+// (~1 s each) and cached per process by (expression, instantiation); modules are loaded per handle (= per device).
+struct Hiprtc {
+    void* lib = nullptr;
+    int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*AddNameExpression)(void*, const char*) = nullptr;
+    int (*CompileProgram)(void*, int, const char**) = nullptr;
+    int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+    int (*GetProgramLog)(void*, char*) = nullptr;
+    int (*GetCodeSize)(void*, size_t*) = nullptr;
+    int (*GetCode)(void*, char*) = nullptr;
+    int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
+    int (*DestroyProgram)(void**) = nullptr;
+    int (*Version)(int*, int*) = nullptr;
+};
+
+std::mutex g_rtc_mu;
+Hiprtc g_hiprtc;
+std::map<std::string, RtcCode> g_rtc_code;        // key: expression '\n' instantiation
+
+int load_hiprtc(Hiprtc& r)
+{
+    if (r.lib) return AMC_OK;
+    const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return fail(AMC_ERR_HIP, "custom potential: cannot dlopen libhiprtc: %s", dlerror());
+#define AMC_RTC_SYM(field, name)                                                        \
+    r.field = (decltype(r.field))dlsym(r.lib, name);                                    \
+    if (!r.field) { r.lib = nullptr; return fail(AMC_ERR_HIP, "libhiprtc is missing %s", name); }
+    AMC_RTC_SYM(CreateProgram, "hiprtcCreateProgram");
+    AMC_RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
+    AMC_RTC_SYM(CompileProgram, "hiprtcCompileProgram");
+    AMC_RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+    AMC_RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
+    AMC_RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
+    AMC_RTC_SYM(GetCode, "hiprtcGetCode");
+    AMC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
+    AMC_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+    AMC_RTC_SYM(Version, "hiprtcVersion");
+#undef AMC_RTC_SYM
+    return AMC_OK;
+}
+
+}  // namespace
+
+// The expression becomes the body of a function-like macro: keep it to one line of ordinary expression text.
+int validate_potential_expr(const char* expr, const char* what, const char* var)
+{
+    if (!expr) return fail(AMC_ERR_BAD_ARG, "%s: expression is NULL", what);
+    const size_t n = std::strlen(expr);
+    if (n == 0 || n > 4000) return fail(AMC_ERR_BAD_ARG, "%s: expression must have 1..4000 characters", what);
+    bool has_x = false;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)expr[i];
+        if (c < 0x20 || c > 0x7e || c == '#' || c == '\\' || c == ';' || c == '{' || c == '}' || c == '"' || c == '\'' ||
+            c == '`' || c == '$' || c == '@')
+            return fail(AMC_ERR_BAD_ARG, "%s: character 0x%02x at offset %zu is not allowed in the expression", what, c, i);
+        const bool ident_before = i > 0 && (std::isalnum((unsigned char)expr[i - 1]) || expr[i - 1] == '_');
+        const size_t vl = std::strlen(var);
+        if (!ident_before && std::strncmp(expr + i, var, vl) == 0 &&
+            !(i + vl < n && (std::isalnum((unsigned char)expr[i + vl]) || expr[i + vl] == '_')))
+            has_x = true;
+    }
+    if (!has_x && var[0] != 0) return fail(AMC_ERR_BAD_ARG, "%s: the expression does not mention %s", what, var);
+    return AMC_OK;
+}
+
+namespace {
+
+// Optional on-disk cache of compiled code objects (AMC_RTC_CACHE_DIR; unset = in-process cache only): one file per
+// (expression, instantiation, kernel sources), named by a 64-bit FNV-1a hash of all three, holding the lowered name
+// and the code object.  A corrupt or truncated file is ignored and recompiled.
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string rtc_cache_path(const std::string& expr, const std::string& inst, const std::string& arch, const std::string& toolchain)
+{
+    const char* dir = std::getenv("AMC_RTC_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    uint64_t h = fnv1a(expr);
+    h = fnv1a(inst, h ^ 0x9E3779B97F4A7C15ull);
+    h = fnv1a(arch, h ^ 0xC2B2AE3D27D4EB4Full);          // a code object is good for one ISA ...
+    h = fnv1a(toolchain, h);                              // ... and one compiler release
+    for (int i = 0; i < AMC_RTC_N_SOURCES; ++i) h = fnv1a(AMC_RTC_SOURCE_TEXTS[i], h);      // every kernel source (embed_sources.py)
+    char name[64];
+    std::snprintf(name, sizeof(name), "/amc_rtc_%016llx.bin", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+
+bool rtc_cache_load(const std::string& path, RtcCode* out)
+{
+    if (path.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t hdr[3] = {0, 0, 0};                       // magic, name length, code length
+    bool ok = std::fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == 0x31435452434d41ull && hdr[1] > 0 && hdr[1] < 4096 &&
+              hdr[2] > 0 && hdr[2] < (1ull << 30);
+    if (ok) {
+        out->lowered.resize((size_t)hdr[1]);
+        out->code.resize((size_t)hdr[2]);
+        ok = std::fread(&out->lowered[0], 1, (size_t)hdr[1], f) == hdr[1] &&
+             std::fread(out->code.data(), 1, (size_t)hdr[2], f) == hdr[2] && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+void rtc_cache_store(const std::string& path, const RtcCode& rc)
+{
+    if (path.empty()) return;
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;                                    // an unwritable cache directory is not an error
+    const uint64_t hdr[3] = {0x31435452434d41ull, rc.lowered.size(), rc.code.size()};
+    const bool ok = std::fwrite(hdr, sizeof(hdr), 1, f) == 1 && std::fwrite(rc.lowered.data(), 1, rc.lowered.size(), f) == rc.lowered.size() &&
+                    std::fwrite(rc.code.data(), 1, rc.code.size(), f) == rc.code.size();
+    std::fclose(f);
+    if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());   // atomic publish
+}
+
+}  // namespace
+
+// Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
+// Needs no device.  On a compile error the hiprtc log goes into the error message (and *log_out).
+int rtc_compile(const std::string& expr_in, const std::string& inst, const std::string& arch, const RtcCode** out, std::string* log_out)
+{
+    std::lock_guard<std::mutex> lock(g_rtc_mu);
+    const std::string key = arch + "\n" + expr_in + "\n" + inst;
+    auto it = g_rtc_code.find(key);
+    if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
+    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
+    int rtc_major = 0, rtc_minor = 0;
+    (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
+    // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
+    // (decided from the instantiation's FOURTH template argument, SWEEP == 2 -- `<POT, NL, BETA, SWEEP, REDUCE, MIDFLUSH>`: a
+    // substring test would also catch NL = 2 followed by BETA)
+    const bool licm_off = [&] {
+        const std::string head = "amc::pg_estimate_kernel<";
+        if (inst.rfind(head, 0) != 0) return false;
+        size_t at = head.size();
+        for (int arg = 0; arg < 3; ++arg) {
+            at = inst.find(',', at);
+            if (at == std::string::npos) return false;
+            ++at;
+        }
+        const size_t end = inst.find_first_of(",>", at);
+        return end != std::string::npos && inst.substr(at, end - at) == "2";
+    }();
+    const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+                                                                           (licm_off ? " licm-off" : ""));
+    {
+        RtcCode cached;
+        if (rtc_cache_load(cache_file, &cached)) {
+            if (log_out) log_out->clear();
+            *out = &g_rtc_code.emplace(key, std::move(cached)).first->second;
+            return AMC_OK;
+        }
+    }
+    // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ]
+    //             [ '\x07' perform ] [ '\x08' invert ] ] ]
+    const bool f32 = !expr_in.empty() && expr_in[0] == '\x02';
+    const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
+    std::string expr = expr_full;
+    std::string src;
+    if (f32) src += "#define AMC_STATE_F32 1\n";
+    auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
+        const size_t at = expr.find(mark);
+        if (at == std::string::npos) return std::string();
+        const std::string tail = expr.substr(at + 1);
+        expr.erase(at);
+        return tail;
+    };
+    const std::string e_classes = cut_tail('\x0f');      // [ '\x0f' n_classes { sections of the classes 1 .. } ]: pools that mix policies / actions
+    const std::string e_np = cut_tail('\x0e');           // [ '\x0e' P ]: parameters of the policy, when more than one; the dlogq section then holds P
+                                                         // expressions, '\x0b' between them
+    const std::string e_invert = cut_tail('\x08'), e_perform = cut_tail('\x07');
+    const std::string e_dlogq = cut_tail('\x06'), e_logq = cut_tail('\x05'), e_sample = cut_tail('\x04'), e_scale = cut_tail('\x03');
+    if (!e_perform.empty()) src += "#define AMC_USER_PERFORM(x, delta) (" + e_perform + ")\n";
+    if (!e_invert.empty()) src += "#define AMC_USER_INVERT(delta, x) (" + e_invert + ")\n";
+    if (!e_sample.empty()) src += "#define AMC_USER_SAMPLE(z, x, sigma) (" + e_sample + ")\n";
+    if (!e_logq.empty()) src += "#define AMC_USER_LOGQ(delta, x, sigma) (" + e_logq + ")\n";
+    if (!e_np.empty()) src += "#define AMC_NP " + e_np + "\n";
+    if (!e_dlogq.empty()) {
+        size_t from = 0;
+        for (int pidx = 0; from <= e_dlogq.size(); ++pidx) {
+            const size_t to = e_dlogq.find('\x0b', from);
+            const std::string one = e_dlogq.substr(from, to == std::string::npos ? std::string::npos : to - from);
+            src += "#define AMC_USER_DLOGQ" + (pidx == 0 ? std::string() : std::to_string(pidx)) + "(delta, x, sigma) (" + one + ")\n";
+            if (to == std::string::npos) break;
+            from = to + 1;
+        }
+    }
+    if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
+    if (!e_classes.empty()) {
+        const size_t first = e_classes.find('\x10');
+        src += "#define AMC_NCLASS " + e_classes.substr(0, first) + "\n";
+        size_t at = first;
+        for (int c = 1; at != std::string::npos; ++c) {
+            const size_t nxt = e_classes.find('\x10', at + 1);
+            const std::string blob = e_classes.substr(at + 1, nxt == std::string::npos ? std::string::npos : nxt - at - 1);
+            const size_t m1 = blob.find('\x11'), m2 = blob.find('\x12'), m3 = blob.find('\x13'), m4 = blob.find('\x14');
+            const std::string sfx = "_" + std::to_string(c);
+            const std::string c_sample = blob.substr(0, m1), c_logq = blob.substr(m1 + 1, m2 - m1 - 1), c_dlogq = blob.substr(m2 + 1, m3 - m2 - 1),
+                              c_perform = blob.substr(m3 + 1, m4 - m3 - 1), c_invert = blob.substr(m4 + 1);
+            src += "#define AMC_USER_SAMPLE" + sfx + "(z, x, sigma) (" + c_sample + ")\n";
+            src += "#define AMC_USER_LOGQ" + sfx + "(delta, x, sigma) (" + c_logq + ")\n";
+            if (!c_dlogq.empty()) src += "#define AMC_USER_DLOGQ" + sfx + "(delta, x, sigma) (" + c_dlogq + ")\n";
+            src += "#define AMC_USER_PERFORM" + sfx + "(x, delta) (" + (c_perform.empty() ? std::string("(x) + (delta)") : c_perform) + ")\n";
+            src += "#define AMC_USER_INVERT" + sfx + "(delta, x) (" + (c_invert.empty() ? std::string("-(delta)") : c_invert) + ")\n";
+            at = nxt;
+        }
+    }
+    const size_t cut = expr.find('\x01');
+    if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
+    if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
+    src += "#include \"amc_kernels.h\"\n";
+    // the kernel sources travel in the library (amc_rtc_sources.gen.h): hiprtc finds every `#include "amc_*.h"` among them by name
+    void* prog = nullptr;
+    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", AMC_RTC_N_SOURCES, AMC_RTC_SOURCE_TEXTS, AMC_RTC_SOURCE_NAMES);
+    if (e != 0) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", e);
+    e = g_hiprtc.AddNameExpression(prog, inst.c_str());
+    if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
+    // the flags of the offline build (Makefile): only the explicit fma()s may fuse
+    const std::string arch_opt = "--offload-arch=" + arch;
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm"};
+    e = g_hiprtc.CompileProgram(prog, licm_off ? 7 : 5, opts);
+    // (-disable-machine-licm is one of LLVM's generic code-generation options; a back end without it would not return an error
+    // here but end the process in its option parser, so there is nothing to fall back from)
+    std::string log;
+    size_t ls = 0;
+    if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+        log.resize(ls);
+        g_hiprtc.GetProgramLog(prog, &log[0]);
+    }
+    if (log_out) *log_out = log;
+    if (e != 0) {
+        g_hiprtc.DestroyProgram(&prog);
+        // the first diagnostic is what the user needs (not the "In file included from" lines in front of it); keep the message bounded
+        size_t from = log.find("error:");
+        from = from == std::string::npos ? 0 : log.rfind('\n', from) + 1;       // (npos + 1 == 0: the log's first line)
+        return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr_full.empty() ? "run-time kernel build failed" : "custom potential does not compile",
+                    log.empty() ? "(no log)" : log.c_str() + from);
+    }
+    RtcCode rc;
+    size_t cs = 0;
+    const char* lowered = nullptr;
+    if (g_hiprtc.GetCodeSize(prog, &cs) != 0 || cs == 0 || g_hiprtc.GetLoweredName(prog, inst.c_str(), &lowered) != 0 || !lowered) {
+        g_hiprtc.DestroyProgram(&prog);
+        return fail(AMC_ERR_HIP, "hiprtc produced no code for %s", inst.c_str());
+    }
+    rc.code.resize(cs);
+    g_hiprtc.GetCode(prog, rc.code.data());
+    rc.lowered = lowered;
+    g_hiprtc.DestroyProgram(&prog);
+    rtc_cache_store(cache_file, rc);
+    *out = &g_rtc_code.emplace(key, std::move(rc)).first->second;
+    return AMC_OK;
+}
+
+// The function of instantiation `inst` for this handle's expression, loaded on this handle's device.
+int rtc_function(amc_handle* h, const std::string& inst, hipFunction_t* fn)
+{
+    auto it = h->rtc_fn.find(inst);
+    if (it != h->rtc_fn.end()) { *fn = it->second; return AMC_OK; }
+    const RtcCode* code = nullptr;
+    { const int rc = rtc_compile(h->pot_expr, inst, h->arch, &code, nullptr); if (rc != AMC_OK) return rc; }
+    hipModule_t mod = nullptr;
+    AMC_HIP(hipModuleLoadData(&mod, code->code.data()));
+    h->rtc_mods.push_back(mod);
+    hipFunction_t f = nullptr;
+    AMC_HIP(hipModuleGetFunction(&f, mod, code->lowered.c_str()));
+    h->rtc_fn[inst] = f;
+    *fn = f;
+    return AMC_OK;
+}
+
+int rtc_launch(amc_handle* h, const std::string& inst, int grid, void** params)
+{
+    hipFunction_t fn = nullptr;
+    { const int rc = rtc_function(h, inst, &fn); if (rc != AMC_OK) return rc; }
+    AMC_HIP(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, AMC_BLOCK, 1, 1, 0, h->stream, params, nullptr));
+    return AMC_OK;
+}
+
+
+extern "C" {
+
+int amc_potential_check(const char* potential_expr, char* log, int log_capacity)
+{
+    if (log && log_capacity > 0) log[0] = 0;
+    { const int rc = validate_potential_expr(potential_expr); if (rc != AMC_OK) return rc; }
+    const RtcCode* code = nullptr;
+    std::string text;
+    const int rc = rtc_compile(potential_expr, "amc::energy_kernel<2>", AMC_BUILD_ARCH, &code, &text);
+    if (log && log_capacity > 0) {
+        std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
+        log[log_capacity - 1] = 0;
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -9,7 +9,7 @@ rm -rf $B; mkdir -p $B/montecarlo_amd $B/include
 cp -r $R/montecarlo_amd/csrc $B/montecarlo_amd/csrc
 cp $R/include/amc.h $B/include/
 rm -f $B/montecarlo_amd/csrc/*.o $B/montecarlo_amd/csrc/*.s $B/montecarlo_amd/csrc/*.gen.h
-make -C $B/montecarlo_amd/csrc EXTRA_HIPFLAGS="$*" OUT=$B/libamc.so 2>&1 | grep -v "warning" | tail -3
+make -j4 -C $B/montecarlo_amd/csrc EXTRA_HIPFLAGS="$*" OUT=$B/libamc.so 2>&1 | grep -v "warning" | tail -3
 V=$R/tools/_variants/$NAME
 rm -rf $V; mkdir -p $V/montecarlo_amd
 cp $R/montecarlo_amd/*.py $V/montecarlo_amd/
