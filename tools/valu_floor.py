@@ -118,7 +118,7 @@ def parse_blocks(lines):
                     break
             continue
         t = l.strip()
-        if not l.startswith("\t") or t.startswith((".", ";")):
+        if not l.startswith("\t") or not t or t.startswith((".", ";")):
             continue
         op = t.split()[0]
         cur["ops"].append(op)
