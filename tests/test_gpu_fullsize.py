@@ -446,6 +446,30 @@ def test_pick_table_and_filter_soak_mixed_pool_at_full_size(gpu, monkeypatch):
     assert tot[0].sum() / (1000 * M_FULL) == pytest.approx(0.3, abs=2e-5)       # 1e10 picks: sd 4.6e-6
 
 
+def test_accept_filter_soak_script_proposal_at_full_size(gpu, monkeypatch):
+    """The script-defined counterpart (round 5: accept_filter_arg): 1e7 chains x 1000 steps of a Langevin proposal written as
+    expressions -- its arg = (dlogp + logq_b) - logq_f has nothing that cancels -- = 1e10 decisions, once through the filter and
+    once through the reference-ordered decision alone (AMC_EXACT_ACCEPT=1): every position and the accepted total identical,
+    and the acceptance where MALA's is for U = x^2, beta = 2, sigma = 0.4."""
+    sample = "-2.0*sigma*sigma*x + sigma*z"
+    logq = "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)"
+    kw = dict(n_chains=M_FULL, potential="harmonic", beta=2.0, sigma=[0.4], weight=[1.0], seed=17, per_chain_counters=False,
+              proposal=(sample, logq, None))
+    runs = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("AMC_EXACT_ACCEPT", exact)
+        e = gpu.HipEngine(**kw)
+        e.init_uniform(-2, 2)
+        for _ in range(10):
+            e.sweep(1)
+        e.sweep(990)
+        runs.append((e.download_state(want_e=False)[0], int(e.counter_totals()[0][0])))
+        e.close()
+    assert runs[0][1] == runs[1][1]
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    assert 0.8 < runs[0][1] / (1000 * M_FULL) < 1.0          # a Langevin step of this size is accepted most of the time
+
+
 @pytest.mark.parametrize("group", ["nccl", "store"])
 def test_sharded_pgmc_device_resident_over_rccl(group):
     """PGMC with the shards connected: PolicyGradientEstimator.connect_shards() hands the engines a communicator of

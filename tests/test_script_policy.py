@@ -244,7 +244,7 @@ def test_scaling_action_bit_exact_and_half_gaussian_on_the_device(gpu, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["proposal_k1", "proposal_k2", "scaled", "classes", "two_parameters"])
+@pytest.mark.parametrize("case", ["proposal_k1", "proposal_k2", "scaled", "scaled_f32", "classes", "two_parameters"])
 def test_accept_filter_equals_the_exact_decision_for_script_proposals(gpu, monkeypatch, case):
     """Round 5: the decisions of script-defined proposals go through the 12-bit accept filter too (accept_filter_arg: arg is
     formed in full, the filter saves exp(arg) and the accept draw).  2e6 chains x 300 steps = 6e8 decisions per case, once
@@ -263,6 +263,8 @@ def test_accept_filter_equals_the_exact_decision_for_script_proposals(gpu, monke
         kw.update(potential="double_well", sigma=[0.2, 0.6], weight=[0.3, 0.7], proposal=MALA)
     elif case == "scaled":
         kw.update(sigma=[0.4], weight=[1.0], scale_expr="0.5 + fabs(x)")
+    elif case == "scaled_f32":                       # Particle{Float32}: x, delta, dlogp in Float32, arg stays Float64
+        kw.update(sigma=[0.4], weight=[1.0], scale_expr="0.5 + fabs(x)", dtype="f32")
     elif case == "classes":
         kw.update(sigma=[0.3, 0.4], weight=[0.5, 0.5], classes=[gauss, MALA], class_of_move=[0, 1])
     else:
