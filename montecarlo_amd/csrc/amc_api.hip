@@ -7,10 +7,11 @@
 #include "amc_internal.h"
 // defined in amc_pg_fused.hip (compiled with other code-generation options, see there): not instantiated here
 namespace amc {
-#define AMC_PG_FUSED(POT, NL, BETA)                                                                             \
-    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false>(const PgArgs, const SweepArgs); \
-    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, true>(const PgArgs, const SweepArgs);  \
-    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false, true>(const PgArgs, const SweepArgs)
+#define AMC_PG_FUSED(POT, NL, BETA)                                                                                     \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_NONE>(const PgArgs, const SweepArgs);   \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_COLS>(const PgArgs, const SweepArgs);   \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_E>(const PgArgs, const SweepArgs);      \
+    extern template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_NONE, true>(const PgArgs, const SweepArgs)
 AMC_PG_FUSED(POT_HARMONIC, 1, false);
 AMC_PG_FUSED(POT_HARMONIC, 1, true);
 AMC_PG_FUSED(POT_HARMONIC, 2, false);
@@ -219,22 +220,38 @@ int log_room(amc_handle* h, int* rows)
     return AMC_OK;
 }
 
-template <int POT, bool MULTI, int LOG>
-int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
+// The form of a launch that also leaves the callback sums (amc::RED_FORM_*): the one with sum e alone compiled in when the
+// callbacks read nothing else (amc_set_reduce_columns; harmonic potential, Float64 state: sum x^2 is the same sum), else the one
+// that forms whatever SweepArgs.red_cols names.
+int red_form(const amc_handle* h)
+{
+    const int e_alone = (h->potential == AMC_POTENTIAL_HARMONIC && !h->f32) ? (amc::RED_WANT_E | amc::RED_WANT_XX) : amc::RED_WANT_E;
+    return (h->red_cols & ~e_alone) == 0 ? amc::RED_FORM_E : amc::RED_FORM_COLS;
+}
+
+template <int POT, bool MULTI, int LOG, int FORM>
+int launch_sweep_reduce_mlf(amc_handle* h, const amc::SweepArgs& a, int grid)
 {
     if (a.n_steps == 1) {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, true, FORM>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, true, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, true, FORM>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     } else {
         if (h->beta_arr)
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, true, false, FORM>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, false, true>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
+            hipLaunchKernelGGL((amc::sweep_kernel<POT, MULTI, LOG, false, false, FORM>), dim3(grid), dim3(AMC_BLOCK), 0, h->stream, a);
     }
     AMC_HIP(hipGetLastError());
     return AMC_OK;
+}
+
+template <int POT, bool MULTI, int LOG>
+int launch_sweep_reduce_ml(amc_handle* h, const amc::SweepArgs& a, int grid)
+{
+    return red_form(h) == amc::RED_FORM_E ? launch_sweep_reduce_mlf<POT, MULTI, LOG, amc::RED_FORM_E>(h, a, grid)
+                                          : launch_sweep_reduce_mlf<POT, MULTI, LOG, amc::RED_FORM_COLS>(h, a, grid);
 }
 
 template <int POT>
@@ -252,7 +269,7 @@ int launch_sweep(amc_handle* h, const amc::SweepArgs& a, int grid)
     return a.n_steps == 1 ? launch_sweep_s<POT, true>(h, a, grid) : launch_sweep_s<POT, false>(h, a, grid);
 }
 
-template <int POT, int NL, int SWEEP, bool REDUCE = false, bool MID = false>
+template <int POT, int NL, int SWEEP, int REDUCE = amc::RED_FORM_NONE, bool MID = false>
 int launch_pg_nls(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid)
 {
     if (grid < 0) {            // a query: how many blocks of this form a CU holds
@@ -278,21 +295,28 @@ template <int POT>
 int launch_pg(amc_handle* h, const amc::PgArgs& a, const amc::SweepArgs& sw, int grid, int nl_cap, int sweep, bool reduce, bool mid)
 {
     if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on launches that need no flush mid-launch (see pg_plan)");
+    constexpr int NONE = amc::RED_FORM_NONE, COLS = amc::RED_FORM_COLS, E = amc::RED_FORM_E;
     if (mid) {
-        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, false, true>(h, a, sw, grid);
-        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, false, true>(h, a, sw, grid);
-        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, false, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, false, true>(h, a, sw, grid);
+        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, NONE, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, NONE, true>(h, a, sw, grid);
+        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, NONE, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, NONE, true>(h, a, sw, grid);
+        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, NONE, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, NONE, true>(h, a, sw, grid);
         switch (nl_cap) {
-        case 1: return launch_pg_nls<POT, 1, 0, false, true>(h, a, sw, grid);
-        case 2: return launch_pg_nls<POT, 2, 0, false, true>(h, a, sw, grid);
-        case 4: return launch_pg_nls<POT, 4, 0, false, true>(h, a, sw, grid);
-        default: return launch_pg_nls<POT, 8, 0, false, true>(h, a, sw, grid);
+        case 1: return launch_pg_nls<POT, 1, 0, NONE, true>(h, a, sw, grid);
+        case 2: return launch_pg_nls<POT, 2, 0, NONE, true>(h, a, sw, grid);
+        case 4: return launch_pg_nls<POT, 4, 0, NONE, true>(h, a, sw, grid);
+        default: return launch_pg_nls<POT, 8, 0, NONE, true>(h, a, sw, grid);
         }
     }
+    if (reduce && red_form(h) == E) {
+        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, E>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, E>(h, a, sw, grid);
+        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, E>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, E>(h, a, sw, grid);
+        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, E>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, E>(h, a, sw, grid);
+        return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on the fused time step only");
+    }
     if (reduce) {
-        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, true>(h, a, sw, grid);
-        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, true>(h, a, sw, grid);
-        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, true>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, true>(h, a, sw, grid);
+        if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1, COLS>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1, COLS>(h, a, sw, grid);
+        if (sweep == 2) return nl_cap == 1 ? launch_pg_nls<POT, 1, 2, COLS>(h, a, sw, grid) : launch_pg_nls<POT, 2, 2, COLS>(h, a, sw, grid);
+        if (sweep == 3) return nl_cap == 1 ? launch_pg_nls<POT, 1, 3, COLS>(h, a, sw, grid) : launch_pg_nls<POT, 2, 3, COLS>(h, a, sw, grid);
         return fail(AMC_ERR_STATE, "launch_pg: the callback sums ride on the fused time step only");
     }
     if (sweep == 1) return nl_cap == 1 ? launch_pg_nls<POT, 1, 1>(h, a, sw, grid) : launch_pg_nls<POT, 2, 1>(h, a, sw, grid);
@@ -329,7 +353,7 @@ int launch_sweep_custom(amc_handle* h, amc::SweepArgs& a, int grid, bool reduce)
 {
     const bool multi = h->K > 1;
     const std::string inst = "amc::sweep_kernel<" + std::to_string(h->potential) + "," + tf(multi) + "," + std::to_string(log_form(h)) + "," + tf(h->beta_arr) + "," +
-                             tf(a.n_steps == 1) + "," + tf(reduce) + ">";
+                             tf(a.n_steps == 1) + "," + std::to_string(reduce ? red_form(h) : (int)amc::RED_FORM_NONE) + ">";
     void* params[] = {&a};
     return rtc_launch(h, inst, grid, params);
 }
@@ -338,7 +362,7 @@ int launch_pg_custom(amc_handle* h, amc::PgArgs& a, amc::SweepArgs& sw, int grid
 {
     if (mid && reduce) return fail(AMC_ERR_STATE, "launch_pg_custom: the callback sums ride on launches that need no flush mid-launch");
     const std::string inst = "amc::pg_estimate_kernel<" + std::to_string(h->potential) + "," + std::to_string(nl_cap) + "," + tf(h->beta_arr) + "," +
-                             std::to_string(sweep) + "," + tf(reduce) + "," + tf(mid) + ">";
+                             std::to_string(sweep) + "," + std::to_string(reduce ? red_form(h) : (int)amc::RED_FORM_NONE) + "," + tf(mid) + ">";
     if (grid < 0) {            // a query: how many blocks of this form a CU holds
         hipFunction_t fn = nullptr;
         { const int rc = rtc_function(h, inst, &fn); if (rc != AMC_OK) return rc; }
@@ -1856,7 +1880,7 @@ static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, P
     auto resident = [&](bool mid, int* per_cu) -> int {
         if (h->blocks_per_cu_pg) { *per_cu = h->blocks_per_cu_pg; return AMC_OK; }
         const bool red = reduce && !mid;             // (the callback sums ride on launches that need no flush: launch_pg)
-        const int key = (nl << 8) | (sweep << 4) | (red ? 1 : 0) | (mid ? 2 : 0);
+        const int key = (nl << 8) | (sweep << 4) | (red ? red_form(h) : 0) | (mid ? 4 : 0);      // (the callback sums' form may change: amc_set_reduce_columns)
         auto it = h->pg_resident.find(key);
         if (it == h->pg_resident.end()) {
             amc::PgArgs a0;

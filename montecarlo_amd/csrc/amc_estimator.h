@@ -18,7 +18,7 @@ namespace amc {
 // accepted total) of the state it stores -- AFTER the estimator's samples, which is what a callback scheduled at the same t
 // observes (run! calls Metropolis, estimator, update, then the callbacks: src/simulation.jl:185-190) -- as one row per block in
 // sw.red_partials, like sweep_kernel<.., REDUCE>: a callback after a fused time step needs no pass over x.
-template <int POT, int NL, bool BETA, int SWEEP = 0, bool REDUCE = false, bool MIDFLUSH = false>
+template <int POT, int NL, bool BETA, int SWEEP = 0, int REDUCE = RED_FORM_NONE, bool MIDFLUSH = false>
 __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
@@ -29,7 +29,8 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
     constexpr int NV = NL * NC;
     static_assert(NV <= 32, "the tail's wave 0 owns a row's columns");
     // the callback sums: reproducible (amc_xsum.h); the count of full trips lives on the scalar unit
-    constexpr int RNC = RedCols<POT>::NC;
+    constexpr bool RED_E = REDUCE == RED_FORM_E;
+    constexpr int RNC = RedCols<POT, RED_E>::NC;
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
     if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         if (base_done >= 0) store_pair_block_writethrough(a.x + 2 * base_done, x_done);
         if (SWEEP) mh(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), base + threadIdx.x, true, true);
         samples(xv, b0, b1, a.pair0 + (uint64_t)(base + threadIdx.x), true, true, true);
-        if (REDUCE) red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
+        if (REDUCE) red_add_pair<POT, RED_E>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
         x_done = xv;
         base_done = base;
     }
@@ -362,10 +363,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, 
         // end go through the motions on a pair nobody stores and add zeros
         samples(xv, b_nxt.x, b_nxt.y, a.pair0 + (uint64_t)(v0 ? p : 0), v0, v1, false);
         if (v0) store_pair_block_writethrough(a.x + 2 * base, xv);   // a lone last chain writes its whole pair: padding
-        if (REDUCE) red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
+        if (REDUCE) red_add_pair<POT, RED_E>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], sw.red_cols);
     }
     if (REDUCE)
-        red_finish<POT>(red, s_red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride, sw.red_stride == RED_COMPACT_WORDS, sw.red_cols);
+        red_finish<POT, RED_E>(red, s_red, sw.red_partials + (int64_t)blockIdx.x * sw.red_stride, sw.red_stride == RED_COMPACT_WORDS, sw.red_cols);
     if (SWEEP == 1 || SWEEP == 3) {      // K == 1: the pool-wide accepted total (counter_totals)
         const unsigned long long t = add_block_accepts(sw.acc_total, wave_acc);
         // this block's slot after this launch (exact in a double below 2^53)

@@ -10,12 +10,14 @@
 #include "amc_kernels.h"
 
 namespace amc {
-// (.., false): the time step alone; (.., true): with the callback sums of the state it leaves (REDUCE); (.., false, true): the
-// time step of launches whose lanes empty their accumulators on the way (MIDFLUSH: large q_batch)
-#define AMC_PG_FUSED(POT, NL, BETA)                                                                      \
-    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false>(const PgArgs, const SweepArgs); \
-    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, true>(const PgArgs, const SweepArgs);  \
-    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, false, true>(const PgArgs, const SweepArgs)
+// (.., RED_FORM_NONE): the time step alone; (.., RED_FORM_COLS / RED_FORM_E): with the callback sums of the state it leaves (REDUCE: those
+// SweepArgs.red_cols names / sum e alone); (.., RED_FORM_NONE, true): the time step of launches whose lanes empty their accumulators on
+// the way (MIDFLUSH: large q_batch)
+#define AMC_PG_FUSED(POT, NL, BETA)                                                                              \
+    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_NONE>(const PgArgs, const SweepArgs);   \
+    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_COLS>(const PgArgs, const SweepArgs);   \
+    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_E>(const PgArgs, const SweepArgs);      \
+    template __global__ void pg_estimate_kernel<POT, NL, BETA, 2, RED_FORM_NONE, true>(const PgArgs, const SweepArgs)
 AMC_PG_FUSED(POT_HARMONIC, 1, false);
 AMC_PG_FUSED(POT_HARMONIC, 1, true);
 AMC_PG_FUSED(POT_HARMONIC, 2, false);

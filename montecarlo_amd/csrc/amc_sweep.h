@@ -162,15 +162,17 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
 // SINGLE: exactly one MH step per launch (the default sweepstep = 1 make_step!): no step loop
 // REDUCE: also leave the callback sums of the state AFTER the sweep in red_partials (sum e, sum x, sum x^2, count;
 //         and, pool-wide counter only, the accepted total), so a sweep that is followed by callback_energy /
-//         callback_acceptance needs no second pass over x
-template <int POT, bool MULTI, int LOG, bool BETA, bool SINGLE, bool REDUCE = false>
+//         callback_acceptance needs no second pass over x.  RED_FORM_COLS: the sums SweepArgs.red_cols names; RED_FORM_E: sum e
+//         alone, compiled in (RedCols) -- what the host launches when nothing else is asked for
+template <int POT, bool MULTI, int LOG, bool BETA, bool SINGLE, int REDUCE = RED_FORM_NONE>
 __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
 {
     // REDUCE with LOG (per-chain counters): rows carry the sums over x only; the acceptance ratios of the same
     // callback come from the fold of the step log that follows (fold_log_kernel<KS, true>)
     static_assert(!MULTI || LOG, "K > 1 always keeps per-chain counters");
     // the callback sums: reproducible (amc_xsum.h); the count of full trips lives on the scalar unit
-    constexpr int RNC = RedCols<POT>::NC;
+    constexpr bool RED_E = REDUCE == RED_FORM_E;
+    constexpr int RNC = RedCols<POT, RED_E>::NC;
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
     if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
         // a successor exists (loop condition); lanes past the end of a ragged one form draws nobody uses
         if (AHEAD) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(p + stride), a.t0);
         if (REDUCE) {
-            red_add_pair<POT>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], a.red_cols);
+            red_add_pair<POT, RED_E>(red, xv, true, true, s_math, s_red[threadIdx.x >> 6], a.red_cols);
         }
         x_done = xv;
         lw_done = lw;
@@ -287,10 +289,10 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             store_pair_block_writethrough(a.x + 2 * base, xv);
             if (LOG && SINGLE) store_log_pair<LOG>(a, a.log_pos, p, lw);
         }
-        if (REDUCE) red_add_pair<POT>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], a.red_cols);
+        if (REDUCE) red_add_pair<POT, RED_E>(red, xv, v0, v1, s_math, s_red[threadIdx.x >> 6], a.red_cols);
     }
     if (REDUCE)
-        red_finish<POT>(red, s_red, a.red_partials + (int64_t)blockIdx.x * a.red_stride, a.red_stride == RED_COMPACT_WORDS, a.red_cols);
+        red_finish<POT, RED_E>(red, s_red, a.red_partials + (int64_t)blockIdx.x * a.red_stride, a.red_stride == RED_COMPACT_WORDS, a.red_cols);
     if (!MULTI) {
         // Pool-wide accepted count: each block owns ONE u64 slot (thousands of atomics on a single
         // address at kernel end serialise at ~13 ns each; one address per block does not contend).

@@ -495,10 +495,15 @@ enum { RED_COMPACT_WORDS = 8, RED_COMPACT_SLOT = 7, RED_COMPACT_TRIPS = 32 };
 // test/distribution_test.jl sum x and sum x^2 -- a deposit costs nine vector instructions per trip and column, so what nobody
 // asked for is not formed (its record stays empty).
 enum { RED_WANT_E = 1, RED_WANT_X = 2, RED_WANT_XX = 4, RED_WANT_ALL = 7 };
-template <int POT>
+// EONLY (round 5): the form of a launch whose callbacks read sum e alone (callback_energy: BASELINE configs 2 - 5; RED_FORM_E) -- one lane
+// column, compiled in: the launch keeps 81 instead of 89 VGPRs and loses the other columns' branches (K = 2 sweep with sums 40.3 ->
+// 38.2 us, fused PGMC step with sums 71.6 -> 70.2, same-box A/B).  Its rows have the same layout; the columns nobody asked for repeat column 0
+// and the host, which knows what was asked for, leaves their records empty.
+enum { RED_FORM_NONE = 0, RED_FORM_COLS = 1, RED_FORM_E = 2 };        // the REDUCE template argument of sweep_kernel / pg_estimate_kernel
+template <int POT, bool EONLY = false>
 struct RedCols {
     static constexpr bool X2_IS_E = POT == POT_HARMONIC && sizeof(real_t) == 8;
-    static constexpr int NC = X2_IS_E ? 2 : 3;
+    static constexpr int NC = EONLY ? 1 : X2_IS_E ? 2 : 3;
 };
 __host__ __device__ inline xs::PartR xs_load_compact_row(const xs_word* row, int c)
 {
@@ -512,8 +517,8 @@ __host__ __device__ inline xs::PartR xs_load_compact_row(const xs_word* row, int
 }
 
 // cols: RED_WANT_* bits (wave-uniform: a kernel argument)
-template <int POT>
-__device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 xv, bool v0, bool v1, const double* s_math,
+template <int POT, bool EONLY = false>
+__device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT, EONLY>::NC>& L, real2 xv, bool v0, bool v1, const double* s_math,
                                              xs::PartR* slot, int cols)
 {
     const double x0 = v0 ? (double)xv.x : 0.0, x1 = v1 ? (double)xv.y : 0.0;
@@ -521,6 +526,7 @@ __device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 
         const double e0 = v0 ? (double)potential<POT>(xv.x, s_math) : 0.0, e1 = v1 ? (double)potential<POT>(xv.y, s_math) : 0.0;
         r_deposit(L, 0, e0 + e1, slot);
     }
+    if (EONLY) return;                  // (the host picks this form only when nothing else is asked for)
     if (cols & RED_WANT_X) r_deposit(L, 1, x0 + x1, slot);
     if (!RedCols<POT>::X2_IS_E && (cols & RED_WANT_XX)) r_deposit(L, 2, x0 * x0 + x1 * x1, slot);
 }
@@ -533,11 +539,11 @@ __device__ __forceinline__ void red_add_pair(RLanes<RedCols<POT>::NC>& L, real2 
 // the slots only carry the flags of the rare arm.  (Round 4's form, kept as the wide form below, cost the K = 2 launch 4.2 us
 // at 1e7 chains, its three-line row 1.4 us of them.)
 // wide: flush into the wave slots, thread c merges the block's slots of column c (any number of summands, mid-launch flushes).
-template <int POT>
-__device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::PartR (*slots)[RedCols<POT>::NC], xs_word* row, bool compact,
+template <int POT, bool EONLY = false>
+__device__ __forceinline__ void red_finish(RLanes<RedCols<POT, EONLY>::NC>& L, xs::PartR (*slots)[RedCols<POT, EONLY>::NC], xs_word* row, bool compact,
                                            int cols)
 {
-    constexpr int NC = RedCols<POT>::NC;
+    constexpr int NC = RedCols<POT, EONLY>::NC;
     if (compact) {
         __shared__ long long s_fin_k[AMC_BLOCK / 64][2 * NC];
         __shared__ int s_fin_top[AMC_BLOCK / 64][NC];
@@ -550,7 +556,7 @@ __device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::Part
         }
         // (the common request is sum e alone -- callback_energy --: its two integers travel by themselves, the columns nobody
         // deposited into are zero without a sum)
-        if ((cols & ~(RedCols<POT>::X2_IS_E ? (RED_WANT_E | RED_WANT_XX) : RED_WANT_E)) == 0) {
+        if (EONLY || (cols & ~(RedCols<POT>::X2_IS_E ? (RED_WANT_E | RED_WANT_XX) : RED_WANT_E)) == 0) {
             long long k0[2] = {k[0], k[1]};
             wave_total_i64<2>(k0);
             k[0] = k0[0]; k[1] = k0[1];
@@ -570,7 +576,7 @@ __device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::Part
         if (t < 1 + 2 * RED_COLS) {
             xs_word w = 0ull;
             // the lane column behind row column rc (sum x^2 = sum e where they are the same sums)
-            auto lane_col = [](int rc) { return (RedCols<POT>::X2_IS_E && rc == 2) ? 0 : rc; };
+            auto lane_col = [](int rc) { return (EONLY || (RedCols<POT>::X2_IS_E && rc == 2)) ? 0 : rc; };
             auto top_of = [&](int c) {
                 int T = s_fin_top[0][c];
                 for (int wv = 1; wv < AMC_BLOCK / 64; ++wv) T = s_fin_top[wv][c] > T ? s_fin_top[wv][c] : T;
@@ -604,7 +610,7 @@ __device__ __forceinline__ void red_finish(RLanes<RedCols<POT>::NC>& L, xs::Part
     // writes on the link instead of twenty 8-byte ones)
     __shared__ xs_word s_row[RED_ROW_WORDS];
     if (threadIdx.x < RED_COLS) {          // thread c: column c (sum x^2 = sum e where they are the same sums)
-        const int c = (RedCols<POT>::X2_IS_E && threadIdx.x == 2) ? 0 : (int)threadIdx.x;
+        const int c = (EONLY || (RedCols<POT>::X2_IS_E && threadIdx.x == 2)) ? 0 : (int)threadIdx.x;
         xs_store_r_row(s_row + threadIdx.x * XS_ROW_R, r_block_total<NC>(slots, c));
         if (threadIdx.x == 0) s_row[RED_ROW_COUNT] = 0ull;          // (unused: the host knows the chains a launch covers)
     }

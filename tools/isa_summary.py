@@ -5,9 +5,9 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = os.environ.get("AMC_ROUND_TAG", "r04")
 S = open(os.path.join(ROOT, "montecarlo_amd/csrc/amc_api.gfx950.s")).read()
-NAMED = ["sweep_kernel<0, false, 0, false, true, false>", "sweep_kernel<1, true, 1, false, true, false>",
-         "sweep_kernel<1, true, 1, false, true, true>", "pg_estimate_kernel<0, 1, false, 2, false, false>", "pg_estimate_kernel<0, 1, false, 2, true, false>",
-         "pg_estimate_kernel<0, 1, false, 0, false, false>",
+NAMED = ["sweep_kernel<0, false, 0, false, true, 0>", "sweep_kernel<1, true, 1, false, true, 0>",
+         "sweep_kernel<1, true, 1, false, true, 2>", "pg_estimate_kernel<0, 1, false, 2, 0, false>", "pg_estimate_kernel<0, 1, false, 2, 2, false>",
+         "pg_estimate_kernel<0, 1, false, 0, 0, false>",
          "fold_log_kernel<2, true>", "fold_log_kernel<2, false>", "reduce_kernel<0>"]
 
 

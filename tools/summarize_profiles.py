@@ -20,12 +20,12 @@ os.makedirs(OUT, exist_ok=True)
 ALGO_BYTES = {"ladder_10000000": 16 * 10_000_000, "ladder_40000000": 16 * 40_000_000, "ladder_160000000": 16 * 160_000_000,
               "k2": 165_000_000, "pgmc": 165_000_000, "est": 16 * 10_000_000,     # 16 B of state + half a step-log byte per update
               "vec1": 165_000_000, "vec": 165_000_000, "mixed": 165_000_000}
-MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, false>", "k2": "sweep_kernel<1, true, 1, false, true",
-        "pgmc": "pg_estimate_kernel<0, 1, false, 2, false, false>", "est": "pg_estimate_kernel<0, 1, false, 0, false, false>",
+MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, 0>", "k2": "sweep_kernel<1, true, 1, false, true",
+        "pgmc": "pg_estimate_kernel<0, 1, false, 2, 0, false>", "est": "pg_estimate_kernel<0, 1, false, 0, 0, false>",
         # hiprtc forms (POT_CUSTOM = 2 names the script-defined family): the fused time step of the one- / two-parameter script
         # policy, the per-move estimator launch of the two-class pool
-        "vec1": "pg_estimate_kernel<2, 1, false, 1, false, false>", "vec": "pg_estimate_kernel<2, 1, false, 1, false, false>",
-        "mixed": "pg_estimate_kernel<2, 1, false, 0, false, false>"}
+        "vec1": "pg_estimate_kernel<2, 1, false, 1, 0, false>", "vec": "pg_estimate_kernel<2, 1, false, 1, 0, false>",
+        "mixed": "pg_estimate_kernel<2, 1, false, 0, 0, false>"}
 
 
 def one(pattern):

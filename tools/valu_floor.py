@@ -25,9 +25,9 @@ N_SIMD = 1024
 LAUNCH_BOUNDARY_US = 2.9          # an empty launch back to back on this stack (tools/ubench_launch.hip)
 
 KERNELS = [  # (title, demangled-name fragment, workload key in the PMC summary, chains per launch, cold-arm weight)
-    ("K = 1 sweep (headline, config 2)", "sweep_kernel<0, false, 0, false, true, false>", "ladder_10000000", 10_000_000, 0.015),
-    ("K = 2 sweep (config 3)", "sweep_kernel<1, true, 1, false, true, false>", "k2", 10_000_000, 0.045),
-    ("fused PGMC time step (config 5)", "pg_estimate_kernel<0, 1, false, 2, false, false>", "pgmc", 10_000_000, 0.045),
+    ("K = 1 sweep (headline, config 2)", "sweep_kernel<0, false, 0, false, true, 0>", "ladder_10000000", 10_000_000, 0.015),
+    ("K = 2 sweep (config 3)", "sweep_kernel<1, true, 1, false, true, 0>", "k2", 10_000_000, 0.045),
+    ("fused PGMC time step (config 5)", "pg_estimate_kernel<0, 1, false, 2, 0, false>", "pgmc", 10_000_000, 0.045),
 ]
 
 
