@@ -149,10 +149,17 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     int rtc_major = 0, rtc_minor = 0;
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
-    // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip)
+    // the K > 1 fused sweep + estimator kernels are built with Machine LICM off, like their offline twins (amc_pg_fused.hip),
     // (decided from the instantiation's FOURTH template argument, SWEEP == 2 -- `<POT, NL, BETA, SWEEP, REDUCE, MIDFLUSH>`: a
     // substring test would also catch NL = 2 followed by BETA)
     const bool licm_off = [&] {
+        // AMC_RTC_LICM=all-off / est-off / off-for-none (developer knob, A/B): every form, every estimator form, no form
+        if (const char* env = std::getenv("AMC_RTC_LICM")) {
+            const std::string v = env;
+            if (v == "all-off") return true;
+            if (v == "off-for-none") return false;
+            if (v == "est-off") return inst.rfind("amc::pg_estimate_kernel<", 0) == 0;
+        }
         const std::string head = "amc::pg_estimate_kernel<";
         if (inst.rfind(head, 0) != 0) return false;
         size_t at = head.size();
@@ -162,7 +169,11 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
             ++at;
         }
         const size_t end = inst.find_first_of(",>", at);
-        return end != std::string::npos && inst.substr(at, end - at) == "2";
+        if (end != std::string::npos && inst.substr(at, end - at) == "2") return true;
+        // ... and the estimator forms of policies with several parameters ('\x0e' section of the expression): with 8 to 19 two-level
+        // accumulator columns live, what the pass hoists costs registers the kernel does not have (two-parameter fused step: 133 -> 123
+        // VGPRs, 66 -> 20 scalar spills, 151 -> 144 us at 1e7 chains; the one-parameter forms are indifferent)
+        return expr_in.find('\x0e') != std::string::npos;
     }();
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : ""));

@@ -14,7 +14,7 @@ for round in $(seq 1 $ROUNDS); do
   for v in $(ls $R/tools/_variants | sort); do
     for wl in $WLS; do
       export AMC_PKG_ROOT=$R/tools/_variants/$v
-      unset AMC_BLOCKS_PER_CU AMC_BLOCKS_PER_CU_REDUCE COLS AMC_NO_DEFERRED_UPDATE; export COLS=1; [ -f $AMC_PKG_ROOT/env ] && source $AMC_PKG_ROOT/env
+      unset AMC_BLOCKS_PER_CU AMC_BLOCKS_PER_CU_REDUCE COLS AMC_NO_DEFERRED_UPDATE AMC_RTC_LICM; export COLS=1; [ -f $AMC_PKG_ROOT/env ] && source $AMC_PKG_ROOT/env
       timeout -k 5 150 rocprofv3 --kernel-trace --stats -d $O/raw/${v}_${wl}_$round --output-format csv -- python3 $R/tools/gpu_workload.py $wl > $O/${v}_${wl}_$round.log 2>&1 || { echo "FAILED $v $wl"; tail -5 $O/${v}_${wl}_$round.log; exit 1; }
       f=$(ls -t $O/raw/${v}_${wl}_$round/*/*_kernel_stats.csv | head -1)
       cp $f $O/${v}_${wl}_${round}_kernel_stats.csv
