@@ -1,7 +1,8 @@
 // amc_internal.h -- what the host-side translation units of libamc.so share: the handle, the error convention, the RCCL and
 // hiprtc surfaces resolved with dlopen.  Nothing here is part of the C ABI (include/amc.h); the functions declared here have
 // hidden visibility.
-//   amc_api.hip       handles, state, sweeps, callback reductions, the estimator's host side
+//   amc_api.hip       handles, state, sweeps, callback reductions
+//   amc_pg.hip        the estimator's host side (amc_pg_*, amc_pgmc_steps*)
 //   amc_rtc.hip       kernels compiled at run time for script-defined models (hiprtc, code-object cache)
 //   amc_comm.hip      the engine's own RCCL communicator (amc_comm_*, amc_allreduce_*)
 //   amc_selftest.hip  parity-test hooks
@@ -197,7 +198,21 @@ struct amc_handle {
 };
 
 // ---- shared between the translation units ----------------------------------------------------------------------------------------
-AMC_INTERNAL int pg_resolve(amc_handle* h);      // takes a pending learning step now (amc_api.hip, with the estimator's host code)
+AMC_INTERNAL int pg_resolve(amc_handle* h);      // takes a pending learning step now (amc_pg.hip)
+// launch plumbing of amc_api.hip that the estimator's host code (amc_pg.hip) shares
+AMC_INTERNAL int grid_for(const amc_handle* h, int64_t n_items, int blocks_per_cu = 0);
+AMC_INTERNAL int log_form(const amc_handle* h);
+AMC_INTERNAL int log_room(amc_handle* h, int* rows);
+AMC_INTERNAL int red_form(const amc_handle* h);
+AMC_INTERNAL int nl_capacity(int n_learn);
+AMC_INTERNAL hipError_t wait_stream(hipStream_t stream);
+AMC_INTERNAL int counter_room(amc_handle* h, const char* who, uint64_t steps);
+AMC_INTERNAL int red_row_stride(const amc_handle* h, int grid);
+AMC_INTERNAL amc::SweepArgs make_sweep_args(const amc_handle* h, int32_t n_steps);
+AMC_INTERNAL int sweep_impl(amc_handle* h, int64_t n_sweeps, bool fuse_reduce, int* grid_out);
+AMC_INTERNAL RedTicket* red_next(amc_handle* h);
+AMC_INTERNAL int finish_fused_reduce(amc_handle* h, int grid);
+AMC_INTERNAL bool reduce_fits_in_grid(const amc_handle* h, int grid);
 AMC_INTERNAL void comm_release(amc_handle* h);   // drops the handle's communicator and its buffers (amc_comm.hip)
 // kernels compiled at run time (amc_rtc.hip)
 struct RtcCode { std::vector<char> code; std::string lowered; };
