@@ -34,6 +34,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The entry points declared here are the library's WHOLE dynamic symbol table: libamc.so is built with hidden visibility
+ * (montecarlo_amd/csrc/Makefile) and these declarations carry the default one. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AMC_VERSION_MAJOR 0
 #define AMC_VERSION_MINOR 1
@@ -453,6 +458,9 @@ int  amc_selftest_philox(int device, uint64_t seed, const uint64_t *pair, const 
  * totals_plain[0..5]: the six sums by plain DPP rounds.  Sums are modulo 2^64. */
 int  amc_selftest_wave_totals(int device, const int64_t *values, int64_t *totals, int64_t *totals_plain);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

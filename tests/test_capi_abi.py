@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol(amc):
         assert hasattr(lib, name), f"libamc.so does not export {name} declared in include/amc.h"
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """The boundary is the header: every function in the dynamic symbol table of libamc.so is an entry point of include/amc.h
+    (the library is built with hidden visibility) -- beside them only what hipcc keeps visible of the HIP kernels in namespace
+    amc (their handle objects and the launch stubs of explicit instantiations)."""
+    so = os.path.join(ROOT, "montecarlo_amd", "libamc.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    functions = sorted(ln.split()[2] for ln in out.splitlines()
+                       if len(ln.split()) == 3 and ln.split()[1] in ("T", "W") and not ln.split()[2].startswith("_ZN3amc"))
+    assert functions == declared_functions()
+
+
 def test_python_binding_covers_the_header(amc):
     lib = amc.load()
     for name in declared_functions():
