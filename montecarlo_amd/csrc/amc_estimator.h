@@ -19,7 +19,12 @@ namespace amc {
 // observes (run! calls Metropolis, estimator, update, then the callbacks: src/simulation.jl:185-190) -- as one row per block in
 // sw.red_partials, like sweep_kernel<.., REDUCE>: a callback after a fused time step needs no pass over x.
 template <int POT, int NL, bool BETA, int SWEEP = 0, int REDUCE = RED_FORM_NONE, bool MIDFLUSH = false>
-__global__ __launch_bounds__(AMC_BLOCK) void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
+// (amdgpu_waves_per_eu: the fused time step that also leaves sum e -- RED_FORM_E, built-in potentials -- needs 97 VGPRs, one more than five
+// waves per SIMD allow; held to 96 it spills ONE register outside the loop and the launch runs on five resident blocks per CU instead
+// of four: 69.9 -> 67.2 us at 1e7 chains, same-box A/B.  The same squeeze on the K = 2 sweep with sums, 81 -> 80 VGPRs for six waves,
+// costs a microsecond instead: profiles/r05_reduce_occupancy_ab.txt.)
+__global__ __launch_bounds__(AMC_BLOCK) __attribute__((amdgpu_waves_per_eu((REDUCE == RED_FORM_E && SWEEP != 0 && PgKind<POT>::Q) ? 5 : 1)))
+void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");
     constexpr bool QK = PgKind<POT>::Q;
