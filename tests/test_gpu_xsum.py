@@ -338,6 +338,37 @@ def test_only_the_sums_asked_for_are_formed(gpu, oracle, cols, potential, sigma,
     eng.close()
 
 
+@pytest.mark.parametrize("cols", [1, 3, 7])
+@pytest.mark.parametrize("potential,sigma,weight,counters", [("harmonic", [0.1], [1.0], False), ("harmonic", [0.1], [1.0], True),
+                                                             ("double_well", [0.2, 0.1], [0.6, 0.4], True)])
+def test_fused_pgmc_steps_form_the_sums_asked_for(gpu, oracle, cols, potential, sigma, weight, counters):
+    """The fused PGMC time step that also leaves the callback sums (amc_pgmc_steps_reduce_begin) in both of its forms -- sum e
+    alone compiled in (cols = 1; harmonic: also with sum x^2, the same sum), the columns of a run-time mask otherwise -- for the
+    three sweep forms it rides on (K = 1 with the pool-wide counter, K = 1 with per-chain counters, K = 2): records of the sums asked
+    for equal the oracle's, the others stay empty; sigma and the chains equal a free-running oracle."""
+    M = 40009
+    kw = dict(potential=potential, beta=2.0, sigma=sigma, weight=weight, seed=33, per_chain_counters=counters)
+    eng = gpu.HipEngine(n_chains=M, device=0, **kw)
+    ref = oracle.OracleEngine(n_chains=M, **kw)
+    lid = len(sigma) - 1
+    for e in (eng, ref):
+        e.init_uniform(-2.0, 2.0)
+        e.set_reduce_columns(cols)
+    for n in (1, 4):
+        for e in (eng, ref):
+            e.pgmc_steps(n, [lid], 1, [1], [1e-3], [0.0], reduce_begin=True)
+        rec, steps = eng.reduce_end_exact()
+        rec_o, steps_o = ref.reduce_end_exact()
+        assert steps == steps_o
+        _records_equal(rec, rec_o, f"{n} fused steps, columns {cols}")
+        out = eng.reduce_records_value(rec, steps)
+        for c in range(3):
+            assert np.isnan(out[c]) == (not cols & (1 << c))
+    assert eng.get_parameters(lid)[0] == ref.get_parameters(lid)[0]
+    assert np.array_equal(bits(eng.download_state()[0]), bits(ref.download_state()[0]))
+    eng.close()
+
+
 def test_compact_and_wide_block_rows_carry_the_same_sums(gpu, oracle, monkeypatch):
     """A launch whose lanes add at most 32 summands per column leaves ONE 64-byte row per block (tops and flags packed, 64-bit
     totals); beyond that, and with AMC_WIDE_RED_ROWS=1, the wide row.  Same records either way -- plain values, wild ones
