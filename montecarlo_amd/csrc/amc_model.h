@@ -494,17 +494,48 @@ __device__ __forceinline__ ScriptStep mh_scaled(real_t x, real_t beta, double si
 #ifdef AMC_USER_LOGQ
 // One mc_step! with a script-defined proposal (see user_sample / user_logq), in the reference's operation order
 // (metropolis.jl:176-190), up to the decision (mh_pair).
+// A class of a mixed pool that IS the particle_1d Gaussian displacement -- its expressions are, character for character, the ones
+// the host mirror writes the built-in policy out as: sample `sigma*z`, logq `-(delta*delta)/(2.0*(sigma*sigma)) -
+// amc_log(6.283185307179586*(sigma*sigma))/2.0`, the displacement's own perform / invert (amc_rtc.hip sets AMC_CLASS_GAUSS_MASK, a bit
+// per class) -- takes its density from the move's table row in the sweep (K > 1): den = 2.0*(sigma*sigma) and logc =
+// amc_log(6.283185307179586*(sigma*sigma))/2.0 are the SAME operations on the same operands, formed once per parameter change
+// (derive_move_params) instead of per lane and step, and the backward density of -delta is the forward one bit for bit
+// ((-d)*(-d) == d*d).  What the lanes of such a class save: a log (fifty vector instructions) and the second density.
+struct GaussRow {
+    bool on;
+    double den, logc;
+};
+__device__ __forceinline__ GaussRow gauss_row_off() { return GaussRow{false, 0.0, 0.0}; }
+// k: the move key (move | class << 8); s_tab: the sweep's LDS copy of the parameter table (rows sigma, den, logc, cum, rden)
+__device__ __forceinline__ GaussRow gauss_row_of(int k, const double* s_tab)
+{
+#if AMC_NCLASS > 1 && defined(AMC_CLASS_GAUSS_MASK)
+    GaussRow g;
+    g.on = (((unsigned)AMC_CLASS_GAUSS_MASK >> (k >> 8)) & 1u) != 0u;
+    g.den = s_tab[1 * AMC_MAX_MOVES + (k & 0xFF)];
+    g.logc = s_tab[2 * AMC_MAX_MOVES + (k & 0xFF)];
+    return g;
+#else
+    (void)k; (void)s_tab;
+    return gauss_row_off();
+#endif
+}
+
 template <int POT>
-__device__ __forceinline__ ScriptStep mh_script(real_t x, real_t beta, double sigma, double z, const double* T, int k, const UserTheta& th)
+__device__ __forceinline__ ScriptStep mh_script(real_t x, real_t beta, double sigma, double z, const double* T, int k, const UserTheta& th,
+                                                const GaussRow& g)
 {
     const real_t delta = user_sample(z, x, sigma, T, k, th);             // :177 sample_action!
-    const double logq_f = user_logq(delta, x, sigma, T, k, th);          // :178
+    double logq_f;                                                        // :178
+    if (g.on) logq_f = ((double)(-(delta * delta))) / g.den - g.logc;
+    else logq_f = user_logq(delta, x, sigma, T, k, th);
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T, k);                      // :179 perform_action!
     const real_t e2 = potential<POT>(xn, T);
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);                // :180
     const real_t nd = user_invert(delta, xn, T, k);                      // :181 invert_action!
-    const double logq_b = user_logq(nd, xn, sigma, T, k, th);            // :182
+    double logq_b = logq_f;                                               // :182
+    if (!g.on) logq_b = user_logq(nd, xn, sigma, T, k, th);
     ScriptStep st;
     st.arg = ((double)dlogp + logq_b) - logq_f;                          // :183
     st.xn = xn;
@@ -539,8 +570,8 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
 #ifdef AMC_USER_LOGQ
         // K == 1: the pool's only move, its parameters wave-uniform values read at the kernel's start; K > 1: the lane's move
         const int mk0 = user_move_key(MULTI ? k0 : 0), mk1 = user_move_key(MULTI ? k1 : 0);
-        const ScriptStep s0 = mh_script<POT>(xv.x, b0, sg0, z0, T, mk0, MULTI ? user_theta_lds(mk0) : th1);
-        const ScriptStep s1 = mh_script<POT>(xv.y, b1, sg1, z1, T, mk1, MULTI ? user_theta_lds(mk1) : th1);
+        const ScriptStep s0 = mh_script<POT>(xv.x, b0, sg0, z0, T, mk0, MULTI ? user_theta_lds(mk0) : th1, MULTI ? gauss_row_of(mk0, s_tab) : gauss_row_off());
+        const ScriptStep s1 = mh_script<POT>(xv.y, b1, sg1, z1, T, mk1, MULTI ? user_theta_lds(mk1) : th1, MULTI ? gauss_row_of(mk1, s_tab) : gauss_row_off());
 #else
         const ScriptStep s0 = mh_scaled<POT>(xv.x, b0, sg0, z0, T), s1 = mh_scaled<POT>(xv.y, b1, sg1, z1, T);
 #endif

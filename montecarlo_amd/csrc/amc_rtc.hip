@@ -143,7 +143,7 @@ void rtc_cache_store(const std::string& path, const RtcCode& rc)
 int rtc_compile(const std::string& expr_in, const std::string& inst, const std::string& arch, const RtcCode** out, std::string* log_out)
 {
     std::lock_guard<std::mutex> lock(g_rtc_mu);
-    const std::string key = arch + "\n" + expr_in + "\n" + inst;
+    const std::string key = arch + "\n" + expr_in + "\n" + inst + (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? "\nno-gauss-rows" : "");
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
@@ -176,7 +176,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         return expr_in.find('\x0e') != std::string::npos;
     }();
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
-                                                                           (licm_off ? " licm-off" : ""));
+                                                                           (licm_off ? " licm-off" : "") +
+                                                                           (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? " no-gauss-rows" : ""));
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -220,6 +221,14 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         }
     }
     if (!e_scale.empty()) src += "#define AMC_USER_SCALE(x) (" + e_scale + ")\n";
+    // a class whose expressions are the built-in Gaussian displacement's, as the host mirror writes them out (montecarlo_amd/metropolis.py
+    // GAUSS_SAMPLE / GAUSS_LOGQ, the displacement's own perform / invert): the sweep takes its density from the move's table row
+    // (amc_model.h GaussRow)
+    auto is_gauss = [](const std::string& sample, const std::string& logq, const std::string& perform, const std::string& invert) {
+        return sample == "sigma*z" && logq == "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0" &&
+               perform.empty() && invert.empty();
+    };
+    unsigned gauss_mask = is_gauss(e_sample, e_logq, e_perform, e_invert) ? 1u : 0u;
     if (!e_classes.empty()) {
         const size_t first = e_classes.find('\x10');
         src += "#define AMC_NCLASS " + e_classes.substr(0, first) + "\n";
@@ -236,8 +245,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
             if (!c_dlogq.empty()) src += "#define AMC_USER_DLOGQ" + sfx + "(delta, x, sigma) (" + c_dlogq + ")\n";
             src += "#define AMC_USER_PERFORM" + sfx + "(x, delta) (" + (c_perform.empty() ? std::string("(x) + (delta)") : c_perform) + ")\n";
             src += "#define AMC_USER_INVERT" + sfx + "(delta, x) (" + (c_invert.empty() ? std::string("-(delta)") : c_invert) + ")\n";
+            if (is_gauss(c_sample, c_logq, c_perform, c_invert)) gauss_mask |= 1u << c;
             at = nxt;
         }
+        if (gauss_mask != 0u && std::getenv("AMC_NO_GAUSS_CLASS_ROWS") == nullptr) src += "#define AMC_CLASS_GAUSS_MASK " + std::to_string(gauss_mask) + "\n";
     }
     const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";

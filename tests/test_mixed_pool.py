@@ -138,6 +138,33 @@ def test_gradient_data_records_equal_the_oracles(gpu, oracle, M, q_batch):
 
 
 @pytest.mark.gpu
+def test_gaussian_class_rows_equal_its_expressions(gpu, monkeypatch):
+    """Round 5: in the sweep, a class whose expressions are the built-in Gaussian displacement's takes den = 2 sigma^2 and
+    log(2 pi sigma^2)/2 from the move's table row instead of forming them per lane and step (amc_model.h GaussRow) -- the same
+    operations on the same operands, so nothing may change: 3e5 chains, single- and multi-step launches, learning steps that move
+    the Gaussian moves' sigma (the rows must follow), with the rows and with AMC_NO_GAUSS_CLASS_ROWS=1."""
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("AMC_NO_GAUSS_CLASS_ROWS", "1")
+        else:
+            monkeypatch.delenv("AMC_NO_GAUSS_CLASS_ROWS", raising=False)
+        e = gpu.HipEngine(device=0, **_kw(300001))
+        e.init_uniform(-2.0, 2.0)
+        for _ in range(5):
+            e.sweep(1)
+        e.sweep(40)
+        e.pgmc_steps(25, [0, 1, 2], 1, [1, 1, 2], [0.05, 0.05, 0.02], [0.0, 0.0, 0.0])
+        e.sweep(20)
+        acc, tot = e.download_counters()
+        runs.append((e.download_state()[0], acc, tot, [e.get_parameters(k)[0] for k in range(4)]))
+        e.close()
+    assert runs[0][3] == runs[1][3] and runs[0][3][0] != SIGMA[0] and runs[0][3][2] != SIGMA[2]     # the Gaussian moves learned
+    assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
+    assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.gpu
 def test_free_running_pgmc_and_shard_split(gpu, oracle):
     eng, ref = gpu.HipEngine(device=0, **_kw(20011)), oracle.OracleEngine(**_kw(20011))
     three = gpu.SplitEngine(device=0, n_parts=3, **_kw(20011))
