@@ -156,8 +156,19 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     const real_t dlogp = ((-e2) * beta) - ((-e1) * beta);
     const double r = (POT == POT_CUSTOM) ? user_reward(delta, xn, T) : (double)(delta * delta);
     const real_t nd = user_invert(delta, xn, T, k);
-    const double logq_b = user_logq(nd, xn, sigma, T, k, th);
-    user_dlogq(nd, xn, sigma, T, k, th, d_b);
+    double logq_b = logq_f;
+#if AMC_NCLASS > 1 && defined(AMC_CLASS_GAUSS_EST_MASK)
+    // the launch's move belongs to a class that IS the built-in Gaussian displacement, derivative included (amc_rtc.hip): the backward
+    // density and its derivative at -delta are the forward ones bit for bit ((-d)*(-d) == d*d) -- not formed again (wave-uniform branch)
+    if ((((unsigned)AMC_CLASS_GAUSS_EST_MASK >> (k >> 8)) & 1u) != 0u) {
+#pragma unroll
+        for (int p = 0; p < AMC_NP; ++p) d_b[p] = d_f[p];
+    } else
+#endif
+    {
+        logq_b = user_logq(nd, xn, sigma, T, k, th);
+        user_dlogq(nd, xn, sigma, T, k, th, d_b);
+    }
     x = user_perform(xn, nd, T, k);
     const double arg = ((double)dlogp + logq_b) - logq_f;
     double ex = exp_core_f64(arg, T);

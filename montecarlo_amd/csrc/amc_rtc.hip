@@ -228,7 +228,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
         return sample == "sigma*z" && logq == "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0" &&
                perform.empty() && invert.empty();
     };
+    // ... derivative included (GAUSS_DLOGQ): the estimator then knows the backward density and derivative without forming them
+    auto is_gauss_d = [](const std::string& dlogq) { return dlogq == "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma"; };
     unsigned gauss_mask = is_gauss(e_sample, e_logq, e_perform, e_invert) ? 1u : 0u;
+    unsigned gauss_est_mask = (gauss_mask && is_gauss_d(e_dlogq)) ? 1u : 0u;
     if (!e_classes.empty()) {
         const size_t first = e_classes.find('\x10');
         src += "#define AMC_NCLASS " + e_classes.substr(0, first) + "\n";
@@ -245,10 +248,16 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
             if (!c_dlogq.empty()) src += "#define AMC_USER_DLOGQ" + sfx + "(delta, x, sigma) (" + c_dlogq + ")\n";
             src += "#define AMC_USER_PERFORM" + sfx + "(x, delta) (" + (c_perform.empty() ? std::string("(x) + (delta)") : c_perform) + ")\n";
             src += "#define AMC_USER_INVERT" + sfx + "(delta, x) (" + (c_invert.empty() ? std::string("-(delta)") : c_invert) + ")\n";
-            if (is_gauss(c_sample, c_logq, c_perform, c_invert)) gauss_mask |= 1u << c;
+            if (is_gauss(c_sample, c_logq, c_perform, c_invert)) {
+                gauss_mask |= 1u << c;
+                if (is_gauss_d(c_dlogq)) gauss_est_mask |= 1u << c;
+            }
             at = nxt;
         }
-        if (gauss_mask != 0u && std::getenv("AMC_NO_GAUSS_CLASS_ROWS") == nullptr) src += "#define AMC_CLASS_GAUSS_MASK " + std::to_string(gauss_mask) + "\n";
+        if (gauss_mask != 0u && std::getenv("AMC_NO_GAUSS_CLASS_ROWS") == nullptr) {
+            src += "#define AMC_CLASS_GAUSS_MASK " + std::to_string(gauss_mask) + "\n";
+            if (gauss_est_mask != 0u) src += "#define AMC_CLASS_GAUSS_EST_MASK " + std::to_string(gauss_est_mask) + "\n";
+        }
     }
     const size_t cut = expr.find('\x01');
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
