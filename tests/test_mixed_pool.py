@@ -78,6 +78,18 @@ def _mixed_simulation(ma, engine_factory, path, device_resident=None, steps=30):
     return chains, pool, sim
 
 
+def test_canonical_gaussian_expressions_are_the_same_text_everywhere():
+    """The sweep's table-row form of a Gaussian class (amc_model.h GaussRow) and the estimator's shortcut are switched on by TEXT:
+    the class's expressions must be, character for character, the ones the host mirror writes the built-in policy out as.  The three
+    places that hold that text -- montecarlo_amd/metropolis.py, amc_rtc.hip, this file's GAUSS -- must agree."""
+    import os
+    from montecarlo_amd import metropolis as mp
+    assert (mp.GAUSS_SAMPLE, mp.GAUSS_LOGQ, mp.GAUSS_DLOGQ) == GAUSS
+    rtc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "montecarlo_amd", "csrc", "amc_rtc.hip")).read()
+    for text in GAUSS:
+        assert '"' + text + '"' in rtc, text
+
+
 def test_host_mirror_builds_the_classes_of_a_mixed_pool(oracle, tmp_path):
     """Metropolis used to refuse a pool whose moves do not share one policy; it now hands the engine one class per distinct
     (policy, action) pair -- the built-in Gaussian written out as expressions -- and the run equals the oracle driven by hand."""
