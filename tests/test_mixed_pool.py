@@ -80,14 +80,16 @@ def _mixed_simulation(ma, engine_factory, path, device_resident=None, steps=30):
 
 def test_canonical_gaussian_expressions_are_the_same_text_everywhere():
     """The sweep's table-row form of a Gaussian class (amc_model.h GaussRow) and the estimator's shortcut are switched on by TEXT:
-    the class's expressions must be, character for character, the ones the host mirror writes the built-in policy out as.  The three
-    places that hold that text -- montecarlo_amd/metropolis.py, amc_rtc.hip, this file's GAUSS -- must agree."""
+    the class's expressions must be, character for character, the ones the host mirror writes the built-in policy out as.  The
+    places that hold that text -- montecarlo_amd/metropolis.py, amc_rtc.hip, julia/AriannaHIP.jl, this file's GAUSS -- must agree."""
     import os
     from montecarlo_amd import metropolis as mp
     assert (mp.GAUSS_SAMPLE, mp.GAUSS_LOGQ, mp.GAUSS_DLOGQ) == GAUSS
     rtc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "montecarlo_amd", "csrc", "amc_rtc.hip")).read()
+    jl = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "AriannaHIP.jl")).read()
     for text in GAUSS:
         assert '"' + text + '"' in rtc, text
+        assert '"' + text + '"' in jl, text            # AriannaHIP.GAUSS_CLASS
 
 
 def test_host_mirror_builds_the_classes_of_a_mixed_pool(oracle, tmp_path):
