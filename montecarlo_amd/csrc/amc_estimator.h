@@ -44,7 +44,7 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
     if (REDUCE && SWEEP == 3 && threadIdx.x == 0)
         for (int sl = (int)blockIdx.x; sl < sw.n_slots; sl += (int)gridDim.x) slots_before += sw.acc_total[sl];
     __shared__ double s_math[TAB_DOUBLES];
-    __shared__ double s_tab[SWEEP == 2 ? 5 * AMC_MAX_MOVES : 1];
+    __shared__ double s_tab[SWEEP == 2 ? (5 + AMC_SIGMA_MEMO) * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[SWEEP == 2 ? AMC_PICK_CELLS : 16];
     // the GradientData fold: wave slots of the columns' integer totals
     __shared__ QSlot s_gq[AMC_BLOCK / 64][QK ? NV : 1];
@@ -57,6 +57,7 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
             s_tab[2 * AMC_MAX_MOVES + i] = sw.ptab[PT_LOGC * AMC_MAX_MOVES + i];
             s_tab[3 * AMC_MAX_MOVES + i] = sw.ptab[PT_CUM * AMC_MAX_MOVES + i];
             s_tab[4 * AMC_MAX_MOVES + i] = sw.ptab[PT_RDEN * AMC_MAX_MOVES + i];
+            if (AMC_SIGMA_MEMO) s_tab[(AMC_SIGMA_MEMO ? 5 : 0) * AMC_MAX_MOVES + i] = log_f64(sw.ptab[PT_SIGMA * AMC_MAX_MOVES + i]);      // (SigmaArg)
         }
     }
     double sw_sigma1 = SWEEP ? sw.ptab[PT_SIGMA * AMC_MAX_MOVES] : 0.0;

@@ -141,6 +141,23 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
 //   AMC_USER_PERFORM(x, delta)    the position after perform_action!(system, action)        (displacement: x + delta)
 //   AMC_USER_INVERT(delta, x)     the parameter of the inverted action, given the NEW state (displacement: -delta)
 // perform_action_cached! (the revert) re-applies the inverted action, as the reference does (metropolis.jl:119,187).
+// `sigma` as the expressions see it in a K > 1 sweep: the lane's sigma with log(sigma) beside it.  There the lanes of a wave hold
+// different moves, so no function of sigma alone leaves the loop the way it does where the move is wave-uniform -- but sigma takes
+// only K values: the block forms amc_log(sigma_k) once per launch (row 5 of the sweep's LDS table, the same log_f64 on the same
+// operand: the same bits) and `amc_log(sigma)` in an expression -- the Langevin proposal's normalisation, say -- reads it instead of
+// spending fifty vector instructions per lane and step.  Everywhere else SigmaArg is a double: it converts, and only this one call
+// knows it.  AMC_SIGMA_MEMO: the row exists (script-defined proposals; AMC_NO_SIGMA_MEMO, set by the run-time compiler for A/B, drops it).
+#if defined(AMC_USER_LOGQ) && !defined(AMC_NO_SIGMA_MEMO)
+#define AMC_SIGMA_MEMO 1
+#else
+#define AMC_SIGMA_MEMO 0
+#endif
+struct SigmaArg {
+    double v, logv;
+    __device__ __forceinline__ operator double() const { return v; }
+};
+__device__ __forceinline__ double log_f64(const SigmaArg& s) { return s.logv; }
+
 struct UserTheta {          // a script-defined policy's parameters theta1 .. theta3 of one move (see AMC_USER_THETAS)
     double t1, t2, t3;
 };
@@ -220,10 +237,10 @@ __device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const doub
 #if AMC_NP > 1
 __shared__ double s_user_theta[AMC_MAX_NP - 1][AMC_MAX_MOVES];
 #define AMC_USER_THETAS(th)                                                                                            \
-    const double theta0 = sigma, theta1 = (th).t1, theta2 = (th).t2, theta3 = (th).t3;                                  \
+    const double theta0 = (double)sigma, theta1 = (th).t1, theta2 = (th).t2, theta3 = (th).t3;                                  \
     (void)theta0; (void)theta1; (void)theta2; (void)theta3
 #else
-#define AMC_USER_THETAS(th) const double theta0 = sigma; (void)theta0; (void)th
+#define AMC_USER_THETAS(th) const double theta0 = (double)sigma; (void)theta0; (void)th
 #endif
 // k: the move key (user_move_key).  Per lane, from the LDS copy staged by stage_user_theta:
 __device__ __forceinline__ UserTheta user_theta_lds(int k)
@@ -281,7 +298,8 @@ __device__ __forceinline__ int user_move_key_uniform(int k, const double* ptab) 
     return k;
 #endif
 }
-__device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th)
+template <class S>
+__device__ __forceinline__ real_t user_sample(double z, real_t x, S sigma, const double* amc_tables_, int k, const UserTheta& th)
 {
     AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
@@ -290,7 +308,8 @@ __device__ __forceinline__ real_t user_sample(double z, real_t x, double sigma, 
     return (real_t)(AMC_USER_SAMPLE(z, x, sigma));    // Displacement.delta::T
 #endif
 }
-__device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th)
+template <class S>
+__device__ __forceinline__ double user_logq(real_t delta, real_t x, S sigma, const double* amc_tables_, int k, const UserTheta& th)
 {
     AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
@@ -300,7 +319,8 @@ __device__ __forceinline__ double user_logq(real_t delta, real_t x, double sigma
 #endif
 }
 // grad log_proposal_density with respect to the parameters, d[p] = d logq / d theta_p
-__device__ __forceinline__ void user_dlogq(real_t delta, real_t x, double sigma, const double* amc_tables_, int k, const UserTheta& th,
+template <class S>
+__device__ __forceinline__ void user_dlogq(real_t delta, real_t x, S sigma, const double* amc_tables_, int k, const UserTheta& th,
                                            double (&d)[AMC_NP])
 {
     AMC_USER_THETAS(th);
@@ -521,8 +541,8 @@ __device__ __forceinline__ GaussRow gauss_row_of(int k, const double* s_tab)
 #endif
 }
 
-template <int POT>
-__device__ __forceinline__ ScriptStep mh_script(real_t x, real_t beta, double sigma, double z, const double* T, int k, const UserTheta& th,
+template <int POT, class S>
+__device__ __forceinline__ ScriptStep mh_script(real_t x, real_t beta, S sigma, double z, const double* T, int k, const UserTheta& th,
                                                 const GaussRow& g)
 {
     const real_t delta = user_sample(z, x, sigma, T, k, th);             // :177 sample_action!
@@ -570,8 +590,15 @@ __device__ __forceinline__ void mh_pair(real2& xv, real_t b0, real_t b1, double 
 #ifdef AMC_USER_LOGQ
         // K == 1: the pool's only move, its parameters wave-uniform values read at the kernel's start; K > 1: the lane's move
         const int mk0 = user_move_key(MULTI ? k0 : 0), mk1 = user_move_key(MULTI ? k1 : 0);
-        const ScriptStep s0 = mh_script<POT>(xv.x, b0, sg0, z0, T, mk0, MULTI ? user_theta_lds(mk0) : th1, MULTI ? gauss_row_of(mk0, s_tab) : gauss_row_off());
-        const ScriptStep s1 = mh_script<POT>(xv.y, b1, sg1, z1, T, mk1, MULTI ? user_theta_lds(mk1) : th1, MULTI ? gauss_row_of(mk1, s_tab) : gauss_row_off());
+        ScriptStep s0, s1;
+        if (MULTI && AMC_SIGMA_MEMO) {          // the lane's sigma with its log from the block's table (SigmaArg)
+            const SigmaArg a0 = {sg0, s_tab[(AMC_SIGMA_MEMO ? 5 : 0) * AMC_MAX_MOVES + (MULTI ? k0 : 0)]}, a1 = {sg1, s_tab[(AMC_SIGMA_MEMO ? 5 : 0) * AMC_MAX_MOVES + (MULTI ? k1 : 0)]};
+            s0 = mh_script<POT>(xv.x, b0, a0, z0, T, mk0, user_theta_lds(mk0), gauss_row_of(mk0, s_tab));
+            s1 = mh_script<POT>(xv.y, b1, a1, z1, T, mk1, user_theta_lds(mk1), gauss_row_of(mk1, s_tab));
+        } else {
+            s0 = mh_script<POT>(xv.x, b0, sg0, z0, T, mk0, MULTI ? user_theta_lds(mk0) : th1, MULTI ? gauss_row_of(mk0, s_tab) : gauss_row_off());
+            s1 = mh_script<POT>(xv.y, b1, sg1, z1, T, mk1, MULTI ? user_theta_lds(mk1) : th1, MULTI ? gauss_row_of(mk1, s_tab) : gauss_row_off());
+        }
 #else
         const ScriptStep s0 = mh_scaled<POT>(xv.x, b0, sg0, z0, T), s1 = mh_scaled<POT>(xv.y, b1, sg1, z1, T);
 #endif

@@ -143,7 +143,8 @@ void rtc_cache_store(const std::string& path, const RtcCode& rc)
 int rtc_compile(const std::string& expr_in, const std::string& inst, const std::string& arch, const RtcCode** out, std::string* log_out)
 {
     std::lock_guard<std::mutex> lock(g_rtc_mu);
-    const std::string key = arch + "\n" + expr_in + "\n" + inst + (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? "\nno-gauss-rows" : "");
+    const std::string key = arch + "\n" + expr_in + "\n" + inst + (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? "\nno-gauss-rows" : "") +
+                            (std::getenv("AMC_NO_SIGMA_MEMO") ? "\nno-sigma-memo" : "");
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
@@ -177,7 +178,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     }();
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : "") +
-                                                                           (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? " no-gauss-rows" : ""));
+                                                                           (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? " no-gauss-rows" : "") +
+                                                                           (std::getenv("AMC_NO_SIGMA_MEMO") ? " no-sigma-memo" : ""));
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -193,6 +195,7 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     std::string expr = expr_full;
     std::string src;
     if (f32) src += "#define AMC_STATE_F32 1\n";
+    if (std::getenv("AMC_NO_SIGMA_MEMO")) src += "#define AMC_NO_SIGMA_MEMO 1\n";      // A/B: amc_log(sigma) per lane and step in K > 1 sweeps (amc_model.h SigmaArg)
     auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
         const size_t at = expr.find(mark);
         if (at == std::string::npos) return std::string();

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     RLanes<RNC> red;
     __shared__ xs::PartR s_red[REDUCE ? AMC_BLOCK / 64 : 1][RNC];
     if (REDUCE) r_init(red, s_red[threadIdx.x >> 6]);
-    __shared__ double s_tab[MULTI ? 5 * AMC_MAX_MOVES : 1];
+    __shared__ double s_tab[MULTI ? (5 + AMC_SIGMA_MEMO) * AMC_MAX_MOVES : 1];
     __shared__ __attribute__((aligned(16))) uint8_t s_pick[MULTI ? AMC_PICK_CELLS : 16];
     __shared__ double s_math[TAB_DOUBLES];        // exp / log / sincospi tables, 4.4 KB
     const int K = a.n_moves;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
             s_tab[2 * AMC_MAX_MOVES + i] = a.ptab[PT_LOGC * AMC_MAX_MOVES + i];
             s_tab[3 * AMC_MAX_MOVES + i] = a.ptab[PT_CUM * AMC_MAX_MOVES + i];
             s_tab[4 * AMC_MAX_MOVES + i] = a.ptab[PT_RDEN * AMC_MAX_MOVES + i];
+            if (AMC_SIGMA_MEMO) s_tab[(AMC_SIGMA_MEMO ? 5 : 0) * AMC_MAX_MOVES + i] = log_f64(a.ptab[PT_SIGMA * AMC_MAX_MOVES + i]);      // (SigmaArg)
         }
         // visible to the block after the barrier that ends stage_math_tables below
     }

@@ -152,28 +152,36 @@ def test_gradient_data_records_equal_the_oracles(gpu, oracle, M, q_batch):
 
 
 @pytest.mark.gpu
-def test_gaussian_class_rows_equal_its_expressions(gpu, monkeypatch):
-    """Round 5: in the sweep, a class whose expressions are the built-in Gaussian displacement's takes den = 2 sigma^2 and
-    log(2 pi sigma^2)/2 from the move's table row instead of forming them per lane and step (amc_model.h GaussRow) -- the same
-    operations on the same operands, so nothing may change: 3e5 chains, single- and multi-step launches, learning steps that move
-    the Gaussian moves' sigma (the rows must follow), with the rows and with AMC_NO_GAUSS_CLASS_ROWS=1."""
+@pytest.mark.parametrize("knob,pool", [("AMC_NO_GAUSS_CLASS_ROWS", "classes"), ("AMC_NO_SIGMA_MEMO", "classes"), ("AMC_NO_SIGMA_MEMO", "langevin_k2")])
+def test_table_rows_and_the_sigma_memo_equal_the_expressions(gpu, monkeypatch, knob, pool):
+    """Round 5, K > 1 sweeps of script-defined pools.  (a) A class whose expressions are the built-in Gaussian displacement's takes
+    den = 2 sigma^2 and log(2 pi sigma^2)/2 from the move's table row instead of forming them per lane and step (amc_model.h
+    GaussRow); (b) `amc_log(sigma)` in any expression reads log(sigma_k), formed once per launch and move, instead of fifty vector
+    instructions per lane and step (SigmaArg).  The same operations on the same operands, so nothing may change: 3e5 chains, single-
+    and multi-step launches, fused time steps, learning steps that move sigma (rows and memo must follow) -- with the shortcut and
+    with its knob set."""
+    if pool == "classes":
+        kw, learn, kinds, h0 = _kw(300001), [0, 1, 2], [1, 1, 2], [0.05, 0.05, 0.02]
+    else:
+        kw = dict(n_chains=300001, potential="double_well", beta=BETA, sigma=[0.2, 0.6], weight=[0.3, 0.7], seed=5, proposal=MALA)
+        learn, kinds, h0 = [0, 1], [1, 2], [0.02, 0.02]
     runs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("AMC_NO_GAUSS_CLASS_ROWS", "1")
+            monkeypatch.setenv(knob, "1")
         else:
-            monkeypatch.delenv("AMC_NO_GAUSS_CLASS_ROWS", raising=False)
-        e = gpu.HipEngine(device=0, **_kw(300001))
+            monkeypatch.delenv(knob, raising=False)
+        e = gpu.HipEngine(device=0, **kw)
         e.init_uniform(-2.0, 2.0)
         for _ in range(5):
             e.sweep(1)
         e.sweep(40)
-        e.pgmc_steps(25, [0, 1, 2], 1, [1, 1, 2], [0.05, 0.05, 0.02], [0.0, 0.0, 0.0])
+        e.pgmc_steps(25, learn, 1, kinds, h0, [0.0] * len(learn))
         e.sweep(20)
         acc, tot = e.download_counters()
-        runs.append((e.download_state()[0], acc, tot, [e.get_parameters(k)[0] for k in range(4)]))
+        runs.append((e.download_state()[0], acc, tot, [e.get_parameters(k)[0] for k in range(len(kw["sigma"]))]))
         e.close()
-    assert runs[0][3] == runs[1][3] and runs[0][3][0] != SIGMA[0] and runs[0][3][2] != SIGMA[2]     # the Gaussian moves learned
+    assert runs[0][3] == runs[1][3] and all(runs[0][3][k] != kw["sigma"][k] for k in learn)        # the moves learned
     assert np.array_equal(bits(runs[0][0]), bits(runs[1][0]))
     assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
 
