@@ -134,7 +134,8 @@ __device__ __forceinline__ double user_scale(real_t x, const double* amc_tables_
 //   AMC_USER_DLOGQ(delta, x, sigma)   its derivative with respect to sigma (what the reference gets from ForwardDiff /
 //                                     Enzyme / Zygote, gradients.jl:28-33); optional, needed by the estimator only
 // mc_step! (metropolis.jl:176-190) evaluates the forward density at the old state and the backward one, of the
-// inverted action, at the new state; nothing cancels, every decision takes the reference-ordered arithmetic.
+// inverted action, at the new state; nothing cancels, arg is formed in full in the reference's operations (and since round 5 decided
+// through the accept filter like the built-in path's: accept_filter_arg).
 // ... and a script-defined ACTION (the reference's Action interface, src/metropolis.jl:15-119: perform_action!,
 // invert_action!, perform_action_cached!; example/particle_1d/particle_1d.jl:30-40 are the displacement's methods), for a
 // one-parameter action on the position:
