@@ -65,10 +65,10 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
     double sw_logc1 = SWEEP ? sw.ptab[PT_LOGC * AMC_MAX_MOVES] : 0.0;
     double sw_rden1 = SWEEP ? sw.ptab[PT_RDEN * AMC_MAX_MOVES] : 0.0;
     // script-defined policies: the further parameters of the sweep's only move (K == 1) and of the learnable moves, wave-uniform
-    UserTheta sw_th1 = {0.0, 0.0, 0.0};
+    UserTheta sw_th1 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     UserTheta c_th[NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) c_th[l] = UserTheta{0.0, 0.0, 0.0};
+    for (int l = 0; l < NL; ++l) c_th[l] = UserTheta{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #ifdef AMC_USER_LOGQ
     if (SWEEP == 1 || SWEEP == 3) sw_th1 = user_theta_uniform(sw.ptab, 0);
 #pragma unroll
@@ -302,7 +302,7 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
         if (BETA) b_nxt = load_b(first);
     }
 #ifdef AMC_USER_LOGQ
-    stage_user_theta(a.ptab);
+    stage_user_theta(a.ptab, SWEEP == 2);
 #endif
     // the accumulators' constants, formed with the first load in flight: they need sigma's value at once -- a scalar load of a table the
     // previous launch's learning step has just rewritten, and a wait

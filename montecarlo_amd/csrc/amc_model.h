@@ -159,8 +159,9 @@ struct SigmaArg {
 };
 __device__ __forceinline__ double log_f64(const SigmaArg& s) { return s.logv; }
 
-struct UserTheta {          // a script-defined policy's parameters theta1 .. theta3 of one move (see AMC_USER_THETAS)
+struct UserTheta {          // a script-defined policy's parameters theta1 .. theta3 of one move (see AMC_USER_THETAS), their logs beside them
     double t1, t2, t3;
+    double l1, l2, l3;      // (AMC_SIGMA_MEMO: what amc_log(theta_p) reads -- per move from the block's table in a K > 1 sweep)
 };
 #ifdef AMC_USER_LOGQ
 #ifndef AMC_USER_PERFORM
@@ -237,20 +238,34 @@ __device__ __forceinline__ real_t user_invert(real_t delta, real_t x, const doub
 // could leave the loop, and the two-parameter drift + width policy paid ~1070 vector instructions per wave-trip.)
 #if AMC_NP > 1
 __shared__ double s_user_theta[AMC_MAX_NP - 1][AMC_MAX_MOVES];
+#if AMC_SIGMA_MEMO
+__shared__ double s_user_theta_log[AMC_MAX_NP - 1][AMC_MAX_MOVES];       // log(theta_p) of every move (stage_user_theta), see SigmaArg
+// theta0 is sigma as the function got it (a SigmaArg in a K > 1 sweep); theta1 .. theta3 carry their logs the same way
+#define AMC_USER_THETAS(th)                                                                                            \
+    const auto theta0 = sigma;                                                                                         \
+    const SigmaArg theta1 = {(th).t1, (th).l1}, theta2 = {(th).t2, (th).l2}, theta3 = {(th).t3, (th).l3};              \
+    (void)theta0; (void)theta1; (void)theta2; (void)theta3
+#else
 #define AMC_USER_THETAS(th)                                                                                            \
     const double theta0 = (double)sigma, theta1 = (th).t1, theta2 = (th).t2, theta3 = (th).t3;                                  \
     (void)theta0; (void)theta1; (void)theta2; (void)theta3
+#endif
 #else
 #define AMC_USER_THETAS(th) const double theta0 = (double)sigma; (void)theta0; (void)th
 #endif
 // k: the move key (user_move_key).  Per lane, from the LDS copy staged by stage_user_theta:
 __device__ __forceinline__ UserTheta user_theta_lds(int k)
 {
-    UserTheta th = {0.0, 0.0, 0.0};
+    UserTheta th = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #if AMC_NP > 1
     th.t1 = s_user_theta[0][k & 0xFF];
     if (AMC_NP > 2) th.t2 = s_user_theta[1][k & 0xFF];
     if (AMC_NP > 3) th.t3 = s_user_theta[2][k & 0xFF];
+#if AMC_SIGMA_MEMO
+    th.l1 = s_user_theta_log[0][k & 0xFF];
+    if (AMC_NP > 2) th.l2 = s_user_theta_log[1][k & 0xFF];
+    if (AMC_NP > 3) th.l3 = s_user_theta_log[2][k & 0xFF];
+#endif
 #else
     (void)k;
 #endif
@@ -259,17 +274,24 @@ __device__ __forceinline__ UserTheta user_theta_lds(int k)
 // ... and of a move the whole wave shares (k wave-uniform), from the parameter table itself: scalar loads
 __device__ __forceinline__ UserTheta user_theta_uniform(const double* ptab, int k)
 {
-    UserTheta th = {0.0, 0.0, 0.0};
+    UserTheta th = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #if AMC_NP > 1
     th.t1 = ptab[PT_THETA1 * AMC_MAX_MOVES + (k & 0xFF)];
     if (AMC_NP > 2) th.t2 = ptab[(PT_THETA1 + 1) * AMC_MAX_MOVES + (k & 0xFF)];
     if (AMC_NP > 3) th.t3 = ptab[(PT_THETA1 + 2) * AMC_MAX_MOVES + (k & 0xFF)];
+#if AMC_SIGMA_MEMO
+    // wave-uniform values formed once, at the kernel's start (and not at all where no expression asks for a log)
+    th.l1 = log_f64(th.t1);
+    if (AMC_NP > 2) th.l2 = log_f64(th.t2);
+    if (AMC_NP > 3) th.l3 = log_f64(th.t3);
+#endif
 #else
     (void)ptab; (void)k;
 #endif
     return th;
 }
-__device__ __forceinline__ void stage_user_theta(const double* ptab)       // before a barrier the caller already has
+// with_logs: the kernel reads the per-lane copy (a K > 1 sweep) -- the block forms log(theta_p) of every move beside it
+__device__ __forceinline__ void stage_user_theta(const double* ptab, bool with_logs = false)       // before a barrier the caller already has
 {
 #if AMC_NCLASS > 1
     for (int i = threadIdx.x; i < AMC_MAX_MOVES; i += AMC_BLOCK) s_user_class[i] = (int)ptab[PT_CLASS * AMC_MAX_MOVES + i];
@@ -277,7 +299,15 @@ __device__ __forceinline__ void stage_user_theta(const double* ptab)       // be
 #if AMC_NP > 1
     for (int i = threadIdx.x; i < (AMC_NP - 1) * AMC_MAX_MOVES; i += AMC_BLOCK)
         s_user_theta[i / AMC_MAX_MOVES][i % AMC_MAX_MOVES] = ptab[(PT_THETA1 + i / AMC_MAX_MOVES) * AMC_MAX_MOVES + i % AMC_MAX_MOVES];
+#if AMC_SIGMA_MEMO
+    if (with_logs)
+        for (int i = threadIdx.x; i < (AMC_NP - 1) * AMC_MAX_MOVES; i += AMC_BLOCK)
+            s_user_theta_log[i / AMC_MAX_MOVES][i % AMC_MAX_MOVES] = log_f64(ptab[(PT_THETA1 + i / AMC_MAX_MOVES) * AMC_MAX_MOVES + i % AMC_MAX_MOVES]);
 #else
+    (void)with_logs;
+#endif
+#else
+    (void)with_logs;
     (void)ptab;
 #endif
 }

@@ -107,7 +107,7 @@ __device__ __forceinline__ void pair_steps(const SweepArgs& a, real2& xv, real_t
                                            const double* s_math, double sigma1, double den1, double rden1, double logc1,
                                            unsigned long long& wave_acc, uint32_t& log_word,
                                            const StepDraws* pre = nullptr, const MathK& mk = math_k_literal(),
-                                           const UserTheta& th1 = UserTheta{0.0, 0.0, 0.0})
+                                           const UserTheta& th1 = UserTheta{0.0, 0.0, 0.0, 0.0, 0.0, 0.0})
 {
     static_assert(!PRE || SINGLE, "pre-formed draws cover exactly one step");
     const int K = a.n_moves;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     const double den1 = a.ptab[PT_DEN * AMC_MAX_MOVES];
     const double logc1 = a.ptab[PT_LOGC * AMC_MAX_MOVES];
     const double rden1 = a.ptab[PT_RDEN * AMC_MAX_MOVES];
-    UserTheta th1 = {0.0, 0.0, 0.0};
+    UserTheta th1 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #ifdef AMC_USER_LOGQ
     if (!MULTI) th1 = user_theta_uniform(a.ptab, 0);
 #endif
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(AMC_BLOCK) void sweep_kernel(const SweepArgs a)
     StepDraws dr_nxt = {};
     if (AHEAD && first < n_pairs) dr_nxt = step_draws(a, a.pair0 + (uint64_t)(first + threadIdx.x), a.t0);
 #ifdef AMC_USER_LOGQ
-    stage_user_theta(a.ptab);
+    stage_user_theta(a.ptab, MULTI);
 #endif
     stage_math_tables(s_math, threadIdx.x, AMC_BLOCK);     // overlaps the latency of the first load; ends in a barrier
     // Drain the first load HERE, once.  Otherwise the compiler must assume it is still pending inside the loop
