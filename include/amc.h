@@ -53,7 +53,13 @@ typedef enum amc_status {
     AMC_ERR_OOM = -3,
     AMC_ERR_NO_DEVICE = -4,
     AMC_ERR_STATE = -5,
-    AMC_ERR_COMM = -6
+    AMC_ERR_COMM = -6,
+    /* a script-defined model could not be BUILT for a reason that is not the script's: the run-time compiler died (a fatal
+     * error inside LLVM), did not come back in time, or could not be started.  It runs in a child process that never touches
+     * the GPU (amc_rtc_worker, beside libamc.so), so the caller's process is alive and amc_last_error() holds the compiler's
+     * last words.  An expression that does not compile is the caller's error: AMC_ERR_BAD_ARG with the first diagnostic.
+     * Reference convention: raise, do not die -- error("No ... is defined"), src/metropolis.jl:35. */
+    AMC_ERR_COMPILE = -7
 } amc_status;
 
 /* potential(x): free function the driver script defines
@@ -218,6 +224,15 @@ int  amc_create_mixed_model(const amc_config *cfg, int n_classes, const int *cla
                             const char *reward_expr, const char *const *sample_exprs, const char *const *logq_exprs,
                             const char *const *dlogq_exprs, const char *const *perform_exprs, const char *const *invert_exprs,
                             amc_handle **out);
+/* How an estimator call over n_learn learnable moves of this handle would run: returns 1 = ONE launch takes every learnable
+ * move (the reference's make_step!(::PolicyGradientEstimator) loops over all of them in one step, estimator.jl:111-134), with
+ * `fused` != 0: one launch per whole time step (sweep + estimator [+ update]: amc_pgmc_steps); 0 = one launch per learnable
+ * move; < 0 = an amc_status.  Only a pool of several classes can answer 0 for a one-parameter policy: its several-move kernel
+ * form is asked of the run-time compiler on first use, and where the compiler fails on it (hipcc 7.2 meets a back-end error on
+ * some pools; the compiler runs in a child process, AMC_ERR_COMPILE) the calls fall back to the one-move form -- same samples,
+ * same sums, same bits.  `why` (may be NULL) then receives the compiler's last words.  The call itself triggers that first
+ * build, so it doubles as a warm-up.  Policies with several parameters: 0, except n_learn == 1 (one launch). */
+int  amc_pg_route(amc_handle *h, int n_learn, int q_batch, int fused, char *why, int why_capacity);
 /* The same with a script-defined ACTION -- the reference's Action interface (src/metropolis.jl:15-119; the displacement's
  * methods are example/particle_1d/particle_1d.jl:30-40) for a one-parameter action on the position:
  *     perform_expr   the position after perform_action!(system, action), from `x` and `delta`      (displacement: x + delta)

@@ -116,6 +116,7 @@ def load() -> C.CDLL:
         "amc_xsum_merge": (C.c_int, [dp, dp, C.c_int]),
         "amc_xsum_round": (C.c_int, [dp, C.c_int, dp]),
         "amc_pg_estimate_exact": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
+        "amc_pg_route": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
         "amc_allreduce_xsum": (C.c_int, [H, dp, C.c_int]),
         "amc_comm_library_forced": (C.c_int, [C.POINTER(C.c_int)]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
@@ -527,6 +528,16 @@ class HipEngine:
         out = np.zeros((n, self.gd_stride, AMC_XSUM_WORDS), dtype=np.float64)
         _check(self._lib.amc_pg_estimate_exact(self._h, n, ids, int(q_batch), _dptr(out)))
         return out
+
+    def pg_route(self, n_learn: int, q_batch: int = 1, fused: bool = False):
+        """(one_launch, why): whether an estimator call over n_learn learnable moves takes them all in ONE launch (with
+        ``fused``: one launch per whole time step), and, for a pool of several classes whose several-move kernel form the
+        run-time compiler fails on, what the compiler said (the calls then take one launch per move: same bits)."""
+        why = C.create_string_buffer(2048)
+        rc = self._lib.amc_pg_route(self._h, int(n_learn), int(q_batch), int(bool(fused)), why, len(why))
+        if rc < 0:
+            _check(rc)
+        return bool(rc), why.value.decode(errors="replace")
 
     def pg_accumulate(self, learn_ids: Sequence[int], q_batch: int) -> None:
         """Estimator step kept on the device: gradients_data[k] += gd (asynchronous)."""

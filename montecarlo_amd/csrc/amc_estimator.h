@@ -77,6 +77,9 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 #endif
     // a learning step the previous launch left pending (pg_apply_pending): wave-uniform
     constexpr bool CAN_DEFER = QK && NL <= 2 && AMC_NP == 1;
+    // the pending branch below rewrites the learnable moves' rows 0, 1, 2, 4 of s_tab from sigma', NOT row 5 (the memoised
+    // log(sigma_k) of script-defined proposals): forms with the memo are kind R and never defer -- keep it that way, or add the row
+    static_assert(!(CAN_DEFER && AMC_SIGMA_MEMO), "a deferred learning step would leave the memoised log(sigma) one step behind");
     const int pending = CAN_DEFER ? pg_pending_of(a.tail_mode) : 0;
     __shared__ double s_pend_val[CAN_DEFER ? NL * 4 : 1];
     __shared__ double s_def[CAN_DEFER ? NL : 1][DEF_N];

@@ -188,11 +188,45 @@ static int pg_plan(amc_handle* h, int nl, int sweep, bool reduce, int q_batch, P
 }
 
 // Handles whose estimator takes one launch per learnable move: policies with several parameters (the move's columns fill a row
-// of the kernel's tail) and pools of several policy / action classes (see PgArgs.l_base).
-static bool per_move_launches(const amc_handle* h) { return h->n_params > 1 || h->n_classes > 1; }
+// of the kernel's tail).  Pools of several policy / action classes (one parameter per move) take the route every other pool takes
+// -- every learnable move in ONE launch, the time step fused, as the reference's make_step!(::PolicyGradientEstimator) loops over
+// all learnable moves whatever their policy types (src/PolicyGuided/estimator.jl:111-134, src/metropolis.jl:140-162) -- wherever
+// the kernel form of the call BUILDS: hipcc 7.2 meets a back-end error ("illegal VGPR to SGPR copy", a fatal error of the compiler)
+// on the unrolled loop over moves with a class switch inside for SOME pools and move counts.  The compiler runs in a child process
+// (amc_rtc.hip build_in_child), so that is an AMC_ERR_COMPILE like any other: class_general_route asks for the form once, keeps
+// the answer per form, and a form that does not build sends its calls down the per-move route (PgArgs.l_base), which needs only
+// the NL = 1 form.  Same samples (draw ids by the move's index in the call), same integer sums: same bits either way.
+static bool per_move_launches(const amc_handle* h) { return h->n_params > 1; }
 // ... of which a policy with several parameters (one class) has the single-launch forms too when ONE move learns: the launch's
 // tail is generic in P (pg_tail_np), so sweep + estimator + gradients_data += + learning step are one launch as for P = 1
 static bool np_single_launch(const amc_handle* h, int n_learn) { return h->n_params > 1 && h->n_classes == 1 && n_learn == 1; }
+
+// A pool of several classes: does this call go down the general route?  *general = the kernel form the call needs builds.  The
+// compiler is asked at most once per form and process (rtc_compile keeps what it learnt, failures included, and so does the
+// code-object cache directory for later processes); errors other than the compiler's are the call's errors.
+static int class_general_route(amc_handle* h, int n_learn, bool with_sweep, bool reduce, int q_batch, bool* general)
+{
+    *general = true;
+    if (h->n_classes <= 1 || h->n_params > 1) return AMC_OK;
+    if (h->class_per_move_forced) { *general = false; return AMC_OK; }
+    if (n_learn < 1 || n_learn > AMC_MAX_LEARN || q_batch < 1 || q_batch > AMC_MAX_QBATCH) return AMC_OK;      // (the call's own validation speaks)
+    const int nl = nl_capacity(n_learn);
+    const int sweep = with_sweep ? (h->K > 1 ? 2 : (h->d_log ? 1 : 3)) : 0;
+    const bool red = reduce && with_sweep;
+    const int key = (nl << 8) | (sweep << 4) | (red ? red_form(h) : 0);
+    auto it = h->class_form_builds.find(key);
+    if (it != h->class_form_builds.end() && !it->second) { *general = false; return AMC_OK; }
+    PgPlan plan;
+    const int rc = pg_plan(h, nl, sweep, red, q_batch, &plan);      // (cheap once the form is loaded: two map lookups)
+    if (rc == AMC_OK) return AMC_OK;
+    if (rc != AMC_ERR_COMPILE) return rc;
+    h->class_form_error = amc_last_error();
+    h->class_form_builds[key] = false;
+    if (std::getenv("AMC_DEBUG_PLAN"))
+        std::fprintf(stderr, "[amc] class pool: estimator form nl=%d sweep=%d reduce=%d does not build, one launch per learnable move instead: %s\n", nl, sweep, (int)red, h->class_form_error.c_str());
+    *general = false;
+    return AMC_OK;
+}
 
 // Validates, launches K3 over this shard.  Shared by the host- and device-resident estimator paths.
 // tail: 1 = the totals of (j, grad j, grad logq, g) per learnable move as records in h->d_out (this shard's slot), 2 = instead
@@ -218,7 +252,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
                                    "No withgrad_log_proposal_density! is defined", who);
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
     if (per_move_launches(h) && (n_learn != 1 || ((tail != 1 || with_sweep) && !np_single_launch(h, n_learn))))
-        return fail(AMC_ERR_STATE, "%s: a policy with several parameters (a pool of several classes) takes one learnable move per launch", who);
+        return fail(AMC_ERR_STATE, "%s: a policy with several parameters takes one learnable move per launch", who);
     AMC_HIP(hipSetDevice(h->device));
     amc::PgArgs a;
     a.x = h->d_x;
@@ -253,7 +287,7 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         tl.n_ranks = h->comm ? h->comm_ranks : 1;
         // (a launch that only leaves records -- one per learnable move of a several-parameter policy or a pool of classes -- reads
         // neither the ids nor the optimisers from the record: kept out, or every such launch would rewrite it, 4.7 us each)
-        if (tail != 1 || !per_move_launches(h))
+        if (tail != 1 || !(per_move_launches(h) || h->n_classes > 1))
             for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
         // a learning step the previous fused launch left pending: this launch takes it in its prologue if it is the very next
@@ -314,7 +348,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
 static int pg_estimate_records(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, const double** recs)
 {
     int nl = 0;
-    if (per_move_launches(h)) {
+    bool general = true;
+    { const int rcg = class_general_route(h, n_learn, false, false, q_batch, &general); if (rcg != AMC_OK) return rcg; }
+    if (per_move_launches(h) || !general) {
         // one launch per learnable move, its 1 + 2P + P(P+1)/2 records behind those of the moves before it
         if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
         if (n_learn == 0) return pg_launch(h, who, 0, learn_ids, q_batch, &nl);
@@ -437,9 +473,11 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
                               bool with_sweep = false, bool reduce = false, int* grid_out = nullptr, bool may_defer = false)
 {
     int nl = 0;
-    if (per_move_launches(h) && !(np_single_launch(h, n_learn) && !h->comm)) {
+    bool general = true;
+    { const int rcg = class_general_route(h, n_learn, with_sweep, reduce, q_batch, &general); if (rcg != AMC_OK) return rcg; }
+    if ((per_move_launches(h) && !(np_single_launch(h, n_learn) && !h->comm)) || !general) {
         // per learnable move: estimator launch (records in d_out), the gather across shards, gradients_data[k] += gd
-        if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters (a pool of several classes)");
+        if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters (a pool of several classes whose fused form does not build)");
         if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
         if (n_learn == 0) return pg_launch(h, "amc_pg_accumulate", 0, learn_ids, q_batch, &nl);
         const int nc = amc::pg_n_columns(h->n_params);
@@ -523,6 +561,24 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     return AMC_OK;
 }
 
+int amc_pg_route(amc_handle* h, int n_learn, int q_batch, int fused, char* why, int why_capacity)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pg_route: NULL handle");
+    if (n_learn < 1 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_route: n_learn must be in [1, %d]", AMC_MAX_LEARN);
+    if (q_batch < 1 || q_batch > AMC_MAX_QBATCH) return fail(AMC_ERR_BAD_ARG, "amc_pg_route: q_batch must be in [1, %d]", AMC_MAX_QBATCH);
+    if (why && why_capacity > 0) why[0] = 0;
+    if (per_move_launches(h)) return np_single_launch(h, n_learn) && !h->comm ? 1 : 0;
+    AMC_HIP(hipSetDevice(h->device));
+    bool general = true;
+    const bool can_fuse = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn <= 2 && log_form(h) != AMC_LOG_BYTES;
+    { const int rc = class_general_route(h, n_learn, fused != 0 && can_fuse, false, q_batch, &general); if (rc != AMC_OK) return rc; }
+    if (!general && why && why_capacity > 0) {
+        std::strncpy(why, h->class_form_error.c_str(), (size_t)why_capacity - 1);
+        why[why_capacity - 1] = 0;
+    }
+    return general ? 1 : 0;
+}
+
 int amc_pg_accumulate(amc_handle* h, int n_learn, const int* learn_ids, int q_batch)
 {
     if (!h) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: NULL handle");
@@ -584,10 +640,18 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // ... and ONE launch per step when the sweep can ride in the estimator launch: sweepstep = 1, at most two learnable
     // moves (the kernel forms offered with a leading sweep: K = 1 with either counter form, K > 1 with its step log)
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
-    const bool fused = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
-                       log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    bool fused = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
+                 log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    if (fused && h->n_classes > 1) {      // a pool of several classes: the fused form where it builds (class_general_route)
+        const int rcg = class_general_route(h, n_learn, true, false, q_batch, &fused);
+        if (rcg != AMC_OK) return rcg;
+    }
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
     bool fused_reduce = reduce && fused && h->K <= 4 && !h->d_acc_base;
+    if (fused_reduce && h->n_classes > 1) {
+        const int rcg = class_general_route(h, n_learn, true, true, q_batch, &fused_reduce);
+        if (rcg != AMC_OK) return rcg;
+    }
     if (fused_reduce) {            // ... and launches that need no flush on the way
         PgPlan plan;
         const int rcp = pg_plan(h, nl_capacity(n_learn), h->K > 1 ? 2 : (h->d_log ? 1 : 3), true, q_batch, &plan);

@@ -5,6 +5,16 @@
 #include "amc_internal.h"
 #include "amc_rtc_sources.gen.h"
 
+#include <fcntl.h>
+#include <poll.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <cerrno>
+
+extern char** environ;
+
 namespace {
 
 // ---- kernels compiled at run time for a user-defined potential (AMC_POTENTIAL_CUSTOM) ---------------------------
@@ -29,6 +39,7 @@ struct Hiprtc {
 std::mutex g_rtc_mu;
 Hiprtc g_hiprtc;
 std::map<std::string, RtcCode> g_rtc_code;        // key: expression '\n' instantiation
+std::map<std::string, std::string> g_rtc_broken;  // same key: instantiations the compiler DIED on (its last words), not to be asked for again
 
 int load_hiprtc(Hiprtc& r)
 {
@@ -136,6 +147,225 @@ void rtc_cache_store(const std::string& path, const RtcCode& rc)
     if (ok) std::rename(tmp.c_str(), path.c_str()); else std::remove(tmp.c_str());   // atomic publish
 }
 
+
+// ---- where the compiler runs ------------------------------------------------------------------------------------------------
+// What one build attempt gave: stage 0 = a code object; 1 / 2 / 3 / 4 = the hiprtc call that failed (create, name expression,
+// compile -- the script's own errors, log attached --, no code), with hiprtc's status.
+struct Built { int stage = -1; int status = 0; std::string log, lowered; std::vector<char> code;
+               bool died = false; };      // died: the compiler process ended by a signal or a failure status -- what it will do again for this input
+
+// The compile inside THIS process: a developer knob (AMC_RTC_IN_PROCESS=1, e.g. under a debugger).  A fatal error of the compiler
+// then is a fatal error of the host -- which is why it is not the default (build_in_child).
+int build_in_process(const std::string& src, const std::string& inst, const std::vector<std::string>& opts, Built* out)
+{
+    { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
+    void* prog = nullptr;
+    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", AMC_RTC_N_SOURCES, AMC_RTC_SOURCE_TEXTS, AMC_RTC_SOURCE_NAMES);
+    if (e != 0) { out->stage = 1; out->status = e; return AMC_OK; }
+    e = g_hiprtc.AddNameExpression(prog, inst.c_str());
+    if (e != 0) { g_hiprtc.DestroyProgram(&prog); out->stage = 2; out->status = e; return AMC_OK; }
+    std::vector<const char*> op;
+    for (const auto& o : opts) op.push_back(o.c_str());
+    e = g_hiprtc.CompileProgram(prog, (int)op.size(), op.data());
+    size_t ls = 0;
+    if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+        out->log.resize(ls);
+        g_hiprtc.GetProgramLog(prog, &out->log[0]);
+        while (!out->log.empty() && out->log.back() == 0) out->log.pop_back();
+    }
+    if (e != 0) { g_hiprtc.DestroyProgram(&prog); out->stage = 3; out->status = e; return AMC_OK; }
+    size_t cs = 0;
+    const char* lowered = nullptr;
+    if (g_hiprtc.GetCodeSize(prog, &cs) != 0 || cs == 0 || g_hiprtc.GetLoweredName(prog, inst.c_str(), &lowered) != 0 || !lowered) {
+        g_hiprtc.DestroyProgram(&prog);
+        out->stage = 4;
+        return AMC_OK;
+    }
+    out->code.resize(cs);
+    g_hiprtc.GetCode(prog, out->code.data());
+    out->lowered = lowered;
+    g_hiprtc.DestroyProgram(&prog);
+    out->stage = 0;
+    return AMC_OK;
+}
+
+// The compile in a short-lived CHILD process (amc_rtc_worker, built beside libamc.so from amc_rtc_worker.cpp) that never touches
+// the GPU: request over a socket pair, answer back over it, the compiler's stderr over a pipe.  The child is a new program started
+// with posix_spawn -- not a fork of this process's HIP state, never an exec of the engine's process.  A child that dies (LLVM's
+// fatal errors end in abort()), answers nonsense or does not come back within AMC_RTC_TIMEOUT_S seconds (default 600) is
+// AMC_ERR_COMPILE with the tail of its stderr in amc_last_error(); the host lives.  Reference convention: a model that cannot be
+// used raises, src/metropolis.jl:35.
+const uint64_t WORKER_MAGIC_REQUEST = 0x3151435452434d41ull;      // "AMCRTCQ1" (amc_rtc_worker.cpp)
+const uint64_t WORKER_MAGIC_ANSWER = 0x3141435452434d41ull;       // "AMCRTCA1"
+
+std::string worker_path()
+{
+    if (const char* env = std::getenv("AMC_RTC_WORKER")) return env;
+    Dl_info info;
+    if (dladdr((const void*)&worker_path, &info) == 0 || !info.dli_fname) return std::string();
+    std::string dir = info.dli_fname;
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    return dir + "/amc_rtc_worker";
+}
+
+void put_blob(std::string* req, const void* p, size_t n)
+{
+    const uint64_t len = n;
+    req->append((const char*)&len, sizeof(len));
+    req->append((const char*)p, n);
+}
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int build_in_child(const std::string& src, const std::string& inst, const std::vector<std::string>& opts, Built* out)
+{
+    const std::string exe = worker_path();
+    if (exe.empty() || access(exe.c_str(), X_OK) != 0)
+        return fail(AMC_ERR_COMPILE, "run-time kernel build: the compiler program %s is missing or not executable (built by montecarlo_amd/csrc/Makefile "
+                                     "beside libamc.so; AMC_RTC_WORKER names another place)", exe.empty() ? "amc_rtc_worker" : exe.c_str());
+    std::string req;
+    req.reserve(512u << 10);
+    const uint32_t counts[2] = {(uint32_t)opts.size(), (uint32_t)AMC_RTC_N_SOURCES};
+    req.append((const char*)&WORKER_MAGIC_REQUEST, sizeof(WORKER_MAGIC_REQUEST));
+    req.append((const char*)counts, sizeof(counts));
+    put_blob(&req, src.data(), src.size());
+    put_blob(&req, "amc_custom_potential.hip", 24);
+    put_blob(&req, inst.data(), inst.size());
+    for (const auto& o : opts) put_blob(&req, o.data(), o.size());
+    for (int i = 0; i < AMC_RTC_N_SOURCES; ++i) put_blob(&req, AMC_RTC_SOURCE_NAMES[i], std::strlen(AMC_RTC_SOURCE_NAMES[i]));
+    for (int i = 0; i < AMC_RTC_N_SOURCES; ++i) put_blob(&req, AMC_RTC_SOURCE_TEXTS[i], std::strlen(AMC_RTC_SOURCE_TEXTS[i]));
+
+    double timeout_s = 600.0;
+    if (const char* env = std::getenv("AMC_RTC_TIMEOUT_S")) { const double v = std::atof(env); if (v > 0.0) timeout_s = v; }
+
+    int sv[2] = {-1, -1}, ep[2] = {-1, -1};
+    if (socketpair(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0, sv) != 0) return fail(AMC_ERR_COMPILE, "run-time kernel build: socketpair: %s", std::strerror(errno));
+    if (pipe2(ep, O_CLOEXEC) != 0) { close(sv[0]); close(sv[1]); return fail(AMC_ERR_COMPILE, "run-time kernel build: pipe: %s", std::strerror(errno)); }
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, sv[1], 0);        // (dup2 clears close-on-exec on the copies; everything else of ours has it set)
+    posix_spawn_file_actions_adddup2(&fa, sv[1], 1);
+    posix_spawn_file_actions_adddup2(&fa, ep[1], 2);
+    // the child's environment: this process's, minus what would load a profiler's tool library into the compiler (rocprofv3 preloads
+    // one into every process it starts: the compile is not part of anybody's kernel trace, and the tool initialises the GPU)
+    std::vector<std::string> env_keep;
+    for (char** e = environ; e && *e; ++e) {
+        const std::string kv = *e;
+        if (kv.rfind("LD_PRELOAD=", 0) == 0) {
+            std::string kept;
+            size_t from = 11;
+            while (from <= kv.size()) {
+                size_t to = kv.find_first_of(": ", from);
+                if (to == std::string::npos) to = kv.size();
+                const std::string one = kv.substr(from, to - from);
+                if (!one.empty() && one.find("rocprof") == std::string::npos) kept += (kept.empty() ? "" : ":") + one;
+                from = to + 1;
+            }
+            if (!kept.empty()) env_keep.push_back("LD_PRELOAD=" + kept);
+            continue;
+        }
+        if (kv.rfind("HSA_TOOLS_LIB=", 0) == 0 || kv.rfind("ROCP_TOOL_LIBRARIES=", 0) == 0 || kv.rfind("ROCPROFILER_", 0) == 0) continue;
+        env_keep.push_back(kv);
+    }
+    std::vector<char*> envp;
+    for (auto& kv : env_keep) envp.push_back(&kv[0]);
+    envp.push_back(nullptr);
+    char* const argv[] = {const_cast<char*>(exe.c_str()), nullptr};
+    pid_t pid = -1;
+    const int se = posix_spawn(&pid, exe.c_str(), &fa, nullptr, argv, envp.data());
+    posix_spawn_file_actions_destroy(&fa);
+    close(sv[1]);
+    close(ep[1]);
+    if (se != 0) { close(sv[0]); close(ep[0]); return fail(AMC_ERR_COMPILE, "run-time kernel build: cannot start %s: %s", exe.c_str(), std::strerror(se)); }
+
+    // feed the request, collect answer and stderr; one deadline for the lot
+    fcntl(sv[0], F_SETFL, fcntl(sv[0], F_GETFL) | O_NONBLOCK);
+    fcntl(ep[0], F_SETFL, fcntl(ep[0], F_GETFL) | O_NONBLOCK);
+    const double deadline = now_s() + timeout_s;
+    std::string ans, err;
+    size_t sent = 0;
+    bool out_open = true, err_open = true, timed_out = false;
+    while (out_open || err_open) {
+        const double left = deadline - now_s();
+        if (left <= 0.0) { timed_out = true; break; }
+        pollfd fds[2] = {{sv[0], (short)(POLLIN | (sent < req.size() ? POLLOUT : 0)), 0}, {ep[0], POLLIN, 0}};
+        if (!out_open) fds[0].fd = -1;
+        if (!err_open) fds[1].fd = -1;
+        const int pr = poll(fds, 2, (int)std::min(left * 1000.0 + 1.0, 1000.0));
+        if (pr < 0 && errno != EINTR) break;
+        if (pr <= 0) continue;
+        if (out_open && sent < req.size() && (fds[0].revents & POLLOUT)) {
+            const ssize_t put = send(sv[0], req.data() + sent, req.size() - sent, MSG_NOSIGNAL);       // (a dead child: EPIPE, not SIGPIPE)
+            if (put > 0) sent += (size_t)put;
+            else if (put < 0 && errno != EAGAIN && errno != EINTR) sent = req.size();               // nothing more to say to it
+            if (sent == req.size()) shutdown(sv[0], SHUT_WR);
+        }
+        char buf[65536];
+        if (out_open && (fds[0].revents & (POLLIN | POLLHUP | POLLERR))) {
+            const ssize_t got = recv(sv[0], buf, sizeof(buf), 0);
+            if (got > 0) { if (ans.size() < (1u << 30)) ans.append(buf, (size_t)got); }
+            else if (got == 0 || (errno != EAGAIN && errno != EINTR)) out_open = false;
+        }
+        if (err_open && (fds[1].revents & (POLLIN | POLLHUP | POLLERR))) {
+            const ssize_t got = read(ep[0], buf, sizeof(buf));
+            if (got > 0) { err.append(buf, (size_t)got); if (err.size() > (1u << 20)) err.erase(0, err.size() - (1u << 19)); }
+            else if (got == 0 || (errno != EAGAIN && errno != EINTR)) err_open = false;
+        }
+    }
+    close(sv[0]);
+    close(ep[0]);
+    int status = 0;
+    if (timed_out) kill(pid, SIGKILL);
+    else {
+        // both ends closed: the child is on its way out -- give it until the deadline, then stop waiting for it
+        while (waitpid(pid, &status, WNOHANG) == 0) {
+            if (now_s() > deadline) { timed_out = true; kill(pid, SIGKILL); break; }
+            usleep(2000);
+        }
+    }
+    if (timed_out) {
+        while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        return fail(AMC_ERR_COMPILE, "run-time kernel build of %s: the compiler did not come back within %.0f s (AMC_RTC_TIMEOUT_S) and was stopped", inst.c_str(), timeout_s);
+    }
+    // the tail of what the compiler said on its way down, on one line
+    auto tail = [&]() {
+        std::string t = err.size() > 900 ? err.substr(err.size() - 900) : err;
+        while (!t.empty() && (t.back() == '\n' || t.back() == ' ')) t.pop_back();
+        return t.empty() ? std::string("(nothing on its stderr)") : t;
+    };
+    out->died = WIFSIGNALED(status) || !WIFEXITED(status) || WEXITSTATUS(status) != 0;
+    if (WIFSIGNALED(status))
+        return fail(AMC_ERR_COMPILE, "run-time kernel build of %s: the compiler died (signal %d, %s): %s", inst.c_str(), WTERMSIG(status), strsignal(WTERMSIG(status)), tail().c_str());
+    if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+        return fail(AMC_ERR_COMPILE, "run-time kernel build of %s: the compiler process ended with status %d: %s", inst.c_str(), WIFEXITED(status) ? WEXITSTATUS(status) : -1, tail().c_str());
+    // parse the answer
+    size_t at = 0;
+    auto take = [&](void* dst, size_t n) { if (ans.size() - at < n) return false; std::memcpy(dst, ans.data() + at, n); at += n; return true; };
+    auto take_blob = [&](std::string* dst) {
+        uint64_t n = 0;
+        if (!take(&n, sizeof(n)) || ans.size() - at < n) return false;
+        dst->assign(ans.data() + at, (size_t)n);
+        at += (size_t)n;
+        return true;
+    };
+    uint64_t magic = 0;
+    int32_t head[2] = {0, 0};
+    std::string code;
+    if (!take(&magic, sizeof(magic)) || magic != WORKER_MAGIC_ANSWER || !take(head, sizeof(head)) || !take_blob(&out->log) || !take_blob(&out->lowered) ||
+        !take_blob(&code) || at != ans.size() || head[0] < 0 || head[0] > 4)
+        return fail(AMC_ERR_COMPILE, "run-time kernel build of %s: the compiler process returned %zu bytes that are not an answer: %s", inst.c_str(), ans.size(), tail().c_str());
+    out->stage = head[0];
+    out->status = head[1];
+    out->code.assign(code.begin(), code.end());
+    return AMC_OK;
+}
+
 }  // namespace
 
 // Compiles (or finds) the code object holding ONE instantiation, e.g. "amc::sweep_kernel<2,false,false,false,true,false>".
@@ -147,6 +377,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
                             (std::getenv("AMC_NO_SIGMA_MEMO") ? "\nno-sigma-memo" : "");
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
+    {
+        auto bk = g_rtc_broken.find(key);
+        if (bk != g_rtc_broken.end()) return fail(AMC_ERR_COMPILE, "%s", bk->second.c_str());
+    }
     { const int rc = load_hiprtc(g_hiprtc); if (rc != AMC_OK) return rc; }
     int rtc_major = 0, rtc_minor = 0;
     (void)g_hiprtc.Version(&rtc_major, &rtc_minor);
@@ -186,6 +420,19 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
             if (log_out) log_out->clear();
             *out = &g_rtc_code.emplace(key, std::move(cached)).first->second;
             return AMC_OK;
+        }
+        // ... or the note that this compiler release dies on this instantiation (the file's name carries the release)
+        if (!cache_file.empty()) {
+            if (FILE* f = std::fopen((cache_file + ".broken").c_str(), "rb")) {
+                char msg[1600];
+                const size_t n = std::fread(msg, 1, sizeof(msg) - 1, f);
+                std::fclose(f);
+                msg[n] = 0;
+                if (n > 0) {
+                    g_rtc_broken[key] = msg;
+                    return fail(AMC_ERR_COMPILE, "%s", msg);
+                }
+            }
         }
     }
     // expr_in = [ '\x02' (Float32 state) ] [ potential [ '\x01' reward ] [ '\x03' scale ] [ '\x04' sample '\x05' logq [ '\x06' dlogq ]
@@ -266,44 +513,42 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     if (!expr.empty()) src += "#define AMC_USER_POTENTIAL(x) (" + expr.substr(0, cut) + ")\n";
     if (cut != std::string::npos) src += "#define AMC_USER_REWARD(delta, x) (" + expr.substr(cut + 1) + ")\n";
     src += "#include \"amc_kernels.h\"\n";
-    // the kernel sources travel in the library (amc_rtc_sources.gen.h): hiprtc finds every `#include "amc_*.h"` among them by name
-    void* prog = nullptr;
-    int e = g_hiprtc.CreateProgram(&prog, src.c_str(), "amc_custom_potential.hip", AMC_RTC_N_SOURCES, AMC_RTC_SOURCE_TEXTS, AMC_RTC_SOURCE_NAMES);
-    if (e != 0) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", e);
-    e = g_hiprtc.AddNameExpression(prog, inst.c_str());
-    if (e != 0) { g_hiprtc.DestroyProgram(&prog); return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), e); }
-    // the flags of the offline build (Makefile): only the explicit fma()s may fuse
+    // the kernel sources travel in the library (amc_rtc_sources.gen.h): hiprtc finds every `#include "amc_*.h"` among them by name.
+    // The flags of the offline build (Makefile): only the explicit fma()s may fuse.
+    // (-disable-machine-licm is one of LLVM's generic code-generation options; a back end without it does not return an error but ends
+    // the compiling process in its option parser -- the child's death below, not the host's)
     const std::string arch_opt = "--offload-arch=" + arch;
-    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm"};
-    e = g_hiprtc.CompileProgram(prog, licm_off ? 7 : 5, opts);
-    // (-disable-machine-licm is one of LLVM's generic code-generation options; a back end without it would not return an error
-    // here but end the process in its option parser, so there is nothing to fall back from)
-    std::string log;
-    size_t ls = 0;
-    if (g_hiprtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
-        log.resize(ls);
-        g_hiprtc.GetProgramLog(prog, &log[0]);
+    std::vector<std::string> opts = {arch_opt, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    if (licm_off) { opts.push_back("-mllvm"); opts.push_back("-disable-machine-licm"); }
+    Built built;
+    {
+        const char* inproc = std::getenv("AMC_RTC_IN_PROCESS");
+        const int rcb = (inproc && inproc[0] == '1') ? build_in_process(src, inst, opts, &built) : build_in_child(src, inst, opts, &built);
+        if (rcb != AMC_OK) {                           // the compiler could not be run, died or timed out: AMC_ERR_COMPILE, message set
+            if (built.died) {                          // ... died: it will again -- remembered for the process and, with a cache directory, beyond
+                const std::string msg = amc_last_error();
+                g_rtc_broken[key] = msg;
+                if (!cache_file.empty())
+                    if (FILE* f = std::fopen((cache_file + ".broken").c_str(), "wb")) { std::fwrite(msg.data(), 1, msg.size(), f); std::fclose(f); }
+            }
+            return rcb;
+        }
     }
-    if (log_out) *log_out = log;
-    if (e != 0) {
-        g_hiprtc.DestroyProgram(&prog);
+    if (log_out) *log_out = built.log;
+    if (built.stage == 1) return fail(AMC_ERR_HIP, "hiprtcCreateProgram failed (%d)", built.status);
+    if (built.stage == 2) return fail(AMC_ERR_HIP, "hiprtcAddNameExpression(%s) failed (%d)", inst.c_str(), built.status);
+    if (built.stage == 3) {
         // the first diagnostic is what the user needs (not the "In file included from" lines in front of it); keep the message bounded
+        const std::string& log = built.log;
         size_t from = log.find("error:");
         from = from == std::string::npos ? 0 : log.rfind('\n', from) + 1;       // (npos + 1 == 0: the log's first line)
         return fail(AMC_ERR_BAD_ARG, "%s: %.400s", expr_full.empty() ? "run-time kernel build failed" : "custom potential does not compile",
                     log.empty() ? "(no log)" : log.c_str() + from);
     }
+    if (built.stage != 0 || built.code.empty() || built.lowered.empty()) return fail(AMC_ERR_HIP, "hiprtc produced no code for %s", inst.c_str());
     RtcCode rc;
-    size_t cs = 0;
-    const char* lowered = nullptr;
-    if (g_hiprtc.GetCodeSize(prog, &cs) != 0 || cs == 0 || g_hiprtc.GetLoweredName(prog, inst.c_str(), &lowered) != 0 || !lowered) {
-        g_hiprtc.DestroyProgram(&prog);
-        return fail(AMC_ERR_HIP, "hiprtc produced no code for %s", inst.c_str());
-    }
-    rc.code.resize(cs);
-    g_hiprtc.GetCode(prog, rc.code.data());
-    rc.lowered = lowered;
-    g_hiprtc.DestroyProgram(&prog);
+    rc.code = std::move(built.code);
+    rc.lowered = std::move(built.lowered);
     rtc_cache_store(cache_file, rc);
     *out = &g_rtc_code.emplace(key, std::move(rc)).first->second;
     return AMC_OK;

@@ -259,9 +259,10 @@ class Metropolis(AriannaAlgorithm):
         callback's row when the next one is due) never makes the host wait for the device, and the sweeps queued in
         between are not held back by it.  Values are those of the state at the time of this call either way."""
         key = self._epoch
-        if self._red_key == key and self._red_val is not None:
-            return self._red_val
-        ticket = Reduction(self)
+        cols = getattr(self, "_red_cols", 7)
+        if self._red_key == key and self._red_val is not None and (self._red_val.cols & cols) == cols:
+            return self._red_val        # (a cached reduction formed with fewer columns than are asked for now is not reused)
+        ticket = Reduction(self, cols)
         if getattr(self, "_pending_red_epoch", None) == self._epoch:
             self._pending_red_epoch = None      # formed inside the launch (make_step(with_reductions=True)): claim it
             self._inflight.append(ticket)
@@ -290,6 +291,11 @@ class Metropolis(AriannaAlgorithm):
         cols = 7 if needs is None else ((1 if "energy" in needs else 0) | (2 if "mean_x" in needs else 0) | (4 if "mean_x2" in needs else 0))
         self._drop_pending_reduction()
         self.engine.set_reduce_columns(cols)
+        if cols != getattr(self, "_red_cols", 7):
+            # a reduction cached for the current state was formed with the old columns: a caller who asks after the change
+            # (callback_moments(simulation) after a run narrowed to energy) gets a new one, not NaN entries
+            self._red_key = self._red_val = None
+        self._red_cols = cols
 
     def invalidate_reductions(self) -> None:
         """Called by algorithms that move the chains behind Metropolis' back (the estimator)."""
@@ -312,9 +318,10 @@ class ParameterRead:
 class Reduction:
     """The callback sums of one observation point (see Metropolis.reductions_async)."""
 
-    def __init__(self, metropolis: Metropolis):
+    def __init__(self, metropolis: Metropolis, cols: int = 7):
         self._met = metropolis
         self._val = None
+        self.cols = cols                # the sums over x it was formed with (bit 0 energy, 1 mean_x, 2 mean_x2)
 
     def _finish(self, records: np.ndarray, steps_counted: int) -> None:
         # the shards' partial sums are merged as exact integer records (reproducible sums, include/amc.h) and rounded ONCE:

@@ -218,9 +218,13 @@ def _declare_reduction_needs(sim: Simulation) -> None:
     those and no others.  Consumers are the algorithms marked ``wants_reductions`` (StoreCallbacks -- callbacks are plain
     functions f(simulation) in the reference, src/algorithms.jl:97-102; the engine-backed ones carry ``needs`` --,
     StoreHistogram); one that does not say what it reads (``reduction_needs()`` missing or None: any user function among the
-    callbacks) keeps everything, and so does a run without consumers (a caller of Metropolis.reductions())."""
+    callbacks) keeps everything, and so does a run without consumers (a caller of Metropolis.reductions()) or with an
+    algorithm of a type this package does not define: a user's algorithm may call Metropolis.reductions() or a callback
+    inside its make_step, and must not read NaN for a sum nobody declared."""
     needs, known, any_consumer = set(), True, False
     for alg in sim.algorithms:
+        if not type(alg).__module__.startswith(__name__.rsplit(".", 1)[0] + "."):
+            known = False
         if not getattr(alg, "wants_reductions", False):
             continue
         any_consumer = True

@@ -115,6 +115,54 @@ def test_run_asks_the_engine_for_the_sums_its_callbacks_read(oracle, tmp_path):
     assert seen == [7, 7]
 
 
+def test_callbacks_after_a_narrowed_run_give_real_values(oracle, tmp_path):
+    """A run narrowed to sum e whose last step is a scheduled callback leaves a reduction of that state in the sampler's cache,
+    formed without sum x and sum x^2.  finalise() widens the engine's columns again, and a callback evaluated after run!
+    (in the reference: any f(simulation), src/algorithms.jl:97-102) must see real values, not the cached NaN entries."""
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 1.0),)
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=3, engine_factory=oracle.OracleEngine),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy,), scheduler=[10, 20, 30]))
+    sim = ma.Simulation(ma.ParticleChains.uniform(6, 2.0), al, 30, path=str(tmp_path))
+    ma.run(sim)
+    met = sim.algorithms[0]
+    mom = ma.callback_moments(sim)
+    assert np.all(np.isfinite(mom)), mom
+    red = met.reductions()
+    assert np.isfinite(red["mean_x"]) and np.isfinite(red["mean_x2"]) and np.isfinite(red["energy"])
+    assert mom[1] == red["mean_x2"] and abs(red["energy"] - red["mean_x2"]) < 1e-12      # harmonic: e = x^2
+    # ... and narrowing by hand between two reads of one state does not hand back the wider read's sibling with holes either
+    met.set_reduction_needs(("energy",))
+    assert np.isfinite(met.reductions()["energy"])
+    met.set_reduction_needs(None)
+    assert np.all(np.isfinite(ma.callback_moments(sim)))
+
+
+def test_a_user_algorithm_in_the_list_keeps_every_sum(oracle, tmp_path):
+    """Only algorithms this package defines are known not to read a reduction on the quiet: with a user's algorithm in the list
+    nothing is narrowed, so callback_moments(simulation) inside its make_step is a number."""
+    seen, got = [], []
+
+    class Watching(oracle.OracleEngine):
+        def set_reduce_columns(self, columns):
+            seen.append(columns)
+            super().set_reduce_columns(columns)
+
+    class UserAlgorithm(ma.AriannaAlgorithm):
+        def __init__(self, chains, **kw):
+            pass
+
+        def make_step(self, simulation):
+            got.append(ma.callback_moments(simulation))
+
+    pool = (ma.Move(ma.Displacement(), ma.StandardGaussian(), [0.1], 1.0),)
+    al = (dict(algorithm=ma.Metropolis, pool=pool, seed=3, engine_factory=Watching),
+          dict(algorithm=UserAlgorithm, scheduler=[0, 10]),
+          dict(algorithm=ma.StoreCallbacks, callbacks=(ma.callback_energy,), scheduler=[0, 10]))
+    ma.run(ma.Simulation(ma.ParticleChains.uniform(6, 2.0), al, 30, path=str(tmp_path)))
+    assert seen == [7, 7]
+    assert got and all(np.all(np.isfinite(m)) for m in got)
+
+
 def test_sweepstep_is_mc_steps_per_sweep(oracle, tmp_path):
     """metropolis.jl:205: one make_step! = sweepstep mc_step!s; sweepstep=3 x 100 sweeps == 300 single steps."""
     a, _ = make_sim(oracle, tmp_path / "a", steps=100, burn=10, sweepstep=3)
