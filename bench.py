@@ -109,12 +109,16 @@ def cpu_baseline(budget_s: float = 10.0):
         pass
     import shutil
     julia = shutil.which("julia")        # the reference itself can only be timed where Julia exists
+    # `cores`: what the sample really had -- the fastest thread count of the ladder, but never more than the cgroup quota grants
+    # (an oversubscribed ladder on a 16-CPU quota still runs on 16 CPUs' worth of time); `threads` is the thread count itself
+    granted = cores if not quota else max(1, min(cores, int(quota)))
     return {
-        "value": out["all"][0], "unit": "chain-updates/s", "cores": cores, "kind": "port",
+        "value": out["all"][0], "unit": "chain-updates/s", "cores": granted, "threads": cores, "kind": "port",
         "reference_runtime": f"julia at {julia} (reference not timed: no package depot offline)" if julia else
                              "julia not found on this host: the reference (pure Julia) cannot be timed here",
         "sample": f"oracle/amc_oracle.c (C restatement of mc_sweep!, OpenMP over chains), M=1e7 chains x "
-                  f"{out['all'][1]} sweeps in {out['all'][2]:.1f} s on {cores} threads; same workload otherwise",
+                  f"{out['all'][1]} sweeps in {out['all'][2]:.1f} s on {cores} threads"
+                  + (f" under a cgroup quota of {quota:g} CPUs" if quota else "") + "; same workload otherwise",
         "single_thread_value": out["single"][0], "cpu_model": cpu_model,
         "cpus_visible": visible, "cpu_quota": quota,
         "thread_ladder": {str(t): round(v) for t, v in probes.items()},
@@ -181,6 +185,42 @@ def ladder(A, sizes, device, reps=5):
                      "achieved_GBps": BYTES_PER_UPDATE * m / us / 1e3, "frac": BYTES_PER_UPDATE * m / us / 1e3 / HBM_PEAK_GBS,
                      "regime": regime_of(m)})
     return rows
+
+
+def widened_paths(A, m, device, reps=5):
+    """The widened paths as bench lines of their own (never part of `value`): the headline's single-sweep launch with
+    Float32 state (Particle{Float32}, particle_1d.jl:9,26: 8 algorithmic bytes per update) and with a script-defined
+    potential compiled at run time (amc_create_custom: 16 bytes).  HIP events on the engine's stream, min over `reps` blocks."""
+    out = {}
+    cases = {"f32_state": (dict(potential="harmonic", dtype="f32"), 8,
+                           "Particle{Float32}: x, beta, e, delta in Float32 (DESIGN.md 3.7), harmonic, K = 1, pool-wide counter"),
+             "custom_potential": (dict(potential=__import__("montecarlo_amd").CustomPotential("x*x*x*x - 2.0*x*x + 0.25*x")), 16,
+                                  "U(x) = x^4 - 2 x^2 + x/4 as a C expression compiled with hiprtc (amc_create_custom), K = 1, pool-wide counter")}
+    for name, (kw, nbytes, what) in cases.items():
+        try:
+            e = A.HipEngine(n_chains=m, beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1, per_chain_counters=False,
+                            device=device, **kw)
+            e.init_uniform(-2.0, 2.0)
+            n = 200
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.3:
+                for _ in range(n):
+                    e.sweep(1)
+                e.sync()
+            ts = []
+            for _ in range(reps):
+                e.timing_begin()
+                for _ in range(n):
+                    e.sweep(1)
+                ts.append(e.timing_end() * 1e3 / n)
+            e.close()
+            us = sorted(ts)[len(ts) // 2]
+            out[name] = {"us_per_launch_median": us, "us_per_launch_min": min(ts), "algorithmic_bytes_per_update": nbytes,
+                         "achieved_GBps": nbytes * m / us / 1e3, "frac": nbytes * m / us / 1e3 / HBM_PEAK_GBS,
+                         "chain_updates_per_s": m / (us * 1e-6), "workload": what}
+        except A.AmcError as err:
+            out[name] = {"error": str(err)[:200]}
+    return out
 
 
 def other_configs(A, m, device, periods=40):
@@ -255,9 +295,41 @@ def other_configs(A, m, device, periods=40):
         e.close()
     except A.AmcError as err:
         out["error"] = str(err)[:200]
+    out.update(widened_paths(A, m, device))
     out["note"] = ("callbacks (callback_energy + callback_acceptance) every 10 time steps, each read one period late; chains x time steps "
-                   "/ time = chain-updates/s of these configurations; not part of `value`")
+                   "/ time = chain-updates/s of these configurations; f32_state / custom_potential: the headline's single-sweep launch on the "
+                   "widened paths, achieved = their algorithmic bytes / HIP-event time per launch; not part of `value`")
     return out
+
+
+def preflight(rank, local_rank, world):
+    """N > 1: what this rank is about to run on, on stderr BEFORE the first collective, and the failures that can be seen
+    from here as errors of their own -- so that the first run on a real 8-GPU node, if it fails, says why in its first lines
+    instead of hanging in a rendezvous.  Counting devices does not initialise the GPU."""
+    from montecarlo_amd import _capi as A
+    n_dev = A.device_count()
+    forced = os.environ.get("AMC_RCCL_LIBRARY")
+    candidates = [forced] if forced else ["/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"]
+    librccl = next((c for c in candidates if c and os.path.exists(c)), None)
+    port = os.environ.get("MASTER_PORT")
+    device = int(os.environ.get("AMC_BENCH_DEVICE", local_rank))
+    print(f"[bench preflight rank {rank}/{world}] local_rank={local_rank} device={device} hip_devices_visible={n_dev} "
+          f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} (must be 0: dmabuf IPC) "
+          f"librccl={librccl or 'NOT FOUND among ' + str(candidates)}{' (AMC_RCCL_LIBRARY)' if forced else ''} "
+          f"master={os.environ.get('MASTER_ADDR', '127.0.0.1')}:{port} store_port={int(port) + 1 if port else 'MASTER_PORT unset'} "
+          f"HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')} ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')}",
+          file=sys.stderr, flush=True)
+    if n_dev < 1:
+        raise SystemExit(f"[bench rank {rank}] no HIP device visible to this process")
+    if not (0 <= device < n_dev):
+        raise SystemExit(f"[bench rank {rank}] device {device} (LOCAL_RANK / AMC_BENCH_DEVICE) but {n_dev} HIP device(s) visible: "
+                         f"one process per GPU needs --nproc-per-node <= the node's GPU count")
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        raise SystemExit(f"[bench rank {rank}] HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}: RCCL between "
+                         f"processes needs dmabuf IPC on this driver (export HSA_ENABLE_IPC_MODE_LEGACY=0)")
+    if world > 1 and librccl is None:
+        print(f"[bench preflight rank {rank}] no librccl found: the callback sums will go over the store and the line will carry no value",
+              file=sys.stderr, flush=True)
 
 
 def main():
@@ -301,6 +373,7 @@ def main():
     from montecarlo_amd import sharding
     grp = None
     if world > 1 or force_dist:
+        preflight(rank, local_rank, world)                           # before the store, before any collective: fail early and loudly
         if "MASTER_PORT" not in os.environ:                          # forced on one rank, started by hand
             import socket
             with socket.socket() as sk:
@@ -505,7 +578,12 @@ def main():
         prof = pmc_profile()
         updates = m_global * args.steps
         launch_s = event_ms * 1e-3 / args.steps
-        achieved = BYTES_PER_UPDATE * (stop - start) / launch_s / 1e9
+        # ONE clock per line: `achieved` / `frac` come from the interval `value` and `ms_per_step` come from (this rank's K
+        # steps by the host clock, max over ranks), so frac x peak x ms_per_step IS the algorithmic bytes of a launch; the
+        # HIP-event figure of the same K launches (the kernel's own duration, what rocprofv3's kernel trace averages) rides
+        # beside it as achieved_events / frac_events / avg_launch_us
+        achieved = BYTES_PER_UPDATE * (stop - start) * args.steps / elapsed / 1e9
+        achieved_events = BYTES_PER_UPDATE * (stop - start) / launch_s / 1e9
         result = {
             "metric": "chain-updates/sec (MC sweeps x M) at M=10^7 per MI355X",
             "value": updates / elapsed,
@@ -535,6 +613,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "clock": "host perf_counter around the K timed steps, max over ranks: the interval of `value` and `ms_per_step`",
+                "achieved_events": achieved_events, "frac_events": achieved_events / HBM_PEAK_GBS,
+                "events_note": "HIP events on the engine's stream around the same K launches (avg_launch_us = their mean): the kernel's own "
+                               "duration, comparable with the rocprofv3 kernel-trace average under profiles/",
                 # the committed PMC figures were taken at 1e7 chains per launch: quoted only for that size
                 "traffic": (prof or {}).get("traffic") if stop - start == M_PER_GPU else None,
                 "valu_busy": (prof or {}).get("valu_busy") if stop - start == M_PER_GPU else None,

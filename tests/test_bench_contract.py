@@ -37,6 +37,12 @@ def check_line(d, n_gpus, cb_every):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 16 * M
+    # ONE clock per line: frac comes from the interval value and ms_per_step come from, so frac x peak x ms_per_step is the
+    # algorithmic bytes of one launch; the HIP-event figure of the same launches rides beside it under its own names
+    nbytes = rf["algorithmic_bytes_per_launch"]
+    assert abs(rf["frac"] * rf["peak"] * 1e9 * d["ms_per_step"] * 1e-3 - nbytes) < 1e-6 * nbytes
+    assert abs(rf["frac_events"] * rf["peak"] * 1e9 * rf["avg_launch_us"] * 1e-6 - nbytes) < 1e-6 * nbytes
+    assert rf["frac_events"] >= rf["frac"] * 0.95 and "perf_counter" in rf["clock"]
     assert rf["valu_busy"] is None                                     # from the committed PMC passes (profiles/) ...
     assert rf["traffic"] is None                                       # ... taken at 1e7 chains per launch: not quoted for this size
     assert isinstance(rf["traffic_provenance"]["kernel_sources_unchanged_since"], bool)
@@ -69,6 +75,12 @@ def test_single_process_line():
     for name in ("config3_double_well_K2", "config5_pgmc"):   # u16 counters for the first 65 535 steps: never slower than u32 by much
         assert 0 < oc[name]["us_per_time_step_first_65535_steps"] < 1.5 * oc[name]["us_per_time_step"]
     assert 0.1 < oc["config5_pgmc"]["sigma_2_after"] < 2.0 and oc["config5_pgmc"]["sigma_2_after"] != 0.1      # it learned
+    # the widened paths as lines of their own: Float32 state (8 algorithmic bytes per update), a script-defined potential (16)
+    for name, nbytes in (("f32_state", 8), ("custom_potential", 16)):
+        w = oc[name]
+        assert "error" not in w, w
+        assert w["algorithmic_bytes_per_update"] == nbytes and 0 < w["us_per_launch_min"] <= w["us_per_launch_median"]
+        assert abs(w["frac"] * 8000.0 * 1e9 * w["us_per_launch_median"] * 1e-6 - nbytes * M) < 1e-6 * nbytes * M
 
 
 def test_distributed_path_on_one_rank():
@@ -84,6 +96,25 @@ def test_distributed_path_on_one_rank():
     assert c["hip_runtime_versions_by_rank"] == [c["hip_runtime_version"]]
     # the N > 1 route runs on the stack the single process runs on: no torch in the worker, the system's HIP runtime
     assert c["torch_imported"] is False and "/opt/rocm" in c["hip_runtime"]
+
+
+def test_preflight_block_comes_before_the_first_collective():
+    """N > 1 (here: the route forced onto one rank): every rank says on stderr what it is about to run on -- devices visible,
+    the IPC mode, the librccl file, master and store ports -- BEFORE the store group and the communicator exist, and a rank whose
+    device does not exist ends there with a sentence, not in a rendezvous."""
+    env = {"AMC_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29537", "RANK": "0",
+           "LOCAL_RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--spinup-s", "0.05", "--repeats", "1",
+           "--min-gpu-seconds", "0", "--chains-per-gpu", str(M), "--no-cpu-baseline", "--no-other-configs", "--no-ladder"]
+    r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    first = r.stderr.lstrip().splitlines()[0]
+    assert first.startswith("[bench preflight rank 0/1]") and "hip_devices_visible=1" in first and "HSA_ENABLE_IPC_MODE_LEGACY=0" in first
+    assert "librccl=/opt/rocm/lib/librccl.so" in first and "store_port=29538" in first
+    bad = subprocess.run(cmd, env=dict(os.environ, **dict(env, LOCAL_RANK="5", MASTER_PORT="29541")), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "device 5" in bad.stderr and "1 HIP device(s) visible" in bad.stderr
+    legacy = subprocess.run(cmd, env=dict(os.environ, **dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1", MASTER_PORT="29545")), capture_output=True, text=True, timeout=600)
+    assert legacy.returncode != 0 and "dmabuf IPC" in legacy.stderr
 
 
 def test_min_gpu_seconds_keeps_the_device_busy():

@@ -104,6 +104,36 @@ def test_two_ranks_two_parameter_policy(fake_rccl):
     assert two["host"]["parameters"] == one["host"]["parameters"]                                     # the host path is shard-invariant too
 
 
+def test_eight_ranks_on_one_gpu(fake_rccl):
+    """The machine's real shape: a communicator of EIGHT ranks.  The box lets six processes use its one GPU, so the eight ranks are
+    four processes x two handles (a communicator belongs to a handle; each rank has a thread, a handle and a stream of its own:
+    tests/aux/eight_rank_worker.py).  Device-resident PGMC in config 5's shape with callbacks every 10 time steps over 60 000
+    chains: sigma, every callback row, the estimator's records and every chain equal ONE rank holding the whole ensemble and the
+    2 x 2 arrangement, bit for bit; the communicator reports eight ranks on every rank; shards are the contiguous even-boundary
+    ranges of sharding.shard_range."""
+    worker = [os.path.join(AUX, "eight_rank_worker.py")]
+    env = dict(AMC_RCCL_LIBRARY=fake_rccl, AMC_TEST_DEVICE="0")
+
+    def run(processes, per_process):
+        r = launch(worker, processes, dict(env, AMC_TEST_RANKS_PER_PROCESS=str(per_process)))
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    eight, four, one = run(4, 2), run(2, 2), run(1, 1)
+    assert eight["n_ranks"] == 8 and eight["processes"] == 4 and len(eight["ranks"]) == 8 and four["n_ranks"] == 4 and one["n_ranks"] == 1
+    for i, r in enumerate(eight["ranks"]):
+        assert r["rank"] == i and r["comm"]["n_ranks"] == 8 and r["comm"]["rank"] == i and r["comm"]["librccl"] == fake_rccl
+        assert r["shard"] == [i * 7500, (i + 1) * 7500]
+        # replicated without a broadcast: every rank learnt the same sigma and saw the same merged callback rows
+        assert r["sigma"] == eight["ranks"][0]["sigma"] and r["rows"] == eight["ranks"][0]["rows"] and r["gd"] == eight["ranks"][0]["gd"]
+    ref = one["ranks"][0]
+    for other in (eight, four):
+        r0 = other["ranks"][0]
+        assert r0["sigma"] == ref["sigma"] and r0["rows"] == ref["rows"] and r0["gd"] == ref["gd"] and r0["x_head"] == ref["x_head"]
+        assert other["x_checksum"] == one["x_checksum"]                  # every chain of the ensemble, xor of the bit patterns
+    assert float.fromhex(ref["sigma"][0]) == 0.2 and float.fromhex(ref["sigma"][1]) > 0.5         # Static stayed, VPG learnt
+    assert len(ref["rows"]) == 12 and all(row[2] == 60_000 for row in ref["rows"])                # the callbacks saw the whole ensemble
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_gpus_n_over_the_stand_in(fake_rccl, world):
     """bench.py under the driver's launch line with N ranks on device 0: the RCCL route (not the store fallback), callbacks

@@ -539,3 +539,24 @@ def test_grouped_pgmc_steps_carry_the_callback_sums_of_their_last_step(oracle, t
     ma.run(ref, fuse=False)
     assert open(tmp_path / "g" / "energy.dat").read() == open(tmp_path / "s" / "energy.dat").read()
     assert open(tmp_path / "g" / "acceptance.dat").read() == open(tmp_path / "s" / "acceptance.dat").read()
+
+
+def test_bench_cpu_baseline_reports_the_cpus_it_was_granted(oracle, monkeypatch):
+    """bench.py's cpu_baseline: `cores` is what the sample really had -- the fastest thread count of the ladder cut by the
+    cgroup quota (BENCH_r05 said "cores: 64" for 64 threads on a 16-CPU quota); `threads` keeps the thread count, the ladder
+    and the quota ride along, and the sample line says under which quota it ran."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "M_PER_GPU", 4000)              # a small ensemble: the 4000-sweep cap ends every timing leg in well under a second
+    monkeypatch.setattr(bench, "cpu_allotment", lambda: (64, 3.0))
+    line = bench.cpu_baseline(budget_s=0.2)
+    assert line["kind"] == "port" and line["unit"] == "chain-updates/s" and line["value"] > 0 and line["single_thread_value"] > 0
+    assert line["cpu_quota"] == 3.0 and line["threads"] >= 2 and str(line["threads"]) in line["thread_ladder"]
+    assert line["cores"] == min(line["threads"], 3)
+    assert "quota of 3 CPUs" in line["sample"] and f"on {line['threads']} threads" in line["sample"]
+    monkeypatch.setattr(bench, "cpu_allotment", lambda: (64, None))
+    line = bench.cpu_baseline(budget_s=0.2)
+    assert line["cores"] == line["threads"] and "quota" not in line["sample"]
