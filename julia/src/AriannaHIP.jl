@@ -1,8 +1,9 @@
 # AriannaHIP.jl -- the reference-side binding of libamc.so (include/amc.h).
 #
 # NOT EXECUTED IN THIS REPOSITORY'S ENVIRONMENT: the build image and the GPU box have no Julia.
-# This is the stub a maintainer of TheDisorderedOrganization/MonteCarlo (Arianna.jl) would add; it
-# is written against the reference's own interfaces:
+# A package (julia/Project.toml; tests: julia/test/runtests.jl, `julia --project=julia -e 'using Pkg; Pkg.test()'` where Julia,
+# Arianna and -- for the device half -- libamc.so and an MI355X exist).  It is what a maintainer of
+# TheDisorderedOrganization/MonteCarlo (Arianna.jl) would add, written against the reference's own interfaces:
 #   AriannaAlgorithm protocol            src/algorithms.jl:6-37
 #   Metropolis(chains; pool, ...)        src/metropolis.jl:288-291
 #   callback_acceptance                  src/metropolis.jl:319-321
@@ -17,7 +18,30 @@ using Arianna
 using Arianna.PolicyGuided
 import Arianna: initialise, make_step!, finalise, write_algorithm
 
-const libamc = get(ENV, "LIBAMC", "libamc.so")
+using Libdl
+
+# LIBAMC names the library file; default: the one built in this repository (montecarlo_amd/libamc.so, two levels up), else the
+# loader's search path.  (ccall needs a constant: read once, when the module is loaded.)
+const libamc = let built = normpath(joinpath(@__DIR__, "..", "..", "montecarlo_amd", "libamc.so"))
+    get(ENV, "LIBAMC", isfile(built) ? built : "libamc.so")
+end
+
+"""
+    available() -> Bool
+
+`true` when libamc.so can be loaded and sees at least one HIP device.  The engine has no CPU path (amc_create answers
+AMC_ERR_NO_DEVICE without a gfx950 GPU): callers that want to run without a GPU use stock `Metropolis`.
+"""
+function available()
+    Libdl.dlopen(libamc; throw_error=false) === nothing && return false
+    n = Ref{Cint}(0)
+    return ccall((:amc_device_count, libamc), Cint, (Ref{Cint},), n) == 0 && n[] > 0
+end
+
+# the engine's draw schedule as an AbstractRNG for the reference's R= hook (src/metropolis.jl:245,263): stock Metropolis then
+# consumes the random numbers the device path uses
+include("PhiloxRNG.jl")
+using .PhiloxRNGs: PhiloxRNG, begin_estimator_step!
 
 # struct amc_config (include/amc.h) -- field order and types are the ABI
 struct AmcConfig
@@ -500,5 +524,7 @@ end
 # Arianna's run! loop with look-ahead over the schedulers, deferred StoreCallbacks / StoreParameters, the device-resident
 # estimator and update as algorithms of the list (what `north_star` asks of the Julia host: the gains of the fused forms)
 include("AriannaHIPRun.jl")
+
+export HIPMetropolis, HIPPolicyGradientEstimator, HIPPolicyGradientUpdate, HIPStoreCallbacks, HIPStoreParameters, run_fused!, PhiloxRNG
 
 end # module

@@ -738,7 +738,7 @@ class Interpreter:
 
 def load_philox_stub():
     """The interpreter with julia/PhiloxRNG.jl (and the tables it includes) loaded."""
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "src")
     it = Interpreter(root)
     it.load("PhiloxRNG.jl")
     return it

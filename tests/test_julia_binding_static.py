@@ -9,8 +9,9 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-JL = os.path.join(ROOT, "julia", "AriannaHIP.jl")
-JL_RUN = os.path.join(ROOT, "julia", "AriannaHIPRun.jl")          # include()d by the module: run_fused!, deferred stores
+JL = os.path.join(ROOT, "julia", "src", "AriannaHIP.jl")
+JL_RUN = os.path.join(ROOT, "julia", "src", "AriannaHIPRun.jl")          # include()d by the module: run_fused!, deferred stores
+JL_TEST = os.path.join(ROOT, "julia", "test", "runtests.jl")             # the package's tests: their ccalls are checked like the module's
 HDR = os.path.join(ROOT, "include", "amc.h")
 
 # C type (normalised: no `const`, single spaces, `*` attached) -> Julia types with the same calling-convention class
@@ -97,7 +98,7 @@ def _split_top(s):
 
 def julia_ccalls():
     # Julia line comments (no '#' inside the strings used there); docstrings name no ccall
-    text = re.sub(r"#[^\n]*", "", open(JL).read()) + "\n" + re.sub(r"#[^\n]*", "", open(JL_RUN).read())
+    text = "\n".join(re.sub(r"#[^\n]*", "", open(f).read()) for f in (JL, JL_RUN, JL_TEST))
     calls = []
     for m in re.finditer(r"ccall\(", text):
         i = m.end()
@@ -185,7 +186,7 @@ def test_philox_rng_stub_follows_the_current_arithmetic_spec():
     """julia/PhiloxRNG.jl restates the draw schedule for the reference's R= hook; it cannot run here, so at least its
     bit-field constants must be the ones the oracle implements (spec v5: 28-bit angle, 12 + 12 spare bits per chain,
     36-bit pick uniform, 12 + 40-bit accept uniform) -- a spec change that forgets the Julia file fails here."""
-    text = re.sub(r"#[^\n]*", "", open(os.path.join(ROOT, "julia", "PhiloxRNG.jl")).read())
+    text = re.sub(r"#[^\n]*", "", open(os.path.join(ROOT, "julia", "src", "PhiloxRNG.jl")).read())
     src = open(os.path.join(ROOT, "oracle", "amc_oracle.c")).read()
     for jl, c in [("Float64(w >> 4) * 2.0^-27", "(double)(w >> 4) * 0x1.0p-27"),
                   ("(v[3] >> 12) & 0x00000fff", "((v[2] >> 12) & 0xFFFu)"),
@@ -221,3 +222,90 @@ def test_julia_host_has_the_fused_run_loop():
     opens = len(re.findall(r"^\s*(?:mutable struct|struct|function|if|for|while|try|begin|let)\b|\bdo\b\s*(?:\([^)]*\)|\w+)?\s*$|=\s*begin\s*$|@elapsed begin", run, flags=re.M))
     closes = len(re.findall(r"^\s*end\b", run, flags=re.M))
     assert opens == closes, (opens, closes)
+
+
+def _balanced(text):
+    """Every `function` / `struct` / control block of a Julia file is closed (a cheap stand-in for a parser)."""
+    text = re.sub(r'"""(?:.|\n)*?"""', '""', text)               # docstrings
+    text = re.sub(r"#[^\n]*", "", text)
+    text = re.sub(r'"(?:[^"\\\n]|\\.)*"', '""', text)            # string literals (no interpolated blocks with keywords in these files)
+    opens = 0
+    for line in text.splitlines():
+        if re.match(r"\s*(?:[\w.]*@[\w.]+\s+(?:\w+\s+)*?)?(?:mutable struct|struct|function|if|for|while|try|begin|let|module|macro|quote)\b", line):
+            opens += 1                 # a block keyword opens the line (possibly behind a macro: `@inbounds for`, `GC.@preserve a b begin`)
+        elif re.search(r"\bdo\b\s*(?:\([^)]*\)|[\w, ]+)?\s*$|\bbegin\s*$|=\s*let\b[^\n]*$", line):
+            opens += 1                 # ... or a block opens at its end (`map(xs) do x`, `@testset "..." begin`, `x = let y = ...`)
+    closes = len(re.findall(r"^\s*end\b", text, flags=re.M))
+    return opens, closes
+
+
+def test_julia_is_a_package_with_its_tests():
+    """SURVEY section 8 row f3 asks for PhiloxRNG for the reference's R= hook AND the package's tests: julia/ is a package
+    (Project.toml, src/, test/runtests.jl) a maintainer runs with one command; the tests replay the committed
+    golden trajectories through STOCK Metropolis(...; R=PhiloxRNG{seed,1}) -- the only route from "statistically pinned" to
+    pinned --, through HIPMetropolis where a GPU exists, and check test/ad_backends_test.jl's closed forms.  No Julia here: what
+    can be checked is that the pieces exist, name what they must, and hang together."""
+    proj = open(os.path.join(ROOT, "julia", "Project.toml")).read()
+    assert re.search(r'^name = "AriannaHIP"$', proj, flags=re.M) and re.search(r'^uuid = "[0-9a-f-]{36}"$', proj, flags=re.M)
+    deps = proj[proj.index("[deps]"):proj.index("[compat]")]
+    assert 'Arianna = "07692032-97b4-4f8d-80d7-e18df88d31a9"' in deps and "Random = " in deps and "Libdl = " in deps
+    ref_toml = "/root/reference/Project.toml"
+    if os.path.exists(ref_toml):           # the uuid IS the reference package's
+        assert 'uuid = "07692032-97b4-4f8d-80d7-e18df88d31a9"' in open(ref_toml).read()
+    extras = proj[proj.index("[extras]"):]
+    for pkg in ("ComponentArrays", "Distributions", "JSON", "Test", "Statistics"):
+        assert re.search(rf"^{pkg} = ", extras, flags=re.M), pkg
+        assert f'"{pkg}"' in extras[extras.index("[targets]"):], pkg
+    main = open(JL).read()
+    assert "module AriannaHIP" in main and 'include("PhiloxRNG.jl")' in main and "using .PhiloxRNGs: PhiloxRNG" in main
+    assert re.search(r"^export .*HIPMetropolis.*PhiloxRNG", main, flags=re.M) and "function available()" in main
+    for f in ("AriannaHIP.jl", "AriannaHIPRun.jl", "PhiloxRNG.jl", "amc_tables.jl"):
+        assert os.path.exists(os.path.join(ROOT, "julia", "src", f)), f
+    t = open(JL_TEST).read()
+    # (i) stock Metropolis through the reference's R= hook on the reference's own model file, replaying cases 0-3
+    assert 'include(joinpath(pkgdir(Arianna), "example", "particle_1d", "particle_1d.jl"))' in t
+    assert "algorithm=Metropolis" in t and "R=PhiloxRNG{seed,1}" in t and 'GOLDEN["cases"][1:4]' in t
+    assert "oracle_trajectories.json" in t and "reference_kats.json" in t
+    # (ii) the device path through the binding, skipped -- and said so -- without libamc / a GPU
+    assert "algorithm=AriannaHIP.HIPMetropolis" in t and "AriannaHIP.available()" in t and "@test_skip" in t
+    # (iii) ad_backends closed forms, through amc_selftest_math where a device exists
+    assert ":amc_selftest_math" in t and 'KATS["ad_backends"]' in t and "withgrad_log_proposal_density!" in t
+    # mismatches are reported, not hidden: the flip note is printed AND the test fails
+    assert "@info" in t and "@test isempty(off)" in t
+    for path in (JL_TEST, JL, JL_RUN, os.path.join(ROOT, "julia", "src", "PhiloxRNG.jl")):
+        opens, closes = _balanced(open(path).read())
+        assert opens == closes, (path, opens, closes)
+    # the fixtures the Julia test reads hold what it indexes
+    import json
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_trajectories.json")))
+    names = [c["spec"]["name"] for c in golden["cases"][:4]]
+    assert names == ["harmonic_K1", "harmonic_K2_pgmc_pool", "double_well_K2", "harmonic_K1_shard_offset"]
+    for c in golden["cases"][:4]:
+        assert c["snapshots"][0]["sweep"] == 0 and {"x", "e", "accepted", "total", "energy", "acceptance"} <= set(c["snapshots"][1])
+        assert "dtype" not in c["spec"] and "proposal" not in c["spec"] and "classes" not in c["spec"]      # plain particle_1d
+    kats = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))
+    assert {"delta", "sigma", "logq", "grad_sigma", "atol"} <= set(kats["ad_backends"])
+
+
+def test_hexfloat_of_the_julia_tests_reads_every_fixture_value():
+    """runtests.jl parses the fixtures' C99 hex floats with a regular expression of its own: every value of the four cases it
+    replays must match it, and the exact reconstruction mantissa x 2^(exponent - 4 digits) must give the value back."""
+    import json
+    rx = re.search(r'm = match\(r"(\^[^"]+\$)", s\)', open(JL_TEST).read()).group(1)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_trajectories.json")))
+    n = 0
+    for c in golden["cases"][:4]:
+        for snap in c["snapshots"]:
+            for key in ("x", "e", "acceptance"):
+                for text in snap.get(key, []):
+                    if text in ("nan", "inf", "-inf"):
+                        continue
+                    m = re.match(rx, text)
+                    assert m, text
+                    frac = m.group(3)
+                    mant = int(m.group(2) + frac, 16)
+                    assert mant < 2 ** 53
+                    val = float(mant) * 2.0 ** (int(m.group(4)) - 4 * len(frac))
+                    assert (-val if m.group(1) else val) == float.fromhex(text)
+                    n += 1
+    assert n > 500

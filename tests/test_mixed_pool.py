@@ -86,7 +86,7 @@ def test_canonical_gaussian_expressions_are_the_same_text_everywhere():
     from montecarlo_amd import metropolis as mp
     assert (mp.GAUSS_SAMPLE, mp.GAUSS_LOGQ, mp.GAUSS_DLOGQ) == GAUSS
     rtc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "montecarlo_amd", "csrc", "amc_rtc.hip")).read()
-    jl = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "AriannaHIP.jl")).read()
+    jl = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "src", "AriannaHIP.jl")).read()
     for text in GAUSS:
         assert '"' + text + '"' in rtc, text
         assert '"' + text + '"' in jl, text            # AriannaHIP.GAUSS_CLASS
