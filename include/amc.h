@@ -179,8 +179,12 @@ int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, 
  *                   depends on x or sigma); mc_step! evaluates it for the forward action at the old state and for the
  *                   inverted action (-delta) at the new state (metropolis.jl:178,182)
  *     dlogq_expr    d logq / d sigma -- what the reference obtains from ForwardDiff / Enzyme / Zygote
- *                   (src/PolicyGuided/gradients.jl:28-33); NULL: the handle runs sweeps, the estimator entry points
- *                   return AMC_ERR_STATE
+ *                   (src/PolicyGuided/gradients.jl:28-33) and never asks its user for.  OPTIONAL: NULL and the engine
+ *                   differentiates logq_expr itself -- the expression evaluated over dual numbers (forward mode,
+ *                   ForwardDiff's rules: montecarlo_amd/csrc/amc_dual.h), the parameters carrying the partials, delta and x
+ *                   constants, exactly ForwardDiff.gradient(p -> log_proposal_density(action, policy, p, system), parameters).
+ *                   Given, the expression is used as given (a hand-derived form may order its operations differently:
+ *                   equal to a few ulp, tests/test_autodiff.py).
  * Variables: z, x, sigma, delta; vocabulary as for amc_create_custom.  potential_expr NULL: cfg->potential's built-in.
  * Float64 state only.  Every accept decision takes the reference-ordered arithmetic (no accept filter). */
 int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
@@ -189,8 +193,8 @@ int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr
  * GradientData keeps grad j and grad logq_forward as arrays of its shape and g as their P x P outer product
  * (src/PolicyGuided/gradients.jl:41-61,104-108), and the natural-gradient optimisers invert g + eps I
  * (learning.jl:103-104,130-133,159-163).  n_params = P in [1, AMC_MAX_PARAMS]; the expressions see the move's parameters as
- * theta0 .. theta{P-1} (`sigma` stays a name of theta0), dlogq_exprs[p] = d logq / d theta_p (all P of them, or NULL: no
- * estimator), perform_expr / invert_expr as in amc_create_action_model (both NULL: the displacement).  E.g. a Gaussian
+ * theta0 .. theta{P-1} (`sigma` stays a name of theta0), dlogq_exprs[p] = d logq / d theta_p (all P of them, or NULL: logq_expr is
+ * differentiated by the engine, see amc_create_proposal_model), perform_expr / invert_expr as in amc_create_action_model (both NULL: the displacement).  E.g. a Gaussian
  * with a learnable drift, delta = theta0 + theta1 z:
  *     sample "theta0 + theta1*z"     logq "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)"
  *     dlogq  { "(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1" }
@@ -215,8 +219,8 @@ int  amc_n_params(amc_handle *h, int *n_params, int *gd_stride);
  * (src/metropolis.jl:140-162; the pool's moves need only agree across CHAINS, :249-260), and sample_action! /
  * log_proposal_density / perform_action! / invert_action! dispatch on their types.  Here: up to AMC_MAX_CLASSES expression sets
  * ("classes"), class_of_move[k] in [0, n_classes) names the one move k uses; sample_exprs / logq_exprs have one entry per class,
- * dlogq_exprs one per class or NULL (no estimator), perform_exprs / invert_exprs one per class with NULL entries (or NULL
- * arrays) for the displacement.  One parameter (sigma) per move.  E.g. a plain Gaussian displacement beside a Langevin
+ * dlogq_exprs one per class with NULL entries, or a NULL array, for the classes whose logq the engine differentiates itself
+ * (amc_create_proposal_model), perform_exprs / invert_exprs one per class with NULL entries (or NULL arrays) for the displacement.  One parameter (sigma) per move.  E.g. a plain Gaussian displacement beside a Langevin
  * (drifted) proposal and a scaling action in one pool.  Everything else -- counters, step log, callbacks, estimator, learning
  * steps, sharding -- is that of amc_create_action_model. */
 #define AMC_MAX_CLASSES 4
@@ -224,6 +228,15 @@ int  amc_create_mixed_model(const amc_config *cfg, int n_classes, const int *cla
                             const char *reward_expr, const char *const *sample_exprs, const char *const *logq_exprs,
                             const char *const *dlogq_exprs, const char *const *perform_exprs, const char *const *invert_exprs,
                             amc_handle **out);
+/* Compile-only check of a script-defined model, amc_potential_check's sibling (no GPU needed): builds the estimator kernel -- the
+ * one that uses every expression: sample, logq, its derivative (given, or by forward-mode differentiation where dlogq is NULL),
+ * perform / invert, reward -- for the library's target ISA.  n_classes = 1: sample_exprs[0] ... describe the one policy and, with
+ * n_params = P > 1, dlogq_exprs holds its P partials (or is NULL); n_classes > 1: one entry per class as for amc_create_mixed_model
+ * (n_params = 1).  potential_expr NULL: the harmonic x*x.  Returns AMC_OK, AMC_ERR_BAD_ARG with the first diagnostic when the
+ * text does not compile (an operator the dual numbers lack shows up here), AMC_ERR_COMPILE when the compiler itself failed. */
+int  amc_model_check(int n_params, int n_classes, const char *potential_expr, const char *reward_expr,
+                     const char *const *sample_exprs, const char *const *logq_exprs, const char *const *dlogq_exprs,
+                     const char *const *perform_exprs, const char *const *invert_exprs, char *log, int log_capacity);
 /* How an estimator call over n_learn learnable moves of this handle would run: returns 1 = ONE launch takes every learnable
  * move (the reference's make_step!(::PolicyGradientEstimator) loops over all of them in one step, estimator.jl:111-134), with
  * `fused` != 0: one launch per whole time step (sweep + estimator [+ update]: amc_pgmc_steps); 0 = one launch per learnable

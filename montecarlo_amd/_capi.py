@@ -173,6 +173,32 @@ def _check(rc: int) -> None:
         raise AmcError(f"amc error {rc}: {msg.decode() if msg else '?'}")
 
 
+def model_check(sample, logq, dlogq=None, perform=None, invert=None, *, n_params: int = 1, potential: Optional[str] = None,
+                reward: Optional[str] = None) -> str:
+    """Compile-only check of a script-defined model (no GPU needed; amc_model_check): one policy -- strings, `dlogq` a string, a
+    list of n_params strings or None (forward-mode differentiation of logq) -- or a pool of classes -- lists with one entry per
+    class, None entries where a class has no expression of that kind.  Returns the compiler log."""
+    many = isinstance(sample, (list, tuple))
+    n_classes = len(sample) if many else 1
+
+    def col(v, n):
+        if v is None:
+            return None
+        items = list(v) if isinstance(v, (list, tuple)) else [v]
+        assert len(items) == n, (items, n)
+        return (C.c_char_p * n)(*[None if e is None else str(e).encode() for e in items])
+    n_d = n_classes if many else int(n_params)
+    buf = C.create_string_buffer(8192)
+    lib = load()
+    lib.amc_model_check.restype = C.c_int
+    lib.amc_model_check.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+    _check(lib.amc_model_check(int(n_params), n_classes, None if potential is None else str(potential).encode(),
+                               None if reward is None else str(reward).encode(), col(sample, n_classes), col(logq, n_classes),
+                               col(dlogq, n_d), col(perform, n_classes), col(invert, n_classes), buf, len(buf)))
+    return buf.value.decode(errors="replace")
+
+
 def device_count() -> int:
     n = C.c_int(0)
     rc = load().amc_device_count(C.byref(n))
@@ -295,9 +321,7 @@ class HipEngine:
             cl = [tuple((list(c) + [None] * 4)[:5]) for c in classes]
             n = len(cl)
             arr = lambda i, need: ((C.c_char_p * n)(*[enc(c[i]) for c in cl]) if need else None)
-            have_d = all(c[2] is not None for c in cl)
-            if not have_d and any(c[2] is not None for c in cl):
-                raise AmcError("dlogq: one expression per class, or none at all")
+            have_d = any(c[2] is not None for c in cl)       # a class without one has its logq differentiated by the engine (NULL entry)
             com = (C.c_int * self.n_moves)(*[int(v) for v in class_of_move])
             if expr is None:
                 cfg.potential = POTENTIALS[potential]

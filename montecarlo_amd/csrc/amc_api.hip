@@ -335,6 +335,65 @@ struct ClassExprs { const char *sample, *logq, *dlogq, *perform, *invert; };
 struct ProposalExprs { const char *sample, *logq, *dlogq, *perform, *invert; int n_params; const char* const* dlogq_more;   // dlogq_more: partials 1 .. n_params - 1
                        int n_classes; const ClassExprs* more_classes; const int* class_of_move; };   // pools that mix policies / actions: classes 1 .. n_classes - 1
 
+// The expressions of a script-defined proposal, checked as text (validate_potential_expr: one line of ordinary expression text
+// that mentions what it must).
+static int validate_proposal_exprs(const ProposalExprs* proposal)
+{
+    int rc_p = validate_potential_expr(proposal->sample, "sample_action expression", "z");
+    if (rc_p == AMC_OK) rc_p = validate_potential_expr(proposal->logq, "log_proposal_density expression", "delta");
+    if (rc_p == AMC_OK && proposal->dlogq) {
+        rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", proposal->n_params > 1 ? "" : "sigma");
+        if (rc_p != AMC_OK && proposal->n_params == 1 &&         // theta0 is another name of sigma
+            validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "theta0") == AMC_OK)
+            rc_p = AMC_OK;
+    }
+    for (int pidx = 1; rc_p == AMC_OK && proposal->dlogq && pidx < proposal->n_params; ++pidx)
+        rc_p = validate_potential_expr(proposal->dlogq_more[pidx - 1], "d log_proposal_density / d theta expression", "");
+    if (rc_p == AMC_OK && (proposal->perform != nullptr) != (proposal->invert != nullptr))
+        rc_p = fail(AMC_ERR_BAD_ARG, "amc_create_action_model: perform_expr and invert_expr come together (No invert_action! is defined)");
+    if (rc_p == AMC_OK && proposal->perform) rc_p = validate_potential_expr(proposal->perform, "perform_action expression", "delta");
+    if (rc_p == AMC_OK && proposal->invert) rc_p = validate_potential_expr(proposal->invert, "invert_action expression", "delta");
+    for (int c = 1; rc_p == AMC_OK && c < proposal->n_classes; ++c) {
+        const ClassExprs& ce = proposal->more_classes[c - 1];
+        rc_p = validate_potential_expr(ce.sample, "sample_action expression", "z");
+        if (rc_p == AMC_OK) rc_p = validate_potential_expr(ce.logq, "log_proposal_density expression", "delta");
+        if (rc_p == AMC_OK && ce.dlogq) rc_p = validate_potential_expr(ce.dlogq, "d log_proposal_density / d sigma expression", "");
+        if (rc_p == AMC_OK && ce.perform) rc_p = validate_potential_expr(ce.perform, "perform_action expression", "delta");
+        if (rc_p == AMC_OK && ce.invert) rc_p = validate_potential_expr(ce.invert, "invert_action expression", "delta");
+    }
+    return rc_p;
+}
+
+// What the run-time compiler is given for a script-defined model: the expressions in one string, section marks between them
+// (amc_rtc.hip rtc_compile takes it apart again).  A derivative section that is absent means: differentiate logq (amc_dual.h).
+static std::string encode_model_expr(bool f32, const char* potential_expr, const char* reward_expr, const char* scale_expr, const ProposalExprs* proposal)
+{
+    std::string e;
+    if (f32) e = "\x02";
+    if (potential_expr) e += potential_expr;
+    if (potential_expr && reward_expr) e += std::string("\x01") + reward_expr;
+    if (potential_expr && scale_expr) e += std::string("\x03") + scale_expr;
+    if (potential_expr && proposal) {
+        e += std::string("\x04") + proposal->sample + std::string("\x05") + proposal->logq;
+        if (proposal->dlogq) {
+            e += std::string("\x06") + proposal->dlogq;
+            for (int pidx = 1; pidx < proposal->n_params; ++pidx) e += std::string("\x0b") + proposal->dlogq_more[pidx - 1];
+        }
+        if (proposal->perform) e += std::string("\x07") + proposal->perform + std::string("\x08") + proposal->invert;
+        if (proposal->n_params > 1) e += std::string("\x0e") + std::to_string(proposal->n_params);
+        if (proposal->n_classes > 1) {
+            // [ '\x0f' n_classes { '\x10' sample '\x11' logq '\x12' dlogq '\x13' perform '\x14' invert } per class 1 .. ]: empty = not given
+            e += std::string("\x0f") + std::to_string(proposal->n_classes);
+            for (int c = 1; c < proposal->n_classes; ++c) {
+                const ClassExprs& ce = proposal->more_classes[c - 1];
+                e += std::string("\x10") + ce.sample + std::string("\x11") + ce.logq + std::string("\x12") + (ce.dlogq ? ce.dlogq : "") +
+                     std::string("\x13") + (ce.perform ? ce.perform : "") + std::string("\x14") + (ce.invert ? ce.invert : "");
+            }
+        }
+    }
+    return e;
+}
+
 static int create_impl(const amc_config* cfg, const char* potential_expr, amc_handle** out, const char* reward_expr = nullptr,
                        const char* scale_expr = nullptr, const ProposalExprs* proposal = nullptr)
 {
@@ -369,28 +428,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
             if (rc_sc != AMC_OK) return rc_sc;
         }
         if (proposal) {
-            int rc_p = validate_potential_expr(proposal->sample, "sample_action expression", "z");
-            if (rc_p == AMC_OK) rc_p = validate_potential_expr(proposal->logq, "log_proposal_density expression", "delta");
-            if (rc_p == AMC_OK && proposal->dlogq) {
-                rc_p = validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", proposal->n_params > 1 ? "" : "sigma");
-                if (rc_p != AMC_OK && proposal->n_params == 1 &&         // theta0 is another name of sigma
-                    validate_potential_expr(proposal->dlogq, "d log_proposal_density / d sigma expression", "theta0") == AMC_OK)
-                    rc_p = AMC_OK;
-            }
-            for (int pidx = 1; rc_p == AMC_OK && proposal->dlogq && pidx < proposal->n_params; ++pidx)
-                rc_p = validate_potential_expr(proposal->dlogq_more[pidx - 1], "d log_proposal_density / d theta expression", "");
-            if (rc_p == AMC_OK && (proposal->perform != nullptr) != (proposal->invert != nullptr))
-                rc_p = fail(AMC_ERR_BAD_ARG, "amc_create_action_model: perform_expr and invert_expr come together (No invert_action! is defined)");
-            if (rc_p == AMC_OK && proposal->perform) rc_p = validate_potential_expr(proposal->perform, "perform_action expression", "delta");
-            if (rc_p == AMC_OK && proposal->invert) rc_p = validate_potential_expr(proposal->invert, "invert_action expression", "delta");
-            for (int c = 1; rc_p == AMC_OK && c < proposal->n_classes; ++c) {
-                const ClassExprs& ce = proposal->more_classes[c - 1];
-                rc_p = validate_potential_expr(ce.sample, "sample_action expression", "z");
-                if (rc_p == AMC_OK) rc_p = validate_potential_expr(ce.logq, "log_proposal_density expression", "delta");
-                if (rc_p == AMC_OK && ce.dlogq) rc_p = validate_potential_expr(ce.dlogq, "d log_proposal_density / d sigma expression", "");
-                if (rc_p == AMC_OK && ce.perform) rc_p = validate_potential_expr(ce.perform, "perform_action expression", "delta");
-                if (rc_p == AMC_OK && ce.invert) rc_p = validate_potential_expr(ce.invert, "invert_action expression", "delta");
-            }
+            const int rc_p = validate_proposal_exprs(proposal);
             if (rc_p != AMC_OK) return rc_p;
             if (state_dtype != AMC_DTYPE_F64)
                 return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: script-defined proposals are offered for Float64 state");
@@ -476,26 +514,10 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     h->potential = cfg->potential;
     h->f32 = state_dtype == AMC_DTYPE_F32;
     h->use_rtc = h->f32 || cfg->potential == AMC_POTENTIAL_CUSTOM;
-    if (h->f32) h->pot_expr = "\x02";
-    if (potential_expr) h->pot_expr += potential_expr;
-    if (potential_expr && reward_expr) h->pot_expr += std::string("\x01") + reward_expr;
-    if (potential_expr && scale_expr) { h->pot_expr += std::string("\x03") + scale_expr; h->scaled_policy = true; }
+    h->pot_expr = encode_model_expr(h->f32, potential_expr, reward_expr, scale_expr, proposal);
+    if (potential_expr && scale_expr) h->scaled_policy = true;
     if (potential_expr && proposal) {
-        h->pot_expr += std::string("\x04") + proposal->sample + std::string("\x05") + proposal->logq;
-        if (proposal->dlogq) {
-            h->pot_expr += std::string("\x06") + proposal->dlogq;
-            for (int pidx = 1; pidx < proposal->n_params; ++pidx) h->pot_expr += std::string("\x0b") + proposal->dlogq_more[pidx - 1];
-        }
-        if (proposal->perform) h->pot_expr += std::string("\x07") + proposal->perform + std::string("\x08") + proposal->invert;
-        if (proposal->n_params > 1) h->pot_expr += std::string("\x0e") + std::to_string(proposal->n_params);
         if (proposal->n_classes > 1) {
-            // [ '\x0f' n_classes { '\x10' sample '\x11' logq '\x12' dlogq '\x13' perform '\x14' invert } per class 1 .. ]: empty = not given
-            h->pot_expr += std::string("\x0f") + std::to_string(proposal->n_classes);
-            for (int c = 1; c < proposal->n_classes; ++c) {
-                const ClassExprs& ce = proposal->more_classes[c - 1];
-                h->pot_expr += std::string("\x10") + ce.sample + std::string("\x11") + ce.logq + std::string("\x12") + (ce.dlogq ? ce.dlogq : "") +
-                               std::string("\x13") + (ce.perform ? ce.perform : "") + std::string("\x14") + (ce.invert ? ce.invert : "");
-            }
             h->n_classes = proposal->n_classes;
             for (int k = 0; k < cfg->n_moves; ++k) h->class_of_move[k] = proposal->class_of_move[k];
         }
@@ -730,8 +752,6 @@ int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* clas
     for (int c = 0; c < n_classes; ++c) {
         if (!sample_exprs[c] || !logq_exprs[c])
             return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class %d has no sample / logq expression (No sample_action! / log_proposal_density is defined)", c);
-        if (dlogq_exprs && !dlogq_exprs[c])
-            return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: dlogq_exprs[%d] is NULL (one expression per class, or none at all)", c);
         const bool p = perform_exprs && perform_exprs[c], i = invert_exprs && invert_exprs[c];
         if (p != i) return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class %d: perform_expr and invert_expr come together (No invert_action! is defined)", c);
     }
@@ -756,6 +776,48 @@ int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* clas
 
 
 
+
+int amc_model_check(int n_params, int n_classes, const char* potential_expr, const char* reward_expr, const char* const* sample_exprs,
+                    const char* const* logq_exprs, const char* const* dlogq_exprs, const char* const* perform_exprs,
+                    const char* const* invert_exprs, char* log, int log_capacity)
+{
+    if (log && log_capacity > 0) log[0] = 0;
+    if (!sample_exprs || !logq_exprs) return fail(AMC_ERR_BAD_ARG, "amc_model_check: NULL argument");
+    if (n_classes < 1 || n_classes > AMC_MAX_CLASSES) return fail(AMC_ERR_BAD_ARG, "amc_model_check: n_classes must be in [1, %d]", AMC_MAX_CLASSES);
+    if (n_params < 1 || n_params > AMC_MAX_NP || (n_params > 1 && n_classes > 1))
+        return fail(AMC_ERR_BAD_ARG, "amc_model_check: n_params must be in [1, %d], and 1 for a pool of several classes", AMC_MAX_NP);
+    for (int c = 0; c < n_classes; ++c) {
+        if (!sample_exprs[c] || !logq_exprs[c]) return fail(AMC_ERR_BAD_ARG, "amc_model_check: class %d has no sample / logq expression", c);
+        const bool p = perform_exprs && perform_exprs[c], i = invert_exprs && invert_exprs[c];
+        if (p != i) return fail(AMC_ERR_BAD_ARG, "amc_model_check: class %d: perform_expr and invert_expr come together (No invert_action! is defined)", c);
+    }
+    // several parameters: dlogq_exprs holds the P partials of the one class (all or none); several classes: one entry per class, NULL entries allowed
+    if (n_params > 1 && dlogq_exprs)
+        for (int q = 0; q < n_params; ++q)
+            if (!dlogq_exprs[q]) return fail(AMC_ERR_BAD_ARG, "amc_model_check: dlogq_exprs[%d] is NULL (one expression per parameter, or none at all)", q);
+    const char* pot = potential_expr ? potential_expr : "x*x";
+    { const int rc = validate_potential_expr(pot); if (rc != AMC_OK) return rc; }
+    if (reward_expr) { const int rc = validate_potential_expr(reward_expr, "custom reward", "delta"); if (rc != AMC_OK) return rc; }
+    ClassExprs more[AMC_MAX_CLASSES];
+    for (int c = 1; c < n_classes; ++c)
+        more[c - 1] = ClassExprs{sample_exprs[c], logq_exprs[c], dlogq_exprs ? dlogq_exprs[c] : nullptr, perform_exprs ? perform_exprs[c] : nullptr,
+                                 invert_exprs ? invert_exprs[c] : nullptr};
+    const int com[1] = {0};
+    const ProposalExprs prop = {sample_exprs[0], logq_exprs[0], dlogq_exprs ? dlogq_exprs[0] : nullptr, perform_exprs ? perform_exprs[0] : nullptr,
+                                invert_exprs ? invert_exprs[0] : nullptr, n_params, (dlogq_exprs && n_params > 1) ? dlogq_exprs + 1 : nullptr,
+                                n_classes, more, com};
+    { const int rc = validate_proposal_exprs(&prop); if (rc != AMC_OK) return rc; }
+    const std::string expr = encode_model_expr(false, pot, reward_expr, nullptr, &prop);
+    // the estimator kernel is the one that uses every expression (sample, logq, its derivative, perform / invert, reward)
+    const RtcCode* code = nullptr;
+    std::string text;
+    const int rc = rtc_compile(expr, "amc::pg_estimate_kernel<2,1,false,0,0,false>", AMC_BUILD_ARCH, &code, &text);
+    if (log && log_capacity > 0) {
+        std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
+        log[log_capacity - 1] = 0;
+    }
+    return rc;
+}
 
 int amc_destroy(amc_handle* h)
 {

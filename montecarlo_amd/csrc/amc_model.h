@@ -158,6 +158,9 @@ struct SigmaArg {
     __device__ __forceinline__ operator double() const { return v; }
 };
 __device__ __forceinline__ double log_f64(const SigmaArg& s) { return s.logv; }
+}  // namespace amc
+#include "amc_dual.h"          // forward-mode differentiation of script-defined densities (dual numbers over the same vocabulary)
+namespace amc {
 
 struct UserTheta {          // a script-defined policy's parameters theta1 .. theta3 of one move (see AMC_USER_THETAS), their logs beside them
     double t1, t2, t3;
@@ -195,21 +198,8 @@ __shared__ int s_user_class[AMC_MAX_MOVES];
 #define AMC_USER_PERFORM_3 AMC_USER_PERFORM
 #define AMC_USER_INVERT_3 AMC_USER_INVERT
 #endif
-// d logq / d sigma: given for every class or for none (the host refuses the estimator then)
-#ifdef AMC_USER_DLOGQ
-#define AMC_USER_DLOGQ_0 AMC_USER_DLOGQ
-#if AMC_NCLASS < 3
-#define AMC_USER_DLOGQ_2 AMC_USER_DLOGQ
-#endif
-#if AMC_NCLASS < 4
-#define AMC_USER_DLOGQ_3 AMC_USER_DLOGQ
-#endif
-#else
-#define AMC_USER_DLOGQ_0(delta, x, sigma) __builtin_nan("")
-#define AMC_USER_DLOGQ_1(delta, x, sigma) __builtin_nan("")
-#define AMC_USER_DLOGQ_2(delta, x, sigma) __builtin_nan("")
-#define AMC_USER_DLOGQ_3(delta, x, sigma) __builtin_nan("")
-#endif
+// d logq / d sigma of a class: AMC_USER_DLOGQ (class 0) / AMC_USER_DLOGQ_c where the script gives the expression; a class without
+// one gets its derivative by forward-mode differentiation of its logq (user_logq_dual below, amc_dual.h)
 #endif
 __device__ __forceinline__ real_t user_perform(real_t x, real_t delta, const double* amc_tables_, int k)
 {
@@ -349,18 +339,85 @@ __device__ __forceinline__ double user_logq(real_t delta, real_t x, S sigma, con
     return (double)(AMC_USER_LOGQ(delta, x, sigma));
 #endif
 }
+// Forward-mode differentiation (amc_dual.h): the class's log_proposal_density evaluated over dual numbers whose partials belong to
+// the move's parameters -- ForwardDiff.gradient(p -> log_proposal_density(action, policy, p, system), parameters),
+// src/PolicyGuided/gradients.jl:28-33; delta and x are constants there and here.  Returns logq (the value parts go through the
+// plain evaluation's operations: the same bits as user_logq) and leaves d[p] = d logq / d theta_p.
+template <class S>
+__device__ __forceinline__ double user_logq_dual(real_t delta, real_t x, S sigma_in, const double* amc_tables_, int k, const UserTheta& th,
+                                                 double (&d)[AMC_NP])
+{
+    typedef Dual<AMC_NP> D_;
+    const D_ sigma = dual_var<AMC_NP>((double)sigma_in, 0), theta0 = sigma;
+    // theta1 .. theta3: parameters 1 .. 3 where the policy has them (a slot beyond AMC_NP carries no partial: a constant)
+    const D_ theta1 = dual_var<AMC_NP>(th.t1, 1), theta2 = dual_var<AMC_NP>(th.t2, 2), theta3 = dual_var<AMC_NP>(th.t3, 3);
+    (void)theta0; (void)theta1; (void)theta2; (void)theta3; (void)k;
+    D_ r;
+#if AMC_NCLASS > 1
+    const int cls_ = k >> 8;
+    if (cls_ == 1) r = as_dual<AMC_NP>(AMC_USER_LOGQ_1(delta, x, sigma));
+    else if (AMC_NCLASS > 2 && cls_ == 2) r = as_dual<AMC_NP>(AMC_USER_LOGQ_2(delta, x, sigma));
+    else if (AMC_NCLASS > 3 && cls_ == 3) r = as_dual<AMC_NP>(AMC_USER_LOGQ_3(delta, x, sigma));
+    else r = as_dual<AMC_NP>(AMC_USER_LOGQ(delta, x, sigma));
+#else
+    r = as_dual<AMC_NP>(AMC_USER_LOGQ(delta, x, sigma));
+#endif
+#pragma unroll
+    for (int p = 0; p < AMC_NP; ++p) d[p] = r.d[p];
+    return r.v;
+}
+// no class of the pool brings a derivative expression: ONE dual evaluation serves log_proposal_density and its gradient
+#if !defined(AMC_USER_DLOGQ) && !defined(AMC_USER_DLOGQ_1) && !defined(AMC_USER_DLOGQ_2) && !defined(AMC_USER_DLOGQ_3)
+#define AMC_DLOGQ_ALL_AUTO 1
+#else
+#define AMC_DLOGQ_ALL_AUTO 0
+#endif
 // grad log_proposal_density with respect to the parameters, d[p] = d logq / d theta_p
 template <class S>
 __device__ __forceinline__ void user_dlogq(real_t delta, real_t x, S sigma, const double* amc_tables_, int k, const UserTheta& th,
                                            double (&d)[AMC_NP])
 {
-    AMC_USER_THETAS(th);
 #if AMC_NCLASS > 1
-    d[0] = [&]() -> double {
-        AMC_BY_CLASS(k, double, AMC_USER_DLOGQ_0(delta, x, sigma), AMC_USER_DLOGQ_1(delta, x, sigma), AMC_USER_DLOGQ_2(delta, x, sigma),
-                     AMC_USER_DLOGQ_3(delta, x, sigma));
-    }();
+    // one parameter per move; the class's own expression, or its logq differentiated
+    const int cls_ = k >> 8;
+    double da_[AMC_NP];
+    (void)da_;
+    AMC_USER_THETAS(th);
+    if (cls_ == 1) {
+#ifdef AMC_USER_DLOGQ_1
+        d[0] = (double)(AMC_USER_DLOGQ_1(delta, x, sigma));
+#else
+        (void)user_logq_dual(delta, x, sigma, amc_tables_, k, th, da_); d[0] = da_[0];
+#endif
+        return;
+    }
+#if AMC_NCLASS > 2
+    if (cls_ == 2) {
+#ifdef AMC_USER_DLOGQ_2
+        d[0] = (double)(AMC_USER_DLOGQ_2(delta, x, sigma));
+#else
+        (void)user_logq_dual(delta, x, sigma, amc_tables_, k, th, da_); d[0] = da_[0];
+#endif
+        return;
+    }
+#endif
+#if AMC_NCLASS > 3
+    if (cls_ == 3) {
+#ifdef AMC_USER_DLOGQ_3
+        d[0] = (double)(AMC_USER_DLOGQ_3(delta, x, sigma));
+#else
+        (void)user_logq_dual(delta, x, sigma, amc_tables_, k, th, da_); d[0] = da_[0];
+#endif
+        return;
+    }
+#endif
+#ifdef AMC_USER_DLOGQ
+    d[0] = (double)(AMC_USER_DLOGQ(delta, x, sigma));
+#else
+    (void)user_logq_dual(delta, x, sigma, amc_tables_, k, th, da_); d[0] = da_[0];
+#endif
 #elif defined(AMC_USER_DLOGQ)
+    AMC_USER_THETAS(th);
     d[0] = (double)(AMC_USER_DLOGQ(delta, x, sigma));
 #if AMC_NP > 1
     d[1] = (double)(AMC_USER_DLOGQ1(delta, x, sigma));
@@ -372,7 +429,20 @@ __device__ __forceinline__ void user_dlogq(real_t delta, real_t x, S sigma, cons
     d[3] = (double)(AMC_USER_DLOGQ3(delta, x, sigma));
 #endif
 #else
-    for (int p = 0; p < AMC_NP; ++p) d[p] = __builtin_nan("");     // the host refuses the estimator for such a handle
+    (void)user_logq_dual(delta, x, sigma, amc_tables_, k, th, d);
+#endif
+}
+// log_proposal_density and its gradient at one point (what withgrad_log_proposal_density! returns and leaves, gradients.jl:28-33)
+template <class S>
+__device__ __forceinline__ double user_logq_dlogq(real_t delta, real_t x, S sigma, const double* amc_tables_, int k, const UserTheta& th,
+                                                  double (&d)[AMC_NP])
+{
+#if AMC_DLOGQ_ALL_AUTO
+    return user_logq_dual(delta, x, sigma, amc_tables_, k, th, d);
+#else
+    const double lq = user_logq(delta, x, sigma, amc_tables_, k, th);
+    user_dlogq(delta, x, sigma, amc_tables_, k, th, d);
+    return lq;
 #endif
 }
 #endif

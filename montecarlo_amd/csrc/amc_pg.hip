@@ -247,9 +247,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         if (learn_ids[l] < 0 || learn_ids[l] >= h->K)
             return fail(AMC_ERR_BAD_ARG, "%s: learn_ids[%d] = %d out of range", who, l, learn_ids[l]);
     *nl_out = 0;
-    if (h->script_policy && !h->script_dlogq && n_learn > 0)
-        return fail(AMC_ERR_STATE, "%s: this handle's script-defined proposal came without d logq / d sigma (dlogq_expr): "
-                                   "No withgrad_log_proposal_density! is defined", who);
+    // (a script-defined proposal that came without d logq / d theta expressions gets them by forward-mode differentiation of its
+    // logq in the kernel -- amc_dual.h; the reference's withgrad_log_proposal_density! does the same with ForwardDiff, gradients.jl:28-33)
     if (n_learn == 0) { h->t_est += 1; return AMC_OK; }
     if (per_move_launches(h) && (n_learn != 1 || ((tail != 1 || with_sweep) && !np_single_launch(h, n_learn))))
         return fail(AMC_ERR_STATE, "%s: a policy with several parameters takes one learnable move per launch", who);

@@ -148,8 +148,7 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
 {
     const real_t delta = user_sample(z, x, sigma, T, k, th);
     double d_f[AMC_NP], d_b[AMC_NP];
-    const double logq_f = user_logq(delta, x, sigma, T, k, th);
-    user_dlogq(delta, x, sigma, T, k, th, d_f);
+    const double logq_f = user_logq_dlogq(delta, x, sigma, T, k, th, d_f);      // withgrad_log_proposal_density!, gradients.jl:97
     const real_t e1 = potential<POT>(x, T);
     const real_t xn = user_perform(x, delta, T, k);
     const real_t e2 = potential<POT>(xn, T);
@@ -166,8 +165,7 @@ __device__ __forceinline__ void pg_sample_script(real_t& x, real_t beta, double 
     } else
 #endif
     {
-        logq_b = user_logq(nd, xn, sigma, T, k, th);
-        user_dlogq(nd, xn, sigma, T, k, th, d_b);
+        logq_b = user_logq_dlogq(nd, xn, sigma, T, k, th, d_b);                 // gradients.jl:102
     }
     x = user_perform(xn, nd, T, k);
     const double arg = ((double)dlogp + logq_b) - logq_f;

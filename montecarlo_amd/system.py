@@ -154,14 +154,15 @@ class ScriptPolicy(Policy):
     each as one C expression compiled for the GPU at run time:
       ``sample``  delta = f(z, x, sigma) from ONE standard normal variate ``z``, the position ``x`` and the parameter ``sigma``
       ``logq``    log q(delta | x, sigma), the log-density of what ``sample`` returns
-      ``dlogq``   d logq / d sigma (the reference's AD backends, gradients.jl:28-33) -- needed by the estimator only
+      ``dlogq``   d logq / d sigma -- OPTIONAL: the reference gets it from its AD backends (gradients.jl:28-33) and so does the
+                  engine when it is None (``logq`` evaluated over dual numbers, ForwardDiff's rules: csrc/amc_dual.h)
     e.g. a drifted Gaussian (Langevin) proposal for U = x^2, beta = 2:
       ScriptPolicy("-2.0*sigma*sigma*x + sigma*z", "-(delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x)/(2.0*sigma*sigma) - amc_log(sigma)", ...)
     All moves of a pool share the policy.
 
     SEVERAL parameters (Move.parameters is an array in the reference, src/metropolis.jl:140-147; grad j, grad logq and the
     P x P metric g of GradientData follow its shape, PolicyGuided/gradients.jl:41-61): ``n_params`` = P <= 4, the expressions
-    say theta0 .. theta{P-1} (``sigma`` stays a name of theta0) and ``dlogq`` lists the P partial derivatives -- e.g. a
+    say theta0 .. theta{P-1} (``sigma`` stays a name of theta0) and ``dlogq`` lists the P partial derivatives (or is None) -- e.g. a
     Gaussian displacement with a learnable drift,
       ScriptPolicy("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)",
                    ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"], n_params=2)"""

@@ -251,9 +251,72 @@ def learning_step(opt: str, h0: float, h1: float, theta: float, gd4) -> float:
 _custom_libs = {}
 # The expressions are compiled as C++ like the kernels' (hiprtc): with Float32 state an overloaded call such as sqrt(x) or
 # fabs(x) then takes its float form on both sides -- Julia's sqrt(x::Float32) is Float32 too; C would promote to double.
+# Dual numbers for the oracle's twins of policies whose derivative the script does not give (the engine differentiates logq itself,
+# montecarlo_amd/csrc/amc_dual.h; the reference: ForwardDiff.gradient over log_proposal_density, src/PolicyGuided/gradients.jl:28-33).
+# The oracle's OWN statement of ForwardDiff 0.10's rules (src/dual.jl, partials.jl): value and partials per operation, in that
+# order of IEEE operations -- x*y -> (vy*px) + (vx*py); x/y -> (inv(vy)*px) + (-(vx/(vy*vy))*py); c/y -> (-( (c/vy) / vy ))*py;
+# x/c -> px/c; log -> inv(v)*p; exp -> e*p; sqrt -> inv(s+s)*p; fabs -> signbit ? -x : x; fma -> ((vy*px) + (vx*py)) + pz.
+_DUAL_PROLOGUE = r"""
+template <int N> struct Dn { double v; double d[N]; };
+template <int N> static inline Dn<N> dn_const(double v) { Dn<N> r; r.v = v; for (int i = 0; i < N; ++i) r.d[i] = 0.0; return r; }
+template <int N> static inline Dn<N> dn_var(double v, int p) { Dn<N> r = dn_const<N>(v); if (p < N) r.d[p] = 1.0; return r; }
+template <int N> static inline Dn<N> dn_of(const Dn<N>& a) { return a; }
+template <int N> static inline Dn<N> dn_of(double a) { return dn_const<N>(a); }
+#define DN template <int N> static inline
+DN Dn<N> operator+(const Dn<N>& a) { return a; }
+DN Dn<N> operator-(const Dn<N>& a) { Dn<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+DN Dn<N> operator+(const Dn<N>& a, const Dn<N>& b) { Dn<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+DN Dn<N> operator+(const Dn<N>& a, double c) { Dn<N> r = a; r.v = a.v + c; return r; }
+DN Dn<N> operator+(double c, const Dn<N>& a) { Dn<N> r = a; r.v = c + a.v; return r; }
+DN Dn<N> operator-(const Dn<N>& a, const Dn<N>& b) { Dn<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+DN Dn<N> operator-(const Dn<N>& a, double c) { Dn<N> r = a; r.v = a.v - c; return r; }
+DN Dn<N> operator-(double c, const Dn<N>& a) { Dn<N> r; r.v = c - a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+DN Dn<N> operator*(const Dn<N>& a, const Dn<N>& b) { Dn<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = (b.v * a.d[i]) + (a.v * b.d[i]); return r; }
+DN Dn<N> operator*(const Dn<N>& a, double c) { Dn<N> r; r.v = a.v * c; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+DN Dn<N> operator*(double c, const Dn<N>& a) { Dn<N> r; r.v = c * a.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+DN Dn<N> operator/(const Dn<N>& a, const Dn<N>& b) { Dn<N> r; r.v = a.v / b.v; const double fa = 1.0 / b.v, fb = -(a.v / (b.v * b.v));
+    for (int i = 0; i < N; ++i) r.d[i] = (fa * a.d[i]) + (fb * b.d[i]); return r; }
+DN Dn<N> operator/(const Dn<N>& a, double c) { Dn<N> r; r.v = a.v / c; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / c; return r; }
+DN Dn<N> operator/(double c, const Dn<N>& b) { Dn<N> r; const double q = c / b.v; r.v = q; const double f = -(q / b.v);
+    for (int i = 0; i < N; ++i) r.d[i] = f * b.d[i]; return r; }
+DN bool operator<(const Dn<N>& a, const Dn<N>& b) { return a.v < b.v; }
+DN bool operator<(const Dn<N>& a, double b) { return a.v < b; }
+DN bool operator<(double a, const Dn<N>& b) { return a < b.v; }
+DN bool operator>(const Dn<N>& a, const Dn<N>& b) { return a.v > b.v; }
+DN bool operator>(const Dn<N>& a, double b) { return a.v > b; }
+DN bool operator>(double a, const Dn<N>& b) { return a > b.v; }
+DN bool operator<=(const Dn<N>& a, const Dn<N>& b) { return a.v <= b.v; }
+DN bool operator<=(const Dn<N>& a, double b) { return a.v <= b; }
+DN bool operator<=(double a, const Dn<N>& b) { return a <= b.v; }
+DN bool operator>=(const Dn<N>& a, const Dn<N>& b) { return a.v >= b.v; }
+DN bool operator>=(const Dn<N>& a, double b) { return a.v >= b; }
+DN bool operator>=(double a, const Dn<N>& b) { return a >= b.v; }
+DN Dn<N> amo_log(const Dn<N>& a) { Dn<N> r; r.v = amo_log(a.v); const double f = 1.0 / a.v; for (int i = 0; i < N; ++i) r.d[i] = f * a.d[i]; return r; }
+DN Dn<N> amo_exp(const Dn<N>& a) { Dn<N> r; r.v = amo_exp(a.v); for (int i = 0; i < N; ++i) r.d[i] = r.v * a.d[i]; return r; }
+DN Dn<N> sqrt(const Dn<N>& a) { Dn<N> r; r.v = std::sqrt(a.v); const double f = 1.0 / (r.v + r.v); for (int i = 0; i < N; ++i) r.d[i] = f * a.d[i]; return r; }
+DN Dn<N> fabs(const Dn<N>& a) { return std::signbit(a.v) ? -a : a; }
+DN Dn<N> fma(const Dn<N>& a, const Dn<N>& b, const Dn<N>& c) { Dn<N> r; r.v = std::fma(a.v, b.v, c.v);
+    for (int i = 0; i < N; ++i) r.d[i] = ((b.v * a.d[i]) + (a.v * b.d[i])) + c.d[i]; return r; }
+DN Dn<N> fma(const Dn<N>& a, const Dn<N>& b, double c) { Dn<N> r; r.v = std::fma(a.v, b.v, c); for (int i = 0; i < N; ++i) r.d[i] = (b.v * a.d[i]) + (a.v * b.d[i]); return r; }
+DN Dn<N> fma(const Dn<N>& a, double b, const Dn<N>& c) { Dn<N> r; r.v = std::fma(a.v, b, c.v); for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] * b) + c.d[i]; return r; }
+DN Dn<N> fma(double a, const Dn<N>& b, const Dn<N>& c) { return fma(b, a, c); }
+DN Dn<N> fma(const Dn<N>& a, double b, double c) { Dn<N> r; r.v = std::fma(a.v, b, c); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+DN Dn<N> fma(double a, const Dn<N>& b, double c) { return fma(b, a, c); }
+DN Dn<N> fma(double a, double b, const Dn<N>& c) { Dn<N> r = c; r.v = std::fma(a, b, c.v); return r; }
+#undef DN
+"""
 _CUSTOM_PROLOGUE = ("#include <cmath>\nusing std::sqrt; using std::fabs; using std::fma;\n"
-                    "extern \"C\" {\ndouble amo_exp(double); double amo_log(double);\n"
+                    "extern \"C\" { double amo_exp(double); double amo_log(double); }\n" + _DUAL_PROLOGUE +
+                    "extern \"C\" {\n"
                     "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n")
+
+
+def _dual_dlogq_body(logq: str, n_params: int = 1) -> str:
+    """C++ statements that leave d logq / d theta_p in out[p]: `logq` evaluated over dual numbers (ForwardDiff's rules above) with
+    unit partials on the parameters; `sigma` is theta0, delta and x are constants."""
+    P = int(n_params)
+    names = "".join(f"const Dn<{P}> theta{i} = dn_var<{P}>({'theta[%d]' % i if i < P else '0.0'}, {i}); (void)theta{i}; " for i in range(4))
+    return f"{names}const Dn<{P}> sigma = theta0; (void)sigma; const Dn<{P}> r_ = dn_of<{P}>({logq}); for (int p_ = 0; p_ < {P}; ++p_) out[p_] = r_.d[p_];"
 
 
 def install_custom_potential(expr: str) -> None:
@@ -353,7 +416,9 @@ def install_custom_proposal(proposal) -> None:
             f.write(_CUSTOM_PROLOGUE +
                     f"double amo_user_sample(double z, double x, double sigma) {{ return ({sample}); }}\n"
                     f"double amo_user_logq(double delta, double x, double sigma) {{ return ({logq}); }}\n" +
-                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else "") +
+                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else
+                     "double amo_user_dlogq(double delta, double x, double sigma_in) { const double theta[1] = {sigma_in}; double out[1]; "
+                     + _dual_dlogq_body(logq, 1) + " return out[0]; }\n") +
                     (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
                      f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
@@ -361,7 +426,7 @@ def install_custom_proposal(proposal) -> None:
         _custom_libs[key] = C.CDLL(so)
     L = _custom_libs[key]
     lib.amo_set_custom_proposal(C.cast(L.amo_user_sample, C.c_void_p), C.cast(L.amo_user_logq, C.c_void_p),
-                                C.cast(L.amo_user_dlogq, C.c_void_p) if dlogq else None)
+                                C.cast(L.amo_user_dlogq, C.c_void_p))           # (the script's expression, or logq over dual numbers)
     if perform:
         lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
     else:
@@ -395,7 +460,8 @@ def install_vector_policy(n_params, proposal) -> None:
                     f"double amo_vec_sample(double z, double x, const double* theta) {{ {names} return ({sample}); }}\n"
                     f"double amo_vec_logq(double delta, double x, const double* theta) {{ {names} return ({logq}); }}\n" +
                     ("void amo_vec_dlogq(double delta, double x, const double* theta, double* out) { " + names +
-                     " ".join(f"out[{i}] = ({e});" for i, e in enumerate(dlogq)) + " }\n" if dlogq else "") +
+                     " ".join(f"out[{i}] = ({e});" for i, e in enumerate(dlogq)) + " }\n" if dlogq else
+                     "void amo_vec_dlogq(double delta, double x, const double* theta, double* out) { " + _dual_dlogq_body(logq, P) + " }\n") +
                     (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
                      f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
@@ -403,7 +469,7 @@ def install_vector_policy(n_params, proposal) -> None:
         _custom_libs[key] = C.CDLL(so)
     L = _custom_libs[key]
     lib.amo_set_vector_policy(P, C.cast(L.amo_vec_sample, C.c_void_p), C.cast(L.amo_vec_logq, C.c_void_p),
-                              C.cast(L.amo_vec_dlogq, C.c_void_p) if dlogq else None)
+                              C.cast(L.amo_vec_dlogq, C.c_void_p))
     if perform:
         lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
     else:
@@ -435,6 +501,9 @@ def install_policy_classes(classes, class_of_move) -> None:
             body += f"double amo_cls_logq_{i}(double delta, double x, double sigma) {{ {th}return ({logq}); }}\n"
             if dlogq:
                 body += f"double amo_cls_dlogq_{i}(double delta, double x, double sigma) {{ {th}return ({dlogq}); }}\n"
+            else:
+                body += (f"double amo_cls_dlogq_{i}(double delta, double x, double sigma_in) {{ const double theta[1] = {{sigma_in}}; double out[1]; "
+                         + _dual_dlogq_body(logq, 1) + " return out[0]; }\n")
             if perform:
                 body += f"double amo_cls_perform_{i}(double x, double delta) {{ return ({perform}); }}\n"
                 body += f"double amo_cls_invert_{i}(double delta, double x) {{ return ({invert}); }}\n"
@@ -448,7 +517,7 @@ def install_policy_classes(classes, class_of_move) -> None:
 
     def ptrs(name, present):
         return (C.c_void_p * n)(*[C.cast(getattr(L, f"amo_cls_{name}_{i}"), C.c_void_p) if present(cl[i]) else None for i in range(n)])
-    have_d = all(c[2] for c in cl)
+    have_d = True            # a class without a derivative expression has its logq differentiated (dual numbers)
     com = (C.c_int * len(class_of_move))(*[int(v) for v in class_of_move])
     lib.amo_set_policy_classes(n, com, len(class_of_move), ptrs("sample", lambda c: True), ptrs("logq", lambda c: True),
                                ptrs("dlogq", lambda c: True) if have_d else None, ptrs("perform", lambda c: c[3]),
