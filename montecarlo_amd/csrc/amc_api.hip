@@ -811,7 +811,10 @@ int amc_model_check(int n_params, int n_classes, const char* potential_expr, con
     // the estimator kernel is the one that uses every expression (sample, logq, its derivative, perform / invert, reward)
     const RtcCode* code = nullptr;
     std::string text;
-    const int rc = rtc_compile(expr, "amc::pg_estimate_kernel<2,1,false,0,0,false>", AMC_BUILD_ARCH, &code, &text);
+    // (developer knob: AMC_MODEL_CHECK_INST names another instantiation to build -- with AMC_RTC_CACHE_DIR the code object lands in a
+    // file that llvm-objdump reads: tools/rtc_isa.py)
+    const char* inst_env = std::getenv("AMC_MODEL_CHECK_INST");
+    const int rc = rtc_compile(expr, inst_env && *inst_env ? inst_env : "amc::pg_estimate_kernel<2,1,false,0,0,false>", AMC_BUILD_ARCH, &code, &text);
     if (log && log_capacity > 0) {
         std::strncpy(log, text.c_str(), (size_t)log_capacity - 1);
         log[log_capacity - 1] = 0;

@@ -114,7 +114,7 @@ elif mode in ("pgmc", "est"):
                 e.pg_accumulate([1], 1)
         us = e.timing_end() * 1e3 / (n // 10 * 10 if mode == "pgmc" else n)
     print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}{' (callback read one period later)' if PIPELINED and mode == 'pgmc' else ''}; sigma = {e.get_parameters(1)[0]:.4f}")
-elif mode in ("vec", "mixed", "vec1"):
+elif mode in ("vec", "mixed", "vec1", "vec_auto", "vec1_auto", "mixed_auto", "vec_mul"):
     # the PGMC time step of a policy with SEVERAL parameters (vec: the drift + width proposal delta = theta0 + theta1 z, one
     # learnable move, VPG), of its one-parameter twin written as a script (vec1: what the several-parameter forms are compared
     # with), and of a pool that mixes two policy classes (mixed: Gaussian + Langevin, one learnable move each)
@@ -126,15 +126,25 @@ elif mode in ("vec", "mixed", "vec1"):
     MALA = ("-2.0*sigma*sigma*x + sigma*z",
             "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)",
             "((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(sigma*sigma*sigma) - 4.0*x*(delta + 2.0*sigma*sigma*x)/sigma - 1.0/sigma")
-    if mode == "vec":
-        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5]], weight=[1.0], seed=42, proposal=DRIFT, n_params=2)
+    # *_auto: the same policies WITHOUT their derivative expressions -- the engine differentiates logq (dual numbers, amc_dual.h)
+    if mode == "vec_mul":
+        # NOT the same bits: every division by a parameter-only divisor written as a multiplication by its reciprocal -- the upper
+        # bound of what a division by a wave-uniform divisor can gain (profiles/NOTES_r06.md)
+        DRIFT_MUL = ("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))*(1.0/(2.0*theta1*theta1)) - amc_log(theta1)",
+                     ["(delta-theta0)*(1.0/(theta1*theta1))", "((delta-theta0)*(delta-theta0))*(1.0/(theta1*theta1*theta1)) - 1.0/theta1"])
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5]], weight=[1.0], seed=42, proposal=DRIFT_MUL, n_params=2)
         learn, kinds, h0 = [0], [1], [1e-3]
-    elif mode == "vec1":
-        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.5], weight=[1.0], seed=42, proposal=GAUSS)
+    elif mode in ("vec", "vec_auto"):
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5]], weight=[1.0], seed=42,
+                        proposal=DRIFT if mode == "vec" else (DRIFT[0], DRIFT[1], None), n_params=2)
+        learn, kinds, h0 = [0], [1], [1e-3]
+    elif mode in ("vec1", "vec1_auto"):
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.5], weight=[1.0], seed=42,
+                        proposal=GAUSS if mode == "vec1" else (GAUSS[0], GAUSS[1], None))
         learn, kinds, h0 = [0], [1], [1e-3]
     else:
         e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.3, 0.4], weight=[0.5, 0.5], seed=42,
-                        classes=[GAUSS, MALA], class_of_move=[0, 1])
+                        classes=[GAUSS, MALA] if mode == "mixed" else [GAUSS, (MALA[0], MALA[1], None)], class_of_move=[0, 1])
         learn, kinds, h0 = [0, 1], [1, 1], [1e-3, 1e-3]
     e.init_uniform(-2, 2)
     want_columns(e)
