@@ -10,6 +10,7 @@ namespace amc {
 // histogram of the chain positions over half-open bins [lo + i w, lo + (i+1) w), i < n_bins, with
 // bin = floor((x - lo) * inv_w) in this exact f64 form; counts[n_bins..n_bins+2] = below lo, >= hi, NaN.
 // Per-block LDS histogram (u32 LDS atomics), flushed with one u64 global atomic per non-empty bin.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel(const double* x, int64_t n_chains, double lo, double hi,
                                                                double inv_w, int n_bins, unsigned long long* counts)
 {
@@ -41,6 +42,7 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void histogram_kernel
     for (int i = threadIdx.x; i < n_bins + 3; i += AMC_BLOCK)
         if (s_hist[i]) atomicAdd(&counts[i], (unsigned long long)s_hist[i]);
 }
+#endif
 
 // e[c] = potential(x[c]) (Particle.e, particle_1d.jl:13-15,33) for amc_download_state when the host cannot
 // evaluate the potential itself (POT_CUSTOM).
@@ -57,27 +59,34 @@ __global__ __launch_bounds__(AMC_BLOCK) void energy_kernel(const real_t* x, int6
 // Float32 state (AMC_STATE_F32 builds only): the C ABI moves positions as doubles whatever the state type, so uploads
 // are narrowed (T(x), round to nearest even -- what Particle(Float32(x), ...) does) and downloads widened (exact).
 // The kernels that only READ positions for host-side consumers (histogram, strided snapshots) run on the widened copy.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void narrow_state_kernel(const double* in, int64_t n, real_t* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (real_t)in[i];
 }
+#endif
 
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void widen_state_kernel(const real_t* in, int64_t n, double* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < n; i += gs) out[i] = (double)in[i];
 }
+#endif
 
 // Strided snapshot: out[i] = x[first + i*stride] (binary stand-in for a subset of trajectory files).
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void gather_strided_kernel(const double* x, int64_t first, int64_t stride,
                                                                     int64_t count, double* out)
 {
     const int64_t gs = (int64_t)gridDim.x * AMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * AMC_BLOCK + threadIdx.x; i < count; i += gs) out[i] = x[first + i * stride];
 }
+#endif
 
 // Parity-test hooks (amc_selftest_*): the arithmetic-spec primitives, one value per thread.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void selftest_math_kernel(int fn, const double* a, const double* b, double* out, int64_t n)
 {
     __shared__ double s_math[TAB_DOUBLES];
@@ -119,10 +128,12 @@ AMC_KERNEL_LINKAGE __global__ void selftest_math_kernel(int fn, const double* a,
     }
     out[i] = r;
 }
+#endif
 
 // Exhaustive check of the accept filter's float estimate (accept_filter): for EVERY float t with bit pattern in
 // [bits_lo, bits_hi] the relative deviation of v_exp_f32(max(t, -17) * log2e) from the spec's f64 exp(t); the maximum
 // over the range lands in out_max_bits (bits of a non-negative double compare like integers).
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(256) void selftest_filter_kernel(uint32_t bits_lo, uint64_t count, unsigned long long* out_max_bits)
 {
     __shared__ double s_math[TAB_DOUBLES];
@@ -142,11 +153,13 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(256) void selftest_filter_kernel
     }
     if ((threadIdx.x & 63) == 0) atomicMax(out_max_bits, (unsigned long long)__double_as_longlong(worst));
 }
+#endif
 
 // The wave-total primitives (wave_total_i64 by folding, wave_max_u32) on one wave's worth of arbitrary lane values: in is
 // [6][64] 64-bit integers; out[0..5] the six totals through wave_total_i64<6>, out[6..7] two of them through <2>, out[8..10]
 // three through <3>, out[11] one through <1>, out[12] wave_max_u32 of the low words of row 0; ref[0..5] the totals by the plain
 // DPP form of round 4.  The host compares both with its own sums.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(64) void selftest_wave_totals_kernel(const long long* in, long long* out, long long* ref)
 {
     const int lane = threadIdx.x & 63;
@@ -169,7 +182,9 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(64) void selftest_wave_totals_ke
         out[12] = (long long)m;
     }
 }
+#endif
 
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void selftest_philox_kernel(uint32_t key0, uint32_t key1, const uint64_t* pair, const uint64_t* t,
                                        uint32_t draw, uint32_t stream, uint32_t* out4, int64_t n)
 {
@@ -178,4 +193,5 @@ AMC_KERNEL_LINKAGE __global__ void selftest_philox_kernel(uint32_t key0, uint32_
     const u32x4 v = philox4x32_10(draw_counter(pair[i], t[i], draw, stream), key0, key1);
     out4[4 * i + 0] = v.x; out4[4 * i + 1] = v.y; out4[4 * i + 2] = v.z; out4[4 * i + 3] = v.w;
 }
+#endif
 }  // namespace amc

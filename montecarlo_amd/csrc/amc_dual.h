@@ -10,7 +10,7 @@
 // NULL there) takes this route; hand-written derivatives, where given, are used as given.
 //
 // The rules are ForwardDiff 0.10's (src/dual.jl, src/partials.jl; DiffRules for log), written out so that the oracle's twin
-// (tests/oracle_lib.py, its own implementation) and this header perform the same IEEE operations in the same order:
+// (the test suite's CPU restatement, its own implementation) and this header perform the same IEEE operations in the same order:
 //   x + y, x - y, -x     componentwise
 //   x * y                (vx * vy,  (vy * px_i) + (vx * py_i))                       _mul_partials(px, py, vy, vx)
 //   x * c, c * x         (vx * c,   px_i * c)

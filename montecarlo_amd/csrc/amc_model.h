@@ -22,6 +22,11 @@ enum { POT_HARMONIC = 0, POT_DOUBLE_WELL = 1, POT_CUSTOM = 2 };
 // Linkage of the kernels that are no templates.  The header is compiled into more than one object (amc_pg_fused.hip holds some
 // instantiations of pg_estimate_kernel, built with other code-generation options); an object that only wants template
 // instantiations defines this as `static` and, not using them, emits none of these kernels.
+// AMC_PLAIN_KERNELS 0 (the run-time compiler, building ONE template instantiation): the headers' plain kernels -- initial ensemble,
+// parameter tables, accumulate / update, selftest hooks, some 9 000 instructions of ISA -- are left out of the translation unit
+#ifndef AMC_PLAIN_KERNELS
+#define AMC_PLAIN_KERNELS 1
+#endif
 #ifndef AMC_KERNEL_LINKAGE
 #define AMC_KERNEL_LINKAGE
 #endif

@@ -8,6 +8,7 @@
 namespace amc {
 
 // K0: synthetic initial ensemble, x_c = lo + (hi-lo)*u (MC_harmonic_oscillator.jl:13).
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_kernel(double* x, int64_t n_chains, uint64_t pair0,
                                                                   uint32_t key0, uint32_t key1, double lo,
                                                                   double hi)
@@ -22,6 +23,7 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void init_uniform_ker
         if (2 * p + 1 < n_chains) x[2 * p + 1] = x1;
     }
 }
+#endif
 
 // Derived per-move parameters, computed ON DEVICE so the arithmetic is the kernel's.
 // den = 2*(s*s); logc = log(2pi*(s*s))/2 (particle_1d.jl:53); cum = running sum of
@@ -75,16 +77,19 @@ __device__ __forceinline__ void prepare_params(double* ptab, int n_moves)
     }
 }
 
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void prepare_params_kernel(double* ptab, int n_moves)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     prepare_params(ptab, n_moves);
 }
+#endif
 
 // The move-pick table (see AMC_PICK_CELLS): cell c covers the pick uniforms r in [c, c+1) 2^-12 (both ends exact).
 // The walk's count #(cum[i] <= r), i < K-1, is monotone in r, so it is the same for every r of the cell iff it is the
 // same at the two ends: #(cum[i] <= c 2^-12) == #(cum[i] < (c+1) 2^-12).  Launched after prepare_params (same stream)
 // whenever the weights change.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void prepare_pick_kernel(const double* ptab, int n_moves, uint8_t* pick_tab)
 {
     const int c = (int)(blockIdx.x * AMC_BLOCK + threadIdx.x);
@@ -98,6 +103,7 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void prepare_pick_ker
     }
     pick_tab[c] = (n_lo == n_hi) ? (uint8_t)n_lo : (uint8_t)AMC_PICK_OPEN;
 }
+#endif
 
 // ---- device-resident policy-gradient bookkeeping (src/PolicyGuided/estimator.jl:130-131, update.jl:50-57) ----
 struct PgIds { int32_t v[AMC_MAX_LEARN]; };
@@ -179,9 +185,11 @@ __device__ __forceinline__ void pg_update_all(double* ptab, double* acc, int n_l
     }
 }
 
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_update_kernel(double* ptab, double* acc, int n_learn, PgIds ids, PgOpts opt, int n_moves, int* status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status);
 }
+#endif
 }  // namespace amc

@@ -54,10 +54,12 @@ struct PgArgs {
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has
 // to outlive the call and launches already queued keep reading the old record until they are done.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_tail_store_kernel(PgTail value, PgTail* dst)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
 }
+#endif
 
 enum { PG_GROUP = 64 };           // blocks per first-level group of the in-kernel final reduction
 
@@ -264,6 +266,7 @@ __device__ __forceinline__ void pg_merge_slots(const double* recs, int n_ranks, 
     }
 }
 
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* recs, int n_ranks, int n_learn, PgIds ids, double n_samples, double* acc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -271,10 +274,12 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_kernel(const double* recs, int 
     pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
     for (int l = 0; l < n_learn; ++l) pg_accumulate_one(vals, l, ids.v[l], n_samples, acc);
 }
+#endif
 
 // Both in one launch, for shards connected by a communicator: what follows the in-place all-reduce of the estimator's sums
 // when the time step also updates (estimator.jl:130, then update.jl:50-57) -- one tiny launch on the critical path instead of two.
 // theta_used: see pg_update_all (the ring slot of the launch before, or nullptr)
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* recs, int n_ranks, double* ptab, double* acc, int n_learn, PgIds ids,
                                                               double n_samples, PgOpts opt, int n_moves, int* status, const double* theta_used)
 {
@@ -283,6 +288,7 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_update_kernel(const double* rec
     pg_merge_slots(recs, n_ranks, n_learn * 4, vals);
     pg_update_all(ptab, acc, n_learn, ids.v, opt, n_moves, status, vals, n_samples, theta_used);
 }
+#endif
 
 // ---- policies with several parameters (handles of amc_create_vector_policy_model with n_params > 1) ----
 // gradients_data of a move: [j, grad j [P], grad logq_forward [P], g [P][P] row by row, n] -- GradientData, gradients.jl:41-61 --
@@ -306,6 +312,7 @@ __host__ __device__ inline void pg_np_unpack(const double* vals, int np, double*
 }
 
 // gradients_data[k] = gradients_data[k] + gd (estimator.jl:130) for the move lid: recs[n_ranks][columns][XS_WORDS]
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_accumulate_np_kernel(const double* recs, int n_ranks, int np, int lid, double n_samples, double* acc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -316,6 +323,7 @@ AMC_KERNEL_LINKAGE __global__ void pg_accumulate_np_kernel(const double* recs, i
     for (int i = 0; i < 1 + 2 * np + np * np; ++i) a[i] += gd[i];
     a[1 + 2 * np + np * np] += n_samples;
 }
+#endif
 
 // inv(A) of a P x P matrix, P <= 4, by Gauss-Jordan elimination with partial pivoting (rows swapped for the largest |pivot| of
 // the column, the first of equals), in this exact order of operations -- the tests' CPU restatement is the same sequence.
@@ -400,6 +408,7 @@ __host__ __device__ inline bool pg_learning_step_np(int kind, double h0, double 
 // make_step!(::PolicyGradientUpdate) (update.jl:50-57) for the move lid of a pool whose policy has np parameters: average
 // (gradients.jl:83-85), learning_step!, initialise_gradient_data.  A step that leaves a parameter non-finite (or meets a
 // singular metric) is not applied; status[0] is set instead.
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ void pg_update_np_kernel(double* ptab, double* acc, int np, int lid, int kind, double h0, double h1, int* status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -418,6 +427,7 @@ AMC_KERNEL_LINKAGE __global__ void pg_update_np_kernel(double* ptab, double* acc
     else
         status[0] = 1;
 }
+#endif
 
 // The same two steps at the end of the estimator launch of such a policy (one learnable move per launch: pg_estimate_kernel's
 // tail, one thread): gradients_data[lid] += gd from the launch's column totals `vals` (estimator.jl:130) and, with `update`,
@@ -597,6 +607,7 @@ __device__ __forceinline__ void pg_apply_pending(const PgTail* tl, int pending, 
 
 // Brings the parameter table up to date with a pending step (one block; the host launches it before anything but the next fused
 // time step reads sigma).
+#if AMC_PLAIN_KERNELS
 AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void pg_resolve_kernel(const PgTail* tl, int pending, int prev, int prev_groups, int n_learn)
 {
     __shared__ double s_val[AMC_MAX_LEARN * 4];
@@ -610,4 +621,5 @@ AMC_KERNEL_LINKAGE __global__ __launch_bounds__(AMC_BLOCK) void pg_resolve_kerne
             prepare_move_params(tl->ptab_rw, k, s_def[l][DEF_SIGMA]);
         }
 }
+#endif
 }  // namespace amc

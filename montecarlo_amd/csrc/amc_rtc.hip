@@ -441,6 +441,10 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     const std::string expr_full = expr_in.substr(f32 ? 1 : 0);
     std::string expr = expr_full;
     std::string src;
+    // a template instantiation is all this translation unit is asked for: the headers' plain kernels (initial ensemble, parameter
+    // tables, accumulate / update, the selftest hooks: ~9 000 instructions of ISA) stay out of it.  (The two plain kernels that ARE
+    // built at run time, for Float32 state, are asked for by name: those builds keep them.)
+    if (inst.find('<') != std::string::npos) src += "#define AMC_PLAIN_KERNELS 0\n";
     if (f32) src += "#define AMC_STATE_F32 1\n";
     if (std::getenv("AMC_NO_SIGMA_MEMO")) src += "#define AMC_NO_SIGMA_MEMO 1\n";      // A/B: amc_log(sigma) per lane and step in K > 1 sweeps (amc_model.h SigmaArg)
     auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
