@@ -29,18 +29,24 @@ class SocketStore:
 
     On the wire: fixed binary frames (`_pack_request` / `_pack_reply`: an operation byte, a UTF-8 key, a value that is absent,
     raw bytes or an integer), at most MAX_FRAME bytes each -- nothing either side receives is ever unpickled or evaluated, and
-    the server stores values as opaque bytes.  Both ends first prove that they belong to the same launch: the server's greeting
-    and the client's answer are SHA-256 digests over a launch token (AMC_STORE_TOKEN, else what the launcher hands every worker of
-    one launch: run id, restart count, world size, port -- and the launcher's pid when the store is local), so a stale server of
-    an earlier run, or a stranger who reaches the port, is neither served nor mistaken for the store.
+    the server stores values as opaque bytes.  Both ends first prove that they belong to the same launch, by challenge and
+    response: the server greets with a fresh nonce; the client answers with a nonce of its own and HMAC-SHA256(token, "client" |
+    both nonces); the server checks it and answers HMAC(token, "server" | both nonces), which the client checks -- so a stale
+    server of an earlier run, or a stranger who reaches the port, is neither served nor mistaken for the store, and nothing that
+    is ever sent is a fixed function of the token.  The token: AMC_STORE_TOKEN, else what the launcher hands every worker of one
+    launch (run id, restart count, world size, port -- and, under torch.distributed.run on one host, the launcher's pid).
     Where it listens: AMC_STORE_BIND if set; 127.0.0.1 when MASTER_ADDR is this host's loopback (one node is the whole machine
-    for this path: nothing off the host can connect); every interface otherwise (ranks on other nodes must reach it)."""
+    for this path: nothing off the host can connect); every interface otherwise (ranks on other nodes must reach it) -- and
+    then only with a secret: without AMC_STORE_TOKEN a store that strangers can reach refuses to start (the derived token is
+    no secret: every part of it can be guessed)."""
 
     # Where the store may sit, relative to the port asked for: the first of these that rank 0 can bind.  Clients walk the same
     # list and know their server by its greeting, so a foreign service that happens to own MASTER_PORT + 1 neither stops the run
     # nor gets mistaken for the store.
     PORT_OFFSETS = (0, 100, 202, 1008, 2006)
-    MAGIC = "amc-socket-store-2"
+    MAGIC = "amc-socket-store-3"
+    NONCE_HEX = 32                       # characters of a nonce on the wire
+    MAC_HEX = 64                         # ... of an HMAC-SHA256
     MAX_FRAME = 1 << 20                  # bytes: the store carries ids, flags and a few dozen doubles
 
     @staticmethod
@@ -50,9 +56,9 @@ class SocketStore:
             return explicit.encode()
         parts = [os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("TORCHELASTIC_RESTART_COUNT", ""),
                  os.environ.get("WORLD_SIZE", ""), str(int(port))]
-        if _is_loopback(host):
-            parts.append(str(os.getppid()))      # the workers of one local launch share their launcher
-        return "/".join(parts).encode()
+        if _is_loopback(host) and os.environ.get("TORCHELASTIC_RUN_ID"):
+            parts.append(str(os.getppid()))      # the workers of one local launch share their launcher (ranks started by hand,
+        return "/".join(parts).encode()          # from different shells, do not: no pid in their token)
 
     def __init__(self, host: str, port: int, is_master: bool, timeout_s: float = 600.0, token: Optional[bytes] = None):
         import errno
@@ -62,16 +68,19 @@ class SocketStore:
         import time
         self._timeout = float(timeout_s)
         self._lock = threading.Lock()
-        token = self.launch_token(host, port) if token is None else bytes(token)
-        digest = lambda who: hashlib.sha256(who + b"\0" + token).hexdigest().encode()
-        self._hello = f"{self.MAGIC} {int(port)} ".encode() + digest(b"server") + b"\n"
-        self._answer = digest(b"client") + b"\n"
+        self._token = self.launch_token(host, port) if token is None else bytes(token)
+        self._hello_head = f"{self.MAGIC} {int(port)} ".encode()          # + the connection's nonce + newline
         if is_master:
             self._data = {}
             self._cond = threading.Condition()
             bind_host = os.environ.get("AMC_STORE_BIND")
             if bind_host is None:
                 bind_host = "127.0.0.1" if _is_loopback(host) else ""
+            if (bind_host == "" or not _is_loopback(bind_host)) and not os.environ.get("AMC_STORE_TOKEN") and token is None:
+                raise OSError(f"SocketStore: asked to listen on {bind_host or 'every interface'} (MASTER_ADDR={host}) without "
+                              f"AMC_STORE_TOKEN: the token derived from the launch's environment is guessable, so a store that "
+                              f"other hosts can reach needs a secret -- export AMC_STORE_TOKEN=<random string> on every rank, "
+                              f"or use MASTER_ADDR=127.0.0.1 on one node")
             srv, last = None, None
             for off in self.PORT_OFFSETS:
                 cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -105,8 +114,7 @@ class SocketStore:
                     continue
                 try:
                     sk.settimeout(3.0)
-                    if _recv_exactly(sk, len(self._hello)) == self._hello:      # our store of THIS launch, not whoever else listens there
-                        sk.sendall(self._answer)
+                    if self._handshake_as_client(sk):      # our store of THIS launch, not whoever else listens there
                         self._sock = sk
                         break
                 except Exception:
@@ -114,10 +122,33 @@ class SocketStore:
                 sk.close()
             if self._sock is None:
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"no SocketStore at {host}:{port} (+{list(self.PORT_OFFSETS)}) after {self._timeout:.0f} s")
+                    raise TimeoutError(
+                        f"no SocketStore of this launch at {host}:{port} (+{list(self.PORT_OFFSETS)}) after {self._timeout:.0f} s: either rank 0 "
+                        f"never served one, or one answers there that does not hold this rank's token.  The token is AMC_STORE_TOKEN if set "
+                        f"({'set' if os.environ.get('AMC_STORE_TOKEN') else 'not set'} here), else TORCHELASTIC_RUN_ID / restart count / WORLD_SIZE / "
+                        f"port (and the launcher's pid under torch.distributed.run): ranks started by hand must agree on all of them -- or "
+                        f"export the same AMC_STORE_TOKEN on every rank")
                 time.sleep(0.05)
         self._sock.settimeout(self._timeout)
         self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+
+    def _mac(self, who: bytes, server_nonce: bytes, client_nonce: bytes) -> bytes:
+        import hashlib
+        import hmac
+        return hmac.new(self._token, who + b"\0" + server_nonce + b"\0" + client_nonce, hashlib.sha256).hexdigest().encode()
+
+    def _handshake_as_client(self, sk) -> bool:
+        """Greeting with the server's nonce in; our nonce and HMAC out; the server's HMAC in.  True: this is our launch's store."""
+        import hmac
+        import secrets
+        hello = _recv_exactly(sk, len(self._hello_head) + self.NONCE_HEX + 1)
+        if hello is None or not hello.startswith(self._hello_head) or not hello.endswith(b"\n"):
+            return False
+        server_nonce = hello[len(self._hello_head):-1]
+        client_nonce = secrets.token_hex(self.NONCE_HEX // 2).encode()
+        sk.sendall(client_nonce + self._mac(b"client", server_nonce, client_nonce) + b"\n")
+        proof = _recv_exactly(sk, self.MAC_HEX + 1)
+        return proof is not None and hmac.compare_digest(proof, self._mac(b"server", server_nonce, client_nonce) + b"\n")
 
     # ---- server side (rank 0) ----
     def _serve(self) -> None:
@@ -153,11 +184,17 @@ class SocketStore:
         import socket
         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         try:
+            import secrets
             conn.settimeout(10.0)
-            conn.sendall(self._hello)                 # the greeting clients know their store by
-            answer = _recv_exactly(conn, len(self._answer))
-            if answer is None or not hmac.compare_digest(answer, self._answer):
+            server_nonce = secrets.token_hex(self.NONCE_HEX // 2).encode()
+            conn.sendall(self._hello_head + server_nonce + b"\n")          # the challenge; nothing about the token yet
+            answer = _recv_exactly(conn, self.NONCE_HEX + self.MAC_HEX + 1)
+            if answer is None or not answer.endswith(b"\n"):
+                return
+            client_nonce, mac = answer[:self.NONCE_HEX], answer[self.NONCE_HEX:-1]
+            if not hmac.compare_digest(mac, self._mac(b"client", server_nonce, client_nonce)):
                 return                                # not a rank of this launch: nothing of it is parsed, nothing served
+            conn.sendall(self._mac(b"server", server_nonce, client_nonce) + b"\n")        # ... and the proof that WE hold the token
             conn.settimeout(None)
             while True:
                 req = _recv_frame(conn, self.MAX_FRAME)

@@ -184,6 +184,80 @@ def test_socket_store_serves_its_own_launch_only(tmp_path):
     master._srv.close()
 
 
+def test_socket_store_handshake_is_a_challenge_and_a_response(monkeypatch):
+    """Nothing on the wire is a fixed function of the token: the server greets with a fresh nonce, the client answers with its own
+    nonce and an HMAC over both, the server proves itself the same way.  A stranger who connects learns a nonce and nothing to
+    brute-force offline; a replay of an honest client's answer on another connection fails (another nonce); an impostor server
+    that cannot prove the token is passed by.  A store other hosts can reach refuses to start without AMC_STORE_TOKEN, and the
+    timeout of a rank that cannot find its store says what the token is made of."""
+    import hashlib
+    import hmac
+    import threading
+    from montecarlo_amd import sharding as S
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    master = S.SocketStore("127.0.0.1", port, is_master=True, timeout_s=20.0, token=b"launch-A")
+    head = f"{S.SocketStore.MAGIC} {port} ".encode()
+    greetings = []
+    for _ in range(2):
+        raw = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+        raw.settimeout(5.0)
+        g = raw.recv(4096)
+        assert g.startswith(head) and g.endswith(b"\n") and len(g) == len(head) + 33
+        greetings.append((raw, g[len(head):-1]))
+    assert greetings[0][1] != greetings[1][1]                                   # a nonce per connection
+    token_digests = [hashlib.sha256(w + b"\0launch-A").hexdigest().encode() for w in (b"server", b"client")]
+    assert all(d not in g for d in token_digests for _, g in greetings)           # (what round 5's greeting was)
+    # an honest answer for connection 0 ...
+    sn0, cn = greetings[0][1], b"0123456789abcdef0123456789abcdef"
+    mac0 = hmac.new(b"launch-A", b"client\0" + sn0 + b"\0" + cn, hashlib.sha256).hexdigest().encode()
+    # ... replayed on connection 1 is refused: dropped without a proof
+    greetings[1][0].sendall(cn + mac0 + b"\n")
+    try:
+        assert greetings[1][0].recv(128) == b""
+    except ConnectionResetError:
+        pass
+    # on its own connection it is accepted, and the server proves that it holds the token too
+    greetings[0][0].sendall(cn + mac0 + b"\n")
+    proof = greetings[0][0].recv(128)
+    assert proof == hmac.new(b"launch-A", b"server\0" + sn0 + b"\0" + cn, hashlib.sha256).hexdigest().encode() + b"\n"
+    for raw, _ in greetings:
+        raw.close()
+    master._srv.close()
+    # an impostor that speaks the greeting but cannot prove the token: the client does not take it for the store
+    imp = socket.socket()
+    imp.bind(("127.0.0.1", 0))
+    imp.listen(8)
+    iport = imp.getsockname()[1]
+
+    def impostor():
+        try:
+            while True:
+                c, _ = imp.accept()
+                c.sendall(f"{S.SocketStore.MAGIC} {iport} ".encode() + b"f" * 32 + b"\n")
+                c.recv(4096)
+                c.sendall(b"0" * 64 + b"\n")
+                c.close()
+        except OSError:
+            pass
+    threading.Thread(target=impostor, daemon=True).start()
+    monkeypatch.delenv("AMC_STORE_TOKEN", raising=False)
+    with pytest.raises(TimeoutError, match="AMC_STORE_TOKEN") as ei:
+        S.SocketStore("127.0.0.1", iport, is_master=False, timeout_s=0.6, token=b"launch-A")
+    assert "TORCHELASTIC_RUN_ID" in str(ei.value) and "WORLD_SIZE" in str(ei.value)
+    imp.close()
+    # reachable from other hosts: only with a secret
+    with pytest.raises(OSError, match="without AMC_STORE_TOKEN"):
+        S.SocketStore("10.255.255.1", port, is_master=True, timeout_s=0.5)
+    # ranks started by hand (no launcher's run id) do not mix the parent's pid into the token; under the launcher they do
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert S.SocketStore.launch_token("127.0.0.1", 29500) == b"//2/29500"
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    assert S.SocketStore.launch_token("127.0.0.1", 29500) == f"none//2/29500/{os.getppid()}".encode()
+
+
 def test_store_values_are_plain_data():
     """What the ranks exchange through the store is a closed set of plain types in a tagged binary form -- round trip, and no
     way in for objects."""
