@@ -2,6 +2,11 @@
 // with the in-kernel fold, gradients_data +=, and learning_step! in its tail.
 // Part of the kernel sources of the many-chain Metropolis engine (gfx950 / CDNA4); amc_kernels.h includes all of them, in order.
 #pragma once
+// script-defined forms (run-time compiled): the waves per SIMD the register allocator is held to (amdgpu_waves_per_eu); the run-time
+// compiler sets it (amc_rtc.hip; AMC_RTC_WAVES in the environment is the A/B knob), 1 = no constraint
+#ifndef AMC_RTC_WAVES
+#define AMC_RTC_WAVES 1
+#endif
 
 #include "amc_pg_tail.h"
 
@@ -23,7 +28,7 @@ template <int POT, int NL, bool BETA, int SWEEP = 0, int REDUCE = RED_FORM_NONE,
 // waves per SIMD allow; held to 96 it spills ONE register outside the loop and the launch runs on five resident blocks per CU instead
 // of four: 69.9 -> 67.2 us at 1e7 chains, same-box A/B.  The same squeeze on the K = 2 sweep with sums, 81 -> 80 VGPRs for six waves,
 // costs a microsecond instead: profiles/r05_reduce_occupancy_ab.txt.)
-__global__ __launch_bounds__(AMC_BLOCK) __attribute__((amdgpu_waves_per_eu((REDUCE == RED_FORM_E && SWEEP != 0 && PgKind<POT>::Q) ? 5 : 1)))
+__global__ __launch_bounds__(AMC_BLOCK) __attribute__((amdgpu_waves_per_eu((REDUCE == RED_FORM_E && SWEEP != 0 && PgKind<POT>::Q) ? 5 : (PgKind<POT>::Q ? 1 : AMC_RTC_WAVES))))
 void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 {
     static_assert(!REDUCE || SWEEP != 0, "the callback sums ride on the fused time step");

@@ -374,7 +374,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
 {
     std::lock_guard<std::mutex> lock(g_rtc_mu);
     const std::string key = arch + "\n" + expr_in + "\n" + inst + (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? "\nno-gauss-rows" : "") +
-                            (std::getenv("AMC_NO_SIGMA_MEMO") ? "\nno-sigma-memo" : "");
+                            (std::getenv("AMC_NO_SIGMA_MEMO") ? "\nno-sigma-memo" : "") +
+                            (std::getenv("AMC_RTC_WAVES") ? std::string("\nwaves") + std::getenv("AMC_RTC_WAVES") : std::string());
     auto it = g_rtc_code.find(key);
     if (it != g_rtc_code.end()) { *out = &it->second; return AMC_OK; }
     {
@@ -413,7 +414,8 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     const std::string cache_file = rtc_cache_path(expr_in, inst, arch, "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                                                            (licm_off ? " licm-off" : "") +
                                                                            (std::getenv("AMC_NO_GAUSS_CLASS_ROWS") ? " no-gauss-rows" : "") +
-                                                                           (std::getenv("AMC_NO_SIGMA_MEMO") ? " no-sigma-memo" : ""));
+                                                                           (std::getenv("AMC_NO_SIGMA_MEMO") ? " no-sigma-memo" : "") +
+                                                                           (std::getenv("AMC_RTC_WAVES") ? std::string(" waves") + std::getenv("AMC_RTC_WAVES") : std::string()));
     {
         RtcCode cached;
         if (rtc_cache_load(cache_file, &cached)) {
@@ -447,6 +449,7 @@ int rtc_compile(const std::string& expr_in, const std::string& inst, const std::
     if (inst.find('<') != std::string::npos) src += "#define AMC_PLAIN_KERNELS 0\n";
     if (f32) src += "#define AMC_STATE_F32 1\n";
     if (std::getenv("AMC_NO_SIGMA_MEMO")) src += "#define AMC_NO_SIGMA_MEMO 1\n";      // A/B: amc_log(sigma) per lane and step in K > 1 sweeps (amc_model.h SigmaArg)
+    if (const char* w = std::getenv("AMC_RTC_WAVES")) src += "#define AMC_RTC_WAVES " + std::to_string(std::atoi(w)) + "\n";       // A/B: amdgpu_waves_per_eu of the script-defined estimator forms
     auto cut_tail = [&](char mark) -> std::string {      // removes and returns what follows the LAST section mark
         const size_t at = expr.find(mark);
         if (at == std::string::npos) return std::string();

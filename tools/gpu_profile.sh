@@ -3,7 +3,7 @@
 # PMC passes (own runs, counters only) of bench.py and of the workloads of tools/gpu_workload.py; tools/summarize_profiles.py
 # turns what lands in gpurun_out/$TAG/ into the files to commit under profiles/ ($TAG_*; TAG = AMC_ROUND_TAG, default r05).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${AMC_ROUND_TAG:-r05}
+TAG=${AMC_ROUND_TAG:-r06}
 export AMC_ROUND_TAG=$TAG
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
@@ -15,6 +15,8 @@ echo "bench done"
 rocprofv3 --kernel-trace --stats -d $O/bench_trace --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-ladder > $O/bench_prof.json 2> $O/bench_prof.err
 echo "bench trace done"
 W="python3 $R/tools/gpu_workload.py"
+export AMC_RTC_CACHE_DIR=$O/rtc_cache; mkdir -p $AMC_RTC_CACHE_DIR      # the script-defined workloads build once, outside the profiled runs
+for wl in vec1 vec mixed; do python3 $R/tools/gpu_workload.py $wl > /dev/null 2>&1; done
 export PIPELINED=1      # callbacks read one period late, as the host mirror's StoreCallbacks does; the at-once figure is logged next to it
 # k2 / pgmc: BASELINE configs 3 / 5 (callbacks every 10 ask for sum e: COLS=1, the callbacks of those configs); vec1 / vec / mixed: the PGMC
 # time step of a script-defined one-parameter policy, of the two-parameter drift + width policy, of a two-class pool (round 5)

@@ -20,7 +20,9 @@ os.environ["AMC_MODEL_CHECK_INST"] = inst
 from montecarlo_amd import _capi as A
 kw = {"vec": dict(sample=DRIFT[0], logq=DRIFT[1], dlogq=DRIFT[2], n_params=2), "vec_auto": dict(sample=DRIFT[0], logq=DRIFT[1], n_params=2),
       "vec1": dict(sample=GAUSS[0], logq=GAUSS[1], dlogq=GAUSS[2]), "vec1_auto": dict(sample=GAUSS[0], logq=GAUSS[1]),
-      "mala": dict(sample=MALA[0], logq=MALA[1], dlogq=MALA[2])}[wl]
+      "mala": dict(sample=MALA[0], logq=MALA[1], dlogq=MALA[2]),
+      "mixed": dict(sample=[GAUSS[0], MALA[0]], logq=[GAUSS[1], MALA[1]], dlogq=[GAUSS[2], MALA[2]]),
+      "mixed_auto": dict(sample=[GAUSS[0], MALA[0]], logq=[GAUSS[1], MALA[1]], dlogq=[GAUSS[2], None])}[wl]
 A.model_check(**kw)
 f = glob.glob(os.path.join(cache, "*.bin"))[0]
 raw = open(f, "rb").read()

@@ -13,7 +13,7 @@
 """
 import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("AMC_ROUND_TAG", "r05")
+TAG = os.environ.get("AMC_ROUND_TAG", "r06")
 G = os.path.join(ROOT, "gpurun_out", TAG)
 OUT = os.environ.get("AMC_PROFILE_OUT", os.path.join(ROOT, "profiles"))       # on the GPU box: a directory under gpurun_out/
 os.makedirs(OUT, exist_ok=True)
@@ -25,7 +25,8 @@ MAIN = {"ladder": "sweep_kernel<0, false, 0, false, true, 0>", "k2": "sweep_kern
         # hiprtc forms (POT_CUSTOM = 2 names the script-defined family): the fused time step of the one- / two-parameter script
         # policy, the per-move estimator launch of the two-class pool
         "vec1": "pg_estimate_kernel<2, 1, false, 1, 0, false>", "vec": "pg_estimate_kernel<2, 1, false, 1, 0, false>",
-        "mixed": "pg_estimate_kernel<2, 1, false, 0, 0, false>"}
+        # round 6: the class pool's time step is ONE launch (every learnable move, the sweep in front)
+        "mixed": "pg_estimate_kernel<2, 2, false, 2, 0, false>"}
 
 
 def one(pattern):
