@@ -142,7 +142,8 @@ end
 const GAUSS_CLASS = ("sigma*z", "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0",
                      "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma", nothing, nothing)
 
-# proposal = (sample, logq, dlogq): a script-defined policy as C expressions (amc_create_proposal_model); with a policy of
+# proposal = (sample, logq, dlogq): a script-defined policy as C expressions (amc_create_proposal_model); dlogq may be `nothing`: the
+# engine then differentiates logq itself (dual numbers in the kernel), as ForwardDiff does for the reference (gradients.jl:28-33); with a policy of
 # SEVERAL parameters (Move.parameters of length P > 1) dlogq is the vector of the P partial derivatives and the expressions
 # say theta0 .. theta{P-1} (amc_create_vector_policy_model).
 function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, potential=:harmonic, reward=nothing, scale=nothing,
@@ -173,7 +174,7 @@ function HIPMetropolis(chains; pool=missing, sweepstep=1, seed=1, device=0, pote
             rew = reward isa AbstractString ? reward : C_NULL
             col(i) = Cstring[(c[i] === nothing ? Cstring(C_NULL) : Base.unsafe_convert(Cstring, Base.cconvert(Cstring, c[i]))) for c in classes]
             texts = [String(t) for c in classes for t in c if t !== nothing]          # keeps the strings alive across the call
-            have_d = all(c -> c[3] !== nothing, classes)
+            have_d = any(c -> c[3] !== nothing, classes)          # a class without a derivative expression: the engine differentiates its logq (NULL entry)
             com = Cint[k - 1 for k in class_of_move]
             GC.@preserve texts classes check(ccall((:amc_create_mixed_model, libamc), Cint,
                         (Ref{AmcConfig}, Cint, Ptr{Cint}, Cstring, Cstring, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ref{Ptr{Cvoid}}),
@@ -442,6 +443,39 @@ function pgmc_steps_observed!(metropolis::HIPMetropolis, n::Integer, learn_ids::
     check(ccall((:amc_reduce_end_exact, libamc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{UInt64}), metropolis.handle, records, steps))
     metropolis.red_t = t; metropolis.red = finish_records!(metropolis, records, steps[])
     return nothing
+end
+
+# How an estimator step over `n_learn` learnable moves would run on this handle (amc_pg_route): (one_launch, why).  one_launch:
+# every learnable move in ONE launch -- with `fused`, one launch per whole time step --, as the reference's
+# make_step!(::PolicyGradientEstimator) loops over all of them in one step (estimator.jl:111-134).  false only for a pool of several
+# classes whose several-move kernel form the run-time compiler fails on (`why`: the compiler's last words; the calls then take one
+# launch per move, same bits), and for policies with several parameters and more than one learnable move.
+function pg_route(alg::HIPMetropolis, n_learn::Integer; q_batch::Integer=1, fused::Bool=false)
+    why = zeros(UInt8, 2048)
+    rc = ccall((:amc_pg_route, libamc), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt8}, Cint),
+               alg.handle, n_learn, q_batch, fused ? 1 : 0, why, length(why))
+    rc < 0 && check(rc)
+    return (rc == 1, unsafe_string(pointer(why)))
+end
+
+# Compile-only check of a script-defined policy, without a GPU (amc_model_check): (sample, logq[, dlogq]) as for `proposal=`;
+# dlogq `nothing`: the engine differentiates logq.  Returns the compiler's log; a script that does not compile raises with the
+# first diagnostic, a compiler that dies raises with status -7 (AMC_ERR_COMPILE) -- the Julia session lives either way.
+function model_check(sample::AbstractString, logq::AbstractString, dlogq=nothing; n_params::Integer=1, potential=nothing, reward=nothing)
+    partials = dlogq === nothing ? String[] : dlogq isa AbstractString ? String[dlogq] : collect(String, dlogq)
+    isempty(partials) || length(partials) == n_params || error("model_check: dlogq must list the $n_params partial derivatives of logq")
+    log = zeros(UInt8, 8192)
+    s, l = String[sample], String[logq]
+    GC.@preserve s l partials begin
+        ps = Cstring[Base.unsafe_convert(Cstring, s[1])]
+        pl = Cstring[Base.unsafe_convert(Cstring, l[1])]
+        pd = Cstring[Base.unsafe_convert(Cstring, d) for d in partials]
+        check(ccall((:amc_model_check, libamc), Cint,
+                    (Cint, Cint, Cstring, Cstring, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{Cstring}, Ptr{UInt8}, Cint),
+                    n_params, 1, potential === nothing ? C_NULL : potential, reward === nothing ? C_NULL : reward, ps, pl,
+                    isempty(pd) ? C_NULL : pointer(pd), C_NULL, C_NULL, log, length(log)))
+    end
+    return unsafe_string(pointer(log))
 end
 
 # What the shards' communicator reports about itself (ncclCommCount, ncclCommUserRank, RCCL version, library file); the
