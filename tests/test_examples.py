@@ -57,3 +57,18 @@ def test_mc_example_with_float32_state(gpu, tmp_path, capsys):
     rows = [ln.split() for ln in open(tmp_path / "mc32" / "trajectories" / "1" / "trajectory.dat")]
     assert all(float(np.float32(float(r[1]))) == pytest.approx(float(r[1]), rel=1e-7) and len(r[1]) <= 14 for r in rows)
     assert float(np.float32(float(rows[-1][1]))) == sim.chains.x[0]
+
+
+def test_pgmc_langevin_policy_example(gpu, tmp_path, capsys):
+    """A policy the script defines, no derivative written by hand, in a pool with the built-in Gaussian: the step sizes are learned
+    (the Langevin proposal's grows far beyond the random walk's: its drift keeps the acceptance up), the target distribution is
+    kept, and the pool takes one launch per time step."""
+    import pgmc_langevin_policy as ex
+    sim = ex.main(["--chains", "60000", "--steps", "600", "--path", str(tmp_path / "langevin")])
+    out = capsys.readouterr().out
+    assert "estimator route of this pool: one launch per time step" in out and "the policy compiles" in out
+    pool = sim.algorithms[0].pool
+    sg, sl = float(pool[0].parameters[0]), float(pool[1].parameters[0])
+    assert sg > 0.4 and sl > 0.4 and sg != sl                               # both learnt from 0.3
+    rows = np.loadtxt(tmp_path / "langevin" / "energy.dat", usecols=(0, 1))
+    assert rows[rows[:, 0] >= 300, 1].mean() == pytest.approx(0.25, abs=6e-3)          # <e> = 1 / (2 beta): the sampler stays exact

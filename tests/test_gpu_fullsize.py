@@ -633,8 +633,11 @@ def test_policy_gradient_sums_against_quadrature_at_full_size(gpu, sigma):
     e.close()
 
 
-def test_two_parameter_gradient_sums_against_quadrature_at_full_size(gpu):
-    """The same for a policy with TWO parameters, delta = mu + sigma z (amc_create_vector_policy_model): the proposal is not
+@pytest.mark.parametrize("derivative", ["given", "differentiated"])
+def test_two_parameter_gradient_sums_against_quadrature_at_full_size(gpu, derivative):
+    """(`differentiated`, round 6: the handle is created WITHOUT the partial derivatives -- the engine differentiates logq itself,
+    dual numbers in the kernel, DESIGN.md section 3.11 -- and must meet the same integrals.)
+    The same for a policy with TWO parameters, delta = mu + sigma z (amc_create_vector_policy_model): the proposal is not
     symmetric, log q_b - log q_f = -2 delta mu / sigma^2 enters the acceptance, and with the chains at stationarity
         j / n           -> J(mu, sigma) = E[delta^2 min(1, exp(dlogp + logq_b - logq_f))]
         grad_j / n      -> (dJ/dmu, dJ/dsigma)                 (score-function identity, gradients.jl:106)
@@ -645,7 +648,7 @@ def test_two_parameter_gradient_sums_against_quadrature_at_full_size(gpu):
     logq = "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)"
     dlogq = ["(delta-theta0)/(theta1*theta1)", "((delta-theta0)*(delta-theta0))/(theta1*theta1*theta1) - 1.0/theta1"]
     e = gpu.HipEngine(n_chains=M_FULL, potential="harmonic", beta=beta, sigma=[[mu, sigma]], weight=[1.0], seed=78,
-                      per_chain_counters=False, proposal=(sample, logq, dlogq), n_params=2)
+                      per_chain_counters=False, proposal=(sample, logq, dlogq if derivative == "given" else None), n_params=2)
     e.init_uniform(-2, 2)
     e.sweep(300)
     x = e.download_strided(0, 10, 1_000_000)
