@@ -17,6 +17,9 @@
 #         The one residual: Julia's exp / log differ from the spec's by <= 2 ulp, and a decision `alpha > u` whose two sides
 #         agree to ~1e-16 can fall the other way (expected rate ~4e-16 per update; 8 chains x 256 sweeps: ~1e-12 per case).
 #         A mismatch is reported chain by chain with the sweep window it happened in -- never hidden.
+#         Then the estimator's hook: stock `PolicyGradientEstimator(...; R=PhiloxRNG{seed,2})` on the state the sweeps left meets the
+#         fixture's GradientData sums (to the rounding the two operation orders allow) and leaves the positions of `x_after_pg`,
+#         bit for bit -- with the reference's aliased scratch buffer (SURVEY App. A.6) accounted for, not papered over.
 #   (ii)  `HIPMetropolis` against the same fixtures where libamc.so and a GPU exist (skipped, and said so, elsewhere): the
 #         device path through the Julia binding, bits and counts equal, callbacks equal to the oracle's reproducible sums.
 #   (iii) test/ad_backends_test.jl's closed forms (logq = 0.6904993792294276, d logq / d sigma = -5 at delta = 0,
@@ -132,6 +135,39 @@ end
             # every generator served exactly three draws per MH step: categorical, normal, accept (metropolis.jl:206,
             # particle_1d.jl:57, metropolis.jl:184)
             @test all(rng -> rng.calls == UInt64(3 * 256 * Int(spec["sweepstep"])), metropolis.rngs)
+        end
+        # The estimator's hook (src/PolicyGuided/estimator.jl:63,92): stock PolicyGradientEstimator with R=PhiloxRNG{seed,2} on the
+        # state the sweeps left, every move learnable, q_batch_size = 3 -- the fixture's `pg_estimate_q3` (j, grad j, grad logq, g, n
+        # per move) and `x_after_pg` (every sample leaves x at (x + delta) + (-delta), gradients.jl:98,103).
+        @testset "$name: estimator" begin
+            q = 3
+            estimator = PolicyGradientEstimator(chains; dependencies=(metropolis,), optimisers=Tuple(VPG(1e-3) for _ in 1:K),
+                                                q_batch_size=q, R=PhiloxRNG{seed,2}, parallel=false)
+            @test estimator.learn_ids == collect(1:K) && estimator.rngs[1].chain == UInt64(offset)
+            make_step!(simulation, estimator)                             # estimator step 0 of every generator (est_step = 0)
+            @test samebits([c.x for c in chains], hexfloat.(case["x_after_pg"]))
+            want = reshape(hexfloat.(case["pg_estimate_q3"]), 5, K)       # row-major (K, 5) in the fixture
+            σs = Float64.(spec["sigma"])
+            for k in 1:K
+                gd = estimator.gradients_data[k]
+                @test gd.n == M * q && gd.n == Int(want[5, k])
+                # the summands' operation order differs from the engine's (DESIGN.md 3.6b: <= 64 ulp of j per sample) and the
+                # reference folds left to right where the fixture holds the exactly rounded sum
+                @test isapprox(gd.j, want[1, k]; rtol=1e-12)
+                @test isapprox(gd.∇j[1], want[2, k]; rtol=1e-11, atol=1e-11)
+                @test isapprox(gd.g[1, 1], want[4, k]; rtol=1e-12)
+                # grad logq_forward: the reference hands its shared scratch buffer out inside every sample's GradientData
+                # (gradients.jl:108 with estimator.jl:122), so under foldxl the first sample's array holds the SECOND sample's
+                # gradient by the time the first `+` runs (SURVEY Appendix A.6): its sum is the true one minus d1 plus d2, where
+                # d1, d2 are the gradients of chain 1's first two samples of this move -- formed here from the same draws
+                replay = PhiloxRNG{seed,2}(seed + offset)
+                replay.calls = UInt64((k - 1) * q)
+                d = map(1:2) do _
+                    δ = 0.0 + σs[k] * randn(replay, Float64)
+                    δ^2 / σs[k]^3 - 1 / σs[k]
+                end
+                @test isapprox(gd.∇logq_forward[1], want[3, k] - d[1] + d[2]; rtol=1e-11, atol=1e-11)
+            end
         end
     end
 end

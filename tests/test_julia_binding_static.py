@@ -266,6 +266,9 @@ def test_julia_is_a_package_with_its_tests():
     assert 'include(joinpath(pkgdir(Arianna), "example", "particle_1d", "particle_1d.jl"))' in t
     assert "algorithm=Metropolis" in t and "R=PhiloxRNG{seed,1}" in t and 'GOLDEN["cases"][1:4]' in t
     assert "oracle_trajectories.json" in t and "reference_kats.json" in t
+    # ... and the estimator's hook (estimator.jl:63,92) on the state the sweeps left, the reference's aliased scratch buffer accounted for
+    assert "PolicyGradientEstimator(chains; dependencies=(metropolis,)" in t and "R=PhiloxRNG{seed,2}" in t
+    assert 'case["x_after_pg"]' in t and 'case["pg_estimate_q3"]' in t and "want[3, k] - d[1] + d[2]" in t
     # (ii) the device path through the binding, skipped -- and said so -- without libamc / a GPU
     assert "algorithm=AriannaHIP.HIPMetropolis" in t and "AriannaHIP.available()" in t and "@test_skip" in t
     # (iii) ad_backends closed forms, through amc_selftest_math where a device exists
@@ -283,6 +286,7 @@ def test_julia_is_a_package_with_its_tests():
     for c in golden["cases"][:4]:
         assert c["snapshots"][0]["sweep"] == 0 and {"x", "e", "accepted", "total", "energy", "acceptance"} <= set(c["snapshots"][1])
         assert "dtype" not in c["spec"] and "proposal" not in c["spec"] and "classes" not in c["spec"]      # plain particle_1d
+        assert len(c["pg_estimate_q3"]) == 5 * len(c["spec"]["sigma"]) and len(c["x_after_pg"]) == c["spec"]["M"]
     kats = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))
     assert {"delta", "sigma", "logq", "grad_sigma", "atol"} <= set(kats["ad_backends"])
 
