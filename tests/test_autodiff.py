@@ -204,6 +204,23 @@ def test_pool_of_classes_where_only_some_bring_a_derivative(gpu, oracle):
     assert [a.get_parameters(k)[0] for k in range(4)] == [o.get_parameters(k)[0] for k in range(4)]
     assert np.array_equal(bits(a.download_state()[0]), bits(o.download_state()[0]))
     a.close()
+    # the other way round: class 0 (the unsuffixed expressions) differentiated, class 1 with its own derivative
+    kw2 = dict(n_chains=M, potential="harmonic", beta=BETA, sigma=[0.3, 0.6], weight=[0.5, 0.5], seed=22,
+               classes=[auto(GAUSS), MALA], class_of_move=[0, 1])
+    a, o = gpu.HipEngine(**kw2), oracle.OracleEngine(**kw2)
+    for e in (a, o):
+        e.init_uniform(-2.0, 2.0)
+        e.sweep(6)
+    assert np.array_equal(a.pg_estimate_exact([0, 1], 2), o.pg_estimate_exact([0, 1], 2))
+    assert a.pg_route(2, 2, fused=True)[0]
+    a.pgmc_steps(3, [0, 1], 2, [1, 1], [0.03, 0.02], [0.0, 0.0])
+    for _ in range(3):
+        o.sweep(1)
+        o.pg_accumulate([0, 1], 2)
+        o.pg_update([0, 1], [1, 1], [0.03, 0.02], [0.0, 0.0])
+    assert [a.get_parameters(k)[0] for k in range(2)] == [o.get_parameters(k)[0] for k in range(2)]
+    assert np.array_equal(bits(a.download_state()[0]), bits(o.download_state()[0]))
+    a.close()
     oracle.install_policy_classes(None, None)
 
 
