@@ -271,11 +271,11 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
                     pg_sample_scaled<POT>(xv.x, b0, c_sg[l], z0, s0, s_math);
                     if (v1) pg_sample_scaled<POT>(xv.y, b1, c_sg[l], z1, s1, s_math);
 #endif
+                    // kind R: ONE summand per lane, sample and column -- the chain PAIR's sum fl(s_even + s_odd), as the callback
+                    // sums take theirs (round 6: half the deposits, -7 .. -10 % per script-defined time step)
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) {
-                        r_deposit(gr, QK ? 0 : l * NC + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
-                        r_deposit(gr, QK ? 0 : l * NC + i, s1[i], s_gr[threadIdx.x >> 6]);
-                    }
+                    for (int i = 0; i < NC; ++i)
+                        r_deposit(gr, QK ? 0 : l * NC + i, (v0 ? s0[i] : 0.0) + s1[i], s_gr[threadIdx.x >> 6]);
 #else
                     if (QK) {
                         if (whole_trip) {
@@ -290,10 +290,8 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
                         pg_sample<POT, false>(xv.x, b0, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z0, s0, s_math);
                         if (v1) pg_sample<POT, false>(xv.y, b1, c_sg[l], c_hi[l], c_lo[l], c_c1[l], z1, s1, s_math);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                        r_deposit(gr, QK ? 0 : l * 4 + i, v0 ? s0[i] : 0.0, s_gr[threadIdx.x >> 6]);
-                        r_deposit(gr, QK ? 0 : l * 4 + i, s1[i], s_gr[threadIdx.x >> 6]);
-                    }
+                        for (int i = 0; i < 4; ++i)           // (the pair's sum: one deposit, see above)
+                            r_deposit(gr, QK ? 0 : l * 4 + i, (v0 ? s0[i] : 0.0) + s1[i], s_gr[threadIdx.x >> 6]);
                     }
 #endif
                 }

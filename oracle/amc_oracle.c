@@ -1417,9 +1417,14 @@ void amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int 
         for (int i = 0; i < 4; ++i) col[i] = xs_new(bounded ? XS_Q : XS_R, ex[i]);
         spec_consts_t k = spec_consts(s->sigma[lid]);
         int64_t n = 0;
+        /* Running-top (kind R) columns take ONE summand per chain PAIR, sample and column: fl(s_even + s_odd), the two chains that
+         * share a Box-Muller draw -- as the callback sums take theirs (xs_r_add(se, e0 + e1) above).  `held`: the even chain's
+         * summands of this move, waiting for its partner's (a shard starts on an even global id; a lone last chain adds + 0.0). */
+        double (*held)[4] = (double (*)[4])malloc((size_t)(q_batch > 0 ? q_batch : 1) * sizeof(double[4]));
         for (int64_t c = 0; c < s->M; ++c) {
             uint64_t g = (uint64_t)(s->offset + c);
             int half = (int)(g & 1u);
+            const int last_alone = !half && c + 1 == s->M;
             for (int q = 0; q < q_batch; ++q) {
                 uint32_t v[4];
                 double zz[2];
@@ -1433,7 +1438,11 @@ void amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int 
                     double gd[4];
                     if (s->f32) pgmc_sample_f32(p, m, s->sigma[lid], s->pot, zz[half], gd);
                     else pgmc_sample(p, m, s->sigma[lid], s->pot, zz[half], gd);
-                    for (int i = 0; i < 4; ++i) xs_r_add(&col[i], gd[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        if (!half) held[q][i] = gd[i];
+                        if (half) xs_r_add(&col[i], (c > 0 ? held[q][i] : 0.0) + gd[i]);       /* (c == 0 odd: a shard that starts inside a pair) */
+                        else if (last_alone) xs_r_add(&col[i], gd[i] + 0.0);
+                    }
                 } else {
                     double j, d;
                     if (s->f32) pgmc_sample_spec_f32(p, m, &k, s->pot, zz[half], &j, &d);
@@ -1444,15 +1453,18 @@ void amo_pg_estimate_records(amo_sim *s, int n_learn, const int *learn_ids, int 
                         xs_q_add(&col[2], d);
                         xs_q_add_product(&col[3], d, d);
                     } else {
-                        xs_r_add(&col[0], j);
-                        xs_r_add(&col[1], j * d);
-                        xs_r_add(&col[2], d);
-                        xs_r_add(&col[3], d * d);
+                        const double gd[4] = { j, j * d, d, d * d };
+                        for (int i = 0; i < 4; ++i) {          /* the pair's sum, as above */
+                            if (!half) held[q][i] = gd[i];
+                            if (half) xs_r_add(&col[i], (c > 0 ? held[q][i] : 0.0) + gd[i]);
+                            else if (last_alone) xs_r_add(&col[i], gd[i] + 0.0);
+                        }
                     }
                 }
                 n += 1;
             }
         }
+        free(held);
         for (int i = 0; i < 4; ++i) xs_to_record(&col[i], recs + (size_t)(l * 5 + i) * XS_WORDS);
         xs_t cnt = xs_new(XS_PLAIN, 0);
         cnt.plain = (double)n;
@@ -1541,19 +1553,28 @@ void amo_pg_estimate_records_vec(amo_sim *s, int n_learn, const int *learn_ids, 
         xs_t col[1 + 2 * AMO_MAX_NP + AMO_MAX_NP * AMO_MAX_NP];
         for (int i = 0; i < nf; ++i) col[i] = xs_new(XS_R, 0);
         int64_t n = 0;
+        /* one summand per chain PAIR, sample and field: fl(s_even + s_odd) (see amo_pg_estimate_records) */
+        enum { NF_MAX = 1 + 2 * AMO_MAX_NP + AMO_MAX_NP * AMO_MAX_NP };
+        double (*held)[NF_MAX] = (double (*)[NF_MAX])malloc((size_t)(q_batch > 0 ? q_batch : 1) * sizeof(double[NF_MAX]));
         for (int64_t c = 0; c < s->M; ++c) {
             uint64_t g = (uint64_t)(s->offset + c);
             int half = (int)(g & 1u);
+            const int last_alone = !half && c + 1 == s->M;
             for (int q = 0; q < q_batch; ++q) {
                 uint32_t v[4];
-                double zz[2], gd[1 + 2 * AMO_MAX_NP + AMO_MAX_NP * AMO_MAX_NP];
+                double zz[2], gd[NF_MAX];
                 draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
                 amo_box_muller(v, zz);
                 pgmc_sample_vec(&s->chains[c], &s->pools[c * s->K + lid], th, s->pot, zz[half], gd);
-                for (int i = 0; i < nf; ++i) xs_r_add(&col[i], gd[i]);
+                for (int i = 0; i < nf; ++i) {
+                    if (!half) held[q][i] = gd[i];
+                    if (half) xs_r_add(&col[i], (c > 0 ? held[q][i] : 0.0) + gd[i]);
+                    else if (last_alone) xs_r_add(&col[i], gd[i] + 0.0);
+                }
                 n += 1;
             }
         }
+        free(held);
         for (int i = 0; i < nf; ++i) xs_to_record(&col[i], recs + (size_t)(l * stride + i) * XS_WORDS);
         xs_t cnt = xs_new(XS_PLAIN, 0);
         cnt.plain = (double)n;
