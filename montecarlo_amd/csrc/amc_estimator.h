@@ -273,9 +273,17 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 #endif
                     // kind R: ONE summand per lane, sample and column -- the chain PAIR's sum fl(s_even + s_odd), as the callback
                     // sums take theirs (round 6: half the deposits, -7 .. -10 % per script-defined time step)
+                    // ... and none for a column nobody will read: in a launch whose tail takes the learning step (tail modes 3 / groups:
+                    // gradients_data is consumed and reset there), VPG reads j and grad j alone, BLPG / BLAPG grad logq too, NPG / ANPG
+                    // the metric g -- the host names, per learnable move, the column groups the move's optimiser leaves unread
+                    // (pg_skip_of: wave-uniform, from the launch's arguments)
+                    const int skip = pg_skip_of(a.tail_mode, l);
 #pragma unroll
-                    for (int i = 0; i < NC; ++i)
+                    for (int i = 0; i < NC; ++i) {
+                        if (i > AMC_NP && i <= 2 * AMC_NP && (skip & 1)) continue;          // grad logq_forward [P]
+                        if (i > 2 * AMC_NP && (skip & 2)) continue;                         // g, upper triangle
                         r_deposit(gr, QK ? 0 : l * NC + i, (v0 ? s0[i] : 0.0) + s1[i], s_gr[threadIdx.x >> 6]);
+                    }
 #else
                     if (QK) {
                         if (whole_trip) {

@@ -146,6 +146,7 @@ struct amc_handle {
     std::map<int, int> pg_resident; // resident blocks per CU of the estimator kernel forms, by (nl, sweep, reduce)
     std::map<int, bool> class_form_builds;  // pools of several classes: does the several-move estimator form (nl, sweep, reduce) build? (amc_pg.hip class_general_route)
     std::string class_form_error;   // ... the compiler's last words about the last one that did not (amc_class_route_report)
+    bool no_column_skip = false;    // env AMC_NO_COLUMN_SKIP=1 (A/B, tests): fused script-defined steps sum every GradientData column whatever the optimiser reads
     bool class_per_move_forced = false;     // env AMC_CLASS_PER_MOVE=1 (read at amc_create; A/B, tests): class pools take one estimator launch per learnable move
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]

@@ -268,6 +268,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.key1 = (uint32_t)(h->seed >> 32);
     a.beta = h->beta;
     a.tail_mode = tail;
+    // a script-defined form whose own tail takes the learning step: the column groups the moves' optimisers never read are not summed
+    // (amc_estimator.h; gradients_data is consumed and reset in that tail, so nothing of them could be seen afterwards)
+    if (opt && (tail == 3 || tail == (int)amc::PG_TAIL_GROUPS) && h->use_rtc && !h->no_column_skip) a.tail_mode |= amc::pg_skip_bits(opt->kind, n_learn);
     a.l_base = l_base;
     {
         amc::PgTail tl;

@@ -560,6 +560,20 @@ enum { PG_PARITY_WORDS = PG_GROUP * 32 * XS_ROW_R };      // words of group rows
 __host__ __device__ inline int pg_tail_of(int tail_mode) { return tail_mode & 0xFF; }
 __host__ __device__ inline int pg_pending_of(int tail_mode) { return (tail_mode >> 8) & 3; }
 __host__ __device__ inline int pg_pending_groups_of(int tail_mode) { return (tail_mode >> 16) & 0xFF; }
+// bits 24 .. 31: per learnable move l < 4, the GradientData column groups its optimiser does not read (bit 0 grad logq_forward, bit 1
+// the metric g) -- set only where the launch's own tail takes the learning step, so that nothing of the skipped sums outlives it
+__host__ __device__ inline int pg_skip_of(int tail_mode, int l) { return l < 4 ? (int)(((unsigned)tail_mode >> (24 + 2 * l)) & 3u) : 0; }
+__host__ inline int pg_skip_bits(const int* kinds, int n_learn)
+{
+    unsigned bits = 0u;
+    for (int l = 0; l < n_learn && l < 4; ++l) {
+        const int k = kinds[l];
+        const bool reads_dlogq = k == 2 || k == 3 || k == 6;         // BLPG, BLAPG, BLANPG: the baseline term j grad logq (learning.jl:50-52,77-79,160-164)
+        const bool reads_g = k == 4 || k == 5 || k == 6;             // NPG, ANPG, BLANPG: the metric (learning.jl:103-105,130-134)
+        bits |= (unsigned)((reads_dlogq ? 0 : 1) | (reads_g ? 0 : 2)) << (2 * l);
+    }
+    return (int)(bits << 24);
+}
 
 // All threads of the block call (one barrier inside).  s_val[n_learn * 4], s_def[n_learn][DEF_N]: LDS; valid after the caller's
 // next barrier.  prev: the parity of the launch that left the step pending; writer: this block records sigma' and the status.
