@@ -237,14 +237,17 @@ int  amc_create_mixed_model(const amc_config *cfg, int n_classes, const int *cla
 int  amc_model_check(int n_params, int n_classes, const char *potential_expr, const char *reward_expr,
                      const char *const *sample_exprs, const char *const *logq_exprs, const char *const *dlogq_exprs,
                      const char *const *perform_exprs, const char *const *invert_exprs, char *log, int log_capacity);
-/* How an estimator call over n_learn learnable moves of this handle would run: returns 1 = ONE launch takes every learnable
- * move (the reference's make_step!(::PolicyGradientEstimator) loops over all of them in one step, estimator.jl:111-134), with
- * `fused` != 0: one launch per whole time step (sweep + estimator [+ update]: amc_pgmc_steps); 0 = one launch per learnable
- * move; < 0 = an amc_status.  Only a pool of several classes can answer 0 for a one-parameter policy: its several-move kernel
- * form is asked of the run-time compiler on first use, and where the compiler fails on it (hipcc 7.2 meets a back-end error on
- * some pools; the compiler runs in a child process, AMC_ERR_COMPILE) the calls fall back to the one-move form -- same samples,
- * same sums, same bits.  `why` (may be NULL) then receives the compiler's last words.  The call itself triggers that first
- * build, so it doubles as a warm-up.  Policies with several parameters: 0, except n_learn == 1 (one launch). */
+/* How an estimator call over n_learn learnable moves of this handle would run.  Returns
+ *     2   (asked with `fused` != 0 only) the whole time step -- sweep + estimator [+ update] -- is ONE launch (amc_pgmc_steps)
+ *     1   one estimator launch takes every learnable move, as the reference's make_step!(::PolicyGradientEstimator) loops over all
+ *         of them in one step whatever their policy types (estimator.jl:111-134)
+ *     0   one launch per learnable move
+ *    < 0  an amc_status.
+ * Only a pool of several classes can answer 0 for one-parameter policies: its several-move kernel form is asked of the run-time
+ * compiler on first use, and where the compiler fails on it (hipcc 7.2 meets a back-end error on some pools; the compiler runs in a
+ * child process, AMC_ERR_COMPILE) the calls fall back to the one-move form -- same samples, same sums, same bits.  `why` (may be
+ * NULL) then receives the compiler's last words.  The call itself triggers that first build, so it doubles as a warm-up.
+ * Policies with several parameters: 0, except n_learn == 1 (1, or 2 for the fused step on a single shard). */
 int  amc_pg_route(amc_handle *h, int n_learn, int q_batch, int fused, char *why, int why_capacity);
 /* The same with a script-defined ACTION -- the reference's Action interface (src/metropolis.jl:15-119; the displacement's
  * methods are example/particle_1d/particle_1d.jl:30-40) for a one-parameter action on the position:

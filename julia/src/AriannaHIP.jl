@@ -455,7 +455,7 @@ function pg_route(alg::HIPMetropolis, n_learn::Integer; q_batch::Integer=1, fuse
     rc = ccall((:amc_pg_route, libamc), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt8}, Cint),
                alg.handle, n_learn, q_batch, fused ? 1 : 0, why, length(why))
     rc < 0 && check(rc)
-    return (rc == 1, unsafe_string(pointer(why)))
+    return ((fused ? rc == 2 : rc >= 1), unsafe_string(pointer(why)))      # amc_pg_route: 2 one launch per time step, 1 one estimator launch, 0 one per move
 end
 
 # Compile-only check of a script-defined policy, without a GPU (amc_model_check): (sample, logq[, dlogq]) as for `proposal=`;

@@ -554,14 +554,19 @@ class HipEngine:
         return out
 
     def pg_route(self, n_learn: int, q_batch: int = 1, fused: bool = False):
-        """(one_launch, why): whether an estimator call over n_learn learnable moves takes them all in ONE launch (with
-        ``fused``: one launch per whole time step), and, for a pool of several classes whose several-move kernel form the
-        run-time compiler fails on, what the compiler said (the calls then take one launch per move: same bits)."""
+        """(one_launch, why): whether an estimator call over n_learn learnable moves takes them all in ONE launch -- with
+        ``fused``: whether the whole time step (sweep + estimator + update) is one launch -- and, for a pool of several classes
+        whose several-move kernel form the run-time compiler fails on, what the compiler said (the calls then take one launch per
+        move: same bits).  ``pg_route_code`` returns amc_pg_route's own answer (2 / 1 / 0)."""
+        code, why = self.pg_route_code(n_learn, q_batch, fused)
+        return (code == 2 if fused else code >= 1), why
+
+    def pg_route_code(self, n_learn: int, q_batch: int = 1, fused: bool = False):
         why = C.create_string_buffer(2048)
         rc = self._lib.amc_pg_route(self._h, int(n_learn), int(q_batch), int(bool(fused)), why, len(why))
         if rc < 0:
             _check(rc)
-        return bool(rc), why.value.decode(errors="replace")
+        return int(rc), why.value.decode(errors="replace")
 
     def pg_accumulate(self, learn_ids: Sequence[int], q_batch: int) -> None:
         """Estimator step kept on the device: gradients_data[k] += gd (asynchronous)."""

@@ -569,15 +569,26 @@ int amc_pg_route(amc_handle* h, int n_learn, int q_batch, int fused, char* why, 
     if (n_learn < 1 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_route: n_learn must be in [1, %d]", AMC_MAX_LEARN);
     if (q_batch < 1 || q_batch > AMC_MAX_QBATCH) return fail(AMC_ERR_BAD_ARG, "amc_pg_route: q_batch must be in [1, %d]", AMC_MAX_QBATCH);
     if (why && why_capacity > 0) why[0] = 0;
-    if (per_move_launches(h)) return np_single_launch(h, n_learn) && !h->comm ? 1 : 0;
     AMC_HIP(hipSetDevice(h->device));
-    bool general = true;
-    const bool can_fuse = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn <= 2 && log_form(h) != AMC_LOG_BYTES;
-    { const int rc = class_general_route(h, n_learn, fused != 0 && can_fuse, false, q_batch, &general); if (rc != AMC_OK) return rc; }
-    if (!general && why && why_capacity > 0) {
-        std::strncpy(why, h->class_form_error.c_str(), (size_t)why_capacity - 1);
-        why[why_capacity - 1] = 0;
+    // the conditions of pgmc_steps_impl's `fused`: the sweep rides in the estimator launch
+    const bool can_fuse = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) &&
+                          n_learn <= 2 && log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    auto say_why = [&]() {
+        if (why && why_capacity > 0 && !h->class_form_error.empty()) {
+            std::strncpy(why, h->class_form_error.c_str(), (size_t)why_capacity - 1);
+            why[why_capacity - 1] = 0;
+        }
+    };
+    if (fused != 0 && can_fuse) {
+        bool general = true;
+        { const int rc = class_general_route(h, n_learn, true, false, q_batch, &general); if (rc != AMC_OK) return rc; }
+        if (general) return 2;
+        say_why();
     }
+    if (per_move_launches(h)) return np_single_launch(h, n_learn) ? 1 : 0;
+    bool general = true;
+    { const int rc = class_general_route(h, n_learn, false, false, q_batch, &general); if (rc != AMC_OK) return rc; }
+    if (!general) say_why();
     return general ? 1 : 0;
 }
 

@@ -143,6 +143,9 @@ def test_the_form_that_kills_hipcc_is_an_error_code_and_the_call_falls_back(gpu,
     # the process is alive and the engine usable: two learnable moves take the one-launch form (it builds)
     two, why2 = eng.pg_route(2, 2)
     assert two, why2
+    # amc_pg_route's own answers: 2 = the whole time step in one launch, 1 = one estimator launch for all moves, 0 = one per move
+    assert eng.pg_route_code(2, 2, fused=True)[0] == 2 and eng.pg_route_code(2, 2)[0] == 1
+    assert eng.pg_route_code(4, 2, fused=True)[0] == (1 if one_launch else 0)          # more than two moves never fuse with the sweep
     assert np.array_equal(eng.pg_estimate_exact([1, 2], 2), ref.pg_estimate_exact([1, 2], 2))
     eng.close()
     oracle.install_policy_classes(None, None)
