@@ -117,6 +117,8 @@ def load() -> C.CDLL:
         "amc_xsum_round": (C.c_int, [dp, C.c_int, dp]),
         "amc_pg_estimate_exact": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.c_int, dp]),
         "amc_pg_route": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+        "amc_model_check": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p, C.c_int]),
         "amc_allreduce_xsum": (C.c_int, [H, dp, C.c_int]),
         "amc_comm_library_forced": (C.c_int, [C.POINTER(C.c_int)]),
         "amc_set_parameters": (C.c_int, [H, C.c_int, dp, C.c_int]),
@@ -190,9 +192,6 @@ def model_check(sample, logq, dlogq=None, perform=None, invert=None, *, n_params
     n_d = n_classes if many else int(n_params)
     buf = C.create_string_buffer(8192)
     lib = load()
-    lib.amc_model_check.restype = C.c_int
-    lib.amc_model_check.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
-                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
     _check(lib.amc_model_check(int(n_params), n_classes, None if potential is None else str(potential).encode(),
                                None if reward is None else str(reward).encode(), col(sample, n_classes), col(logq, n_classes),
                                col(dlogq, n_d), col(perform, n_classes), col(invert, n_classes), buf, len(buf)))
