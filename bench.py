@@ -302,6 +302,19 @@ def other_configs(A, m, device, periods=40):
     return out
 
 
+def pick_device(local_rank, n_dev):
+    """The device ordinal of this rank: AMC_BENCH_DEVICE if given, else LOCAL_RANK -- or 0 where the launcher hands every rank ONE
+    visible device of its own (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per rank: each process then sees a single device 0).
+    None: LOCAL_RANK names a device this process cannot see."""
+    if "AMC_BENCH_DEVICE" in os.environ:
+        return int(os.environ["AMC_BENCH_DEVICE"])
+    if 0 <= local_rank < n_dev:
+        return local_rank
+    if n_dev == 1 and (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")):
+        return 0
+    return None
+
+
 def preflight(rank, local_rank, world):
     """N > 1: what this rank is about to run on, on stderr BEFORE the first collective, and the failures that can be seen
     from here as errors of their own -- so that the first run on a real 8-GPU node, if it fails, says why in its first lines
@@ -312,7 +325,7 @@ def preflight(rank, local_rank, world):
     candidates = [forced] if forced else ["/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"]
     librccl = next((c for c in candidates if c and os.path.exists(c)), None)
     port = os.environ.get("MASTER_PORT")
-    device = int(os.environ.get("AMC_BENCH_DEVICE", local_rank))
+    device = pick_device(local_rank, n_dev)
     print(f"[bench preflight rank {rank}/{world}] local_rank={local_rank} device={device} hip_devices_visible={n_dev} "
           f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} (must be 0: dmabuf IPC) "
           f"librccl={librccl or 'NOT FOUND among ' + str(candidates)}{' (AMC_RCCL_LIBRARY)' if forced else ''} "
@@ -321,8 +334,8 @@ def preflight(rank, local_rank, world):
           file=sys.stderr, flush=True)
     if n_dev < 1:
         raise SystemExit(f"[bench rank {rank}] no HIP device visible to this process")
-    if not (0 <= device < n_dev):
-        raise SystemExit(f"[bench rank {rank}] device {device} (LOCAL_RANK / AMC_BENCH_DEVICE) but {n_dev} HIP device(s) visible: "
+    if device is None or not (0 <= device < n_dev):
+        raise SystemExit(f"[bench rank {rank}] device {local_rank if device is None else device} (LOCAL_RANK / AMC_BENCH_DEVICE) but {n_dev} HIP device(s) visible: "
                          f"one process per GPU needs --nproc-per-node <= the node's GPU count")
     if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
         raise SystemExit(f"[bench rank {rank}] HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}: RCCL between "
@@ -398,7 +411,7 @@ def main():
     start, stop = sharding.shard_range(m_global, rank, world)
     eng = A.HipEngine(n_chains=stop - start, chain_offset=start, n_chains_global=m_global, potential="harmonic",
                       beta=BETA, sigma=[SIGMA], weight=[1.0], seed=SEED, sweepstep=1, per_chain_counters=False,
-                      device=int(os.environ.get("AMC_BENCH_DEVICE", local_rank)))
+                      device=(lambda d: local_rank if d is None else d)(pick_device(local_rank, A.device_count())))
     eng.init_uniform(-2.0, 2.0)
     eng.set_reduce_columns(A.HipEngine.REDUCE_E)     # the callbacks of configs 2 - 5 are callback_energy and callback_acceptance: sum e alone
     allreduce_via = "none (single process)"

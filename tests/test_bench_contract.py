@@ -111,8 +111,14 @@ def test_preflight_block_comes_before_the_first_collective():
     first = r.stderr.lstrip().splitlines()[0]
     assert first.startswith("[bench preflight rank 0/1]") and "hip_devices_visible=1" in first and "HSA_ENABLE_IPC_MODE_LEGACY=0" in first
     assert "librccl=/opt/rocm/lib/librccl.so" in first and "store_port=29538" in first
+    # LOCAL_RANK names a device this process cannot see: an error of its own -- unless the launcher isolates one device per rank
+    # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set: every rank then sees a single device 0 and takes it)
+    isolated = bool(os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
     bad = subprocess.run(cmd, env=dict(os.environ, **dict(env, LOCAL_RANK="5", MASTER_PORT="29541")), capture_output=True, text=True, timeout=600)
-    assert bad.returncode != 0 and "device 5" in bad.stderr and "1 HIP device(s) visible" in bad.stderr
+    if isolated:
+        assert bad.returncode == 0 and "local_rank=5 device=0" in bad.stderr
+    else:
+        assert bad.returncode != 0 and "device 5" in bad.stderr and "1 HIP device(s) visible" in bad.stderr
     legacy = subprocess.run(cmd, env=dict(os.environ, **dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1", MASTER_PORT="29545")), capture_output=True, text=True, timeout=600)
     assert legacy.returncode != 0 and "dmabuf IPC" in legacy.stderr
 
