@@ -355,6 +355,8 @@ def main():
                          "~0.1-0.5 s of load to reach its sustained clock (65 -> 56 us/sweep measured)")
     ap.add_argument("--spinup-cap-s", type=float, default=3.0,
                     help="... and the ramp's upper bound: it ends earlier once three consecutive 200-launch blocks agree within 1 %%")
+    ap.add_argument("--preblocks", type=int, default=12,
+                    help="untimed blocks of the timed region's own shape (barrier, K steps, drain) between the ramp and the W warm-up steps")
     ap.add_argument("--chains-per-gpu", type=int, default=M_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="extra repetitions of the K-step block for min / median (not part of value)")
@@ -468,13 +470,25 @@ def main():
             return eng.reduce_records_value(sharding.allreduce_xsum(rec, eng), steps)
         return None
 
-    def step(i):
-        if cb_every and (i + 1) % cb_every == 0:
-            finish_callback()
-            eng.sweep_reduce_begin(1)        # the sweep whose state the callbacks observe: sums formed in-kernel
-            pending[0] = True
-        else:
-            eng.sweep(1)
+    def run_steps(n):
+        """n steps of the loop: one launch per sweep, queued in stretches by ONE engine call each (amc_sweep_launches: the same n
+        launches, minus the per-launch crossing of the language boundary -- a 20-step timed region is 0.6 ms, and a host hiccup
+        of a few tens of microseconds between two launches is a few per cent of it); with callbacks, every cb_every-th step is
+        the sweep whose state the callbacks observe (sums formed in-kernel), the previous callback's sums read just before it."""
+        if not cb_every:
+            eng.sweep_launches(n)
+            return
+        i = 0
+        while i < n:
+            plain = min(n - i, cb_every - 1 - (i % cb_every))
+            if plain > 0:
+                eng.sweep_launches(plain)
+                i += plain
+            if i < n:
+                finish_callback()
+                eng.sweep_reduce_begin(1)
+                pending[0] = True
+                i += 1
 
     def local_sync():
         eng.sync()                           # everything this rank has queued is done (sweeps: engine's stream; the callback sums' all-reduce is host-synchronous)
@@ -499,8 +513,7 @@ def main():
         # reaches a callback step), the first launch of the sum-forming kernel form and the first real all-reduces happen here;
         # so does a one-off of the stack: some 0.1-0.2 s into a process's first callback-bearing steps the queue stands still
         # once for 30-50 ms (one gap in the kernel trace, with or without a communicator; profiles/NOTES_r03.md)
-        for i in range(200):
-            step(i) if cb_every else eng.sweep(1)
+        run_steps(200)
         finish_callback()
         eng.sync()
         spin_blocks.append((time.perf_counter() - b0) * 1e3)
@@ -517,14 +530,21 @@ def main():
         # every rank must leave after the same number of collectives: the ranks agree through one more of them
         elif sharding.all_ranks(time_up, eng):
             break
-    for i in range(args.warmup):
-        step(i)
+    # ... and then in the timed region's own rhythm: untimed blocks of the very bracket that follows (barrier, K steps, drain), so that
+    # the timed block is one more block of a steady sequence and not the first of its kind after the ramp's 200-launch stretches
+    # (the two HIP-event records that bracket the timed launches cost it ~1.5 % at K = 20 against the blocks of `repeat`, which carry
+    # none: measured by leaving them out, three runs each way on one box; they stay -- roofline.frac_events is taken over the timed region)
+    for _ in range(max(0, args.preblocks)):
+        barrier()
+        run_steps(args.steps)
+        finish_callback()
+        local_sync()
+    run_steps(args.warmup)
     finish_callback()
     barrier()
     eng.timing_begin()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     finish_callback()                      # the last callback's all-reduce belongs to the timed region
     eng.timing_mark()                      # end event behind the K-th launch (asynchronous) ...
     local_sync()
@@ -550,8 +570,7 @@ def main():
             break
         barrier()
         r0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        run_steps(args.steps)
         finish_callback()
         local_sync()
         rep_ms.append((time.perf_counter() - r0) * 1e3 / args.steps)

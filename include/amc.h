@@ -310,6 +310,11 @@ int  amc_download_strided(amc_handle *h, int64_t first, int64_t stride, int64_t 
  * `sweepstep` mc_step!s per chain.  The n*sweepstep steps run fused in one launch
  * (state stays in registers); results are identical to n separate calls. */
 int  amc_sweep(amc_handle *h, int64_t n_sweeps);
+/* n x make_step!(simulation, ::Metropolis) as n LAUNCHES of one sweep each, queued by one host call: what run!'s time loop issues
+ * when every t is observed by nobody in between but the caller wants the state to make its HBM round trip per sweep (the
+ * benchmark's definition of a step; src/simulation.jl:184-191 calls make_step! once per t).  Identical to n calls of
+ * amc_sweep(h, 1), minus n - 1 crossings of the language boundary. */
+int  amc_sweep_launches(amc_handle *h, int64_t n_launches);
 /* MH steps done per chain so far (the Philox step index); settable for resume. */
 int  amc_get_step(amc_handle *h, uint64_t *t);
 int  amc_set_step(amc_handle *h, uint64_t t);

@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         "amc_get_estimator_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "amc_set_estimator_step": (C.c_int, [H, C.c_uint64]),
         "amc_sweep": (C.c_int, [H, C.c_int64]),
+        "amc_sweep_launches": (C.c_int, [H, C.c_int64]),
         "amc_get_step": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "amc_set_step": (C.c_int, [H, C.c_uint64]),
         "amc_reduce": (C.c_int, [H, dp]),
@@ -551,6 +552,10 @@ class HipEngine:
         out = np.zeros((n, self.gd_stride, AMC_XSUM_WORDS), dtype=np.float64)
         _check(self._lib.amc_pg_estimate_exact(self._h, n, ids, int(q_batch), _dptr(out)))
         return out
+
+    def sweep_launches(self, n_launches: int) -> None:
+        """n make_step!s as n launches of one sweep each, queued by one call (amc_sweep_launches)."""
+        _check(self._lib.amc_sweep_launches(self._h, int(n_launches)))
 
     def pg_route(self, n_learn: int, q_batch: int = 1, fused: bool = False):
         """(one_launch, why): whether an estimator call over n_learn learnable moves takes them all in ONE launch -- with

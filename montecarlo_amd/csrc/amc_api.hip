@@ -1251,6 +1251,17 @@ int amc_sweep(amc_handle* h, int64_t n_sweeps)
     return sweep_impl(h, n_sweeps, false, nullptr);
 }
 
+int amc_sweep_launches(amc_handle* h, int64_t n_launches)
+{
+    if (!h) return fail(AMC_ERR_BAD_ARG, "amc_sweep_launches: NULL handle");
+    if (n_launches < 0) return fail(AMC_ERR_BAD_ARG, "amc_sweep_launches: n_launches < 0");
+    for (int64_t i = 0; i < n_launches; ++i) {
+        const int rc = sweep_impl(h, 1, false, nullptr);
+        if (rc != AMC_OK) return rc;
+    }
+    return AMC_OK;
+}
+
 int amc_upload_counters(amc_handle* h, const int64_t* accepted, const int64_t* total)
 {
     if (!h || !accepted) return fail(AMC_ERR_BAD_ARG, "amc_upload_counters: NULL argument");
