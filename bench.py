@@ -170,14 +170,12 @@ def ladder(A, sizes, device, reps=5):
             continue
         e.init_uniform(-2.0, 2.0)
         n = max(10, min(200, int(2_000_000_000 // m)))
-        for _ in range(n):
-            e.sweep(1)
+        e.sweep_launches(n)
         e.sync()
         ts = []
         for _ in range(reps):
             e.timing_begin()
-            for _ in range(n):
-                e.sweep(1)
+            e.sweep_launches(n)
             ts.append(e.timing_end() * 1e3 / n)
         e.close()
         us = min(ts)
@@ -204,14 +202,12 @@ def widened_paths(A, m, device, reps=5):
             n = 200
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.3:
-                for _ in range(n):
-                    e.sweep(1)
+                e.sweep_launches(n)
                 e.sync()
             ts = []
             for _ in range(reps):
                 e.timing_begin()
-                for _ in range(n):
-                    e.sweep(1)
+                e.sweep_launches(n)
                 ts.append(e.timing_end() * 1e3 / n)
             e.close()
             us = sorted(ts)[len(ts) // 2]
@@ -271,8 +267,7 @@ def other_configs(A, m, device, periods=40):
         return sorted(times)[len(times) // 2]
 
     def k2_period(e, read_previous):
-        for _ in range(9):
-            e.sweep(1)                                                 # one launch per sweep, like the headline
+        e.sweep_launches(9)                                            # one launch per sweep, like the headline
         read_previous()
         e.sweep_reduce_begin(1)                                        # the tenth forms the callback sums
 
