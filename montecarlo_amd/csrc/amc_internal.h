@@ -144,8 +144,9 @@ struct amc_handle {
                                     // (hipOccupancyMaxActiveBlocksPerMultiprocessor: 5 for the built-in forms, 4 for most hiprtc ones), see pg_plan
     int occ_query = 0;              // out-slot of a launch_pg call made with grid < 0 (a query, nothing is launched)
     std::map<int, int> pg_resident; // resident blocks per CU of the estimator kernel forms, by (nl, sweep, reduce)
-    std::map<int, bool> class_form_builds;  // pools of several classes: does the several-move estimator form (nl, sweep, reduce) build? (amc_pg.hip class_general_route)
-    std::string class_form_error;   // ... the compiler's last words about the last one that did not (amc_class_route_report)
+    std::map<int, std::string> class_form_errors;  // pools of several classes: the several-move estimator forms (nl, sweep, reduce) that do NOT build, with
+                                                   // the compiler's last words about each (amc_pg.hip class_general_route, amc_pg_route)
+    std::string class_form_error;   // ... of the form the last class_general_route call asked about ("" when it builds)
     bool no_column_skip = false;    // env AMC_NO_COLUMN_SKIP=1 (A/B, tests): fused script-defined steps sum every GradientData column whatever the optimiser reads
     bool class_per_move_forced = false;     // env AMC_CLASS_PER_MOVE=1 (read at amc_create; A/B, tests): class pools take one estimator launch per learnable move
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

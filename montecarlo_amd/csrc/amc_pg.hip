@@ -214,14 +214,15 @@ static int class_general_route(amc_handle* h, int n_learn, bool with_sweep, bool
     const int sweep = with_sweep ? (h->K > 1 ? 2 : (h->d_log ? 1 : 3)) : 0;
     const bool red = reduce && with_sweep;
     const int key = (nl << 8) | (sweep << 4) | (red ? red_form(h) : 0);
-    auto it = h->class_form_builds.find(key);
-    if (it != h->class_form_builds.end() && !it->second) { *general = false; return AMC_OK; }
+    h->class_form_error.clear();
+    auto it = h->class_form_errors.find(key);
+    if (it != h->class_form_errors.end()) { h->class_form_error = it->second; *general = false; return AMC_OK; }
     PgPlan plan;
     const int rc = pg_plan(h, nl, sweep, red, q_batch, &plan);      // (cheap once the form is loaded: two map lookups)
     if (rc == AMC_OK) return AMC_OK;
     if (rc != AMC_ERR_COMPILE) return rc;
     h->class_form_error = amc_last_error();
-    h->class_form_builds[key] = false;
+    h->class_form_errors[key] = h->class_form_error;
     if (std::getenv("AMC_DEBUG_PLAN"))
         std::fprintf(stderr, "[amc] class pool: estimator form nl=%d sweep=%d reduce=%d does not build, one launch per learnable move instead: %s\n", nl, sweep, (int)red, h->class_form_error.c_str());
     *general = false;
