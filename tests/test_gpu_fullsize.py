@@ -681,3 +681,33 @@ def test_two_parameter_gradient_sums_against_quadrature_at_full_size(gpu, deriva
     assert G[1, 1] == pytest.approx(2 / sigma ** 2, rel=6 * np.sqrt(28.0) / 2.0 * se)
     assert G[0, 1] == G[1, 0] and G[0, 1] == pytest.approx(0.0, abs=6 * np.sqrt(10.0) / sigma ** 2 * se)   # E[z (z^2-1)] = 0, var = 10
     e.close()
+
+
+def test_class_pool_one_launch_per_time_step_at_full_size(gpu):
+    """Round 6: a pool that mixes policy types (Gaussian + Langevin, the Langevin class WITHOUT its derivative: the engine
+    differentiates logq) takes its whole PGMC time step in ONE launch (every learnable move, the sweep in front: the route of every
+    other pool; reference: one estimator pass over all learnable moves, estimator.jl:111-134).  At 1e7 chains -- the full grid,
+    the tail's two ticket levels -- three time steps equal the one-launch-per-move route (AMC_CLASS_PER_MOVE=1) bit for bit:
+    parameters, every chain, every counter; and with AMC_NO_COLUMN_SKIP=1 (every GradientData column summed) likewise."""
+    gauss = ("sigma*z", "-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(6.283185307179586*(sigma*sigma))/2.0",
+             "(delta*delta)/(sigma*sigma*sigma) - 1.0/sigma")
+    mala = ("-2.0*sigma*sigma*x + sigma*z", "-((delta + 2.0*sigma*sigma*x)*(delta + 2.0*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)", None)
+    out = []
+    for env in ({}, {"AMC_CLASS_PER_MOVE": "1"}, {"AMC_NO_COLUMN_SKIP": "1"}):
+        os.environ.update(env)
+        try:
+            e = gpu.HipEngine(n_chains=M_FULL, potential="harmonic", beta=2.0, sigma=[0.3, 0.4], weight=[0.5, 0.5], seed=42,
+                              classes=[gauss, mala], class_of_move=[0, 1])
+        finally:
+            for k in env:
+                del os.environ[k]
+        e.init_uniform(-2, 2)
+        assert e.pg_route_code(2, 1, fused=True)[0] == (0 if "AMC_CLASS_PER_MOVE" in env else 2)
+        e.pgmc_steps(3, [0, 1], 1, [1, 2], [1e-3, 1e-3], [0.0, 0.0])              # VPG and BLPG
+        x = e.download_state()[0]
+        acc, tot = e.counter_totals()
+        out.append(([e.get_parameters(k)[0] for k in range(2)], int(np.bitwise_xor.reduce(x.view(np.uint64))), float(x[12345]),
+                    acc.tolist(), tot.tolist()))
+        e.close()
+    assert out[0] == out[1] == out[2]
+    assert out[0][0][0] != 0.3 and out[0][0][1] != 0.4 and sum(out[0][4]) == 3 * M_FULL
