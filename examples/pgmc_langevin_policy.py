@@ -30,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--beta", type=float, default=2.0)
     ap.add_argument("--eta", type=float, default=0.05)
+    ap.add_argument("--dtype", default="f64", choices=("f64", "f32"), help="Particle{T}: Float64 (reference scripts) or Float32")
     ap.add_argument("--path", default=None)
     args = ap.parse_args(argv)
     beta, M, steps = args.beta, args.chains, args.steps
@@ -40,7 +41,7 @@ def main(argv=None):
                                logq=f"-((delta + {beta}*sigma*sigma*x)*(delta + {beta}*sigma*sigma*x))/(2.0*(sigma*sigma)) - amc_log(sigma)")
     print("the policy compiles (no GPU needed for this check):", repr(ma._capi.model_check(langevin.sample, langevin.logq)) or "clean")
 
-    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0)
+    chains = ma.ParticleChains.uniform(M, beta, -2.0, 2.0, dtype=args.dtype)       # (Float32 state: x and delta are Float32 in the expressions, Julia's promotion rules)
     pool = (ma.Move(ma.Displacement(0.0), ma.StandardGaussian(), {"sigma": 0.3}, 0.5),
             ma.Move(ma.Displacement(0.0), langevin, [0.3], 0.5))
     burn = min(200, steps // 10)

@@ -186,7 +186,8 @@ int  amc_create_policy_model(const amc_config *cfg, const char *potential_expr, 
  *                   Given, the expression is used as given (a hand-derived form may order its operations differently:
  *                   equal to a few ulp, tests/test_autodiff.py).
  * Variables: z, x, sigma, delta; vocabulary as for amc_create_custom.  potential_expr NULL: cfg->potential's built-in.
- * Float64 state only.  Every accept decision takes the reference-ordered arithmetic (no accept filter). */
+ * Float32 state (cfg->state_dtype): x and delta are floats in the expressions -- C's usual arithmetic conversions restate Julia's
+ * promotion rules for the same text; parameters, z and the densities stay Float64. */
 int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr, const char *reward_expr,
                                const char *sample_expr, const char *logq_expr, const char *dlogq_expr, amc_handle **out);
 /* The same for a policy with SEVERAL parameters: Move.parameters is an array in the reference (src/metropolis.jl:140-147),

@@ -430,8 +430,6 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
         if (proposal) {
             const int rc_p = validate_proposal_exprs(proposal);
             if (rc_p != AMC_OK) return rc_p;
-            if (state_dtype != AMC_DTYPE_F64)
-                return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: script-defined proposals are offered for Float64 state");
         }
     } else if (potential_expr) {
         return fail(AMC_ERR_BAD_ARG, "amc_create_custom: cfg->potential must be AMC_POTENTIAL_CUSTOM");
@@ -705,7 +703,9 @@ int amc_create_vector_policy_model(const amc_config* cfg, int n_params, const ch
     const char* pot = potential_expr;
     if (!pot) {
         if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
+            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
+                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
         else return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: potential_expr is NULL and cfg->potential names no built-in");
     }
     amc_config c2;
@@ -727,7 +727,9 @@ int amc_create_action_model(const amc_config* cfg, const char* potential_expr, c
     const char* pot = potential_expr;
     if (!pot) {
         if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
+            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
+                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
         else return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: potential_expr is NULL and cfg->potential names no built-in");
     }
     amc_config c2;
@@ -759,7 +761,9 @@ int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* clas
     const char* pot = potential_expr;
     if (!pot) {
         if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) pot = "(x*x - 1.0)*(x*x - 1.0)";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
+            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
+                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
         else return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: potential_expr is NULL and cfg->potential names no built-in");
     }
     amc_config c2;
@@ -808,7 +812,9 @@ int amc_model_check(int n_params, int n_classes, const char* potential_expr, con
                                 invert_exprs ? invert_exprs[0] : nullptr, n_params, (dlogq_exprs && n_params > 1) ? dlogq_exprs + 1 : nullptr,
                                 n_classes, more, com};
     { const int rc = validate_proposal_exprs(&prop); if (rc != AMC_OK) return rc; }
-    const std::string expr = encode_model_expr(false, pot, reward_expr, nullptr, &prop);
+    // (developer knob: AMC_MODEL_CHECK_F32=1 builds the form for Float32 state)
+    const char* f32_env = std::getenv("AMC_MODEL_CHECK_F32");
+    const std::string expr = encode_model_expr(f32_env && f32_env[0] == '1', pot, reward_expr, nullptr, &prop);
     // the estimator kernel is the one that uses every expression (sample, logq, its derivative, perform / invert, reward)
     const RtcCode* code = nullptr;
     std::string text;

@@ -595,8 +595,61 @@ static inline float delta_log_target_density_f32(float e1, float e2, float beta)
     return ((-e2) * beta) - ((-e1) * beta);
 }
 
+/* Float32 state under a script-defined proposal / action.  The generic functions are the model's own (metropolis.jl:35-62); with
+ * Particle{Float32} and Displacement{Float32} their bodies run under Julia's promotion rules, which C's usual arithmetic
+ * conversions restate for the same text: x and delta are Float32, the parameters and the normal variate Float64, a Float32 x
+ * Float32 product stays Float32, anything that meets a Float64 is Float64.  The hooks keep their double signatures (the chain
+ * fields are doubles that hold Float32 values): the functions installed for a Float32 simulation take x and delta as floats
+ * inside and return a Float32 value where the result is assigned to a field of type T (delta, x).  theta: the move's parameter
+ * array (one entry for the one-parameter forms).  Lines: metropolis.jl:176-190. */
+static inline void script_perform_action_f32(particle_t *p, float delta, int pot, float *e1, float *e2)
+{
+    *e1 = (float)p->e;
+    float x = CUR_PERFORM ? (float)CUR_PERFORM(p->x, (double)delta) : (float)p->x + delta;
+    float e = amo_potential_f32(pot, x);
+    p->x = (double)x;
+    p->e = (double)e;
+    *e2 = e;
+}
+static inline float script_sample_f32(const particle_t *p, const double *theta, double z)
+{
+    return (float)(g_vec_logq ? g_vec_sample(z, p->x, theta) : CUR_SAMPLE(z, p->x, theta[0]));
+}
+static inline double script_logq_f32(float delta, const particle_t *p, const double *theta)
+{
+    return g_vec_logq ? g_vec_logq((double)delta, p->x, theta) : CUR_LOGQ((double)delta, p->x, theta[0]);
+}
+static inline void script_dlogq_f32(float delta, const particle_t *p, const double *theta, double *out)
+{
+    if (g_vec_logq) g_vec_dlogq((double)delta, p->x, theta, out);
+    else out[0] = g_custom_dlogq ? CUR_DLOGQ((double)delta, p->x, theta[0]) : (0.0 / 0.0);
+}
+static inline float script_invert_f32(float delta, const particle_t *p)
+{
+    return CUR_INVERT ? (float)CUR_INVERT((double)delta, p->x) : -delta;
+}
+static inline int mc_step_script_f32(particle_t *p, move_t *m, const double *theta, int pot, double z, double u)
+{
+    float delta = script_sample_f32(p, theta, z);                  /* :177 sample_action! */
+    double logq_f = script_logq_f32(delta, p, theta);              /* :178 at the old state */
+    float e1, e2, beta = (float)p->beta;
+    script_perform_action_f32(p, delta, pot, &e1, &e2);            /* :179 */
+    float dlogp = delta_log_target_density_f32(e1, e2, beta);      /* :180 */
+    delta = script_invert_f32(delta, p);                           /* :181 */
+    double logq_b = script_logq_f32(delta, p, theta);              /* :182 at the new state */
+    double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_b - logq_f)); /* :183 */
+    m->delta = (double)delta;
+    if (alpha > u) return 1;                                       /* :184 */
+    script_perform_action_f32(p, delta, pot, &e1, &e2);            /* :187 perform_action_cached! */
+    return 0;
+}
+
 static inline int mc_step_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double u)
 {
+    if (g_custom_logq) {                                           /* script-defined proposal */
+        const double th[1] = { sigma };
+        return mc_step_script_f32(p, m, th, pot, z, u);
+    }
     double s_f = g_custom_scale_f32 ? sigma * (double)g_custom_scale_f32((float)p->x) : sigma;
     float delta = (float)(0.0 + s_f * z);                          /* :177; the field converts */
     double logq_forward = log_proposal_density_f32(delta, s_f);    /* :178 */
@@ -695,7 +748,8 @@ static void mc_sweep(amo_sim *s, int64_t c, uint64_t t0, int mc_steps)
         if (g_vec_logq) {
             double th[AMO_MAX_NP];
             move_theta(s, id, th);
-            move->accepted_calls += mc_step_vec(p, move, th, s->pot, zz[half], u);
+            move->accepted_calls += s->f32 ? mc_step_script_f32(p, move, th, s->pot, zz[half], u)
+                                           : mc_step_vec(p, move, th, s->pot, zz[half], u);
         } else
         move->accepted_calls += s->f32 ? mc_step_f32(p, move, s->sigma[id], s->pot, zz[half], u)
                                        : mc_step(p, move, s->sigma[id], s->pot, zz[half], u); /* :208 */
@@ -1264,8 +1318,41 @@ static void pgmc_sample(particle_t *p, move_t *m, double sigma, int pot, double 
 
 /* The same sample with Float32 state (promotion rules in the Float32 section above): reward (delta)^2 in Float32,
  * j = r * alpha in Float64. */
+/* gradients.jl:93-109 pgmc_estimate with Float32 state under a script-defined policy (one parameter or several):
+ * gd = [j, grad j [P], grad logq_forward [P], g [P][P] row by row]; P = 1: (j, dj, dlogq, g). */
+static void pgmc_sample_script_f32(particle_t *p, move_t *m, const double *theta, int pot, double z, double *gd)
+{
+    const int P = g_vec_logq ? g_np : 1;
+    double d_f[AMO_MAX_NP], d_b[AMO_MAX_NP];
+    float delta = script_sample_f32(p, theta, z);
+    double logq_f = script_logq_f32(delta, p, theta);              /* :97 forward, at the old state */
+    script_dlogq_f32(delta, p, theta, d_f);
+    float e1, e2, beta = (float)p->beta;
+    script_perform_action_f32(p, delta, pot, &e1, &e2);            /* :98 */
+    float dlogp = delta_log_target_density_f32(e1, e2, beta);      /* :99 */
+    double r = g_custom_reward_f32 ? g_custom_reward_f32(delta, (float)p->x) : (double)(delta * delta);   /* :100, (delta)^2 in T */
+    delta = script_invert_f32(delta, p);                           /* :101 */
+    double logq_b = script_logq_f32(delta, p, theta);              /* :102 backward, at the new state */
+    script_dlogq_f32(delta, p, theta, d_b);
+    script_perform_action_f32(p, delta, pot, &e1, &e2);            /* :103 */
+    m->delta = (double)delta;
+    double alpha = julia_min(1.0, amo_exp((double)dlogp + logq_b - logq_f));   /* :104 */
+    double j = r * alpha;                                          /* :105 */
+    gd[0] = j;
+    for (int a = 0; a < P; ++a) {
+        gd[1 + a] = j * (alpha == 1.0 ? d_f[a] : d_b[a]);          /* :106 */
+        gd[1 + P + a] = d_f[a];
+        for (int b = 0; b < P; ++b) gd[1 + 2 * P + a * P + b] = d_f[a] * d_f[b];   /* :107 */
+    }
+}
+
 static void pgmc_sample_f32(particle_t *p, move_t *m, double sigma, int pot, double z, double gd[4])
 {
+    if (g_custom_logq) {
+        const double th[1] = { sigma };
+        pgmc_sample_script_f32(p, m, th, pot, z, gd);
+        return;
+    }
     if (g_custom_scale_f32) {
         double s_f = (double)g_custom_scale_f32((float)p->x), w_f = sigma * s_f;
         float delta = (float)(0.0 + w_f * z);
@@ -1565,7 +1652,8 @@ void amo_pg_estimate_records_vec(amo_sim *s, int n_learn, const int *learn_ids, 
                 double zz[2], gd[NF_MAX];
                 draw4(s, g >> 1, t, (uint32_t)(l * q_batch + q), AMO_STREAM_ESTIMATOR, v);
                 amo_box_muller(v, zz);
-                pgmc_sample_vec(&s->chains[c], &s->pools[c * s->K + lid], th, s->pot, zz[half], gd);
+                if (s->f32) pgmc_sample_script_f32(&s->chains[c], &s->pools[c * s->K + lid], th, s->pot, zz[half], gd);
+                else pgmc_sample_vec(&s->chains[c], &s->pools[c * s->K + lid], th, s->pot, zz[half], gd);
                 for (int i = 0; i < nf; ++i) {
                     if (!half) held[q][i] = gd[i];
                     if (half) xs_r_add(&col[i], (c > 0 ? held[q][i] : 0.0) + gd[i]);

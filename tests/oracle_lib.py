@@ -311,6 +311,11 @@ _CUSTOM_PROLOGUE = ("#include <cmath>\nusing std::sqrt; using std::fabs; using s
                     "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n")
 
 
+# Float32 twins: the hook's double arguments hold Float32 values; the expression sees them as floats
+_F32_X = "const float x = (float)x_; (void)x;"
+_F32_DX = "const float delta = (float)delta_; const float x = (float)x_; (void)delta; (void)x;"
+
+
 def _dual_dlogq_body(logq: str, n_params: int = 1) -> str:
     """C++ statements that leave d logq / d theta_p in out[p]: `logq` evaluated over dual numbers (ForwardDiff's rules above) with
     unit partials on the parameters; `sigma` is theta0, delta and x are constants."""
@@ -393,9 +398,11 @@ def install_custom_scale(expr: Optional[str]) -> None:
     lib.amo_set_custom_scale_f32(C.cast(_custom_libs[key].amo_user_scale_f32, C.c_void_p))
 
 
-def install_custom_proposal(proposal) -> None:
+def install_custom_proposal(proposal, f32: bool = False) -> None:
     """The oracle's global script-defined proposal: None restores the particle_1d Gaussian displacement; else
-    (sample, logq, dlogq or None) as C expressions in (z, x, sigma) / (delta, x, sigma), compiled by gcc."""
+    (sample, logq, dlogq or None) as C expressions in (z, x, sigma) / (delta, x, sigma), compiled by gcc.  f32: the twins of a
+    Float32 simulation -- the same text with x and delta as floats (C's usual arithmetic conversions restate Julia's promotion
+    rules), a Float32 value returned where the result lands in a field of type T (delta, x); the hooks keep double signatures."""
     import hashlib
     import tempfile
     lib = load()
@@ -420,20 +427,29 @@ def install_custom_proposal(proposal) -> None:
                      "double amo_user_dlogq(double delta, double x, double sigma_in) { const double theta[1] = {sigma_in}; double out[1]; "
                      + _dual_dlogq_body(logq, 1) + " return out[0]; }\n") +
                     (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
-                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
+                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") +
+                    # Float32 state: x and delta are floats inside
+                    f"double amo_user_sample_f32(double z, double x_, double sigma) {{ {_F32_X} return (double)(float)({sample}); }}\n"
+                    f"double amo_user_logq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} return (double)({logq}); }}\n" +
+                    (f"double amo_user_dlogq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} return (double)({dlogq}); }}\n" if dlogq else
+                     "double amo_user_dlogq_f32(double delta_, double x_, double sigma_in) { " + _F32_DX + " const double theta[1] = {sigma_in}; double out[1]; "
+                     + _dual_dlogq_body(logq, 1) + " return out[0]; }\n") +
+                    (f"double amo_user_perform_f32(double x_, double delta_) {{ {_F32_DX} return (double)(float)({perform}); }}\n"
+                     f"double amo_user_invert_f32(double delta_, double x_) {{ {_F32_DX} return (double)(float)({invert}); }}\n" if perform else "") + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     L = _custom_libs[key]
-    lib.amo_set_custom_proposal(C.cast(L.amo_user_sample, C.c_void_p), C.cast(L.amo_user_logq, C.c_void_p),
-                                C.cast(L.amo_user_dlogq, C.c_void_p))           # (the script's expression, or logq over dual numbers)
+    sfx = "_f32" if f32 else ""
+    lib.amo_set_custom_proposal(C.cast(getattr(L, "amo_user_sample" + sfx), C.c_void_p), C.cast(getattr(L, "amo_user_logq" + sfx), C.c_void_p),
+                                C.cast(getattr(L, "amo_user_dlogq" + sfx), C.c_void_p))     # (the script's expression, or logq over dual numbers)
     if perform:
-        lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
+        lib.amo_set_custom_action(C.cast(getattr(L, "amo_user_perform" + sfx), C.c_void_p), C.cast(getattr(L, "amo_user_invert" + sfx), C.c_void_p))
     else:
         lib.amo_set_custom_action(None, None)
 
 
-def install_vector_policy(n_params, proposal) -> None:
+def install_vector_policy(n_params, proposal, f32: bool = False) -> None:
     """The oracle's global policy with SEVERAL parameters (amo_set_vector_policy): proposal = (sample, logq, [dlogq_0 .. dlogq_{P-1}]
     or None[, perform, invert]) as C expressions in z / delta, x and theta0 .. theta{P-1} (`sigma` names theta0), compiled by
     gcc.  None restores the one-parameter forms."""
@@ -463,20 +479,29 @@ def install_vector_policy(n_params, proposal) -> None:
                      " ".join(f"out[{i}] = ({e});" for i, e in enumerate(dlogq)) + " }\n" if dlogq else
                      "void amo_vec_dlogq(double delta, double x, const double* theta, double* out) { " + _dual_dlogq_body(logq, P) + " }\n") +
                     (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
-                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") + "}\n")
+                     f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") +
+                    # Float32 state (see install_custom_proposal)
+                    f"double amo_vec_sample_f32(double z, double x_, const double* theta) {{ {_F32_X} {names} return (double)(float)({sample}); }}\n"
+                    f"double amo_vec_logq_f32(double delta_, double x_, const double* theta) {{ {_F32_DX} {names} return (double)({logq}); }}\n" +
+                    ("void amo_vec_dlogq_f32(double delta_, double x_, const double* theta, double* out) { " + _F32_DX + " " + names +
+                     " ".join(f"out[{i}] = (double)({e});" for i, e in enumerate(dlogq)) + " }\n" if dlogq else
+                     "void amo_vec_dlogq_f32(double delta_, double x_, const double* theta, double* out) { " + _F32_DX + " " + _dual_dlogq_body(logq, P) + " }\n") +
+                    (f"double amo_user_perform_f32(double x_, double delta_) {{ {_F32_DX} return (double)(float)({perform}); }}\n"
+                     f"double amo_user_invert_f32(double delta_, double x_) {{ {_F32_DX} return (double)(float)({invert}); }}\n" if perform else "") + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
                         src, "-o", so, LIB_PATH, "-lm", f"-Wl,-rpath,{ORACLE_DIR}"], check=True, capture_output=True)
         _custom_libs[key] = C.CDLL(so)
     L = _custom_libs[key]
-    lib.amo_set_vector_policy(P, C.cast(L.amo_vec_sample, C.c_void_p), C.cast(L.amo_vec_logq, C.c_void_p),
-                              C.cast(L.amo_vec_dlogq, C.c_void_p))
+    sfx = "_f32" if f32 else ""
+    lib.amo_set_vector_policy(P, C.cast(getattr(L, "amo_vec_sample" + sfx), C.c_void_p), C.cast(getattr(L, "amo_vec_logq" + sfx), C.c_void_p),
+                              C.cast(getattr(L, "amo_vec_dlogq" + sfx), C.c_void_p))
     if perform:
-        lib.amo_set_custom_action(C.cast(L.amo_user_perform, C.c_void_p), C.cast(L.amo_user_invert, C.c_void_p))
+        lib.amo_set_custom_action(C.cast(getattr(L, "amo_user_perform" + sfx), C.c_void_p), C.cast(getattr(L, "amo_user_invert" + sfx), C.c_void_p))
     else:
         lib.amo_set_custom_action(None, None)
 
 
-def install_policy_classes(classes, class_of_move) -> None:
+def install_policy_classes(classes, class_of_move, f32: bool = False) -> None:
     """The oracle's global policy CLASSES of a pool that mixes policy / action types (amo_set_policy_classes): classes = list of
     (sample, logq, dlogq or None, perform or None, invert or None) as C expressions; class_of_move[k] = the class of move k.
     None restores the one-policy forms."""
@@ -507,6 +532,17 @@ def install_policy_classes(classes, class_of_move) -> None:
             if perform:
                 body += f"double amo_cls_perform_{i}(double x, double delta) {{ return ({perform}); }}\n"
                 body += f"double amo_cls_invert_{i}(double delta, double x) {{ return ({invert}); }}\n"
+            # Float32 state (see install_custom_proposal)
+            body += f"double amo_cls_sample_f32_{i}(double z, double x_, double sigma) {{ {_F32_X} {th}return (double)(float)({sample}); }}\n"
+            body += f"double amo_cls_logq_f32_{i}(double delta_, double x_, double sigma) {{ {_F32_DX} {th}return (double)({logq}); }}\n"
+            if dlogq:
+                body += f"double amo_cls_dlogq_f32_{i}(double delta_, double x_, double sigma) {{ {_F32_DX} {th}return (double)({dlogq}); }}\n"
+            else:
+                body += (f"double amo_cls_dlogq_f32_{i}(double delta_, double x_, double sigma_in) {{ {_F32_DX} const double theta[1] = {{sigma_in}}; double out[1]; "
+                         + _dual_dlogq_body(logq, 1) + " return out[0]; }\n")
+            if perform:
+                body += f"double amo_cls_perform_f32_{i}(double x_, double delta_) {{ {_F32_DX} return (double)(float)({perform}); }}\n"
+                body += f"double amo_cls_invert_f32_{i}(double delta_, double x_) {{ {_F32_DX} return (double)(float)({invert}); }}\n"
         with open(src, "w") as f:
             f.write(_CUSTOM_PROLOGUE + body + "}\n")
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-math-errno",
@@ -516,7 +552,8 @@ def install_policy_classes(classes, class_of_move) -> None:
     n = len(cl)
 
     def ptrs(name, present):
-        return (C.c_void_p * n)(*[C.cast(getattr(L, f"amo_cls_{name}_{i}"), C.c_void_p) if present(cl[i]) else None for i in range(n)])
+        sfx = "_f32" if f32 else ""
+        return (C.c_void_p * n)(*[C.cast(getattr(L, f"amo_cls_{name}{sfx}_{i}"), C.c_void_p) if present(cl[i]) else None for i in range(n)])
     have_d = True            # a class without a derivative expression has its logq differentiated (dual numbers)
     com = (C.c_int * len(class_of_move))(*[int(v) for v in class_of_move])
     lib.amo_set_policy_classes(n, com, len(class_of_move), ptrs("sample", lambda c: True), ptrs("logq", lambda c: True),
@@ -557,9 +594,10 @@ class OracleSim:
             theta = [np.ascontiguousarray(v, dtype=np.float64).reshape(-1) for v in sigma]
             sigma = [float(v[0]) for v in theta]
         install_custom_scale(scale_expr)            # process-global like the potential: one simulation at a time
-        install_custom_proposal(None if self.n_params > 1 else proposal)
-        install_vector_policy(self.n_params, proposal if self.n_params > 1 else None)
-        install_policy_classes(classes, class_of_move)       # after the one-policy installer: it sets the script switches
+        f32 = dtype == "f32"
+        install_custom_proposal(None if self.n_params > 1 else proposal, f32)
+        install_vector_policy(self.n_params, proposal if self.n_params > 1 else None, f32)
+        install_policy_classes(classes, class_of_move, f32)       # after the one-policy installer: it sets the script switches
         install_custom_reward(reward_expr)          # process-global, like the reference's script-level definition
         self.M = int(n_chains)
         self.K = len(sigma)

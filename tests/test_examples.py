@@ -72,3 +72,18 @@ def test_pgmc_langevin_policy_example(gpu, tmp_path, capsys):
     assert sg > 0.4 and sl > 0.4 and sg != sl                               # both learnt from 0.3
     rows = np.loadtxt(tmp_path / "langevin" / "energy.dat", usecols=(0, 1))
     assert rows[rows[:, 0] >= 300, 1].mean() == pytest.approx(0.25, abs=6e-3)          # <e> = 1 / (2 beta): the sampler stays exact
+
+
+def test_pgmc_langevin_policy_example_with_float32_state(gpu, tmp_path, capsys):
+    """The same script with Particle{Float32}: the policy's expressions see x and delta as Float32 (the generic functions of a model
+    are generic in T, particle_1d.jl:9,26), the step sizes are learned, the target distribution is kept."""
+    import pgmc_langevin_policy as ex
+    sim = ex.main(["--chains", "40000", "--steps", "400", "--dtype", "f32", "--path", str(tmp_path / "langevin32")])
+    capsys.readouterr()
+    assert "Particle{Float32} x 40000" in open(tmp_path / "langevin32" / "summary.log").read()
+    pool = sim.algorithms[0].pool
+    assert float(pool[0].parameters[0]) > 0.4 and float(pool[1].parameters[0]) > 0.4
+    x = sim.chains.x
+    assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    rows = np.loadtxt(tmp_path / "langevin32" / "energy.dat", usecols=(0, 1))
+    assert rows[rows[:, 0] >= 200, 1].mean() == pytest.approx(0.25, abs=8e-3)

@@ -70,8 +70,7 @@ def test_argument_validation_needs_no_gpu(amc):
         amc.HipEngine(proposal=("sigma*x", LOGQ, None), **kw)
     with pytest.raises(amc.AmcError, match="does not mention delta"):
         amc.HipEngine(proposal=(SAMPLE, "x*x", None), **kw)
-    with pytest.raises(amc.AmcError, match="Float64 state"):
-        amc.HipEngine(proposal=MALA, dtype="f32", **kw)
+    # (Float32 state is no error any more: tests/test_f32_script_policy.py)
     with pytest.raises(amc.AmcError, match="not allowed"):
         amc.HipEngine(proposal=(SAMPLE + "; }", LOGQ, None), **kw)
     with pytest.raises(amc.AmcError, match="cannot be combined"):
