@@ -639,22 +639,31 @@ int amc_create_custom(const amc_config* cfg, const char* potential_expr, amc_han
     return create_impl(cfg, potential_expr, out);
 }
 
+// The creators of run-time compiled models: the potential's text (the script's, or the built-in's own expression where the script
+// names cfg->potential -- compiled at run time it is the built-in bit for bit; with Float32 state the double well subtracts a Float32
+// one, as Julia's `(x^2 - 1)^2` does) and the caller's config as an AMC_POTENTIAL_CUSTOM one (a 0.1 caller's struct is shorter).
+static int as_custom_model(const amc_config* cfg, const char* potential_expr, const char* who, const char** pot, amc_config* c2)
+{
+    *pot = potential_expr;
+    if (!*pot) {
+        const bool f32 = cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32;
+        if (cfg->potential == AMC_POTENTIAL_HARMONIC) *pot = "x*x";
+        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL) *pot = f32 ? "(x*x - 1.0f)*(x*x - 1.0f)" : "(x*x - 1.0)*(x*x - 1.0)";
+        else return fail(AMC_ERR_BAD_ARG, "%s: potential_expr is NULL and cfg->potential names no built-in", who);
+    }
+    std::memset(c2, 0, sizeof(*c2));
+    std::memcpy(c2, cfg, cfg->struct_size < sizeof(*c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(*c2));
+    c2->potential = AMC_POTENTIAL_CUSTOM;
+    return AMC_OK;
+}
+
 int amc_create_model(const amc_config* cfg, const char* potential_expr, const char* reward_expr, amc_handle** out)
 {
     if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_model: NULL argument");
     // a built-in potential with a custom reward: the built-in's own expression, compiled at run time (bit-identical)
-    const char* pot = potential_expr;
-    if (!pot) {
-        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
-            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
-                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
-        else return fail(AMC_ERR_BAD_ARG, "amc_create_model: potential_expr is NULL and cfg->potential names no built-in");
-    }
+    const char* pot = nullptr;
     amc_config c2;
-    std::memset(&c2, 0, sizeof(c2));
-    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));   // a 0.1 caller's struct is shorter
-    c2.potential = AMC_POTENTIAL_CUSTOM;
+    { const int rc = as_custom_model(cfg, potential_expr, "amc_create_model", &pot, &c2); if (rc != AMC_OK) return rc; }
     return create_impl(&c2, pot, out, reward_expr);
 }
 
@@ -663,18 +672,9 @@ int amc_create_policy_model(const amc_config* cfg, const char* potential_expr, c
 {
     if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_policy_model: NULL argument");
     if (!scale_expr) return amc_create_model(cfg, potential_expr, reward_expr, out);
-    const char* pot = potential_expr;
-    if (!pot) {
-        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)
-            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
-                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
-        else return fail(AMC_ERR_BAD_ARG, "amc_create_policy_model: potential_expr is NULL and cfg->potential names no built-in");
-    }
+    const char* pot = nullptr;
     amc_config c2;
-    std::memset(&c2, 0, sizeof(c2));
-    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
-    c2.potential = AMC_POTENTIAL_CUSTOM;
+    { const int rc = as_custom_model(cfg, potential_expr, "amc_create_policy_model", &pot, &c2); if (rc != AMC_OK) return rc; }
     return create_impl(&c2, pot, out, reward_expr, scale_expr);
 }
 
@@ -700,18 +700,9 @@ int amc_create_vector_policy_model(const amc_config* cfg, int n_params, const ch
     if (dlogq_exprs)
         for (int p = 0; p < n_params; ++p)
             if (!dlogq_exprs[p]) return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: dlogq_exprs[%d] is NULL (one expression per parameter, or none at all)", p);
-    const char* pot = potential_expr;
-    if (!pot) {
-        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
-            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
-                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
-        else return fail(AMC_ERR_BAD_ARG, "amc_create_vector_policy_model: potential_expr is NULL and cfg->potential names no built-in");
-    }
+    const char* pot = nullptr;
     amc_config c2;
-    std::memset(&c2, 0, sizeof(c2));
-    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
-    c2.potential = AMC_POTENTIAL_CUSTOM;
+    { const int rc = as_custom_model(cfg, potential_expr, "amc_create_vector_policy_model", &pot, &c2); if (rc != AMC_OK) return rc; }
     const ProposalExprs prop = {sample_expr, logq_expr, dlogq_exprs ? dlogq_exprs[0] : nullptr, perform_expr, invert_expr, n_params,
                                 dlogq_exprs ? dlogq_exprs + 1 : nullptr, 1, nullptr, nullptr};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
@@ -724,18 +715,9 @@ int amc_create_action_model(const amc_config* cfg, const char* potential_expr, c
     if (!cfg) return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: NULL argument");
     if (!sample_expr || !logq_expr)
         return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: sample_expr and logq_expr are both required (No sample_action! / log_proposal_density is defined)");
-    const char* pot = potential_expr;
-    if (!pot) {
-        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
-            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
-                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
-        else return fail(AMC_ERR_BAD_ARG, "amc_create_proposal_model: potential_expr is NULL and cfg->potential names no built-in");
-    }
+    const char* pot = nullptr;
     amc_config c2;
-    std::memset(&c2, 0, sizeof(c2));
-    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
-    c2.potential = AMC_POTENTIAL_CUSTOM;
+    { const int rc = as_custom_model(cfg, potential_expr, "amc_create_proposal_model", &pot, &c2); if (rc != AMC_OK) return rc; }
     const ProposalExprs prop = {sample_expr, logq_expr, dlogq_expr, perform_expr, invert_expr, 1, nullptr, 1, nullptr, nullptr};
     return create_impl(&c2, pot, out, reward_expr, nullptr, &prop);
 }
@@ -758,18 +740,9 @@ int amc_create_mixed_model(const amc_config* cfg, int n_classes, const int* clas
         const bool p = perform_exprs && perform_exprs[c], i = invert_exprs && invert_exprs[c];
         if (p != i) return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: class %d: perform_expr and invert_expr come together (No invert_action! is defined)", c);
     }
-    const char* pot = potential_expr;
-    if (!pot) {
-        if (cfg->potential == AMC_POTENTIAL_HARMONIC) pot = "x*x";
-        else if (cfg->potential == AMC_POTENTIAL_DOUBLE_WELL)   // Float32 state: the built-in subtracts a Float32 one
-            pot = (cfg->struct_size == sizeof(amc_config) && cfg->state_dtype == AMC_DTYPE_F32) ? "(x*x - 1.0f)*(x*x - 1.0f)"
-                                                                                                : "(x*x - 1.0)*(x*x - 1.0)";
-        else return fail(AMC_ERR_BAD_ARG, "amc_create_mixed_model: potential_expr is NULL and cfg->potential names no built-in");
-    }
+    const char* pot = nullptr;
     amc_config c2;
-    std::memset(&c2, 0, sizeof(c2));
-    std::memcpy(&c2, cfg, cfg->struct_size < sizeof(c2) ? (cfg->struct_size >= 4 ? cfg->struct_size : 4) : sizeof(c2));
-    c2.potential = AMC_POTENTIAL_CUSTOM;
+    { const int rc = as_custom_model(cfg, potential_expr, "amc_create_mixed_model", &pot, &c2); if (rc != AMC_OK) return rc; }
     ClassExprs more[AMC_MAX_CLASSES];
     for (int c = 1; c < n_classes; ++c)
         more[c - 1] = ClassExprs{sample_exprs[c], logq_exprs[c], dlogq_exprs ? dlogq_exprs[c] : nullptr, perform_exprs ? perform_exprs[c] : nullptr,
