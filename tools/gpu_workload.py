@@ -6,6 +6,8 @@
   pgmc         BASELINE config 5: amc_pgmc_steps at 1e7 chains (fused sweep + estimator + update per step), callbacks every 10
   est          the estimator launch alone (amc_pg_accumulate) on the config-5 pool
   vec / vec1 / mixed   PGMC time steps of a two-parameter policy, its one-parameter script twin, a pool of two policy classes
+  pgmc7        the pool of the reference's test/pgmc_test.jl:16-27 at 1e7 chains: K = 7 Gaussian displacements, six of them learnable, one
+               optimiser each (VPG .. BLANPG), q_batch_size = 10 (QBATCH), sweep + estimator + learning step per time step
 Environment: LAUNCHES, PIPELINED, PRECOUNT, COLS (which sums the callbacks ask for), COMM=1 (pgmc: connect a one-rank communicator).
 """
 import os, sys, time
@@ -114,6 +116,25 @@ elif mode in ("pgmc", "est"):
                 e.pg_accumulate([1], 1)
         us = e.timing_end() * 1e3 / (n // 10 * 10 if mode == "pgmc" else n)
     print(f"{mode}: {us:.2f} us per {'time step incl. callbacks every 10' if mode == 'pgmc' else 'estimator launch'}{' (callback read one period later)' if PIPELINED and mode == 'pgmc' else ''}; sigma = {e.get_parameters(1)[0]:.4f}")
+elif mode == "pgmc7":
+    M = int(os.environ.get("CHAINS", "10000000"))
+    q = int(os.environ.get("QBATCH", "10"))
+    e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1] * 7, weight=[0.4] + [0.1] * 6, seed=42)
+    learn, kinds = [1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6]
+    h0, h1 = [0.001, 0.001, 1e-6, 1e-2, 1e-6, 1e-6], [0.0, 0.0, 1e-6, 1e-6, 1e-6, 1e-6]
+    e.init_uniform(-2, 2)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        e.pgmc_steps(2, learn, q, kinds, h0, h1)
+        e.sync()
+    n = min(n, 60)
+    for rep in range(2):
+        e.timing_begin()
+        e.pgmc_steps(n, learn, q, kinds, h0, h1)
+        us = e.timing_end() * 1e3 / n
+    samples = M * (1 + len(learn) * q)
+    print(f"pgmc7: {us:.1f} us per PGMC time step (K = 7 sweep + {len(learn)} learnable moves x {q} samples + learning steps) = "
+          f"{us / (1 + len(learn) * q) / (M / 1e7):.2f} us per proposal of 1e7 chains; {samples / us * 1e6:.3e} proposals/s; sigma = {[round(float(e.get_parameters(k)[0]), 5) for k in range(7)]}")
 elif mode in ("vec", "mixed", "vec1", "vec_auto", "vec1_auto", "mixed_auto", "vec_mul"):
     # the PGMC time step of a policy with SEVERAL parameters (vec: the drift + width proposal delta = theta0 + theta1 z, one
     # learnable move, VPG), of its one-parameter twin written as a script (vec1: what the several-parameter forms are compared
