@@ -204,8 +204,9 @@ int  amc_create_proposal_model(const amc_config *cfg, const char *potential_expr
  *   - every output that holds GradientData has AMC_GD_STRIDE_P(P) = 2 + 2P + P^2 doubles (records) per learnable move:
  *     j, grad j [P], grad logq_forward [P], g [P][P] row by row, n  (P = 1: the five of AMC_GD_*);
  *   - the estimator takes one launch per learnable move (1 + 2P + P(P+1)/2 reproducible column sums: g is symmetric), the
- *     accumulate and update steps one tiny launch each; with ONE learnable move (and no communicator) amc_pgmc_steps takes the
- *     whole time step -- sweep, estimator, learning step -- in one launch (amc_pg_route says which route a call gets);
+ *     accumulate and update steps ride in that launch's own tail on a single shard (between shards: records, all-reduce, one tiny
+ *     launch each); with ONE learnable move amc_pgmc_steps takes the whole time step -- sweep, estimator, learning step -- in one
+ *     launch, with several the sweep rides in the first move's launch (amc_pg_route says which route a call gets);
  *   - a learning step that leaves a parameter non-finite, or meets a singular g + eps I, is not applied (as for P = 1:
  *     reported by amc_pg_get_accumulated);
  *   - inv(g + eps I) is Gauss-Jordan elimination with partial pivoting (amc::pg_inv_small) where Julia calls LAPACK's

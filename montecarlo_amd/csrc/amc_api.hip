@@ -504,6 +504,7 @@ static int create_impl(const amc_config* cfg, const char* potential_expr, amc_ha
     if (const char* env = std::getenv("AMC_NO_DEFERRED_UPDATE")) h->no_deferred_update = std::atoi(env) != 0;
     if (const char* env = std::getenv("AMC_CLASS_PER_MOVE")) h->class_per_move_forced = std::atoi(env) != 0;
     if (const char* env = std::getenv("AMC_NO_COLUMN_SKIP")) h->no_column_skip = std::atoi(env) != 0;
+    if (const char* env = std::getenv("AMC_NP_SMALL_LAUNCHES")) h->np_small_launches = std::atoi(env) != 0;
     h->M = cfg->n_chains;
     // padding: unclamped 16-B tail loads stay in bounds; rows of every per-chain array start on a 256-byte boundary
     // (M_pad is a multiple of 256): a wave's 128-byte step-log store then covers exactly one aligned line

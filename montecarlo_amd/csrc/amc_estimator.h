@@ -496,8 +496,8 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
 #if AMC_NP > 1
         // a policy with several parameters: the launch's one learnable move (the host sees to it), its 1 + 2P + P(P+1)/2 totals
         if (tail_mode >= 2)
-            pg_tail_np(s_tot, AMC_NP, tl->learn_ids[0], tl->n_samples, tail_mode >= 3, tl->opt.kind[0], tl->opt.h0[0], tl->opt.h1[0],
-                       tl->ptab_rw, tl->gd_acc, tl->status);
+            pg_tail_np(s_tot, AMC_NP, tl->learn_ids[a.l_base], tl->n_samples, tail_mode >= 3, tl->opt.kind[a.l_base], tl->opt.h0[a.l_base],
+                       tl->opt.h1[a.l_base], tl->ptab_rw, tl->gd_acc, tl->status);      // (the record describes the estimator call; l_base: this launch's move)
 #else
         if (tail_mode >= 3) {
             // (theta: the sigma this launch proposed with -- in registers; the table's, or sigma' of a pending step)

@@ -148,6 +148,7 @@ struct amc_handle {
                                                    // the compiler's last words about each (amc_pg.hip class_general_route, amc_pg_route)
     std::string class_form_error;   // ... of the form the last class_general_route call asked about ("" when it builds)
     bool no_column_skip = false;    // env AMC_NO_COLUMN_SKIP=1 (A/B, tests): fused script-defined steps sum every GradientData column whatever the optimiser reads
+    bool np_small_launches = false;    // A/B knob (AMC_NP_SMALL_LAUNCHES=1): several parameters, several learnable moves: records + the small accumulate / update launches, as before round 6
     bool class_per_move_forced = false;     // env AMC_CLASS_PER_MOVE=1 (read at amc_create; A/B, tests): class pools take one estimator launch per learnable move
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_hist = nullptr;   // running histogram of amc_histogram_accumulate: [hist_bins + 3]

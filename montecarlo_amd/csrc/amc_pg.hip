@@ -200,6 +200,11 @@ static bool per_move_launches(const amc_handle* h) { return h->n_params > 1; }
 // ... of which a policy with several parameters (one class) has the single-launch forms too when ONE move learns: the launch's
 // tail is generic in P (pg_tail_np), so sweep + estimator + gradients_data += + learning step are one launch as for P = 1
 static bool np_single_launch(const amc_handle* h, int n_learn) { return h->n_params > 1 && h->n_classes == 1 && n_learn == 1; }
+// ... and with SEVERAL learnable moves on one shard, a chain of such launches, one per move, each with its own tail (pg_accumulate_impl)
+static bool np_move_chain(const amc_handle* h, int n_learn)
+{
+    return h->n_params > 1 && h->n_classes == 1 && !h->comm && n_learn > 1 && !h->np_small_launches;
+}
 
 // A pool of several classes: does this call go down the general route?  *general = the kernel form the call needs builds.  The
 // compiler is asked at most once per form and process (rtc_compile keeps what it learnt, failures included, and so does the
@@ -236,9 +241,12 @@ static int class_general_route(amc_handle* h, int n_learn, bool with_sweep, bool
 // reduce (with_sweep only): the launch also leaves the callback sums of the state it stores in the next reduction ticket's rows.
 // l_base, advance (policies with several parameters: one launch per learnable move): the move's index in the estimator call,
 // and whether this launch is the call's last (the estimator's step counter then advances).
+// call_ids, call_n (a policy with several parameters, one launch per learnable move with the launch's own tail): the estimator CALL's
+// learnable moves -- the tail's record (ids, optimisers) then describes the call, the launch names its move by l_base, and the record
+// stays what it is from launch to launch (a rewrite is a 5 us launch of its own).
 static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, int* nl_out,
                      int tail = 1, const amc::PgOpts* opt = nullptr, bool with_sweep = false, bool reduce = false,
-                     int* grid_out = nullptr, int l_base = 0, bool advance = true)
+                     int* grid_out = nullptr, int l_base = 0, bool advance = true, const int* call_ids = nullptr, int call_n = 0)
 {
     if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
     if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
@@ -271,7 +279,8 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
     a.tail_mode = tail;
     // a script-defined form whose own tail takes the learning step: the column groups the moves' optimisers never read are not summed
     // (amc_estimator.h; gradients_data is consumed and reset in that tail, so nothing of them could be seen afterwards)
-    if (opt && (tail == 3 || tail == (int)amc::PG_TAIL_GROUPS) && h->use_rtc && !h->no_column_skip) a.tail_mode |= amc::pg_skip_bits(opt->kind, n_learn);
+    if (opt && (tail == 3 || tail == (int)amc::PG_TAIL_GROUPS) && h->use_rtc && !h->no_column_skip)
+        a.tail_mode |= amc::pg_skip_bits(opt->kind + (call_ids ? l_base : 0), n_learn);
     a.l_base = l_base;
     {
         amc::PgTail tl;
@@ -290,7 +299,9 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
         tl.n_ranks = h->comm ? h->comm_ranks : 1;
         // (a launch that only leaves records -- one per learnable move of a several-parameter policy or a pool of classes -- reads
         // neither the ids nor the optimisers from the record: kept out, or every such launch would rewrite it, 4.7 us each)
-        if (tail != 1 || !(per_move_launches(h) || h->n_classes > 1))
+        if (call_ids)
+            for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = l < call_n ? call_ids[l] : 0;
+        else if (tail != 1 || !(per_move_launches(h) || h->n_classes > 1))
             for (int l = 0; l < AMC_MAX_LEARN; ++l) tl.learn_ids[l] = a.learn_ids[l];
         if (opt) tl.opt = *opt;
         // a learning step the previous fused launch left pending: this launch takes it in its prologue if it is the very next
@@ -478,6 +489,23 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     int nl = 0;
     bool general = true;
     { const int rcg = class_general_route(h, n_learn, with_sweep, reduce, q_batch, &general); if (rcg != AMC_OK) return rcg; }
+    if (np_move_chain(h, n_learn)) {
+        // several parameters, several learnable moves, one shard: one launch per move whose own tail folds, accumulates and (opt) takes
+        // the move's learning step -- what np_single_launch does for one move, move after move.  A move's estimator reads its own
+        // parameters and the positions only (estimator.jl:111-129), so a learning step taken before the next move's samples are drawn
+        // changes nothing those samples see; the draws are named by the move's index in the call (l_base), as ever.
+        uint64_t ids_mask = 0;
+        for (int l = 0; l < n_learn; ++l) {
+            // (with_sweep: the time step's make_step!(::Metropolis) rides in the first move's launch, as in the one-move fused step)
+            const int rc = pg_launch(h, "amc_pg_accumulate", 1, learn_ids + l, q_batch, &nl, opt ? 3 : 2, opt, with_sweep && l == 0, false, nullptr, l,
+                                     l + 1 == n_learn, learn_ids, n_learn);
+            if (rc != AMC_OK) return rc;
+            ids_mask |= 1ull << (learn_ids[l] & 63);
+        }
+        if (opt) h->gd_nonzero &= ~ids_mask;
+        else h->gd_nonzero |= ids_mask;
+        return AMC_OK;
+    }
     if ((per_move_launches(h) && !(np_single_launch(h, n_learn) && !h->comm)) || !general) {
         // per learnable move: estimator launch (records in d_out), the gather across shards, gradients_data[k] += gd
         if (with_sweep) return fail(AMC_ERR_STATE, "amc_pg_accumulate: no fused time step for a policy with several parameters (a pool of several classes whose fused form does not build)");
@@ -656,12 +684,16 @@ static int pgmc_steps_impl(amc_handle* h, const char* who, int64_t n_steps, int 
     // (pools of more than AMC_PACKED_LOG_MOVES moves take the two launches: the fused forms write the packed step log)
     bool fused = (!per_move_launches(h) || (np_single_launch(h, n_learn) && !h->comm)) && h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && n_learn >= 1 && n_learn <= 2 &&
                  log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
+    // several parameters, several learnable moves, one shard: the sweep rides in the first move's launch of the chain
+    const bool chain = np_move_chain(h, n_learn);
+    if (chain)
+        fused = h->sweepstep == 1 && (h->d_log != nullptr || h->K == 1) && log_form(h) != AMC_LOG_BYTES && std::getenv("AMC_NO_SWEEP_ESTIMATOR_FUSION") == nullptr;
     if (fused && h->n_classes > 1) {      // a pool of several classes: the fused form where it builds (class_general_route)
         const int rcg = class_general_route(h, n_learn, true, false, q_batch, &fused);
         if (rcg != AMC_OK) return rcg;
     }
     // the callback sums ride in the last fused launch (rows the host sums: K <= 4; launches that need no flush on the way)
-    bool fused_reduce = reduce && fused && h->K <= 4 && !h->d_acc_base;
+    bool fused_reduce = reduce && fused && !chain && h->K <= 4 && !h->d_acc_base;
     if (fused_reduce && h->n_classes > 1) {
         const int rcg = class_general_route(h, n_learn, true, true, q_batch, &fused_reduce);
         if (rcg != AMC_OK) return rcg;

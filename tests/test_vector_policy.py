@@ -366,6 +366,46 @@ def test_one_learnable_move_takes_the_single_launch_time_step(gpu, oracle, opt, 
 
 
 @pytest.mark.gpu
+def test_two_learnable_moves_take_a_chain_of_launches(gpu, oracle, monkeypatch):
+    """Several parameters AND several learnable moves on one shard (round 6): one launch per move, each with its own tail -- fold,
+    gradients_data +=, the move's learning step --, the time step's sweep riding in the first: two launches where the records route
+    took seven (sweep, two estimator launches, two accumulate and two update launches; 260 -> 202 us at 1e7 chains).  A different
+    optimiser per move (the tail's record describes the CALL, the launch names its move), callbacks in the same stretch, steps without
+    an update: the same bits as the records route and as the free-running oracle."""
+    kinds, h0, h1 = [4, 2], [5e-3, 2e-2], [1e-6, 0.0]                       # NPG on move 1, BLPG on move 2
+    eng, ref = _pair(gpu, oracle, 20011, DRIFT, 2, [[0.1, 0.3], [0.0, 0.8]], [0.5, 0.5])
+    monkeypatch.setenv("AMC_NP_SMALL_LAUNCHES", "1")
+    old, _ref2 = _pair(gpu, oracle, 20011, DRIFT, 2, [[0.1, 0.3], [0.0, 0.8]], [0.5, 0.5])
+    monkeypatch.delenv("AMC_NP_SMALL_LAUNCHES")
+    ids = [0, 1]
+    assert eng.pg_route(2, 2, fused=True)[0] is False                       # one launch per learnable move, as the route says
+    for stretch in (1, 2, 7):
+        for e in (eng, old, ref):
+            e.pgmc_steps(stretch, ids, 2, kinds, h0, h1)
+        for k in ids:
+            assert np.array_equal(bits(eng.get_parameters(k)), bits(ref.get_parameters(k))), (stretch, k)
+            assert np.array_equal(bits(eng.get_parameters(k)), bits(old.get_parameters(k))), (stretch, k)
+    for e in (eng, old, ref):
+        e.pgmc_steps(3, ids, 1, kinds, h0, h1, reduce_begin=True)
+    (ra, sa), (rb, sb), (rc, sc) = eng.reduce_end_exact(), ref.reduce_end_exact(), old.reduce_end_exact()
+    assert np.array_equal(ra, rb) and np.array_equal(ra, rc) and sa == sb == sc
+    for e in (eng, old, ref):
+        e.pgmc_steps(2, ids, 3)                                              # estimator steps, no update: the accumulators fill
+    acc = eng.pg_get_accumulated(ids)
+    assert np.array_equal(bits(acc), bits(ref.pg_get_accumulated(ids))) and np.array_equal(bits(acc), bits(old.pg_get_accumulated(ids)))
+    assert acc[0, -1] == 2 * 3 * 20011
+    x = eng.download_state()[0]
+    assert np.array_equal(bits(x), bits(ref.download_state()[0])) and np.array_equal(bits(x), bits(old.download_state()[0]))
+    a, t = eng.download_counters()
+    ao, to = ref.download_counters()
+    assert np.array_equal(a, ao) and np.array_equal(t, to)
+    assert eng.estimator_step == ref.estimator_step == old.estimator_step
+    eng.close()
+    old.close()
+    oracle.install_vector_policy(1, None)
+
+
+@pytest.mark.gpu
 def test_single_launch_time_step_of_a_three_parameter_policy(gpu, oracle):
     eng, ref = _pair(gpu, oracle, 9001, LEAN, 3, [[0.0, 0.6, -0.1]], [1.0])
     for stretch in (1, 7):

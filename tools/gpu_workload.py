@@ -135,7 +135,7 @@ elif mode == "pgmc7":
     samples = M * (1 + len(learn) * q)
     print(f"pgmc7: {us:.1f} us per PGMC time step (K = 7 sweep + {len(learn)} learnable moves x {q} samples + learning steps) = "
           f"{us / (1 + len(learn) * q) / (M / 1e7):.2f} us per proposal of 1e7 chains; {samples / us * 1e6:.3e} proposals/s; sigma = {[round(float(e.get_parameters(k)[0]), 5) for k in range(7)]}")
-elif mode in ("vec", "mixed", "vec1", "vec_auto", "vec1_auto", "mixed_auto", "vec_mul"):
+elif mode in ("vec", "mixed", "vec1", "vec_auto", "vec1_auto", "mixed_auto", "vec_mul", "vec2"):
     # the PGMC time step of a policy with SEVERAL parameters (vec: the drift + width proposal delta = theta0 + theta1 z, one
     # learnable move, VPG), of its one-parameter twin written as a script (vec1: what the several-parameter forms are compared
     # with), and of a pool that mixes two policy classes (mixed: Gaussian + Langevin, one learnable move each)
@@ -159,6 +159,10 @@ elif mode in ("vec", "mixed", "vec1", "vec_auto", "vec1_auto", "mixed_auto", "ve
         e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5]], weight=[1.0], seed=42,
                         proposal=DRIFT if mode == "vec" else (DRIFT[0], DRIFT[1], None), n_params=2)
         learn, kinds, h0 = [0], [1], [1e-3]
+    elif mode == "vec2":
+        # two moves of the two-parameter policy, both learnable: one estimator launch per move (amc_pg_route says so)
+        e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[[0.0, 0.5], [0.1, 0.9]], weight=[0.5, 0.5], seed=42, proposal=DRIFT, n_params=2)
+        learn, kinds, h0 = [0, 1], [1, 1], [1e-3, 1e-3]
     elif mode in ("vec1", "vec1_auto"):
         e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.5], weight=[1.0], seed=42,
                         proposal=GAUSS if mode == "vec1" else (GAUSS[0], GAUSS[1], None))
