@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats -d $O/bench_trace --output-format csv -- python
 echo "bench trace done"
 W="python3 $R/tools/gpu_workload.py"
 export AMC_RTC_CACHE_DIR=$O/rtc_cache; mkdir -p $AMC_RTC_CACHE_DIR      # the script-defined workloads build once, outside the profiled runs
-for wl in vec1 vec mixed; do python3 $R/tools/gpu_workload.py $wl > /dev/null 2>&1; done
+for wl in vec1 vec mixed vec2; do python3 $R/tools/gpu_workload.py $wl > /dev/null 2>&1; done
 export PIPELINED=1      # callbacks read one period late, as the host mirror's StoreCallbacks does; the at-once figure is logged next to it
 # k2 / pgmc: BASELINE configs 3 / 5 (callbacks every 10 ask for sum e: COLS=1, the callbacks of those configs); vec1 / vec / mixed: the PGMC
 # time step of a script-defined one-parameter policy, of the two-parameter drift + width policy, of a two-class pool (round 5)
@@ -32,6 +32,12 @@ for wl in "ladder 10000000" "ladder 40000000" "ladder 160000000" "k2" "pgmc" "es
   LAUNCHES=120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/$tag/pmc_sq --output-format csv -- $W $wl > /dev/null 2>&1
   LAUNCHES=120 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace -d $O/$tag/pmc_sq2 --output-format csv -- $W $wl > /dev/null 2>&1
   echo "$tag done: $(cat $O/$tag.log | tail -1)"
+done
+# kernel traces only: the K = 2 pool of the two-parameter policy with both moves learnable (a chain of launches), the pool of the
+# reference's test/pgmc_test.jl (K = 7, six optimisers, q_batch_size = 10)
+for wl in vec2 pgmc7; do
+  rocprofv3 --kernel-trace --stats -d $O/$wl/trace --output-format csv -- $W $wl > $O/$wl.log 2>&1
+  echo "$wl done: $(cat $O/$wl.log | tail -1)"
 done
 # the per-dispatch traces and counter tables are large (gpurun merges at most 64 MiB back): summarise them here, keep
 # the summaries (gpurun_out/${TAG}_out/ -> copied into profiles/ by hand) and drop the raw tables
