@@ -330,7 +330,7 @@ def test_free_running_pgmc_with_three_and_four_parameters(gpu, oracle, case, opt
 @pytest.mark.parametrize("shape", ["K1", "K2"])
 def test_one_learnable_move_takes_the_single_launch_time_step(gpu, oracle, opt, shape):
     """ONE move of a several-parameter policy learns: sweep + estimator + gradients_data += + learning step are ONE launch per
-    time step (round 5; the tail is generic in P), where two learnable moves take a launch each plus two small ones.  Same
+    time step (round 5; the tail is generic in P), where two learnable moves take a launch each (round 6: with their tails in them).  Same
     bits as the free-running oracle after every stretch -- parameter vectors, positions, counters, the callback sums that ride
     in the last launch, and the accumulators when no update follows."""
     name, kind, h0, h1 = opt
