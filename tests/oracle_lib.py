@@ -311,6 +311,7 @@ _CUSTOM_PROLOGUE = ("#include <cmath>\nusing std::sqrt; using std::fabs; using s
                     "#define amc_exp(v) amo_exp(v)\n#define amc_log(v) amo_log(v)\n")
 
 
+_TH0 = "const double theta0 = sigma; (void)theta0; "      # theta0 is another name of sigma (amc_model.h AMC_USER_THETAS)
 # Float32 twins: the hook's double arguments hold Float32 values; the expression sees them as floats
 _F32_X = "const float x = (float)x_; (void)x;"
 _F32_DX = "const float delta = (float)delta_; const float x = (float)x_; (void)delta; (void)x;"
@@ -421,17 +422,17 @@ def install_custom_proposal(proposal, f32: bool = False) -> None:
         src, so = os.path.join(d, "prop.cpp"), os.path.join(d, f"prop_{key}.so")
         with open(src, "w") as f:
             f.write(_CUSTOM_PROLOGUE +
-                    f"double amo_user_sample(double z, double x, double sigma) {{ return ({sample}); }}\n"
-                    f"double amo_user_logq(double delta, double x, double sigma) {{ return ({logq}); }}\n" +
-                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ return ({dlogq}); }}\n" if dlogq else
+                    f"double amo_user_sample(double z, double x, double sigma) {{ {_TH0}return ({sample}); }}\n"
+                    f"double amo_user_logq(double delta, double x, double sigma) {{ {_TH0}return ({logq}); }}\n" +
+                    (f"double amo_user_dlogq(double delta, double x, double sigma) {{ {_TH0}return ({dlogq}); }}\n" if dlogq else
                      "double amo_user_dlogq(double delta, double x, double sigma_in) { const double theta[1] = {sigma_in}; double out[1]; "
                      + _dual_dlogq_body(logq, 1) + " return out[0]; }\n") +
                     (f"double amo_user_perform(double x, double delta) {{ return ({perform}); }}\n"
                      f"double amo_user_invert(double delta, double x) {{ return ({invert}); }}\n" if perform else "") +
                     # Float32 state: x and delta are floats inside
-                    f"double amo_user_sample_f32(double z, double x_, double sigma) {{ {_F32_X} return (double)(float)({sample}); }}\n"
-                    f"double amo_user_logq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} return (double)({logq}); }}\n" +
-                    (f"double amo_user_dlogq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} return (double)({dlogq}); }}\n" if dlogq else
+                    f"double amo_user_sample_f32(double z, double x_, double sigma) {{ {_F32_X} {_TH0}return (double)(float)({sample}); }}\n"
+                    f"double amo_user_logq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} {_TH0}return (double)({logq}); }}\n" +
+                    (f"double amo_user_dlogq_f32(double delta_, double x_, double sigma) {{ {_F32_DX} {_TH0}return (double)({dlogq}); }}\n" if dlogq else
                      "double amo_user_dlogq_f32(double delta_, double x_, double sigma_in) { " + _F32_DX + " const double theta[1] = {sigma_in}; double out[1]; "
                      + _dual_dlogq_body(logq, 1) + " return out[0]; }\n") +
                     (f"double amo_user_perform_f32(double x_, double delta_) {{ {_F32_DX} return (double)(float)({perform}); }}\n"

@@ -149,3 +149,61 @@ def test_dual_partials_agree_with_central_differences(tmp_path):
             lib.fuzz_eval(k, 16, lo.ctypes.data, vl.ctypes.data, twin.ctypes.data)
             fd = (vh[:, 0] - vl[:, 0]) / (2 * h)
             assert np.allclose(out[:, 1 + p], fd, rtol=2e-6, atol=2e-8), (k, p, out[:, 1 + p], fd)
+
+
+def _policy_expressions(seed, n, n_params):
+    """Random log-densities over the vocabulary, finite for every (delta, x, theta) the chains can reach: they need not normalise --
+    parity is about operations, not about sampling the right distribution."""
+    rng = np.random.default_rng(seed)
+    thetas = [f"theta{i}" for i in range(n_params)]
+    leaves = thetas + ["sigma", "delta", "x", "0.5", "2.0", "1.25"]
+
+    def lit():
+        return str(rng.choice(["0.5", "2.0", "1.25", "3.0"]))
+
+    def gen(depth):
+        if depth == 0 or rng.random() < 0.15:
+            return str(rng.choice(leaves))
+        a, b, c = gen(depth - 1), gen(depth - 1), gen(depth - 1)
+        forms = [f"({a} + {b})", f"({a} - {b})", f"({a} * {b})", f"(-{a})", f"({a} / (fabs({b}) + 0.75))", f"({lit()} / (fabs({a}) + 1.0))",
+                 f"({lit()} * {a})", f"({a} - {lit()})", f"amc_log(fabs({a}) + 0.5)", f"amc_exp(-fabs({a}))", f"sqrt(fabs({a}) + 0.25)",
+                 f"fma({a}, {b}, {c})", f"fma({a}, {lit()}, {c})", f"(({a}) < ({b}) ? (theta0 * {a}) : (theta0 + {b}))"]
+        return str(rng.choice(forms))
+
+    out = []
+    while len(out) < n:
+        e = gen(3)
+        # a density the acceptance can work with: bounded above by the Gaussian term, every parameter and delta in it
+        body = " + ".join(f"0.01*{t}" for t in thetas)
+        out.append(f"-(delta*delta)/(2.0*(sigma*sigma)) - amc_log(fabs(sigma) + 0.1) + 0.05*amc_exp(-fabs({e})) + 0.02*sqrt(fabs({e}) + 1.0) + {body}")
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_params", [1, 2])
+def test_random_densities_differentiated_on_the_device(gpu, n_params):
+    """The DEVICE build of the dual numbers (hiprtc, the estimator kernel) against the twin on random log-densities nobody wrote a
+    derivative for: sweeps, counters and GradientData records equal to the oracle's, bit for bit -- Float64 and Float32 state."""
+    for i, logq in enumerate(_policy_expressions(100 + n_params, 3, n_params)):
+        dtype = "f32" if i == 2 else "f64"
+        sample = "sigma*z" if n_params == 1 else "theta1*0.1 + sigma*z"
+        kw = dict(n_chains=3001, potential="harmonic", beta=2.0, weight=[0.5, 0.5], seed=31 + i, proposal=(sample, logq, None), dtype=dtype)
+        if n_params == 1:
+            kw["sigma"] = [0.4, 0.9]
+        else:
+            kw.update(sigma=[[0.4, 0.2], [0.9, -0.3]], n_params=2)
+        eng, ref = gpu.HipEngine(**kw), oracle_lib.OracleEngine(**kw)
+        for e in (eng, ref):
+            e.init_uniform(-2.0, 2.0)
+            e.sweep(12)
+        assert np.array_equal(eng.download_state()[0].view(np.uint64), ref.download_state()[0].view(np.uint64)), logq
+        a, t = eng.download_counters()
+        ao, to = ref.download_counters()
+        assert np.array_equal(a, ao) and np.array_equal(t, to) and 0.05 < a.sum() / t.sum() < 0.999, logq
+        got, want = eng.pg_estimate_exact([0, 1], 2), ref.pg_estimate_exact([0, 1], 2)
+        assert np.array_equal(got, want, equal_nan=True), logq
+        vals = eng.pg_estimate([0, 1], 1)
+        assert np.all(np.isfinite(vals)) and np.any(vals[:, 1:1 + n_params] != 0.0), logq
+        eng.close()
+    oracle_lib.install_custom_proposal(None)
+    oracle_lib.install_vector_policy(1, None)
