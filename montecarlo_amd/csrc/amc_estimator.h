@@ -251,11 +251,9 @@ void pg_estimate_kernel(const PgArgs a, const SweepArgs sw)
                 }
                 for (int q = q0; q < q1; ++q) {
                     double z0, z1;
-#if AMC_NP > 1 || AMC_NCLASS > 1
+                    // (l_base: the launch's first move in the estimator CALL -- a call may be taken in several launches, the draw is
+                    // named by the move's index in the call)
                     const uint32_t sample_id = (uint32_t)((a.l_base + l) * a.q_batch + q);
-#else
-                    const uint32_t sample_id = (uint32_t)(l * a.q_batch + q);
-#endif
                     box_muller(philox4x32_10(draw_counter(pair, a.t_est, sample_id, STREAM_ESTIMATOR),
                                              a.key0, a.key1),
                                z0, z1, s_math, mk);

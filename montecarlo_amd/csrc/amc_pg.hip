@@ -546,6 +546,31 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
     // amc_pgmc_steps call that left it.
     uint64_t ids_mask = 0;
     for (int l = 0; l < n_learn; ++l) ids_mask |= 1ull << (learn_ids[l] & 63);
+    // More than four learnable moves of the built-in policy whose samples need the flushing form (q_batch x trips beyond what a lane's
+    // accumulators take): the form of capacity 8 keeps 64 KiB of lane integers in LDS and a CU holds two of its blocks; two launches
+    // of capacity <= 4 hold four each -- the pool of the reference's test/pgmc_test.jl (six learnable moves, q_batch_size = 10) at 1e7
+    // chains: 29.6 -> 25.x us per sample.  The launches take the call's moves in order, so every chain sees its samples in the
+    // reference's order (move-major), the draws are named by the move's index in the call (l_base): the same bits.
+    if (!shards && !with_sweep && n_learn > 4 && !h->use_rtc && !h->np_small_launches) {
+        PgPlan whole;
+        { const int rcp = pg_plan(h, nl_capacity(n_learn), 0, false, q_batch, &whole); if (rcp != AMC_OK) return rcp; }
+        if (whole.mid) {
+            for (int base = 0; base < n_learn; base += 4) {
+                const int n = n_learn - base < 4 ? n_learn - base : 4;
+                amc::PgOpts sub;
+                if (opt) {
+                    sub = *opt;
+                    for (int l = 0; l < n; ++l) { sub.kind[l] = opt->kind[base + l]; sub.h0[l] = opt->h0[base + l]; sub.h1[l] = opt->h1[base + l]; }
+                }
+                const int rcl = pg_launch(h, "amc_pg_accumulate", n, learn_ids + base, q_batch, &nl, opt ? 3 : 2, opt ? &sub : nullptr, false, false, nullptr,
+                                          base, base + n >= n_learn);
+                if (rcl != AMC_OK) return rcl;
+            }
+            if (opt) h->gd_nonzero &= ~ids_mask;
+            else h->gd_nonzero |= ids_mask;
+            return AMC_OK;
+        }
+    }
     const bool defer = may_defer && opt && with_sweep && n_learn > 0 && pg_form_defers(h, n_learn) && (h->gd_nonzero & ids_mask) == 0;
     const int tail = shards ? 1 : (defer ? (int)amc::PG_TAIL_GROUPS : (opt ? 3 : 2));
     const uint64_t t_est = h->t_est;

@@ -47,9 +47,10 @@ struct PgArgs {
     // dependent-launch gap on this part).  tail_mode 0: block rows only; 1: + their total as records in `out`;
     // 2: + gradients_data[k] += gd (estimator.jl:130); 3: + make_step!(::PolicyGradientUpdate).
     int32_t tail_mode;
-    // AMC_NP > 1, AMC_NCLASS > 1: a launch takes ONE learnable move (several parameters: its columns fill a row; classes: hipcc
-    // 7.2 fails on the unrolled loop over moves with a class switch in it, "illegal VGPR to SGPR copy"), the l_base-th of the
-    // estimator call -- the index that, with q, names the sample's draw
+    // the launch's first learnable move in the estimator CALL -- the index that, with q, names a sample's draw.  AMC_NP > 1,
+    // AMC_NCLASS > 1: a launch takes ONE learnable move (several parameters: its columns fill a row; classes: hipcc 7.2 fails on the
+    // unrolled loop over moves with a class switch in it for some pools); built-in forms: a call over more than four learnable moves
+    // whose samples need the flushing form goes in launches of four (amc_pg.hip pg_accumulate_impl)
     int32_t l_base;
 };
 // Rewrites the record in stream order: the value travels as a kernel argument (copied at launch), so no host buffer has

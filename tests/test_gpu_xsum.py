@@ -398,3 +398,39 @@ def test_compact_and_wide_block_rows_carry_the_same_sums(gpu, oracle, monkeypatc
             _records_equal(ra, rb)
             assert sa == sb
     monkeypatch.delenv("AMC_WIDE_RED_ROWS")
+
+
+def test_more_than_four_learnable_moves_go_in_launches_of_four(gpu, oracle, monkeypatch):
+    """The pool of the reference's test/pgmc_test.jl:16-27 -- seven Gaussian displacements, six learnable, one optimiser each,
+    q_batch_size = 10 -- where the samples need the estimator's flushing form: the call goes in two launches (moves 1-4, 5-6;
+    the draws named by the move's index in the call) instead of one of capacity 8.  Parameters, positions, accumulators: the same
+    bits as the one launch (AMC_NP_SMALL_LAUNCHES=1 keeps it) and as the free-running oracle."""
+    M = 40001
+    kw = dict(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1] * 7, weight=[0.4] + [0.1] * 6, seed=17)
+    learn, kinds = [1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6]
+    h0, h1 = [0.001, 0.001, 1e-6, 1e-2, 1e-6, 1e-6], [0.0, 0.0, 1e-6, 1e-6, 1e-6, 1e-6]
+    eng = gpu.HipEngine(**kw)
+    monkeypatch.setenv("AMC_NP_SMALL_LAUNCHES", "1")
+    one = gpu.HipEngine(**kw)
+    monkeypatch.delenv("AMC_NP_SMALL_LAUNCHES")
+    ref = oracle.OracleEngine(**kw)
+    for e in (eng, one, ref):
+        e.init_uniform(-2.0, 2.0)
+    q = 20                                               # a lane's accumulators take 32 summands between flushes: 2 x 20 per pair calls for the flushing form
+    for stretch in (1, 2):
+        for e in (eng, one, ref):
+            e.pgmc_steps(stretch, learn, q, kinds, h0, h1)
+        for k in range(7):
+            assert eng.get_parameters(k)[0] == ref.get_parameters(k)[0] == one.get_parameters(k)[0], (stretch, k)
+    for e in (eng, one, ref):
+        e.sweep(1)
+        e.pg_accumulate(learn, q)                        # no update: gradients_data holds the sums
+    acc = eng.pg_get_accumulated(learn)
+    assert np.array_equal(acc, ref.pg_get_accumulated(learn)) and np.array_equal(acc, one.pg_get_accumulated(learn))
+    assert acc[0, 4] == M * q and np.all(acc[:, 0] > 0)
+    x = eng.download_state()[0]
+    assert np.array_equal(x.view(np.uint64), ref.download_state()[0].view(np.uint64))
+    assert np.array_equal(x.view(np.uint64), one.download_state()[0].view(np.uint64))
+    assert eng.estimator_step == ref.estimator_step == one.estimator_step
+    eng.close()
+    one.close()

@@ -120,8 +120,9 @@ elif mode == "pgmc7":
     M = int(os.environ.get("CHAINS", "10000000"))
     q = int(os.environ.get("QBATCH", "10"))
     e = A.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.1] * 7, weight=[0.4] + [0.1] * 6, seed=42)
-    learn, kinds = [1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6]
-    h0, h1 = [0.001, 0.001, 1e-6, 1e-2, 1e-6, 1e-6], [0.0, 0.0, 1e-6, 1e-6, 1e-6, 1e-6]
+    nl = int(os.environ.get("LEARN", "6"))          # how many of the six learn (the estimator's kernel form: capacity 1, 2, 4, 8)
+    learn, kinds = [1, 2, 3, 4, 5, 6][:nl], [1, 2, 3, 4, 5, 6][:nl]
+    h0, h1 = [0.001, 0.001, 1e-6, 1e-2, 1e-6, 1e-6][:nl], [0.0, 0.0, 1e-6, 1e-6, 1e-6, 1e-6][:nl]
     e.init_uniform(-2, 2)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.5:
