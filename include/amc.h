@@ -243,7 +243,8 @@ int  amc_model_check(int n_params, int n_classes, const char *potential_expr, co
 /* How an estimator call over n_learn learnable moves of this handle would run.  Returns
  *     2   (asked with `fused` != 0 only) the whole time step -- sweep + estimator [+ update] -- is ONE launch (amc_pgmc_steps)
  *     1   one estimator launch takes every learnable move, as the reference's make_step!(::PolicyGradientEstimator) loops over all
- *         of them in one step whatever their policy types (estimator.jl:111-134)
+ *         of them in one step whatever their policy types (estimator.jl:111-134) -- (more than four learnable moves of the built-in
+ *         policy with a q_batch that calls for the kernel's flushing form: launches of four moves, the form a CU holds more blocks of)
  *     0   one launch per learnable move
  *    < 0  an amc_status.
  * Only a pool of several classes can answer 0 for one-parameter policies: its several-move kernel form is asked of the run-time
