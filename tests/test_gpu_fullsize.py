@@ -711,3 +711,39 @@ def test_class_pool_one_launch_per_time_step_at_full_size(gpu):
         e.close()
     assert out[0] == out[1] == out[2]
     assert out[0][0][0] != 0.3 and out[0][0][1] != 0.4 and sum(out[0][4]) == 3 * M_FULL
+
+
+def test_launch_plans_of_the_round_at_full_size(gpu):
+    """Round 6, at 1e7 chains (the full grid, 13 trips per lane, the tail's two ticket levels): (a) the pool of the reference's
+    test/pgmc_test.jl:16-27 -- seven moves, six optimisers, q_batch_size = 10 -- whose estimator call goes in launches of four moves;
+    (b) two learnable moves of a two-parameter policy as a chain of launches with their own tails.  Each against the route it
+    replaced (AMC_NP_SMALL_LAUNCHES=1): parameters, every chain, every counter the same bits; and the learning goes the reference's
+    way (test/pgmc_test.jl:50: sigma grows from 0.1 towards 1.2 under every optimiser)."""
+    drift = ("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)", None)
+    cases = [
+        (dict(potential="harmonic", beta=2.0, sigma=[0.1] * 7, weight=[0.4] + [0.1] * 6, seed=42),
+         ([1, 2, 3, 4, 5, 6], 10, [1, 2, 3, 4, 5, 6], [0.001, 0.001, 1e-6, 1e-2, 1e-6, 1e-6], [0.0, 0.0, 1e-6, 1e-6, 1e-6, 1e-6]), 2),
+        (dict(potential="harmonic", beta=2.0, sigma=[[0.0, 0.5], [0.1, 0.9]], weight=[0.5, 0.5], seed=42, proposal=drift, n_params=2),
+         ([0, 1], 1, [1, 4], [1e-3, 5e-3], [0.0, 1e-6]), 3),
+    ]
+    for kw, (learn, q, kinds, h0, h1), steps in cases:
+        out = []
+        for env in ({}, {"AMC_NP_SMALL_LAUNCHES": "1"}):
+            os.environ.update(env)
+            try:
+                e = gpu.HipEngine(n_chains=M_FULL, **kw)
+            finally:
+                for k in env:
+                    del os.environ[k]
+            e.init_uniform(-2, 2)
+            e.pgmc_steps(steps, learn, q, kinds, h0, h1)
+            x = e.download_state()[0]
+            acc, tot = e.counter_totals()
+            out.append(([list(e.get_parameters(k)) for k in range(e.n_moves)], int(np.bitwise_xor.reduce(x.view(np.uint64))), float(x[7654321]),
+                        acc.tolist(), tot.tolist()))
+            e.close()
+        assert out[0] == out[1], kw["sigma"]
+        assert sum(out[0][4]) == steps * M_FULL
+        if len(learn) == 6:
+            sig = [p[0] for p in out[0][0]]
+            assert sig[0] == 0.1 and all(s > 0.1 for s in sig[1:]), sig
