@@ -488,6 +488,14 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
 {
     int nl = 0;
     bool general = true;
+    // (the routes below read learn_ids before a launch would validate them)
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
+    if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: learn_ids is NULL");
+    // (... and a call that goes in several launches must not stop half way over an argument)
+    for (int l = 0; l < n_learn; ++l)
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: learn_ids[%d] = %d out of range", l, learn_ids[l]);
+    if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)
+        return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: q_batch must be in [1, %d] and q_batch*n_learn < 4096", AMC_MAX_QBATCH);
     { const int rcg = class_general_route(h, n_learn, with_sweep, reduce, q_batch, &general); if (rcg != AMC_OK) return rcg; }
     if (np_move_chain(h, n_learn)) {
         // several parameters, several learnable moves, one shard: one launch per move whose own tail folds, accumulates and (opt) takes

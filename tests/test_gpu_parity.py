@@ -1295,3 +1295,29 @@ def test_uploaded_totals_must_add_up_to_one_step_count(gpu):
     with pytest.raises(gpu.AmcError, match="same step count"):
         e.upload_counters(acc, bad)
     e.close()
+
+
+def test_estimator_entry_points_refuse_bad_arguments(gpu):
+    """The C ABI's own checks (include/amc.h: negative status + amc_last_error, nothing throws or faults): a NULL id array, counts out
+    of range, ids that name no move -- on the handle kinds whose routes read the ids on the host before a launch would look at them."""
+    import ctypes as C
+    lib = gpu.load()
+    drift = ("theta0 + theta1*z", "-((delta-theta0)*(delta-theta0))/(2.0*theta1*theta1) - amc_log(theta1)", None)
+    for kw in (dict(sigma=[0.2, 0.4], weight=[0.5, 0.5]),
+               dict(sigma=[[0.0, 0.5], [0.1, 0.9]], weight=[0.5, 0.5], proposal=drift, n_params=2),
+               dict(sigma=[0.1] * 7, weight=[0.4] + [0.1] * 6)):
+        e = gpu.HipEngine(n_chains=1001, potential="harmonic", beta=2.0, seed=3, **kw)
+        e.init_uniform(-2, 2)
+        h = e._h
+        ids = (C.c_int * 8)(0, 1, 0, 0, 0, 0, 0, 0)
+        bad = (C.c_int * 2)(0, 99)
+        assert lib.amc_pg_accumulate(h, 2, None, 1) == -1 and b"learn_ids is NULL" in lib.amc_last_error()
+        assert lib.amc_pg_accumulate(h, 1000, ids, 1) == -1 and lib.amc_pg_accumulate(h, -1, ids, 1) == -1
+        assert lib.amc_pg_accumulate(h, 2, bad, 1) == -1 and b"out of range" in lib.amc_last_error()
+        assert lib.amc_pg_accumulate(h, 2, ids, 0) == -1
+        assert lib.amc_pgmc_steps(h, 1, 2, None, 1, 0, None, None, None) == -1
+        assert lib.amc_pgmc_steps(h, 1, 2, ids, 1, 1, None, None, None) == -1            # an update without optimisers
+        assert lib.amc_pg_accumulate(h, 0, None, 1) == 0                                 # no learnable move: the estimator step counts on
+        e.pg_accumulate([0, 1], 2)                                                       # and the handle is as usable as before
+        assert e.pg_get_accumulated([0, 1])[0, -1] == 2 * 1001
+        e.close()
