@@ -359,10 +359,24 @@ static int pg_launch(amc_handle* h, const char* who, int n_learn, const int* lea
 }
 
 // The estimator's fold over this shard as records: n_learn * 4 of them (j, grad j, grad logq, g per learnable move).
+// The arguments of an estimator call, checked BEFORE its first launch: a call may go in several (one per learnable move, or four moves
+// at a time), and must not stop half way over an argument -- samples drawn, sums accumulated, the step counter not advanced.
+static int pg_check_call(const amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch)
+{
+    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "%s: n_learn must be in [0, %d]", who, AMC_MAX_LEARN);
+    if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids is NULL", who);
+    for (int l = 0; l < n_learn; ++l)
+        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "%s: learn_ids[%d] = %d out of range", who, l, learn_ids[l]);
+    if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)
+        return fail(AMC_ERR_BAD_ARG, "%s: q_batch must be in [1, %d] and q_batch*n_learn < 4096", who, AMC_MAX_QBATCH);
+    return AMC_OK;
+}
+
 static int pg_estimate_records(amc_handle* h, const char* who, int n_learn, const int* learn_ids, int q_batch, const double** recs)
 {
     int nl = 0;
     bool general = true;
+    { const int rcc = pg_check_call(h, who, n_learn, learn_ids, q_batch); if (rcc != AMC_OK) return rcc; }
     { const int rcg = class_general_route(h, n_learn, false, false, q_batch, &general); if (rcg != AMC_OK) return rcg; }
     if (per_move_launches(h) || !general) {
         // one launch per learnable move, its 1 + 2P + P(P+1)/2 records behind those of the moves before it
@@ -488,14 +502,7 @@ static int pg_accumulate_impl(amc_handle* h, int n_learn, const int* learn_ids, 
 {
     int nl = 0;
     bool general = true;
-    // (the routes below read learn_ids before a launch would validate them)
-    if (n_learn < 0 || n_learn > AMC_MAX_LEARN) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: n_learn must be in [0, %d]", AMC_MAX_LEARN);
-    if (n_learn > 0 && !learn_ids) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: learn_ids is NULL");
-    // (... and a call that goes in several launches must not stop half way over an argument)
-    for (int l = 0; l < n_learn; ++l)
-        if (learn_ids[l] < 0 || learn_ids[l] >= h->K) return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: learn_ids[%d] = %d out of range", l, learn_ids[l]);
-    if (q_batch < 1 || q_batch > AMC_MAX_QBATCH || (int64_t)q_batch * n_learn >= 4096)
-        return fail(AMC_ERR_BAD_ARG, "amc_pg_accumulate: q_batch must be in [1, %d] and q_batch*n_learn < 4096", AMC_MAX_QBATCH);
+    { const int rcc = pg_check_call(h, "amc_pg_accumulate", n_learn, learn_ids, q_batch); if (rcc != AMC_OK) return rcc; }
     { const int rcg = class_general_route(h, n_learn, with_sweep, reduce, q_batch, &general); if (rcg != AMC_OK) return rcg; }
     if (np_move_chain(h, n_learn)) {
         // several parameters, several learnable moves, one shard: one launch per move whose own tail folds, accumulates and (opt) takes

@@ -1317,6 +1317,11 @@ def test_estimator_entry_points_refuse_bad_arguments(gpu):
         assert lib.amc_pg_accumulate(h, 2, ids, 0) == -1
         assert lib.amc_pgmc_steps(h, 1, 2, None, 1, 0, None, None, None) == -1
         assert lib.amc_pgmc_steps(h, 1, 2, ids, 1, 1, None, None, None) == -1            # an update without optimisers
+        x_before, t_before = e.download_state()[0], e.estimator_step
+        out = (C.c_double * 64)()
+        assert lib.amc_pg_estimate(h, 2, bad, 1, out) == -1 and b"out of range" in lib.amc_last_error()
+        assert lib.amc_pg_estimate(h, 2, None, 1, out) == -1
+        assert np.array_equal(e.download_state()[0], x_before) and e.estimator_step == t_before      # nothing was drawn
         assert lib.amc_pg_accumulate(h, 0, None, 1) == 0                                 # no learnable move: the estimator step counts on
         e.pg_accumulate([0, 1], 2)                                                       # and the handle is as usable as before
         assert e.pg_get_accumulated([0, 1])[0, -1] == 2 * 1001
