@@ -55,6 +55,7 @@ STATE_DTYPES = {"f64": 0, "f32": 1, "float64": 0, "float32": 1}
 
 
 _lib = None
+SIGNATURES: dict = {}          # name -> (restype, argtypes) of every bound entry point (filled by load(); tests walk it)
 
 
 def load() -> C.CDLL:
@@ -158,6 +159,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    SIGNATURES.update(sig)
     _lib = lib
     return lib
 

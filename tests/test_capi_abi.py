@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -142,3 +143,18 @@ def test_plain_c_client_links_and_runs(tmp_path):
     pg = dict(zip(lines[4].split()[1::2], map(float, lines[4].split()[2::2])))     # "pgmc sigma2 .. mean_e .. acc0 .. acc1 .. hip .."
     assert pg["sigma2"] == pytest.approx(1.2, abs=0.2) and pg["mean_e"] == pytest.approx(0.25, abs=1e-2)      # pgmc_test.jl:45,50
     assert pg["acc0"] > pg["acc1"] > 0.3 and pg["hip"] > 60000000
+
+
+def test_every_entry_survives_null_arguments():
+    """"Errors: negative amc_status + amc_last_error(); nothing throws" (INTEGRATION.md): every entry point of the ABI called with a
+    NULL handle and zeros / NULLs for every other argument -- in a process of its own, so that a fault would show up as the name
+    it died on.  No GPU involved: the argument checks come first."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "aux", "null_handle_calls.py")], capture_output=True, text=True, timeout=120)
+    lines = r.stdout.split("\n")
+    assert r.returncode == 0 and "done" in lines, (r.returncode, lines[-3:], r.stderr[-500:])
+    got = dict(ln.split() for ln in lines if len(ln.split()) == 2)
+    assert len(got) >= 70, len(got)
+    ok_with_nothing = {"amc_destroy", "amc_runtime_info"}          # destroying nothing and asking for no answer are no errors
+    assert {n for n, rc in got.items() if rc == "0"} == ok_with_nothing
+    assert all(rc == "-1" for n, rc in got.items() if n not in ok_with_nothing), {n: rc for n, rc in got.items() if rc not in ("-1", "0")}
