@@ -158,3 +158,14 @@ def test_every_entry_survives_null_arguments():
     ok_with_nothing = {"amc_destroy", "amc_runtime_info"}          # destroying nothing and asking for no answer are no errors
     assert {n for n, rc in got.items() if rc == "0"} == ok_with_nothing
     assert all(rc == "-1" for n, rc in got.items() if n not in ok_with_nothing), {n: rc for n, rc in got.items() if rc not in ("-1", "0")}
+
+
+@pytest.mark.gpu
+def test_every_entry_survives_null_arguments_on_a_live_handle(gpu):
+    """The same with a LIVE handle (three kinds): NULL arrays and zero counts are refused or mean "nothing", never a fault, and the
+    handle sweeps on afterwards."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "aux", "valid_handle_null_calls.py")], capture_output=True, text=True, timeout=300)
+    lines = r.stdout.split("\n")
+    assert r.returncode == 0 and "done" in lines, (r.returncode, lines[-3:], r.stderr[-800:])
+    got = [ln.split() for ln in lines if len(ln.split()) == 3]
+    assert len(got) >= 3 * 45 and all(int(rc) <= 0 or name == "amc_pg_route" for _, name, rc in got), [g for g in got if int(g[2]) > 0]
