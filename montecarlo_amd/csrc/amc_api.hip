@@ -1434,7 +1434,8 @@ int amc_histogram_fetch(amc_handle* h, uint64_t* counts, int n_bins, int reset)
 int amc_download_strided(amc_handle* h, int64_t first, int64_t stride, int64_t count, double* x)
 {
     if (!h || !x) return fail(AMC_ERR_BAD_ARG, "amc_download_strided: NULL argument");
-    if (first < 0 || stride < 1 || count < 0 || (count > 0 && first + (count - 1) * stride >= h->M))
+    // (no product that could overflow: count - 1 <= (M - 1 - first) / stride)
+    if (first < 0 || stride < 1 || count < 0 || (count > 0 && (first >= h->M || count - 1 > (h->M - 1 - first) / stride)))
         return fail(AMC_ERR_BAD_ARG, "amc_download_strided: range [first + i*stride] leaves the local shard");
     if (count == 0) return AMC_OK;
     AMC_HIP(hipSetDevice(h->device));

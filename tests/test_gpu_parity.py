@@ -1326,3 +1326,21 @@ def test_estimator_entry_points_refuse_bad_arguments(gpu):
         e.pg_accumulate([0, 1], 2)                                                       # and the handle is as usable as before
         assert e.pg_get_accumulated([0, 1])[0, -1] == 2 * 1001
         e.close()
+
+
+def test_strided_snapshot_ranges(gpu):
+    """amc_download_strided: every range that leaves the shard is refused -- the ones whose last index would overflow an Int64
+    included -- and the edges of the shard are served."""
+    import ctypes as C
+    lib = gpu.load()
+    M = 1001
+    e = gpu.HipEngine(n_chains=M, potential="harmonic", beta=2.0, sigma=[0.3], weight=[1.0], seed=5)
+    e.init_uniform(-2, 2)
+    x = e.download_state()[0]
+    assert np.array_equal(e.download_strided(0, 1, M), x) and np.array_equal(e.download_strided(M - 1, 1, 1), x[-1:])
+    assert np.array_equal(e.download_strided(0, 500, 3), x[0::500]) and e.download_strided(5, 1, 0).size == 0
+    out = (C.c_double * 8)()
+    for first, stride, count in ((0, 1, M + 1), (M, 1, 1), (-1, 1, 1), (0, 0, 1), (0, 1, -1), (1, 500, 3), (0, 2**62, 3), (0, 4, 2**62), (2**62, 1, 1),
+                                 (0, 2**63 - 1, 2)):
+        assert lib.amc_download_strided(e._h, first, stride, count, out) == -1, (first, stride, count)
+    e.close()
